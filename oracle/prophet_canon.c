@@ -1,0 +1,776 @@
+/*
+ * oracle/prophet_canon.c -- TEST INFRASTRUCTURE ONLY (CPU oracle; never shipped, never the
+ * thing measured).  PARITY UNPINNED w.r.t. real fbprophet/pystan output: see
+ * oracle/fbprophet_restated.py.
+ *
+ * The complete per-series path the reference runs at
+ *   /root/reference/src/jobs/prophet_modeler.py:56-66   (floor/cap, Prophet(...).fit)
+ *   /root/reference/src/jobs/prophet_scorer.py:64-70    (make_future_dataframe, predict)
+ * restated in plain C in ONE FIXED ARITHMETIC ORDER ("canonical W64 arithmetic"):
+ *
+ *   - every sum over time is taken as 64 contiguous chunk partials (chunk length
+ *     NT = ceil(T/64), accumulated with fma from the LAST element of the chunk to the
+ *     first), combined either by an xor-butterfly (offsets 1,2,4,8,16,32) or, for the
+ *     per-column sums, sequentially over chunks 0..63;
+ *   - every dot product over parameters is 64 partials (parameter p lives in slot p%64,
+ *     second term fma'd for p>=64) combined by the same xor-butterfly;
+ *   - exp/log/sin/cos come from det_math.h; everything else is IEEE double + - * / sqrt
+ *     and fma, compiled with -ffp-contract=off.
+ *
+ * The HIP kernels in time_series_spark_amd/csrc/ execute exactly this operation sequence
+ * (one wavefront = the 64 chunks/slots), so that product and oracle agree bit-for-bit and the
+ * north-star 1e-4 forecast tolerance is meaningful despite the optimiser being chaotic.
+ * Per-evaluation agreement of this canonical form with the literal dense-A Stan form
+ * (fbprophet_restated.stan_neg_log_prob_grad) is asserted in tests/test_oracle.py.
+ *
+ * Upstream routines followed (fbprophet 0.5 forecaster.py / prophet.stan / stan 2.19
+ * optimization/*.hpp; UPSTREAM-RECALL, not in /root/reference):
+ *   cn_prepare      setup_dataframe, initialize_scales, set_changepoints,
+ *                   make_all_seasonality_features (fourier_series), *_growth_init
+ *   cn_eval         prophet.stan model block (-log_prob and gradient)
+ *   cn_lbfgs        BFGSMinimizer<LBFGSUpdate>::step, WolfeLineSearch, WolfLSZoom, CubicInterp
+ *   cn_predict      predict_trend (piecewise_linear / piecewise_logistic),
+ *                   predict_seasonal_components, yhat = trend*(1+mult)+add
+ */
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "det_math.h"
+
+#define CN_W 64
+#define CN_MAX_S 64
+#define CN_MAX_SEAS 8
+#define CN_MAX_EXTRA 64
+#define CN_MAX_P 128
+#define CN_MAX_HIST 8
+
+typedef struct {
+    int32_t growth;                 /* 0 linear, 1 logistic */
+    int32_t n_changepoints;         /* 25 */
+    double changepoint_range;       /* 0.8 */
+    double tau;                     /* changepoint_prior_scale 0.05 */
+    int32_t n_seas;
+    int32_t n_extra;
+    double seas_period[CN_MAX_SEAS];
+    double seas_prior[CN_MAX_SEAS];
+    int32_t seas_order[CN_MAX_SEAS];
+    int32_t seas_mode[CN_MAX_SEAS]; /* 0 additive, 1 multiplicative */
+    double extra_prior[CN_MAX_EXTRA];
+    int32_t extra_mode[CN_MAX_EXTRA];
+    int32_t max_iter;               /* 10000 */
+    int32_t history;                /* 5 */
+    double init_alpha;              /* 1e-3 */
+    double tol_obj, tol_rel_obj, tol_grad, tol_rel_grad, tol_param;
+} cn_spec;
+
+typedef struct {
+    int32_t status;   /* Stan TERM_* code, or <0 error */
+    int32_t n_iter;
+    int32_t n_eval;
+    int32_t S;
+    int32_t K;
+    int32_t pad_;
+    double f;
+    double y_scale;
+    double floor_;
+    double cap_scaled;
+    int64_t start_ns;
+    int64_t t_scale_ns;
+} cn_fitinfo;
+
+enum { TERM_SUCCESS = 0, TERM_ABSX = 10, TERM_ABSF = 20, TERM_RELF = 21, TERM_ABSGRAD = 30,
+       TERM_RELGRAD = 31, TERM_MAXIT = 40, TERM_LSFAIL = -1, CN_INIT_NONFINITE = -2,
+       CN_CONSTANT = 50, CN_ERR_TOO_FEW = -10, CN_ERR_CAP = -11, CN_ERR_SIZE = -12 };
+
+typedef struct {
+    int T, NT, S, K, Ka, P, growth;
+    double *t, *y, *X;       /* X: [T][K] internal column order (additive first) */
+    int *cidx;
+    int perm[CN_MAX_P];      /* internal column -> original column */
+    double prior[CN_MAX_P];  /* prior scale per internal column */
+    double t_change[CN_MAX_S];
+    double cap, floor_, y_scale, tau;
+    int64_t start_ns, tscale_ns;
+    double k0, m0;
+    int constant_y;
+    int n_eval;
+} cn_series;
+
+/* ---- canonical reductions ----------------------------------------------------------- */
+
+static double bfly(double v[CN_W])
+{
+    double n[CN_W];
+    for (int off = 1; off < CN_W; off <<= 1) {
+        for (int i = 0; i < CN_W; ++i) n[i] = v[i] + v[i ^ off];
+        memcpy(v, n, sizeof(n));
+    }
+    return v[0];
+}
+
+/* dot over (zero padded) 128-vectors */
+static double dotc(const double *a, const double *b)
+{
+    double part[CN_W];
+    for (int l = 0; l < CN_W; ++l) part[l] = fma(a[l + CN_W], b[l + CN_W], a[l] * b[l]);
+    return bfly(part);
+}
+
+/* ---- column bookkeeping -------------------------------------------------------------- */
+
+static int spec_K(const cn_spec *sp)
+{
+    int K = sp->n_extra;
+    for (int s = 0; s < sp->n_seas; ++s) K += 2 * sp->seas_order[s];
+    return K;
+}
+
+static void free_series(cn_series *se)
+{
+    if (!se) return;
+    free(se->t); free(se->y); free(se->X); free(se->cidx); free(se);
+}
+
+/* fbprophet fourier_series argument: 2.0*(i+1)*np.pi*t/period with
+ * t = (1e-9 * ns) / 86400. (pandas 0.25 Timedelta.total_seconds = 1e-9 * asi8). */
+static void fourier_row(const cn_spec *sp, int64_t ns, double *row /* original order */)
+{
+    const double tdays = (1e-9 * (double)ns) / 86400.0;
+    int col = 0;
+    for (int s = 0; s < sp->n_seas; ++s) {
+        for (int h = 0; h < sp->seas_order[s]; ++h) {
+            const double arg = ((2.0 * (double)(h + 1)) * 3.141592653589793 * tdays) / sp->seas_period[s];
+            det_sincos(arg, &row[col], &row[col + 1]);
+            col += 2;
+        }
+    }
+}
+
+static int build_perm(const cn_spec *sp, int K, int *perm, double *prior, int *Ka_out)
+{
+    int mode[CN_MAX_P];
+    double pr[CN_MAX_P];
+    int col = 0;
+    for (int s = 0; s < sp->n_seas; ++s)
+        for (int h = 0; h < 2 * sp->seas_order[s]; ++h) { mode[col] = sp->seas_mode[s]; pr[col] = sp->seas_prior[s]; col++; }
+    for (int e = 0; e < sp->n_extra; ++e) { mode[col] = sp->extra_mode[e]; pr[col] = sp->extra_prior[e]; col++; }
+    int n = 0;
+    for (int j = 0; j < K; ++j) if (mode[j] == 0) { perm[n] = j; prior[n] = pr[j]; n++; }
+    *Ka_out = n;
+    for (int j = 0; j < K; ++j) if (mode[j] != 0) { perm[n] = j; prior[n] = pr[j]; n++; }
+    return 0;
+}
+
+/* ---- setup --------------------------------------------------------------------------- */
+
+static cn_series *cn_prepare(const cn_spec *sp, int T, const int64_t *ds, const double *y,
+                             double floor_in, double cap_in, const double *extra, int *err)
+{
+    *err = 0;
+    if (T < 2) { *err = CN_ERR_TOO_FEW; return NULL; }
+    const int K = spec_K(sp);
+    cn_series *se = (cn_series *)calloc(1, sizeof(cn_series));
+    se->T = T; se->NT = (T + CN_W - 1) / CN_W; se->growth = sp->growth; se->K = K; se->tau = sp->tau;
+    se->t = (double *)calloc(T, sizeof(double));
+    se->y = (double *)calloc(T, sizeof(double));
+    se->cidx = (int *)calloc(T, sizeof(int));
+    se->X = (double *)calloc((size_t)T * (K > 0 ? K : 1), sizeof(double));
+    /* initialize_scales */
+    const double floor_ = (sp->growth == 1) ? floor_in : 0.0;
+    double ys = 0.0, ymin = y[0], ymax = y[0];
+    for (int i = 0; i < T; ++i) {
+        double a = fabs(y[i] - floor_);
+        if (a > ys) ys = a;
+        if (y[i] < ymin) ymin = y[i];
+        if (y[i] > ymax) ymax = y[i];
+    }
+    if (ys == 0.0) ys = 1.0;
+    se->y_scale = ys; se->floor_ = floor_;
+    se->constant_y = (ymin == ymax) && sp->growth == 0;
+    se->start_ns = ds[0]; se->tscale_ns = ds[T - 1] - ds[0];
+    if (sp->growth == 1) {
+        if (cap_in <= floor_) { *err = CN_ERR_CAP; free_series(se); return NULL; }
+        se->cap = (cap_in - floor_) / ys;
+    }
+    const double tsc = (double)se->tscale_ns;
+    for (int i = 0; i < T; ++i) {
+        se->t[i] = (double)(ds[i] - se->start_ns) / tsc;
+        se->y[i] = (y[i] - floor_) / ys;
+    }
+    /* set_changepoints */
+    int hist = (int)floor((double)T * sp->changepoint_range);
+    int S = sp->n_changepoints;
+    if (S + 1 > hist) S = hist - 1;
+    if (S < 0) S = 0;
+    if (S > CN_MAX_S) { *err = CN_ERR_SIZE; free_series(se); return NULL; }
+    se->S = S;
+    if (S > 0) {
+        const double step = (double)(hist - 1) / (double)S;
+        for (int j = 1; j <= S; ++j) {
+            double v = (j == S) ? (double)(hist - 1) : (double)j * step;
+            int idx = (int)rint(v);
+            se->t_change[j - 1] = se->t[idx];
+        }
+    }
+    for (int i = 0; i < T; ++i) {
+        int c = 0;
+        while (c < S && se->t[i] >= se->t_change[c]) ++c;
+        se->cidx[i] = c;
+    }
+    se->P = 3 + S + K;
+    if (se->P > CN_MAX_P || K > CN_MAX_P) { *err = CN_ERR_SIZE; free_series(se); return NULL; }
+    /* design matrix, internal column order */
+    build_perm(sp, K, se->perm, se->prior, &se->Ka);
+    {
+        double row[CN_MAX_P];
+        const int nf = K - sp->n_extra;
+        for (int i = 0; i < T; ++i) {
+            fourier_row(sp, ds[i], row);
+            for (int e = 0; e < sp->n_extra; ++e) row[nf + e] = extra[(size_t)e * T + i];
+            for (int j = 0; j < K; ++j) se->X[(size_t)i * K + j] = row[se->perm[j]];
+        }
+    }
+    /* growth init: first row with min ds, first row with max ds (idxmin / idxmax) */
+    int i0 = 0, i1 = T - 1;
+    while (i1 > 0 && ds[i1 - 1] == ds[T - 1]) --i1;
+    const double Td = se->t[i1] - se->t[i0];
+    if (sp->growth == 0) {
+        se->k0 = (se->y[i1] - se->y[i0]) / Td;
+        se->m0 = se->y[i0] - se->k0 * se->t[i0];
+    } else {
+        const double C0 = se->cap, C1 = se->cap;
+        double y0 = fmax(0.01 * C0, fmin(0.99 * C0, se->y[i0]));
+        double y1 = fmax(0.01 * C1, fmin(0.99 * C1, se->y[i1]));
+        double r0 = C0 / y0, r1 = C1 / y1;
+        if (fabs(r0 - r1) <= 0.01) r0 = 1.05 * r0;
+        const double L0 = det_log(r0 - 1.0), L1 = det_log(r1 - 1.0);
+        se->m0 = L0 * Td / (L0 - L1);
+        se->k0 = (L0 - L1) / Td;
+    }
+    return se;
+}
+
+/* ---- -log_prob and gradient, canonical W64 arithmetic --------------------------------- */
+/* th, g: zero padded 128-vectors, internal layout [k, m, log sigma, delta[S], beta_int[K]]. */
+
+static int cn_eval(cn_series *se, const double *th, double *f_out, double *g)
+{
+    const int T = se->T, NT = se->NT, S = se->S, K = se->K, Ka = se->Ka;
+    const double k = th[0], m = th[1], ls = th[2];
+    const double *delta = th + 3, *beta = th + 3 + S;
+    se->n_eval++;
+    const double sigma = det_exp(ls);
+    const double inv_s2 = 1.0 / (sigma * sigma);
+    double ks[CN_MAX_S + 1], mc[CN_MAX_S + 1];
+    ks[0] = k;
+    for (int j = 0; j < S; ++j) ks[j + 1] = ks[j] + delta[j];
+    mc[0] = m;
+    if (se->growth == 0) {
+        for (int j = 0; j < S; ++j) mc[j + 1] = mc[j] + ((-se->t_change[j]) * delta[j]);
+    } else {
+        for (int j = 0; j < S; ++j) {
+            const double gamma = (se->t_change[j] - mc[j]) * (1.0 - ks[j] / ks[j + 1]);
+            mc[j + 1] = mc[j] + gamma;
+        }
+    }
+    double sseL[CN_W], tot1[CN_W], tot2[CN_W];
+    double tp1[CN_MAX_S + 1], tp2[CN_MAX_S + 1];
+    static __thread double accL[CN_W][CN_MAX_P];
+    for (int j = 0; j < S; ++j) tp1[j] = tp2[j] = 0.0;
+    for (int L = 0; L < CN_W; ++L) {
+        const int lo = L * NT, hi = (lo + NT < T) ? lo + NT : T;
+        double sse = 0.0, rt1 = 0.0, rt2 = 0.0;
+        double *acc = accL[L];
+        for (int j = 0; j < K; ++j) acc[j] = 0.0;
+        for (int i = hi - 1; i >= lo; --i) {
+            const int c = se->cidx[i];
+            const double *x = se->X + (size_t)i * K;
+            const double ti = se->t[i];
+            double xa = 0.0, xm = 0.0;
+            for (int j = 0; j < Ka; ++j) xa = fma(x[j], beta[j], xa);
+            for (int j = Ka; j < K; ++j) xm = fma(x[j], beta[j], xm);
+            double gtr, q = 0.0;
+            if (se->growth == 0) {
+                gtr = fma(ks[c], ti, mc[c]);
+            } else {
+                const double z = ks[c] * (ti - mc[c]);
+                const double e = det_exp(-z);
+                const double sg = 1.0 / (1.0 + e);
+                gtr = se->cap * sg;
+                q = gtr * (1.0 - sg);
+            }
+            const double opm = 1.0 + xm;
+            const double mu = fma(gtr, opm, xa);
+            const double r = se->y[i] - mu;
+            sse = fma(r, r, sse);
+            for (int j = 0; j < Ka; ++j) acc[j] = fma(x[j], r, acc[j]);
+            if (Ka < K) {
+                const double rg = r * gtr;
+                for (int j = Ka; j < K; ++j) acc[j] = fma(x[j], rg, acc[j]);
+            }
+            double v = r * opm;
+            if (se->growth == 1) v = v * q;
+            rt1 = fma(v, ti, rt1);
+            rt2 = rt2 + v;
+            const int cprev = (i > 0) ? se->cidx[i - 1] : 0;
+            for (int j = cprev; j < c; ++j) { tp1[j] = rt1; tp2[j] = rt2; }
+        }
+        sseL[L] = sse; tot1[L] = rt1; tot2[L] = rt2;
+    }
+    const double sse = bfly(sseL);
+    /* inclusive suffix scan over chunks (Hillis-Steele, offsets 1..32) */
+    for (int off = 1; off < CN_W; off <<= 1) {
+        double n1[CN_W], n2[CN_W];
+        for (int L = 0; L < CN_W; ++L) {
+            n1[L] = (L + off < CN_W) ? tot1[L] + tot1[L + off] : tot1[L];
+            n2[L] = (L + off < CN_W) ? tot2[L] + tot2[L + off] : tot2[L];
+        }
+        memcpy(tot1, n1, sizeof(n1)); memcpy(tot2, n2, sizeof(n2));
+    }
+    const double TA = tot1[0], TB = tot2[0];
+    double SA[CN_MAX_S + 1], SB[CN_MAX_S + 1];
+    for (int j = 0; j < S; ++j) {
+        /* chunk holding the first point with t >= t_change[j] */
+        int fj = 0;
+        while (fj < T && se->cidx[fj] <= j) ++fj;
+        const int Lj = fj / NT;
+        const double e1 = (Lj + 1 < CN_W) ? tot1[Lj + 1] : 0.0;
+        const double e2 = (Lj + 1 < CN_W) ? tot2[Lj + 1] : 0.0;
+        SA[j] = tp1[j] + e1;
+        SB[j] = tp2[j] + e2;
+    }
+    /* per-column sums: sequential over chunks */
+    double ACC[CN_MAX_P];
+    for (int j = 0; j < K; ++j) {
+        double a = accL[0][j];
+        for (int L = 1; L < CN_W; ++L) a = a + accL[L][j];
+        ACC[j] = a;
+    }
+    /* priors */
+    double pa[CN_W], pb[CN_W];
+    for (int l = 0; l < CN_W; ++l) { pa[l] = 0.0; pb[l] = 0.0; }
+    for (int p = 0; p < se->P; ++p) {
+        const int l = p % CN_W;
+        if (p >= 3 && p < 3 + S) pa[l] = pa[l] + fabs(th[p]);
+        if (p >= 3 + S) { const double qq = th[p] / se->prior[p - 3 - S]; pb[l] = fma(qq, qq, pb[l]); }
+    }
+    const double sabs = bfly(pa), sb = bfly(pb);
+    const double s2 = sigma * sigma;
+    double f = ((0.5 * k) * k) / 25.0 + ((0.5 * m) * m) / 25.0;
+    f = f + sabs / se->tau;
+    f = f + 2.0 * s2;
+    f = f + 0.5 * sb;
+    f = f + (double)T * ls;
+    f = f + (0.5 * sse) * inv_s2;
+
+    for (int p = 0; p < CN_MAX_P; ++p) g[p] = 0.0;
+    const double nis = -inv_s2;
+    double gk, gm;
+    double *gd = g + 3;
+    if (se->growth == 0) {
+        for (int j = 0; j < S; ++j) gd[j] = nis * (SA[j] - se->t_change[j] * SB[j]);
+        gk = nis * TA;
+        gm = nis * TB;
+    } else {
+        double D1[CN_MAX_S + 1], D2[CN_MAX_S + 1];
+        for (int c = 0; c <= S; ++c) {
+            const double hiA = (c == 0) ? TA : SA[c - 1], hiB = (c == 0) ? TB : SB[c - 1];
+            const double loA = (c == S) ? 0.0 : SA[c], loB = (c == S) ? 0.0 : SB[c];
+            const double A = hiA - loA, B = hiB - loB;
+            D1[c] = A - mc[c] * B;
+            D2[c] = -(ks[c] * B);
+        }
+        double abar = D2[S];
+        for (int c = S - 1; c >= 0; --c) {
+            const double ratio = ks[c] / ks[c + 1];
+            const double rho_bar = abar * (se->t_change[c] - mc[c]);
+            D1[c] = D1[c] + rho_bar * (-1.0 / ks[c + 1]);
+            D1[c + 1] = D1[c + 1] + rho_bar * (ratio / ks[c + 1]);
+            abar = D2[c] + abar * ratio;
+        }
+        double sK = 0.0;
+        for (int c = S; c >= 1; --c) { sK = sK + D1[c]; gd[c - 1] = nis * sK; }
+        gk = nis * (sK + D1[0]);
+        gm = nis * abar;
+    }
+    g[0] = gk + k / 25.0;
+    g[1] = gm + m / 25.0;
+    g[2] = ((double)T - sse * inv_s2) + 4.0 * s2;
+    for (int j = 0; j < S; ++j) {
+        const double sgn = (double)((delta[j] > 0.0) - (delta[j] < 0.0));
+        gd[j] = gd[j] + sgn / se->tau;
+    }
+    double *gb = g + 3 + S;
+    for (int j = 0; j < K; ++j) gb[j] = nis * ACC[j] + beta[j] / (se->prior[j] * se->prior[j]);
+    *f_out = f;
+    if (!isfinite(f)) return 2;
+    for (int p = 0; p < se->P; ++p) if (!isfinite(g[p])) return 3;
+    return 0;
+}
+
+/* ---- Stan L-BFGS ---------------------------------------------------------------------- */
+
+static double cubic_interp6(double df0, double x1, double f1, double df1, double loX, double hiX)
+{
+    const double c3 = (-12.0 * f1 + 6.0 * x1 * (df0 + df1)) / (x1 * x1 * x1);
+    const double c2 = -(4.0 * df0 + 2.0 * df1) / x1 + 6.0 * f1 / (x1 * x1);
+    const double c1 = df0;
+    const double t_s = sqrt(c2 * c2 - 2.0 * c1 * c3);
+    const double s1 = -(c2 + t_s) / c3;
+    const double s2 = -(c2 - t_s) / c3;
+    double tmpF, minF, minX;
+    minF = loX * (loX * (loX * c3 / 3.0 + c2) / 2.0 + c1);
+    minX = loX;
+    tmpF = hiX * (hiX * (hiX * c3 / 3.0 + c2) / 2.0 + c1);
+    if (tmpF < minF) { minF = tmpF; minX = hiX; }
+    if (loX < s1 && s1 < hiX) {
+        tmpF = s1 * (s1 * (s1 * c3 / 3.0 + c2) / 2.0 + c1);
+        if (tmpF < minF) { minF = tmpF; minX = s1; }
+    }
+    if (loX < s2 && s2 < hiX) {
+        tmpF = s2 * (s2 * (s2 * c3 / 3.0 + c2) / 2.0 + c1);
+        if (tmpF < minF) { minF = tmpF; minX = s2; }
+    }
+    return minX;
+}
+
+static void axpy_to(double *out, const double *x, double a, const double *p)
+{
+    for (int i = 0; i < CN_MAX_P; ++i) out[i] = fma(a, p[i], x[i]);
+}
+
+/* Line search written as ONE loop with ONE evaluation site (the HIP kernel has the same
+ * shape); the control flow is WolfeLineSearch followed by WolfLSZoom. */
+static int line_search(cn_series *se, double *alpha_io, double *x1, double *f1_out, double *g1,
+                       const double *p, const double *x0, double f0, const double *g0)
+{
+    const double c1 = 1e-4, c2 = 0.9, minAlpha = 1e-12, min_range = 1e-16;
+    const int maxLSIts = 20, maxLSRestarts = 10;
+    const double dfp = dotc(g0, p);
+    const double c1dfp = c1 * dfp, c2dfp = c2 * dfp;
+    double alpha = *alpha_io;
+    double alpha0 = minAlpha, prevF = f0, prevDFp = dfp;
+    int nits = 0, lsRestarts = 0;
+    int zoom = 0, itNum = 0;
+    double alo = 0, aloF = 0, aloDFp = 0, ahi = 0, ahiF = 0, ahiDFp = 0;
+    int rc = 0;
+    for (;;) {
+        if (!zoom) {
+            if (nits >= maxLSIts) { rc = 1; break; }
+        } else {
+            itNum++;
+            if (fabs(alo - ahi) < min_range) { rc = 1; break; }
+            if (itNum % 5 == 0) {
+                alpha = 0.5 * (alo + ahi);
+            } else {
+                const double d1 = aloDFp + ahiDFp - 3.0 * (aloF - ahiF) / (alo - ahi);
+                double d2 = sqrt(d1 * d1 - aloDFp * ahiDFp);
+                if (ahi < alo) d2 = -d2;
+                alpha = ahi - (ahi - alo) * (ahiDFp + d2 - d1) / (ahiDFp - aloDFp + 2.0 * d2);
+                const double lo = fmin(alo, ahi), hi = fmax(alo, ahi), w = fabs(alo - ahi);
+                if (!isfinite(alpha) || alpha < lo + 0.01 * w || alpha > hi - 0.01 * w)
+                    alpha = 0.5 * (alo + ahi);
+            }
+        }
+        double f1, newDFp;
+        int bad = 0;
+        for (;;) {   /* evaluation with Stan's non-finite handling */
+            axpy_to(x1, x0, alpha, p);
+            const int ret = cn_eval(se, x1, &f1, g1);
+            if (ret == 0) break;
+            if (!zoom) {
+                if (lsRestarts >= maxLSRestarts) { bad = 1; break; }
+                alpha = 0.5 * (alpha0 + alpha);
+                lsRestarts++;
+            } else {
+                alpha = 0.5 * (alpha + fmin(alo, ahi));
+                if (fabs(fmin(alo, ahi) - alpha) < min_range) { bad = 1; break; }
+            }
+        }
+        if (bad) { rc = 1; break; }
+        newDFp = dotc(g1, p);
+        if (!zoom) {
+            lsRestarts = 0;
+            if (f1 > f0 + alpha * c1dfp || (f1 >= prevF && nits > 0)) {
+                zoom = 1; alo = alpha0; aloF = prevF; aloDFp = prevDFp;
+                ahi = alpha; ahiF = f1; ahiDFp = newDFp;
+                continue;
+            }
+            if (fabs(newDFp) <= -c2dfp) { rc = 0; *f1_out = f1; break; }
+            if (newDFp >= 0) {
+                zoom = 1; alo = alpha; aloF = f1; aloDFp = newDFp;
+                ahi = alpha0; ahiF = prevF; ahiDFp = prevDFp;
+                continue;
+            }
+            alpha0 = alpha; prevF = f1; prevDFp = newDFp;
+            alpha *= 10.0;
+            nits++;
+        } else {
+            if (f1 > (f0 + alpha * c1dfp) || f1 >= aloF) {
+                ahi = alpha; ahiF = f1; ahiDFp = newDFp;
+            } else {
+                if (fabs(newDFp) <= -c2dfp) { rc = 0; *f1_out = f1; break; }
+                if (newDFp * (ahi - alo) >= 0) { ahi = alo; ahiF = aloF; ahiDFp = aloDFp; }
+                alo = alpha; aloF = f1; aloDFp = newDFp;
+            }
+        }
+    }
+    *alpha_io = alpha;
+    return rc;
+}
+
+static int cn_lbfgs(cn_series *se, const cn_spec *o, const double *theta0, double *theta_out,
+                    cn_fitinfo *res)
+{
+    const int NP = CN_MAX_P;
+    const int H = o->history > CN_MAX_HIST ? CN_MAX_HIST : o->history;
+    const double eps = DBL_EPSILON;
+    const double minAlpha = 1e-12;
+    double xk[CN_MAX_P], gk[CN_MAX_P], pk[CN_MAX_P], xk_1[CN_MAX_P], gk_1[CN_MAX_P],
+           pk_1[CN_MAX_P], sk[CN_MAX_P], yk[CN_MAX_P];
+    double Sb[CN_MAX_HIST][CN_MAX_P], Yb[CN_MAX_HIST][CN_MAX_P];
+    double rho[CN_MAX_HIST], alphas[CN_MAX_HIST];
+    int hist_len = 0, hist_head = 0;
+    double gammak = 1.0, fk, fk_1 = 0.0, alpha = o->init_alpha;
+    int itNum = 0, ret = 0;
+    memset(pk_1, 0, sizeof(pk_1)); memset(gk_1, 0, sizeof(gk_1)); memset(xk_1, 0, sizeof(xk_1));
+    memcpy(xk, theta0, sizeof(xk));
+    se->n_eval = 0;
+    if (cn_eval(se, xk, &fk, gk)) {
+        memcpy(theta_out, theta0, sizeof(xk));
+        res->status = CN_INIT_NONFINITE; res->n_iter = 0; res->n_eval = se->n_eval; res->f = fk;
+        return 0;
+    }
+    for (int i = 0; i < NP; ++i) pk[i] = -gk[i];
+    while (ret == 0) {
+        int resetB;
+        itNum++;
+        resetB = (itNum == 1) ? 1 : 0;
+        for (;;) {
+            if (resetB) for (int i = 0; i < NP; ++i) pk[i] = -gk[i];
+            if (itNum > 1 && resetB != 2) {
+                const double ci = cubic_interp6(dotc(gk_1, pk_1), alpha, fk - fk_1, dotc(gk, pk),
+                                                minAlpha, 1.0);
+                alpha = fmin(1.0, 1.01 * ci);
+            } else {
+                alpha = o->init_alpha;
+            }
+            const int rc = line_search(se, &alpha, xk_1, &fk_1, gk_1, pk, xk, fk, gk);
+            if (rc) {
+                if (resetB) { ret = TERM_LSFAIL; goto done; }
+                resetB = 2;
+                continue;
+            }
+            break;
+        }
+        /* swap: k becomes the most recent iterate */
+        { double tf = fk; fk = fk_1; fk_1 = tf; }
+        for (int i = 0; i < NP; ++i) {
+            double tx = xk[i]; xk[i] = xk_1[i]; xk_1[i] = tx;
+            double tg = gk[i]; gk[i] = gk_1[i]; gk_1[i] = tg;
+            double tp = pk[i]; pk[i] = pk_1[i]; pk_1[i] = tp;
+        }
+        for (int i = 0; i < NP; ++i) { sk[i] = xk[i] - xk_1[i]; yk[i] = gk[i] - gk_1[i]; }
+        const double gradNorm = sqrt(dotc(gk, gk));
+        const double stepNorm = sqrt(dotc(sk, sk));
+        const double skyk = dotc(yk, sk);
+        const double ykyk = dotc(yk, yk);
+        if (resetB) {
+            const double B0fact = ykyk / skyk;
+            hist_len = 0; hist_head = 0;
+            for (int i = 0; i < NP; ++i) pk_1[i] = pk_1[i] / B0fact;
+            alpha = alpha * B0fact;
+        }
+        gammak = skyk / ykyk;
+        {
+            int slot;
+            if (hist_len < H) { slot = (hist_head + hist_len) % H; hist_len++; }
+            else { slot = hist_head; hist_head = (hist_head + 1) % H; }
+            rho[slot] = 1.0 / skyk;
+            memcpy(Sb[slot], sk, sizeof(sk));
+            memcpy(Yb[slot], yk, sizeof(yk));
+        }
+        for (int i = 0; i < NP; ++i) pk[i] = -gk[i];
+        for (int h = hist_len - 1; h >= 0; --h) {
+            const int slot = (hist_head + h) % H;
+            const double a = rho[slot] * dotc(Sb[slot], pk);
+            for (int i = 0; i < NP; ++i) pk[i] = fma(-a, Yb[slot][i], pk[i]);
+            alphas[h] = a;
+        }
+        for (int i = 0; i < NP; ++i) pk[i] = pk[i] * gammak;
+        for (int h = 0; h < hist_len; ++h) {
+            const int slot = (hist_head + h) % H;
+            const double b = rho[slot] * dotc(Yb[slot], pk);
+            const double cc = alphas[h] - b;
+            for (int i = 0; i < NP; ++i) pk[i] = fma(cc, Sb[slot][i], pk[i]);
+        }
+        const double dF = fabs(fk_1 - fk);
+        const double fmaxv = fmax(fabs(fk_1), fmax(fabs(fk), 1.0));
+        if (dF < o->tol_obj) ret = TERM_ABSF;
+        else if (dF < o->tol_rel_obj * eps * fmaxv) ret = TERM_RELF;
+        else if (gradNorm < o->tol_grad) ret = TERM_ABSGRAD;
+        else if (-dotc(gk, pk) / fmax(fabs(fk), 1.0) < o->tol_rel_grad * eps) ret = TERM_RELGRAD;
+        else if (stepNorm < o->tol_param) ret = TERM_ABSX;
+        else if (itNum >= o->max_iter) ret = TERM_MAXIT;
+        else ret = TERM_SUCCESS;
+    }
+done:
+    memcpy(theta_out, xk, sizeof(xk));
+    res->status = ret; res->n_iter = itNum; res->n_eval = se->n_eval; res->f = fk;
+    return 0;
+}
+
+/* ---- exported entry points (theta in ORIGINAL column order) ----------------------------- */
+
+static void to_internal(const cn_series *se, const double *th_orig, double *th_int)
+{
+    memset(th_int, 0, sizeof(double) * CN_MAX_P);
+    for (int p = 0; p < 3 + se->S; ++p) th_int[p] = th_orig[p];
+    for (int j = 0; j < se->K; ++j) th_int[3 + se->S + j] = th_orig[3 + se->S + se->perm[j]];
+}
+
+static void to_original(const cn_series *se, const double *th_int, double *th_orig)
+{
+    for (int p = 0; p < 3 + se->S; ++p) th_orig[p] = th_int[p];
+    for (int j = 0; j < se->K; ++j) th_orig[3 + se->S + se->perm[j]] = th_int[3 + se->S + j];
+}
+
+static void fill_info(const cn_series *se, cn_fitinfo *info)
+{
+    info->S = se->S; info->K = se->K; info->y_scale = se->y_scale; info->floor_ = se->floor_;
+    info->cap_scaled = se->cap; info->start_ns = se->start_ns; info->t_scale_ns = se->tscale_ns;
+}
+
+void cn_default_spec(cn_spec *sp)
+{
+    memset(sp, 0, sizeof(*sp));
+    sp->growth = 0; sp->n_changepoints = 25; sp->changepoint_range = 0.8; sp->tau = 0.05;
+    sp->max_iter = 10000; sp->history = 5; sp->init_alpha = 1e-3; sp->tol_obj = 1e-12;
+    sp->tol_rel_obj = 1e4; sp->tol_grad = 1e-8; sp->tol_rel_grad = 1e7; sp->tol_param = 1e-8;
+}
+
+int cn_spec_size(void) { return (int)sizeof(cn_spec); }
+
+/* Design matrix in original column order [T][K], scaled t [T], scaled y [T], t_change [S],
+ * init (k, m).  Any output pointer may be NULL. */
+int cn_design(const cn_spec *sp, int T, const int64_t *ds, const double *y, double floor_,
+              double cap, const double *extra, double *X_out, double *t_out, double *y_out,
+              double *tchange_out, double *init_out, cn_fitinfo *info)
+{
+    int err;
+    cn_series *se = cn_prepare(sp, T, ds, y, floor_, cap, extra, &err);
+    if (!se) { info->status = err; return err; }
+    fill_info(se, info);
+    info->status = 0;
+    if (X_out)
+        for (int i = 0; i < T; ++i)
+            for (int j = 0; j < se->K; ++j)
+                X_out[(size_t)i * se->K + se->perm[j]] = se->X[(size_t)i * se->K + j];
+    if (t_out) memcpy(t_out, se->t, sizeof(double) * T);
+    if (y_out) memcpy(y_out, se->y, sizeof(double) * T);
+    if (tchange_out) memcpy(tchange_out, se->t_change, sizeof(double) * se->S);
+    if (init_out) { init_out[0] = se->k0; init_out[1] = se->m0; }
+    free_series(se);
+    return 0;
+}
+
+/* f = -log_prob and gradient at theta (original order). */
+int cn_eval_at(const cn_spec *sp, int T, const int64_t *ds, const double *y, double floor_,
+               double cap, const double *extra, const double *theta, double *f_out,
+               double *g_out)
+{
+    int err;
+    cn_series *se = cn_prepare(sp, T, ds, y, floor_, cap, extra, &err);
+    if (!se) return err;
+    double th[CN_MAX_P], g[CN_MAX_P];
+    to_internal(se, theta, th);
+    const int rc = cn_eval(se, th, f_out, g);
+    to_original(se, g, g_out);
+    free_series(se);
+    return rc;
+}
+
+/* Full fit.  theta_out: [3+S+K] original order; tchange_out: [S]. */
+int cn_fit(const cn_spec *sp, int T, const int64_t *ds, const double *y, double floor_,
+           double cap, const double *extra, double *theta_out, double *tchange_out,
+           cn_fitinfo *info)
+{
+    int err;
+    memset(info, 0, sizeof(*info));
+    cn_series *se = cn_prepare(sp, T, ds, y, floor_, cap, extra, &err);
+    if (!se) { info->status = err; return 0; }
+    fill_info(se, info);
+    double th0[CN_MAX_P], th[CN_MAX_P];
+    memset(th0, 0, sizeof(th0));
+    th0[0] = se->k0; th0[1] = se->m0; th0[2] = 0.0;
+    if (se->constant_y) {
+        /* fbprophet: "Nothing to fit": params = init, sigma_obs = 1e-9 */
+        memcpy(th, th0, sizeof(th));
+        th[2] = -20.72326583694641;
+        info->status = CN_CONSTANT; info->n_iter = 0; info->n_eval = 0; info->f = 0.0;
+    } else {
+        cn_lbfgs(se, sp, th0, th, info);
+    }
+    to_original(se, th, theta_out);
+    if (tchange_out) memcpy(tchange_out, se->t_change, sizeof(double) * se->S);
+    free_series(se);
+    return 0;
+}
+
+/* Point forecast.  theta original order; extra_future [n_extra][H]. */
+int cn_predict(const cn_spec *sp, const cn_fitinfo *info, const double *theta,
+               const double *t_change, int H, const int64_t *ds, double floor_, double cap,
+               const double *extra_future, double *yhat, double *trend_out)
+{
+    const int S = info->S, K = info->K;
+    const double k = theta[0], m = theta[1];
+    const double *delta = theta + 3, *beta = theta + 3 + S;
+    const double fl = (sp->growth == 1) ? floor_ : 0.0;
+    const double cap_sc = (sp->growth == 1) ? (cap - fl) / info->y_scale : 0.0;
+    double ks[CN_MAX_S + 1], mc[CN_MAX_S + 1];
+    int perm[CN_MAX_P], Ka;
+    double prior[CN_MAX_P];
+    build_perm(sp, K, perm, prior, &Ka);
+    ks[0] = k; mc[0] = m;
+    for (int j = 0; j < S; ++j) ks[j + 1] = ks[j] + delta[j];
+    if (sp->growth == 0) {
+        for (int j = 0; j < S; ++j) mc[j + 1] = mc[j] + ((-t_change[j]) * delta[j]);
+    } else {
+        for (int j = 0; j < S; ++j) {
+            const double gamma = (t_change[j] - mc[j]) * (1.0 - ks[j] / ks[j + 1]);
+            mc[j + 1] = mc[j] + gamma;
+        }
+    }
+    const double tsc = (double)info->t_scale_ns;
+    const int nf = K - sp->n_extra;
+    for (int h = 0; h < H; ++h) {
+        const double t = (double)(ds[h] - info->start_ns) / tsc;
+        int c = 0;
+        while (c < S && t >= t_change[c]) ++c;
+        double row[CN_MAX_P];
+        fourier_row(sp, ds[h], row);
+        for (int e = 0; e < sp->n_extra; ++e) row[nf + e] = extra_future[(size_t)e * H + h];
+        double xa = 0.0, xm = 0.0;
+        for (int j = 0; j < Ka; ++j) xa = fma(row[perm[j]], beta[perm[j]], xa);
+        for (int j = Ka; j < K; ++j) xm = fma(row[perm[j]], beta[perm[j]], xm);
+        double gtr;
+        if (sp->growth == 0) {
+            gtr = fma(ks[c], t, mc[c]);
+        } else {
+            const double z = ks[c] * (t - mc[c]);
+            gtr = cap_sc * (1.0 / (1.0 + det_exp(-z)));
+        }
+        const double trend = gtr * info->y_scale + fl;
+        if (trend_out) trend_out[h] = trend;
+        yhat[h] = trend * (1.0 + xm) + xa * info->y_scale;
+    }
+    return 0;
+}
+
+/* libm cross-check hooks for tests */
+double cn_det_exp(double x) { return det_exp(x); }
+double cn_det_log(double x) { return det_log(x); }
+void cn_det_sincos(double x, double *s, double *c) { det_sincos(x, s, c); }
