@@ -1,0 +1,192 @@
+/*
+ * tsf.h -- C ABI of libtsf_amd.so: batched per-series Prophet-model MAP fit + predict on
+ * MI355X (gfx950).  Plain pointers and sizes, no C++/torch types, no exceptions.
+ *
+ * What each entry point replaces in the reference (mageky/time-series-spark):
+ *
+ *   tsf_fit_aligned / tsf_fit_ragged (+ _dev)
+ *       `Prophet(growth=..., seasonality_mode=...)` + `model.fit(pdf)` executed once per
+ *       (series_id, dim_id) group inside the grouped-map pandas_udf
+ *       /root/reference/src/jobs/prophet_modeler.py:56-66 (floor :56-57, cap :59-60,
+ *       constructor :65, fit :66), i.e. fbprophet 0.5 setup_dataframe / set_changepoints /
+ *       make_all_seasonality_features / *_growth_init and pystan 2.19.1.1
+ *       StanModel.optimizing(algorithm='LBFGS') on prophet.stan -- for a whole panel of
+ *       series in one call.
+ *   tsf_predict (+ _dev)
+ *       `model.predict(future_df)` + the int cast + floor clamp of
+ *       /root/reference/src/jobs/prophet_scorer.py:64-84 (future frame :64-68, predict :70,
+ *       astype(int) :73, clamp :76-84).  Only `yhat` is produced: the reference keeps
+ *       nothing else (:86).
+ *   tsf_eval / tsf_design
+ *       no reference counterpart: expose the log-posterior/gradient and the design matrix
+ *       so tests can check them against the CPU oracle one evaluation at a time.
+ *
+ * Conventions
+ *   - Every function returns 0 on success, <0 on API misuse / HIP failure
+ *     (tsf_last_error(ctx) gives the text).  Per-series outcomes go to status[] (TSF_ST_*),
+ *     mirroring the reference's "RuntimeError -> series dropped" (prophet_modeler.py:81-85)
+ *     vs "ValueError propagates" split: the Python layer decides what to raise.
+ *   - All buffers are caller-allocated and caller-owned.  `_dev` variants take DEVICE
+ *     pointers on the context's GPU plus a hipStream_t (as void*, NULL = default stream) and
+ *     are asynchronous; the plain variants take HOST pointers, copy in, run, copy out, sync.
+ *   - A tsf_ctx is bound to one GPU and is not re-entrant; use one per GPU / host thread.
+ *   - Timestamps are int64 nanoseconds since the Unix epoch (pandas datetime64[ns]), sorted
+ *     ascending within a series, rows with NaN y already removed (fbprophet
+ *     setup_dataframe does both on the host as well).
+ *   - theta layout per series, stride tsf_theta_stride(spec):
+ *       [k, m, log(sigma_obs), delta[n_changepoints], beta[K]]
+ *     beta in design-column order: seasonalities in spec order, each
+ *     [sin1, cos1, sin2, cos2, ...], then the extra (holiday / regressor) columns.
+ *     When a series is too short for n_changepoints, S < n_changepoints and the unused
+ *     deltas are 0.
+ */
+#ifndef TSF_H
+#define TSF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TSF_MAX_SEAS 8
+#define TSF_MAX_EXTRA 64
+#define TSF_MAX_S 60          /* max changepoints */
+#define TSF_MAX_K 64          /* max design columns */
+#define TSF_MAX_P 128         /* 3 + S + K */
+
+enum { TSF_GROWTH_LINEAR = 0, TSF_GROWTH_LOGISTIC = 1 };
+enum { TSF_MODE_ADDITIVE = 0, TSF_MODE_MULTIPLICATIVE = 1 };
+enum { TSF_Y_F64 = 0, TSF_Y_F32 = 1, TSF_Y_I32 = 2 };
+
+/* per-series status: >= 0 are Stan's optimiser termination codes */
+enum {
+    TSF_ST_CONTINUE = 0,       /* never returned */
+    TSF_ST_ABSX = 10, TSF_ST_ABSF = 20, TSF_ST_RELF = 21, TSF_ST_ABSGRAD = 30,
+    TSF_ST_RELGRAD = 31, TSF_ST_MAXIT = 40,
+    TSF_ST_CONSTANT = 50,      /* constant y, linear growth: fbprophet skips optimisation */
+    TSF_ST_LSFAIL = -1,        /* line search failed (pystan raises RuntimeError) */
+    TSF_ST_INIT_NONFINITE = -2,/* log_prob non-finite at the initial point (RuntimeError) */
+    TSF_ST_TOO_FEW = -10,      /* < 2 rows (fbprophet raises ValueError) */
+    TSF_ST_CAP = -11           /* cap <= floor (fbprophet raises ValueError) */
+};
+
+/* Model + optimiser settings shared by every series of a call.  Defaults = fbprophet 0.5
+ * Prophet.__init__ and stan::services::optimize::lbfgs as pystan 2.19 drives it. */
+typedef struct {
+    int32_t growth;                         /* TSF_GROWTH_* */
+    int32_t n_changepoints;                 /* 25 */
+    double changepoint_range;               /* 0.8 */
+    double changepoint_prior_scale;         /* tau = 0.05 */
+    int32_t n_seas;                         /* Fourier seasonalities */
+    int32_t n_extra;                        /* explicit design columns (holidays, regressors) */
+    double seas_period[TSF_MAX_SEAS];       /* days: 365.25, 7, 1 */
+    double seas_prior_scale[TSF_MAX_SEAS];  /* 10 */
+    int32_t seas_order[TSF_MAX_SEAS];       /* 10, 3, 4 */
+    int32_t seas_mode[TSF_MAX_SEAS];        /* TSF_MODE_* */
+    double extra_prior_scale[TSF_MAX_EXTRA];
+    int32_t extra_mode[TSF_MAX_EXTRA];
+    int32_t max_iter;                       /* 10000 */
+    int32_t history;                        /* 5 */
+    double init_alpha;                      /* 1e-3 */
+    double tol_obj;                         /* 1e-12 */
+    double tol_rel_obj;                     /* 1e4  (x DBL_EPSILON) */
+    double tol_grad;                        /* 1e-8 */
+    double tol_rel_grad;                    /* 1e7  (x DBL_EPSILON) */
+    double tol_param;                       /* 1e-8 */
+} tsf_spec;
+
+/* What setup derives from one timestamp vector ("grid").  One per call for aligned panels,
+ * one per series for ragged panels. */
+typedef struct {
+    int64_t start_ns;                       /* min ds */
+    int64_t t_scale_ns;                     /* max ds - min ds */
+    int32_t T;                              /* rows */
+    int32_t S;                              /* changepoints actually used */
+    int32_t i1;                             /* first row holding max ds */
+    int32_t NT;                             /* chunk length ceil(T/64) */
+    double t_change[TSF_MAX_S + 4];         /* scaled changepoint times */
+} tsf_grid_info;
+
+/* Fit outputs; every pointer caller-allocated (host or device to match the call). */
+typedef struct {
+    double *theta;          /* [N][tsf_theta_stride(spec)] */
+    double *y_scale;        /* [N] */
+    double *fval;           /* [N] -log posterior at the returned theta */
+    int32_t *status;        /* [N] TSF_ST_* */
+    int32_t *n_iter;        /* [N] L-BFGS iterations */
+    int32_t *n_eval;        /* [N] log_prob+gradient evaluations */
+    tsf_grid_info *grid;    /* [1] aligned, [N] ragged */
+} tsf_fit_out;
+
+typedef struct tsf_ctx tsf_ctx;
+
+int tsf_create(int device_id, tsf_ctx **out);
+void tsf_destroy(tsf_ctx *ctx);
+const char *tsf_last_error(const tsf_ctx *ctx);
+int tsf_device_count(void);
+
+void tsf_spec_default(tsf_spec *spec);
+int tsf_spec_size(void);                      /* sizeof(tsf_spec), for binding self-checks */
+int tsf_grid_info_size(void);
+int tsf_spec_K(const tsf_spec *spec);         /* design columns */
+int tsf_theta_stride(const tsf_spec *spec);   /* 3 + n_changepoints + K */
+
+/* ---- fit ------------------------------------------------------------------------------
+ * aligned: every series observed on the same T timestamps.  y is [N][T] row-major of
+ * y_dtype.  floor / cap: [N] or NULL (NULL = 0; floor is ignored for linear growth exactly
+ * as fbprophet ignores the column).  extra: [n_extra][T] or NULL. */
+int tsf_fit_aligned(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int32_t T,
+                    const int64_t *ds, const void *y, int32_t y_dtype, const double *floor,
+                    const double *cap, const double *extra, tsf_fit_out *out);
+int tsf_fit_aligned_dev(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int32_t T,
+                        const int64_t *ds, const void *y, int32_t y_dtype,
+                        const double *floor, const double *cap, const double *extra,
+                        tsf_fit_out *out, void *stream);
+
+/* ragged: series n owns rows [offsets[n], offsets[n+1]) of ds / y / extra
+ * (extra: [n_extra][total_rows]). */
+int tsf_fit_ragged(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, const int64_t *offsets,
+                   const int64_t *ds, const void *y, int32_t y_dtype, const double *floor,
+                   const double *cap, const double *extra, tsf_fit_out *out);
+int tsf_fit_ragged_dev(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, const int64_t *offsets,
+                       int64_t total_rows, int32_t max_T, const int64_t *ds, const void *y,
+                       int32_t y_dtype, const double *floor, const double *cap,
+                       const double *extra, tsf_fit_out *out, void *stream);
+
+/* ---- predict --------------------------------------------------------------------------
+ * yhat[n][h] = trend*(1+multiplicative)+additive in original units (float64).  If
+ * yhat_int != NULL also the reference's post-step: (int) truncation toward zero, then
+ * values below floor[n] replaced by floor[n] (prophet_scorer.py:73-84).
+ * n_grids = 1 (aligned fit) or N.  ds_future: [H] if shared_future else [N][H].
+ * extra_future: [n_extra][H] (shared) or [N][n_extra][H]; NULL if n_extra == 0.
+ * floor/cap: the values the caller puts in the future frame (prophet_scorer.py:67-68). */
+int tsf_predict(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int32_t H, const double *theta,
+                const double *y_scale, const tsf_grid_info *grid, int32_t n_grids,
+                const int64_t *ds_future, int32_t shared_future, const double *floor,
+                const double *cap, const double *extra_future, double *yhat,
+                int32_t *yhat_int);
+int tsf_predict_dev(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int32_t H,
+                    const double *theta, const double *y_scale, const tsf_grid_info *grid,
+                    int32_t n_grids, const int64_t *ds_future, int32_t shared_future,
+                    const double *floor, const double *cap, const double *extra_future,
+                    double *yhat, int32_t *yhat_int, void *stream);
+
+/* ---- test / diagnostics hooks (host pointers) -------------------------------------------
+ * tsf_eval: f = -log posterior and gradient [N][stride] at theta [N][stride] for an aligned
+ * panel.  tsf_design: X [T][K] (row-major, original column order), scaled t [T]. */
+int tsf_eval(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int32_t T, const int64_t *ds,
+             const void *y, int32_t y_dtype, const double *floor, const double *cap,
+             const double *extra, const double *theta, double *f_out, double *grad_out);
+int tsf_design(tsf_ctx *ctx, const tsf_spec *spec, int32_t T, const int64_t *ds,
+               const double *extra, double *X_out, double *t_out, tsf_grid_info *grid_out);
+/* IEEE self test of the device arithmetic the canonical order relies on: fills out[n] with
+ * op(a[n], b[n]) for op in {0:div, 1:sqrt(a), 2:det_exp(a), 3:det_log(a), 4:det_sin(a),
+ * 5:det_cos(a), 6:fma(a,b,a)} computed on the GPU. */
+int tsf_selftest_math(tsf_ctx *ctx, int32_t op, int64_t n, const double *a, const double *b,
+                      double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TSF_H */

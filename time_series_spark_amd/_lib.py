@@ -1,0 +1,174 @@
+"""ctypes binding of libtsf_amd.so (C-ABI declared in include/tsf.h).
+
+This is the only place Python touches the native library.  There is NO CPU fallback: if the
+shared library is missing or no GPU is visible, the functions raise.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libtsf_amd.so')
+
+MAX_SEAS = 8
+MAX_EXTRA = 64
+MAX_S = 60
+MAX_K = 64
+MAX_P = 128
+
+GROWTH_LINEAR, GROWTH_LOGISTIC = 0, 1
+MODE_ADDITIVE, MODE_MULTIPLICATIVE = 0, 1
+Y_F64, Y_F32, Y_I32 = 0, 1, 2
+
+ST_ABSX, ST_ABSF, ST_RELF, ST_ABSGRAD, ST_RELGRAD, ST_MAXIT = 10, 20, 21, 30, 31, 40
+ST_CONSTANT, ST_LSFAIL, ST_INIT_NONFINITE, ST_TOO_FEW, ST_CAP = 50, -1, -2, -10, -11
+STATUS_NAMES = {10: 'ABSX', 20: 'ABSF', 21: 'RELF', 30: 'ABSGRAD', 31: 'RELGRAD', 40: 'MAXIT',
+                50: 'CONSTANT', -1: 'LSFAIL', -2: 'INIT_NONFINITE', -10: 'TOO_FEW', -11: 'CAP'}
+
+
+class TsfSpec(ctypes.Structure):
+    """tsf_spec (include/tsf.h)."""
+    _fields_ = [('growth', ctypes.c_int32), ('n_changepoints', ctypes.c_int32),
+                ('changepoint_range', ctypes.c_double),
+                ('changepoint_prior_scale', ctypes.c_double),
+                ('n_seas', ctypes.c_int32), ('n_extra', ctypes.c_int32),
+                ('seas_period', ctypes.c_double * MAX_SEAS),
+                ('seas_prior_scale', ctypes.c_double * MAX_SEAS),
+                ('seas_order', ctypes.c_int32 * MAX_SEAS),
+                ('seas_mode', ctypes.c_int32 * MAX_SEAS),
+                ('extra_prior_scale', ctypes.c_double * MAX_EXTRA),
+                ('extra_mode', ctypes.c_int32 * MAX_EXTRA),
+                ('max_iter', ctypes.c_int32), ('history', ctypes.c_int32),
+                ('init_alpha', ctypes.c_double), ('tol_obj', ctypes.c_double),
+                ('tol_rel_obj', ctypes.c_double), ('tol_grad', ctypes.c_double),
+                ('tol_rel_grad', ctypes.c_double), ('tol_param', ctypes.c_double)]
+
+
+class TsfGridInfo(ctypes.Structure):
+    """tsf_grid_info (include/tsf.h)."""
+    _fields_ = [('start_ns', ctypes.c_int64), ('t_scale_ns', ctypes.c_int64),
+                ('T', ctypes.c_int32), ('S', ctypes.c_int32), ('i1', ctypes.c_int32),
+                ('NT', ctypes.c_int32), ('t_change', ctypes.c_double * (MAX_S + 4))]
+
+
+GRID_DTYPE = np.dtype([('start_ns', '<i8'), ('t_scale_ns', '<i8'), ('T', '<i4'), ('S', '<i4'),
+                       ('i1', '<i4'), ('NT', '<i4'), ('t_change', '<f8', (MAX_S + 4,))])
+
+
+class TsfFitOut(ctypes.Structure):
+    """tsf_fit_out (include/tsf.h)."""
+    _fields_ = [('theta', ctypes.c_void_p), ('y_scale', ctypes.c_void_p),
+                ('fval', ctypes.c_void_p), ('status', ctypes.c_void_p),
+                ('n_iter', ctypes.c_void_p), ('n_eval', ctypes.c_void_p),
+                ('grid', ctypes.c_void_p)]
+
+
+# every symbol include/tsf.h declares; tests check the library exports all of them
+EXPORTS = ['tsf_create', 'tsf_destroy', 'tsf_last_error', 'tsf_device_count', 'tsf_spec_default',
+           'tsf_spec_size', 'tsf_grid_info_size', 'tsf_spec_K', 'tsf_theta_stride',
+           'tsf_fit_aligned', 'tsf_fit_aligned_dev', 'tsf_fit_ragged', 'tsf_fit_ragged_dev',
+           'tsf_predict', 'tsf_predict_dev', 'tsf_eval', 'tsf_design', 'tsf_selftest_math']
+
+_lib = None
+
+
+class TsfError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libtsf_amd.so (once).  Raises if it has not been built -- no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TsfError('libtsf_amd.so not built: run `python -m time_series_spark_amd.build` '
+                       '(or __graft_entry__.build()).  There is no CPU fallback.')
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
+    psp = ctypes.POINTER(TsfSpec)
+    L.tsf_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
+    L.tsf_destroy.argtypes = [vp]
+    L.tsf_destroy.restype = None
+    L.tsf_last_error.argtypes = [vp]
+    L.tsf_last_error.restype = ctypes.c_char_p
+    L.tsf_device_count.argtypes = []
+    L.tsf_spec_default.argtypes = [psp]
+    L.tsf_spec_default.restype = None
+    L.tsf_spec_K.argtypes = [psp]
+    L.tsf_theta_stride.argtypes = [psp]
+    L.tsf_fit_aligned.argtypes = [vp, psp, i64, i32, vp, vp, i32, vp, vp, vp,
+                                  ctypes.POINTER(TsfFitOut)]
+    L.tsf_fit_aligned_dev.argtypes = [vp, psp, i64, i32, vp, vp, i32, vp, vp, vp,
+                                      ctypes.POINTER(TsfFitOut), vp]
+    L.tsf_fit_ragged.argtypes = [vp, psp, i64, vp, vp, vp, i32, vp, vp, vp,
+                                 ctypes.POINTER(TsfFitOut)]
+    L.tsf_fit_ragged_dev.argtypes = [vp, psp, i64, vp, i64, i32, vp, vp, i32, vp, vp, vp,
+                                     ctypes.POINTER(TsfFitOut), vp]
+    L.tsf_predict.argtypes = [vp, psp, i64, i32, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp]
+    L.tsf_predict_dev.argtypes = [vp, psp, i64, i32, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp,
+                                  vp]
+    L.tsf_eval.argtypes = [vp, psp, i64, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp]
+    L.tsf_design.argtypes = [vp, psp, i32, vp, vp, vp, vp, vp]
+    L.tsf_selftest_math.argtypes = [vp, i32, i64, vp, vp, vp]
+    if L.tsf_spec_size() != ctypes.sizeof(TsfSpec):
+        raise TsfError('tsf_spec layout mismatch between _lib.py and libtsf_amd.so')
+    if L.tsf_grid_info_size() != ctypes.sizeof(TsfGridInfo) or GRID_DTYPE.itemsize != ctypes.sizeof(TsfGridInfo):
+        raise TsfError('tsf_grid_info layout mismatch between _lib.py and libtsf_amd.so')
+    _lib = L
+    return L
+
+
+class Context(object):
+    """One tsf_ctx: bound to one GPU, not re-entrant."""
+
+    def __init__(self, device=0):
+        L = load()
+        h = ctypes.c_void_p()
+        rc = L.tsf_create(int(device), ctypes.byref(h))
+        if rc != 0:
+            raise TsfError('tsf_create(device=%d) failed (rc=%d): no usable MI355X visible. '
+                           'This library has no CPU fallback.' % (device, rc))
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, '_h', None):
+            load().tsf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc):
+        if rc != 0:
+            msg = load().tsf_last_error(self._h)
+            raise TsfError('libtsf_amd: rc=%d: %s' % (rc, msg.decode() if msg else '?'))
+
+    @property
+    def handle(self):
+        return self._h
+
+
+def default_spec():
+    s = TsfSpec()
+    load().tsf_spec_default(ctypes.byref(s))
+    return s
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+def y_dtype_code(y):
+    if y.dtype == np.float64:
+        return Y_F64
+    if y.dtype == np.float32:
+        return Y_F32
+    if y.dtype == np.int32:
+        return Y_I32
+    raise TypeError('y must be float64, float32 or int32')

@@ -1,0 +1,563 @@
+// tsf_api.hip -- C-ABI of libtsf_amd.so (include/tsf.h): context, device workspace, kernel
+// dispatch, host-pointer convenience wrappers.
+//
+// The entry points stand where the reference calls into fbprophet per series:
+//   fit      /root/reference/src/jobs/prophet_modeler.py:56-66
+//   predict  /root/reference/src/jobs/prophet_scorer.py:64-84
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "tsf_aux_kernels.h"
+#include "tsf_fit_kernels.h"
+#include "tsf_launch.h"
+
+using namespace tsf;
+
+struct tsf_ctx {
+    int device;
+    std::string err;
+    // cached device workspace (grown on demand, never shrunk)
+    void *ws;
+    size_t ws_bytes;
+    DevSpec *d_spec;
+};
+
+#define HIP_TRY(ctx, expr)                                                                   \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                  \
+            return -2;                                                                       \
+        }                                                                                    \
+    } while (0)
+
+static int fail(tsf_ctx *ctx, const char *msg)
+{
+    if (ctx) ctx->err = msg;
+    return -1;
+}
+
+extern "C" int tsf_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int tsf_create(int device_id, tsf_ctx **out)
+{
+    if (!out) return -1;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device_id < 0 || device_id >= n) return -2;
+    if (hipSetDevice(device_id) != hipSuccess) return -2;
+    tsf_ctx *c = new tsf_ctx();
+    c->device = device_id; c->ws = nullptr; c->ws_bytes = 0; c->d_spec = nullptr;
+    if (hipMalloc((void **)&c->d_spec, sizeof(DevSpec)) != hipSuccess) { delete c; return -2; }
+    *out = c;
+    return 0;
+}
+
+extern "C" void tsf_destroy(tsf_ctx *ctx)
+{
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    if (ctx->ws) hipFree(ctx->ws);
+    if (ctx->d_spec) hipFree(ctx->d_spec);
+    delete ctx;
+}
+
+extern "C" const char *tsf_last_error(const tsf_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+extern "C" void tsf_spec_default(tsf_spec *s)
+{
+    memset(s, 0, sizeof(*s));
+    s->growth = TSF_GROWTH_LINEAR; s->n_changepoints = 25; s->changepoint_range = 0.8;
+    s->changepoint_prior_scale = 0.05;
+    s->max_iter = 10000; s->history = 5; s->init_alpha = 1e-3; s->tol_obj = 1e-12;
+    s->tol_rel_obj = 1e4; s->tol_grad = 1e-8; s->tol_rel_grad = 1e7; s->tol_param = 1e-8;
+}
+
+extern "C" int tsf_spec_size(void) { return (int)sizeof(tsf_spec); }
+extern "C" int tsf_grid_info_size(void) { return (int)sizeof(tsf_grid_info); }
+
+extern "C" int tsf_spec_K(const tsf_spec *s)
+{
+    int K = s->n_extra;
+    for (int i = 0; i < s->n_seas; ++i) K += 2 * s->seas_order[i];
+    return K;
+}
+
+extern "C" int tsf_theta_stride(const tsf_spec *s) { return 3 + s->n_changepoints + tsf_spec_K(s); }
+
+// ---- spec validation + device form ---------------------------------------------------------
+
+static int pick_KP(int K, int n_cp, int mixed)
+{
+    const int P = 3 + n_cp + K;
+    if (mixed || P > 64) return 64;
+    if (K <= 8) return 8;
+    if (K <= 16) return 16;
+    if (K <= 28) return 28;
+    return 64;
+}
+
+static int build_devspec(tsf_ctx *ctx, const tsf_spec *s, DevSpec *d, int *mode_out)
+{
+    if (!s) return fail(ctx, "spec is NULL");
+    if (s->growth != TSF_GROWTH_LINEAR && s->growth != TSF_GROWTH_LOGISTIC) return fail(ctx, "bad growth");
+    if (s->n_seas < 0 || s->n_seas > TSF_MAX_SEAS || s->n_extra < 0 || s->n_extra > TSF_MAX_EXTRA)
+        return fail(ctx, "too many seasonalities / extra columns");
+    if (s->n_changepoints < 0 || s->n_changepoints > TSF_MAX_S) return fail(ctx, "n_changepoints out of range");
+    if (!(s->changepoint_range >= 0.0 && s->changepoint_range <= 1.0)) return fail(ctx, "changepoint_range must be in [0,1]");
+    if (!(s->changepoint_prior_scale > 0.0)) return fail(ctx, "changepoint_prior_scale must be > 0");
+    if (s->history < 1 || s->history > MAXH) return fail(ctx, "history must be in [1,8]");
+    const int K = tsf_spec_K(s);
+    if (K < 1) return fail(ctx, "model needs at least one design column (fbprophet adds a zero column; pass one extra column of zeros)");
+    if (K > TSF_MAX_K || 3 + s->n_changepoints + K > TSF_MAX_P) return fail(ctx, "too many parameters (3+S+K must be <= 128, K <= 64)");
+    memset(d, 0, sizeof(*d));
+    int mode[TSF_MAX_P];
+    double pr[TSF_MAX_P];
+    int col = 0, np = 0;
+    for (int i = 0; i < s->n_seas; ++i) {
+        if (s->seas_order[i] < 1) return fail(ctx, "fourier order must be >= 1");
+        if (!(s->seas_prior_scale[i] > 0.0) || !(s->seas_period[i] > 0.0)) return fail(ctx, "bad seasonality prior scale / period");
+        for (int h = 0; h < s->seas_order[i]; ++h) {
+            d->pair_period[np] = s->seas_period[i];
+            d->pair_mult[np] = 2.0 * (double)(h + 1);
+            d->pair_col[np] = col;
+            np++;
+            mode[col] = s->seas_mode[i]; pr[col] = s->seas_prior_scale[i]; col++;
+            mode[col] = s->seas_mode[i]; pr[col] = s->seas_prior_scale[i]; col++;
+        }
+    }
+    for (int e = 0; e < s->n_extra; ++e) {
+        if (!(s->extra_prior_scale[e] > 0.0)) return fail(ctx, "bad extra prior scale");
+        mode[col] = s->extra_mode[e]; pr[col] = s->extra_prior_scale[e]; col++;
+    }
+    int n = 0;
+    for (int j = 0; j < K; ++j) if (mode[j] == TSF_MODE_ADDITIVE) { d->perm[n] = j; d->inv_perm[j] = n; d->prior[n] = pr[j]; n++; }
+    const int Ka = n;
+    for (int j = 0; j < K; ++j) if (mode[j] != TSF_MODE_ADDITIVE) { d->perm[n] = j; d->inv_perm[j] = n; d->prior[n] = pr[j]; n++; }
+    for (int j = K; j < TSF_MAX_P; ++j) d->prior[j] = 1.0;
+    const int m = (Ka == K) ? 0 : (Ka == 0 ? 1 : 2);
+    d->growth = s->growth; d->n_cp = s->n_changepoints; d->K = K; d->Ka = Ka;
+    d->KP = pick_KP(K, s->n_changepoints, m == 2);
+    d->n_seas = s->n_seas; d->n_extra = s->n_extra; d->n_pairs = np;
+    d->max_iter = s->max_iter; d->history = s->history;
+    d->cp_range = s->changepoint_range; d->tau = s->changepoint_prior_scale;
+    d->init_alpha = s->init_alpha; d->tol_obj = s->tol_obj; d->tol_rel_obj = s->tol_rel_obj;
+    d->tol_grad = s->tol_grad; d->tol_rel_grad = s->tol_rel_grad; d->tol_param = s->tol_param;
+    *mode_out = m;
+    return 0;
+}
+
+// ---- workspace ------------------------------------------------------------------------------
+
+struct WsLayout {
+    size_t gtab, stab, tw, cw, Xw, yw, total;
+};
+
+static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static WsLayout ws_layout(int64_t N, int64_t n_grids, int NTmax, int KP)
+{
+    WsLayout l;
+    size_t off = 0;
+    l.gtab = off; off = align_up(off + sizeof(GridTab) * (size_t)n_grids);
+    l.stab = off; off = align_up(off + sizeof(SeriesTab) * (size_t)N);
+    l.tw = off; off = align_up(off + sizeof(double) * (size_t)n_grids * NTmax * W);
+    l.cw = off; off = align_up(off + sizeof(uint16_t) * (size_t)n_grids * NTmax * W);
+    l.Xw = off; off = align_up(off + sizeof(double) * (size_t)n_grids * NTmax * KP * W);
+    l.yw = off; off = align_up(off + sizeof(double) * (size_t)N * NTmax * W);
+    l.total = off;
+    return l;
+}
+
+static int ensure_ws(tsf_ctx *ctx, size_t bytes)
+{
+    if (ctx->ws_bytes >= bytes) return 0;
+    if (ctx->ws) { HIP_TRY(ctx, hipFree(ctx->ws)); ctx->ws = nullptr; ctx->ws_bytes = 0; }
+    HIP_TRY(ctx, hipMalloc(&ctx->ws, bytes));
+    ctx->ws_bytes = bytes;
+    return 0;
+}
+
+typedef int (*launch_t)(int, const FitArgs &, int, hipStream_t);
+
+static launch_t pick_launch(int growth, int mode)
+{
+    static const launch_t tab[2][3] = {{launch_g0m0, launch_g0m1, launch_g0m2},
+                                       {launch_g1m0, launch_g1m1, launch_g1m2}};
+    return tab[growth][mode];
+}
+
+// Common driver: setup kernels + fit (or eval-only) kernel on device pointers.
+static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, int32_t T,
+                   const int64_t *offsets, int64_t total_rows, int32_t max_T, const int64_t *ds,
+                   const void *y, int32_t y_dtype, const double *floor_, const double *cap,
+                   const double *extra, tsf_fit_out *out, const double *theta_in,
+                   double *grad_out, hipStream_t st)
+{
+    if (!ctx) return -1;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (N <= 0) return fail(ctx, "N must be > 0");
+    if (!ds || !y || !out) return fail(ctx, "NULL input");
+    if (y_dtype < TSF_Y_F64 || y_dtype > TSF_Y_I32) return fail(ctx, "bad y_dtype");
+    DevSpec hs;
+    int mode = 0;
+    int rc = build_devspec(ctx, spec, &hs, &mode);
+    if (rc) return rc;
+    if (hs.n_extra > 0 && !extra) return fail(ctx, "extra columns declared but extra is NULL");
+    if (hs.growth == TSF_GROWTH_LOGISTIC && !cap) return fail(ctx, "logistic growth needs cap");
+    const int Tm = aligned ? T : max_T;
+    if (Tm < 1) return fail(ctx, "no rows");
+    const int NTmax = (Tm + W - 1) / W;
+    const int64_t n_grids = aligned ? 1 : N;
+    const WsLayout l = ws_layout(N, n_grids, NTmax, hs.KP);
+    rc = ensure_ws(ctx, l.total);
+    if (rc) return rc;
+    char *ws = (char *)ctx->ws;
+    GridTab *gtab = (GridTab *)(ws + l.gtab);
+    SeriesTab *stab = (SeriesTab *)(ws + l.stab);
+    double *tw = (double *)(ws + l.tw);
+    uint16_t *cw = (uint16_t *)(ws + l.cw);
+    double *Xw = (double *)(ws + l.Xw);
+    double *yw = (double *)(ws + l.yw);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_spec, &hs, sizeof(hs), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemsetAsync(Xw, 0, sizeof(double) * (size_t)n_grids * NTmax * hs.KP * W, st));
+    HIP_TRY(ctx, hipMemsetAsync(gtab, 0, sizeof(GridTab) * (size_t)n_grids, st));
+    hipLaunchKernelGGL(setup_grid_kernel, dim3((unsigned)n_grids), dim3(256), 0, st, ctx->d_spec,
+                       (int)n_grids, aligned ? nullptr : offsets, T, ds, extra,
+                       aligned ? (int64_t)T : total_rows, NTmax, gtab, tw, cw, Xw);
+    HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(setup_series_kernel, dim3((unsigned)N), dim3(64), 0, st, ctx->d_spec, N,
+                       aligned ? nullptr : offsets, T, ds, y, y_dtype, floor_, cap, NTmax, gtab,
+                       aligned, stab, yw);
+    HIP_TRY(ctx, hipGetLastError());
+    FitArgs a;
+    memset(&a, 0, sizeof(a));
+    a.sp = ctx->d_spec; a.N = N; a.aligned = aligned; a.NTmax = NTmax;
+    a.theta_stride = tsf_theta_stride(spec);
+    a.gtab = gtab; a.stab = stab; a.tw = tw; a.yw = yw; a.Xw = Xw; a.cw = cw;
+    a.theta = out->theta; a.y_scale = out->y_scale; a.fval = out->fval; a.status = out->status;
+    a.n_iter = out->n_iter; a.n_eval = out->n_eval; a.grid_out = out->grid;
+    a.theta_in = theta_in; a.grad_out = grad_out;
+    const int lrc = pick_launch(hs.growth, mode)(hs.KP, a, theta_in != nullptr, st);
+    if (lrc != 0) {
+        ctx->err = std::string("kernel launch failed: ") + (lrc > 0 ? hipGetErrorString((hipError_t)lrc) : "no kernel for this shape");
+        return -2;
+    }
+    return 0;
+}
+
+extern "C" int tsf_fit_aligned_dev(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int32_t T,
+                                   const int64_t *ds, const void *y, int32_t y_dtype,
+                                   const double *floor_, const double *cap, const double *extra,
+                                   tsf_fit_out *out, void *stream)
+{
+    if (!ctx) return -1;
+    if (!out || !out->theta || !out->y_scale || !out->fval || !out->status || !out->n_iter ||
+        !out->n_eval || !out->grid)
+        return fail(ctx, "tsf_fit_out has NULL members");
+    return run_fit(ctx, spec, N, 1, T, nullptr, 0, T, ds, y, y_dtype, floor_, cap, extra, out,
+                   nullptr, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int tsf_fit_ragged_dev(tsf_ctx *ctx, const tsf_spec *spec, int64_t N,
+                                  const int64_t *offsets, int64_t total_rows, int32_t max_T,
+                                  const int64_t *ds, const void *y, int32_t y_dtype,
+                                  const double *floor_, const double *cap, const double *extra,
+                                  tsf_fit_out *out, void *stream)
+{
+    if (!ctx) return -1;
+    if (!offsets) return fail(ctx, "offsets is NULL");
+    if (!out || !out->theta || !out->y_scale || !out->fval || !out->status || !out->n_iter ||
+        !out->n_eval || !out->grid)
+        return fail(ctx, "tsf_fit_out has NULL members");
+    return run_fit(ctx, spec, N, 0, 0, offsets, total_rows, max_T, ds, y, y_dtype, floor_, cap,
+                   extra, out, nullptr, nullptr, (hipStream_t)stream);
+}
+
+// ---- host-pointer wrappers --------------------------------------------------------------------
+
+namespace {
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 8); }
+    template <class T> T *as() { return (T *)p; }
+};
+
+size_t ysize(int dt) { return dt == TSF_Y_F64 ? 8 : 4; }
+}  // namespace
+
+static int fit_host(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, int32_t T,
+                    const int64_t *offsets, const int64_t *ds, const void *y, int32_t y_dtype,
+                    const double *floor_, const double *cap, const double *extra,
+                    tsf_fit_out *out, const double *theta_in, double *f_out, double *grad_out)
+{
+    if (!ctx) return -1;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (N <= 0) return fail(ctx, "N must be > 0");
+    if (!spec) return fail(ctx, "spec is NULL");
+    if (y_dtype < TSF_Y_F64 || y_dtype > TSF_Y_I32) return fail(ctx, "bad y_dtype");
+    const int stride = tsf_theta_stride(spec);
+    int64_t total = 0;
+    int32_t max_T = 0;
+    if (aligned) {
+        total = (int64_t)N * T; max_T = T;
+    } else {
+        if (!offsets) return fail(ctx, "offsets is NULL");
+        total = offsets[N] - offsets[0];
+        if (offsets[0] != 0) return fail(ctx, "offsets[0] must be 0");
+        for (int64_t n = 0; n < N; ++n) {
+            const int64_t len = offsets[n + 1] - offsets[n];
+            if (len < 0 || len > (int64_t)W * 255) return fail(ctx, "series length out of range");
+            if (len > max_T) max_T = (int32_t)len;
+        }
+    }
+    if (max_T < 1) return fail(ctx, "no rows");
+    if (max_T > W * 255) return fail(ctx, "series too long (max 16320 rows)");
+    const int64_t n_ds = aligned ? T : total;
+    const int64_t n_grids = aligned ? 1 : N;
+    DevBuf d_ds, d_y, d_off, d_floor, d_cap, d_extra, d_theta, d_ys, d_f, d_st, d_it, d_ev, d_grid, d_thin, d_grad;
+    HIP_TRY(ctx, d_ds.alloc(8 * n_ds));
+    HIP_TRY(ctx, d_y.alloc(ysize(y_dtype) * total));
+    HIP_TRY(ctx, hipMemcpy(d_ds.p, ds, 8 * n_ds, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(d_y.p, y, ysize(y_dtype) * total, hipMemcpyHostToDevice));
+    if (!aligned) {
+        HIP_TRY(ctx, d_off.alloc(8 * (N + 1)));
+        HIP_TRY(ctx, hipMemcpy(d_off.p, offsets, 8 * (N + 1), hipMemcpyHostToDevice));
+    }
+    if (floor_) { HIP_TRY(ctx, d_floor.alloc(8 * N)); HIP_TRY(ctx, hipMemcpy(d_floor.p, floor_, 8 * N, hipMemcpyHostToDevice)); }
+    if (cap) { HIP_TRY(ctx, d_cap.alloc(8 * N)); HIP_TRY(ctx, hipMemcpy(d_cap.p, cap, 8 * N, hipMemcpyHostToDevice)); }
+    if (spec->n_extra > 0) {
+        if (!extra) return fail(ctx, "extra columns declared but extra is NULL");
+        const size_t nb = 8 * (size_t)spec->n_extra * n_ds;
+        HIP_TRY(ctx, d_extra.alloc(nb));
+        HIP_TRY(ctx, hipMemcpy(d_extra.p, extra, nb, hipMemcpyHostToDevice));
+    }
+    HIP_TRY(ctx, d_theta.alloc(8 * (size_t)N * stride));
+    HIP_TRY(ctx, d_ys.alloc(8 * N)); HIP_TRY(ctx, d_f.alloc(8 * N));
+    HIP_TRY(ctx, d_st.alloc(4 * N)); HIP_TRY(ctx, d_it.alloc(4 * N)); HIP_TRY(ctx, d_ev.alloc(4 * N));
+    HIP_TRY(ctx, d_grid.alloc(sizeof(tsf_grid_info) * n_grids));
+    HIP_TRY(ctx, hipMemset(d_st.p, 0, 4 * N)); HIP_TRY(ctx, hipMemset(d_it.p, 0, 4 * N));
+    HIP_TRY(ctx, hipMemset(d_ev.p, 0, 4 * N));
+    HIP_TRY(ctx, hipMemset(d_grid.p, 0, sizeof(tsf_grid_info) * n_grids));
+    tsf_fit_out dout;
+    dout.theta = d_theta.as<double>(); dout.y_scale = d_ys.as<double>(); dout.fval = d_f.as<double>();
+    dout.status = d_st.as<int32_t>(); dout.n_iter = d_it.as<int32_t>(); dout.n_eval = d_ev.as<int32_t>();
+    dout.grid = d_grid.as<tsf_grid_info>();
+    if (theta_in) {
+        HIP_TRY(ctx, d_thin.alloc(8 * (size_t)N * stride));
+        HIP_TRY(ctx, hipMemcpy(d_thin.p, theta_in, 8 * (size_t)N * stride, hipMemcpyHostToDevice));
+        HIP_TRY(ctx, d_grad.alloc(8 * (size_t)N * stride));
+    }
+    int rc = run_fit(ctx, spec, N, aligned, T, d_off.as<int64_t>(), total, max_T, d_ds.as<int64_t>(),
+                     d_y.p, y_dtype, floor_ ? d_floor.as<double>() : nullptr,
+                     cap ? d_cap.as<double>() : nullptr,
+                     spec->n_extra > 0 ? d_extra.as<double>() : nullptr, &dout,
+                     theta_in ? d_thin.as<double>() : nullptr,
+                     theta_in ? d_grad.as<double>() : nullptr, nullptr);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    if (theta_in) {
+        HIP_TRY(ctx, hipMemcpy(f_out, d_f.p, 8 * N, hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(grad_out, d_grad.p, 8 * (size_t)N * stride, hipMemcpyDeviceToHost));
+        return 0;
+    }
+    HIP_TRY(ctx, hipMemcpy(out->theta, d_theta.p, 8 * (size_t)N * stride, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(out->y_scale, d_ys.p, 8 * N, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(out->fval, d_f.p, 8 * N, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(out->status, d_st.p, 4 * N, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(out->n_iter, d_it.p, 4 * N, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(out->n_eval, d_ev.p, 4 * N, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(out->grid, d_grid.p, sizeof(tsf_grid_info) * n_grids, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int tsf_fit_aligned(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int32_t T,
+                               const int64_t *ds, const void *y, int32_t y_dtype,
+                               const double *floor_, const double *cap, const double *extra,
+                               tsf_fit_out *out)
+{
+    if (!ctx) return -1;
+    if (!ds || !y || !out) return fail(ctx, "NULL input");
+    return fit_host(ctx, spec, N, 1, T, nullptr, ds, y, y_dtype, floor_, cap, extra, out, nullptr,
+                    nullptr, nullptr);
+}
+
+extern "C" int tsf_fit_ragged(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, const int64_t *offsets,
+                              const int64_t *ds, const void *y, int32_t y_dtype,
+                              const double *floor_, const double *cap, const double *extra,
+                              tsf_fit_out *out)
+{
+    if (!ctx) return -1;
+    if (!ds || !y || !out) return fail(ctx, "NULL input");
+    return fit_host(ctx, spec, N, 0, 0, offsets, ds, y, y_dtype, floor_, cap, extra, out, nullptr,
+                    nullptr, nullptr);
+}
+
+extern "C" int tsf_eval(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int32_t T, const int64_t *ds,
+                        const void *y, int32_t y_dtype, const double *floor_, const double *cap,
+                        const double *extra, const double *theta, double *f_out, double *grad_out)
+{
+    if (!ctx) return -1;
+    if (!ds || !y || !theta || !f_out || !grad_out) return fail(ctx, "NULL input");
+    tsf_fit_out dummy;
+    memset(&dummy, 0, sizeof(dummy));
+    return fit_host(ctx, spec, N, 1, T, nullptr, ds, y, y_dtype, floor_, cap, extra, &dummy, theta,
+                    f_out, grad_out);
+}
+
+// ---- predict ----------------------------------------------------------------------------------
+
+extern "C" int tsf_predict_dev(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int32_t H,
+                               const double *theta, const double *y_scale,
+                               const tsf_grid_info *grid, int32_t n_grids, const int64_t *ds_future,
+                               int32_t shared_future, const double *floor_, const double *cap,
+                               const double *extra_future, double *yhat, int32_t *yhat_int,
+                               void *stream)
+{
+    if (!ctx) return -1;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (N <= 0 || H <= 0) return fail(ctx, "N and H must be > 0");
+    if (!theta || !y_scale || !grid || !ds_future || !yhat) return fail(ctx, "NULL input");
+    if (n_grids != 1 && n_grids != N) return fail(ctx, "n_grids must be 1 or N");
+    DevSpec hs;
+    int mode = 0;
+    int rc = build_devspec(ctx, spec, &hs, &mode);
+    if (rc) return rc;
+    if (hs.n_extra > 0 && !extra_future) return fail(ctx, "extra_future is NULL");
+    if (hs.growth == TSF_GROWTH_LOGISTIC && !cap) return fail(ctx, "logistic growth needs cap");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_spec, &hs, sizeof(hs), hipMemcpyHostToDevice, st));
+    PredictArgs a;
+    a.sp = ctx->d_spec; a.N = N; a.H = H; a.theta_stride = tsf_theta_stride(spec);
+    a.n_grids = n_grids; a.shared_future = shared_future; a.theta = theta; a.y_scale = y_scale;
+    a.grid = grid; a.ds_future = ds_future; a.floor_ = floor_; a.cap = cap;
+    a.extra_future = extra_future; a.yhat = yhat; a.yhat_int = yhat_int;
+    const int64_t total = N * (int64_t)H;
+    hipLaunchKernelGGL(predict_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+extern "C" int tsf_predict(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int32_t H,
+                           const double *theta, const double *y_scale, const tsf_grid_info *grid,
+                           int32_t n_grids, const int64_t *ds_future, int32_t shared_future,
+                           const double *floor_, const double *cap, const double *extra_future,
+                           double *yhat, int32_t *yhat_int)
+{
+    if (!ctx) return -1;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (N <= 0 || H <= 0) return fail(ctx, "N and H must be > 0");
+    if (!spec || !theta || !y_scale || !grid || !ds_future || !yhat) return fail(ctx, "NULL input");
+    if (n_grids != 1 && n_grids != N) return fail(ctx, "n_grids must be 1 or N");
+    const int stride = tsf_theta_stride(spec);
+    const size_t nfut = shared_future ? (size_t)H : (size_t)N * H;
+    DevBuf d_th, d_ys, d_grid, d_ds, d_fl, d_cap, d_ex, d_yh, d_yi;
+    HIP_TRY(ctx, d_th.alloc(8 * (size_t)N * stride));
+    HIP_TRY(ctx, hipMemcpy(d_th.p, theta, 8 * (size_t)N * stride, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, d_ys.alloc(8 * N));
+    HIP_TRY(ctx, hipMemcpy(d_ys.p, y_scale, 8 * N, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, d_grid.alloc(sizeof(tsf_grid_info) * n_grids));
+    HIP_TRY(ctx, hipMemcpy(d_grid.p, grid, sizeof(tsf_grid_info) * n_grids, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, d_ds.alloc(8 * nfut));
+    HIP_TRY(ctx, hipMemcpy(d_ds.p, ds_future, 8 * nfut, hipMemcpyHostToDevice));
+    if (floor_) { HIP_TRY(ctx, d_fl.alloc(8 * N)); HIP_TRY(ctx, hipMemcpy(d_fl.p, floor_, 8 * N, hipMemcpyHostToDevice)); }
+    if (cap) { HIP_TRY(ctx, d_cap.alloc(8 * N)); HIP_TRY(ctx, hipMemcpy(d_cap.p, cap, 8 * N, hipMemcpyHostToDevice)); }
+    if (spec->n_extra > 0) {
+        if (!extra_future) return fail(ctx, "extra_future is NULL");
+        const size_t nb = 8 * (size_t)spec->n_extra * nfut;
+        HIP_TRY(ctx, d_ex.alloc(nb));
+        HIP_TRY(ctx, hipMemcpy(d_ex.p, extra_future, nb, hipMemcpyHostToDevice));
+    }
+    HIP_TRY(ctx, d_yh.alloc(8 * (size_t)N * H));
+    if (yhat_int) HIP_TRY(ctx, d_yi.alloc(4 * (size_t)N * H));
+    int rc = tsf_predict_dev(ctx, spec, N, H, d_th.as<double>(), d_ys.as<double>(),
+                             d_grid.as<tsf_grid_info>(), n_grids, d_ds.as<int64_t>(), shared_future,
+                             floor_ ? d_fl.as<double>() : nullptr, cap ? d_cap.as<double>() : nullptr,
+                             spec->n_extra > 0 ? d_ex.as<double>() : nullptr, d_yh.as<double>(),
+                             yhat_int ? d_yi.as<int32_t>() : nullptr, nullptr);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    HIP_TRY(ctx, hipMemcpy(yhat, d_yh.p, 8 * (size_t)N * H, hipMemcpyDeviceToHost));
+    if (yhat_int) HIP_TRY(ctx, hipMemcpy(yhat_int, d_yi.p, 4 * (size_t)N * H, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---- diagnostics --------------------------------------------------------------------------------
+
+extern "C" int tsf_design(tsf_ctx *ctx, const tsf_spec *spec, int32_t T, const int64_t *ds,
+                          const double *extra, double *X_out, double *t_out,
+                          tsf_grid_info *grid_out)
+{
+    if (!ctx) return -1;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!spec || !ds || T < 2) return fail(ctx, "bad input");
+    DevSpec hs;
+    int mode = 0;
+    int rc = build_devspec(ctx, spec, &hs, &mode);
+    if (rc) return rc;
+    if (hs.n_extra > 0 && !extra) return fail(ctx, "extra is NULL");
+    const int NT = (T + W - 1) / W;
+    const WsLayout l = ws_layout(1, 1, NT, hs.KP);
+    rc = ensure_ws(ctx, l.total);
+    if (rc) return rc;
+    char *ws = (char *)ctx->ws;
+    DevBuf d_ds, d_ex;
+    HIP_TRY(ctx, d_ds.alloc(8 * (size_t)T));
+    HIP_TRY(ctx, hipMemcpy(d_ds.p, ds, 8 * (size_t)T, hipMemcpyHostToDevice));
+    if (hs.n_extra > 0) {
+        HIP_TRY(ctx, d_ex.alloc(8 * (size_t)hs.n_extra * T));
+        HIP_TRY(ctx, hipMemcpy(d_ex.p, extra, 8 * (size_t)hs.n_extra * T, hipMemcpyHostToDevice));
+    }
+    HIP_TRY(ctx, hipMemcpy(ctx->d_spec, &hs, sizeof(hs), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemset(ws + l.Xw, 0, sizeof(double) * (size_t)NT * hs.KP * W));
+    HIP_TRY(ctx, hipMemset(ws + l.gtab, 0, sizeof(GridTab)));
+    hipLaunchKernelGGL(setup_grid_kernel, dim3(1), dim3(256), 0, nullptr, ctx->d_spec, 1, nullptr, T,
+                       d_ds.as<int64_t>(), d_ex.as<double>(), (int64_t)T, NT, (GridTab *)(ws + l.gtab),
+                       (double *)(ws + l.tw), (uint16_t *)(ws + l.cw), (double *)(ws + l.Xw));
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    std::vector<double> Xw((size_t)NT * hs.KP * W), tw((size_t)NT * W);
+    GridTab gt;
+    HIP_TRY(ctx, hipMemcpy(Xw.data(), ws + l.Xw, Xw.size() * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(tw.data(), ws + l.tw, tw.size() * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(&gt, ws + l.gtab, sizeof(gt), hipMemcpyDeviceToHost));
+    for (int i = 0; i < T; ++i) {
+        const int L = i / NT, q = i - L * NT;
+        if (t_out) t_out[i] = tw[(size_t)q * W + L];
+        if (X_out)
+            for (int j = 0; j < hs.K; ++j)
+                X_out[(size_t)i * hs.K + hs.perm[j]] = Xw[((size_t)q * hs.KP + j) * W + L];
+    }
+    if (grid_out) *grid_out = gt.info;
+    return 0;
+}
+
+extern "C" int tsf_selftest_math(tsf_ctx *ctx, int32_t op, int64_t n, const double *a,
+                                 const double *b, double *out)
+{
+    if (!ctx) return -1;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (n <= 0 || !a || !out) return fail(ctx, "bad input");
+    DevBuf da, db, dout;
+    HIP_TRY(ctx, da.alloc(8 * n)); HIP_TRY(ctx, dout.alloc(8 * n));
+    HIP_TRY(ctx, hipMemcpy(da.p, a, 8 * n, hipMemcpyHostToDevice));
+    if (b) { HIP_TRY(ctx, db.alloc(8 * n)); HIP_TRY(ctx, hipMemcpy(db.p, b, 8 * n, hipMemcpyHostToDevice)); }
+    hipLaunchKernelGGL(selftest_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, op, n,
+                       da.as<double>(), b ? db.as<double>() : nullptr, dout.as<double>());
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    HIP_TRY(ctx, hipMemcpy(out, dout.p, 8 * n, hipMemcpyDeviceToHost));
+    return 0;
+}

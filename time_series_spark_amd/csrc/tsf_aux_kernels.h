@@ -1,0 +1,289 @@
+// tsf_aux_kernels.h -- setup (scaling, changepoints, design matrix), predict and self-test
+// kernels.  Non-template __global__ functions: include from exactly one translation unit
+// (tsf_api.hip).
+#pragma once
+#include "tsf_common.h"
+
+namespace tsf {
+
+// ---------------------------------------------------------------------------------------
+// setup kernels
+// ---------------------------------------------------------------------------------------
+
+// One block per grid.  Derives scaled time, changepoints, segment indices and the design
+// matrix (fbprophet setup_dataframe / set_changepoints / make_all_seasonality_features).
+// Xw must be zero-filled by the caller (padding columns / rows).
+__global__ void setup_grid_kernel(const DevSpec *__restrict__ sp, int n_grids,
+                                  const int64_t *__restrict__ offsets, int T_aligned,
+                                  const int64_t *__restrict__ ds_all,
+                                  const double *__restrict__ extra, int64_t extra_stride,
+                                  int NTmax, GridTab *__restrict__ gtab,
+                                  double *__restrict__ tw_all, uint16_t *__restrict__ cw_all,
+                                  double *__restrict__ Xw_all)
+{
+    const int g = blockIdx.x;
+    if (g >= n_grids) return;
+    const int64_t row0 = offsets ? offsets[g] : 0;
+    const int T = offsets ? (int)(offsets[g + 1] - offsets[g]) : T_aligned;
+    const int64_t *ds = ds_all + row0;
+    GridTab &gt = gtab[g];
+    double *tw = tw_all + (size_t)g * NTmax * W;
+    uint16_t *cw = cw_all + (size_t)g * NTmax * W;
+    double *Xw = Xw_all + (size_t)g * NTmax * sp->KP * W;
+    const int KP = sp->KP;
+    __shared__ double tch[NTAB];
+    __shared__ int S_sh;
+    const int NT = (T + W - 1) / W;
+    if (T < 2) {
+        if (threadIdx.x == 0) {
+            gt.info.T = T; gt.info.S = 0; gt.info.NT = NT > 0 ? NT : 1; gt.info.i1 = 0;
+            gt.info.start_ns = T > 0 ? ds[0] : 0; gt.info.t_scale_ns = 0;
+        }
+        return;
+    }
+    const int64_t start = ds[0];
+    const double tsc = (double)(ds[T - 1] - ds[0]);
+    int hist = (int)__builtin_floor((double)T * sp->cp_range);
+    int S = sp->n_cp;
+    if (S + 1 > hist) S = hist - 1;
+    if (S < 0) S = 0;
+    if (threadIdx.x == 0) S_sh = S;
+    const double step = (S > 0) ? (double)(hist - 1) / (double)S : 0.0;
+    for (int j = threadIdx.x; j < S; j += blockDim.x) {
+        const double v = (j + 1 == S) ? (double)(hist - 1) : (double)(j + 1) * step;
+        const int idx = (int)__builtin_rint(v);
+        tch[j] = (double)(ds[idx] - start) / tsc;
+        int fj = idx;
+        while (fj > 0 && ds[fj - 1] == ds[idx]) --fj;
+        gt.Lj[j] = fj / NT;
+        gt.info.t_change[j] = tch[j];
+    }
+    if (threadIdx.x == 0) {
+        int i1 = T - 1;
+        while (i1 > 0 && ds[i1 - 1] == ds[T - 1]) --i1;
+        gt.info.start_ns = start; gt.info.t_scale_ns = ds[T - 1] - ds[0];
+        gt.info.T = T; gt.info.S = S; gt.info.i1 = i1; gt.info.NT = NT;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < T; i += blockDim.x) {
+        const int L = i / NT, q = i - L * NT;
+        const double ti = (double)(ds[i] - start) / tsc;
+        tw[q * W + L] = ti;
+        int c = 0;
+        while (c < S && ti >= tch[c]) ++c;
+        int cp = 0;
+        if (i > 0) {
+            const double tp = (double)(ds[i - 1] - start) / tsc;
+            while (cp < S && tp >= tch[cp]) ++cp;
+        }
+        cw[q * W + L] = (uint16_t)(c | (cp << 8));
+    }
+    // Fourier columns: one (row, harmonic) pair per work item
+    const int n_pairs = sp->n_pairs;
+    for (int w = threadIdx.x; w < T * n_pairs; w += blockDim.x) {
+        const int i = w / n_pairs, pr = w - i * n_pairs;
+        const int L = i / NT, q = i - L * NT;
+        const double tdays = (1e-9 * (double)ds[i]) / 86400.0;
+        const double arg = (sp->pair_mult[pr] * 3.141592653589793 * tdays) / sp->pair_period[pr];
+        double s, c;
+        dm_sincos(arg, s, c);
+        const int col = sp->pair_col[pr];
+        Xw[((size_t)q * KP + sp->inv_perm[col]) * W + L] = s;
+        Xw[((size_t)q * KP + sp->inv_perm[col + 1]) * W + L] = c;
+    }
+    const int nf = sp->K - sp->n_extra;
+    for (int w = threadIdx.x; w < T * sp->n_extra; w += blockDim.x) {
+        const int e = w / T, i = w - e * T;
+        const int L = i / NT, q = i - L * NT;
+        Xw[((size_t)q * KP + sp->inv_perm[nf + e]) * W + L] = extra[(size_t)e * extra_stride + row0 + i];
+    }
+}
+
+__device__ __forceinline__ double load_y(const void *y, int dtype, int64_t i)
+{
+    if (dtype == TSF_Y_F64) return ((const double *)y)[i];
+    if (dtype == TSF_Y_F32) return (double)((const float *)y)[i];
+    return (double)((const int32_t *)y)[i];
+}
+
+// One wave per series: y scaling (initialize_scales), step-major copy of scaled y, growth
+// init (linear_growth_init / logistic_growth_init).
+__global__ __launch_bounds__(64) void setup_series_kernel(
+    const DevSpec *__restrict__ sp, int64_t N, const int64_t *__restrict__ offsets, int T_aligned,
+    const int64_t *__restrict__ ds_all, const void *__restrict__ y_all, int y_dtype,
+    const double *__restrict__ floor_in, const double *__restrict__ cap_in, int NTmax,
+    const GridTab *__restrict__ gtab, int aligned, SeriesTab *__restrict__ stab,
+    double *__restrict__ yw_all)
+{
+    const int64_t n = blockIdx.x;
+    if (n >= N) return;
+    const int lane = threadIdx.x;
+    const GridTab &gt = gtab[aligned ? 0 : n];
+    const int T = gt.info.T, NT = gt.info.NT;
+    const int64_t row0 = offsets ? offsets[n] : n * (int64_t)T_aligned;
+    const int64_t *ds = ds_all + (offsets ? offsets[n] : 0);
+    double *yw = yw_all + (size_t)n * NTmax * W;
+    SeriesTab &st = stab[n];
+    const double fl = (sp->growth == TSF_GROWTH_LOGISTIC && floor_in) ? floor_in[n] : 0.0;
+    const double capv = cap_in ? cap_in[n] : 0.0;
+    if (T < 2) {
+        if (lane == 0) { st.status0 = TSF_ST_TOO_FEW; st.y_scale = 1.0; st.cap = 0; st.k0 = 0; st.m0 = 0; st.floor_ = fl; }
+        return;
+    }
+    double amax = 0.0, ymin = __builtin_huge_val(), ymax = -__builtin_huge_val();
+    for (int i = lane; i < T; i += W) {
+        const double v = load_y(y_all, y_dtype, row0 + i);
+        amax = __builtin_fmax(amax, __builtin_fabs(v - fl));
+        ymin = __builtin_fmin(ymin, v);
+        ymax = __builtin_fmax(ymax, v);
+    }
+#pragma unroll
+    for (int off = 1; off < W; off <<= 1) {
+        amax = __builtin_fmax(amax, __shfl_xor(amax, off, W));
+        ymin = __builtin_fmin(ymin, __shfl_xor(ymin, off, W));
+        ymax = __builtin_fmax(ymax, __shfl_xor(ymax, off, W));
+    }
+    const double ys = (amax == 0.0) ? 1.0 : amax;
+    for (int i = lane; i < T; i += W) {
+        const int L = i / NT, q = i - L * NT;
+        yw[q * W + L] = (load_y(y_all, y_dtype, row0 + i) - fl) / ys;
+    }
+    if (lane == 0) {
+        int status0 = 0;
+        double capsc = 0.0, k0 = 0.0, m0 = 0.0;
+        const int i0 = 0, i1 = gt.info.i1;
+        const double tsc = (double)gt.info.t_scale_ns;
+        const double t0 = (double)(ds[i0] - gt.info.start_ns) / tsc;
+        const double t1 = (double)(ds[i1] - gt.info.start_ns) / tsc;
+        const double y0 = (load_y(y_all, y_dtype, row0 + i0) - fl) / ys;
+        const double y1 = (load_y(y_all, y_dtype, row0 + i1) - fl) / ys;
+        const double Td = t1 - t0;
+        if (sp->growth == TSF_GROWTH_LINEAR) {
+            k0 = (y1 - y0) / Td;
+            m0 = y0 - k0 * t0;
+            if (ymin == ymax) status0 = TSF_ST_CONSTANT;
+        } else {
+            if (capv <= fl) {
+                status0 = TSF_ST_CAP;
+            } else {
+                capsc = (capv - fl) / ys;
+                const double C0 = capsc, C1 = capsc;
+                const double yy0 = __builtin_fmax(0.01 * C0, __builtin_fmin(0.99 * C0, y0));
+                const double yy1 = __builtin_fmax(0.01 * C1, __builtin_fmin(0.99 * C1, y1));
+                double r0 = C0 / yy0;
+                const double r1 = C1 / yy1;
+                if (__builtin_fabs(r0 - r1) <= 0.01) r0 = 1.05 * r0;
+                const double L0 = dm_log(r0 - 1.0), L1 = dm_log(r1 - 1.0);
+                m0 = L0 * Td / (L0 - L1);
+                k0 = (L0 - L1) / Td;
+            }
+        }
+        st.status0 = status0; st.y_scale = ys; st.cap = capsc; st.k0 = k0; st.m0 = m0; st.floor_ = fl;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// predict: one thread per (series, horizon step)
+// ---------------------------------------------------------------------------------------
+
+struct PredictArgs {
+    const DevSpec *sp;
+    int64_t N;
+    int H, theta_stride, n_grids, shared_future;
+    const double *theta, *y_scale;
+    const tsf_grid_info *grid;
+    const int64_t *ds_future;
+    const double *floor_, *cap, *extra_future;
+    double *yhat;
+    int32_t *yhat_int;
+};
+
+__global__ void predict_kernel(PredictArgs a)
+{
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= a.N * (int64_t)a.H) return;
+    const int64_t n = gid / a.H;
+    const int h = (int)(gid - n * a.H);
+    const DevSpec *sp = a.sp;
+    const tsf_grid_info &gi = a.grid[a.n_grids == 1 ? 0 : n];
+    const int S = gi.S, K = sp->K, Ka = sp->Ka, n_cp = sp->n_cp;
+    const double *th = a.theta + (size_t)n * a.theta_stride;
+    const double *delta = th + 3, *beta = th + 3 + n_cp;
+    const double ys = a.y_scale[n];
+    const double fl = (sp->growth == TSF_GROWTH_LOGISTIC && a.floor_) ? a.floor_[n] : 0.0;
+    const double fl_clamp = a.floor_ ? a.floor_[n] : 0.0;
+    const int64_t dsv = a.ds_future[a.shared_future ? h : n * (int64_t)a.H + h];
+    const double t = (double)(dsv - gi.start_ns) / (double)gi.t_scale_ns;
+    double ks = th[0], mc = th[1];
+    int c = 0;
+    while (c < S && t >= gi.t_change[c]) {
+        const double dj = delta[c], tcj = gi.t_change[c];
+        const double ksn = ks + dj;
+        if (sp->growth == TSF_GROWTH_LINEAR) {
+            mc = mc + ((-tcj) * dj);
+        } else {
+            const double gamma = (tcj - mc) * (1.0 - ks / ksn);
+            mc = mc + gamma;
+        }
+        ks = ksn;
+        ++c;
+    }
+    // design row in original column order
+    double row[TSF_MAX_K];
+    const double tdays = (1e-9 * (double)dsv) / 86400.0;
+    for (int pr = 0; pr < sp->n_pairs; ++pr) {
+        const double arg = (sp->pair_mult[pr] * 3.141592653589793 * tdays) / sp->pair_period[pr];
+        dm_sincos(arg, row[sp->pair_col[pr]], row[sp->pair_col[pr] + 1]);
+    }
+    const int nf = K - sp->n_extra;
+    for (int e = 0; e < sp->n_extra; ++e) {
+        const size_t off = a.shared_future ? (size_t)e * a.H + h
+                                           : ((size_t)n * sp->n_extra + e) * a.H + h;
+        row[nf + e] = a.extra_future[off];
+    }
+    double xa = 0.0, xm = 0.0;
+    for (int j = 0; j < Ka; ++j) xa = __builtin_fma(row[sp->perm[j]], beta[sp->perm[j]], xa);
+    for (int j = Ka; j < K; ++j) xm = __builtin_fma(row[sp->perm[j]], beta[sp->perm[j]], xm);
+    double gtr;
+    if (sp->growth == TSF_GROWTH_LINEAR) {
+        gtr = __builtin_fma(ks, t, mc);
+    } else {
+        const double capsc = (a.cap[n] - fl) / ys;
+        const double z = ks * (t - mc);
+        gtr = capsc * (1.0 / (1.0 + dm_exp(-z)));
+    }
+    const double trend = gtr * ys + fl;
+    const double yh = trend * (1.0 + xm) + xa * ys;
+    a.yhat[gid] = yh;
+    if (a.yhat_int) {
+        // prophet_scorer.py:73 astype(int) truncates toward zero; :76-84 clamp to floor
+        double tr = __builtin_trunc(yh);
+        if (!(tr >= -2147483648.0)) tr = -2147483648.0;
+        if (tr > 2147483647.0) tr = 2147483647.0;
+        int32_t iv = (int32_t)tr;
+        if ((double)iv < fl_clamp) iv = (int32_t)fl_clamp;
+        a.yhat_int[gid] = iv;
+    }
+}
+
+// IEEE self test of the primitive operations the canonical order relies on
+__global__ void selftest_kernel(int op, int64_t n, const double *a, const double *b, double *out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double x = a[i], y = b ? b[i] : 0.0;
+    double r = 0.0, s, c;
+    switch (op) {
+    case 0: r = x / y; break;
+    case 1: r = __builtin_sqrt(x); break;
+    case 2: r = dm_exp(x); break;
+    case 3: r = dm_log(x); break;
+    case 4: dm_sincos(x, s, c); r = s; break;
+    case 5: dm_sincos(x, s, c); r = c; break;
+    case 6: r = __builtin_fma(x, y, x); break;
+    default: break;
+    }
+    out[i] = r;
+}
+
+}  // namespace tsf

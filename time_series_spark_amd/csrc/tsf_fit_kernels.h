@@ -1,0 +1,620 @@
+// tsf_fit_kernels.h -- the fit / eval kernel templates (see tsf_common.h for the execution
+// model and the canonical-arithmetic contract).  Instantiated by tsf_inst_g*m*.hip.
+#pragma once
+#include "tsf_common.h"
+
+namespace tsf {
+
+// ---------------------------------------------------------------------------------------
+// -log posterior and gradient (prophet.stan model block), one wave per series
+// ---------------------------------------------------------------------------------------
+
+struct SeriesView {
+    int T, NT, S, P, cnt;               // cnt: valid rows of this lane's chunk
+    const double *tw, *yw, *Xw;         // step-major tables
+    const uint16_t *cw;
+    const int32_t *Lj;
+    const double *t_change;
+    double cap, tau;
+    int n_eval;
+};
+
+// LDS carve-up for one wave
+template <int KP, int PPL>
+struct WaveLds {
+    double th[TSF_MAX_P + W];          // zero beyond P (padding columns read it)
+    double ks[NTAB + 1], mc[NTAB + 1];
+    double tp1[NTAB], tp2[NTAB];
+    double tot1[W + 1], tot2[W + 1];
+    double d1[NTAB + 1], d2[NTAB + 1], rb[NTAB + 1], ab[NTAB + 1];
+    double rho[MAXH], alphas[MAXH];
+    double accT[KP * W];
+    double Sb[MAXH * PPL * W], Yb[MAXH * PPL * W];
+};
+
+#define TSF_WAVE_SYNC() __syncthreads()
+
+// MODE: 0 all columns additive, 1 all multiplicative, 2 mixed (Ka additive first)
+template <int KP, int GROWTH, int MODE, int PPL>
+__device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesView &sv,
+                                        WaveLds<KP, PPL> &lds, const double (&th)[PPL],
+                                        double &f_out, double (&g)[PPL])
+{
+    const int lane = threadIdx.x;
+    const int S = sv.S, NT = sv.NT, T = sv.T;
+    const int Ka = (MODE == 0) ? KP : (MODE == 1 ? 0 : sp->Ka);
+    sv.n_eval++;
+#pragma unroll
+    for (int s = 0; s < PPL; ++s) lds.th[lane + s * W] = th[s];
+    TSF_WAVE_SYNC();
+    const double k = lds.th[0], m = lds.th[1], ls = lds.th[2];
+    const double sigma = dm_exp(ls);
+    const double inv_s2 = 1.0 / (sigma * sigma);
+    // segment tables ks[c], mc[c]
+    {
+        double ksv = k, mcv = m;
+        if (lane == 0) { lds.ks[0] = ksv; lds.mc[0] = mcv; }
+        for (int j = 0; j < S; ++j) {
+            const double dj = lds.th[3 + j];
+            const double tcj = sv.t_change[j];
+            const double ksn = ksv + dj;
+            if (GROWTH == 0) {
+                mcv = mcv + ((-tcj) * dj);
+            } else {
+                const double gamma = (tcj - mcv) * (1.0 - ksv / ksn);
+                mcv = mcv + gamma;
+            }
+            ksv = ksn;
+            if (lane == 0) { lds.ks[j + 1] = ksv; lds.mc[j + 1] = mcv; }
+        }
+    }
+    // coefficients as wave-uniform scalars (kept in SGPRs for KP <= 32; read from LDS above)
+    constexpr bool HOLD = (KP <= 32);
+    double bs[HOLD ? KP : 1];
+    if (HOLD) {
+#pragma unroll
+        for (int j = 0; j < (HOLD ? KP : 1); ++j) bs[j] = uniform_f64(lds.th[3 + S + j]);
+    }
+    TSF_WAVE_SYNC();
+
+    double sse = 0.0, rt1 = 0.0, rt2 = 0.0;
+    double acc[KP];
+#pragma unroll
+    for (int j = 0; j < KP; ++j) acc[j] = 0.0;
+    for (int q = NT - 1; q >= 0; --q) {
+        if (q < sv.cnt) {
+            const int idx = q * W + lane;
+            const unsigned cwv = sv.cw[idx];
+            const int c = (int)(cwv & 0xffu), cprev = (int)(cwv >> 8);
+            const double ti = sv.tw[idx];
+            const double yi = sv.yw[idx];
+            double x[HOLD ? KP : 1];
+            const double *xp = sv.Xw + (size_t)q * KP * W + lane;
+            if (HOLD) {
+#pragma unroll
+                for (int j = 0; j < (HOLD ? KP : 1); ++j) x[j] = xp[j * W];
+            }
+            double xa = 0.0, xm = 0.0;
+#pragma unroll 8
+            for (int j = 0; j < KP; ++j) {
+                const double xv = HOLD ? x[HOLD ? j : 0] : xp[j * W];
+                const double bv = HOLD ? bs[HOLD ? j : 0] : lds.th[3 + S + j];
+                if (MODE == 0) xa = __builtin_fma(xv, bv, xa);
+                else if (MODE == 1) xm = __builtin_fma(xv, bv, xm);
+                else { if (j < Ka) xa = __builtin_fma(xv, bv, xa); else xm = __builtin_fma(xv, bv, xm); }
+            }
+            const double ksc = lds.ks[c], mcc = lds.mc[c];
+            double gtr, qv = 0.0;
+            if (GROWTH == 0) {
+                gtr = __builtin_fma(ksc, ti, mcc);
+            } else {
+                const double z = ksc * (ti - mcc);
+                const double e = dm_exp(-z);
+                const double sg = 1.0 / (1.0 + e);
+                gtr = sv.cap * sg;
+                qv = gtr * (1.0 - sg);
+            }
+            const double opm = 1.0 + xm;
+            const double mu = __builtin_fma(gtr, opm, xa);
+            const double r = yi - mu;
+            sse = __builtin_fma(r, r, sse);
+            const double rg = r * gtr;
+#pragma unroll
+            for (int j = 0; j < KP; ++j) {
+                const double xv = HOLD ? x[HOLD ? j : 0] : xp[j * W];
+                if (MODE == 0) acc[j] = __builtin_fma(xv, r, acc[j]);
+                else if (MODE == 1) acc[j] = __builtin_fma(xv, rg, acc[j]);
+                else acc[j] = __builtin_fma(xv, (j < Ka) ? r : rg, acc[j]);
+            }
+            double v = r * opm;
+            if (GROWTH == 1) v = v * qv;
+            rt1 = __builtin_fma(v, ti, rt1);
+            rt2 = rt2 + v;
+            for (int j = cprev; j < c; ++j) { lds.tp1[j] = rt1; lds.tp2[j] = rt2; }
+        }
+    }
+    // reductions over the time axis
+    const double sse_t = bfly_sum(sse);
+    double s1 = rt1, s2v = rt2;
+#pragma unroll
+    for (int off = 1; off < W; off <<= 1) {
+        const double o1 = __shfl_down(s1, off, W), o2 = __shfl_down(s2v, off, W);
+        if (lane + off < W) { s1 = s1 + o1; s2v = s2v + o2; }
+    }
+    lds.tot1[lane] = s1; lds.tot2[lane] = s2v;
+    if (lane == 0) { lds.tot1[W] = 0.0; lds.tot2[W] = 0.0; }
+#pragma unroll
+    for (int j = 0; j < KP; ++j) lds.accT[j * W + lane] = acc[j];
+    TSF_WAVE_SYNC();
+    const double TA = lds.tot1[0], TB = lds.tot2[0];
+
+    // prior terms
+    double pa = 0.0, pb = 0.0;
+#pragma unroll
+    for (int s = 0; s < PPL; ++s) {
+        const int p = lane + s * W;
+        if (p >= 3 && p < 3 + S) pa = pa + __builtin_fabs(th[s]);
+        if (p >= 3 + S && p < sv.P) { const double qq = th[s] / sp->prior[p - 3 - S]; pb = __builtin_fma(qq, qq, pb); }
+    }
+    const double sabs = bfly_sum(pa), sb = bfly_sum(pb);
+    const double s2 = sigma * sigma;
+    double f = ((0.5 * k) * k) / 25.0 + ((0.5 * m) * m) / 25.0;
+    f = f + sabs / sv.tau;
+    f = f + 2.0 * s2;
+    f = f + 0.5 * sb;
+    f = f + (double)T * ls;
+    f = f + (0.5 * sse_t) * inv_s2;
+
+    const double nis = -inv_s2;
+    double gk = 0.0, gm = 0.0;
+    if (GROWTH == 1) {
+        // per-segment sums from suffix sums, then reverse sweep through the gamma recurrence
+        for (int c = lane; c <= S; c += W) {
+            const int Ljm = (c > 0) ? sv.Lj[c - 1] : 0, Ljc = (c < S) ? sv.Lj[c] : 0;
+            const double hiA = (c == 0) ? TA : lds.tp1[c - 1] + lds.tot1[Ljm + 1];
+            const double hiB = (c == 0) ? TB : lds.tp2[c - 1] + lds.tot2[Ljm + 1];
+            const double loA = (c == S) ? 0.0 : lds.tp1[c] + lds.tot1[Ljc + 1];
+            const double loB = (c == S) ? 0.0 : lds.tp2[c] + lds.tot2[Ljc + 1];
+            const double A = hiA - loA, B = hiB - loB;
+            lds.d1[c] = A - lds.mc[c] * B;
+            lds.d2[c] = -(lds.ks[c] * B);
+        }
+        TSF_WAVE_SYNC();
+        {
+            double abar = lds.d2[S];
+            for (int c = S - 1; c >= 0; --c) {
+                const double ratio = lds.ks[c] / lds.ks[c + 1];
+                if (lane == 0) lds.rb[c] = abar * (sv.t_change[c] - lds.mc[c]);
+                abar = lds.d2[c] + abar * ratio;
+            }
+            gm = nis * abar;
+        }
+        TSF_WAVE_SYNC();
+        for (int c = lane; c <= S; c += W) {
+            double d = lds.d1[c];
+            if (c < S) d = d + lds.rb[c] * (-1.0 / lds.ks[c + 1]);
+            if (c >= 1) d = d + lds.rb[c - 1] * ((lds.ks[c - 1] / lds.ks[c]) / lds.ks[c]);
+            lds.ab[c] = d;
+        }
+        TSF_WAVE_SYNC();
+    }
+
+#pragma unroll
+    for (int s = 0; s < PPL; ++s) g[s] = 0.0;
+    double sK_all = 0.0;
+    if (GROWTH == 1) {
+        // sequential suffix of the adjusted per-segment sums: gd[c-1] = nis * sum_{c'>=c} D1[c']
+        double sK = 0.0;
+        for (int c = S; c >= 1; --c) {
+            sK = sK + lds.ab[c];
+#pragma unroll
+            for (int s = 0; s < PPL; ++s)
+                if (lane + s * W == 3 + (c - 1)) g[s] = nis * sK;
+        }
+        sK_all = sK + lds.ab[0];
+        gk = nis * sK_all;
+    } else {
+        gk = nis * TA;
+        gm = nis * TB;
+    }
+    bool bad = !finite_f64(f);
+#pragma unroll
+    for (int s = 0; s < PPL; ++s) {
+        const int p = lane + s * W;
+        double gv = 0.0;
+        if (p == 0) gv = gk + k / 25.0;
+        else if (p == 1) gv = gm + m / 25.0;
+        else if (p == 2) gv = ((double)T - sse_t * inv_s2) + 4.0 * s2;
+        else if (p < 3 + S) {
+            const int j = p - 3;
+            double gd;
+            if (GROWTH == 0) {
+                const int Lj = sv.Lj[j];
+                const double SA = lds.tp1[j] + lds.tot1[Lj + 1];
+                const double SB = lds.tp2[j] + lds.tot2[Lj + 1];
+                gd = nis * (SA - sv.t_change[j] * SB);
+            } else {
+                gd = g[s];
+            }
+            const double dj = th[s];
+            const double sgn = (double)((dj > 0.0) - (dj < 0.0));
+            gv = gd + sgn / sv.tau;
+        } else if (p < sv.P) {
+            const int j = p - 3 - S;
+            double a = lds.accT[j * W];
+            for (int L = 1; L < W; ++L) a = a + lds.accT[j * W + L];
+            const double pr = sp->prior[j];
+            gv = nis * a + th[s] / (pr * pr);
+        }
+        g[s] = gv;
+        bad = bad || !finite_f64(gv);
+    }
+    f_out = f;
+    TSF_WAVE_SYNC();
+    return __any(bad);
+}
+
+// ---------------------------------------------------------------------------------------
+// Stan L-BFGS (BFGSMinimizer<LBFGSUpdate>::step, WolfeLineSearch, WolfLSZoom, CubicInterp)
+// ---------------------------------------------------------------------------------------
+
+__device__ __forceinline__ double cubic_interp6(double df0, double x1, double f1, double df1,
+                                                double loX, double hiX)
+{
+    const double c3 = (-12.0 * f1 + 6.0 * x1 * (df0 + df1)) / (x1 * x1 * x1);
+    const double c2 = -(4.0 * df0 + 2.0 * df1) / x1 + 6.0 * f1 / (x1 * x1);
+    const double c1 = df0;
+    const double t_s = __builtin_sqrt(c2 * c2 - 2.0 * c1 * c3);
+    const double s1 = -(c2 + t_s) / c3;
+    const double s2 = -(c2 - t_s) / c3;
+    double tmpF, minF, minX;
+    minF = loX * (loX * (loX * c3 / 3.0 + c2) / 2.0 + c1);
+    minX = loX;
+    tmpF = hiX * (hiX * (hiX * c3 / 3.0 + c2) / 2.0 + c1);
+    if (tmpF < minF) { minF = tmpF; minX = hiX; }
+    if (loX < s1 && s1 < hiX) {
+        tmpF = s1 * (s1 * (s1 * c3 / 3.0 + c2) / 2.0 + c1);
+        if (tmpF < minF) { minF = tmpF; minX = s1; }
+    }
+    if (loX < s2 && s2 < hiX) {
+        tmpF = s2 * (s2 * (s2 * c3 / 3.0 + c2) / 2.0 + c1);
+        if (tmpF < minF) { minF = tmpF; minX = s2; }
+    }
+    return minX;
+}
+
+struct FitArgs {
+    const DevSpec *sp;
+    int64_t N;
+    int aligned, NTmax, theta_stride;
+    const GridTab *gtab;
+    const SeriesTab *stab;
+    const double *tw, *yw, *Xw;
+    const uint16_t *cw;
+    // outputs
+    double *theta, *y_scale, *fval;
+    int32_t *status, *n_iter, *n_eval;
+    tsf_grid_info *grid_out;
+    // eval-only mode
+    const double *theta_in;
+    double *grad_out;
+};
+
+template <int KP, int PPL>
+__device__ __forceinline__ void make_view(const FitArgs &a, int64_t n, SeriesView &sv)
+{
+    const int g = a.aligned ? 0 : (int)n;
+    const GridTab &gt = a.gtab[g];
+    sv.T = gt.info.T; sv.NT = gt.info.NT; sv.S = gt.info.S;
+    sv.P = 3 + sv.S + a.sp->K;
+    int cnt = sv.T - (int)threadIdx.x * sv.NT;
+    cnt = cnt < 0 ? 0 : (cnt > sv.NT ? sv.NT : cnt);
+    sv.cnt = cnt;
+    sv.tw = a.tw + (size_t)g * a.NTmax * W;
+    sv.cw = a.cw + (size_t)g * a.NTmax * W;
+    sv.Xw = a.Xw + (size_t)g * a.NTmax * KP * W;
+    sv.yw = a.yw + (size_t)n * a.NTmax * W;
+    sv.Lj = gt.Lj;
+    sv.t_change = gt.info.t_change;
+    sv.cap = a.stab[n].cap;
+    sv.tau = a.sp->tau;
+    sv.n_eval = 0;
+}
+
+// theta (internal order, registers) -> caller layout [k,m,log sigma,delta[n_cp],beta[K]]
+template <int PPL>
+__device__ __forceinline__ void store_theta(const FitArgs &a, const SeriesView &sv, int64_t n,
+                                            const double (&x)[PPL], double *dst)
+{
+    const int n_cp = a.sp->n_cp;
+    double *out = dst + (size_t)n * a.theta_stride;
+    for (int i = threadIdx.x; i < a.theta_stride; i += W) out[i] = 0.0;
+    TSF_WAVE_SYNC();
+#pragma unroll
+    for (int s = 0; s < PPL; ++s) {
+        const int p = threadIdx.x + s * W;
+        if (p < 3 + sv.S) out[p] = x[s];
+        else if (p < sv.P) out[3 + n_cp + a.sp->perm[p - 3 - sv.S]] = x[s];
+    }
+}
+
+template <int PPL>
+__device__ __forceinline__ void load_theta(const FitArgs &a, const SeriesView &sv, int64_t n,
+                                           const double *src, double (&x)[PPL])
+{
+    const int n_cp = a.sp->n_cp;
+    const double *in = src + (size_t)n * a.theta_stride;
+#pragma unroll
+    for (int s = 0; s < PPL; ++s) {
+        const int p = threadIdx.x + s * W;
+        double v = 0.0;
+        if (p < 3 + sv.S) v = in[p];
+        else if (p < sv.P) v = in[3 + n_cp + a.sp->perm[p - 3 - sv.S]];
+        x[s] = v;
+    }
+}
+
+// eval-only kernel (parity tests): f and gradient at a caller-supplied theta
+template <int KP, int GROWTH, int MODE, int PPL>
+__global__ __launch_bounds__(64) void eval_kernel(FitArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    WaveLds<KP, PPL> &lds = *reinterpret_cast<WaveLds<KP, PPL> *>(smem);
+    const int64_t n = blockIdx.x;
+    if (n >= a.N) return;
+    SeriesView sv;
+    make_view<KP, PPL>(a, n, sv);
+    for (int i = threadIdx.x; i < TSF_MAX_P + W; i += W) lds.th[i] = 0.0;
+    TSF_WAVE_SYNC();
+    double x[PPL], g[PPL], f;
+    load_theta<PPL>(a, sv, n, a.theta_in, x);
+    const bool bad = eval_fg<KP, GROWTH, MODE, PPL>(a.sp, sv, lds, x, f, g);
+    store_theta<PPL>(a, sv, n, g, a.grad_out);
+    if (threadIdx.x == 0) { a.fval[n] = f; a.status[n] = bad ? 1 : 0; }
+}
+
+template <int KP, int GROWTH, int MODE, int PPL>
+__global__ __launch_bounds__(64) void fit_kernel(FitArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    WaveLds<KP, PPL> &lds = *reinterpret_cast<WaveLds<KP, PPL> *>(smem);
+    const int64_t n = blockIdx.x;
+    if (n >= a.N) return;
+    const int lane = threadIdx.x;
+    const DevSpec *sp = a.sp;
+    SeriesView sv;
+    make_view<KP, PPL>(a, n, sv);
+    for (int i = threadIdx.x; i < TSF_MAX_P + W; i += W) lds.th[i] = 0.0;
+    TSF_WAVE_SYNC();
+    const SeriesTab st = a.stab[n];
+    if (lane == 0) {
+        a.y_scale[n] = st.y_scale;
+        if (!a.aligned || n == 0) a.grid_out[a.aligned ? 0 : n] = a.gtab[a.aligned ? 0 : n].info;
+    }
+
+    double xk[PPL], gk[PPL], pk[PPL], xk1[PPL], gk1[PPL], pk1[PPL];
+#pragma unroll
+    for (int s = 0; s < PPL; ++s) {
+        const int p = lane + s * W;
+        xk[s] = (p == 0) ? st.k0 : (p == 1 ? st.m0 : 0.0);
+        gk[s] = 0.0; pk[s] = 0.0; xk1[s] = xk[s]; gk1[s] = 0.0; pk1[s] = 0.0;
+    }
+    if (st.status0 != 0) {
+        // fbprophet raises (too few rows / cap <= floor) or skips optimisation (constant y)
+        if (st.status0 == TSF_ST_CONSTANT) {
+#pragma unroll
+            for (int s = 0; s < PPL; ++s) if (lane + s * W == 2) xk[s] = -20.72326583694641;
+        }
+        store_theta<PPL>(a, sv, n, xk, a.theta);
+        if (lane == 0) { a.status[n] = st.status0; a.n_iter[n] = 0; a.n_eval[n] = 0; a.fval[n] = 0.0; }
+        return;
+    }
+
+    const int H = sp->history > MAXH ? MAXH : sp->history;
+    const double eps = 2.220446049250313e-16;
+    const double c1 = 1e-4, c2 = 0.9, minAlpha = 1e-12, min_range = 1e-16;
+    const int maxLSIts = 20, maxLSRestarts = 10;
+
+    double fk = 0.0, fk1 = 0.0, alpha = sp->init_alpha, gammak = 1.0;
+    int itNum = 0, ret = 0, resetB = 0, hist_len = 0, hist_head = 0;
+    // line-search state
+    double dfp = 0, c1dfp = 0, c2dfp = 0, alpha0 = 0, prevF = 0, prevDFp = 0;
+    double alo = 0, aloF = 0, aloDFp = 0, ahi = 0, ahiF = 0, ahiDFp = 0;
+    int nits = 0, lsRestarts = 0, zoom = 0, zit = 0;
+
+    enum { ST_INIT = 0, ST_START_ITER, ST_START_LS, ST_LS_PRE, ST_LS_EVAL };
+    int stage = ST_INIT;
+    for (;;) {
+        if (stage == ST_START_ITER) {
+            itNum++;
+            resetB = (itNum == 1) ? 1 : 0;
+            stage = ST_START_LS;
+        }
+        if (stage == ST_START_LS) {
+            if (resetB) {
+#pragma unroll
+                for (int s = 0; s < PPL; ++s) pk[s] = -gk[s];
+            }
+            if (itNum > 1 && resetB != 2) {
+                const double ci = cubic_interp6(pdot<PPL>(gk1, pk1), alpha, fk - fk1,
+                                                pdot<PPL>(gk, pk), minAlpha, 1.0);
+                alpha = __builtin_fmin(1.0, 1.01 * ci);
+            } else {
+                alpha = sp->init_alpha;
+            }
+            dfp = pdot<PPL>(gk, pk);
+            c1dfp = c1 * dfp; c2dfp = c2 * dfp;
+            alpha0 = minAlpha; prevF = fk; prevDFp = dfp;
+            nits = 0; lsRestarts = 0; zoom = 0; zit = 0;
+            stage = ST_LS_PRE;
+        }
+        bool ls_fail = false;
+        if (stage == ST_LS_PRE) {
+            if (!zoom) {
+                if (nits >= maxLSIts) ls_fail = true;
+            } else {
+                zit++;
+                if (__builtin_fabs(alo - ahi) < min_range) {
+                    ls_fail = true;
+                } else if (zit % 5 == 0) {
+                    alpha = 0.5 * (alo + ahi);
+                } else {
+                    const double d1 = aloDFp + ahiDFp - 3.0 * (aloF - ahiF) / (alo - ahi);
+                    double d2 = __builtin_sqrt(d1 * d1 - aloDFp * ahiDFp);
+                    if (ahi < alo) d2 = -d2;
+                    alpha = ahi - (ahi - alo) * (ahiDFp + d2 - d1) / (ahiDFp - aloDFp + 2.0 * d2);
+                    const double lo = __builtin_fmin(alo, ahi), hi = __builtin_fmax(alo, ahi),
+                                 w = __builtin_fabs(alo - ahi);
+                    if (!finite_f64(alpha) || alpha < lo + 0.01 * w || alpha > hi - 0.01 * w)
+                        alpha = 0.5 * (alo + ahi);
+                }
+            }
+            if (!ls_fail) stage = ST_LS_EVAL;
+        }
+        if (!ls_fail) {
+            if (stage == ST_LS_EVAL) {
+#pragma unroll
+                for (int s = 0; s < PPL; ++s) xk1[s] = __builtin_fma(alpha, pk[s], xk[s]);
+            }
+            double f1;
+            const bool bad = eval_fg<KP, GROWTH, MODE, PPL>(sp, sv, lds, xk1, f1, gk1);
+            if (stage == ST_INIT) {
+                if (bad) { ret = TSF_ST_INIT_NONFINITE; fk = f1; break; }
+                fk = f1;
+#pragma unroll
+                for (int s = 0; s < PPL; ++s) { gk[s] = gk1[s]; pk[s] = -gk[s]; gk1[s] = 0.0; xk1[s] = 0.0; }
+                stage = ST_START_ITER;
+                continue;
+            }
+            if (bad) {
+                if (!zoom) {
+                    if (lsRestarts >= maxLSRestarts) ls_fail = true;
+                    else { alpha = 0.5 * (alpha0 + alpha); lsRestarts++; }
+                } else {
+                    alpha = 0.5 * (alpha + __builtin_fmin(alo, ahi));
+                    if (__builtin_fabs(__builtin_fmin(alo, ahi) - alpha) < min_range) ls_fail = true;
+                }
+                if (!ls_fail) continue;            // re-evaluate at the shortened step
+            }
+            if (!ls_fail) {
+                const double newDFp = pdot<PPL>(gk1, pk);
+                bool ls_ok = false;
+                if (!zoom) {
+                    lsRestarts = 0;
+                    if (f1 > fk + alpha * c1dfp || (f1 >= prevF && nits > 0)) {
+                        zoom = 1; alo = alpha0; aloF = prevF; aloDFp = prevDFp;
+                        ahi = alpha; ahiF = f1; ahiDFp = newDFp;
+                    } else if (__builtin_fabs(newDFp) <= -c2dfp) {
+                        ls_ok = true;
+                    } else if (newDFp >= 0) {
+                        zoom = 1; alo = alpha; aloF = f1; aloDFp = newDFp;
+                        ahi = alpha0; ahiF = prevF; ahiDFp = prevDFp;
+                    } else {
+                        alpha0 = alpha; prevF = f1; prevDFp = newDFp;
+                        alpha *= 10.0;
+                        nits++;
+                    }
+                } else {
+                    if (f1 > (fk + alpha * c1dfp) || f1 >= aloF) {
+                        ahi = alpha; ahiF = f1; ahiDFp = newDFp;
+                    } else if (__builtin_fabs(newDFp) <= -c2dfp) {
+                        ls_ok = true;
+                    } else {
+                        if (newDFp * (ahi - alo) >= 0) { ahi = alo; ahiF = aloF; ahiDFp = aloDFp; }
+                        alo = alpha; aloF = f1; aloDFp = newDFp;
+                    }
+                }
+                if (!ls_ok) { stage = ST_LS_PRE; continue; }
+                fk1 = f1;
+                // ---- accepted step: k becomes the most recent iterate ----
+                { const double tf = fk; fk = fk1; fk1 = tf; }
+                double sk[PPL], yk[PPL];
+#pragma unroll
+                for (int s = 0; s < PPL; ++s) {
+                    const double tx = xk[s]; xk[s] = xk1[s]; xk1[s] = tx;
+                    const double tg = gk[s]; gk[s] = gk1[s]; gk1[s] = tg;
+                    const double tp = pk[s]; pk[s] = pk1[s]; pk1[s] = tp;
+                    sk[s] = xk[s] - xk1[s];
+                    yk[s] = gk[s] - gk1[s];
+                }
+                const double gradNorm = __builtin_sqrt(pdot<PPL>(gk, gk));
+                const double stepNorm = __builtin_sqrt(pdot<PPL>(sk, sk));
+                const double skyk = pdot<PPL>(yk, sk);
+                const double ykyk = pdot<PPL>(yk, yk);
+                if (resetB) {
+                    const double B0fact = ykyk / skyk;
+                    hist_len = 0; hist_head = 0;
+#pragma unroll
+                    for (int s = 0; s < PPL; ++s) pk1[s] = pk1[s] / B0fact;
+                    alpha = alpha * B0fact;
+                }
+                gammak = skyk / ykyk;
+                {
+                    int slot;
+                    if (hist_len < H) { slot = (hist_head + hist_len) % H; hist_len++; }
+                    else { slot = hist_head; hist_head = (hist_head + 1) % H; }
+                    if (lane == 0) lds.rho[slot] = 1.0 / skyk;
+#pragma unroll
+                    for (int s = 0; s < PPL; ++s) {
+                        lds.Sb[(slot * PPL + s) * W + lane] = sk[s];
+                        lds.Yb[(slot * PPL + s) * W + lane] = yk[s];
+                    }
+                }
+                TSF_WAVE_SYNC();
+#pragma unroll
+                for (int s = 0; s < PPL; ++s) pk[s] = -gk[s];
+                for (int h = hist_len - 1; h >= 0; --h) {
+                    const int slot = (hist_head + h) % H;
+                    double si[PPL], yi[PPL];
+#pragma unroll
+                    for (int s = 0; s < PPL; ++s) {
+                        si[s] = lds.Sb[(slot * PPL + s) * W + lane];
+                        yi[s] = lds.Yb[(slot * PPL + s) * W + lane];
+                    }
+                    const double aa = lds.rho[slot] * pdot<PPL>(si, pk);
+#pragma unroll
+                    for (int s = 0; s < PPL; ++s) pk[s] = __builtin_fma(-aa, yi[s], pk[s]);
+                    if (lane == 0) lds.alphas[h] = aa;
+                }
+                TSF_WAVE_SYNC();
+#pragma unroll
+                for (int s = 0; s < PPL; ++s) pk[s] = pk[s] * gammak;
+                for (int h = 0; h < hist_len; ++h) {
+                    const int slot = (hist_head + h) % H;
+                    double si[PPL], yi[PPL];
+#pragma unroll
+                    for (int s = 0; s < PPL; ++s) {
+                        si[s] = lds.Sb[(slot * PPL + s) * W + lane];
+                        yi[s] = lds.Yb[(slot * PPL + s) * W + lane];
+                    }
+                    const double bb = lds.rho[slot] * pdot<PPL>(yi, pk);
+                    const double cc = lds.alphas[h] - bb;
+#pragma unroll
+                    for (int s = 0; s < PPL; ++s) pk[s] = __builtin_fma(cc, si[s], pk[s]);
+                }
+                TSF_WAVE_SYNC();
+                const double dF = __builtin_fabs(fk1 - fk);
+                const double fmaxv = __builtin_fmax(__builtin_fabs(fk1),
+                                                    __builtin_fmax(__builtin_fabs(fk), 1.0));
+                if (dF < sp->tol_obj) ret = TSF_ST_ABSF;
+                else if (dF < sp->tol_rel_obj * eps * fmaxv) ret = TSF_ST_RELF;
+                else if (gradNorm < sp->tol_grad) ret = TSF_ST_ABSGRAD;
+                else if (-pdot<PPL>(gk, pk) / __builtin_fmax(__builtin_fabs(fk), 1.0) < sp->tol_rel_grad * eps) ret = TSF_ST_RELGRAD;
+                else if (stepNorm < sp->tol_param) ret = TSF_ST_ABSX;
+                else if (itNum >= sp->max_iter) ret = TSF_ST_MAXIT;
+                else ret = 0;
+                if (ret != 0) break;
+                stage = ST_START_ITER;
+                continue;
+            }
+        }
+        // line search failed
+        if (resetB) { ret = TSF_ST_LSFAIL; break; }
+        resetB = 2;
+        stage = ST_START_LS;
+    }
+    store_theta<PPL>(a, sv, n, xk, a.theta);
+    if (lane == 0) { a.status[n] = ret; a.n_iter[n] = itNum; a.n_eval[n] = sv.n_eval; a.fval[n] = fk; }
+}
+
+}  // namespace tsf

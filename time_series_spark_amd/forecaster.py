@@ -1,0 +1,330 @@
+"""Batched panel API over the C-ABI: fit_aligned / fit_ragged / predict on numpy arrays.
+
+Stands where the reference calls fbprophet one series at a time
+(/root/reference/src/jobs/prophet_modeler.py:65-66, /root/reference/src/jobs/prophet_scorer.py:70)
+but takes the whole (series x timestamp x y) panel in one call.  The model options mirror
+fbprophet 0.5's ``Prophet.__init__`` / ``set_auto_seasonalities`` (spec in SURVEY.md 8a
+U1-U5); the arithmetic runs in libtsf_amd.so on the GPU -- this module only packs arrays.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+DAY_NS = 86400 * 10 ** 9
+
+
+class ModelSpec(object):
+    """Model + optimiser settings shared by all series of a call.
+
+    seasonalities: list of dicts {name, period (days), fourier_order, prior_scale, mode}.
+    extra: list of dicts {name, prior_scale, mode} for explicit design columns (holiday
+    indicators, regressors) whose values the caller supplies.
+    """
+
+    def __init__(self, growth='linear', seasonality_mode='additive', n_changepoints=25,
+                 changepoint_range=0.8, changepoint_prior_scale=0.05,
+                 seasonality_prior_scale=10.0, holidays_prior_scale=10.0,
+                 seasonalities=None, extra=None, **lbfgs):
+        if growth not in ('linear', 'logistic'):
+            raise ValueError("Parameter 'growth' should be 'linear' or 'logistic'.")
+        if seasonality_mode not in ('additive', 'multiplicative'):
+            raise ValueError("seasonality_mode must be 'additive' or 'multiplicative'")
+        if changepoint_range < 0 or changepoint_range > 1:
+            raise ValueError("Parameter 'changepoint_range' must be in [0, 1]")
+        self.growth = growth
+        self.seasonality_mode = seasonality_mode
+        self.n_changepoints = int(n_changepoints)
+        self.changepoint_range = float(changepoint_range)
+        self.changepoint_prior_scale = float(changepoint_prior_scale)
+        self.seasonality_prior_scale = float(seasonality_prior_scale)
+        self.holidays_prior_scale = float(holidays_prior_scale)
+        self.seasonalities = [dict(s) for s in (seasonalities or [])]
+        self.extra = [dict(e) for e in (extra or [])]
+        self.lbfgs = dict(lbfgs)
+        for k in self.lbfgs:
+            if k not in ('max_iter', 'history', 'init_alpha', 'tol_obj', 'tol_rel_obj',
+                         'tol_grad', 'tol_rel_grad', 'tol_param'):
+                raise TypeError('unknown L-BFGS option %r' % k)
+
+    # -- fbprophet set_auto_seasonalities on a timestamp vector --------------------------------
+    @staticmethod
+    def auto_seasonalities(ds_ns, yearly='auto', weekly='auto', daily='auto',
+                           seasonality_mode='additive', seasonality_prior_scale=10.0,
+                           user_seasonalities=()):
+        """Returns the seasonality list fbprophet 0.5 would build for history timestamps
+        ``ds_ns`` (int64 ns, sorted): yearly (365.25 d, order 10) off when span < 730 d;
+        weekly (7 d, order 3) off when span < 14 d or the smallest non-zero spacing >= 7 d;
+        daily (1 d, order 4) off when span < 2 d or the smallest spacing >= 1 d."""
+        ds_ns = np.asarray(ds_ns, dtype=np.int64)
+        first, last = int(ds_ns.min()), int(ds_ns.max())
+        diffs = np.diff(np.sort(ds_ns))
+        nz = diffs[diffs != 0]
+        min_dt = int(nz.min()) if nz.size else None
+        span = last - first
+        names = {s['name'] for s in user_seasonalities}
+
+        def order(name, arg, auto_disable, default):
+            if isinstance(arg, str) and arg == 'auto':
+                if name in names or auto_disable:
+                    return 0
+                return default
+            if arg is True:
+                return default
+            if arg is False:
+                return 0
+            return int(arg)
+
+        out = [dict(s) for s in user_seasonalities]
+        big = min_dt is None
+        fo = order('yearly', yearly, span < 730 * DAY_NS, 10)
+        if fo > 0:
+            out.append({'name': 'yearly', 'period': 365.25, 'fourier_order': fo,
+                        'prior_scale': seasonality_prior_scale, 'mode': seasonality_mode})
+        fo = order('weekly', weekly, (span < 14 * DAY_NS) or (not big and min_dt >= 7 * DAY_NS), 3)
+        if fo > 0:
+            out.append({'name': 'weekly', 'period': 7, 'fourier_order': fo,
+                        'prior_scale': seasonality_prior_scale, 'mode': seasonality_mode})
+        fo = order('daily', daily, (span < 2 * DAY_NS) or (not big and min_dt >= DAY_NS), 4)
+        if fo > 0:
+            out.append({'name': 'daily', 'period': 1, 'fourier_order': fo,
+                        'prior_scale': seasonality_prior_scale, 'mode': seasonality_mode})
+        return out
+
+    @property
+    def K(self):
+        return sum(2 * int(s['fourier_order']) for s in self.seasonalities) + len(self.extra)
+
+    @property
+    def theta_stride(self):
+        return 3 + self.n_changepoints + self.K
+
+    def to_c(self):
+        s = _lib.default_spec()
+        s.growth = _lib.GROWTH_LOGISTIC if self.growth == 'logistic' else _lib.GROWTH_LINEAR
+        s.n_changepoints = self.n_changepoints
+        s.changepoint_range = self.changepoint_range
+        s.changepoint_prior_scale = self.changepoint_prior_scale
+        if len(self.seasonalities) > _lib.MAX_SEAS or len(self.extra) > _lib.MAX_EXTRA:
+            raise ValueError('too many seasonalities (max %d) or extra columns (max %d)'
+                             % (_lib.MAX_SEAS, _lib.MAX_EXTRA))
+        s.n_seas = len(self.seasonalities)
+        for i, se in enumerate(self.seasonalities):
+            s.seas_period[i] = float(se['period'])
+            s.seas_order[i] = int(se['fourier_order'])
+            s.seas_prior_scale[i] = float(se.get('prior_scale', self.seasonality_prior_scale))
+            s.seas_mode[i] = int(se.get('mode', self.seasonality_mode) == 'multiplicative')
+        s.n_extra = len(self.extra)
+        for i, e in enumerate(self.extra):
+            s.extra_prior_scale[i] = float(e.get('prior_scale', self.holidays_prior_scale))
+            s.extra_mode[i] = int(e.get('mode', self.seasonality_mode) == 'multiplicative')
+        for k, v in self.lbfgs.items():
+            setattr(s, k, v)
+        return s
+
+    def to_dict(self):
+        return {'growth': self.growth, 'seasonality_mode': self.seasonality_mode,
+                'n_changepoints': self.n_changepoints, 'changepoint_range': self.changepoint_range,
+                'changepoint_prior_scale': self.changepoint_prior_scale,
+                'seasonality_prior_scale': self.seasonality_prior_scale,
+                'holidays_prior_scale': self.holidays_prior_scale,
+                'seasonalities': self.seasonalities, 'extra': self.extra, 'lbfgs': self.lbfgs}
+
+    @classmethod
+    def from_dict(cls, d):
+        d = dict(d)
+        lb = d.pop('lbfgs', {})
+        return cls(**d, **lb)
+
+
+class FitResult(object):
+    """Arrays returned by a fit: theta [N][stride], y_scale [N], fval [N], status [N],
+    n_iter [N], n_eval [N], grid (structured array, 1 or N entries)."""
+
+    def __init__(self, spec, theta, y_scale, fval, status, n_iter, n_eval, grid):
+        self.spec = spec
+        self.theta = theta
+        self.y_scale = y_scale
+        self.fval = fval
+        self.status = status
+        self.n_iter = n_iter
+        self.n_eval = n_eval
+        self.grid = grid
+
+    @property
+    def N(self):
+        return self.theta.shape[0]
+
+    def grid_of(self, n):
+        return self.grid[0 if len(self.grid) == 1 else n]
+
+
+_ctx_cache = {}
+
+
+def get_context(device=0):
+    c = _ctx_cache.get(device)
+    if c is None:
+        c = _lib.Context(device)
+        _ctx_cache[device] = c
+    return c
+
+
+def _opt_f64(a, N, name):
+    if a is None:
+        return None
+    a = np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float64), (N,)))
+    return a
+
+
+def _alloc_out(N, stride, n_grids):
+    theta = np.zeros((N, stride))
+    y_scale = np.zeros(N)
+    fval = np.zeros(N)
+    status = np.zeros(N, dtype=np.int32)
+    n_iter = np.zeros(N, dtype=np.int32)
+    n_eval = np.zeros(N, dtype=np.int32)
+    grid = np.zeros(n_grids, dtype=_lib.GRID_DTYPE)
+    out = _lib.TsfFitOut(theta.ctypes.data, y_scale.ctypes.data, fval.ctypes.data,
+                         status.ctypes.data, n_iter.ctypes.data, n_eval.ctypes.data,
+                         grid.ctypes.data)
+    return out, (theta, y_scale, fval, status, n_iter, n_eval, grid)
+
+
+def fit_aligned(spec, ds_ns, y, floor=None, cap=None, extra=None, ctx=None):
+    """Fit N series observed on the same T timestamps.  y: [N][T] float64/float32/int32."""
+    ctx = ctx or get_context()
+    L = _lib.load()
+    ds_ns = np.ascontiguousarray(ds_ns, dtype=np.int64)
+    y = np.ascontiguousarray(y)
+    if y.ndim != 2 or y.shape[1] != ds_ns.shape[0]:
+        raise ValueError('y must be [N][T] with T == len(ds)')
+    N, T = y.shape
+    cs = spec.to_c()
+    floor = _opt_f64(floor, N, 'floor')
+    cap = _opt_f64(cap, N, 'cap')
+    ex = None
+    if spec.extra:
+        ex = np.ascontiguousarray(extra, dtype=np.float64)
+        if ex.shape != (len(spec.extra), T):
+            raise ValueError('extra must be [n_extra][T]')
+    out, arrs = _alloc_out(N, spec.theta_stride, 1)
+    rc = L.tsf_fit_aligned(ctx.handle, ctypes.byref(cs), N, T, ds_ns.ctypes.data, y.ctypes.data,
+                           _lib.y_dtype_code(y), _lib._ptr(floor), _lib._ptr(cap), _lib._ptr(ex),
+                           ctypes.byref(out))
+    ctx.check(rc)
+    return FitResult(spec, *arrs)
+
+
+def fit_ragged(spec, offsets, ds_ns, y, floor=None, cap=None, extra=None, ctx=None):
+    """Fit N series of different lengths / timestamps; series n owns rows
+    offsets[n]:offsets[n+1] of ds_ns / y (each slice sorted by ds, NaN rows removed)."""
+    ctx = ctx or get_context()
+    L = _lib.load()
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    ds_ns = np.ascontiguousarray(ds_ns, dtype=np.int64)
+    y = np.ascontiguousarray(y)
+    N = len(offsets) - 1
+    if y.ndim != 1 or y.shape[0] != ds_ns.shape[0] or offsets[-1] != y.shape[0]:
+        raise ValueError('ds / y must be 1-D with offsets[-1] rows')
+    cs = spec.to_c()
+    floor = _opt_f64(floor, N, 'floor')
+    cap = _opt_f64(cap, N, 'cap')
+    ex = None
+    if spec.extra:
+        ex = np.ascontiguousarray(extra, dtype=np.float64)
+        if ex.shape != (len(spec.extra), y.shape[0]):
+            raise ValueError('extra must be [n_extra][total_rows]')
+    out, arrs = _alloc_out(N, spec.theta_stride, N)
+    rc = L.tsf_fit_ragged(ctx.handle, ctypes.byref(cs), N, offsets.ctypes.data, ds_ns.ctypes.data,
+                          y.ctypes.data, _lib.y_dtype_code(y), _lib._ptr(floor), _lib._ptr(cap),
+                          _lib._ptr(ex), ctypes.byref(out))
+    ctx.check(rc)
+    return FitResult(spec, *arrs)
+
+
+def predict(spec, theta, y_scale, grid, ds_future_ns, floor=None, cap=None, extra_future=None,
+            want_int=False, ctx=None):
+    """yhat [N][H] (float64) and, if want_int, the reference's int-truncated + floor-clamped
+    column (prophet_scorer.py:73-84).  ds_future_ns: [H] (shared) or [N][H]."""
+    ctx = ctx or get_context()
+    L = _lib.load()
+    theta = np.ascontiguousarray(theta, dtype=np.float64)
+    N = theta.shape[0]
+    y_scale = np.ascontiguousarray(y_scale, dtype=np.float64)
+    grid = np.ascontiguousarray(grid, dtype=_lib.GRID_DTYPE)
+    ds_future_ns = np.ascontiguousarray(ds_future_ns, dtype=np.int64)
+    shared = ds_future_ns.ndim == 1
+    H = ds_future_ns.shape[-1]
+    if not shared and ds_future_ns.shape != (N, H):
+        raise ValueError('ds_future must be [H] or [N][H]')
+    cs = spec.to_c()
+    floor = _opt_f64(floor, N, 'floor')
+    cap = _opt_f64(cap, N, 'cap')
+    ex = None
+    if spec.extra:
+        ex = np.ascontiguousarray(extra_future, dtype=np.float64)
+        want = (len(spec.extra), H) if shared else (N, len(spec.extra), H)
+        if ex.shape != want:
+            raise ValueError('extra_future must be %r' % (want,))
+    yhat = np.zeros((N, H))
+    yint = np.zeros((N, H), dtype=np.int32) if want_int else None
+    rc = L.tsf_predict(ctx.handle, ctypes.byref(cs), N, H, theta.ctypes.data, y_scale.ctypes.data,
+                       grid.ctypes.data, len(grid), ds_future_ns.ctypes.data, int(shared),
+                       _lib._ptr(floor), _lib._ptr(cap), _lib._ptr(ex), yhat.ctypes.data,
+                       _lib._ptr(yint))
+    ctx.check(rc)
+    return (yhat, yint) if want_int else yhat
+
+
+# ---- diagnostics used by the parity tests -----------------------------------------------------
+
+def eval_aligned(spec, ds_ns, y, theta, floor=None, cap=None, extra=None, ctx=None):
+    """-log posterior and gradient at theta [N][stride] for an aligned panel."""
+    ctx = ctx or get_context()
+    L = _lib.load()
+    ds_ns = np.ascontiguousarray(ds_ns, dtype=np.int64)
+    y = np.ascontiguousarray(y)
+    N, T = y.shape
+    theta = np.ascontiguousarray(theta, dtype=np.float64)
+    cs = spec.to_c()
+    floor = _opt_f64(floor, N, 'floor')
+    cap = _opt_f64(cap, N, 'cap')
+    ex = np.ascontiguousarray(extra, dtype=np.float64) if spec.extra else None
+    f = np.zeros(N)
+    g = np.zeros_like(theta)
+    rc = L.tsf_eval(ctx.handle, ctypes.byref(cs), N, T, ds_ns.ctypes.data, y.ctypes.data,
+                    _lib.y_dtype_code(y), _lib._ptr(floor), _lib._ptr(cap), _lib._ptr(ex),
+                    theta.ctypes.data, f.ctypes.data, g.ctypes.data)
+    ctx.check(rc)
+    return f, g
+
+
+def design(spec, ds_ns, extra=None, ctx=None):
+    """Design matrix X [T][K], scaled time t [T] and the grid info, as the device builds them."""
+    ctx = ctx or get_context()
+    L = _lib.load()
+    ds_ns = np.ascontiguousarray(ds_ns, dtype=np.int64)
+    T = len(ds_ns)
+    cs = spec.to_c()
+    ex = np.ascontiguousarray(extra, dtype=np.float64) if spec.extra else None
+    X = np.zeros((T, spec.K))
+    t = np.zeros(T)
+    grid = np.zeros(1, dtype=_lib.GRID_DTYPE)
+    rc = L.tsf_design(ctx.handle, ctypes.byref(cs), T, ds_ns.ctypes.data, _lib._ptr(ex),
+                      X.ctypes.data, t.ctypes.data, grid.ctypes.data)
+    ctx.check(rc)
+    return X, t, grid
+
+
+def selftest_math(op, a, b=None, ctx=None):
+    ctx = ctx or get_context()
+    L = _lib.load()
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = None if b is None else np.ascontiguousarray(b, dtype=np.float64)
+    out = np.zeros_like(a)
+    rc = L.tsf_selftest_math(ctx.handle, int(op), a.size, a.ctypes.data, _lib._ptr(b),
+                             out.ctypes.data)
+    ctx.check(rc)
+    return out
