@@ -186,6 +186,17 @@ int tsf_design(tsf_ctx *ctx, const tsf_spec *spec, int32_t T, const int64_t *ds,
 int tsf_selftest_math(tsf_ctx *ctx, int32_t op, int64_t n, const double *a, const double *b,
                       double *out);
 
+/* ---- measurement hooks ------------------------------------------------------------------
+ * With profiling enabled every tsf_fit_*_dev call records a pair of HIP events on ITS stream
+ * right before and after the fit kernel (the dominant kernel of the path); up to
+ * TSF_PROFILE_RING calls are kept.  tsf_profile_read waits for the recorded events and
+ * returns the kernel durations (milliseconds, oldest first) of the calls made since
+ * profiling was last (re-)enabled; tsf_last_fit_kernel_ms returns the newest one. */
+#define TSF_PROFILE_RING 64
+int tsf_set_profiling(tsf_ctx *ctx, int32_t enable);
+int tsf_profile_read(tsf_ctx *ctx, float *ms_out, int32_t max_n, int32_t *n_out);
+int tsf_last_fit_kernel_ms(tsf_ctx *ctx, float *ms_out);
+
 #ifdef __cplusplus
 }
 #endif

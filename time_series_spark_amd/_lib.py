@@ -68,7 +68,8 @@ class TsfFitOut(ctypes.Structure):
 EXPORTS = ['tsf_create', 'tsf_destroy', 'tsf_last_error', 'tsf_device_count', 'tsf_spec_default',
            'tsf_spec_size', 'tsf_grid_info_size', 'tsf_spec_K', 'tsf_theta_stride',
            'tsf_fit_aligned', 'tsf_fit_aligned_dev', 'tsf_fit_ragged', 'tsf_fit_ragged_dev',
-           'tsf_predict', 'tsf_predict_dev', 'tsf_eval', 'tsf_design', 'tsf_selftest_math']
+           'tsf_predict', 'tsf_predict_dev', 'tsf_eval', 'tsf_design', 'tsf_selftest_math',
+           'tsf_set_profiling', 'tsf_profile_read', 'tsf_last_fit_kernel_ms']
 
 _lib = None
 
@@ -112,6 +113,9 @@ def load():
     L.tsf_eval.argtypes = [vp, psp, i64, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp]
     L.tsf_design.argtypes = [vp, psp, i32, vp, vp, vp, vp, vp]
     L.tsf_selftest_math.argtypes = [vp, i32, i64, vp, vp, vp]
+    L.tsf_set_profiling.argtypes = [vp, i32]
+    L.tsf_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_float), i32, ctypes.POINTER(i32)]
+    L.tsf_last_fit_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
     if L.tsf_spec_size() != ctypes.sizeof(TsfSpec):
         raise TsfError('tsf_spec layout mismatch between _lib.py and libtsf_amd.so')
     if L.tsf_grid_info_size() != ctypes.sizeof(TsfGridInfo) or GRID_DTYPE.itemsize != ctypes.sizeof(TsfGridInfo):

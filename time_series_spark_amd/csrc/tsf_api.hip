@@ -26,6 +26,10 @@ struct tsf_ctx {
     void *ws;
     size_t ws_bytes;
     DevSpec *d_spec;
+    int profiling;
+    hipEvent_t ev0[TSF_PROFILE_RING], ev1[TSF_PROFILE_RING];
+    int ev_created;
+    long ev_count;          // profiled calls since profiling was enabled
 };
 
 #define HIP_TRY(ctx, expr)                                                                   \
@@ -59,6 +63,7 @@ extern "C" int tsf_create(int device_id, tsf_ctx **out)
     if (hipSetDevice(device_id) != hipSuccess) return -2;
     tsf_ctx *c = new tsf_ctx();
     c->device = device_id; c->ws = nullptr; c->ws_bytes = 0; c->d_spec = nullptr;
+    c->profiling = 0; c->ev_created = 0; c->ev_count = 0;
     if (hipMalloc((void **)&c->d_spec, sizeof(DevSpec)) != hipSuccess) { delete c; return -2; }
     *out = c;
     return 0;
@@ -70,6 +75,8 @@ extern "C" void tsf_destroy(tsf_ctx *ctx)
     hipSetDevice(ctx->device);
     if (ctx->ws) hipFree(ctx->ws);
     if (ctx->d_spec) hipFree(ctx->d_spec);
+    if (ctx->ev_created)
+        for (int i = 0; i < TSF_PROFILE_RING; ++i) { hipEventDestroy(ctx->ev0[i]); hipEventDestroy(ctx->ev1[i]); }
     delete ctx;
 }
 
@@ -249,7 +256,10 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     a.theta = out->theta; a.y_scale = out->y_scale; a.fval = out->fval; a.status = out->status;
     a.n_iter = out->n_iter; a.n_eval = out->n_eval; a.grid_out = out->grid;
     a.theta_in = theta_in; a.grad_out = grad_out;
+    const int slot = (int)(ctx->ev_count % TSF_PROFILE_RING);
+    if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev0[slot], st));
     const int lrc = pick_launch(hs.growth, mode)(hs.KP, a, theta_in != nullptr, st);
+    if (ctx->profiling) { HIP_TRY(ctx, hipEventRecord(ctx->ev1[slot], st)); ctx->ev_count++; }
     if (lrc != 0) {
         ctx->err = std::string("kernel launch failed: ") + (lrc > 0 ? hipGetErrorString((hipError_t)lrc) : "no kernel for this shape");
         return -2;
@@ -559,5 +569,52 @@ extern "C" int tsf_selftest_math(tsf_ctx *ctx, int32_t op, int64_t n, const doub
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipDeviceSynchronize());
     HIP_TRY(ctx, hipMemcpy(out, dout.p, 8 * n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---- measurement hooks --------------------------------------------------------------------------
+
+extern "C" int tsf_set_profiling(tsf_ctx *ctx, int32_t enable)
+{
+    if (!ctx) return -1;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (enable && !ctx->ev_created) {
+        for (int i = 0; i < TSF_PROFILE_RING; ++i) {
+            HIP_TRY(ctx, hipEventCreate(&ctx->ev0[i]));
+            HIP_TRY(ctx, hipEventCreate(&ctx->ev1[i]));
+        }
+        ctx->ev_created = 1;
+    }
+    ctx->profiling = enable ? 1 : 0;
+    ctx->ev_count = 0;
+    return 0;
+}
+
+extern "C" int tsf_profile_read(tsf_ctx *ctx, float *ms_out, int32_t max_n, int32_t *n_out)
+{
+    if (!ctx) return -1;
+    if (!ms_out || !n_out) return fail(ctx, "NULL output");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    long n = ctx->ev_count < TSF_PROFILE_RING ? ctx->ev_count : TSF_PROFILE_RING;
+    if (n > max_n) n = max_n;
+    const long first = ctx->ev_count - n;
+    for (long i = 0; i < n; ++i) {
+        const int slot = (int)((first + i) % TSF_PROFILE_RING);
+        HIP_TRY(ctx, hipEventSynchronize(ctx->ev1[slot]));
+        HIP_TRY(ctx, hipEventElapsedTime(&ms_out[i], ctx->ev0[slot], ctx->ev1[slot]));
+    }
+    *n_out = (int32_t)n;
+    return 0;
+}
+
+extern "C" int tsf_last_fit_kernel_ms(tsf_ctx *ctx, float *ms_out)
+{
+    if (!ctx) return -1;
+    if (!ms_out || ctx->ev_count == 0) return fail(ctx, "no profiled fit call recorded");
+    int32_t n = 0;
+    float tmp[TSF_PROFILE_RING];
+    int rc = tsf_profile_read(ctx, tmp, TSF_PROFILE_RING, &n);
+    if (rc) return rc;
+    *ms_out = tmp[n - 1];
     return 0;
 }
