@@ -1,0 +1,52 @@
+"""World-size-2 CPU test of the multi-GPU plumbing (gloo): contiguous shard-by-id partition,
+max-over-ranks step time, gather of per-rank results in series order.  The data path itself has
+no collective (series are independent), so there is nothing else to exercise."""
+import os
+import socket
+
+import numpy as np
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_items, q):
+    os.environ.update({'RANK': str(rank), 'WORLD_SIZE': str(world), 'LOCAL_RANK': str(rank),
+                       'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port)})
+    import torch.distributed as dist
+    from time_series_spark_amd import parallel
+    r, w, _ = parallel.init_process_group(backend='gloo')
+    lo, hi = parallel.shard_bounds(n_items, r, w)
+    # stand-in for the per-rank fit: row i -> [i, 2i]
+    local = np.stack([np.arange(lo, hi, dtype=np.float64), 2.0 * np.arange(lo, hi)], axis=1)
+    parallel.barrier()
+    t = parallel.max_over_ranks(1.0 + r)
+    tot = parallel.sum_over_ranks(hi - lo)
+    allrows = parallel.gather_rows(local)
+    q.put((r, lo, hi, t, tot, allrows))
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_and_gather():
+    world, n_items = 2, 11
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_items, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [(r[1], r[2]) for r in res] == [(0, 6), (6, 11)]
+    for r in res:
+        assert r[3] == 2.0                       # max over ranks of (1 + rank)
+        assert r[4] == n_items
+        assert np.array_equal(r[5][:, 0], np.arange(n_items)) and np.array_equal(r[5][:, 1], 2.0 * np.arange(n_items))

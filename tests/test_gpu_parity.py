@@ -1,0 +1,260 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X): the HIP path, called through the C-ABI,
+against the canonical CPU oracle on the same seeded inputs and against the committed golden
+vectors.  Bar: floating-point forecasts within the north-star 1e-4 relative tolerance
+(BASELINE.json); because product and oracle share one canonical arithmetic the tests also
+assert the much sharper "identical bits" wherever both are run.  Parity is vs the restated
+oracle, NOT real fbprophet (parity unpinned, see oracle/ headers)."""
+import numpy as np
+import pandas as pd
+import pytest
+
+from tests import helpers
+from tests.helpers import n_bit_diff
+
+pytestmark = pytest.mark.gpu
+REL_TOL = 1e-4          # BASELINE.json north_star
+
+
+@pytest.fixture(scope='module')
+def env(built):
+    from time_series_spark_amd import _lib, forecaster as fc
+    if _lib.load().tsf_device_count() < 1:
+        pytest.fail('no GPU visible: GPU parity tests cannot run (product has no CPU fallback)')
+    from oracle import canon_lib as cl
+    cl.lib()
+    return fc, cl
+
+
+def test_device_arithmetic_is_ieee_and_detmath_matches(env):
+    fc, cl = env
+    import ctypes
+    L = cl.lib()
+    rng = np.random.default_rng(0)
+    n = 100000
+    a = rng.normal(0, 1, n) * np.exp(rng.uniform(-30, 30, n))
+    b = rng.normal(0, 1, n) * np.exp(rng.uniform(-30, 30, n))
+    assert n_bit_diff(fc.selftest_math(0, a, b), a / b) == 0
+    assert n_bit_diff(fc.selftest_math(1, np.abs(a)), np.sqrt(np.abs(a))) == 0
+    x = rng.uniform(-60, 60, 5000)
+    assert n_bit_diff(fc.selftest_math(2, x), [L.cn_det_exp(v) for v in x]) == 0
+    x = np.exp(rng.uniform(-30, 30, 5000))
+    assert n_bit_diff(fc.selftest_math(3, x), [L.cn_det_log(v) for v in x]) == 0
+    x = rng.uniform(-5000, 5000, 5000)
+    s, c = ctypes.c_double(), ctypes.c_double()
+    S, C = [], []
+    for v in x:
+        L.cn_det_sincos(v, ctypes.byref(s), ctypes.byref(c))
+        S.append(s.value)
+        C.append(c.value)
+    assert n_bit_diff(fc.selftest_math(4, x), S) == 0 and n_bit_diff(fc.selftest_math(5, x), C) == 0
+
+
+@pytest.mark.parametrize('case', list(helpers.CASES))
+def test_design_and_single_evaluation(env, case):
+    fc, cl = env
+    spec, ds, y, floor, cap, extra, fut, exf = helpers.make_case(case)
+    csp = helpers.oracle_spec(spec)
+    X, t, grid = fc.design(spec, ds, extra)
+    des = cl.design(csp, ds, y[0], floor[0], cap[0], extra)
+    assert n_bit_diff(X, des['X']) == 0 and n_bit_diff(t, des['t']) == 0
+    assert grid['S'][0] == des['info'].S
+    assert n_bit_diff(grid['t_change'][0][:des['info'].S], des['t_change']) == 0
+    N = y.shape[0]
+    rng = np.random.default_rng(5)
+    th = np.zeros((N, spec.theta_stride))
+    for n in range(N):
+        d = cl.design(csp, ds, y[n], floor[n], cap[n], extra)
+        th[n, 0], th[n, 1] = d['k0'], d['m0']
+    th += rng.normal(0, 0.01, th.shape)
+    f, g = fc.eval_aligned(spec, ds, y, th, floor=floor, cap=cap, extra=extra)
+    for n in range(N):
+        fo, go, rc = cl.eval_at(csp, ds, y[n], th[n], floor[n], cap[n], extra)
+        assert abs(f[n] - fo) <= 1e-12 * abs(fo)
+        assert np.max(np.abs(g[n] - go) / (1 + np.abs(go))) <= 1e-11
+        assert n_bit_diff(f[n], fo) == 0 and n_bit_diff(g[n], go) == 0
+
+
+@pytest.mark.parametrize('case', list(helpers.CASES))
+def test_fit_predict_against_oracle_and_golden(env, case):
+    fc, cl = env
+    spec, ds, y, floor, cap, extra, fut, exf = helpers.make_case(case)
+    csp = helpers.oracle_spec(spec)
+    g = np.load(helpers.GOLDEN + '/synthetic_cases.npz')
+    r = fc.fit_aligned(spec, ds, y, floor=floor, cap=cap, extra=extra)
+    yhat, yint = fc.predict(spec, r.theta, r.y_scale, r.grid, fut, floor=floor, cap=cap,
+                            extra_future=exf, want_int=True)
+    # committed golden vectors (oracle outputs generated in the build container)
+    assert np.array_equal(r.n_iter, g[case + '/n_iter']) and np.array_equal(r.status, g[case + '/status'])
+    assert np.max(np.abs(yhat - g[case + '/yhat']) / np.abs(g[case + '/yhat'])) <= REL_TOL
+    assert np.array_equal(yhat, g[case + '/yhat'])
+    assert np.array_equal(r.theta, g[case + '/theta'])
+    # live oracle on the same inputs
+    for n in range(y.shape[0]):
+        o = cl.fit(csp, ds, y[n], floor[n], cap[n], extra)
+        yo, _ = cl.predict(csp, o, fut, floor[n], cap[n], exf)
+        assert r.n_eval[n] == o['n_eval'] and n_bit_diff(r.fval[n], o['f']) == 0
+        assert np.max(np.abs(yhat[n] - yo) / np.abs(yo)) <= REL_TOL
+    # the reference's post-step: int truncation, clamp to floor (prophet_scorer.py:73-84)
+    assert np.array_equal(yint, np.maximum(np.trunc(yhat), floor[:, None]).astype(np.int32))
+
+
+def test_truncated_trajectories_match(env):
+    """Same iterate after 1, 3, 10, 40 L-BFGS iterations: checks line search, two-loop
+    recursion and the history ring step by step rather than only at the end."""
+    fc, cl = env
+    for case in ('cfg2_linear_additive', 'ref_logistic_multiplicative'):
+        spec0, ds, y, floor, cap, extra, fut, exf = helpers.make_case(case)
+        for mi in (1, 3, 10, 40):
+            spec = fc.ModelSpec.from_dict(dict(spec0.to_dict(), lbfgs={'max_iter': mi}))
+            csp = helpers.oracle_spec(spec)
+            r = fc.fit_aligned(spec, ds, y, floor=floor, cap=cap)
+            for n in range(y.shape[0]):
+                o = cl.fit(csp, ds, y[n], floor[n], cap[n])
+                S = o['info'].S
+                assert r.n_iter[n] == o['n_iter'] and r.n_eval[n] == o['n_eval']
+                assert n_bit_diff(r.theta[n][:3 + S], o['theta'][:3 + S]) == 0
+
+
+def test_reference_fixture_ragged_irregular_timestamps(env):
+    """The reference's own fixture (two dim_ids, 410/406 rows, Thu-Sun 11:15/21:45 observations,
+    four duplicate timestamps) with the reference's settings, through the ragged entry point;
+    golden = canonical oracle outputs committed in tests/golden/fixture_751.npz."""
+    fc, cl = env
+    from time_series_spark_amd import panel as pk
+    g = np.load(helpers.GOLDEN + '/fixture_751.npz')
+    df = pd.DataFrame({'series_id': 751, 'dim_id': g['raw_dim_id'],
+                       'ds': g['raw_ds_ns'].astype('datetime64[ns]'), 'y': g['raw_y']})
+    p = pk.pack_long_frame(df)
+    span, min_dt, ymax = pk.per_series_stats(p)
+    seas = fc.ModelSpec.auto_from_stats(int(span[0]), int(min_dt[0]), seasonality_mode='multiplicative')
+    spec = fc.ModelSpec(growth='logistic', seasonality_mode='multiplicative', seasonalities=seas)
+    cap = ymax * 1.1
+    r = fc.fit_ragged(spec, p.offsets, p.ds_ns, p.y, floor=np.zeros(2), cap=cap)
+    assert np.array_equal(r.n_iter, g['n_iter']) and np.array_equal(r.status, g['status'])
+    assert np.array_equal(r.theta, g['theta'])
+    yhat = fc.predict(spec, r.theta, r.y_scale, r.grid, g['fut'], floor=np.zeros(2, dtype=np.float32).astype(np.float64),
+                      cap=cap.astype(np.float32).astype(np.float64))
+    assert np.max(np.abs(yhat - g['yhat']) / np.abs(g['yhat'])) <= REL_TOL
+    assert np.array_equal(yhat, g['yhat'])
+
+
+def test_edge_cases(env):
+    fc, cl = env
+    from time_series_spark_amd import _lib
+    spec, ds, y, floor, cap, extra, fut, exf = helpers.make_case('cfg2_linear_additive')
+    csp = helpers.oracle_spec(spec)
+    yy = y.copy()
+    yy[0] = 7.0                                   # constant series, linear growth
+    r = fc.fit_aligned(spec, ds, yy)
+    assert r.status[0] == _lib.ST_CONSTANT and r.n_iter[0] == 0
+    o = cl.fit(csp, ds, yy[0])
+    assert np.array_equal(r.theta[0], np.concatenate([o['theta'][:3 + 25], o['theta'][28:]]))
+    yh = fc.predict(spec, r.theta, r.y_scale, r.grid, fut)
+    assert np.allclose(yh[0], 7.0)
+    # int32 / float32 inputs give the same fit as float64 (values are integers)
+    r64 = fc.fit_aligned(spec, ds, y)
+    r32 = fc.fit_aligned(spec, ds, y.astype(np.int32))
+    rf32 = fc.fit_aligned(spec, ds, y.astype(np.float32))
+    assert np.array_equal(r64.theta, r32.theta) and np.array_equal(r64.theta, rf32.theta)
+    # cap <= floor is reported per series (fbprophet raises ValueError)
+    lspec = helpers.make_case('ref_logistic_multiplicative')[0]
+    capbad = cap.copy()
+    capbad[2] = -1.0
+    rl = fc.fit_aligned(lspec, ds, y, floor=floor, cap=capbad)
+    assert rl.status[2] == _lib.ST_CAP and (rl.status[[0, 1, 3]] > 0).all()
+    # ragged: one-row series -> TOO_FEW; short series -> fewer changepoints; duplicates fine
+    off = np.array([0, 1, 21, 21 + 90, 21 + 90 + 730], dtype=np.int64)
+    dsr = np.concatenate([ds[:1], ds[:20], np.sort(np.concatenate([ds[:88], ds[10:12]])), ds])
+    yr = np.concatenate([y[0][:1], y[0][:20], y[1][:90], y[2]])
+    sp90 = helpers.make_case('short_90')[0]
+    rr = fc.fit_ragged(sp90, off, dsr, yr)
+    assert rr.status[0] == _lib.ST_TOO_FEW and (rr.status[1:] > 0).all()
+    assert list(rr.grid['S']) == [0, 15, 25, 25]
+    c90 = helpers.oracle_spec(sp90)
+    for n in (1, 2, 3):
+        o = cl.fit(c90, dsr[off[n]:off[n + 1]], yr[off[n]:off[n + 1]])
+        S = o['info'].S
+        assert rr.n_iter[n] == o['n_iter']
+        assert n_bit_diff(rr.theta[n][:3 + S], o['theta'][:3 + S]) == 0
+        assert n_bit_diff(rr.theta[n][28:], o['theta'][3 + S:]) == 0
+
+
+def test_full_size_panel_properties(env):
+    """BASELINE config 2 at full size (10 000 x 730): size-independent properties --
+    every series terminates normally, forecasts finite, doubling y doubles the forecast
+    exactly (power-of-two scaling leaves the scaled problem bit-identical), and a random
+    sample agrees with the oracle."""
+    fc, cl = env
+    from time_series_spark_amd import synth
+    N, T, H = 10000, 730, 90
+    spec = helpers.make_case('cfg2_linear_additive')[0]
+    ds, y = synth.make_panel(N, T, 'linear', seed=751)
+    fut = ds[-1] + helpers.DAY_NS * np.arange(1, H + 1)
+    r = fc.fit_aligned(spec, ds, y)
+    assert (r.status > 0).all() and (r.n_iter >= 1).all()
+    yh = fc.predict(spec, r.theta, r.y_scale, r.grid, fut)
+    assert np.isfinite(yh).all()
+    sub = np.arange(0, N, 97)
+    r2 = fc.fit_aligned(spec, ds, 2.0 * y[sub])
+    assert np.array_equal(r2.theta, r.theta[sub])
+    yh2 = fc.predict(spec, r2.theta, r2.y_scale, r2.grid, fut)
+    assert np.array_equal(yh2, 2.0 * yh[sub])
+    csp = helpers.oracle_spec(spec)
+    for n in np.random.default_rng(0).choice(N, 12, replace=False):
+        o = cl.fit(csp, ds, y[n])
+        yo, _ = cl.predict(csp, o, fut)
+        assert r.n_iter[n] == o['n_iter']
+        assert np.max(np.abs(yh[n] - yo) / np.abs(yo)) <= REL_TOL
+
+
+def test_reference_contract_fit_and_forecast_udfs(env, tmp_path):
+    """/root/reference/tests/unit/prophet_modeler_test.py:59-75 and
+    prophet_scorer_test.py:83-114 re-expressed on pandas: 2 model rows with the reference's
+    columns, parquet round trip, 40 forecasts per series / 80 rows, CSV with 6 named columns."""
+    from time_series_spark_amd.jobs import prophet_modeler as pm, prophet_scorer as ps
+    g = np.load(helpers.GOLDEN + '/fixture_751.npz')
+    d = tmp_path / 'model-input' / 'series_id=751'
+    d.mkdir(parents=True)
+    pd.DataFrame({'dim_id': g['raw_dim_id'],
+                  'ds': pd.Series(g['raw_ds_ns'].astype('datetime64[ns]')).dt.strftime('%Y-%m-%d %H:%M:%S'),
+                  'y': g['raw_y']}).to_csv(d / 'sample-model-input.csv', header=False, index=False)
+    mconfig = {'io': {'input': str(tmp_path / 'model-input'), 'models': str(tmp_path / 'models')},
+               'model': {'floor': 0, 'cap_multiplier': 1.1}}
+    modeler = pm.ProphetModeler(mconfig)
+    input_df = modeler.read_input_dataframe(None)
+    udf = pm.model_time_series(mconfig)
+    output_df = pd.concat([udf(grp.copy()) for _, grp in input_df.groupby(['series_id', 'dim_id'])],
+                          ignore_index=True)
+    assert len(output_df) == 2
+    assert list(output_df.columns) == ['series_id', 'dim_id', 'floor', 'cap', 'model']
+    assert len(output_df.query('series_id == 751 and dim_id == 91')) == 1
+    assert len(output_df.query('series_id == 751 and dim_id == 155')) == 1
+    modeler.persist_models(output_df)
+    sconfig = {'io': {'models': str(tmp_path / 'models'), 'forecasts': str(tmp_path / 'forecasts')},
+               'forecast': {'periods': 40, 'frequency': '15min'}}
+    scorer = ps.ProphetScorer(sconfig)
+    model_df = scorer.read_model_dataframe(None)
+    assert list(model_df.columns) == ['series_id', 'dim_id', 'floor', 'cap', 'model']
+    assert len(model_df) == 2 and model_df['series_id'].nunique() == 1 and model_df['dim_id'].nunique() == 2
+    assert str(model_df['floor'].dtype) == 'float32' and str(model_df['cap'].dtype) == 'float32'
+    fudf = ps.forecast_time_series(sconfig)
+    fdf = pd.concat([fudf(grp) for _, grp in model_df.groupby(['series_id', 'dim_id'])], ignore_index=True)
+    assert len(fdf) == 80 and list(fdf.columns) == ['series_id', 'dim_id', 'ds', 'yhat']
+    assert len(fdf.query('series_id == 751 and dim_id == 91')) == 40
+    assert len(fdf.query('series_id == 751 and dim_id == 155')) == 40
+    assert str(fdf['yhat'].dtype) == 'int32'
+    # numbers: the golden oracle forecasts, int-truncated as prophet_scorer.py:73 does
+    for j, dim in enumerate(g['dim_ids']):
+        got = fdf[fdf['dim_id'] == dim]['yhat'].values
+        assert np.array_equal(got, np.trunc(g['yhat'][j]).astype(np.int32))
+    scorer.write_forecasts(scorer.convert_forecasts(fdf))
+    import glob
+    back = pd.concat([pd.read_csv(f) for f in glob.glob(str(tmp_path / 'forecasts' / '*.csv'))])
+    assert list(back.columns) == ['created_timestamp', 'series_id', 'dim_id', 'forecast_date',
+                                  'forecast_timestamp', 'forecast_quantity']
+    assert len(back) == 80
+    # the batched job entry points give the same rows as the per-group UDF calls
+    both = pm.ProphetModeler.model(None, mconfig)
+    assert len(both) == 2
+    conv = ps.ProphetScorer.score(None, sconfig)
+    assert len(conv) == 80 and np.array_equal(np.sort(conv['forecast_quantity'].values), np.sort(fdf['yhat'].values))

@@ -1,0 +1,175 @@
+"""CPU tests of the host layer: panel packing, fbprophet's auto-seasonality rules, model blob,
+future frames, the reference's exact-value conversion test re-expressed without Spark
+(/root/reference/tests/unit/prophet_scorer_test.py:70-80), CSV/parquet IO, and that the C-ABI
+library loads and exports every symbol include/tsf.h declares (no compute: no GPU here)."""
+import ctypes
+import os
+import re
+from datetime import datetime
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from tests import helpers
+from time_series_spark_amd import _lib, forecaster as fc, panel as pk, parallel
+from time_series_spark_amd.jobs import prophet_modeler as pm, prophet_scorer as ps
+
+
+def test_library_loads_and_exports_every_declared_symbol(built):
+    L = _lib.load()
+    hdr = open(os.path.join(helpers.ROOT, 'include', 'tsf.h')).read()
+    declared = set(re.findall(r'\b(tsf_[a-z_A-Z0-9]+)\s*\(', hdr))
+    assert declared == set(_lib.EXPORTS)
+    for sym in declared:
+        assert hasattr(L, sym), sym
+    assert L.tsf_spec_size() == ctypes.sizeof(_lib.TsfSpec)
+    s = _lib.default_spec()
+    assert (s.n_changepoints, s.history, s.max_iter) == (25, 5, 10000)
+    assert s.changepoint_range == 0.8 and s.changepoint_prior_scale == 0.05
+    assert (s.init_alpha, s.tol_obj, s.tol_rel_obj, s.tol_grad, s.tol_rel_grad, s.tol_param) == \
+        (1e-3, 1e-12, 1e4, 1e-8, 1e7, 1e-8)
+
+
+def test_no_cpu_fallback(built):
+    # on a box without a GPU the product path must fail loudly, not fall back
+    if _lib.load().tsf_device_count() > 0:
+        pytest.skip('GPU present')
+    with pytest.raises(_lib.TsfError):
+        _lib.Context(0)
+
+
+def test_pack_long_frame_sorts_drops_nan_keeps_duplicates():
+    df = pd.DataFrame({
+        'series_id': [1, 1, 1, 1, 2, 2, 1],
+        'dim_id': [5, 5, 5, 5, 5, 5, 4],
+        'ds': pd.to_datetime(['2020-01-03', '2020-01-01', '2020-01-02', '2020-01-02',
+                              '2020-01-01', '2020-01-02', '2020-01-01']),
+        'y': [3.0, 1.0, np.nan, 2.5, 10.0, 11.0, 7.0]})
+    p = pk.pack_long_frame(df)
+    assert p.N == 3
+    assert list(p.keys['series_id']) == [1, 1, 2] and list(p.keys['dim_id']) == [4, 5, 5]
+    assert list(p.offsets) == [0, 1, 4, 6]
+    assert list(p.y) == [7.0, 1.0, 2.5, 3.0, 10.0, 11.0]
+    assert not p.aligned
+    df2 = pd.DataFrame({'series_id': [1] * 3 + [2] * 3, 'dim_id': 0,
+                        'ds': list(pd.date_range('2020-01-01', periods=3)) * 2, 'y': np.arange(6.0)})
+    p2 = pk.pack_long_frame(df2)
+    assert p2.aligned and p2.y2d.shape == (2, 3)
+    with pytest.raises(ValueError):
+        pk.pack_long_frame(pd.DataFrame({'series_id': [1], 'dim_id': [1],
+                                         'ds': pd.to_datetime(['2020-01-01']), 'y': [np.inf]}))
+
+
+def test_auto_seasonality_rules():
+    day = fc.DAY_NS
+    names = lambda s: [x['name'] for x in s]
+    assert names(fc.ModelSpec.auto_seasonalities(day * np.arange(730))) == ['weekly']      # F8
+    assert names(fc.ModelSpec.auto_seasonalities(day * np.arange(731))) == ['yearly', 'weekly']
+    assert names(fc.ModelSpec.auto_seasonalities(day * np.arange(731), yearly=False)) == ['weekly']
+    assert names(fc.ModelSpec.auto_seasonalities(day * np.arange(90))) == ['weekly']
+    assert names(fc.ModelSpec.auto_seasonalities(7 * day * np.arange(200))) == ['yearly']
+    hourly = (day // 24) * np.arange(24 * 20)
+    assert names(fc.ModelSpec.auto_seasonalities(hourly)) == ['weekly', 'daily']
+    assert names(fc.ModelSpec.auto_seasonalities(day * np.arange(730), yearly=True)) == ['yearly', 'weekly']
+    s = fc.ModelSpec.auto_seasonalities(day * np.arange(800))
+    assert [(x['period'], x['fourier_order']) for x in s] == [(365.25, 10), (7, 3)]
+    # the reference fixture: Thu-Sun 11:15 / 21:45 observations -> weekly + daily
+    g = np.load(helpers.GOLDEN + '/fixture_751.npz')
+    df = pd.DataFrame({'series_id': 751, 'dim_id': g['raw_dim_id'],
+                       'ds': g['raw_ds_ns'].astype('datetime64[ns]'), 'y': g['raw_y']})
+    p = pk.pack_long_frame(df)
+    assert list(p.lengths) == [410, 406]
+    span, min_dt, ymax = pk.per_series_stats(p)
+    assert names(fc.ModelSpec.auto_from_stats(int(span[0]), int(min_dt[0]))) == ['weekly', 'daily']
+    assert np.allclose(ymax * 1.1, [103591.4, 140054.2])
+
+
+def test_model_blob_roundtrip():
+    spec = fc.ModelSpec(growth='logistic', seasonality_mode='multiplicative',
+                        seasonalities=[dict(helpers.WEEKLY)], tol_grad=1e-9)
+    grid = np.zeros(1, dtype=_lib.GRID_DTYPE)
+    grid[0]['start_ns'] = 123; grid[0]['t_scale_ns'] = 456; grid[0]['T'] = 100; grid[0]['S'] = 25
+    grid[0]['t_change'][:25] = np.linspace(0.03, 0.8, 25)
+    theta = np.arange(34.0)
+    b = pk.dump_model(spec.to_dict(), theta, 2.5, grid[0], 999, 31, 77)
+    m = pk.load_model(b)
+    assert np.array_equal(m['theta'], theta) and m['y_scale'] == 2.5 and m['last_ds_ns'] == 999
+    assert np.array_equal(m['t_change'], grid[0]['t_change'][:25])
+    s2 = fc.ModelSpec.from_dict(m['spec'])
+    assert s2.to_dict() == spec.to_dict() and s2.lbfgs == {'tol_grad': 1e-9}
+    assert pk.load_model(None) is None
+    with pytest.raises(ValueError):
+        pk.load_model(b'nope' + b[4:])
+    g2 = pk.grid_from_models([m])
+    assert g2[0]['S'] == 25 and g2[0]['start_ns'] == 123
+
+
+def test_future_dates_match_make_future_dataframe():
+    last = pd.Timestamp('2002-12-28 21:45:00').value
+    f = pk.future_dates([last], 40, '15min')[0].astype('datetime64[ns]')
+    assert f[0] == np.datetime64('2002-12-28T22:00:00') and len(f) == 40
+    assert f[-1] == np.datetime64('2002-12-28T22:00:00') + np.timedelta64(39 * 15, 'm')
+    # 'W' would snap to Sundays; the reference substitutes pd.offsets.Week() (prophet_scorer.py:59-62)
+    sat = pd.Timestamp('2002-12-28').value
+    w = pk.future_dates([sat], 2, pd.offsets.Week())[0].astype('datetime64[ns]')
+    assert list(w) == [np.datetime64('2003-01-04'), np.datetime64('2003-01-11')]
+    d = pk.future_dates([sat], 3, 'D')[0].astype('datetime64[ns]').astype('datetime64[D]')
+    assert list(d) == [np.datetime64('2002-12-29'), np.datetime64('2002-12-30'), np.datetime64('2002-12-31')]
+
+
+def test_convert_forecasts():
+    # /root/reference/tests/unit/prophet_scorer_test.py:55-80 without Spark
+    fdf = pd.DataFrame({'series_id': np.array([101], dtype='int32'), 'dim_id': np.array([66], dtype='int32'),
+                        'ds': [datetime.strptime('2015-07-05 10:15:00', '%Y-%m-%d %H:%M:%S')],
+                        'yhat': np.array([873242], dtype='int32')})
+    out = ps.ProphetScorer.convert_forecasts(fdf)
+    timestamp_regex = re.compile(r'^([0-9]{4})-(1[0-2]|0[1-9])-(3[01]|0[1-9]|[12][0-9])T'
+                                 r'(2[0-3]|[01][0-9]):([0-5][0-9]):([0-5][0-9])(\+00:00)$')
+    row = out.iloc[0]
+    assert timestamp_regex.match(row.iloc[0])
+    assert row.iloc[1] == 101 and row.iloc[2] == 66
+    assert row.iloc[3] == '2015-07-05'
+    assert pd.Timestamp(row.iloc[4]).to_pydatetime() == datetime(2015, 7, 5, 10, 15)
+    assert row.iloc[5] == 873242
+    assert list(out.columns) == ['created_timestamp', 'series_id', 'dim_id', 'forecast_date',
+                                 'forecast_timestamp', 'forecast_quantity']
+
+
+def test_read_input_dataframe_hive_layout(tmp_path):
+    # /root/reference/tests/unit/prophet_modeler_test.py:52-56: the fixture's layout and counts
+    g = np.load(helpers.GOLDEN + '/fixture_751.npz')
+    d = tmp_path / 'model-input' / 'series_id=751'
+    d.mkdir(parents=True)
+    pd.DataFrame({'dim_id': g['raw_dim_id'],
+                  'ds': pd.Series(g['raw_ds_ns'].astype('datetime64[ns]')).dt.strftime('%Y-%m-%d %H:%M:%S'),
+                  'y': g['raw_y']}).to_csv(d / 'sample-model-input.csv', header=False, index=False)
+    modeler = pm.ProphetModeler({'io': {'input': str(tmp_path / 'model-input'), 'models': str(tmp_path / 'models')},
+                                 'model': {'floor': 0, 'cap_multiplier': 1.1}})
+    df = modeler.read_input_dataframe(None)
+    assert list(df.columns) == ['series_id', 'dim_id', 'ds', 'y']
+    assert df['series_id'].nunique() == 1 and df['dim_id'].nunique() == 2 and len(df) == 816
+    assert str(df['y'].dtype) == 'int32' and str(df['ds'].dtype).startswith('datetime64')
+
+
+def test_shard_bounds_partition():
+    for n, w in [(10, 3), (10000, 8), (7, 8), (100000, 8), (1, 1)]:
+        cuts = [parallel.shard_bounds(n, r, w) for r in range(w)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == n
+        assert all(cuts[i][1] == cuts[i + 1][0] for i in range(w - 1))
+        sizes = [b - a for a, b in cuts]
+        assert max(sizes) - min(sizes) <= 1
+        for i in range(0, n, max(1, n // 17)):
+            r = parallel.shard_of(i, n, w)
+            assert cuts[r][0] <= i < cuts[r][1]
+
+
+def test_spec_validation_messages():
+    with pytest.raises(ValueError):
+        fc.ModelSpec(growth='flat')
+    with pytest.raises(ValueError):
+        fc.ModelSpec(seasonality_mode='both')
+    with pytest.raises(TypeError):
+        fc.ModelSpec(tolerance=1)
+    s = fc.ModelSpec(seasonalities=[dict(helpers.YEARLY), dict(helpers.WEEKLY)])
+    assert s.K == 26 and s.theta_stride == 54

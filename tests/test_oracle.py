@@ -1,0 +1,181 @@
+"""CPU tests of the oracle itself (oracle/ is test infrastructure): the canonical C oracle
+against the literal dense-A numpy restatement of prophet.stan, finite differences, libm, and
+the committed golden vectors.  PARITY UNPINNED w.r.t. real fbprophet (see oracle/ headers)."""
+import ctypes
+import math
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from tests import helpers
+from oracle import canon_lib as cl, oracle_lib
+from oracle.fbprophet_restated import (ProphetOracle, stan_log_prob, stan_neg_log_prob_grad,
+                                       fourier_series)
+
+ULP = 2.220446049250313e-16
+
+
+def test_det_math_close_to_libm():
+    L = cl.lib()
+    rng = np.random.default_rng(0)
+    x = rng.uniform(-60, 60, 4000)
+    e = np.array([L.cn_det_exp(v) for v in x])
+    assert np.max(np.abs(e - np.exp(x)) / np.exp(x)) <= 2 * ULP
+    x = np.exp(rng.uniform(-30, 30, 4000))
+    l = np.array([L.cn_det_log(v) for v in x])
+    assert np.max(np.abs(l - np.log(x)) / np.maximum(np.abs(np.log(x)), 1e-3)) <= 4 * ULP
+    s, c = ctypes.c_double(), ctypes.c_double()
+    worst = 0.0
+    for v in rng.uniform(-5000, 5000, 4000):
+        L.cn_det_sincos(v, ctypes.byref(s), ctypes.byref(c))
+        worst = max(worst, abs(s.value - math.sin(v)), abs(c.value - math.cos(v)))
+    assert worst <= 2 * ULP
+    assert L.cn_det_exp(800.0) == float('inf') and L.cn_det_exp(-800.0) == 0.0
+
+
+def _literal(case, n=0):
+    spec, ds, y, floor, cap, extra, fut, extra_future = helpers.make_case(case)
+    growth, mode = spec.growth, spec.seasonality_mode
+    has_yearly = any(s['name'] == 'yearly' for s in spec.seasonalities)
+    hol = None
+    if extra is not None:
+        # rebuild an fbprophet-style holidays frame from the indicator columns
+        rows = []
+        dates = pd.to_datetime(np.concatenate([ds, fut]))
+        allm = np.concatenate([extra, extra_future], axis=1)
+        for e, sp in enumerate(spec.extra):
+            name, off = sp['name'].split('_delim_')
+            offv = int(off)
+            for d in dates[allm[e] == 1.0]:
+                if offv == 0:
+                    rows.append((name, d))
+        hol = pd.DataFrame(rows, columns=['holiday', 'ds'])
+        hol['lower_window'] = -1
+        hol['upper_window'] = 1
+    m = ProphetOracle(growth=growth, seasonality_mode=mode, yearly_seasonality=has_yearly,
+                      weekly_seasonality=True, daily_seasonality=False, holidays=hol)
+    df = pd.DataFrame({'ds': pd.to_datetime(ds), 'y': y[n]})
+    if growth == 'logistic':
+        df['floor'] = floor[n]
+        df['cap'] = cap[n]
+    dat, th0 = m.stan_data(df)
+    return m, dat, th0, (spec, ds, y, floor, cap, extra, fut, extra_future)
+
+
+@pytest.mark.parametrize('case', list(helpers.CASES))
+def test_canonical_eval_matches_literal_stan(case):
+    m, dat, th0, (spec, ds, y, floor, cap, extra, fut, exf) = _literal(case)
+    csp = helpers.oracle_spec(spec)
+    des = cl.design(csp, ds, y[0], floor[0], cap[0], extra)
+    assert des['X'].shape == dat['X'].shape
+    assert np.max(np.abs(des['X'] - dat['X'])) <= 2 * ULP          # det_sincos vs np.sin/cos
+    assert np.array_equal(des['t'], dat['t'])
+    assert np.array_equal(des['y_scaled'], dat['y'])
+    assert np.array_equal(des['t_change'], dat['t_change'])
+    assert abs(des['k0'] - th0[0]) <= 4 * ULP * max(1, abs(th0[0]))
+    assert abs(des['m0'] - th0[1]) <= 4 * ULP * max(1, abs(th0[1]))
+    rng = np.random.default_rng(1)
+    for trial in range(3):
+        th = th0 + rng.normal(0, 0.02, th0.size)
+        f1, g1 = stan_neg_log_prob_grad(dat, th)
+        assert abs(f1 + stan_log_prob(dat, th)) <= 1e-10 * abs(f1)
+        f2, g2, rc = cl.eval_at(csp, ds, y[0], th, floor[0], cap[0], extra)
+        assert rc == 0
+        assert abs(f1 - f2) <= 1e-12 * abs(f1)
+        assert np.max(np.abs(g1 - g2) / (1 + np.abs(g1))) <= 1e-11
+        f3, g3, rc3 = oracle_lib.neg_log_prob_grad(dat, th)
+        assert abs(f1 - f3) <= 1e-12 * abs(f1) and np.max(np.abs(g1 - g3) / (1 + np.abs(g1))) <= 1e-11
+
+
+@pytest.mark.parametrize('case', ['cfg2_linear_additive', 'ref_logistic_multiplicative'])
+def test_gradient_finite_difference(case):
+    m, dat, th0, _ = _literal(case)
+    rng = np.random.default_rng(2)
+    th = th0 + rng.normal(0, 0.02, th0.size)
+    f, g = stan_neg_log_prob_grad(dat, th)
+    for i in rng.choice(th.size, 12, replace=False):
+        e = np.zeros_like(th)
+        e[i] = 1e-6
+        fd = (stan_neg_log_prob_grad(dat, th + e)[0] - stan_neg_log_prob_grad(dat, th - e)[0]) / 2e-6
+        assert abs(fd - g[i]) <= 1e-6 * (1 + abs(g[i]))
+
+
+def test_fourier_column_order_and_changepoints():
+    ds = pd.date_range('2018-01-01', periods=100, freq='D')
+    X = fourier_series(ds, 7, 3)
+    t = (ds.asi8 / 1e9) / 86400.0
+    assert np.allclose(X[:, 0], np.sin(2 * np.pi * t / 7)) and np.allclose(X[:, 1], np.cos(2 * np.pi * t / 7))
+    assert np.allclose(X[:, 4], np.sin(2 * np.pi * 3 * t / 7))
+    m = ProphetOracle()
+    m.fit(pd.DataFrame({'ds': ds, 'y': np.arange(100.0) + np.sin(np.arange(100.0))}),
+          optimizer=lambda dat, th0: (th0, {'status': 0}))
+    # 25 changepoints over the first 80 %: indices round(linspace(0, 79, 26))[1:]
+    idx = np.linspace(0, 79, 26).round().astype(int)[1:]
+    assert np.allclose(m.changepoints_t, idx / 99.0)
+
+
+def test_auto_seasonality_trap_730_daily_points():
+    # 730 daily points span 729 d < 730 d -> yearly is auto-DISABLED
+    ds = pd.date_range('2018-01-01', periods=730, freq='D')
+    m = ProphetOracle()
+    m.stan_data(pd.DataFrame({'ds': ds, 'y': np.arange(730.0)}))
+    assert list(m.seasonalities) == ['weekly']
+    m = ProphetOracle()
+    m.stan_data(pd.DataFrame({'ds': pd.date_range('2018-01-01', periods=731, freq='D'),
+                              'y': np.arange(731.0)}))
+    assert list(m.seasonalities) == ['yearly', 'weekly']
+
+
+def test_lbfgs_decreases_objective_and_fits():
+    m, dat, th0, (spec, ds, y, floor, cap, extra, fut, exf) = _literal('cfg2_linear_additive')
+    csp = helpers.oracle_spec(spec)
+    f0, _, _ = cl.eval_at(csp, ds, y[0], th0)
+    r = cl.fit(csp, ds, y[0])
+    assert r['status'] > 0 and r['f'] < f0 - 100
+    # in-sample fit: residual std close to the 5 % noise the generator used
+    f, g = stan_neg_log_prob_grad(dat, r['theta'])
+    assert abs(f - r['f']) <= 1e-9 * abs(f)
+    sigma = np.exp(r['theta'][2])
+    assert 0.005 < sigma < 0.2
+    # the plain (order-agnostic) C restatement reaches a comparable optimum
+    th2, info = oracle_lib.stan_lbfgs(dat, th0)
+    assert abs(info['f'] - r['f']) < 5.0
+
+
+def test_scaling_y_by_two_scales_forecast_exactly():
+    spec, ds, y, floor, cap, extra, fut, exf = helpers.make_case('cfg2_linear_additive')
+    csp = helpers.oracle_spec(spec)
+    r1 = cl.fit(csp, ds, y[1])
+    r2 = cl.fit(csp, ds, 2.0 * y[1])
+    assert np.array_equal(r1['theta'], r2['theta'])           # scaled problem is identical
+    y1, _ = cl.predict(csp, r1, fut)
+    y2, _ = cl.predict(csp, r2, fut)
+    assert np.array_equal(2.0 * y1, y2)
+
+
+def test_golden_vectors_reproduce():
+    g = np.load(helpers.GOLDEN + '/synthetic_cases.npz')
+    for case in helpers.CASES:
+        spec, ds, y, floor, cap, extra, fut, exf = helpers.make_case(case)
+        csp = helpers.oracle_spec(spec)
+        for n in (0, 3):
+            r = cl.fit(csp, ds, y[n], floor[n], cap[n], extra)
+            yo, _ = cl.predict(csp, r, fut, floor[n], cap[n], exf)
+            assert r['n_iter'] == g[case + '/n_iter'][n] and r['status'] == g[case + '/status'][n]
+            assert np.array_equal(yo, g[case + '/yhat'][n])
+
+
+def test_edge_cases():
+    spec, ds, y, floor, cap, extra, fut, exf = helpers.make_case('cfg2_linear_additive')
+    csp = helpers.oracle_spec(spec)
+    r = cl.fit(csp, ds, np.full(len(ds), 7.0))
+    assert r['status_name'] == 'CONSTANT' and r['n_iter'] == 0
+    r = cl.fit(csp, ds[:1], y[0][:1])
+    assert r['status_name'] == 'ERR_TOO_FEW'
+    lsp = helpers.oracle_spec(helpers.make_case('ref_logistic_multiplicative')[0])
+    r = cl.fit(lsp, ds, y[0], 10.0, 5.0)
+    assert r['status_name'] == 'ERR_CAP'
+    # short history: fewer changepoints than requested (hist_size - 1)
+    r = cl.fit(helpers.oracle_spec(helpers.make_case('short_90')[0]), ds[:20], y[0][:20])
+    assert r['info'].S == 15 and r['status'] > 0

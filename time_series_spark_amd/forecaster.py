@@ -61,8 +61,16 @@ class ModelSpec(object):
         first, last = int(ds_ns.min()), int(ds_ns.max())
         diffs = np.diff(np.sort(ds_ns))
         nz = diffs[diffs != 0]
-        min_dt = int(nz.min()) if nz.size else None
-        span = last - first
+        min_dt = int(nz.min()) if nz.size else -1
+        return ModelSpec.auto_from_stats(last - first, min_dt, yearly, weekly, daily,
+                                         seasonality_mode, seasonality_prior_scale,
+                                         user_seasonalities)
+
+    @staticmethod
+    def auto_from_stats(span, min_dt, yearly='auto', weekly='auto', daily='auto',
+                        seasonality_mode='additive', seasonality_prior_scale=10.0,
+                        user_seasonalities=()):
+        """Same rules from (span_ns, smallest non-zero spacing in ns or -1 if none)."""
         names = {s['name'] for s in user_seasonalities}
 
         def order(name, arg, auto_disable, default):
@@ -77,16 +85,16 @@ class ModelSpec(object):
             return int(arg)
 
         out = [dict(s) for s in user_seasonalities]
-        big = min_dt is None
+        has_dt = min_dt is not None and min_dt >= 0
         fo = order('yearly', yearly, span < 730 * DAY_NS, 10)
         if fo > 0:
             out.append({'name': 'yearly', 'period': 365.25, 'fourier_order': fo,
                         'prior_scale': seasonality_prior_scale, 'mode': seasonality_mode})
-        fo = order('weekly', weekly, (span < 14 * DAY_NS) or (not big and min_dt >= 7 * DAY_NS), 3)
+        fo = order('weekly', weekly, (span < 14 * DAY_NS) or (has_dt and min_dt >= 7 * DAY_NS), 3)
         if fo > 0:
             out.append({'name': 'weekly', 'period': 7, 'fourier_order': fo,
                         'prior_scale': seasonality_prior_scale, 'mode': seasonality_mode})
-        fo = order('daily', daily, (span < 2 * DAY_NS) or (not big and min_dt >= DAY_NS), 4)
+        fo = order('daily', daily, (span < 2 * DAY_NS) or (has_dt and min_dt >= DAY_NS), 4)
         if fo > 0:
             out.append({'name': 'daily', 'period': 1, 'fourier_order': fo,
                         'prior_scale': seasonality_prior_scale, 'mode': seasonality_mode})

@@ -1,0 +1,241 @@
+"""Fit side of the drop-in boundary: same names, config keys, column order and error behaviour
+as /root/reference/src/jobs/prophet_modeler.py, with the per-series fbprophet fit replaced by
+one batched GPU fit of every (series_id, dim_id) group in the frame.
+
+    model_time_series(config)        prophet_modeler.py:22-87   curried grouped-map function
+    ProphetModeler.read_input_dataframe                  :102-116
+    ProphetModeler.persist_models                        :118-125
+    ProphetModeler.model                                 :127-143
+
+Spark is optional (pyspark/JVM are not in this image): the factories return plain
+`pdf -> pdf` functions; when pyspark is importable `as_pandas_udf` wraps them with the
+reference's output schema for `df.groupby('series_id','dim_id').apply(...)`.  A grouped map
+that hands over ONE series per call cannot batch; `model_panel(config)` takes a frame holding
+many groups (e.g. grouped by a shard key) and is what ProphetModeler.model uses.
+"""
+import glob
+import logging
+import os
+import time
+
+import numpy as np
+import pandas as pd
+
+from .. import _lib, forecaster as fc, panel as pk
+
+# prophet_modeler.py:12-17 (names and nullability; types: int, int, timestamp, int)
+MODEL_INPUT_SCHEMA = [('series_id', 'int32'), ('dim_id', 'int32'), ('start_time', 'datetime64[ns]'),
+                      ('quantity', 'int32')]
+# prophet_modeler.py:32-38
+MODEL_OUTPUT_COLUMNS = ['series_id', 'dim_id', 'floor', 'cap', 'model']
+MODEL_OUTPUT_DTYPES = {'series_id': 'int32', 'dim_id': 'int32', 'floor': 'float32', 'cap': 'float32'}
+
+
+def _prophet_kwargs(config):
+    """The reference hard-codes Prophet(growth='logistic', seasonality_mode='multiplicative')
+    (prophet_modeler.py:65).  config['model']['prophet'] (optional, not in the reference) may
+    override constructor arguments, e.g. for BASELINE config 2."""
+    kw = {'growth': 'logistic', 'seasonality_mode': 'multiplicative'}
+    kw.update((config.get('model') or {}).get('prophet') or {})
+    return kw
+
+
+def _empty_models():
+    return pd.DataFrame(columns=MODEL_OUTPUT_COLUMNS)
+
+
+def fit_packed(panel, floor, cap, kw):
+    """Fit every series of a PackedPanel.  Series are bucketed by the seasonality set
+    fbprophet's 'auto' rules give their own history (each Prophet object decides alone), one
+    kernel launch per bucket.  Returns per-series (blob | None, status)."""
+    N = panel.N
+    span, min_dt, _ = pk.per_series_stats(panel)
+    growth = kw.get('growth', 'linear')
+    mode = kw.get('seasonality_mode', 'additive')
+    sps = float(kw.get('seasonality_prior_scale', 10.0))
+    # the auto rules depend on the series only through three booleans
+    sig = np.stack([span < 730 * fc.DAY_NS,
+                    (span < 14 * fc.DAY_NS) | ((min_dt >= 0) & (min_dt >= 7 * fc.DAY_NS)),
+                    (span < 2 * fc.DAY_NS) | ((min_dt >= 0) & (min_dt >= fc.DAY_NS))], axis=1)
+    specs = {}
+    for row in np.unique(sig, axis=0):
+        members = np.flatnonzero((sig == row).all(axis=1))
+        n0 = int(members[0])
+        seas = fc.ModelSpec.auto_from_stats(
+            int(span[n0]), int(min_dt[n0]), yearly=kw.get('yearly_seasonality', 'auto'),
+            weekly=kw.get('weekly_seasonality', 'auto'), daily=kw.get('daily_seasonality', 'auto'),
+            seasonality_mode=mode, seasonality_prior_scale=sps,
+            user_seasonalities=kw.get('seasonalities', ()))
+        key = tuple((s['name'], s['fourier_order']) for s in seas)
+        if key in specs:
+            specs[key] = (seas, np.concatenate([specs[key][1], members]))
+        else:
+            specs[key] = (seas, members)
+    blobs = [None] * N
+    status = np.zeros(N, dtype=np.int32)
+    last_ds = panel.ds_ns[panel.offsets[1:] - 1] if N else np.zeros(0, np.int64)
+    for key, (seas, members) in specs.items():
+        members = np.sort(np.asarray(members))
+        if not seas:
+            # fbprophet adds a zero column when there is no seasonality at all
+            spec = fc.ModelSpec(growth=growth, seasonality_mode=mode, seasonalities=[],
+                                extra=[{'name': 'zeros', 'prior_scale': 1.0, 'mode': 'additive'}],
+                                **_spec_opts(kw))
+        else:
+            spec = fc.ModelSpec(growth=growth, seasonality_mode=mode, seasonalities=seas,
+                                **_spec_opts(kw))
+        sd = spec.to_dict()
+        if panel.aligned and len(members) == N:
+            ex = np.zeros((1, panel.ds_grid.shape[0])) if not seas else None
+            res = fc.fit_aligned(spec, panel.ds_grid, panel.y2d, floor=floor, cap=cap, extra=ex)
+        else:
+            lens = panel.lengths[members]
+            off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+            idx = np.concatenate([np.arange(panel.offsets[m], panel.offsets[m + 1]) for m in members])
+            ex = np.zeros((1, len(idx))) if not seas else None
+            res = fc.fit_ragged(spec, off, panel.ds_ns[idx], panel.y[idx],
+                                floor=None if floor is None else np.asarray(floor)[members],
+                                cap=None if cap is None else np.asarray(cap)[members], extra=ex)
+        for i, m in enumerate(members):
+            st = int(res.status[i])
+            status[m] = st
+            if st in (_lib.ST_LSFAIL, _lib.ST_INIT_NONFINITE, _lib.ST_TOO_FEW, _lib.ST_CAP):
+                continue
+            blobs[m] = pk.dump_model(sd, res.theta[i], res.y_scale[i], res.grid_of(i), last_ds[m],
+                                     st, res.n_iter[i])
+    return blobs, status
+
+
+def _spec_opts(kw):
+    out = {}
+    for k in ('n_changepoints', 'changepoint_range', 'changepoint_prior_scale',
+              'seasonality_prior_scale', 'holidays_prior_scale', 'max_iter', 'history',
+              'init_alpha', 'tol_obj', 'tol_rel_obj', 'tol_grad', 'tol_rel_grad', 'tol_param'):
+        if k in kw:
+            out[k] = kw[k]
+    return out
+
+
+def model_panel(config):
+    """Batched form of model_time_series: the frame may hold any number of
+    (series_id, dim_id) groups; one output row per fitted group."""
+
+    def model_panel_fn(pdf):
+        execution_time = time.time()
+        if len(pdf.index) == 0:
+            return _empty_models()
+        panel = pk.pack_long_frame(pdf)
+        floor = config['model']['floor']                                   # :56-57
+        _, _, ymax = pk.per_series_stats(panel)
+        cap = ymax * config['model']['cap_multiplier']                     # :59-60
+        kw = _prophet_kwargs(config)
+        floors = np.full(panel.N, float(floor))
+        # ValueError cases propagate exactly as fbprophet's would (SURVEY 8b error convention)
+        if (panel.lengths < 2).any():
+            raise ValueError('Dataframe has less than 2 non-NaN rows.')
+        if kw['growth'] == 'logistic' and (cap <= floors).any():
+            raise ValueError('cap must be greater than floor (which defaults to 0).')
+        blobs, status = fit_packed(panel, floors, cap, kw)
+        rows = []
+        for n in range(panel.N):
+            sid, did = int(panel.keys['series_id'].iloc[n]), int(panel.keys['dim_id'].iloc[n])
+            if blobs[n] is None:
+                # pystan RuntimeError -> the reference prints and drops the series (:81-85)
+                print(f"Runtime error {_lib.STATUS_NAMES.get(int(status[n]), status[n])} for "
+                      f"series_id: {sid}, dim_id: {did}")
+                continue
+            rows.append((sid, did, floor, cap[n], blobs[n]))
+        out = pd.DataFrame(rows, columns=MODEL_OUTPUT_COLUMNS)
+        print(f"Modeled {panel.N} series ({len(pdf.index)} rows) in {time.time() - execution_time}")
+        return out
+
+    return model_panel_fn
+
+
+def model_time_series(config):
+    """Model time series per dimensions (series_id, dim_id) -- prophet_modeler.py:22.
+    Returns the grouped-map function `pdf -> pdf`; the frame of one group gives one row
+    [series_id, dim_id, floor, cap, model]."""
+    batched = model_panel(config)
+
+    def model_time_series_udf(pdf):
+        series_id = int(pdf.iloc[0]['series_id'])
+        dim_id = int(pdf.iloc[0]['dim_id'])
+        print(f"Modeling series_id: {series_id}, dim_id: {dim_id}"
+              f" with {len(pdf.index)} modeling rows")
+        return batched(pdf)
+
+    return model_time_series_udf
+
+
+def as_pandas_udf(fn, columns=MODEL_OUTPUT_COLUMNS):
+    """Wrap a `pdf -> pdf` function as a GROUPED_MAP pandas_udf with the reference's output
+    schema (prophet_modeler.py:32-40).  Only where pyspark exists."""
+    from pyspark.sql.functions import pandas_udf, PandasUDFType
+    from pyspark.sql.types import (BinaryType, FloatType, IntegerType, StructField, StructType,
+                                   TimestampType)
+    types = {'series_id': IntegerType(), 'dim_id': IntegerType(), 'floor': FloatType(),
+             'cap': FloatType(), 'model': BinaryType(), 'ds': TimestampType(), 'yhat': IntegerType()}
+    schema = StructType([StructField(c, types[c], True) for c in columns])
+    return pandas_udf(schema, PandasUDFType.GROUPED_MAP)(fn)
+
+
+class ProphetModeler:
+    """Create models to forecast quantities (prophet_modeler.py:90-143), Spark-free: the frames
+    are pandas, the IO is pyarrow/pandas, the fit is one batched GPU call."""
+
+    def __init__(self, config, logger=None):
+        self.logger = logger or logging.getLogger(self.__class__.__name__)
+        self.config = config
+
+    def read_input_dataframe(self, spark=None):
+        """Header-less CSV files under config['io']['input'], Hive-style partition directories
+        (`series_id=751/…csv` supplies the series_id column), schema MODEL_INPUT_SCHEMA;
+        renames start_time -> ds, quantity -> y (:109-114)."""
+        root = self.config['io']['input']
+        files = sorted(glob.glob(os.path.join(root, '**', '*.csv'), recursive=True))
+        if os.path.isfile(root):
+            files = [root]
+        frames = []
+        for f in files:
+            parts = {}
+            for seg in os.path.relpath(os.path.dirname(f), root).split(os.sep):
+                if '=' in seg:
+                    k, v = seg.split('=', 1)
+                    parts[k] = v
+            names = [n for n, _ in MODEL_INPUT_SCHEMA if n not in parts]
+            df = pd.read_csv(f, header=None, names=names)
+            for k, v in parts.items():
+                df[k] = v
+            frames.append(df)
+        if not frames:
+            return pd.DataFrame(columns=['series_id', 'dim_id', 'ds', 'y'])
+        df = pd.concat(frames, ignore_index=True)
+        df['series_id'] = pd.to_numeric(df['series_id']).astype('int32')
+        df['dim_id'] = pd.to_numeric(df['dim_id']).astype('int32')
+        df['start_time'] = pd.to_datetime(df['start_time'])
+        df['quantity'] = pd.to_numeric(df['quantity']).astype('int32')
+        df = df[['series_id', 'dim_id', 'start_time', 'quantity']]
+        return df.rename(columns={'start_time': 'ds', 'quantity': 'y'})
+
+    def persist_models(self, model_df):
+        """Parquet, mode='overwrite' (:123-125)."""
+        import shutil
+        path = self.config['io']['models']
+        if os.path.isdir(path):
+            shutil.rmtree(path)
+        os.makedirs(path, exist_ok=True)
+        out = model_df.copy()
+        for c, t in MODEL_OUTPUT_DTYPES.items():
+            out[c] = out[c].astype(t)
+        out.to_parquet(os.path.join(path, 'part-00000.parquet'), index=False)
+
+    @staticmethod
+    def model(spark_session, config):
+        """Create the trained time series models (:127-143).  spark_session is accepted for
+        signature compatibility and may be None."""
+        scorer = ProphetModeler(config)
+        input_df = scorer.read_input_dataframe(spark_session)
+        model_df = model_panel(scorer.config)(input_df)
+        scorer.persist_models(model_df)
+        return model_df
