@@ -10,8 +10,9 @@
  *
  *   - every sum over time is taken as 64 contiguous chunk partials (chunk length
  *     NT = ceil(T/64), accumulated with fma from the LAST element of the chunk to the
- *     first), combined either by an xor-butterfly (offsets 1,2,4,8,16,32) or, for the
- *     per-column sums, sequentially over chunks 0..63;
+ *     first), combined by an xor-butterfly (offsets 1,2,4,8,16,32 for scalars; 32,16,1,2,4,8
+ *     for the per-column sums X^T r) or, for the trend gradient, a 16-wide Hillis-Steele suffix
+ *     scan plus a carry over the four groups of 16;
  *   - every dot product over parameters is 64 partials (parameter p lives in slot p%64,
  *     second term fma'd for p>=64) combined by the same xor-butterfly;
  *   - exp/log/sin/cos come from det_math.h; everything else is IEEE double + - * / sqrt
@@ -101,14 +102,49 @@ typedef struct {
 
 /* ---- canonical reductions ----------------------------------------------------------- */
 
-static double bfly(double v[CN_W])
+static double bfly_offsets(double v[CN_W], const int *offs, int noff)
 {
     double n[CN_W];
-    for (int off = 1; off < CN_W; off <<= 1) {
+    for (int o = 0; o < noff; ++o) {
+        const int off = offs[o];
         for (int i = 0; i < CN_W; ++i) n[i] = v[i] + v[i ^ off];
         memcpy(v, n, sizeof(n));
     }
     return v[0];
+}
+
+/* scalar reductions: offsets 1,2,4,8,16,32 */
+static double bfly(double v[CN_W])
+{
+    static const int offs[6] = {1, 2, 4, 8, 16, 32};
+    return bfly_offsets(v, offs, 6);
+}
+
+/* per-column sums: offsets 32,16,1,2,4,8 (the order of the register transpose network) */
+static double bfly_cols(double v[CN_W])
+{
+    static const int offs[6] = {32, 16, 1, 2, 4, 8};
+    return bfly_offsets(v, offs, 6);
+}
+
+/* inclusive suffix sum over the 64 chunks: Hillis-Steele (1,2,4,8) inside each group of 16
+ * (out-of-group terms are an explicit + 0.0), then the totals of the later groups are added
+ * as one carry: group 0 += T1 + (T2 + T3), group 1 += T2 + T3, group 2 += T3, group 3 += 0.0 */
+static void suffix_scan(double v[CN_W])
+{
+    double n[CN_W];
+    for (int off = 1; off < 16; off <<= 1) {
+        for (int L = 0; L < CN_W; ++L) n[L] = v[L] + (((L & 15) + off < 16) ? v[L + off] : 0.0);
+        memcpy(v, n, sizeof(n));
+    }
+    const double t1 = v[16], t2 = v[32], t3 = v[48];
+    const double s2 = t2 + t3;
+    const double s1 = t1 + s2;
+    for (int L = 0; L < CN_W; ++L) {
+        const int row = L >> 4;
+        const double carry = (row == 0) ? s1 : (row == 1 ? s2 : (row == 2 ? t3 : 0.0));
+        v[L] = v[L] + carry;
+    }
 }
 
 /* dot over (zero padded) 128-vectors */
@@ -321,15 +357,8 @@ static int cn_eval(cn_series *se, const double *th, double *f_out, double *g)
         sseL[L] = sse; tot1[L] = rt1; tot2[L] = rt2;
     }
     const double sse = bfly(sseL);
-    /* inclusive suffix scan over chunks (Hillis-Steele, offsets 1..32) */
-    for (int off = 1; off < CN_W; off <<= 1) {
-        double n1[CN_W], n2[CN_W];
-        for (int L = 0; L < CN_W; ++L) {
-            n1[L] = (L + off < CN_W) ? tot1[L] + tot1[L + off] : tot1[L];
-            n2[L] = (L + off < CN_W) ? tot2[L] + tot2[L + off] : tot2[L];
-        }
-        memcpy(tot1, n1, sizeof(n1)); memcpy(tot2, n2, sizeof(n2));
-    }
+    suffix_scan(tot1);
+    suffix_scan(tot2);
     const double TA = tot1[0], TB = tot2[0];
     double SA[CN_MAX_S + 1], SB[CN_MAX_S + 1];
     for (int j = 0; j < S; ++j) {
@@ -342,12 +371,12 @@ static int cn_eval(cn_series *se, const double *th, double *f_out, double *g)
         SA[j] = tp1[j] + e1;
         SB[j] = tp2[j] + e2;
     }
-    /* per-column sums: sequential over chunks */
+    /* per-column sums over the 64 chunk partials */
     double ACC[CN_MAX_P];
     for (int j = 0; j < K; ++j) {
-        double a = accL[0][j];
-        for (int L = 1; L < CN_W; ++L) a = a + accL[L][j];
-        ACC[j] = a;
+        double col[CN_W];
+        for (int L = 0; L < CN_W; ++L) col[L] = accL[L][j];
+        ACC[j] = bfly_cols(col);
     }
     /* priors */
     double pa[CN_W], pb[CN_W];

@@ -63,10 +63,60 @@ struct SeriesTab {
 // cross-lane helpers (wave64)
 // ---------------------------------------------------------------------------------------
 
+// ---- DPP / permlane primitives (wave64, gfx950) -------------------------------------------
+// All of these only MOVE data; the arithmetic tree they implement is written next to each use.
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v)          // invalid source lanes read 0.0
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
+constexpr int DPP_XOR1 = 0xB1;          // quad_perm [1,0,3,2]
+constexpr int DPP_XOR2 = 0x4E;          // quad_perm [2,3,0,1]
+constexpr int DPP_HALF_MIRROR = 0x141;  // lane i <-> 7-i within 8  (== xor 4 once quads are uniform)
+constexpr int DPP_MIRROR = 0x140;       // lane i <-> 15-i within 16 (== xor 8 once octets are uniform)
+#define DPP_ROW_SHL(n) (0x100 + (n))    // lane i reads lane i+n of its 16-lane row
+
+// v_permlane16_swap: rows 1,3 of a <-> rows 0,2 of b.   v_permlane32_swap: a.hi32 <-> b.lo32.
+__device__ __forceinline__ void swap16(double &a, double &b)
+{
+    auto r0 = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    auto r1 = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    a = __hiloint2double((int)r1[0], (int)r0[0]);
+    b = __hiloint2double((int)r1[1], (int)r0[1]);
+}
+__device__ __forceinline__ void swap32(double &a, double &b)
+{
+    auto r0 = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    auto r1 = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    a = __hiloint2double((int)r1[0], (int)r0[0]);
+    b = __hiloint2double((int)r1[1], (int)r0[1]);
+}
+
+// xor-butterfly sum, offsets 1,2,4,8,16,32; every lane ends with the same bits.
+// (a + b is commutative, so exchanging through mirrors / swaps gives the butterfly's values.)
 __device__ __forceinline__ double bfly_sum(double v)
 {
-#pragma unroll
-    for (int off = 1; off < W; off <<= 1) v = v + __shfl_xor(v, off, W);
+    v = v + dpp_mov<DPP_XOR1>(v);
+    v = v + dpp_mov<DPP_XOR2>(v);
+    v = v + dpp_mov<DPP_HALF_MIRROR>(v);
+    v = v + dpp_mov<DPP_MIRROR>(v);
+    { double a = v, b = v; swap16(a, b); v = a + b; }
+    { double a = v, b = v; swap32(a, b); v = a + b; }
+    return v;
+}
+
+// within-row butterfly 1,2,4,8 (used after the 32/16 stages of the column network)
+__device__ __forceinline__ double row_bfly_sum(double v)
+{
+    v = v + dpp_mov<DPP_XOR1>(v);
+    v = v + dpp_mov<DPP_XOR2>(v);
+    v = v + dpp_mov<DPP_HALF_MIRROR>(v);
+    v = v + dpp_mov<DPP_MIRROR>(v);
     return v;
 }
 
@@ -77,6 +127,30 @@ __device__ __forceinline__ double uniform_f64(double v)
     int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
     int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
     return __hiloint2double(hi, lo);
+}
+
+// value held by `lane` (wave-uniform index) as a scalar
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// inclusive suffix sum over the 64 lanes: Hillis-Steele (1,2,4,8) inside each 16-lane row, then
+// the totals of the later rows are added as one carry ((T3), (T2+T3), (T1+(T2+T3))).
+__device__ __forceinline__ double suffix_scan(double v)
+{
+    v = v + dpp_mov<DPP_ROW_SHL(1)>(v);
+    v = v + dpp_mov<DPP_ROW_SHL(2)>(v);
+    v = v + dpp_mov<DPP_ROW_SHL(4)>(v);
+    v = v + dpp_mov<DPP_ROW_SHL(8)>(v);
+    const double t1 = readlane_f64(v, 16), t2 = readlane_f64(v, 32), t3 = readlane_f64(v, 48);
+    const double s2 = t2 + t3;
+    const double s1 = t1 + s2;
+    const int row = (int)threadIdx.x >> 4;
+    const double carry = (row == 0) ? s1 : (row == 1 ? s2 : (row == 2 ? t3 : 0.0));
+    return v + carry;
 }
 
 // dot product over the parameter axis: slot 0 product, slot 1 fma'd in, then butterfly

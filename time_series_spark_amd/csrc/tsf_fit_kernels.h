@@ -22,17 +22,56 @@ struct SeriesView {
 // LDS carve-up for one wave
 template <int KP, int PPL>
 struct WaveLds {
-    double th[TSF_MAX_P + W];          // zero beyond P (padding columns read it)
+    double th[TSF_MAX_P + W];          // theta as stored by the last evaluation; zero beyond P
     double ks[NTAB + 1], mc[NTAB + 1];
     double tp1[NTAB], tp2[NTAB];
     double tot1[W + 1], tot2[W + 1];
     double d1[NTAB + 1], d2[NTAB + 1], rb[NTAB + 1], ab[NTAB + 1];
     double rho[MAXH], alphas[MAXH];
-    double accT[KP * W];
+    double accR[KP];                   // per-column sums X^T r
     double Sb[MAXH * PPL * W], Yb[MAXH * PPL * W];
 };
 
 #define TSF_WAVE_SYNC() __syncthreads()
+
+// theta[p] for a wave-uniform p, straight from the owning lane's register
+template <int PPL>
+__device__ __forceinline__ double theta_at(const double (&th)[PPL], int p)
+{
+    if (PPL == 1) return readlane_f64(th[0], p);
+    return (p < W) ? readlane_f64(th[0], p) : readlane_f64(th[PPL - 1], p - W);
+}
+
+// Column sums ACC_j = sum over the 64 chunk partials acc[j], as a butterfly with offsets
+// 32, 16, 1, 2, 4, 8, done for all KP columns at once: the 32- and 16-stages transpose pairs of
+// registers with v_permlane32_swap / v_permlane16_swap (halving the register count each time),
+// the last four stages are DPP butterflies inside the 16-lane rows.  Results go to lds.accR.
+template <int KP, int PPL>
+__device__ __forceinline__ void column_sums(double (&acc)[KP], WaveLds<KP, PPL> &lds)
+{
+    static_assert(KP % 4 == 0, "KP must be a multiple of 4");
+    const int lane = threadIdx.x;
+    double c[KP / 2];
+#pragma unroll
+    for (int i = 0; i < KP / 2; ++i) {
+        double a = acc[2 * i], b = acc[2 * i + 1];
+        swap32(a, b);                  // a = [col 2i lo | col 2i+1 lo], b = [col 2i hi | col 2i+1 hi]
+        c[i] = a + b;                  // lanes 0-31: column 2i, lanes 32-63: column 2i+1
+    }
+    double d[KP / 4];
+#pragma unroll
+    for (int i = 0; i < KP / 4; ++i) {
+        double a = c[2 * i], b = c[2 * i + 1];
+        swap16(a, b);                  // a = [A.r0, B.r0, A.r2, B.r2], b = [A.r1, B.r1, A.r3, B.r3]
+        d[i] = row_bfly_sum(a + b);    // row 0: col 4i, row 1: col 4i+2, row 2: col 4i+1, row 3: col 4i+3
+    }
+    if ((lane & 15) == 0) {
+        const int r = lane >> 4;
+        const int sub = (r == 0) ? 0 : (r == 1 ? 2 : (r == 2 ? 1 : 3));
+#pragma unroll
+        for (int i = 0; i < KP / 4; ++i) lds.accR[4 * i + sub] = d[i];
+    }
+}
 
 // MODE: 0 all columns additive, 1 all multiplicative, 2 mixed (Ka additive first)
 template <int KP, int GROWTH, int MODE, int PPL>
@@ -43,19 +82,21 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
     const int lane = threadIdx.x;
     const int S = sv.S, NT = sv.NT, T = sv.T;
     const int Ka = (MODE == 0) ? KP : (MODE == 1 ? 0 : sp->Ka);
+    constexpr bool HOLD = (KP <= 32);   // design row + coefficients held in registers / SGPRs
     sv.n_eval++;
-#pragma unroll
-    for (int s = 0; s < PPL; ++s) lds.th[lane + s * W] = th[s];
-    TSF_WAVE_SYNC();
-    const double k = lds.th[0], m = lds.th[1], ls = lds.th[2];
+    const double k = theta_at<PPL>(th, 0), m = theta_at<PPL>(th, 1), ls = theta_at<PPL>(th, 2);
     const double sigma = dm_exp(ls);
     const double inv_s2 = 1.0 / (sigma * sigma);
-    // segment tables ks[c], mc[c]
+    if (!HOLD) {
+#pragma unroll
+        for (int s = 0; s < PPL; ++s) lds.th[lane + s * W] = th[s];
+    }
+    // segment tables ks[c], mc[c] (sequential recurrences, wave-uniform)
     {
         double ksv = k, mcv = m;
         if (lane == 0) { lds.ks[0] = ksv; lds.mc[0] = mcv; }
         for (int j = 0; j < S; ++j) {
-            const double dj = lds.th[3 + j];
+            const double dj = theta_at<PPL>(th, 3 + j);
             const double tcj = sv.t_change[j];
             const double ksn = ksv + dj;
             if (GROWTH == 0) {
@@ -68,12 +109,10 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
             if (lane == 0) { lds.ks[j + 1] = ksv; lds.mc[j + 1] = mcv; }
         }
     }
-    // coefficients as wave-uniform scalars (kept in SGPRs for KP <= 32; read from LDS above)
-    constexpr bool HOLD = (KP <= 32);
     double bs[HOLD ? KP : 1];
     if (HOLD) {
 #pragma unroll
-        for (int j = 0; j < (HOLD ? KP : 1); ++j) bs[j] = uniform_f64(lds.th[3 + S + j]);
+        for (int j = 0; j < (HOLD ? KP : 1); ++j) bs[j] = (3 + S + j < PPL * W) ? theta_at<PPL>(th, 3 + S + j) : 0.0;
     }
     TSF_WAVE_SYNC();
 
@@ -88,20 +127,26 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
             const int c = (int)(cwv & 0xffu), cprev = (int)(cwv >> 8);
             const double ti = sv.tw[idx];
             const double yi = sv.yw[idx];
-            double x[HOLD ? KP : 1];
             const double *xp = sv.Xw + (size_t)q * KP * W + lane;
+            double x[HOLD ? KP : 1];
+            double xa = 0.0, xm = 0.0;
             if (HOLD) {
 #pragma unroll
                 for (int j = 0; j < (HOLD ? KP : 1); ++j) x[j] = xp[j * W];
-            }
-            double xa = 0.0, xm = 0.0;
-#pragma unroll 8
-            for (int j = 0; j < KP; ++j) {
-                const double xv = HOLD ? x[HOLD ? j : 0] : xp[j * W];
-                const double bv = HOLD ? bs[HOLD ? j : 0] : lds.th[3 + S + j];
-                if (MODE == 0) xa = __builtin_fma(xv, bv, xa);
-                else if (MODE == 1) xm = __builtin_fma(xv, bv, xm);
-                else { if (j < Ka) xa = __builtin_fma(xv, bv, xa); else xm = __builtin_fma(xv, bv, xm); }
+#pragma unroll
+                for (int j = 0; j < (HOLD ? KP : 1); ++j) {
+                    if (MODE == 0) xa = __builtin_fma(x[j], bs[j], xa);
+                    else if (MODE == 1) xm = __builtin_fma(x[j], bs[j], xm);
+                    else { if (j < Ka) xa = __builtin_fma(x[j], bs[j], xa); else xm = __builtin_fma(x[j], bs[j], xm); }
+                }
+            } else {
+#pragma unroll 4
+                for (int j = 0; j < KP; ++j) {
+                    const double xv = xp[j * W], bv = lds.th[3 + S + j];
+                    if (MODE == 0) xa = __builtin_fma(xv, bv, xa);
+                    else if (MODE == 1) xm = __builtin_fma(xv, bv, xm);
+                    else { if (j < Ka) xa = __builtin_fma(xv, bv, xa); else xm = __builtin_fma(xv, bv, xm); }
+                }
             }
             const double ksc = lds.ks[c], mcc = lds.mc[c];
             double gtr, qv = 0.0;
@@ -135,16 +180,10 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
     }
     // reductions over the time axis
     const double sse_t = bfly_sum(sse);
-    double s1 = rt1, s2v = rt2;
-#pragma unroll
-    for (int off = 1; off < W; off <<= 1) {
-        const double o1 = __shfl_down(s1, off, W), o2 = __shfl_down(s2v, off, W);
-        if (lane + off < W) { s1 = s1 + o1; s2v = s2v + o2; }
-    }
+    const double s1 = suffix_scan(rt1), s2v = suffix_scan(rt2);
     lds.tot1[lane] = s1; lds.tot2[lane] = s2v;
     if (lane == 0) { lds.tot1[W] = 0.0; lds.tot2[W] = 0.0; }
-#pragma unroll
-    for (int j = 0; j < KP; ++j) lds.accT[j * W + lane] = acc[j];
+    column_sums<KP, PPL>(acc, lds);
     TSF_WAVE_SYNC();
     const double TA = lds.tot1[0], TB = lds.tot2[0];
 
@@ -201,7 +240,6 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
 
 #pragma unroll
     for (int s = 0; s < PPL; ++s) g[s] = 0.0;
-    double sK_all = 0.0;
     if (GROWTH == 1) {
         // sequential suffix of the adjusted per-segment sums: gd[c-1] = nis * sum_{c'>=c} D1[c']
         double sK = 0.0;
@@ -211,8 +249,7 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
             for (int s = 0; s < PPL; ++s)
                 if (lane + s * W == 3 + (c - 1)) g[s] = nis * sK;
         }
-        sK_all = sK + lds.ab[0];
-        gk = nis * sK_all;
+        gk = nis * (sK + lds.ab[0]);
     } else {
         gk = nis * TA;
         gm = nis * TB;
@@ -241,10 +278,8 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
             gv = gd + sgn / sv.tau;
         } else if (p < sv.P) {
             const int j = p - 3 - S;
-            double a = lds.accT[j * W];
-            for (int L = 1; L < W; ++L) a = a + lds.accT[j * W + L];
             const double pr = sp->prior[j];
-            gv = nis * a + th[s] / (pr * pr);
+            gv = nis * lds.accR[j] + th[s] / (pr * pr);
         }
         g[s] = gv;
         bad = bad || !finite_f64(gv);
