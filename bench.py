@@ -159,6 +159,7 @@ def main():
                      'fp64_frac_of_vector_peak': tflops / FP64_PEAK_TFLOPS},
         'optimizer': {'mean_iters': float(n_iter.mean()), 'mean_evals': float(n_eval.mean()),
                       'total_evals': int(n_eval.sum()),
+                      'evals_p50_p90_p99_max': [float(v) for v in np.percentile(n_eval, [50, 90, 99, 100])],
                       'status_counts': {str(int(k)): int(v) for k, v in
                                         zip(*np.unique(status, return_counts=True))}},
     }
