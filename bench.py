@@ -45,9 +45,13 @@ def oracle_spec(spec):
     from oracle import canon_lib as cl
     seas = [(s['period'], s['fourier_order'], s.get('mode', spec.seasonality_mode),
              s.get('prior_scale', spec.seasonality_prior_scale)) for s in spec.seasonalities]
+    # cfg2 is linear growth + additive columns on an aligned panel: the product evaluates the
+    # data term in quadratic (Gram) form there unless eval_form forces the residual form; the
+    # checker follows the same choice (oracle eval_mode)
     return cl.make_spec(growth=spec.growth, n_changepoints=spec.n_changepoints,
                         changepoint_range=spec.changepoint_range,
-                        changepoint_prior_scale=spec.changepoint_prior_scale, seasonalities=seas)
+                        changepoint_prior_scale=spec.changepoint_prior_scale, seasonalities=seas,
+                        eval_mode=int(spec.lbfgs.get('eval_form', 0) != 1))
 
 
 def cpu_baseline(spec, ds, y, fut, budget_s=12.0):

@@ -58,6 +58,7 @@ extern "C" {
 enum { TSF_GROWTH_LINEAR = 0, TSF_GROWTH_LOGISTIC = 1 };
 enum { TSF_MODE_ADDITIVE = 0, TSF_MODE_MULTIPLICATIVE = 1 };
 enum { TSF_Y_F64 = 0, TSF_Y_F32 = 1, TSF_Y_I32 = 2 };
+enum { TSF_EVAL_AUTO = 0, TSF_EVAL_RESIDUAL = 1, TSF_EVAL_QUADRATIC = 2 };
 
 /* per-series status: >= 0 are Stan's optimiser termination codes */
 enum {
@@ -94,6 +95,14 @@ typedef struct {
     double tol_grad;                        /* 1e-8 */
     double tol_rel_grad;                    /* 1e7  (x DBL_EPSILON) */
     double tol_param;                       /* 1e-8 */
+    /* How the normal likelihood's data term is evaluated (same function, different rounding):
+     * TSF_EVAL_RESIDUAL sums residuals over the T rows at every evaluation; TSF_EVAL_QUADRATIC
+     * uses SSE(theta) = s0 - 2 c.D + D.(Z^T Z) D around a re-centred reference point -- only
+     * possible where the mean is linear in (k, m, delta, beta): linear growth, every column
+     * additive, aligned panel, history == 5.  TSF_EVAL_AUTO picks QUADRATIC where possible. */
+    int32_t eval_form;                      /* TSF_EVAL_AUTO */
+    int32_t recenter_every;                 /* 32: re-centre at least every n accepted iterations */
+    double recenter_ratio;                  /* 0.25: ... and when |Z D|^2 > ratio * s0 */
 } tsf_spec;
 
 /* What setup derives from one timestamp vector ("grid").  One per call for aligned panels,

@@ -38,7 +38,9 @@ class CnSpec(ctypes.Structure):
                 ('max_iter', ctypes.c_int32), ('history', ctypes.c_int32),
                 ('init_alpha', ctypes.c_double), ('tol_obj', ctypes.c_double),
                 ('tol_rel_obj', ctypes.c_double), ('tol_grad', ctypes.c_double),
-                ('tol_rel_grad', ctypes.c_double), ('tol_param', ctypes.c_double)]
+                ('tol_rel_grad', ctypes.c_double), ('tol_param', ctypes.c_double),
+                ('eval_mode', ctypes.c_int32), ('recenter_every', ctypes.c_int32),
+                ('recenter_ratio', ctypes.c_double)]
 
 
 class CnFitInfo(ctypes.Structure):
@@ -78,6 +80,8 @@ def lib():
                                  ctypes.POINTER(f64), vp]
         L.cn_fit.argtypes = [ctypes.POINTER(CnSpec), i32, vp, vp, f64, f64, vp, vp, vp,
                              ctypes.POINTER(CnFitInfo)]
+        L.cn_fit_checked.argtypes = [ctypes.POINTER(CnSpec), i32, vp, vp, f64, f64, vp, vp,
+                                     ctypes.POINTER(CnFitInfo), vp]
         L.cn_predict.argtypes = [ctypes.POINTER(CnSpec), ctypes.POINTER(CnFitInfo), vp, vp, i32,
                                  vp, f64, f64, vp, vp, vp]
         L.cn_det_exp.argtypes = [f64]
@@ -118,7 +122,8 @@ def make_spec(growth='linear', n_changepoints=25, changepoint_range=0.8,
         sp.extra_prior[i] = float(prior)
     for k, v in opt.items():
         if k not in ('max_iter', 'history', 'init_alpha', 'tol_obj', 'tol_rel_obj', 'tol_grad',
-                     'tol_rel_grad', 'tol_param'):
+                     'tol_rel_grad', 'tol_param', 'eval_mode', 'recenter_every',
+                     'recenter_ratio'):
             raise TypeError('unknown option %r' % k)
         setattr(sp, k, v)
     return sp
@@ -191,7 +196,21 @@ def fit(sp, ds_ns, y, floor=0.0, cap=0.0, extra=None):
     P = 3 + info.S + info.K
     return {'theta': theta[:P].copy(), 't_change': tch[:info.S].copy(), 'info': info,
             'status': info.status, 'status_name': STATUS_NAMES.get(info.status, '?'),
-            'n_iter': info.n_iter, 'n_eval': info.n_eval, 'f': info.f}
+            'n_iter': info.n_iter, 'n_eval': info.n_eval, 'n_resid': info.pad_, 'f': info.f}
+
+
+def fit_checked(sp, ds_ns, y):
+    """Quadratic-form fit (linear growth, additive columns) in which every evaluation is also
+    done in residual form; returns (fit dict, max rel |df|, max rel |dg|_2)."""
+    ds_ns, y = _i64(ds_ns), _f64(y)
+    theta = np.zeros(128)
+    info = CnFitInfo()
+    chk = np.zeros(2)
+    lib().cn_fit_checked(ctypes.byref(sp), len(ds_ns), ds_ns.ctypes.data, y.ctypes.data, 0.0, 0.0,
+                         None, theta.ctypes.data, ctypes.byref(info), chk.ctypes.data)
+    P = 3 + info.S + info.K
+    return ({'theta': theta[:P].copy(), 'status': info.status, 'n_iter': info.n_iter,
+             'n_eval': info.n_eval, 'n_resid': info.pad_, 'f': info.f}, chk[0], chk[1])
 
 
 def predict(sp, fitres, ds_future_ns, floor=0.0, cap=0.0, extra_future=None):

@@ -65,6 +65,11 @@ typedef struct {
     int32_t history;                /* 5 */
     double init_alpha;              /* 1e-3 */
     double tol_obj, tol_rel_obj, tol_grad, tol_rel_grad, tol_param;
+    int32_t eval_mode;              /* 0 residual form always; 1 quadratic (Gram) form where the
+                                       model is linear in (k, m, delta, beta): linear growth,
+                                       all columns additive */
+    int32_t recenter_every;         /* quadratic form: re-centre at least every n accepted iters */
+    double recenter_ratio;          /* ... and whenever |Z(theta-ref)|^2 > ratio * SSE(ref) */
 } cn_spec;
 
 typedef struct {
@@ -98,6 +103,15 @@ typedef struct {
     double k0, m0;
     int constant_y;
     int n_eval;
+    /* raw data-term pieces of the last residual-form evaluation: SSE and Z^T r */
+    double last_sse, last_ztr[CN_MAX_P];
+    /* quadratic (Gram) form state */
+    int gram, since_rc, n_resid;
+    double *M;               /* [P][P] Gram matrix Z^T Z (row/column 2 = log sigma: zero) */
+    double ref[CN_MAX_P], cvec[CN_MAX_P], s0, last_q2;
+    /* optional cross-check of every quadratic-form evaluation against the residual form */
+    int check;
+    double chk_f, chk_g;     /* max |df| / max(1,|f|),  max |dg|_2 / |g|_2 */
 } cn_series;
 
 /* ---- canonical reductions ----------------------------------------------------------- */
@@ -167,7 +181,7 @@ static int spec_K(const cn_spec *sp)
 static void free_series(cn_series *se)
 {
     if (!se) return;
-    free(se->t); free(se->y); free(se->X); free(se->cidx); free(se);
+    free(se->t); free(se->y); free(se->X); free(se->cidx); free(se->M); free(se);
 }
 
 /* fbprophet fourier_series argument: 2.0*(i+1)*np.pi*t/period with
@@ -400,7 +414,14 @@ static int cn_eval(cn_series *se, const double *th, double *f_out, double *g)
     double gk, gm;
     double *gd = g + 3;
     if (se->growth == 0) {
-        for (int j = 0; j < S; ++j) gd[j] = nis * (SA[j] - se->t_change[j] * SB[j]);
+        for (int j = 0; j < S; ++j) {
+            const double zr = SA[j] - se->t_change[j] * SB[j];
+            se->last_ztr[3 + j] = zr;
+            gd[j] = nis * zr;
+        }
+        se->last_ztr[0] = TA; se->last_ztr[1] = TB; se->last_ztr[2] = 0.0;
+        for (int j = 0; j < K; ++j) se->last_ztr[3 + S + j] = ACC[j];
+        se->last_sse = sse;
         gk = nis * TA;
         gm = nis * TB;
     } else {
@@ -438,6 +459,217 @@ static int cn_eval(cn_series *se, const double *th, double *f_out, double *g)
     if (!isfinite(f)) return 2;
     for (int p = 0; p < se->P; ++p) if (!isfinite(g[p])) return 3;
     return 0;
+}
+
+
+/* ---- quadratic (Gram) form of the data term, linear growth + additive columns only --------
+ *
+ * With linear growth and only additive columns the mean is LINEAR in (k, m, delta, beta):
+ * mu = Z theta, Z = [t, 1, (t - s_j)+ ..., X].  Around a reference point `ref` with residual
+ * r_ref = y - Z ref, s0 = |r_ref|^2, c = Z^T r_ref (all three produced by ONE residual-form
+ * evaluation, cn_eval):
+ *     SSE(theta)   = s0 - 2 c.D + D.M D,     Z^T r(theta) = c - M D,     D = theta - ref,
+ * with M = Z^T Z.  This is the same normal log-likelihood prophet.stan evaluates (algebra, not
+ * an approximation); the rounding differs from the residual form, and stays at the level of
+ * the residual form's as long as |Z D|^2 is not large against s0 -- hence the re-centring rule
+ * in cn_lbfgs (a residual-form evaluation at the accepted iterate becomes the new reference).
+ *
+ * Canonical order: M's column q is "Z^T r" of the residual machinery with r := column q of Z
+ * (cn_ztr below: same chunk partials, scans and butterflies as cn_eval); the mat-vec
+ * (M D)[p] is four interleaved fma chains over q (q mod 4), combined (a0 + a1) + (a2 + a3).
+ */
+
+/* Z^T r and r.r for a given weight vector r[T], in cn_eval's exact operation order */
+static void cn_ztr(const cn_series *se, const double *r_in, double *ztr, double *sse_out)
+{
+    const int T = se->T, NT = se->NT, S = se->S, K = se->K;
+    double sseL[CN_W], tot1[CN_W], tot2[CN_W];
+    double tp1[CN_MAX_S + 1], tp2[CN_MAX_S + 1];
+    static __thread double accL[CN_W][CN_MAX_P];
+    for (int j = 0; j < S; ++j) tp1[j] = tp2[j] = 0.0;
+    for (int L = 0; L < CN_W; ++L) {
+        const int lo = L * NT, hi = (lo + NT < T) ? lo + NT : T;
+        double sse = 0.0, rt1 = 0.0, rt2 = 0.0;
+        double *acc = accL[L];
+        for (int j = 0; j < K; ++j) acc[j] = 0.0;
+        for (int i = hi - 1; i >= lo; --i) {
+            const int c = se->cidx[i];
+            const double *x = se->X + (size_t)i * K;
+            const double r = r_in[i];
+            sse = fma(r, r, sse);
+            for (int j = 0; j < K; ++j) acc[j] = fma(x[j], r, acc[j]);
+            rt1 = fma(r, se->t[i], rt1);
+            rt2 = rt2 + r;
+            const int cprev = (i > 0) ? se->cidx[i - 1] : 0;
+            for (int j = cprev; j < c; ++j) { tp1[j] = rt1; tp2[j] = rt2; }
+        }
+        sseL[L] = sse; tot1[L] = rt1; tot2[L] = rt2;
+    }
+    *sse_out = bfly(sseL);
+    suffix_scan(tot1);
+    suffix_scan(tot2);
+    ztr[0] = tot1[0]; ztr[1] = tot2[0]; ztr[2] = 0.0;
+    for (int j = 0; j < S; ++j) {
+        int fj = 0;
+        while (fj < T && se->cidx[fj] <= j) ++fj;
+        const int Lj = fj / NT;
+        const double e1 = (Lj + 1 < CN_W) ? tot1[Lj + 1] : 0.0;
+        const double e2 = (Lj + 1 < CN_W) ? tot2[Lj + 1] : 0.0;
+        const double SA = tp1[j] + e1, SB = tp2[j] + e2;
+        ztr[3 + j] = SA - se->t_change[j] * SB;
+    }
+    for (int j = 0; j < K; ++j) {
+        double col[CN_W];
+        for (int L = 0; L < CN_W; ++L) col[L] = accL[L][j];
+        ztr[3 + S + j] = bfly_cols(col);
+    }
+}
+
+/* column p of Z at row i */
+static double cn_zcol(const cn_series *se, int p, int i)
+{
+    if (p == 0) return se->t[i];
+    if (p == 1) return 1.0;
+    if (p == 2) return 0.0;
+    if (p < 3 + se->S) return (se->cidx[i] > p - 3) ? se->t[i] - se->t_change[p - 3] : 0.0;
+    return se->X[(size_t)i * se->K + (p - 3 - se->S)];
+}
+
+static void cn_build_gram(cn_series *se)
+{
+    const int P = se->P, T = se->T;
+    se->M = (double *)calloc((size_t)P * P, sizeof(double));
+    double *z = (double *)calloc(T, sizeof(double));
+    double col[CN_MAX_P], dummy;
+    for (int q = 0; q < P; ++q) {
+        if (q == 2) continue;
+        for (int i = 0; i < T; ++i) z[i] = cn_zcol(se, q, i);
+        cn_ztr(se, z, col, &dummy);
+        for (int p = 0; p < P; ++p) se->M[(size_t)p * P + q] = col[p];     /* M[p][q] */
+    }
+    free(z);
+}
+
+static void cn_set_ref(cn_series *se, const double *th)
+{
+    for (int p = 0; p < CN_MAX_P; ++p) { se->ref[p] = 0.0; se->cvec[p] = 0.0; }
+    for (int p = 0; p < se->P; ++p) { se->ref[p] = th[p]; se->cvec[p] = se->last_ztr[p]; }
+    se->ref[2] = 0.0; se->cvec[2] = 0.0;
+    se->s0 = se->last_sse;
+    se->since_rc = 0;
+    se->n_resid++;
+}
+
+/* f and gradient from the data-term pieces (SSE, Z^T r), quadratic-path form: the prior
+ * terms use reciprocals computed once per series (1/25, 1/tau, 1/prior, 1/prior^2) and one
+ * uniform per-parameter gradient formula
+ *     g_p = fma(theta_p, lc_p, nis * ztr_p) + sgn(theta_p) * sc_p        (p != 2)
+ * (lc_p = 1/25 for k,m; 0 for delta; 1/prior^2 for beta;  sc_p = 1/tau for delta, else 0). */
+static int cn_assemble_q(const cn_series *se, const double *th, double sse, const double *ztr,
+                         double *f_out, double *g)
+{
+    const int T = se->T, S = se->S, P = se->P;
+    const double k = th[0], m = th[1], ls = th[2];
+    const double C25 = 1.0 / 25.0, inv_tau = 1.0 / se->tau;
+    const double sigma = det_exp(ls);
+    const double s2 = sigma * sigma;
+    const double inv_s2 = 1.0 / s2;
+    double pa[CN_W], pb[CN_W];
+    for (int l = 0; l < CN_W; ++l) { pa[l] = 0.0; pb[l] = 0.0; }
+    for (int p = 0; p < P; ++p) {
+        const int l = p % CN_W;
+        if (p >= 3 && p < 3 + S) pa[l] = pa[l] + fabs(th[p]);
+        if (p >= 3 + S) { const double qq = th[p] * (1.0 / se->prior[p - 3 - S]); pb[l] = fma(qq, qq, pb[l]); }
+    }
+    const double sabs = bfly(pa), sb = bfly(pb);
+    double f = ((0.5 * k) * k) * C25 + ((0.5 * m) * m) * C25;
+    f = f + sabs * inv_tau;
+    f = f + 2.0 * s2;
+    f = f + 0.5 * sb;
+    f = f + (double)T * ls;
+    f = f + (0.5 * sse) * inv_s2;
+    for (int p = 0; p < CN_MAX_P; ++p) g[p] = 0.0;
+    const double nis = -inv_s2;
+    for (int p = 0; p < P; ++p) {
+        if (p == 2) { g[2] = ((double)T - sse * inv_s2) + 4.0 * s2; continue; }
+        double lc, sc;
+        if (p < 2) { lc = C25; sc = 0.0; }
+        else if (p < 3 + S) { lc = 0.0; sc = inv_tau; }
+        else { const double pr = se->prior[p - 3 - S]; lc = 1.0 / (pr * pr); sc = 0.0; }
+        const double sgn = (double)((th[p] > 0.0) - (th[p] < 0.0));
+        g[p] = fma(th[p], lc, nis * ztr[p]) + sgn * sc;
+    }
+    *f_out = f;
+    if (!isfinite(f)) return 2;
+    for (int p = 0; p < P; ++p) if (!isfinite(g[p])) return 3;
+    return 0;
+}
+
+/* residual-form evaluation on the quadratic path (initial point and re-centring): r = y - mu
+ * with mu = (ks[c] t + mc[c]) + x.beta exactly as cn_eval computes it for linear growth /
+ * additive columns, then Z^T r by cn_ztr, then cn_assemble_q.  Leaves SSE and Z^T r in
+ * se->last_sse / se->last_ztr for cn_set_ref. */
+static int cn_resid_q(cn_series *se, const double *th, double *f_out, double *g)
+{
+    const int T = se->T, S = se->S, K = se->K;
+    const double *delta = th + 3, *beta = th + 3 + S;
+    se->n_eval++;
+    double ks[CN_MAX_S + 1], mc[CN_MAX_S + 1];
+    ks[0] = th[0]; mc[0] = th[1];
+    for (int j = 0; j < S; ++j) {
+        ks[j + 1] = ks[j] + delta[j];
+        mc[j + 1] = mc[j] + ((-se->t_change[j]) * delta[j]);
+    }
+    double *r = (double *)malloc(sizeof(double) * T);
+    for (int i = 0; i < T; ++i) {
+        const double *x = se->X + (size_t)i * K;
+        double xa = 0.0;
+        for (int j = 0; j < K; ++j) xa = fma(x[j], beta[j], xa);
+        const double gtr = fma(ks[se->cidx[i]], se->t[i], mc[se->cidx[i]]);
+        r[i] = se->y[i] - (gtr + xa);
+    }
+    cn_ztr(se, r, se->last_ztr, &se->last_sse);
+    free(r);
+    return cn_assemble_q(se, th, se->last_sse, se->last_ztr, f_out, g);
+}
+
+static int cn_eval_gram(cn_series *se, const double *th, double *f_out, double *g)
+{
+    const int P = se->P;
+    se->n_eval++;
+    double D[CN_MAX_P], v[CN_MAX_P], ztr[CN_MAX_P];
+    for (int p = 0; p < CN_MAX_P; ++p) { D[p] = 0.0; v[p] = 0.0; ztr[p] = 0.0; }
+    for (int p = 0; p < P; ++p) D[p] = (p == 2) ? 0.0 : th[p] - se->ref[p];
+    for (int p = 0; p < P; ++p) {
+        double a[4] = {0.0, 0.0, 0.0, 0.0};
+        const double *row = se->M + (size_t)p * P;
+        for (int q = 0; q < P; ++q) a[q & 3] = fma(row[q], D[q], a[q & 3]);
+        v[p] = (a[0] + a[1]) + (a[2] + a[3]);
+    }
+    const double q2 = dotc(D, v);
+    const double cd = dotc(se->cvec, D);
+    const double sse = fma(-2.0, cd, se->s0) + q2;
+    se->last_q2 = q2;
+    for (int p = 0; p < P; ++p) ztr[p] = se->cvec[p] - v[p];
+    return cn_assemble_q(se, th, sse, ztr, f_out, g);
+}
+
+static int cn_eval_any(cn_series *se, const double *th, double *f_out, double *g)
+{
+    if (!se->gram) return cn_eval(se, th, f_out, g);
+    const int rc = cn_eval_gram(se, th, f_out, g);
+    if (se->check && rc == 0) {
+        double fr, gr[CN_MAX_P], dn = 0.0, gn = 0.0;
+        const int ne = se->n_eval;
+        if (cn_eval(se, th, &fr, gr) == 0) {
+            for (int p = 0; p < se->P; ++p) { dn += (g[p] - gr[p]) * (g[p] - gr[p]); gn += gr[p] * gr[p]; }
+            const double ef = fabs(*f_out - fr) / fmax(1.0, fabs(fr)), eg = sqrt(dn) / sqrt(gn);
+            if (ef > se->chk_f) se->chk_f = ef;
+            if (eg > se->chk_g) se->chk_g = eg;
+        }
+        se->n_eval = ne;
+    }
+    return rc;
 }
 
 /* ---- Stan L-BFGS ---------------------------------------------------------------------- */
@@ -508,7 +740,7 @@ static int line_search(cn_series *se, double *alpha_io, double *x1, double *f1_o
         int bad = 0;
         for (;;) {   /* evaluation with Stan's non-finite handling */
             axpy_to(x1, x0, alpha, p);
-            const int ret = cn_eval(se, x1, &f1, g1);
+            const int ret = cn_eval_any(se, x1, &f1, g1);
             if (ret == 0) break;
             if (!zoom) {
                 if (lsRestarts >= maxLSRestarts) { bad = 1; break; }
@@ -568,11 +800,12 @@ static int cn_lbfgs(cn_series *se, const cn_spec *o, const double *theta0, doubl
     memset(pk_1, 0, sizeof(pk_1)); memset(gk_1, 0, sizeof(gk_1)); memset(xk_1, 0, sizeof(xk_1));
     memcpy(xk, theta0, sizeof(xk));
     se->n_eval = 0;
-    if (cn_eval(se, xk, &fk, gk)) {
+    if (se->gram ? cn_resid_q(se, xk, &fk, gk) : cn_eval(se, xk, &fk, gk)) {
         memcpy(theta_out, theta0, sizeof(xk));
         res->status = CN_INIT_NONFINITE; res->n_iter = 0; res->n_eval = se->n_eval; res->f = fk;
         return 0;
     }
+    if (se->gram) cn_set_ref(se, xk);
     for (int i = 0; i < NP; ++i) pk[i] = -gk[i];
     while (ret == 0) {
         int resetB;
@@ -601,6 +834,18 @@ static int cn_lbfgs(cn_series *se, const cn_spec *o, const double *theta0, doubl
             double tx = xk[i]; xk[i] = xk_1[i]; xk_1[i] = tx;
             double tg = gk[i]; gk[i] = gk_1[i]; gk_1[i] = tg;
             double tp = pk[i]; pk[i] = pk_1[i]; pk_1[i] = tp;
+        }
+        if (se->gram) {
+            /* re-centring rule: the accepted iterate is re-evaluated in residual form and
+             * becomes the reference when the quadratic term has grown against s0, or after
+             * recenter_every accepted iterations */
+            se->since_rc++;
+            if (se->last_q2 > o->recenter_ratio * se->s0 || se->since_rc >= o->recenter_every) {
+                double fr, gr[CN_MAX_P];
+                if (cn_resid_q(se, xk, &fr, gr) == 0) {
+                    fk = fr; memcpy(gk, gr, sizeof(gr)); cn_set_ref(se, xk);
+                }
+            }
         }
         for (int i = 0; i < NP; ++i) { sk[i] = xk[i] - xk_1[i]; yk[i] = gk[i] - gk_1[i]; }
         const double gradNorm = sqrt(dotc(gk, gk));
@@ -679,6 +924,7 @@ void cn_default_spec(cn_spec *sp)
     sp->growth = 0; sp->n_changepoints = 25; sp->changepoint_range = 0.8; sp->tau = 0.05;
     sp->max_iter = 10000; sp->history = 5; sp->init_alpha = 1e-3; sp->tol_obj = 1e-12;
     sp->tol_rel_obj = 1e4; sp->tol_grad = 1e-8; sp->tol_rel_grad = 1e7; sp->tol_param = 1e-8;
+    sp->eval_mode = 0; sp->recenter_every = 32; sp->recenter_ratio = 0.25;
 }
 
 int cn_spec_size(void) { return (int)sizeof(cn_spec); }
@@ -741,7 +987,9 @@ int cn_fit(const cn_spec *sp, int T, const int64_t *ds, const double *y, double 
         th[2] = -20.72326583694641;
         info->status = CN_CONSTANT; info->n_iter = 0; info->n_eval = 0; info->f = 0.0;
     } else {
+        if (sp->eval_mode == 1 && sp->growth == 0 && se->Ka == se->K) { se->gram = 1; cn_build_gram(se); }
         cn_lbfgs(se, sp, th0, th, info);
+        info->pad_ = se->n_resid;       /* residual-form evaluations (quadratic form only) */
     }
     to_original(se, th, theta_out);
     if (tchange_out) memcpy(tchange_out, se->t_change, sizeof(double) * se->S);
@@ -796,6 +1044,33 @@ int cn_predict(const cn_spec *sp, const cn_fitinfo *info, const double *theta,
         if (trend_out) trend_out[h] = trend;
         yhat[h] = trend * (1.0 + xm) + xa * info->y_scale;
     }
+    return 0;
+}
+
+/* Quadratic-form fit with every evaluation cross-checked against the residual form.
+ * chk_out[0] = max |f_quad - f_resid| / max(1, |f_resid|), chk_out[1] = max relative 2-norm
+ * gradient difference, over all evaluations of the fit. */
+int cn_fit_checked(const cn_spec *sp, int T, const int64_t *ds, const double *y, double floor_,
+                   double cap, const double *extra, double *theta_out, cn_fitinfo *info,
+                   double *chk_out)
+{
+    int err;
+    memset(info, 0, sizeof(*info));
+    cn_series *se = cn_prepare(sp, T, ds, y, floor_, cap, extra, &err);
+    if (!se) { info->status = err; return 0; }
+    fill_info(se, info);
+    double th0[CN_MAX_P], th[CN_MAX_P];
+    memset(th0, 0, sizeof(th0));
+    th0[0] = se->k0; th0[1] = se->m0;
+    chk_out[0] = chk_out[1] = 0.0;
+    if (se->constant_y || !(sp->growth == 0 && se->Ka == se->K)) { info->status = CN_ERR_SIZE; free_series(se); return 0; }
+    se->gram = 1; se->check = 1;
+    cn_build_gram(se);
+    cn_lbfgs(se, sp, th0, th, info);
+    info->pad_ = se->n_resid;
+    chk_out[0] = se->chk_f; chk_out[1] = se->chk_g;
+    to_original(se, th, theta_out);
+    free_series(se);
     return 0;
 }
 

@@ -61,7 +61,7 @@ def fixture():
 
 def synthetic():
     out = {}
-    for name in helpers.CASES:
+    for name in list(helpers.CASES) + helpers.RESID_VARIANTS:
         spec, ds, y, floor, cap, extra, fut, extra_future = helpers.make_case(name)
         csp = helpers.oracle_spec(spec)
         th, yh, it, st, ev = [], [], [], [], []

@@ -74,8 +74,10 @@ def test_design_and_single_evaluation(env, case):
         assert n_bit_diff(f[n], fo) == 0 and n_bit_diff(g[n], go) == 0
 
 
-@pytest.mark.parametrize('case', list(helpers.CASES))
+@pytest.mark.parametrize('case', list(helpers.CASES) + helpers.RESID_VARIANTS)
 def test_fit_predict_against_oracle_and_golden(env, case):
+    """case 'name@resid' = the same case with eval_form forced to RESIDUAL (cases whose default
+    is the quadratic form: linear growth + additive columns)."""
     fc, cl = env
     spec, ds, y, floor, cap, extra, fut, exf = helpers.make_case(case)
     csp = helpers.oracle_spec(spec)
@@ -170,7 +172,7 @@ def test_edge_cases(env):
     rr = fc.fit_ragged(sp90, off, dsr, yr)
     assert rr.status[0] == _lib.ST_TOO_FEW and (rr.status[1:] > 0).all()
     assert list(rr.grid['S']) == [0, 15, 25, 25]
-    c90 = helpers.oracle_spec(sp90)
+    c90 = helpers.oracle_spec(sp90, aligned=False)      # ragged panels use the residual form
     for n in (1, 2, 3):
         o = cl.fit(c90, dsr[off[n]:off[n + 1]], yr[off[n]:off[n + 1]])
         S = o['info'].S

@@ -20,6 +20,7 @@ MAX_P = 128
 GROWTH_LINEAR, GROWTH_LOGISTIC = 0, 1
 MODE_ADDITIVE, MODE_MULTIPLICATIVE = 0, 1
 Y_F64, Y_F32, Y_I32 = 0, 1, 2
+EVAL_AUTO, EVAL_RESIDUAL, EVAL_QUADRATIC = 0, 1, 2
 
 ST_ABSX, ST_ABSF, ST_RELF, ST_ABSGRAD, ST_RELGRAD, ST_MAXIT = 10, 20, 21, 30, 31, 40
 ST_CONSTANT, ST_LSFAIL, ST_INIT_NONFINITE, ST_TOO_FEW, ST_CAP = 50, -1, -2, -10, -11
@@ -42,7 +43,9 @@ class TsfSpec(ctypes.Structure):
                 ('max_iter', ctypes.c_int32), ('history', ctypes.c_int32),
                 ('init_alpha', ctypes.c_double), ('tol_obj', ctypes.c_double),
                 ('tol_rel_obj', ctypes.c_double), ('tol_grad', ctypes.c_double),
-                ('tol_rel_grad', ctypes.c_double), ('tol_param', ctypes.c_double)]
+                ('tol_rel_grad', ctypes.c_double), ('tol_param', ctypes.c_double),
+                ('eval_form', ctypes.c_int32), ('recenter_every', ctypes.c_int32),
+                ('recenter_ratio', ctypes.c_double)]
 
 
 class TsfGridInfo(ctypes.Structure):

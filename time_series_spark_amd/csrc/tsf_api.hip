@@ -15,6 +15,7 @@
 
 #include "tsf_aux_kernels.h"
 #include "tsf_fit_kernels.h"
+#include "tsf_quad_kernels.h"
 #include "tsf_launch.h"
 
 using namespace tsf;
@@ -89,6 +90,7 @@ extern "C" void tsf_spec_default(tsf_spec *s)
     s->changepoint_prior_scale = 0.05;
     s->max_iter = 10000; s->history = 5; s->init_alpha = 1e-3; s->tol_obj = 1e-12;
     s->tol_rel_obj = 1e4; s->tol_grad = 1e-8; s->tol_rel_grad = 1e7; s->tol_param = 1e-8;
+    s->eval_form = TSF_EVAL_AUTO; s->recenter_every = 32; s->recenter_ratio = 0.25;
 }
 
 extern "C" int tsf_spec_size(void) { return (int)sizeof(tsf_spec); }
@@ -125,6 +127,9 @@ static int build_devspec(tsf_ctx *ctx, const tsf_spec *s, DevSpec *d, int *mode_
     if (!(s->changepoint_range >= 0.0 && s->changepoint_range <= 1.0)) return fail(ctx, "changepoint_range must be in [0,1]");
     if (!(s->changepoint_prior_scale > 0.0)) return fail(ctx, "changepoint_prior_scale must be > 0");
     if (s->history < 1 || s->history > MAXH) return fail(ctx, "history must be in [1,8]");
+    if (s->eval_form < TSF_EVAL_AUTO || s->eval_form > TSF_EVAL_QUADRATIC) return fail(ctx, "bad eval_form");
+    if (s->eval_form != TSF_EVAL_RESIDUAL && (s->recenter_every < 1 || !(s->recenter_ratio > 0.0)))
+        return fail(ctx, "recenter_every must be >= 1 and recenter_ratio > 0");
     const int K = tsf_spec_K(s);
     if (K < 1) return fail(ctx, "model needs at least one design column (fbprophet adds a zero column; pass one extra column of zeros)");
     if (K > TSF_MAX_K || 3 + s->n_changepoints + K > TSF_MAX_P) return fail(ctx, "too many parameters (3+S+K must be <= 128, K <= 64)");
@@ -168,12 +173,13 @@ static int build_devspec(tsf_ctx *ctx, const tsf_spec *s, DevSpec *d, int *mode_
 // ---- workspace ------------------------------------------------------------------------------
 
 struct WsLayout {
-    size_t gtab, stab, tw, cw, Xw, yw, total;
+    size_t gtab, stab, tw, cw, Xw, yw, Mg, rbuf, counter, total;
 };
 
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
-static WsLayout ws_layout(int64_t N, int64_t n_grids, int NTmax, int KP)
+static WsLayout ws_layout(int64_t N, int64_t n_grids, int NTmax, int KP, int quad_P4 = 0,
+                          int quad_slots = 0)
 {
     WsLayout l;
     size_t off = 0;
@@ -183,6 +189,9 @@ static WsLayout ws_layout(int64_t N, int64_t n_grids, int NTmax, int KP)
     l.cw = off; off = align_up(off + sizeof(uint16_t) * (size_t)n_grids * NTmax * W);
     l.Xw = off; off = align_up(off + sizeof(double) * (size_t)n_grids * NTmax * KP * W);
     l.yw = off; off = align_up(off + sizeof(double) * (size_t)N * NTmax * W);
+    l.Mg = off; off = align_up(off + sizeof(double) * (size_t)quad_P4 * 2 * W);
+    l.rbuf = off; off = align_up(off + sizeof(double) * (size_t)quad_slots * NTmax * W);
+    l.counter = off; off = align_up(off + 256);
     l.total = off;
     return l;
 }
@@ -193,6 +202,27 @@ static int ensure_ws(tsf_ctx *ctx, size_t bytes)
     if (ctx->ws) { HIP_TRY(ctx, hipFree(ctx->ws)); ctx->ws = nullptr; ctx->ws_bytes = 0; }
     HIP_TRY(ctx, hipMalloc(&ctx->ws, bytes));
     ctx->ws_bytes = bytes;
+    return 0;
+}
+
+// grid / LDS plan of the quadratic-form kernel for this device
+static int quad_plan(tsf_ctx *ctx, const DevSpec &hs, int64_t N, QuadPlan *qp)
+{
+    hipDeviceProp_t prop;
+    HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    const int P = 3 + hs.n_cp + hs.K;
+    qp->P4 = (P + 3) & ~3;
+    qp->PPL = (hs.KP == 64) ? 2 : 1;
+    qp->NW = quad_waves_per_block();
+    const char *e = getenv("TSF_QUAD_BLOCKS_PER_CU");
+    const int per_cu = e ? atoi(e) : 2;
+    int64_t blocks = (int64_t)prop.multiProcessorCount * (per_cu > 0 ? per_cu : 2);
+    const int64_t need = (N + qp->NW - 1) / qp->NW;
+    if (blocks > need) blocks = need;
+    if (blocks < 1) blocks = 1;
+    qp->blocks = (int)blocks;
+    qp->slots = (int)blocks * qp->NW;
+    if (qp->slots < qp->P4) qp->slots = qp->P4;
     return 0;
 }
 
@@ -227,7 +257,19 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     if (Tm < 1) return fail(ctx, "no rows");
     const int NTmax = (Tm + W - 1) / W;
     const int64_t n_grids = aligned ? 1 : N;
-    const WsLayout l = ws_layout(N, n_grids, NTmax, hs.KP);
+    // quadratic (Gram) form of the data term: see tsf_quad_kernels.h
+    const bool quad_ok = aligned && hs.growth == TSF_GROWTH_LINEAR && mode == 0 && hs.history == QH &&
+                         theta_in == nullptr;
+    if (spec->eval_form == TSF_EVAL_QUADRATIC && !quad_ok && theta_in == nullptr)
+        return fail(ctx, "eval_form QUADRATIC needs linear growth, additive columns only, an aligned panel and history == 5");
+    const bool quad = quad_ok && spec->eval_form != TSF_EVAL_RESIDUAL;
+    QuadPlan qp;
+    memset(&qp, 0, sizeof(qp));
+    if (quad) {
+        rc = quad_plan(ctx, hs, N, &qp);
+        if (rc) return rc;
+    }
+    const WsLayout l = ws_layout(N, n_grids, NTmax, hs.KP, qp.P4, qp.slots);
     rc = ensure_ws(ctx, l.total);
     if (rc) return rc;
     char *ws = (char *)ctx->ws;
@@ -258,7 +300,18 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     a.theta_in = theta_in; a.grad_out = grad_out;
     const int slot = (int)(ctx->ev_count % TSF_PROFILE_RING);
     if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev0[slot], st));
-    const int lrc = pick_launch(hs.growth, mode)(hs.KP, a, theta_in != nullptr, st);
+    int lrc;
+    if (quad) {
+        QuadArgs qa;
+        qa.f = a; qa.Mg = (const double *)(ws + l.Mg); qa.rbuf = (double *)(ws + l.rbuf);
+        qa.counter = (int *)(ws + l.counter); qa.P4 = qp.P4;
+        qa.recenter_every = spec->recenter_every; qa.recenter_ratio = spec->recenter_ratio;
+        { const char *d = getenv("TSF_QUAD_STAGE"); qa.debug = d ? atoi(d) : 0; qa.dbg = nullptr; }
+        HIP_TRY(ctx, hipMemsetAsync(qa.counter, 0, sizeof(int), st));
+        lrc = launch_quad(hs.KP, qp, qa, (double *)(ws + l.Mg), st);
+    } else {
+        lrc = pick_launch(hs.growth, mode)(hs.KP, a, theta_in != nullptr, st);
+    }
     if (ctx->profiling) { HIP_TRY(ctx, hipEventRecord(ctx->ev1[slot], st)); ctx->ev_count++; }
     if (lrc != 0) {
         ctx->err = std::string("kernel launch failed: ") + (lrc > 0 ? hipGetErrorString((hipError_t)lrc) : "no kernel for this shape");

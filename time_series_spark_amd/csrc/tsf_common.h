@@ -148,7 +148,7 @@ __device__ __forceinline__ double suffix_scan(double v)
     const double t1 = readlane_f64(v, 16), t2 = readlane_f64(v, 32), t3 = readlane_f64(v, 48);
     const double s2 = t2 + t3;
     const double s1 = t1 + s2;
-    const int row = (int)threadIdx.x >> 4;
+    const int row = ((int)threadIdx.x & (W - 1)) >> 4;
     const double carry = (row == 0) ? s1 : (row == 1 ? s2 : (row == 2 ? t3 : 0.0));
     return v + carry;
 }
@@ -160,6 +160,16 @@ __device__ __forceinline__ double pdot(const double (&a)[PPL], const double (&b)
     double part = a[0] * b[0];
     if (PPL == 2) part = __builtin_fma(a[PPL - 1], b[PPL - 1], part);
     return bfly_sum(part);
+}
+
+// LDS hand-off between the lanes of ONE wave (multi-wave workgroups must not use s_barrier for
+// this): LDS operations of a wave execute in program order, so only the compiler has to be
+// kept from moving accesses across the point.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 __device__ __forceinline__ bool finite_f64(double x)

@@ -1,0 +1,724 @@
+// tsf_quad_kernels.h -- fit kernel for models that are LINEAR in (k, m, delta, beta): linear
+// growth with only additive design columns (the BASELINE cfg2 / cfg3 / cfg5 shape), aligned
+// panels.  Same model, same Stan L-BFGS as tsf_fit_kernels.h; what changes is how the normal
+// log-likelihood's data term is evaluated.
+//
+// With mu = Z theta_L (Z = [t, 1, (t - s_j)+ ..., X], shared by every series of an aligned
+// panel) and a reference point `ref` with residual r_ref = y - Z ref:
+//       SSE(theta) = s0 - 2 c.D + D.(M D),   Z^T r(theta) = c - M D,    D = theta - ref,
+//       s0 = |r_ref|^2,  c = Z^T r_ref,  M = Z^T Z  (P x P, built once per grid).
+// One evaluation is then a P x P mat-vec out of LDS instead of a pass over T x K design values:
+// ~3 k instead of ~40 k fma for cfg2, and no design-matrix traffic at all.  s0 and c come from
+// a residual-form pass (the initial point, then again whenever |Z D|^2 > recenter_ratio * s0
+// at an accepted iterate or after recenter_every accepted iterates), which keeps the rounding
+// error of the quadratic form at the level of the residual form's (measured by
+// oracle/prophet_canon.c cn_fit_checked: f agrees to ~1e-14 relative on every evaluation).
+//
+// Execution model: persistent workgroups of NW waves; M lives once per workgroup in LDS;
+// every wave pulls series indices from a global atomic counter and runs the whole L-BFGS for
+// its series (one wavefront per series, parameter p in lane p%64).  L-BFGS history is held in
+// registers.  oracle/prophet_canon.c (cn_resid_q / cn_eval_gram / cn_assemble_q / cn_lbfgs)
+// performs the identical operation sequence; tests require bit equality.
+#pragma once
+#include "tsf_fit_kernels.h"
+
+namespace tsf {
+
+constexpr int QH = 5;                   // L-BFGS history of the register-resident path
+#ifndef TSF_QUAD_WPS
+#define TSF_QUAD_WPS 2
+#endif
+constexpr int QUAD_WAVES_PER_SIMD = TSF_QUAD_WPS;   // register budget: 512 / this per lane
+
+struct QuadArgs {
+    FitArgs f;
+    const double *Mg;                   // [P4][PPL][64] Gram matrix, column-major over q
+    double *rbuf;                       // [slots][NTmax][64] residual scratch
+    int *counter;                       // work queue head (zeroed before the launch)
+    int P4;                             // P rounded up to a multiple of 4
+    int recenter_every;
+    double recenter_ratio;
+    int debug;                          // dev only: 1 = no fit, 2 = stop after the initial evaluation
+    volatile long long *dbg;            // dev only: host-coherent progress markers (or NULL)
+};
+
+template <int KP, int PPL>
+struct QuadLds {
+    double th[PPL * W + W];             // theta of the running residual pass; zero beyond P
+    double ks[NTAB + 1], mc[NTAB + 1];
+    double tp1[NTAB], tp2[NTAB];
+    double tot1[W + 1], tot2[W + 1];
+    double accR[KP];
+};
+
+__device__ __forceinline__ int lane_id() { return (int)threadIdx.x & (W - 1); }
+
+// G-column slice of the register transpose network of column_sums (tsf_fit_kernels.h)
+template <int G>
+__device__ __forceinline__ void column_sums_g(double (&acc)[G], double *accR)
+{
+    static_assert(G % 4 == 0, "column groups are multiples of 4");
+    const int lane = lane_id();
+    double c[G / 2];
+#pragma unroll
+    for (int i = 0; i < G / 2; ++i) {
+        double a = acc[2 * i], b = acc[2 * i + 1];
+        swap32(a, b);
+        c[i] = a + b;
+    }
+    double d[G / 4];
+#pragma unroll
+    for (int i = 0; i < G / 4; ++i) {
+        double a = c[2 * i], b = c[2 * i + 1];
+        swap16(a, b);
+        d[i] = row_bfly_sum(a + b);
+    }
+    if ((lane & 15) == 0) {
+        const int r = lane >> 4;
+        const int sub = (r == 0) ? 0 : (r == 1 ? 2 : (r == 2 ? 1 : 3));
+#pragma unroll
+        for (int i = 0; i < G / 4; ++i) accR[4 * i + sub] = d[i];
+    }
+}
+
+template <int KP, int G>
+__device__ __forceinline__ void column_group(const SeriesView &sv, const double *rb, int g0,
+                                             double *accR)
+{
+    const int lane = lane_id();
+    double acc[G];
+#pragma unroll
+    for (int j = 0; j < G; ++j) acc[j] = 0.0;
+    for (int q = sv.NT - 1; q >= 0; --q) {
+        if (q < sv.cnt) {
+            const double r = rb[q * W + lane];
+            const double *xp = sv.Xw + ((size_t)q * KP + g0) * W + lane;
+#pragma unroll
+            for (int j = 0; j < G; ++j) acc[j] = __builtin_fma(xp[j * W], r, acc[j]);
+        }
+    }
+    column_sums_g<G>(acc, accR + g0);
+}
+
+// Z^T r and r.r for the weights r held in rb[q*64+lane] (row lane*NT+q), in the operation
+// order of eval_fg<GROWTH 0, MODE 0>.  ztr[s]: entry p = lane + 64 s.
+template <int KP, int PPL>
+__device__ __forceinline__ void ztr_pass(const SeriesView &sv, QuadLds<KP, PPL> &wl,
+                                         const double *rb, double &sse_out, double (&ztr)[PPL])
+{
+    const int lane = lane_id();
+    const int S = sv.S;
+    double sse = 0.0, rt1 = 0.0, rt2 = 0.0;
+    for (int q = sv.NT - 1; q >= 0; --q) {
+        if (q < sv.cnt) {
+            const int idx = q * W + lane;
+            const unsigned cwv = sv.cw[idx];
+            const int c = (int)(cwv & 0xffu), cprev = (int)(cwv >> 8);
+            const double ti = sv.tw[idx];
+            const double r = rb[idx];
+            sse = __builtin_fma(r, r, sse);
+            rt1 = __builtin_fma(r, ti, rt1);
+            rt2 = rt2 + r;
+            for (int j = cprev; j < c; ++j) { wl.tp1[j] = rt1; wl.tp2[j] = rt2; }
+        }
+    }
+    sse_out = bfly_sum(sse);
+    const double s1 = suffix_scan(rt1), s2v = suffix_scan(rt2);
+    wl.tot1[lane] = s1; wl.tot2[lane] = s2v;
+    if (lane == 0) { wl.tot1[W] = 0.0; wl.tot2[W] = 0.0; }
+    constexpr int G8 = (KP / 8) * 8;
+#pragma unroll 1
+    for (int g0 = 0; g0 < G8; g0 += 8) column_group<KP, 8>(sv, rb, g0, wl.accR);
+    if (KP % 8 != 0) column_group<KP, 4>(sv, rb, G8, wl.accR);
+    wave_sync();
+#pragma unroll
+    for (int s = 0; s < PPL; ++s) {
+        const int p = lane + s * W;
+        double v = 0.0;
+        if (p == 0) v = wl.tot1[0];
+        else if (p == 1) v = wl.tot2[0];
+        else if (p >= 3 && p < 3 + S) {
+            const int j = p - 3, Lj = sv.Lj[j];
+            const double SA = wl.tp1[j] + wl.tot1[Lj + 1];
+            const double SB = wl.tp2[j] + wl.tot2[Lj + 1];
+            v = SA - sv.t_change[j] * SB;
+        } else if (p >= 3 + S && p < sv.P) {
+            v = wl.accR[p - 3 - S];
+        }
+        ztr[s] = v;
+    }
+    wave_sync();
+}
+
+// per-lane constants of cn_assemble_q
+template <int PPL>
+struct LaneConst {
+    double lc[PPL], sc[PPL], qc[PPL];
+    bool isdelta[PPL];
+    double inv_tau;
+};
+
+template <int PPL>
+__device__ __forceinline__ void lane_consts(const DevSpec *sp, const SeriesView &sv, LaneConst<PPL> &k)
+{
+    const double C25 = 1.0 / 25.0;
+    k.inv_tau = 1.0 / sv.tau;
+#pragma unroll
+    for (int s = 0; s < PPL; ++s) {
+        const int p = lane_id() + s * W;
+        k.lc[s] = 0.0; k.sc[s] = 0.0; k.qc[s] = 0.0; k.isdelta[s] = false;
+        if (p < 2) k.lc[s] = C25;
+        else if (p >= 3 && p < 3 + sv.S) { k.sc[s] = k.inv_tau; k.isdelta[s] = true; }
+        else if (p >= 3 + sv.S && p < sv.P) {
+            const double pr = sp->prior[p - 3 - sv.S];
+            k.lc[s] = 1.0 / (pr * pr);
+            k.qc[s] = 1.0 / pr;
+        }
+    }
+}
+
+// f and gradient from (SSE, Z^T r): cn_assemble_q
+template <int PPL>
+__device__ __forceinline__ bool assemble_q(const SeriesView &sv, const LaneConst<PPL> &lk,
+                                           const double (&th)[PPL], double sse,
+                                           const double (&ztr)[PPL], double &f_out,
+                                           double (&g)[PPL])
+{
+    const int lane = lane_id();
+    const double k = readlane_f64(th[0], 0), m = readlane_f64(th[0], 1), ls = readlane_f64(th[0], 2);
+    const double C25 = 1.0 / 25.0;
+    const double sigma = dm_exp(ls);
+    const double s2 = sigma * sigma;
+    const double inv_s2 = 1.0 / s2;
+    double pa = 0.0, pb = 0.0;
+#pragma unroll
+    for (int s = 0; s < PPL; ++s) {
+        if (lk.isdelta[s]) pa = pa + __builtin_fabs(th[s]);
+        const double qq = th[s] * lk.qc[s];
+        pb = __builtin_fma(qq, qq, pb);
+    }
+    const double sabs = bfly_sum(pa), sb = bfly_sum(pb);
+    double f = ((0.5 * k) * k) * C25 + ((0.5 * m) * m) * C25;
+    f = f + sabs * lk.inv_tau;
+    f = f + 2.0 * s2;
+    f = f + 0.5 * sb;
+    f = f + (double)sv.T * ls;
+    f = f + (0.5 * sse) * inv_s2;
+    const double nis = -inv_s2;
+    const double g2 = ((double)sv.T - sse * inv_s2) + 4.0 * s2;
+    bool bad = !finite_f64(f);
+#pragma unroll
+    for (int s = 0; s < PPL; ++s) {
+        const double sgn = (double)((th[s] > 0.0) - (th[s] < 0.0));
+        double gv = __builtin_fma(th[s], lk.lc[s], nis * ztr[s]) + sgn * lk.sc[s];
+        if (s == 0 && lane == 2) gv = g2;
+        if (lane + s * W >= sv.P) gv = 0.0;
+        g[s] = gv;
+        bad = bad || !finite_f64(gv);
+    }
+    f_out = f;
+    return __any(bad);
+}
+
+// residual-form evaluation (cn_resid_q): r -> rb, then Z^T r, then assemble_q
+template <int KP, int PPL>
+__device__ __forceinline__ bool resid_eval_q(const SeriesView &sv, QuadLds<KP, PPL> &wl,
+                                             const LaneConst<PPL> &lk, double *rb,
+                                             const double (&th)[PPL], double &f_out,
+                                             double (&g)[PPL], double &sse_out,
+                                             double (&ztr)[PPL])
+{
+    const int lane = lane_id();
+    const int S = sv.S;
+#pragma unroll
+    for (int s = 0; s < PPL; ++s) wl.th[lane + s * W] = th[s];
+    {
+        double ksv = readlane_f64(th[0], 0), mcv = readlane_f64(th[0], 1);
+        if (lane == 0) { wl.ks[0] = ksv; wl.mc[0] = mcv; }
+        for (int j = 0; j < S; ++j) {
+            const double dj = theta_at<PPL>(th, 3 + j);
+            ksv = ksv + dj;
+            mcv = mcv + ((-sv.t_change[j]) * dj);
+            if (lane == 0) { wl.ks[j + 1] = ksv; wl.mc[j + 1] = mcv; }
+        }
+    }
+    wave_sync();
+    const double *beta = wl.th + 3 + S;
+    for (int q = sv.NT - 1; q >= 0; --q) {
+        if (q < sv.cnt) {
+            const int idx = q * W + lane;
+            const int c = (int)(sv.cw[idx] & 0xffu);
+            const double ti = sv.tw[idx];
+            const double yi = sv.yw[idx];
+            const double *xp = sv.Xw + (size_t)q * KP * W + lane;
+            double xa = 0.0;
+#pragma unroll 4
+            for (int j = 0; j < KP; ++j) xa = __builtin_fma(xp[j * W], beta[j], xa);
+            const double gtr = __builtin_fma(wl.ks[c], ti, wl.mc[c]);
+            rb[idx] = yi - (gtr + xa);
+        }
+    }
+    ztr_pass<KP, PPL>(sv, wl, rb, sse_out, ztr);
+    return assemble_q<PPL>(sv, lk, th, sse_out, ztr, f_out, g);
+}
+
+// quadratic-form evaluation (cn_eval_gram).  Ml: [P4][PPL][64] in LDS (or global).
+template <int PPL>
+__device__ __forceinline__ bool gram_eval_q(const SeriesView &sv, const LaneConst<PPL> &lk,
+                                            const double *Ml, int P4, const double (&th)[PPL],
+                                            const double (&ref)[PPL], const double (&cvec)[PPL],
+                                            double s0, double &f_out, double (&g)[PPL],
+                                            double &q2_out)
+{
+    const int lane = lane_id();
+    double D[PPL], v[PPL], a[PPL][4];
+#pragma unroll
+    for (int s = 0; s < PPL; ++s) {
+        const int p = lane + s * W;
+        D[s] = (p == 2 || p >= sv.P) ? 0.0 : th[s] - ref[s];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[s][u] = 0.0;
+    }
+    const double *mp = Ml + lane;
+    const int q_lo = P4 < W ? P4 : W;
+    for (int q = 0; q < q_lo; q += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double Dq = readlane_f64(D[0], q + u);
+#pragma unroll
+            for (int s = 0; s < PPL; ++s)
+                a[s][u] = __builtin_fma(mp[((q + u) * PPL + s) * W], Dq, a[s][u]);
+        }
+    }
+    if (PPL == 2) {
+        for (int q = W; q < P4; q += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double Dq = readlane_f64(D[PPL - 1], q + u - W);
+#pragma unroll
+                for (int s = 0; s < PPL; ++s)
+                    a[s][u] = __builtin_fma(mp[((q + u) * PPL + s) * W], Dq, a[s][u]);
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < PPL; ++s) v[s] = (a[s][0] + a[s][1]) + (a[s][2] + a[s][3]);
+    const double q2 = pdot<PPL>(D, v);
+    const double cd = pdot<PPL>(cvec, D);
+    const double sse = __builtin_fma(-2.0, cd, s0) + q2;
+    q2_out = q2;
+    double ztr[PPL];
+#pragma unroll
+    for (int s = 0; s < PPL; ++s) ztr[s] = cvec[s] - v[s];
+    return assemble_q<PPL>(sv, lk, th, sse, ztr, f_out, g);
+}
+
+// lane-id based variants of make_view / store_theta for multi-wave workgroups
+template <int KP, int PPL>
+__device__ __forceinline__ void make_view_q(const FitArgs &a, int64_t n, SeriesView &sv)
+{
+    const GridTab &gt = a.gtab[0];
+    sv.T = gt.info.T; sv.NT = gt.info.NT; sv.S = gt.info.S;
+    sv.P = 3 + sv.S + a.sp->K;
+    int cnt = sv.T - lane_id() * sv.NT;
+    cnt = cnt < 0 ? 0 : (cnt > sv.NT ? sv.NT : cnt);
+    sv.cnt = cnt;
+    sv.tw = a.tw; sv.cw = a.cw; sv.Xw = a.Xw;
+    sv.yw = a.yw + (size_t)n * a.NTmax * W;
+    sv.Lj = gt.Lj;
+    sv.t_change = gt.info.t_change;
+    sv.cap = 0.0;
+    sv.tau = a.sp->tau;
+    sv.n_eval = 0;
+}
+
+template <int PPL>
+__device__ __forceinline__ void store_theta_q(const FitArgs &a, const SeriesView &sv, int64_t n,
+                                              const double (&x)[PPL], double *dst)
+{
+    const int n_cp = a.sp->n_cp;
+    double *out = dst + (size_t)n * a.theta_stride;
+    // every slot of the row is written exactly once: fitted entries, zeros elsewhere
+    for (int i = lane_id(); i < a.theta_stride; i += W) {
+        bool fitted = i < 3 + sv.S;
+        if (i >= 3 + n_cp && i < 3 + n_cp + a.sp->K) fitted = true;
+        if (!fitted) out[i] = 0.0;
+    }
+#pragma unroll
+    for (int s = 0; s < PPL; ++s) {
+        const int p = lane_id() + s * W;
+        if (p < 3 + sv.S) out[p] = x[s];
+        else if (p < sv.P) out[3 + n_cp + a.sp->perm[p - 3 - sv.S]] = x[s];
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Gram matrix: block q computes column q of M = Z^T Z as "Z^T r" with r := column q of Z
+// ---------------------------------------------------------------------------------------
+template <int KP, int PPL>
+__global__ __launch_bounds__(64) void gram_build_kernel(QuadArgs qa, double *Mout)
+{
+    __shared__ QuadLds<KP, PPL> wl;
+    const int q = blockIdx.x, lane = threadIdx.x;
+    SeriesView sv;
+    make_view_q<KP, PPL>(qa.f, 0, sv);
+    double *out = Mout + (size_t)q * PPL * W;
+    if (q == 2 || q >= sv.P) {
+#pragma unroll
+        for (int s = 0; s < PPL; ++s) out[s * W + lane] = 0.0;
+        return;
+    }
+    double *rb = qa.rbuf + (size_t)q * qa.f.NTmax * W;
+    for (int st = 0; st < sv.NT; ++st) {
+        if (st < sv.cnt) {
+            const int idx = st * W + lane;
+            double z;
+            if (q == 0) z = sv.tw[idx];
+            else if (q == 1) z = 1.0;
+            else if (q < 3 + sv.S) {
+                const int c = (int)(sv.cw[idx] & 0xffu);
+                z = (c > q - 3) ? sv.tw[idx] - sv.t_change[q - 3] : 0.0;
+            } else {
+                z = sv.Xw[((size_t)st * KP + (q - 3 - sv.S)) * W + lane];
+            }
+            rb[idx] = z;
+        }
+    }
+    double sse, ztr[PPL];
+    ztr_pass<KP, PPL>(sv, wl, rb, sse, ztr);
+#pragma unroll
+    for (int s = 0; s < PPL; ++s) out[s * W + lane] = ztr[s];
+}
+
+// ---------------------------------------------------------------------------------------
+// the fit kernel
+// ---------------------------------------------------------------------------------------
+// One series, start to finish, by one wave.  Deliberately NOT inlined into the persistent loop
+// of fit_quad_kernel: with the lane-0 epilogue stores sitting right in front of the loop's
+// back-edge the structurizer let lanes 1..63 re-enter the loop header (and its readfirstlane)
+// ahead of lane 0.  A call boundary keeps the loop body uniform.
+template <int KP, int PPL>
+__device__ __noinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL> &wl, double *rb,
+                                          const double *Mp, int64_t n)
+{
+    const FitArgs &a = qa.f;
+    const DevSpec *sp = a.sp;
+    const int lane = lane_id();
+    const int P4 = qa.P4;
+    const double eps = 2.220446049250313e-16;
+    const double c1 = 1e-4, c2 = 0.9, minAlpha = 1e-12, min_range = 1e-16;
+    const int maxLSIts = 20, maxLSRestarts = 10;
+    SeriesView sv;
+    make_view_q<KP, PPL>(a, n, sv);
+    const SeriesTab st = a.stab[n];
+    if (lane == 0) {
+        a.y_scale[n] = st.y_scale;
+        if (n == 0) a.grid_out[0] = a.gtab[0].info;
+    }
+    double xk[PPL], gk[PPL], pk[PPL], xk1[PPL], gk1[PPL], pk1[PPL];
+#pragma unroll
+    for (int s = 0; s < PPL; ++s) {
+        const int p = lane + s * W;
+        xk[s] = (p == 0) ? st.k0 : (p == 1 ? st.m0 : 0.0);
+        gk[s] = 0.0; pk[s] = 0.0; xk1[s] = xk[s]; gk1[s] = 0.0; pk1[s] = 0.0;
+    }
+    if (qa.debug == 1) {
+        store_theta_q<PPL>(a, sv, n, xk, a.theta);
+        if (lane == 0) { a.status[n] = 77; a.n_iter[n] = 0; a.n_eval[n] = 0; a.fval[n] = 0.0; }
+        return;
+    }
+    if (st.status0 != 0) {
+        if (st.status0 == TSF_ST_CONSTANT) {
+#pragma unroll
+            for (int s = 0; s < PPL; ++s) if (lane + s * W == 2) xk[s] = -20.72326583694641;
+        }
+        store_theta_q<PPL>(a, sv, n, xk, a.theta);
+        if (lane == 0) { a.status[n] = st.status0; a.n_iter[n] = 0; a.n_eval[n] = 0; a.fval[n] = 0.0; }
+        return;
+    }
+    LaneConst<PPL> lk;
+    lane_consts<PPL>(sp, sv, lk);
+
+    double ref[PPL], cvec[PPL], s0 = 0.0, q2 = 0.0;
+    double Sh[QH][PPL], Yh[QH][PPL], rho[QH], alphas[QH];
+#pragma unroll
+    for (int h = 0; h < QH; ++h) {
+        rho[h] = 0.0; alphas[h] = 0.0;
+#pragma unroll
+        for (int s = 0; s < PPL; ++s) { Sh[h][s] = 0.0; Yh[h][s] = 0.0; }
+    }
+#pragma unroll
+    for (int s = 0; s < PPL; ++s) { ref[s] = 0.0; cvec[s] = 0.0; }
+
+    double fk = 0.0, fk1 = 0.0, alpha = sp->init_alpha, gammak = 1.0;
+    int itNum = 0, ret = 0, resetB = 0, hist_len = 0, since_rc = 0;
+    double dfp = 0, c1dfp = 0, c2dfp = 0, alpha0 = 0, prevF = 0, prevDFp = 0;
+    double alo = 0, aloF = 0, aloDFp = 0, ahi = 0, ahiF = 0, ahiDFp = 0;
+    int nits = 0, lsRestarts = 0, zoom = 0, zit = 0;
+
+    enum { ST_INIT = 0, ST_START_ITER, ST_START_LS, ST_LS_PRE, ST_LS_EVAL, ST_RECENTER, ST_POST };
+    int stage = ST_INIT;
+    long turns = 0;
+    const long max_turns = 64L * sp->max_iter + 1024;     // guard: never spin forever
+    for (;;) {
+        if (++turns > max_turns) { ret = -99 - stage; break; }
+        if (stage == ST_POST) {
+            // ---- accepted step: k is the most recent iterate ----
+            double sk[PPL], yk[PPL];
+#pragma unroll
+            for (int s = 0; s < PPL; ++s) { sk[s] = xk[s] - xk1[s]; yk[s] = gk[s] - gk1[s]; }
+            const double gradNorm = __builtin_sqrt(pdot<PPL>(gk, gk));
+            const double stepNorm = __builtin_sqrt(pdot<PPL>(sk, sk));
+            const double skyk = pdot<PPL>(yk, sk);
+            const double ykyk = pdot<PPL>(yk, yk);
+            if (resetB) {
+                const double B0fact = ykyk / skyk;
+                hist_len = 0;
+#pragma unroll
+                for (int s = 0; s < PPL; ++s) pk1[s] = pk1[s] / B0fact;
+                alpha = alpha * B0fact;
+            }
+            gammak = skyk / ykyk;
+            const double rho_new = 1.0 / skyk;
+            if (hist_len < QH) {
+#pragma unroll
+                for (int h = 0; h < QH; ++h) {
+                    if (h == hist_len) {
+                        rho[h] = rho_new;
+#pragma unroll
+                        for (int s = 0; s < PPL; ++s) { Sh[h][s] = sk[s]; Yh[h][s] = yk[s]; }
+                    }
+                }
+                hist_len++;
+            } else {
+#pragma unroll
+                for (int h = 0; h + 1 < QH; ++h) {
+                    rho[h] = rho[h + 1];
+#pragma unroll
+                    for (int s = 0; s < PPL; ++s) { Sh[h][s] = Sh[h + 1][s]; Yh[h][s] = Yh[h + 1][s]; }
+                }
+                rho[QH - 1] = rho_new;
+#pragma unroll
+                for (int s = 0; s < PPL; ++s) { Sh[QH - 1][s] = sk[s]; Yh[QH - 1][s] = yk[s]; }
+            }
+#pragma unroll
+            for (int s = 0; s < PPL; ++s) pk[s] = -gk[s];
+#pragma unroll
+            for (int h = QH - 1; h >= 0; --h) {
+                if (h < hist_len) {
+                    const double aa = rho[h] * pdot<PPL>(Sh[h], pk);
+#pragma unroll
+                    for (int s = 0; s < PPL; ++s) pk[s] = __builtin_fma(-aa, Yh[h][s], pk[s]);
+                    alphas[h] = aa;
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < PPL; ++s) pk[s] = pk[s] * gammak;
+#pragma unroll
+            for (int h = 0; h < QH; ++h) {
+                if (h < hist_len) {
+                    const double bb = rho[h] * pdot<PPL>(Yh[h], pk);
+                    const double cc = alphas[h] - bb;
+#pragma unroll
+                    for (int s = 0; s < PPL; ++s) pk[s] = __builtin_fma(cc, Sh[h][s], pk[s]);
+                }
+            }
+            const double dF = __builtin_fabs(fk1 - fk);
+            const double fmaxv = __builtin_fmax(__builtin_fabs(fk1),
+                                                __builtin_fmax(__builtin_fabs(fk), 1.0));
+            if (dF < sp->tol_obj) ret = TSF_ST_ABSF;
+            else if (dF < sp->tol_rel_obj * eps * fmaxv) ret = TSF_ST_RELF;
+            else if (gradNorm < sp->tol_grad) ret = TSF_ST_ABSGRAD;
+            else if (-pdot<PPL>(gk, pk) / __builtin_fmax(__builtin_fabs(fk), 1.0) < sp->tol_rel_grad * eps) ret = TSF_ST_RELGRAD;
+            else if (stepNorm < sp->tol_param) ret = TSF_ST_ABSX;
+            else if (itNum >= sp->max_iter) ret = TSF_ST_MAXIT;
+            else ret = 0;
+            if (ret != 0) break;
+            stage = ST_START_ITER;
+        }
+        if (stage == ST_START_ITER) {
+            itNum++;
+            resetB = (itNum == 1) ? 1 : 0;
+            stage = ST_START_LS;
+        }
+        if (stage == ST_START_LS) {
+            if (resetB) {
+#pragma unroll
+                for (int s = 0; s < PPL; ++s) pk[s] = -gk[s];
+            }
+            if (itNum > 1 && resetB != 2) {
+                const double ci = cubic_interp6(pdot<PPL>(gk1, pk1), alpha, fk - fk1,
+                                                pdot<PPL>(gk, pk), minAlpha, 1.0);
+                alpha = __builtin_fmin(1.0, 1.01 * ci);
+            } else {
+                alpha = sp->init_alpha;
+            }
+            dfp = pdot<PPL>(gk, pk);
+            c1dfp = c1 * dfp; c2dfp = c2 * dfp;
+            alpha0 = minAlpha; prevF = fk; prevDFp = dfp;
+            nits = 0; lsRestarts = 0; zoom = 0; zit = 0;
+            stage = ST_LS_PRE;
+        }
+        bool ls_fail = false;
+        if (stage == ST_LS_PRE) {
+            if (!zoom) {
+                if (nits >= maxLSIts) ls_fail = true;
+            } else {
+                zit++;
+                if (__builtin_fabs(alo - ahi) < min_range) {
+                    ls_fail = true;
+                } else if (zit % 5 == 0) {
+                    alpha = 0.5 * (alo + ahi);
+                } else {
+                    const double d1 = aloDFp + ahiDFp - 3.0 * (aloF - ahiF) / (alo - ahi);
+                    double d2 = __builtin_sqrt(d1 * d1 - aloDFp * ahiDFp);
+                    if (ahi < alo) d2 = -d2;
+                    alpha = ahi - (ahi - alo) * (ahiDFp + d2 - d1) / (ahiDFp - aloDFp + 2.0 * d2);
+                    const double lo = __builtin_fmin(alo, ahi), hi = __builtin_fmax(alo, ahi),
+                                 w = __builtin_fabs(alo - ahi);
+                    if (!finite_f64(alpha) || alpha < lo + 0.01 * w || alpha > hi - 0.01 * w)
+                        alpha = 0.5 * (alo + ahi);
+                }
+            }
+            if (!ls_fail) stage = ST_LS_EVAL;
+        }
+        if (!ls_fail) {
+            // ---- the single evaluation site ----
+            double xe[PPL], ge[PPL], fe;
+            bool bad;
+            if (stage == ST_INIT || stage == ST_RECENTER) {
+                double sse_e, ztr_e[PPL];
+#pragma unroll
+                for (int s = 0; s < PPL; ++s) xe[s] = xk[s];
+                sv.n_eval++;
+                bad = resid_eval_q<KP, PPL>(sv, wl, lk, rb, xe, fe, ge, sse_e, ztr_e);
+                if (!bad) {
+#pragma unroll
+                    for (int s = 0; s < PPL; ++s) {
+                        const int p = lane + s * W;
+                        ref[s] = (p == 2) ? 0.0 : xe[s];
+                        cvec[s] = ztr_e[s];
+                        gk[s] = ge[s];
+                    }
+                    s0 = sse_e; since_rc = 0; fk = fe;
+                }
+                if (stage == ST_INIT) {
+                    if (bad) { ret = TSF_ST_INIT_NONFINITE; fk = fe; break; }
+                    if (qa.debug == 2) { ret = 78; break; }
+#pragma unroll
+                    for (int s = 0; s < PPL; ++s) { pk[s] = -gk[s]; gk1[s] = 0.0; xk1[s] = 0.0; }
+                    stage = ST_START_ITER;
+                } else {
+                    stage = ST_POST;
+                }
+                continue;
+            }
+#pragma unroll
+            for (int s = 0; s < PPL; ++s) { xk1[s] = __builtin_fma(alpha, pk[s], xk[s]); xe[s] = xk1[s]; }
+            sv.n_eval++;
+            bad = gram_eval_q<PPL>(sv, lk, Mp, P4, xe, ref, cvec, s0, fe, ge, q2);
+#pragma unroll
+            for (int s = 0; s < PPL; ++s) gk1[s] = ge[s];
+            const double f1 = fe;
+            if (bad) {
+                if (!zoom) {
+                    if (lsRestarts >= maxLSRestarts) ls_fail = true;
+                    else { alpha = 0.5 * (alpha0 + alpha); lsRestarts++; }
+                } else {
+                    alpha = 0.5 * (alpha + __builtin_fmin(alo, ahi));
+                    if (__builtin_fabs(__builtin_fmin(alo, ahi) - alpha) < min_range) ls_fail = true;
+                }
+                if (!ls_fail) continue;            // re-evaluate at the shortened step
+            }
+            if (!ls_fail) {
+                const double newDFp = pdot<PPL>(gk1, pk);
+                bool ls_ok = false;
+                if (!zoom) {
+                    lsRestarts = 0;
+                    if (f1 > fk + alpha * c1dfp || (f1 >= prevF && nits > 0)) {
+                        zoom = 1; alo = alpha0; aloF = prevF; aloDFp = prevDFp;
+                        ahi = alpha; ahiF = f1; ahiDFp = newDFp;
+                    } else if (__builtin_fabs(newDFp) <= -c2dfp) {
+                        ls_ok = true;
+                    } else if (newDFp >= 0) {
+                        zoom = 1; alo = alpha; aloF = f1; aloDFp = newDFp;
+                        ahi = alpha0; ahiF = prevF; ahiDFp = prevDFp;
+                    } else {
+                        alpha0 = alpha; prevF = f1; prevDFp = newDFp;
+                        alpha *= 10.0;
+                        nits++;
+                    }
+                } else {
+                    if (f1 > (fk + alpha * c1dfp) || f1 >= aloF) {
+                        ahi = alpha; ahiF = f1; ahiDFp = newDFp;
+                    } else if (__builtin_fabs(newDFp) <= -c2dfp) {
+                        ls_ok = true;
+                    } else {
+                        if (newDFp * (ahi - alo) >= 0) { ahi = alo; ahiF = aloF; ahiDFp = aloDFp; }
+                        alo = alpha; aloF = f1; aloDFp = newDFp;
+                    }
+                }
+                if (!ls_ok) { stage = ST_LS_PRE; continue; }
+                fk1 = f1;
+                { const double tf = fk; fk = fk1; fk1 = tf; }
+#pragma unroll
+                for (int s = 0; s < PPL; ++s) {
+                    const double tx = xk[s]; xk[s] = xk1[s]; xk1[s] = tx;
+                    const double tg = gk[s]; gk[s] = gk1[s]; gk1[s] = tg;
+                    const double tp = pk[s]; pk[s] = pk1[s]; pk1[s] = tp;
+                }
+                since_rc++;
+                stage = (q2 > qa.recenter_ratio * s0 || since_rc >= qa.recenter_every) ? ST_RECENTER : ST_POST;
+                continue;
+            }
+        }
+        // line search failed
+        if (resetB) { ret = TSF_ST_LSFAIL; break; }
+        resetB = 2;
+        stage = ST_START_LS;
+    }
+    store_theta_q<PPL>(a, sv, n, xk, a.theta);
+    if (lane == 0) { a.status[n] = ret; a.n_iter[n] = itNum; a.n_eval[n] = sv.n_eval; a.fval[n] = fk; }
+}
+
+template <int KP, int PPL, int NW, bool MLDS>
+__global__ __launch_bounds__(NW * 64, QUAD_WAVES_PER_SIMD) void fit_quad_kernel(QuadArgs qa)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const FitArgs &a = qa.f;
+    const int lane = lane_id(), wid = (int)threadIdx.x >> 6;
+    const int P4 = qa.P4;
+    double *Ml = reinterpret_cast<double *>(smem);
+    const size_t m_bytes = MLDS ? sizeof(double) * (size_t)P4 * PPL * W : 0;
+    QuadLds<KP, PPL> &wl = *reinterpret_cast<QuadLds<KP, PPL> *>(smem + m_bytes + sizeof(QuadLds<KP, PPL>) * wid);
+    if (MLDS) {
+        for (int i = threadIdx.x; i < P4 * PPL * W; i += NW * 64) Ml[i] = qa.Mg[i];
+        __syncthreads();
+    }
+#ifdef TSF_QUAD_MARKERS     // dev only: progress markers in host-coherent memory
+#define QDBG(k, v) do { if (qa.dbg && lane == 0) { qa.dbg[((size_t)blockIdx.x * NW + wid) * 8 + (k)] = (long long)(v); __threadfence_system(); } } while (0)
+#else
+#define QDBG(k, v) do { } while (0)
+#endif
+    QDBG(0, 1);
+    const double *Mp = MLDS ? Ml : qa.Mg;
+    double *rb = qa.rbuf + ((size_t)blockIdx.x * NW + wid) * a.NTmax * W;
+    for (int i = lane; i < PPL * W + W; i += W) wl.th[i] = 0.0;
+    wave_sync();
+
+    for (;;) {
+        // every lane takes part (lane 0 adds 1, the others 0): no divergent branch at the loop head
+        int n32 = atomicAdd(qa.counter, lane == 0 ? 1 : 0);
+        n32 = __builtin_amdgcn_readfirstlane(n32);
+        const int64_t n = n32;
+        QDBG(1, 1000 + n);
+        if (n >= a.N) break;
+        fit_one_quad<KP, PPL>(qa, wl, rb, Mp, n);
+        QDBG(2, 2000 + n);
+    }
+    QDBG(3, 3);
+#undef QDBG
+}
+
+
+}  // namespace tsf

@@ -45,7 +45,8 @@ class ModelSpec(object):
         self.lbfgs = dict(lbfgs)
         for k in self.lbfgs:
             if k not in ('max_iter', 'history', 'init_alpha', 'tol_obj', 'tol_rel_obj',
-                         'tol_grad', 'tol_rel_grad', 'tol_param'):
+                         'tol_grad', 'tol_rel_grad', 'tol_param', 'eval_form', 'recenter_every',
+                         'recenter_ratio'):
                 raise TypeError('unknown L-BFGS option %r' % k)
 
     # -- fbprophet set_auto_seasonalities on a timestamp vector --------------------------------
