@@ -16,7 +16,7 @@ OBJ = os.path.join(HERE, '_obj')
 LIB = os.path.join(HERE, 'libtsf_amd.so')
 ARCH = 'gfx950'
 FLAGS = ['--offload-arch=' + ARCH, '-O3', '-ffp-contract=off', '-fPIC', '-std=c++17',
-         '-Wno-unused-value']
+         '-Wno-unused-value'] + os.environ.get('TSF_HIPCC_FLAGS', '').split()
 
 
 def _hipcc():

@@ -211,12 +211,14 @@ static int quad_plan(tsf_ctx *ctx, const DevSpec &hs, int64_t N, QuadPlan *qp)
     hipDeviceProp_t prop;
     HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
     const int P = 3 + hs.n_cp + hs.K;
-    qp->P4 = (P + 3) & ~3;
     qp->PPL = (hs.KP == 64) ? 2 : 1;
-    qp->NW = quad_waves_per_block();
+    // rows of M the kernel walks: compile-time 40 / 56 / 64 for the one-slot kernels (zero rows
+    // beyond P are bit-neutral), P rounded up to 4 for the two-slot kernel
+    qp->P4 = (qp->PPL == 2) ? ((P + 3) & ~3) : (P <= 40 ? 40 : (P <= 56 ? 56 : 64));
+    qp->NW = quad_waves_per_block(qp->PPL);
     const char *e = getenv("TSF_QUAD_BLOCKS_PER_CU");
-    const int per_cu = e ? atoi(e) : 2;
-    int64_t blocks = (int64_t)prop.multiProcessorCount * (per_cu > 0 ? per_cu : 2);
+    const int per_cu = e ? atoi(e) : 1;         // LDS admits one workgroup per CU
+    int64_t blocks = (int64_t)prop.multiProcessorCount * (per_cu > 0 ? per_cu : 1);
     const int64_t need = (N + qp->NW - 1) / qp->NW;
     if (blocks > need) blocks = need;
     if (blocks < 1) blocks = 1;

@@ -4,20 +4,24 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 #include <unistd.h>
 
 #ifndef TSF_QUAD_NW
 #define TSF_QUAD_NW 8
 #endif
+#ifndef TSF_QUAD_NW2
+#define TSF_QUAD_NW2 4      // two-slot kernel (P > 64): twice the per-wave LDS
+#endif
 
 namespace tsf {
 
-int quad_waves_per_block() { return TSF_QUAD_NW; }
+int quad_waves_per_block(int PPL) { return PPL == 2 ? TSF_QUAD_NW2 : TSF_QUAD_NW; }
 
-template <int KP, int PPL, bool MLDS>
+template <int KP, int PPL, bool MLDS, int PQ>
 static int launch_quad_one(const QuadPlan &qp, const QuadArgs &qa, double *Mg, hipStream_t st)
 {
-    constexpr int NW = TSF_QUAD_NW;
+    constexpr int NW = (PPL == 2) ? TSF_QUAD_NW2 : TSF_QUAD_NW;
     const char *dbg = getenv("TSF_QUAD_DEBUG");
     hipLaunchKernelGGL((gram_build_kernel<KP, PPL>), dim3((unsigned)qp.P4), dim3(64), 0, st, qa, Mg);
     hipError_t e = hipGetLastError();
@@ -30,7 +34,7 @@ static int launch_quad_one(const QuadPlan &qp, const QuadArgs &qa, double *Mg, h
     const size_t lds = (MLDS ? sizeof(double) * (size_t)qp.P4 * PPL * W : 0) + sizeof(QuadLds<KP, PPL>) * NW;
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute((const void *)fit_quad_kernel<KP, PPL, NW, MLDS>,
+        hipFuncSetAttribute((const void *)fit_quad_kernel<KP, PPL, NW, MLDS, PQ>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
@@ -41,7 +45,7 @@ static int launch_quad_one(const QuadPlan &qp, const QuadArgs &qa, double *Mg, h
         memset(hdbg, 0, sizeof(long long) * 8 * qp.blocks * NW);
         qb.dbg = hdbg;
     }
-    hipLaunchKernelGGL((fit_quad_kernel<KP, PPL, NW, MLDS>), dim3((unsigned)qp.blocks), dim3(NW * 64), lds, st, qb);
+    hipLaunchKernelGGL((fit_quad_kernel<KP, PPL, NW, MLDS, PQ>), dim3((unsigned)qp.blocks), dim3(NW * 64), lds, st, qb);
     if (hdbg) {
         e = hipGetLastError();
         fprintf(stderr, "[quad] fit launched: %s lds %zu\n", hipGetErrorString(e), lds);
@@ -53,6 +57,25 @@ static int launch_quad_one(const QuadPlan &qp, const QuadArgs &qa, double *Mg, h
             fprintf(stderr, "[quad] wave %d: m0 %lld m1 %lld m2 %lld m3 %lld m7 %lld\n", w, hdbg[w * 8], hdbg[w * 8 + 1], hdbg[w * 8 + 2], hdbg[w * 8 + 3], hdbg[w * 8 + 7]);
         fflush(stderr);
         if (hipStreamQuery(st) != hipSuccess) _exit(3);
+        return 0;
+    }
+    if (dbg && dbg[0] == '4') {     // phase timing (build with -DTSF_QUAD_TIMING)
+        long long *dd = nullptr;
+        const size_t nb = sizeof(long long) * 8 * (size_t)qa.f.N;
+        hipMalloc((void **)&dd, nb);
+        hipMemsetAsync(dd, 0, nb, st);
+        qb.dbg = dd;
+        hipMemsetAsync(qa.counter, 0, sizeof(int), st);
+        hipLaunchKernelGGL((fit_quad_kernel<KP, PPL, NW, MLDS, PQ>), dim3((unsigned)qp.blocks), dim3(NW * 64), lds, st, qb);
+        hipStreamSynchronize(st);
+        std::vector<long long> h(8 * (size_t)qa.f.N);
+        hipMemcpy(h.data(), dd, nb, hipMemcpyDeviceToHost);
+        double sum[8] = {0};
+        long long mx = 0;
+        for (int64_t i = 0; i < qa.f.N; ++i) { for (int k = 0; k < 8; ++k) sum[k] += (double)h[i * 8 + k]; if (h[i * 8 + 7] > mx) mx = h[i * 8 + 7]; }
+        fprintf(stderr, "[quad-timing] N %lld mean cycles/series: misc %.0f post %.0f ls %.0f resid %.0f gram %.0f | total %.0f max %lld\n",
+                (long long)qa.f.N, sum[0] / qa.f.N, sum[1] / qa.f.N, sum[2] / qa.f.N, sum[3] / qa.f.N, sum[4] / qa.f.N, sum[7] / qa.f.N, mx);
+        hipFree(dd);
         return 0;
     }
     if (dbg) {
@@ -67,11 +90,19 @@ static int launch_quad_one(const QuadPlan &qp, const QuadArgs &qa, double *Mg, h
 
 int launch_quad(int KP, const QuadPlan &qp, const QuadArgs &qa, double *Mg, hipStream_t st)
 {
-    switch (KP) {
-    case 8: return launch_quad_one<8, 1, true>(qp, qa, Mg, st);
-    case 16: return launch_quad_one<16, 1, true>(qp, qa, Mg, st);
-    case 28: return launch_quad_one<28, 1, true>(qp, qa, Mg, st);
-    case 64: return launch_quad_one<64, 2, false>(qp, qa, Mg, st);
+    // qp.P4 is the M row count the plan chose: 40 / 56 / 64 (compile-time, P <= 64) or any
+    // multiple of 4 for the two-slot kernel
+    switch (KP * 100 + (KP == 64 ? 0 : qp.P4)) {
+    case 840: return launch_quad_one<8, 1, true, 40>(qp, qa, Mg, st);
+    case 856: return launch_quad_one<8, 1, true, 56>(qp, qa, Mg, st);
+    case 864: return launch_quad_one<8, 1, true, 64>(qp, qa, Mg, st);
+    case 1640: return launch_quad_one<16, 1, true, 40>(qp, qa, Mg, st);
+    case 1656: return launch_quad_one<16, 1, true, 56>(qp, qa, Mg, st);
+    case 1664: return launch_quad_one<16, 1, true, 64>(qp, qa, Mg, st);
+    case 2840: return launch_quad_one<28, 1, true, 40>(qp, qa, Mg, st);
+    case 2856: return launch_quad_one<28, 1, true, 56>(qp, qa, Mg, st);
+    case 2864: return launch_quad_one<28, 1, true, 64>(qp, qa, Mg, st);
+    case 6400: return launch_quad_one<64, 2, false, 0>(qp, qa, Mg, st);
     default: return -1;
     }
 }

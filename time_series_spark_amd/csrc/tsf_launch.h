@@ -5,7 +5,7 @@ namespace tsf {
 struct FitArgs;
 struct QuadArgs;
 struct QuadPlan { int P4, PPL, NW, blocks, slots; };
-int quad_waves_per_block();
+int quad_waves_per_block(int PPL);
 // gram_build_kernel + fit_quad_kernel (tsf_inst_quad.hip)
 int launch_quad(int KP, const QuadPlan &qp, const QuadArgs &qa, double *Mg, hipStream_t st);
 int launch_g0m0(int KP, const FitArgs &a, int eval_only, hipStream_t st);

@@ -49,6 +49,10 @@ struct QuadLds {
     double tp1[NTAB], tp2[NTAB];
     double tot1[W + 1], tot2[W + 1];
     double accR[KP];
+    // per-series vectors that are cold during an evaluation live here, not in registers
+    double lc[PPL * W], sc[PPL * W], qc[PPL * W];      // cn_assemble_q lane constants
+    double ref[PPL * W], cvec[PPL * W];                // reference point and c = Z^T r_ref
+    double Sb[QH * PPL * W], Yb[QH * PPL * W];         // L-BFGS history ring
 };
 
 __device__ __forceinline__ int lane_id() { return (int)threadIdx.x & (W - 1); }
@@ -89,38 +93,46 @@ __device__ __forceinline__ void column_group(const SeriesView &sv, const double 
     double acc[G];
 #pragma unroll
     for (int j = 0; j < G; ++j) acc[j] = 0.0;
+    // branch-free over the NT steps: rows past the end of the series hold r = 0 (written by
+    // ztr_pass) and X = 0 (zero-filled padding), and fma(0, 0, acc) leaves acc unchanged
+#pragma unroll 4
     for (int q = sv.NT - 1; q >= 0; --q) {
-        if (q < sv.cnt) {
-            const double r = rb[q * W + lane];
-            const double *xp = sv.Xw + ((size_t)q * KP + g0) * W + lane;
+        const double r = rb[q * W + lane];
+        const double *xp = sv.Xw + ((size_t)q * KP + g0) * W + lane;
+        double x[G];
 #pragma unroll
-            for (int j = 0; j < G; ++j) acc[j] = __builtin_fma(xp[j * W], r, acc[j]);
-        }
+        for (int j = 0; j < G; ++j) x[j] = xp[j * W];
+#pragma unroll
+        for (int j = 0; j < G; ++j) acc[j] = __builtin_fma(x[j], r, acc[j]);
     }
     column_sums_g<G>(acc, accR + g0);
 }
 
-// Z^T r and r.r for the weights r held in rb[q*64+lane] (row lane*NT+q), in the operation
-// order of eval_fg<GROWTH 0, MODE 0>.  ztr[s]: entry p = lane + 64 s.
-template <int KP, int PPL>
-__device__ __forceinline__ void ztr_pass(const SeriesView &sv, QuadLds<KP, PPL> &wl,
-                                         const double *rb, double &sse_out, double (&ztr)[PPL])
+// Z^T r and r.r, in the operation order of eval_fg<GROWTH 0, MODE 0> (cn_ztr).  The weight of
+// row lane*NT+q comes from gen(q, idx, c, ti) (called for valid rows only, q descending); it is
+// parked in rb[q*64+lane] for the per-column passes (0 for rows past the end of the series).
+// ztr[s]: entry p = lane + 64 s.
+template <int KP, int PPL, class RGen>
+__device__ __forceinline__ void ztr_pass(const SeriesView &sv, QuadLds<KP, PPL> &wl, double *rb,
+                                         RGen gen, double &sse_out, double (&ztr)[PPL])
 {
     const int lane = lane_id();
     const int S = sv.S;
     double sse = 0.0, rt1 = 0.0, rt2 = 0.0;
+#pragma unroll 1
     for (int q = sv.NT - 1; q >= 0; --q) {
-        if (q < sv.cnt) {
-            const int idx = q * W + lane;
-            const unsigned cwv = sv.cw[idx];
-            const int c = (int)(cwv & 0xffu), cprev = (int)(cwv >> 8);
-            const double ti = sv.tw[idx];
-            const double r = rb[idx];
-            sse = __builtin_fma(r, r, sse);
-            rt1 = __builtin_fma(r, ti, rt1);
-            rt2 = rt2 + r;
-            for (int j = cprev; j < c; ++j) { wl.tp1[j] = rt1; wl.tp2[j] = rt2; }
-        }
+        const bool valid = q < sv.cnt;
+        const int idx = q * W + lane;
+        const unsigned cwv = valid ? (unsigned)sv.cw[idx] : 0u;
+        const int c = (int)(cwv & 0xffu), cprev = (int)(cwv >> 8);
+        const double ti = valid ? sv.tw[idx] : 0.0;
+        double r = gen(q, idx, c, ti);
+        if (!valid) r = 0.0;
+        rb[idx] = r;
+        sse = __builtin_fma(r, r, sse);
+        rt1 = __builtin_fma(r, ti, rt1);
+        rt2 = rt2 + r;
+        for (int j = cprev; j < c; ++j) { wl.tp1[j] = rt1; wl.tp2[j] = rt2; }
     }
     sse_out = bfly_sum(sse);
     const double s1 = suffix_scan(rt1), s2v = suffix_scan(rt2);
@@ -153,28 +165,31 @@ __device__ __forceinline__ void ztr_pass(const SeriesView &sv, QuadLds<KP, PPL> 
 // per-lane constants of cn_assemble_q
 template <int PPL>
 struct LaneConst {
-    double lc[PPL], sc[PPL], qc[PPL];
-    bool isdelta[PPL];
+    const double *lc, *sc, *qc;         // in LDS, entry p = lane + 64 s at [s * 64 + lane]
     double inv_tau;
 };
 
-template <int PPL>
-__device__ __forceinline__ void lane_consts(const DevSpec *sp, const SeriesView &sv, LaneConst<PPL> &k)
+template <int KP, int PPL>
+__device__ __forceinline__ void lane_consts(const DevSpec *sp, const SeriesView &sv,
+                                            QuadLds<KP, PPL> &wl, LaneConst<PPL> &k)
 {
     const double C25 = 1.0 / 25.0;
     k.inv_tau = 1.0 / sv.tau;
+    k.lc = wl.lc; k.sc = wl.sc; k.qc = wl.qc;
 #pragma unroll
     for (int s = 0; s < PPL; ++s) {
         const int p = lane_id() + s * W;
-        k.lc[s] = 0.0; k.sc[s] = 0.0; k.qc[s] = 0.0; k.isdelta[s] = false;
-        if (p < 2) k.lc[s] = C25;
-        else if (p >= 3 && p < 3 + sv.S) { k.sc[s] = k.inv_tau; k.isdelta[s] = true; }
+        double lc = 0.0, sc = 0.0, qc = 0.0;
+        if (p < 2) lc = C25;
+        else if (p >= 3 && p < 3 + sv.S) sc = k.inv_tau;
         else if (p >= 3 + sv.S && p < sv.P) {
             const double pr = sp->prior[p - 3 - sv.S];
-            k.lc[s] = 1.0 / (pr * pr);
-            k.qc[s] = 1.0 / pr;
+            lc = 1.0 / (pr * pr);
+            qc = 1.0 / pr;
         }
+        wl.lc[p] = lc; wl.sc[p] = sc; wl.qc[p] = qc;
     }
+    wave_sync();
 }
 
 // f and gradient from (SSE, Z^T r): cn_assemble_q
@@ -191,10 +206,12 @@ __device__ __forceinline__ bool assemble_q(const SeriesView &sv, const LaneConst
     const double s2 = sigma * sigma;
     const double inv_s2 = 1.0 / s2;
     double pa = 0.0, pb = 0.0;
+    double lc[PPL], sc[PPL];
 #pragma unroll
     for (int s = 0; s < PPL; ++s) {
-        if (lk.isdelta[s]) pa = pa + __builtin_fabs(th[s]);
-        const double qq = th[s] * lk.qc[s];
+        lc[s] = lk.lc[s * W + lane]; sc[s] = lk.sc[s * W + lane];
+        if (sc[s] != 0.0) pa = pa + __builtin_fabs(th[s]);          // delta lanes
+        const double qq = th[s] * lk.qc[s * W + lane];
         pb = __builtin_fma(qq, qq, pb);
     }
     const double sabs = bfly_sum(pa), sb = bfly_sum(pb);
@@ -210,7 +227,7 @@ __device__ __forceinline__ bool assemble_q(const SeriesView &sv, const LaneConst
 #pragma unroll
     for (int s = 0; s < PPL; ++s) {
         const double sgn = (double)((th[s] > 0.0) - (th[s] < 0.0));
-        double gv = __builtin_fma(th[s], lk.lc[s], nis * ztr[s]) + sgn * lk.sc[s];
+        double gv = __builtin_fma(th[s], lc[s], nis * ztr[s]) + sgn * sc[s];
         if (s == 0 && lane == 2) gv = g2;
         if (lane + s * W >= sv.P) gv = 0.0;
         g[s] = gv;
@@ -244,32 +261,36 @@ __device__ __forceinline__ bool resid_eval_q(const SeriesView &sv, QuadLds<KP, P
     }
     wave_sync();
     const double *beta = wl.th + 3 + S;
-    for (int q = sv.NT - 1; q >= 0; --q) {
-        if (q < sv.cnt) {
-            const int idx = q * W + lane;
-            const int c = (int)(sv.cw[idx] & 0xffu);
-            const double ti = sv.tw[idx];
-            const double yi = sv.yw[idx];
-            const double *xp = sv.Xw + (size_t)q * KP * W + lane;
-            double xa = 0.0;
-#pragma unroll 4
-            for (int j = 0; j < KP; ++j) xa = __builtin_fma(xp[j * W], beta[j], xa);
-            const double gtr = __builtin_fma(wl.ks[c], ti, wl.mc[c]);
-            rb[idx] = yi - (gtr + xa);
-        }
-    }
-    ztr_pass<KP, PPL>(sv, wl, rb, sse_out, ztr);
+    auto gen = [&](int q, int idx, int c, double ti) -> double {
+        const double yi = sv.yw[idx];
+        const double *xp = sv.Xw + (size_t)q * KP * W + lane;
+        double x[KP];
+#pragma unroll
+        for (int j = 0; j < KP; ++j) x[j] = xp[j * W];
+        double xa = 0.0;
+#pragma unroll
+        for (int j = 0; j < KP; ++j) xa = __builtin_fma(x[j], beta[j], xa);
+        const double gtr = __builtin_fma(wl.ks[c], ti, wl.mc[c]);
+        return yi - (gtr + xa);
+    };
+    ztr_pass<KP, PPL>(sv, wl, rb, gen, sse_out, ztr);
     return assemble_q<PPL>(sv, lk, th, sse_out, ztr, f_out, g);
 }
 
 // quadratic-form evaluation (cn_eval_gram).  Ml: [P4][PPL][64] in LDS (or global).
-template <int PPL>
+// PQ > 0: compile-time row count of M (PPL == 1; rows >= P are zero, which is bit-neutral), the
+// whole evaluation is then ONE basic block and the scheduler can run the exp / division /
+// prior-sum chains of assemble_q underneath the LDS reads and the four fma chains.
+template <int PPL, int PQ>
 __device__ __forceinline__ bool gram_eval_q(const SeriesView &sv, const LaneConst<PPL> &lk,
                                             const double *Ml, int P4, const double (&th)[PPL],
-                                            const double (&ref)[PPL], const double (&cvec)[PPL],
+                                            const double *ref_l, const double *cvec_l,
                                             double s0, double &f_out, double (&g)[PPL],
                                             double &q2_out)
 {
+    double ref[PPL], cvec[PPL];
+#pragma unroll
+    for (int s = 0; s < PPL; ++s) { ref[s] = ref_l[s * W + lane_id()]; cvec[s] = cvec_l[s * W + lane_id()]; }
     const int lane = lane_id();
     double D[PPL], v[PPL], a[PPL][4];
 #pragma unroll
@@ -280,8 +301,35 @@ __device__ __forceinline__ bool gram_eval_q(const SeriesView &sv, const LaneCons
         for (int u = 0; u < 4; ++u) a[s][u] = 0.0;
     }
     const double *mp = Ml + lane;
+    if (PQ > 0) {
+        static_assert(PQ == 0 || PPL == 1, "compile-time M rows only for P <= 64");
+        double m[PQ > 0 ? PQ : 1];
+#pragma unroll
+        for (int q = 0; q < PQ; ++q) m[q] = mp[q * W];
+#pragma unroll
+        for (int q = 0; q < PQ; ++q) {
+            const double Dq = readlane_f64(D[0], q);
+            a[0][q & 3] = __builtin_fma(m[q], Dq, a[0][q & 3]);
+        }
+    } else {
     const int q_lo = P4 < W ? P4 : W;
-    for (int q = 0; q < q_lo; q += 4) {
+    // P4 is a multiple of 4 (rows >= P are zero); the q & 3 chain assignment is kept while the
+    // loop is unrolled by 8 so that the LDS reads of a batch are issued ahead of the fmas
+    int q = 0;
+    for (; q + 8 <= q_lo; q += 8) {
+        double m[8][PPL];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int s = 0; s < PPL; ++s) m[u][s] = mp[((q + u) * PPL + s) * W];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const double Dq = readlane_f64(D[0], q + u);
+#pragma unroll
+            for (int s = 0; s < PPL; ++s) a[s][u & 3] = __builtin_fma(m[u][s], Dq, a[s][u & 3]);
+        }
+    }
+    for (; q < q_lo; q += 4) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const double Dq = readlane_f64(D[0], q + u);
@@ -291,7 +339,7 @@ __device__ __forceinline__ bool gram_eval_q(const SeriesView &sv, const LaneCons
         }
     }
     if (PPL == 2) {
-        for (int q = W; q < P4; q += 4) {
+        for (q = W; q < P4; q += 4) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const double Dq = readlane_f64(D[PPL - 1], q + u - W);
@@ -300,6 +348,7 @@ __device__ __forceinline__ bool gram_eval_q(const SeriesView &sv, const LaneCons
                     a[s][u] = __builtin_fma(mp[((q + u) * PPL + s) * W], Dq, a[s][u]);
             }
         }
+    }
     }
 #pragma unroll
     for (int s = 0; s < PPL; ++s) v[s] = (a[s][0] + a[s][1]) + (a[s][2] + a[s][3]);
@@ -369,23 +418,14 @@ __global__ __launch_bounds__(64) void gram_build_kernel(QuadArgs qa, double *Mou
         return;
     }
     double *rb = qa.rbuf + (size_t)q * qa.f.NTmax * W;
-    for (int st = 0; st < sv.NT; ++st) {
-        if (st < sv.cnt) {
-            const int idx = st * W + lane;
-            double z;
-            if (q == 0) z = sv.tw[idx];
-            else if (q == 1) z = 1.0;
-            else if (q < 3 + sv.S) {
-                const int c = (int)(sv.cw[idx] & 0xffu);
-                z = (c > q - 3) ? sv.tw[idx] - sv.t_change[q - 3] : 0.0;
-            } else {
-                z = sv.Xw[((size_t)st * KP + (q - 3 - sv.S)) * W + lane];
-            }
-            rb[idx] = z;
-        }
-    }
+    auto gen = [&](int st, int idx, int c, double ti) -> double {
+        if (q == 0) return ti;
+        if (q == 1) return 1.0;
+        if (q < 3 + sv.S) return (c > q - 3) ? ti - sv.t_change[q - 3] : 0.0;
+        return sv.Xw[((size_t)st * KP + (q - 3 - sv.S)) * W + lane];
+    };
     double sse, ztr[PPL];
-    ztr_pass<KP, PPL>(sv, wl, rb, sse, ztr);
+    ztr_pass<KP, PPL>(sv, wl, rb, gen, sse, ztr);
 #pragma unroll
     for (int s = 0; s < PPL; ++s) out[s * W + lane] = ztr[s];
 }
@@ -393,12 +433,19 @@ __global__ __launch_bounds__(64) void gram_build_kernel(QuadArgs qa, double *Mou
 // ---------------------------------------------------------------------------------------
 // the fit kernel
 // ---------------------------------------------------------------------------------------
-// One series, start to finish, by one wave.  Deliberately NOT inlined into the persistent loop
-// of fit_quad_kernel: with the lane-0 epilogue stores sitting right in front of the loop's
-// back-edge the structurizer let lanes 1..63 re-enter the loop header (and its readfirstlane)
-// ahead of lane 0.  A call boundary keeps the loop body uniform.
-template <int KP, int PPL>
-__device__ __noinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL> &wl, double *rb,
+#ifdef TSF_QUAD_TIMING      // dev only: cycles per phase (s_memtime), summed per series into qa.dbg
+#define QT_DECL long long qt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long qt_t0 = __builtin_readcyclecounter(), qt_start = qt_t0
+#define QT_LAP(k) do { const long long t_ = __builtin_readcyclecounter(); qt_acc[k] += t_ - qt_t0; qt_t0 = t_; } while (0)
+#define QT_FLUSH() do { if (qa.dbg && lane == 0) { qt_acc[7] = __builtin_readcyclecounter() - qt_start; for (int k_ = 0; k_ < 8; ++k_) qa.dbg[(size_t)n * 8 + k_] = qt_acc[k_]; } } while (0)
+#else
+#define QT_DECL do { } while (0)
+#define QT_LAP(k) do { } while (0)
+#define QT_FLUSH() do { } while (0)
+#endif
+
+// One series, start to finish, by one wave.
+template <int KP, int PPL, int PQ>
+__device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL> &wl, double *rb,
                                           const double *Mp, int64_t n)
 {
     const FitArgs &a = qa.f;
@@ -437,18 +484,13 @@ __device__ __noinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL> &
         return;
     }
     LaneConst<PPL> lk;
-    lane_consts<PPL>(sp, sv, lk);
+    lane_consts<KP, PPL>(sp, sv, wl, lk);
 
-    double ref[PPL], cvec[PPL], s0 = 0.0, q2 = 0.0;
-    double Sh[QH][PPL], Yh[QH][PPL], rho[QH], alphas[QH];
+    double s0 = 0.0, q2 = 0.0;
+    double rho[QH];                     // indexed by ring slot
 #pragma unroll
-    for (int h = 0; h < QH; ++h) {
-        rho[h] = 0.0; alphas[h] = 0.0;
-#pragma unroll
-        for (int s = 0; s < PPL; ++s) { Sh[h][s] = 0.0; Yh[h][s] = 0.0; }
-    }
-#pragma unroll
-    for (int s = 0; s < PPL; ++s) { ref[s] = 0.0; cvec[s] = 0.0; }
+    for (int h = 0; h < QH; ++h) rho[h] = 0.0;
+    int hist_head = 0;
 
     double fk = 0.0, fk1 = 0.0, alpha = sp->init_alpha, gammak = 1.0;
     int itNum = 0, ret = 0, resetB = 0, hist_len = 0, since_rc = 0;
@@ -458,10 +500,12 @@ __device__ __noinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL> &
 
     enum { ST_INIT = 0, ST_START_ITER, ST_START_LS, ST_LS_PRE, ST_LS_EVAL, ST_RECENTER, ST_POST };
     int stage = ST_INIT;
+    QT_DECL;
     long turns = 0;
     const long max_turns = 64L * sp->max_iter + 1024;     // guard: never spin forever
     for (;;) {
         if (++turns > max_turns) { ret = -99 - stage; break; }
+        QT_LAP(0);
         if (stage == ST_POST) {
             // ---- accepted step: k is the most recent iterate ----
             double sk[PPL], yk[PPL];
@@ -473,40 +517,47 @@ __device__ __noinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL> &
             const double ykyk = pdot<PPL>(yk, yk);
             if (resetB) {
                 const double B0fact = ykyk / skyk;
-                hist_len = 0;
+                hist_len = 0; hist_head = 0;
 #pragma unroll
                 for (int s = 0; s < PPL; ++s) pk1[s] = pk1[s] / B0fact;
                 alpha = alpha * B0fact;
             }
             gammak = skyk / ykyk;
             const double rho_new = 1.0 / skyk;
-            if (hist_len < QH) {
+            {
+                int slot;
+                if (hist_len < QH) { slot = (hist_head + hist_len) % QH; hist_len++; }
+                else { slot = hist_head; hist_head = (hist_head + 1) % QH; }
 #pragma unroll
-                for (int h = 0; h < QH; ++h) {
-                    if (h == hist_len) {
-                        rho[h] = rho_new;
+                for (int h = 0; h < QH; ++h) if (h == slot) rho[h] = rho_new;
 #pragma unroll
-                        for (int s = 0; s < PPL; ++s) { Sh[h][s] = sk[s]; Yh[h][s] = yk[s]; }
-                    }
+                for (int s = 0; s < PPL; ++s) {
+                    wl.Sb[(slot * PPL + s) * W + lane] = sk[s];
+                    wl.Yb[(slot * PPL + s) * W + lane] = yk[s];
                 }
-                hist_len++;
-            } else {
+            }
+            wave_sync();
+            // the whole history ring is fetched up front (age order), so that the sequential
+            // two-loop recursion below runs out of registers
+            double Sh[QH][PPL], Yh[QH][PPL], rh[QH], alphas[QH];
 #pragma unroll
-                for (int h = 0; h + 1 < QH; ++h) {
-                    rho[h] = rho[h + 1];
+            for (int h = 0; h < QH; ++h) {
+                const int slot = (hist_head + h) % QH;
+                rh[h] = 0.0;
 #pragma unroll
-                    for (int s = 0; s < PPL; ++s) { Sh[h][s] = Sh[h + 1][s]; Yh[h][s] = Yh[h + 1][s]; }
+                for (int k = 0; k < QH; ++k) if (k == slot) rh[h] = rho[k];
+#pragma unroll
+                for (int s = 0; s < PPL; ++s) {
+                    Sh[h][s] = wl.Sb[(slot * PPL + s) * W + lane];
+                    Yh[h][s] = wl.Yb[(slot * PPL + s) * W + lane];
                 }
-                rho[QH - 1] = rho_new;
-#pragma unroll
-                for (int s = 0; s < PPL; ++s) { Sh[QH - 1][s] = sk[s]; Yh[QH - 1][s] = yk[s]; }
             }
 #pragma unroll
             for (int s = 0; s < PPL; ++s) pk[s] = -gk[s];
 #pragma unroll
             for (int h = QH - 1; h >= 0; --h) {
                 if (h < hist_len) {
-                    const double aa = rho[h] * pdot<PPL>(Sh[h], pk);
+                    const double aa = rh[h] * pdot<PPL>(Sh[h], pk);
 #pragma unroll
                     for (int s = 0; s < PPL; ++s) pk[s] = __builtin_fma(-aa, Yh[h][s], pk[s]);
                     alphas[h] = aa;
@@ -517,7 +568,7 @@ __device__ __noinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL> &
 #pragma unroll
             for (int h = 0; h < QH; ++h) {
                 if (h < hist_len) {
-                    const double bb = rho[h] * pdot<PPL>(Yh[h], pk);
+                    const double bb = rh[h] * pdot<PPL>(Yh[h], pk);
                     const double cc = alphas[h] - bb;
 #pragma unroll
                     for (int s = 0; s < PPL; ++s) pk[s] = __builtin_fma(cc, Sh[h][s], pk[s]);
@@ -533,6 +584,7 @@ __device__ __noinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL> &
             else if (stepNorm < sp->tol_param) ret = TSF_ST_ABSX;
             else if (itNum >= sp->max_iter) ret = TSF_ST_MAXIT;
             else ret = 0;
+            QT_LAP(1);
             if (ret != 0) break;
             stage = ST_START_ITER;
         }
@@ -586,21 +638,24 @@ __device__ __noinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL> &
             // ---- the single evaluation site ----
             double xe[PPL], ge[PPL], fe;
             bool bad;
+            QT_LAP(2);
             if (stage == ST_INIT || stage == ST_RECENTER) {
                 double sse_e, ztr_e[PPL];
 #pragma unroll
                 for (int s = 0; s < PPL; ++s) xe[s] = xk[s];
                 sv.n_eval++;
                 bad = resid_eval_q<KP, PPL>(sv, wl, lk, rb, xe, fe, ge, sse_e, ztr_e);
+                QT_LAP(3);
                 if (!bad) {
 #pragma unroll
                     for (int s = 0; s < PPL; ++s) {
                         const int p = lane + s * W;
-                        ref[s] = (p == 2) ? 0.0 : xe[s];
-                        cvec[s] = ztr_e[s];
+                        wl.ref[p] = (p == 2) ? 0.0 : xe[s];
+                        wl.cvec[p] = ztr_e[s];
                         gk[s] = ge[s];
                     }
                     s0 = sse_e; since_rc = 0; fk = fe;
+                    wave_sync();
                 }
                 if (stage == ST_INIT) {
                     if (bad) { ret = TSF_ST_INIT_NONFINITE; fk = fe; break; }
@@ -616,7 +671,8 @@ __device__ __noinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL> &
 #pragma unroll
             for (int s = 0; s < PPL; ++s) { xk1[s] = __builtin_fma(alpha, pk[s], xk[s]); xe[s] = xk1[s]; }
             sv.n_eval++;
-            bad = gram_eval_q<PPL>(sv, lk, Mp, P4, xe, ref, cvec, s0, fe, ge, q2);
+            bad = gram_eval_q<PPL, PQ>(sv, lk, Mp, P4, xe, wl.ref, wl.cvec, s0, fe, ge, q2);
+            QT_LAP(4);
 #pragma unroll
             for (int s = 0; s < PPL; ++s) gk1[s] = ge[s];
             const double f1 = fe;
@@ -679,9 +735,10 @@ __device__ __noinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL> &
     }
     store_theta_q<PPL>(a, sv, n, xk, a.theta);
     if (lane == 0) { a.status[n] = ret; a.n_iter[n] = itNum; a.n_eval[n] = sv.n_eval; a.fval[n] = fk; }
+    QT_FLUSH();
 }
 
-template <int KP, int PPL, int NW, bool MLDS>
+template <int KP, int PPL, int NW, bool MLDS, int PQ>
 __global__ __launch_bounds__(NW * 64, QUAD_WAVES_PER_SIMD) void fit_quad_kernel(QuadArgs qa)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -707,13 +764,16 @@ __global__ __launch_bounds__(NW * 64, QUAD_WAVES_PER_SIMD) void fit_quad_kernel(
     wave_sync();
 
     for (;;) {
-        // every lane takes part (lane 0 adds 1, the others 0): no divergent branch at the loop head
+        // Every lane takes part (lane 0 adds 1, the others 0).  With `if (lane == 0) n = atomicAdd`
+        // here, the compiler threaded lane 0's path from the lane-0-only epilogue stores of the
+        // previous series straight into this block, and lanes 1..63 re-entered the loop (and
+        // the readfirstlane below) without lane 0: an endless loop on the hardware.
         int n32 = atomicAdd(qa.counter, lane == 0 ? 1 : 0);
         n32 = __builtin_amdgcn_readfirstlane(n32);
         const int64_t n = n32;
         QDBG(1, 1000 + n);
         if (n >= a.N) break;
-        fit_one_quad<KP, PPL>(qa, wl, rb, Mp, n);
+        fit_one_quad<KP, PPL, PQ>(qa, wl, rb, Mp, n);
         QDBG(2, 2000 + n);
     }
     QDBG(3, 3);
