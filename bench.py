@@ -85,6 +85,24 @@ def cpu_baseline(spec, ds, y, fut, budget_s=12.0):
             'mean_evals': float(np.mean(evals))}
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/pmc_latest.json, written by tools/pmc_summary.py from separate FETCH_SIZE and
+    WRITE_SIZE runs of this same command): 2 x FETCH_SIZE (the gfx950 correction of
+    MI355X_MICROARCH.md: FETCH_SIZE counts 128-B requests as 64 B) + WRITE_SIZE, both in KiB.
+    bench.py cannot collect counters itself (they need rocprofv3 around the process)."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_latest.json')
+    try:
+        with open(path) as fh:
+            d = json.load(fh)
+        k = d['kernels'][kernel]
+        if d.get('series_per_launch') != N_SERIES or d.get('points') != T_POINTS:
+            return None, 'profiles/pmc_latest.json is for another workload size'
+        return (2.0 * k['FETCH_SIZE_KiB'] + k['WRITE_SIZE_KiB']) * 1024.0, d.get('source', path)
+    except Exception as e:       # no profile committed for this kernel
+        return None, 'unavailable: %s' % e
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -140,6 +158,9 @@ def main():
     bytes_per_series = T_POINTS * 8 + P * 8 + HORIZON * 8
     fit_ms = float(np.mean(kernel_ms)) if kernel_ms else float('nan')
     achieved = bytes_per_series * N_SERIES / (fit_ms * 1e-3) / 1e9
+    quad = spec.lbfgs.get('eval_form', 0) != 1      # cfg2 is linear + additive + aligned
+    kernel = 'fit_quad_kernel' if quad else 'fit_kernel'
+    traffic, traffic_src = pmc_traffic(kernel)
     flops_per_eval = 4 * T_POINTS * spec.K + 20 * T_POINTS + 6 * spec.n_changepoints
     tflops = float(n_eval.sum()) * flops_per_eval / (fit_ms * 1e-3) / 1e12
     res = {
@@ -152,10 +173,13 @@ def main():
                                '(Stan default tolerances) + %d-step forecast'
                                % (N_SERIES, T_POINTS, HORIZON),
                    'series_per_gpu': N_SERIES, 'points': T_POINTS, 'horizon': HORIZON,
-                   'K': spec.K, 'S': spec.n_changepoints, 'P': P, 'parallelism': 'shard-by-id x%d' % world},
-        'roofline': {'bound': 'hbm', 'kernel': 'fit_kernel', 'achieved': achieved,
+                   'K': spec.K, 'S': spec.n_changepoints, 'P': P,
+                   'eval_form': 'quadratic (Gram) form, re-centred' if quad else 'residual form',
+                   'parallelism': 'shard-by-id x%d' % world},
+        'roofline': {'bound': 'hbm', 'kernel': kernel, 'achieved': achieved,
                      'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS,
-                     'traffic': None, 'algorithmic_bytes_per_launch': bytes_per_series * N_SERIES,
+                     'traffic': traffic, 'traffic_source': traffic_src,
+                     'algorithmic_bytes_per_launch': bytes_per_series * N_SERIES,
                      'kernel_ms_avg': fit_ms, 'launches_timed': len(kernel_ms),
                      'note': 'path is fp64-VALU/latency bound by construction (SURVEY 8d); '
                              'fp64 figure alongside',

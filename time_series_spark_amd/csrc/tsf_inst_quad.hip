@@ -18,8 +18,8 @@ namespace tsf {
 
 int quad_waves_per_block(int PPL) { return PPL == 2 ? TSF_QUAD_NW2 : TSF_QUAD_NW; }
 
-template <int KP, int PPL, bool MLDS, int PQ>
-static int launch_quad_one(const QuadPlan &qp, const QuadArgs &qa, double *Mg, hipStream_t st)
+template <int KP, int PPL, bool MLDS, int PQ, bool RLDS>
+static int launch_quad_rl(const QuadPlan &qp, const QuadArgs &qa, double *Mg, hipStream_t st)
 {
     constexpr int NW = (PPL == 2) ? TSF_QUAD_NW2 : TSF_QUAD_NW;
     const char *dbg = getenv("TSF_QUAD_DEBUG");
@@ -31,10 +31,11 @@ static int launch_quad_one(const QuadPlan &qp, const QuadArgs &qa, double *Mg, h
         fprintf(stderr, "[quad] gram_build done: %s (P4 %d blocks %d slots %d)\n", hipGetErrorString(e), qp.P4, qp.blocks, qp.slots);
         if (dbg[0] == '1') return (int)e;
     }
-    const size_t lds = (MLDS ? sizeof(double) * (size_t)qp.P4 * PPL * W : 0) + sizeof(QuadLds<KP, PPL>) * NW;
+    const size_t lds = (MLDS ? sizeof(double) * (size_t)qp.P4 * PPL * W : 0) + sizeof(QuadLds<KP, PPL>) * NW +
+                       (RLDS ? sizeof(double) * (size_t)NW * qa.f.NTmax * W : 0);
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute((const void *)fit_quad_kernel<KP, PPL, NW, MLDS, PQ>,
+        hipFuncSetAttribute((const void *)fit_quad_kernel<KP, PPL, NW, MLDS, PQ, RLDS>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
@@ -45,7 +46,7 @@ static int launch_quad_one(const QuadPlan &qp, const QuadArgs &qa, double *Mg, h
         memset(hdbg, 0, sizeof(long long) * 8 * qp.blocks * NW);
         qb.dbg = hdbg;
     }
-    hipLaunchKernelGGL((fit_quad_kernel<KP, PPL, NW, MLDS, PQ>), dim3((unsigned)qp.blocks), dim3(NW * 64), lds, st, qb);
+    hipLaunchKernelGGL((fit_quad_kernel<KP, PPL, NW, MLDS, PQ, RLDS>), dim3((unsigned)qp.blocks), dim3(NW * 64), lds, st, qb);
     if (hdbg) {
         e = hipGetLastError();
         fprintf(stderr, "[quad] fit launched: %s lds %zu\n", hipGetErrorString(e), lds);
@@ -66,7 +67,7 @@ static int launch_quad_one(const QuadPlan &qp, const QuadArgs &qa, double *Mg, h
         hipMemsetAsync(dd, 0, nb, st);
         qb.dbg = dd;
         hipMemsetAsync(qa.counter, 0, sizeof(int), st);
-        hipLaunchKernelGGL((fit_quad_kernel<KP, PPL, NW, MLDS, PQ>), dim3((unsigned)qp.blocks), dim3(NW * 64), lds, st, qb);
+        hipLaunchKernelGGL((fit_quad_kernel<KP, PPL, NW, MLDS, PQ, RLDS>), dim3((unsigned)qp.blocks), dim3(NW * 64), lds, st, qb);
         hipStreamSynchronize(st);
         std::vector<long long> h(8 * (size_t)qa.f.N);
         hipMemcpy(h.data(), dd, nb, hipMemcpyDeviceToHost);
@@ -86,6 +87,17 @@ static int launch_quad_one(const QuadPlan &qp, const QuadArgs &qa, double *Mg, h
         return (int)e;
     }
     return (int)hipGetLastError();
+}
+
+// residual staging in LDS when M + per-wave state + NW x NTmax x 64 doubles fit in 160 KB
+template <int KP, int PPL, bool MLDS, int PQ>
+static int launch_quad_one(const QuadPlan &qp, const QuadArgs &qa, double *Mg, hipStream_t st)
+{
+    constexpr int NW = (PPL == 2) ? TSF_QUAD_NW2 : TSF_QUAD_NW;
+    const size_t base = (MLDS ? sizeof(double) * (size_t)qp.P4 * PPL * W : 0) + sizeof(QuadLds<KP, PPL>) * NW;
+    const size_t rbytes = sizeof(double) * (size_t)NW * qa.f.NTmax * W;
+    if (base + rbytes <= 160 * 1024) return launch_quad_rl<KP, PPL, MLDS, PQ, true>(qp, qa, Mg, st);
+    return launch_quad_rl<KP, PPL, MLDS, PQ, false>(qp, qa, Mg, st);
 }
 
 int launch_quad(int KP, const QuadPlan &qp, const QuadArgs &qa, double *Mg, hipStream_t st)

@@ -52,7 +52,6 @@ struct QuadLds {
     // per-series vectors that are cold during an evaluation live here, not in registers
     double lc[PPL * W], sc[PPL * W], qc[PPL * W];      // cn_assemble_q lane constants
     double ref[PPL * W], cvec[PPL * W];                // reference point and c = Z^T r_ref
-    double Sb[QH * PPL * W], Yb[QH * PPL * W];         // L-BFGS history ring
 };
 
 __device__ __forceinline__ int lane_id() { return (int)threadIdx.x & (W - 1); }
@@ -303,13 +302,22 @@ __device__ __forceinline__ bool gram_eval_q(const SeriesView &sv, const LaneCons
     const double *mp = Ml + lane;
     if (PQ > 0) {
         static_assert(PQ == 0 || PPL == 1, "compile-time M rows only for P <= 64");
-        double m[PQ > 0 ? PQ : 1];
+        // batches of MB rows: MB LDS reads in flight, then their fmas; the scheduling barrier
+        // keeps the compiler from hoisting every read of M to the top (register pressure)
+        constexpr int MB = 16;
 #pragma unroll
-        for (int q = 0; q < PQ; ++q) m[q] = mp[q * W];
+        for (int q0 = 0; q0 < PQ; q0 += MB) {
+            double m[MB];
 #pragma unroll
-        for (int q = 0; q < PQ; ++q) {
-            const double Dq = readlane_f64(D[0], q);
-            a[0][q & 3] = __builtin_fma(m[q], Dq, a[0][q & 3]);
+            for (int u = 0; u < MB; ++u) if (q0 + u < PQ) m[u] = mp[(q0 + u) * W];
+#pragma unroll
+            for (int u = 0; u < MB; ++u) {
+                if (q0 + u < PQ) {
+                    const double Dq = readlane_f64(D[0], q0 + u);
+                    a[0][(q0 + u) & 3] = __builtin_fma(m[u], Dq, a[0][(q0 + u) & 3]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     } else {
     const int q_lo = P4 < W ? P4 : W;
@@ -487,10 +495,14 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
     lane_consts<KP, PPL>(sp, sv, wl, lk);
 
     double s0 = 0.0, q2 = 0.0;
-    double rho[QH];                     // indexed by ring slot
+    // L-BFGS history in registers, age order (index 0 = oldest)
+    double Sh[QH][PPL], Yh[QH][PPL], rh[QH];
 #pragma unroll
-    for (int h = 0; h < QH; ++h) rho[h] = 0.0;
-    int hist_head = 0;
+    for (int h = 0; h < QH; ++h) {
+        rh[h] = 0.0;
+#pragma unroll
+        for (int s = 0; s < PPL; ++s) { Sh[h][s] = 0.0; Yh[h][s] = 0.0; }
+    }
 
     double fk = 0.0, fk1 = 0.0, alpha = sp->init_alpha, gammak = 1.0;
     int itNum = 0, ret = 0, resetB = 0, hist_len = 0, since_rc = 0;
@@ -517,41 +529,35 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
             const double ykyk = pdot<PPL>(yk, yk);
             if (resetB) {
                 const double B0fact = ykyk / skyk;
-                hist_len = 0; hist_head = 0;
+                hist_len = 0;
 #pragma unroll
                 for (int s = 0; s < PPL; ++s) pk1[s] = pk1[s] / B0fact;
                 alpha = alpha * B0fact;
             }
             gammak = skyk / ykyk;
             const double rho_new = 1.0 / skyk;
-            {
-                int slot;
-                if (hist_len < QH) { slot = (hist_head + hist_len) % QH; hist_len++; }
-                else { slot = hist_head; hist_head = (hist_head + 1) % QH; }
+            if (hist_len < QH) {
 #pragma unroll
-                for (int h = 0; h < QH; ++h) if (h == slot) rho[h] = rho_new;
+                for (int h = 0; h < QH; ++h) {
+                    if (h == hist_len) {
+                        rh[h] = rho_new;
 #pragma unroll
-                for (int s = 0; s < PPL; ++s) {
-                    wl.Sb[(slot * PPL + s) * W + lane] = sk[s];
-                    wl.Yb[(slot * PPL + s) * W + lane] = yk[s];
+                        for (int s = 0; s < PPL; ++s) { Sh[h][s] = sk[s]; Yh[h][s] = yk[s]; }
+                    }
                 }
-            }
-            wave_sync();
-            // the whole history ring is fetched up front (age order), so that the sequential
-            // two-loop recursion below runs out of registers
-            double Sh[QH][PPL], Yh[QH][PPL], rh[QH], alphas[QH];
+                hist_len++;
+            } else {
 #pragma unroll
-            for (int h = 0; h < QH; ++h) {
-                const int slot = (hist_head + h) % QH;
-                rh[h] = 0.0;
+                for (int h = 0; h + 1 < QH; ++h) {
+                    rh[h] = rh[h + 1];
 #pragma unroll
-                for (int k = 0; k < QH; ++k) if (k == slot) rh[h] = rho[k];
-#pragma unroll
-                for (int s = 0; s < PPL; ++s) {
-                    Sh[h][s] = wl.Sb[(slot * PPL + s) * W + lane];
-                    Yh[h][s] = wl.Yb[(slot * PPL + s) * W + lane];
+                    for (int s = 0; s < PPL; ++s) { Sh[h][s] = Sh[h + 1][s]; Yh[h][s] = Yh[h + 1][s]; }
                 }
+                rh[QH - 1] = rho_new;
+#pragma unroll
+                for (int s = 0; s < PPL; ++s) { Sh[QH - 1][s] = sk[s]; Yh[QH - 1][s] = yk[s]; }
             }
+            double alphas[QH];
 #pragma unroll
             for (int s = 0; s < PPL; ++s) pk[s] = -gk[s];
 #pragma unroll
@@ -738,7 +744,7 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
     QT_FLUSH();
 }
 
-template <int KP, int PPL, int NW, bool MLDS, int PQ>
+template <int KP, int PPL, int NW, bool MLDS, int PQ, bool RLDS>
 __global__ __launch_bounds__(NW * 64, QUAD_WAVES_PER_SIMD) void fit_quad_kernel(QuadArgs qa)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -759,7 +765,10 @@ __global__ __launch_bounds__(NW * 64, QUAD_WAVES_PER_SIMD) void fit_quad_kernel(
 #endif
     QDBG(0, 1);
     const double *Mp = MLDS ? Ml : qa.Mg;
-    double *rb = qa.rbuf + ((size_t)blockIdx.x * NW + wid) * a.NTmax * W;
+    // residual staging r[q][lane] of the running residual pass: in LDS when the launch found room
+    // for NW x NTmax x 64 doubles, else in the global scratch (long series)
+    double *rb = RLDS ? reinterpret_cast<double *>(smem + m_bytes + sizeof(QuadLds<KP, PPL>) * NW) + (size_t)wid * a.NTmax * W
+                      : qa.rbuf + ((size_t)blockIdx.x * NW + wid) * a.NTmax * W;
     for (int i = lane; i < PPL * W + W; i += W) wl.th[i] = 0.0;
     wave_sync();
 

@@ -18,3 +18,28 @@ for f in sorted(glob.glob(os.path.join(out, 'prof_*', '**', '*counter_collection
     for (k, c), d in sorted(per.items()):
         vals = list(d.values())
         print('%-62s %-22s n=%-4d mean=%.6g' % (k, c, len(vals), sum(vals) / len(vals)))
+
+
+# profiles/pmc_latest.json: what bench.py reports as roofline.traffic
+import json
+want = {}
+for f in sorted(glob.glob(os.path.join(out, 'prof_*', '**', '*counter_collection.csv'), recursive=True)):
+    per = defaultdict(lambda: defaultdict(float))
+    with open(f) as fh:
+        for row in csv.DictReader(fh):
+            if row['Counter_Name'] in ('FETCH_SIZE', 'WRITE_SIZE'):
+                k = row['Kernel_Name'].split('(')[0]
+                for short in ('fit_quad_kernel', 'fit_kernel'):
+                    if short in k and 'gram' not in k:
+                        per[(short, row['Counter_Name'])][row['Dispatch_Id']] += float(row['Counter_Value'])
+                        break
+    for (k, c), d in per.items():
+        want.setdefault(k, {})[c + '_KiB'] = sum(d.values()) / len(d)
+if want:
+    js = {'kernels': want, 'series_per_launch': int(os.environ.get('BENCH_N', '10000')),
+          'points': int(os.environ.get('BENCH_T', '730')),
+          'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) around bench.py, '
+                    'tools/gpu_round.sh %s' % os.path.basename(os.path.normpath(out))}
+    with open(os.path.join(out, 'pmc_latest.json'), 'w') as fh:
+        json.dump(js, fh, indent=1)
+    print('wrote', os.path.join(out, 'pmc_latest.json'))
