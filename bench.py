@@ -161,7 +161,14 @@ def main():
     quad = spec.lbfgs.get('eval_form', 0) != 1      # cfg2 is linear + additive + aligned
     kernel = 'fit_quad_kernel' if quad else 'fit_kernel'
     traffic, traffic_src = pmc_traffic(kernel)
-    flops_per_eval = 4 * T_POINTS * spec.K + 20 * T_POINTS + 6 * spec.n_changepoints
+    # residual form: every evaluation is a pass over the T x K design values (BASELINE.md
+    # section 4); quadratic form: a P x P mat-vec (2 P^2 flops) plus O(P) -- the residual-form
+    # passes it still needs (initial point + re-centring, ~4 % of the evaluations) are not
+    # counted separately by the kernel, so only the lower bound is quoted for it
+    if quad:
+        flops_per_eval = 2 * P * P + 16 * P
+    else:
+        flops_per_eval = 4 * T_POINTS * spec.K + 20 * T_POINTS + 6 * spec.n_changepoints
     tflops = float(n_eval.sum()) * flops_per_eval / (fit_ms * 1e-3) / 1e12
     res = {
         'metric': 'series_fitted_per_sec', 'value': world * N_SERIES * args.steps / dt,
@@ -181,8 +188,12 @@ def main():
                      'traffic': traffic, 'traffic_source': traffic_src,
                      'algorithmic_bytes_per_launch': bytes_per_series * N_SERIES,
                      'kernel_ms_avg': fit_ms, 'launches_timed': len(kernel_ms),
-                     'note': 'path is fp64-VALU/latency bound by construction (SURVEY 8d); '
-                             'fp64 figure alongside',
+                     'note': 'HBM sees each series once in and once out; the fit itself is a '
+                             'dependent-latency-bound fp64 L-BFGS loop on registers/LDS '
+                             '(SURVEY 8d, DESIGN.md section 5), so the HBM fraction is small by '
+                             'construction; evaluation rate and fp64 figure alongside',
+                     'evaluations_per_s': float(n_eval.sum()) / (fit_ms * 1e-3),
+                     'flops_per_evaluation_algorithmic': flops_per_eval,
                      'fp64_tflops_algorithmic': tflops,
                      'fp64_frac_of_vector_peak': tflops / FP64_PEAK_TFLOPS},
         'optimizer': {'mean_iters': float(n_iter.mean()), 'mean_evals': float(n_eval.mean()),
