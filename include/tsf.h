@@ -68,6 +68,8 @@ enum {
     TSF_ST_CONSTANT = 50,      /* constant y, linear growth: fbprophet skips optimisation */
     TSF_ST_LSFAIL = -1,        /* line search failed (pystan raises RuntimeError) */
     TSF_ST_INIT_NONFINITE = -2,/* log_prob non-finite at the initial point (RuntimeError) */
+    TSF_ST_EVAL_LIMIT = -3,    /* > 64*max_iter+1024 evaluations: the line search never settled
+                                  (guard; treated like LSFAIL) */
     TSF_ST_TOO_FEW = -10,      /* < 2 rows (fbprophet raises ValueError) */
     TSF_ST_CAP = -11           /* cap <= floor (fbprophet raises ValueError) */
 };

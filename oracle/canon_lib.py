@@ -21,7 +21,7 @@ MAX_SEAS = 8
 MAX_EXTRA = 64
 
 STATUS_NAMES = {0: 'SUCCESS', 10: 'ABSX', 20: 'ABSF', 21: 'RELF', 30: 'ABSGRAD', 31: 'RELGRAD',
-                40: 'MAXIT', -1: 'LSFAIL', -2: 'INIT_NONFINITE', 50: 'CONSTANT',
+                40: 'MAXIT', -1: 'LSFAIL', -2: 'INIT_NONFINITE', -3: 'EVAL_LIMIT', 50: 'CONSTANT',
                 -10: 'ERR_TOO_FEW', -11: 'ERR_CAP', -12: 'ERR_SIZE'}
 
 

@@ -89,6 +89,7 @@ typedef struct {
 
 enum { TERM_SUCCESS = 0, TERM_ABSX = 10, TERM_ABSF = 20, TERM_RELF = 21, TERM_ABSGRAD = 30,
        TERM_RELGRAD = 31, TERM_MAXIT = 40, TERM_LSFAIL = -1, CN_INIT_NONFINITE = -2,
+       CN_EVAL_LIMIT = -3,   /* more than 64*max_iter+1024 evaluations: the line search never settled */
        CN_CONSTANT = 50, CN_ERR_TOO_FEW = -10, CN_ERR_CAP = -11, CN_ERR_SIZE = -12 };
 
 typedef struct {
@@ -103,6 +104,7 @@ typedef struct {
     double k0, m0;
     int constant_y;
     int n_eval;
+    int eval_limit;          /* evaluation budget of the whole fit (guard, see cn_lbfgs) */
     /* raw data-term pieces of the last residual-form evaluation: SSE and Z^T r */
     double last_sse, last_ztr[CN_MAX_P];
     /* quadratic (Gram) form state */
@@ -739,6 +741,7 @@ static int line_search(cn_series *se, double *alpha_io, double *x1, double *f1_o
         double f1, newDFp;
         int bad = 0;
         for (;;) {   /* evaluation with Stan's non-finite handling */
+            if (se->n_eval >= se->eval_limit) return 2;      /* guard: budget exhausted */
             axpy_to(x1, x0, alpha, p);
             const int ret = cn_eval_any(se, x1, &f1, g1);
             if (ret == 0) break;
@@ -800,6 +803,10 @@ static int cn_lbfgs(cn_series *se, const cn_spec *o, const double *theta0, doubl
     memset(pk_1, 0, sizeof(pk_1)); memset(gk_1, 0, sizeof(gk_1)); memset(xk_1, 0, sizeof(xk_1));
     memcpy(xk, theta0, sizeof(xk));
     se->n_eval = 0;
+    /* Guard against a line search that never settles (a non-finite bracket makes every exit test
+     * of the zoom phase false): the whole fit may spend at most 64*max_iter+1024 evaluations.
+     * Reported as CN_EVAL_LIMIT (< 0, i.e. "optimiser failed": the reference drops the series). */
+    se->eval_limit = 64 * o->max_iter + 1024;
     if (se->gram ? cn_resid_q(se, xk, &fk, gk) : cn_eval(se, xk, &fk, gk)) {
         memcpy(theta_out, theta0, sizeof(xk));
         res->status = CN_INIT_NONFINITE; res->n_iter = 0; res->n_eval = se->n_eval; res->f = fk;
@@ -821,6 +828,7 @@ static int cn_lbfgs(cn_series *se, const cn_spec *o, const double *theta0, doubl
                 alpha = o->init_alpha;
             }
             const int rc = line_search(se, &alpha, xk_1, &fk_1, gk_1, pk, xk, fk, gk);
+            if (rc == 2) { ret = CN_EVAL_LIMIT; goto done; }
             if (rc) {
                 if (resetB) { ret = TERM_LSFAIL; goto done; }
                 resetB = 2;

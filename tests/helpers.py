@@ -48,6 +48,7 @@ def oracle_spec(spec, aligned=True):
 YEARLY = {'name': 'yearly', 'period': 365.25, 'fourier_order': 10}
 WEEKLY = {'name': 'weekly', 'period': 7, 'fourier_order': 3}
 DAILY = {'name': 'daily', 'period': 1, 'fourier_order': 4}
+YEARLY5 = {'name': 'yearly', 'period': 365.25, 'fourier_order': 5}
 
 # name -> (growth, mode, T, seasonalities, n_holidays)
 CASES = {
@@ -57,6 +58,12 @@ CASES = {
     'logistic_additive_400': ('logistic', 'additive', 400, [WEEKLY], 0),
     'short_90': ('linear', 'additive', 90, [WEEKLY], 0),
     'cfg4_holidays': ('logistic', 'multiplicative', 730, [YEARLY, WEEKLY], 10),
+    # quadratic-form kernel variants: NT = 18 (cfg3 length), residual staging in global memory
+    # (T too long for LDS), the 16-column kernel, and the two-slot (P > 64) kernel
+    'cfg3_linear_1095': ('linear', 'additive', 1095, [YEARLY, WEEKLY], 0),
+    'long_linear_1400': ('linear', 'additive', 1400, [YEARLY, WEEKLY], 0),
+    'kp16_linear_400': ('linear', 'additive', 400, [YEARLY5, WEEKLY], 0),
+    'linear_additive_holidays': ('linear', 'additive', 730, [YEARLY, WEEKLY], 10),
 }
 
 

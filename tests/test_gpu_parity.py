@@ -209,6 +209,39 @@ def test_full_size_panel_properties(env):
         assert np.max(np.abs(yh[n] - yo) / np.abs(yo)) <= REL_TOL
 
 
+@pytest.mark.parametrize('cfg', ['cfg3', 'cfg5'])
+def test_full_size_other_baseline_configs(env, cfg):
+    """BASELINE configs 3 (one GPU's 12 500 x 1 095 share of the 100 000 series) and 5
+    (1 000 000 x 90, float32 y) at full size: every series terminates, forecasts finite, a
+    random sample is bit-identical to the oracle."""
+    fc, cl = env
+    from time_series_spark_amd import synth
+    if cfg == 'cfg3':
+        N, T, dt = 12500, 1095, np.float64
+    else:
+        N, T, dt = 1000000, 90, np.float32
+    ds, y = synth.make_panel(N, T, 'linear', seed=751, dtype=dt)
+    spec = fc.ModelSpec(growth='linear', seasonalities=fc.ModelSpec.auto_seasonalities(ds))
+    assert spec.K == (26 if cfg == 'cfg3' else 6)
+    fut = ds[-1] + helpers.DAY_NS * np.arange(1, 91)
+    r = fc.fit_aligned(spec, ds, y)
+    # a handful of the million short series end in a failed line search (pystan would raise
+    # RuntimeError and the reference drop the series); none may end any other way
+    bad = r.status <= 0
+    assert bad.sum() <= N // 20000 and np.isin(r.status[bad], [-1, -3]).all() and (r.n_iter >= 1).all()
+    sub = np.random.default_rng(1).choice(N, 10, replace=False)
+    sub = np.concatenate([sub[~bad[sub]], np.flatnonzero(bad)[:3]])
+    yh = fc.predict(spec, r.theta[sub], r.y_scale[sub], r.grid, fut)
+    assert np.isfinite(yh).all()
+    csp = helpers.oracle_spec(spec)
+    for i, n in enumerate(sub):
+        o = cl.fit(csp, ds, y[n].astype(np.float64))
+        yo, _ = cl.predict(csp, o, fut)
+        assert r.n_iter[n] == o['n_iter'] and r.n_eval[n] == o['n_eval'] and r.status[n] == o['status']
+        assert np.max(np.abs(yh[i] - yo) / np.abs(yo)) <= REL_TOL
+        assert np.array_equal(yh[i], yo)
+
+
 def test_reference_contract_fit_and_forecast_udfs(env, tmp_path):
     """/root/reference/tests/unit/prophet_modeler_test.py:59-75 and
     prophet_scorer_test.py:83-114 re-expressed on pandas: 2 model rows with the reference's

@@ -37,7 +37,9 @@ def test_det_math_close_to_libm():
 def _literal(case, n=0):
     spec, ds, y, floor, cap, extra, fut, extra_future = helpers.make_case(case)
     growth, mode = spec.growth, spec.seasonality_mode
-    has_yearly = any(s['name'] == 'yearly' for s in spec.seasonalities)
+    # fbprophet: yearly_seasonality accepts a Fourier order as well as True/False
+    has_yearly = max([s['fourier_order'] for s in spec.seasonalities if s['name'] == 'yearly'] + [0])
+    has_yearly = True if has_yearly == 10 else (has_yearly or False)
     hol = None
     if extra is not None:
         # rebuild an fbprophet-style holidays frame from the indicator columns

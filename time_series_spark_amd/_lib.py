@@ -24,8 +24,10 @@ EVAL_AUTO, EVAL_RESIDUAL, EVAL_QUADRATIC = 0, 1, 2
 
 ST_ABSX, ST_ABSF, ST_RELF, ST_ABSGRAD, ST_RELGRAD, ST_MAXIT = 10, 20, 21, 30, 31, 40
 ST_CONSTANT, ST_LSFAIL, ST_INIT_NONFINITE, ST_TOO_FEW, ST_CAP = 50, -1, -2, -10, -11
+ST_EVAL_LIMIT = -3
 STATUS_NAMES = {10: 'ABSX', 20: 'ABSF', 21: 'RELF', 30: 'ABSGRAD', 31: 'RELGRAD', 40: 'MAXIT',
-                50: 'CONSTANT', -1: 'LSFAIL', -2: 'INIT_NONFINITE', -10: 'TOO_FEW', -11: 'CAP'}
+                50: 'CONSTANT', -1: 'LSFAIL', -2: 'INIT_NONFINITE', -3: 'EVAL_LIMIT', -10: 'TOO_FEW',
+                -11: 'CAP'}
 
 
 class TsfSpec(ctypes.Structure):

@@ -229,6 +229,14 @@ static int quad_plan(tsf_ctx *ctx, const DevSpec &hs, int64_t N, QuadPlan *qp)
 }
 
 typedef int (*launch_t)(int, const FitArgs &, int, hipStream_t);
+typedef int (*launch_tile_t)(int, const FitArgs &, int *, int, hipStream_t);
+
+static launch_tile_t pick_tile_launch(int growth, int mode)
+{
+    static const launch_tile_t tab[2][3] = {{launch_tile_g0m0, launch_tile_g0m1, launch_tile_g0m2},
+                                            {launch_tile_g1m0, launch_tile_g1m1, launch_tile_g1m2}};
+    return tab[growth][mode];
+}
 
 static launch_t pick_launch(int growth, int mode)
 {
@@ -311,6 +319,16 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
         { const char *d = getenv("TSF_QUAD_STAGE"); qa.debug = d ? atoi(d) : 0; qa.dbg = nullptr; }
         HIP_TRY(ctx, hipMemsetAsync(qa.counter, 0, sizeof(int), st));
         lrc = launch_quad(hs.KP, qp, qa, (double *)(ws + l.Mg), st);
+    } else if (aligned && theta_in == nullptr && getenv("TSF_TILE")) {
+        // EXPERIMENT (off by default, TSF_TILE=1): aligned panel, residual form, persistent
+        // workgroups sharing the design tiles in LDS.  Bit-identical to fit_kernel, but measured
+        // SLOWER on cfg2 (92 ms vs 64 ms): one workgroup barrier per step
+        // serialises eight latency-bound waves.
+        int *cnt = (int *)(ws + l.counter);
+        HIP_TRY(ctx, hipMemsetAsync(cnt, 0, sizeof(int), st));
+        hipDeviceProp_t prop;
+        HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
+        lrc = pick_tile_launch(hs.growth, mode)(hs.KP, a, cnt, prop.multiProcessorCount, st);
     } else {
         lrc = pick_launch(hs.growth, mode)(hs.KP, a, theta_in != nullptr, st);
     }

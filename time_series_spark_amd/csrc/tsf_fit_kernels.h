@@ -32,7 +32,28 @@ struct WaveLds {
     double Sb[MAXH * PPL * W], Yb[MAXH * PPL * W];
 };
 
-#define TSF_WAVE_SYNC() __syncthreads()
+// LDS hand-off inside one wave (see wave_sync in tsf_common.h); never a workgroup barrier, so
+// the same code runs in one-wave and in multi-wave workgroups
+#define TSF_WAVE_SYNC() wave_sync()
+
+__device__ __forceinline__ int lane_id() { return (int)threadIdx.x & (W - 1); }
+
+// Shared design tiles of a multi-wave workgroup (fit_tile_kernel): step q of the step-major
+// tables -- Xw[q] (KP x 64 doubles), tw[q], cw[q] -- is staged ONCE per workgroup in LDS,
+// double buffered, while the waves (one series each) work on step q+1.
+// The LDS buffers are described by BYTE OFFSETS into the workgroup's dynamic LDS and turned
+// into pointers at the point of use (pointers kept in a struct would decay to generic/flat
+// accesses).
+struct TileCtx {
+    unsigned xoff, toff, coff;  // two buffers each: [2][KP][64] f64, [2][64] f64, [2][64] u16
+    const double *Xg, *tg;      // global step-major tables of the (aligned) grid
+    const uint16_t *cg;
+};
+extern __shared__ __align__(16) unsigned char tsf_dyn_lds[];
+template <int KP>
+__device__ __forceinline__ double *tile_x(const TileCtx &tc, int b) { return reinterpret_cast<double *>(tsf_dyn_lds + tc.xoff) + b * KP * W; }
+__device__ __forceinline__ double *tile_t(const TileCtx &tc, int b) { return reinterpret_cast<double *>(tsf_dyn_lds + tc.toff) + b * W; }
+__device__ __forceinline__ uint16_t *tile_c(const TileCtx &tc, int b) { return reinterpret_cast<uint16_t *>(tsf_dyn_lds + tc.coff) + b * W; }
 
 // theta[p] for a wave-uniform p, straight from the owning lane's register
 template <int PPL>
@@ -50,7 +71,7 @@ template <int KP, int PPL>
 __device__ __forceinline__ void column_sums(double (&acc)[KP], WaveLds<KP, PPL> &lds)
 {
     static_assert(KP % 4 == 0, "KP must be a multiple of 4");
-    const int lane = threadIdx.x;
+    const int lane = lane_id();
     double c[KP / 2];
 #pragma unroll
     for (int i = 0; i < KP / 2; ++i) {
@@ -74,16 +95,22 @@ __device__ __forceinline__ void column_sums(double (&acc)[KP], WaveLds<KP, PPL> 
 }
 
 // MODE: 0 all columns additive, 1 all multiplicative, 2 mixed (Ka additive first)
-template <int KP, int GROWTH, int MODE, int PPL>
+// NW > 0: called by EVERY wave of an NW-wave workgroup in the same round (workgroup barriers
+// inside); `active` says whether this wave has a point to evaluate, tc is the tile context.
+template <int KP, int GROWTH, int MODE, int PPL, int NW = 0>
 __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesView &sv,
                                         WaveLds<KP, PPL> &lds, const double (&th)[PPL],
-                                        double &f_out, double (&g)[PPL])
+                                        double &f_out, double (&g)[PPL],
+                                        const TileCtx tc = TileCtx(), bool active = true)
 {
-    const int lane = threadIdx.x;
+    constexpr bool TILED = NW > 0;
+    const int lane = lane_id();
     const int S = sv.S, NT = sv.NT, T = sv.T;
     const int Ka = (MODE == 0) ? KP : (MODE == 1 ? 0 : sp->Ka);
-    constexpr bool HOLD = (KP <= 32);   // design row + coefficients held in registers / SGPRs
-    sv.n_eval++;
+    // design row + coefficients held in registers / SGPRs; from LDS tiles re-reading the row is
+    // cheap, and the tiled kernel needs the registers for its longer-lived state
+    constexpr bool HOLD = TILED ? (KP <= 16) : (KP <= 32);
+    if (active) sv.n_eval++;
     const double k = theta_at<PPL>(th, 0), m = theta_at<PPL>(th, 1), ls = theta_at<PPL>(th, 2);
     const double sigma = dm_exp(ls);
     const double inv_s2 = 1.0 / (sigma * sigma);
@@ -120,14 +147,42 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
     double acc[KP];
 #pragma unroll
     for (int j = 0; j < KP; ++j) acc[j] = 0.0;
+    // ---- tile pipeline (TILED): every thread of the workgroup moves its share of step q-1 from
+    // global memory to the other LDS buffer while the waves compute step q ----
+    constexpr int NTH = TILED ? NW * W : 1;
+    constexpr int TL = TILED ? (KP * W + NTH - 1) / NTH : 1;
+    const int tid = (int)threadIdx.x;
+    double tr[TL], tt = 0.0;
+    unsigned tcv = 0;
+    auto tile_issue = [&](int q) {
+#pragma unroll
+        for (int i = 0; i < TL; ++i) {
+            const int e = tid + i * NTH;
+            tr[i] = (e < KP * W) ? tc.Xg[(size_t)q * KP * W + e] : 0.0;
+        }
+        if (tid < W) tt = tc.tg[q * W + tid];
+        else if (tid < 2 * W) tcv = tc.cg[q * W + tid - W];
+    };
+    auto tile_commit = [&](int q) {
+        double *xb = tile_x<KP>(tc, q & 1);
+#pragma unroll
+        for (int i = 0; i < TL; ++i) {
+            const int e = tid + i * NTH;
+            if (e < KP * W) xb[e] = tr[i];
+        }
+        if (tid < W) tile_t(tc, q & 1)[tid] = tt;
+        else if (tid < 2 * W) tile_c(tc, q & 1)[tid - W] = (uint16_t)tcv;
+    };
+    if (TILED) { tile_issue(NT - 1); tile_commit(NT - 1); __syncthreads(); }
     for (int q = NT - 1; q >= 0; --q) {
-        if (q < sv.cnt) {
+        if (TILED && q > 0) tile_issue(q - 1);
+        if (active && q < sv.cnt) {
             const int idx = q * W + lane;
-            const unsigned cwv = sv.cw[idx];
+            const unsigned cwv = TILED ? (unsigned)tile_c(tc, q & 1)[lane] : (unsigned)sv.cw[idx];
             const int c = (int)(cwv & 0xffu), cprev = (int)(cwv >> 8);
-            const double ti = sv.tw[idx];
+            const double ti = TILED ? tile_t(tc, q & 1)[lane] : sv.tw[idx];
             const double yi = sv.yw[idx];
-            const double *xp = sv.Xw + (size_t)q * KP * W + lane;
+            const double *xp = TILED ? tile_x<KP>(tc, q & 1) + lane : sv.Xw + (size_t)q * KP * W + lane;
             double x[HOLD ? KP : 1];
             double xa = 0.0, xm = 0.0;
             if (HOLD) {
@@ -164,12 +219,22 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
             const double r = yi - mu;
             sse = __builtin_fma(r, r, sse);
             const double rg = r * gtr;
+            // batches of 8 columns: all of acc[] stays in registers, only 8 design values in flight
 #pragma unroll
-            for (int j = 0; j < KP; ++j) {
-                const double xv = HOLD ? x[HOLD ? j : 0] : xp[j * W];
-                if (MODE == 0) acc[j] = __builtin_fma(xv, r, acc[j]);
-                else if (MODE == 1) acc[j] = __builtin_fma(xv, rg, acc[j]);
-                else acc[j] = __builtin_fma(xv, (j < Ka) ? r : rg, acc[j]);
+            for (int j0 = 0; j0 < KP; j0 += 8) {
+                double xv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) if (j0 + u < KP) xv[u] = HOLD ? x[HOLD ? j0 + u : 0] : xp[(j0 + u) * W];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (j0 + u < KP) {
+                        const int j = j0 + u;
+                        if (MODE == 0) acc[j] = __builtin_fma(xv[u], r, acc[j]);
+                        else if (MODE == 1) acc[j] = __builtin_fma(xv[u], rg, acc[j]);
+                        else acc[j] = __builtin_fma(xv[u], (j < Ka) ? r : rg, acc[j]);
+                    }
+                }
+                if (!HOLD) __builtin_amdgcn_sched_barrier(0);
             }
             double v = r * opm;
             if (GROWTH == 1) v = v * qv;
@@ -177,7 +242,12 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
             rt2 = rt2 + v;
             for (int j = cprev; j < c; ++j) { lds.tp1[j] = rt1; lds.tp2[j] = rt2; }
         }
+        if (TILED) {
+            if (q > 0) tile_commit(q - 1);
+            __syncthreads();
+        }
     }
+    if (!active) { f_out = 0.0; return false; }
     // reductions over the time axis
     const double sse_t = bfly_sum(sse);
     const double s1 = suffix_scan(rt1), s2v = suffix_scan(rt2);
@@ -342,7 +412,7 @@ __device__ __forceinline__ void make_view(const FitArgs &a, int64_t n, SeriesVie
     const GridTab &gt = a.gtab[g];
     sv.T = gt.info.T; sv.NT = gt.info.NT; sv.S = gt.info.S;
     sv.P = 3 + sv.S + a.sp->K;
-    int cnt = sv.T - (int)threadIdx.x * sv.NT;
+    int cnt = sv.T - lane_id() * sv.NT;
     cnt = cnt < 0 ? 0 : (cnt > sv.NT ? sv.NT : cnt);
     sv.cnt = cnt;
     sv.tw = a.tw + (size_t)g * a.NTmax * W;
@@ -357,17 +427,21 @@ __device__ __forceinline__ void make_view(const FitArgs &a, int64_t n, SeriesVie
 }
 
 // theta (internal order, registers) -> caller layout [k,m,log sigma,delta[n_cp],beta[K]]
+// (every slot of the row is written exactly once: fitted entries, zeros elsewhere)
 template <int PPL>
 __device__ __forceinline__ void store_theta(const FitArgs &a, const SeriesView &sv, int64_t n,
                                             const double (&x)[PPL], double *dst)
 {
     const int n_cp = a.sp->n_cp;
     double *out = dst + (size_t)n * a.theta_stride;
-    for (int i = threadIdx.x; i < a.theta_stride; i += W) out[i] = 0.0;
-    TSF_WAVE_SYNC();
+    for (int i = lane_id(); i < a.theta_stride; i += W) {
+        bool fitted = i < 3 + sv.S;
+        if (i >= 3 + n_cp && i < 3 + n_cp + a.sp->K) fitted = true;
+        if (!fitted) out[i] = 0.0;
+    }
 #pragma unroll
     for (int s = 0; s < PPL; ++s) {
-        const int p = threadIdx.x + s * W;
+        const int p = lane_id() + s * W;
         if (p < 3 + sv.S) out[p] = x[s];
         else if (p < sv.P) out[3 + n_cp + a.sp->perm[p - 3 - sv.S]] = x[s];
     }
@@ -381,7 +455,7 @@ __device__ __forceinline__ void load_theta(const FitArgs &a, const SeriesView &s
     const double *in = src + (size_t)n * a.theta_stride;
 #pragma unroll
     for (int s = 0; s < PPL; ++s) {
-        const int p = threadIdx.x + s * W;
+        const int p = lane_id() + s * W;
         double v = 0.0;
         if (p < 3 + sv.S) v = in[p];
         else if (p < sv.P) v = in[3 + n_cp + a.sp->perm[p - 3 - sv.S]];
@@ -508,6 +582,8 @@ __global__ __launch_bounds__(64) void fit_kernel(FitArgs a)
         }
         if (!ls_fail) {
             if (stage == ST_LS_EVAL) {
+                // guard against a line search that never settles (oracle cn_lbfgs eval_limit)
+                if (sv.n_eval >= 64 * sp->max_iter + 1024) { ret = TSF_ST_EVAL_LIMIT; break; }
 #pragma unroll
                 for (int s = 0; s < PPL; ++s) xk1[s] = __builtin_fma(alpha, pk[s], xk[s]);
             }

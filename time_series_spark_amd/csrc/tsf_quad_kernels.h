@@ -54,7 +54,6 @@ struct QuadLds {
     double ref[PPL * W], cvec[PPL * W];                // reference point and c = Z^T r_ref
 };
 
-__device__ __forceinline__ int lane_id() { return (int)threadIdx.x & (W - 1); }
 
 // G-column slice of the register transpose network of column_sums (tsf_fit_kernels.h)
 template <int G>
@@ -389,26 +388,6 @@ __device__ __forceinline__ void make_view_q(const FitArgs &a, int64_t n, SeriesV
     sv.n_eval = 0;
 }
 
-template <int PPL>
-__device__ __forceinline__ void store_theta_q(const FitArgs &a, const SeriesView &sv, int64_t n,
-                                              const double (&x)[PPL], double *dst)
-{
-    const int n_cp = a.sp->n_cp;
-    double *out = dst + (size_t)n * a.theta_stride;
-    // every slot of the row is written exactly once: fitted entries, zeros elsewhere
-    for (int i = lane_id(); i < a.theta_stride; i += W) {
-        bool fitted = i < 3 + sv.S;
-        if (i >= 3 + n_cp && i < 3 + n_cp + a.sp->K) fitted = true;
-        if (!fitted) out[i] = 0.0;
-    }
-#pragma unroll
-    for (int s = 0; s < PPL; ++s) {
-        const int p = lane_id() + s * W;
-        if (p < 3 + sv.S) out[p] = x[s];
-        else if (p < sv.P) out[3 + n_cp + a.sp->perm[p - 3 - sv.S]] = x[s];
-    }
-}
-
 // ---------------------------------------------------------------------------------------
 // Gram matrix: block q computes column q of M = Z^T Z as "Z^T r" with r := column q of Z
 // ---------------------------------------------------------------------------------------
@@ -478,7 +457,7 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
         gk[s] = 0.0; pk[s] = 0.0; xk1[s] = xk[s]; gk1[s] = 0.0; pk1[s] = 0.0;
     }
     if (qa.debug == 1) {
-        store_theta_q<PPL>(a, sv, n, xk, a.theta);
+        store_theta<PPL>(a, sv, n, xk, a.theta);
         if (lane == 0) { a.status[n] = 77; a.n_iter[n] = 0; a.n_eval[n] = 0; a.fval[n] = 0.0; }
         return;
     }
@@ -487,7 +466,7 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
 #pragma unroll
             for (int s = 0; s < PPL; ++s) if (lane + s * W == 2) xk[s] = -20.72326583694641;
         }
-        store_theta_q<PPL>(a, sv, n, xk, a.theta);
+        store_theta<PPL>(a, sv, n, xk, a.theta);
         if (lane == 0) { a.status[n] = st.status0; a.n_iter[n] = 0; a.n_eval[n] = 0; a.fval[n] = 0.0; }
         return;
     }
@@ -513,10 +492,8 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
     enum { ST_INIT = 0, ST_START_ITER, ST_START_LS, ST_LS_PRE, ST_LS_EVAL, ST_RECENTER, ST_POST };
     int stage = ST_INIT;
     QT_DECL;
-    long turns = 0;
-    const long max_turns = 64L * sp->max_iter + 1024;     // guard: never spin forever
+    const int eval_limit = 64 * sp->max_iter + 1024;      // guard, see cn_lbfgs (oracle)
     for (;;) {
-        if (++turns > max_turns) { ret = -99 - stage; break; }
         QT_LAP(0);
         if (stage == ST_POST) {
             // ---- accepted step: k is the most recent iterate ----
@@ -674,6 +651,7 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
                 }
                 continue;
             }
+            if (sv.n_eval >= eval_limit) { ret = TSF_ST_EVAL_LIMIT; break; }
 #pragma unroll
             for (int s = 0; s < PPL; ++s) { xk1[s] = __builtin_fma(alpha, pk[s], xk[s]); xe[s] = xk1[s]; }
             sv.n_eval++;
@@ -739,7 +717,7 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
         resetB = 2;
         stage = ST_START_LS;
     }
-    store_theta_q<PPL>(a, sv, n, xk, a.theta);
+    store_theta<PPL>(a, sv, n, xk, a.theta);
     if (lane == 0) { a.status[n] = ret; a.n_iter[n] = itNum; a.n_eval[n] = sv.n_eval; a.fval[n] = fk; }
     QT_FLUSH();
 }

@@ -99,7 +99,7 @@ def fit_packed(panel, floor, cap, kw):
         for i, m in enumerate(members):
             st = int(res.status[i])
             status[m] = st
-            if st in (_lib.ST_LSFAIL, _lib.ST_INIT_NONFINITE, _lib.ST_TOO_FEW, _lib.ST_CAP):
+            if st < 0:       # optimiser failure (pystan RuntimeError) or invalid input
                 continue
             blobs[m] = pk.dump_model(sd, res.theta[i], res.y_scale[i], res.grid_of(i), last_ds[m],
                                      st, res.n_iter[i])

@@ -1,0 +1,111 @@
+"""Times the hot path on the other BASELINE.json configurations (bench.py is the headline
+cfg2 line the driver reads; this tool gives the table in DESIGN.md section 7).  Same rules:
+inputs resident in HBM, step = fit + 90-step predict, fit-path kernel time from the library's
+HIP events.  One JSON line per configuration.
+
+  python tools/bench_configs.py cfg1 cfg3 cfg4 cfg5 cfg2_resid
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from time_series_spark_amd import forecaster as fc, synth  # noqa: E402
+from time_series_spark_amd.device import DeviceForecaster  # noqa: E402
+
+YEARLY = {'name': 'yearly', 'period': 365.25, 'fourier_order': 10}
+WEEKLY = {'name': 'weekly', 'period': 7, 'fourier_order': 3}
+H = 90
+
+
+def build(name):
+    """-> (description, spec, ds, y, floor, cap, extra, extra_future, bytes_per_series)"""
+    if name in ('cfg2', 'cfg2_resid'):
+        N, T = 10000, 730
+        lb = {'eval_form': 1} if name.endswith('resid') else {}
+        spec = fc.ModelSpec(growth='linear', seasonalities=[YEARLY, WEEKLY], **lb)
+        ds, y = synth.make_panel(N, T, 'linear', seed=751)
+        return ('10000 x 730 linear additive yearly+weekly' + (' (residual form forced)' if lb else ''),
+                spec, ds, y, None, None, None, None, T * 8 + 54 * 8 + H * 8)
+    if name == 'cfg1':
+        N, T = 100, 365
+        ds, y = synth.make_panel(N, T, 'logistic', seed=751)
+        seas = fc.ModelSpec.auto_seasonalities(ds, seasonality_mode='multiplicative')
+        spec = fc.ModelSpec(growth='logistic', seasonality_mode='multiplicative', seasonalities=seas)
+        return ('100 x 365, reference settings (logistic, floor 0, cap 1.1 max y, multiplicative, auto seasonalities)',
+                spec, ds, y, np.zeros(N), y.max(axis=1) * 1.1, None, None, T * 8 + (3 + 25 + spec.K) * 8 + H * 8)
+    if name == 'cfg3':
+        N, T = 12500, 1095       # one GPU's share of 100 000 series over 8 GPUs
+        ds, y = synth.make_panel(N, T, 'linear', seed=751)
+        seas = fc.ModelSpec.auto_seasonalities(ds)
+        spec = fc.ModelSpec(growth='linear', seasonalities=seas)
+        return ('12500 x 1095 (1/8 of cfg3) linear additive, yearly on by auto', spec, ds, y, None, None,
+                None, None, T * 8 + (3 + 25 + spec.K) * 8 + H * 8)
+    if name == 'cfg4':
+        N, T = 50000, 730
+        ds = synth.daily_grid(T)
+        fut = ds[-1] + synth.DAY_NS * np.arange(1, H + 1)
+        allm, names = synth.holiday_matrix(np.concatenate([ds, fut]), 10)
+        extra, exf = np.ascontiguousarray(allm[:, :T]), np.ascontiguousarray(allm[:, T:])
+        ds, y = synth.make_panel(N, T, 'logistic', seed=751, holidays=extra)
+        spec = fc.ModelSpec(growth='logistic', seasonality_mode='multiplicative',
+                            seasonalities=[YEARLY, WEEKLY], extra=[{'name': n} for n in names])
+        return ('50000 x 730 logistic + floor, multiplicative, 25 changepoints, 10 holidays x window [-1,+1]',
+                spec, ds, y, np.zeros(N), y.max(axis=1) * 1.1, extra, exf,
+                T * 8 + (3 + 25 + spec.K) * 8 + H * 8 + 8)
+    if name == 'cfg5':
+        N, T = 1000000, 90
+        ds, y = synth.make_panel(N, T, 'linear', seed=751, dtype=np.float32)
+        seas = fc.ModelSpec.auto_seasonalities(ds)
+        spec = fc.ModelSpec(growth='linear', seasonalities=seas)
+        return ('1000000 x 90 fp32 y, linear additive, weekly only (L-BFGS; fbprophet would use Newton for T<100)',
+                spec, ds, y, None, None, None, None, T * 4 + (3 + 25 + spec.K) * 4 + H * 4)
+    raise SystemExit('unknown config ' + name)
+
+
+def run(name, steps=2, warmup=1):
+    import torch
+    desc, spec, ds_np, y_np, floor, cap, extra, exf, bps = build(name)
+    dev = torch.device('cuda', 0)
+    N, T = y_np.shape
+    fut_np = ds_np[-1] + synth.DAY_NS * np.arange(1, H + 1)
+    to = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    ds, y, fut, fl, cp, ex, exfd = to(ds_np), to(y_np), to(fut_np), to(floor), to(cap), to(extra), to(exf)
+    f = DeviceForecaster(spec, 0)
+    out = f.alloc_fit_output(N)
+    yhat = torch.zeros((N, H), dtype=torch.float64, device=dev)
+
+    def step():
+        f.fit_aligned(ds, y, out, floor=fl, cap=cp, extra=ex)
+        f.predict(out, fut, yhat, None, floor=fl, cap=cp, extra_future=exfd)
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    f.set_profiling(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    kms = f.profile_read()
+    n_eval = out.n_eval.cpu().numpy().astype(np.int64)
+    status = out.status.cpu().numpy()
+    fit_ms = float(np.mean(kms))
+    res = {'config': name, 'workload': desc, 'series': N, 'points': T, 'K': spec.K,
+           'P': 3 + spec.n_changepoints + spec.K, 'series_per_s': N / dt, 'ms_per_step': 1e3 * dt,
+           'fit_kernel_ms': fit_ms, 'mean_evals': float(n_eval.mean()), 'max_evals': int(n_eval.max()),
+           'evals_per_s': float(n_eval.sum()) / (fit_ms * 1e-3),
+           'algorithmic_bytes_per_series': bps, 'hbm_GBps_algorithmic': bps * N / (fit_ms * 1e-3) / 1e9,
+           'status_counts': {str(int(k)): int(v) for k, v in zip(*np.unique(status, return_counts=True))},
+           'finite_forecasts': bool(torch.isfinite(yhat[status > 0]).all().item())}
+    print(json.dumps(res), flush=True)
+
+
+if __name__ == '__main__':
+    for nm in (sys.argv[1:] or ['cfg1', 'cfg3', 'cfg4', 'cfg5', 'cfg2_resid']):
+        run(nm)
