@@ -109,7 +109,10 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
     const int Ka = (MODE == 0) ? KP : (MODE == 1 ? 0 : sp->Ka);
     // design row + coefficients held in registers / SGPRs; from LDS tiles re-reading the row is
     // cheap, and the tiled kernel needs the registers for its longer-lived state
+    // design row + coefficients held in registers / SGPRs; the tiled kernel re-reads the row and
+    // the coefficients from LDS instead (it needs the registers for its longer-lived state)
     constexpr bool HOLD = TILED ? (KP <= 16) : (KP <= 32);
+    constexpr bool BLDS = false;
     if (active) sv.n_eval++;
     const double k = theta_at<PPL>(th, 0), m = theta_at<PPL>(th, 1), ls = theta_at<PPL>(th, 2);
     const double sigma = dm_exp(ls);
@@ -136,8 +139,8 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
             if (lane == 0) { lds.ks[j + 1] = ksv; lds.mc[j + 1] = mcv; }
         }
     }
-    double bs[HOLD ? KP : 1];
-    if (HOLD) {
+    double bs[(HOLD && !BLDS) ? KP : 1];
+    if (HOLD && !BLDS) {
 #pragma unroll
         for (int j = 0; j < (HOLD ? KP : 1); ++j) bs[j] = (3 + S + j < PPL * W) ? theta_at<PPL>(th, 3 + S + j) : 0.0;
     }
@@ -173,15 +176,26 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
         if (tid < W) tile_t(tc, q & 1)[tid] = tt;
         else if (tid < 2 * W) tile_c(tc, q & 1)[tid - W] = (uint16_t)tcv;
     };
-    if (TILED) { tile_issue(NT - 1); tile_commit(NT - 1); __syncthreads(); }
+    // (TILED) y of the NEXT step is requested one step ahead: it comes from HBM / Infinity Cache
+    // and a step between two workgroup barriers is too short to hide that latency
+    double y_next = 0.0;
+    if (TILED) {
+        tile_issue(NT - 1); tile_commit(NT - 1);
+        if (active && NT - 1 < sv.cnt) y_next = sv.yw[(NT - 1) * W + lane];
+        __syncthreads();
+    }
     for (int q = NT - 1; q >= 0; --q) {
-        if (TILED && q > 0) tile_issue(q - 1);
+        const double y_cur = y_next;
+        if (TILED && q > 0) {
+            tile_issue(q - 1);
+            if (active && q - 1 < sv.cnt) y_next = sv.yw[(q - 1) * W + lane];
+        }
         if (active && q < sv.cnt) {
             const int idx = q * W + lane;
             const unsigned cwv = TILED ? (unsigned)tile_c(tc, q & 1)[lane] : (unsigned)sv.cw[idx];
             const int c = (int)(cwv & 0xffu), cprev = (int)(cwv >> 8);
             const double ti = TILED ? tile_t(tc, q & 1)[lane] : sv.tw[idx];
-            const double yi = sv.yw[idx];
+            const double yi = TILED ? y_cur : sv.yw[idx];
             const double *xp = TILED ? tile_x<KP>(tc, q & 1) + lane : sv.Xw + (size_t)q * KP * W + lane;
             double x[HOLD ? KP : 1];
             double xa = 0.0, xm = 0.0;
@@ -190,9 +204,10 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
                 for (int j = 0; j < (HOLD ? KP : 1); ++j) x[j] = xp[j * W];
 #pragma unroll
                 for (int j = 0; j < (HOLD ? KP : 1); ++j) {
-                    if (MODE == 0) xa = __builtin_fma(x[j], bs[j], xa);
-                    else if (MODE == 1) xm = __builtin_fma(x[j], bs[j], xm);
-                    else { if (j < Ka) xa = __builtin_fma(x[j], bs[j], xa); else xm = __builtin_fma(x[j], bs[j], xm); }
+                    const double bj = BLDS ? ((3 + S + j < PPL * W) ? theta_at<PPL>(th, 3 + S + j) : 0.0) : bs[BLDS ? 0 : j];
+                    if (MODE == 0) xa = __builtin_fma(x[j], bj, xa);
+                    else if (MODE == 1) xm = __builtin_fma(x[j], bj, xm);
+                    else { if (j < Ka) xa = __builtin_fma(x[j], bj, xa); else xm = __builtin_fma(x[j], bj, xm); }
                 }
             } else {
 #pragma unroll 4
