@@ -216,9 +216,7 @@ static int quad_plan(tsf_ctx *ctx, const DevSpec &hs, int64_t N, QuadPlan *qp)
     // beyond P are bit-neutral), P rounded up to 4 for the two-slot kernel
     qp->P4 = (qp->PPL == 2) ? ((P + 3) & ~3) : (P <= 40 ? 40 : (P <= 56 ? 56 : 64));
     qp->NW = quad_waves_per_block(qp->PPL);
-    const char *e = getenv("TSF_QUAD_BLOCKS_PER_CU");
-    const int per_cu = e ? atoi(e) : 1;         // LDS admits one workgroup per CU
-    int64_t blocks = (int64_t)prop.multiProcessorCount * (per_cu > 0 ? per_cu : 1);
+    int64_t blocks = prop.multiProcessorCount;      // persistent: LDS admits one workgroup per CU
     const int64_t need = (N + qp->NW - 1) / qp->NW;
     if (blocks > need) blocks = need;
     if (blocks < 1) blocks = 1;
@@ -316,7 +314,7 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
         qa.f = a; qa.Mg = (const double *)(ws + l.Mg); qa.rbuf = (double *)(ws + l.rbuf);
         qa.counter = (int *)(ws + l.counter); qa.P4 = qp.P4;
         qa.recenter_every = spec->recenter_every; qa.recenter_ratio = spec->recenter_ratio;
-        { const char *d = getenv("TSF_QUAD_STAGE"); qa.debug = d ? atoi(d) : 0; qa.dbg = nullptr; }
+        qa.dbg = nullptr;
         HIP_TRY(ctx, hipMemsetAsync(qa.counter, 0, sizeof(int), st));
         lrc = launch_quad(hs.KP, qp, qa, (double *)(ws + l.Mg), st);
     } else if (aligned && theta_in == nullptr && getenv("TSF_TILE")) {

@@ -5,7 +5,6 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
-#include <unistd.h>
 
 #ifndef TSF_QUAD_NW
 #define TSF_QUAD_NW 8
@@ -22,15 +21,9 @@ template <int KP, int PPL, bool MLDS, int PQ, bool RLDS>
 static int launch_quad_rl(const QuadPlan &qp, const QuadArgs &qa, double *Mg, hipStream_t st)
 {
     constexpr int NW = (PPL == 2) ? TSF_QUAD_NW2 : TSF_QUAD_NW;
-    const char *dbg = getenv("TSF_QUAD_DEBUG");
     hipLaunchKernelGGL((gram_build_kernel<KP, PPL>), dim3((unsigned)qp.P4), dim3(64), 0, st, qa, Mg);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    if (dbg) {
-        e = hipStreamSynchronize(st);
-        fprintf(stderr, "[quad] gram_build done: %s (P4 %d blocks %d slots %d)\n", hipGetErrorString(e), qp.P4, qp.blocks, qp.slots);
-        if (dbg[0] == '1') return (int)e;
-    }
     const size_t lds = (MLDS ? sizeof(double) * (size_t)qp.P4 * PPL * W : 0) + sizeof(QuadLds<KP, PPL>) * NW +
                        (RLDS ? sizeof(double) * (size_t)NW * qa.f.NTmax * W : 0);
     static bool attr_done = false;
@@ -39,53 +32,26 @@ static int launch_quad_rl(const QuadPlan &qp, const QuadArgs &qa, double *Mg, hi
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    QuadArgs qb = qa;
-    long long *hdbg = nullptr;
-    if (dbg && dbg[0] == '3') {
-        hipHostMalloc((void **)&hdbg, sizeof(long long) * 8 * qp.blocks * NW, hipHostMallocCoherent);
-        memset(hdbg, 0, sizeof(long long) * 8 * qp.blocks * NW);
-        qb.dbg = hdbg;
-    }
-    hipLaunchKernelGGL((fit_quad_kernel<KP, PPL, NW, MLDS, PQ, RLDS>), dim3((unsigned)qp.blocks), dim3(NW * 64), lds, st, qb);
-    if (hdbg) {
-        e = hipGetLastError();
-        fprintf(stderr, "[quad] fit launched: %s lds %zu\n", hipGetErrorString(e), lds);
-        for (int it = 0; it < 50; ++it) {
-            if (hipStreamQuery(st) == hipSuccess) { fprintf(stderr, "[quad] finished after %d polls\n", it); break; }
-            usleep(100000);
-        }
-        for (int w = 0; w < qp.blocks * NW && w < 32; ++w)
-            fprintf(stderr, "[quad] wave %d: m0 %lld m1 %lld m2 %lld m3 %lld m7 %lld\n", w, hdbg[w * 8], hdbg[w * 8 + 1], hdbg[w * 8 + 2], hdbg[w * 8 + 3], hdbg[w * 8 + 7]);
-        fflush(stderr);
-        if (hipStreamQuery(st) != hipSuccess) _exit(3);
-        return 0;
-    }
-    if (dbg && dbg[0] == '4') {     // phase timing (build with -DTSF_QUAD_TIMING)
-        long long *dd = nullptr;
+#ifdef TSF_QUAD_TIMING      // dev build: per-phase cycle counts (s_memtime) summed per series
+    {
+        QuadArgs qb = qa;
         const size_t nb = sizeof(long long) * 8 * (size_t)qa.f.N;
-        hipMalloc((void **)&dd, nb);
-        hipMemsetAsync(dd, 0, nb, st);
-        qb.dbg = dd;
-        hipMemsetAsync(qa.counter, 0, sizeof(int), st);
+        hipMalloc((void **)&qb.dbg, nb);
+        hipMemsetAsync(qb.dbg, 0, nb, st);
         hipLaunchKernelGGL((fit_quad_kernel<KP, PPL, NW, MLDS, PQ, RLDS>), dim3((unsigned)qp.blocks), dim3(NW * 64), lds, st, qb);
         hipStreamSynchronize(st);
         std::vector<long long> h(8 * (size_t)qa.f.N);
-        hipMemcpy(h.data(), dd, nb, hipMemcpyDeviceToHost);
+        hipMemcpy(h.data(), qb.dbg, nb, hipMemcpyDeviceToHost);
         double sum[8] = {0};
         long long mx = 0;
         for (int64_t i = 0; i < qa.f.N; ++i) { for (int k = 0; k < 8; ++k) sum[k] += (double)h[i * 8 + k]; if (h[i * 8 + 7] > mx) mx = h[i * 8 + 7]; }
         fprintf(stderr, "[quad-timing] N %lld mean cycles/series: misc %.0f post %.0f ls %.0f resid %.0f gram %.0f | total %.0f max %lld\n",
                 (long long)qa.f.N, sum[0] / qa.f.N, sum[1] / qa.f.N, sum[2] / qa.f.N, sum[3] / qa.f.N, sum[4] / qa.f.N, sum[7] / qa.f.N, mx);
-        hipFree(dd);
-        return 0;
+        hipFree(qb.dbg);
+        return (int)hipGetLastError();
     }
-    if (dbg) {
-        e = hipGetLastError();
-        fprintf(stderr, "[quad] fit launched: %s lds %zu\n", hipGetErrorString(e), lds);
-        e = hipStreamSynchronize(st);
-        fprintf(stderr, "[quad] fit done: %s\n", hipGetErrorString(e));
-        return (int)e;
-    }
+#endif
+    hipLaunchKernelGGL((fit_quad_kernel<KP, PPL, NW, MLDS, PQ, RLDS>), dim3((unsigned)qp.blocks), dim3(NW * 64), lds, st, qa);
     return (int)hipGetLastError();
 }
 

@@ -38,8 +38,7 @@ struct QuadArgs {
     int P4;                             // P rounded up to a multiple of 4
     int recenter_every;
     double recenter_ratio;
-    int debug;                          // dev only: 1 = no fit, 2 = stop after the initial evaluation
-    volatile long long *dbg;            // dev only: host-coherent progress markers (or NULL)
+    long long *dbg;                     // -DTSF_QUAD_TIMING builds only: [N][8] cycles per phase
 };
 
 template <int KP, int PPL>
@@ -456,11 +455,6 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
         xk[s] = (p == 0) ? st.k0 : (p == 1 ? st.m0 : 0.0);
         gk[s] = 0.0; pk[s] = 0.0; xk1[s] = xk[s]; gk1[s] = 0.0; pk1[s] = 0.0;
     }
-    if (qa.debug == 1) {
-        store_theta<PPL>(a, sv, n, xk, a.theta);
-        if (lane == 0) { a.status[n] = 77; a.n_iter[n] = 0; a.n_eval[n] = 0; a.fval[n] = 0.0; }
-        return;
-    }
     if (st.status0 != 0) {
         if (st.status0 == TSF_ST_CONSTANT) {
 #pragma unroll
@@ -642,7 +636,6 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
                 }
                 if (stage == ST_INIT) {
                     if (bad) { ret = TSF_ST_INIT_NONFINITE; fk = fe; break; }
-                    if (qa.debug == 2) { ret = 78; break; }
 #pragma unroll
                     for (int s = 0; s < PPL; ++s) { pk[s] = -gk[s]; gk1[s] = 0.0; xk1[s] = 0.0; }
                     stage = ST_START_ITER;
@@ -736,12 +729,6 @@ __global__ __launch_bounds__(NW * 64, QUAD_WAVES_PER_SIMD) void fit_quad_kernel(
         for (int i = threadIdx.x; i < P4 * PPL * W; i += NW * 64) Ml[i] = qa.Mg[i];
         __syncthreads();
     }
-#ifdef TSF_QUAD_MARKERS     // dev only: progress markers in host-coherent memory
-#define QDBG(k, v) do { if (qa.dbg && lane == 0) { qa.dbg[((size_t)blockIdx.x * NW + wid) * 8 + (k)] = (long long)(v); __threadfence_system(); } } while (0)
-#else
-#define QDBG(k, v) do { } while (0)
-#endif
-    QDBG(0, 1);
     const double *Mp = MLDS ? Ml : qa.Mg;
     // residual staging r[q][lane] of the running residual pass: in LDS when the launch found room
     // for NW x NTmax x 64 doubles, else in the global scratch (long series)
@@ -758,13 +745,9 @@ __global__ __launch_bounds__(NW * 64, QUAD_WAVES_PER_SIMD) void fit_quad_kernel(
         int n32 = atomicAdd(qa.counter, lane == 0 ? 1 : 0);
         n32 = __builtin_amdgcn_readfirstlane(n32);
         const int64_t n = n32;
-        QDBG(1, 1000 + n);
         if (n >= a.N) break;
         fit_one_quad<KP, PPL, PQ>(qa, wl, rb, Mp, n);
-        QDBG(2, 2000 + n);
     }
-    QDBG(3, 3);
-#undef QDBG
 }
 
 
