@@ -378,26 +378,44 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
 // Stan L-BFGS (BFGSMinimizer<LBFGSUpdate>::step, WolfeLineSearch, WolfLSZoom, CubicInterp)
 // ---------------------------------------------------------------------------------------
 
+// value a/b/c/d in lane 0/1/2/3 (other lanes: d)
+__device__ __forceinline__ double lanes4(double a, double b, double c, double d)
+{
+    const int l = (int)threadIdx.x & (W - 1);
+    return l == 0 ? a : (l == 1 ? b : (l == 2 ? c : d));
+}
+
+// Stan's CubicInterp (cubic through f(0)=0, f'(0)=df0, f(x1)=f1, f'(x1)=df1; minimiser in
+// [loX, hiX]).  All operands are wave-uniform scalars, and an fp64 division is a ~150-cycle
+// dependent sequence, so the INDEPENDENT divisions / polynomial evaluations are done in
+// different lanes of one vector operation (three quotients of c3/c2, the two roots, the four
+// candidate points) and read back with v_readlane: 5 division latencies instead of 13.  Every
+// element goes through exactly the operations of the scalar expression (oracle cubic_interp6).
 __device__ __forceinline__ double cubic_interp6(double df0, double x1, double f1, double df1,
                                                 double loX, double hiX)
 {
-    const double c3 = (-12.0 * f1 + 6.0 * x1 * (df0 + df1)) / (x1 * x1 * x1);
-    const double c2 = -(4.0 * df0 + 2.0 * df1) / x1 + 6.0 * f1 / (x1 * x1);
+    const double x1sq = x1 * x1;
+    const double q = lanes4(-12.0 * f1 + 6.0 * x1 * (df0 + df1), -(4.0 * df0 + 2.0 * df1), 6.0 * f1, 1.0) /
+                     lanes4(x1sq * x1, x1, x1sq, 1.0);
+    const double c3 = readlane_f64(q, 0);
+    const double c2 = readlane_f64(q, 1) + readlane_f64(q, 2);
     const double c1 = df0;
     const double t_s = __builtin_sqrt(c2 * c2 - 2.0 * c1 * c3);
-    const double s1 = -(c2 + t_s) / c3;
-    const double s2 = -(c2 - t_s) / c3;
+    const double sr = lanes4(-(c2 + t_s), -(c2 - t_s), 0.0, 0.0) / c3;
+    const double s1 = readlane_f64(sr, 0), s2 = readlane_f64(sr, 1);
+    const double xs = lanes4(loX, hiX, s1, s2);
+    const double pv = xs * (xs * (xs * c3 / 3.0 + c2) / 2.0 + c1);
     double tmpF, minF, minX;
-    minF = loX * (loX * (loX * c3 / 3.0 + c2) / 2.0 + c1);
+    minF = readlane_f64(pv, 0);
     minX = loX;
-    tmpF = hiX * (hiX * (hiX * c3 / 3.0 + c2) / 2.0 + c1);
+    tmpF = readlane_f64(pv, 1);
     if (tmpF < minF) { minF = tmpF; minX = hiX; }
     if (loX < s1 && s1 < hiX) {
-        tmpF = s1 * (s1 * (s1 * c3 / 3.0 + c2) / 2.0 + c1);
+        tmpF = readlane_f64(pv, 2);
         if (tmpF < minF) { minF = tmpF; minX = s1; }
     }
     if (loX < s2 && s2 < hiX) {
-        tmpF = s2 * (s2 * (s2 * c3 / 3.0 + c2) / 2.0 + c1);
+        tmpF = readlane_f64(pv, 3);
         if (tmpF < minF) { minF = tmpF; minX = s2; }
     }
     return minX;

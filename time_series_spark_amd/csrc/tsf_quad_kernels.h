@@ -494,19 +494,22 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
             double sk[PPL], yk[PPL];
 #pragma unroll
             for (int s = 0; s < PPL; ++s) { sk[s] = xk[s] - xk1[s]; yk[s] = gk[s] - gk1[s]; }
-            const double gradNorm = __builtin_sqrt(pdot<PPL>(gk, gk));
-            const double stepNorm = __builtin_sqrt(pdot<PPL>(sk, sk));
+            const double gg = pdot<PPL>(gk, gk), ss = pdot<PPL>(sk, sk);
             const double skyk = pdot<PPL>(yk, sk);
             const double ykyk = pdot<PPL>(yk, yk);
+            // the two square roots and the three quotients are independent: one lane each
+            const double nrm = __builtin_sqrt(lanes4(gg, ss, 0.0, 0.0));
+            const double gradNorm = readlane_f64(nrm, 0), stepNorm = readlane_f64(nrm, 1);
+            const double qv = lanes4(ykyk, skyk, 1.0, 1.0) / lanes4(skyk, ykyk, skyk, 1.0);
             if (resetB) {
-                const double B0fact = ykyk / skyk;
+                const double B0fact = readlane_f64(qv, 0);
                 hist_len = 0;
 #pragma unroll
                 for (int s = 0; s < PPL; ++s) pk1[s] = pk1[s] / B0fact;
                 alpha = alpha * B0fact;
             }
-            gammak = skyk / ykyk;
-            const double rho_new = 1.0 / skyk;
+            gammak = readlane_f64(qv, 1);
+            const double rho_new = readlane_f64(qv, 2);
             if (hist_len < QH) {
 #pragma unroll
                 for (int h = 0; h < QH; ++h) {
