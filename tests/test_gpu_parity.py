@@ -291,5 +291,13 @@ def test_reference_contract_fit_and_forecast_udfs(env, tmp_path):
     # the batched job entry points give the same rows as the per-group UDF calls
     both = pm.ProphetModeler.model(None, mconfig)
     assert len(both) == 2
+    # the two command-line drivers (the reference's *_spark_driver.py without Spark)
+    import yaml
+    from time_series_spark_amd import modeler_driver, scorer_driver
+    (tmp_path / 'm.yaml').write_text(yaml.safe_dump(mconfig))
+    (tmp_path / 's.yaml').write_text(yaml.safe_dump(sconfig))
+    assert modeler_driver.main(['x']) == 1                      # "arg1 must be the config YAML"
+    assert modeler_driver.main(['x', str(tmp_path / 'm.yaml')]) == 0
+    assert scorer_driver.main(['x', str(tmp_path / 's.yaml')]) == 0
     conv = ps.ProphetScorer.score(None, sconfig)
     assert len(conv) == 80 and np.array_equal(np.sort(conv['forecast_quantity'].values), np.sort(fdf['yhat'].values))

@@ -183,3 +183,10 @@ def test_spec_validation_messages():
         fc.ModelSpec(tolerance=1)
     s = fc.ModelSpec(seasonalities=[dict(helpers.YEARLY), dict(helpers.WEEKLY)])
     assert s.K == 26 and s.theta_stride == 54
+
+
+def test_drivers_usage_message(capsys):
+    """/root/reference/src/modeler_spark_driver.py:9-11: wrong argument count -> message, exit 1."""
+    from time_series_spark_amd import modeler_driver, scorer_driver
+    assert modeler_driver.main(['prog']) == 1 and scorer_driver.main(['prog', 'a', 'b']) == 1
+    assert capsys.readouterr().out.count('arg1 must be the config YAML') == 2
