@@ -100,6 +100,21 @@ def test_fit_predict_against_oracle_and_golden(env, case):
     assert np.array_equal(yint, np.maximum(np.trunc(yhat), floor[:, None]).astype(np.int32))
 
 
+@pytest.mark.parametrize('case', ['ref_logistic_multiplicative', 'cfg2_linear_additive@resid',
+                                  'cfg4_holidays', 'linear_multiplicative_365'])
+def test_experimental_tile_kernel_is_bit_identical(env, case, monkeypatch):
+    """The LDS tile-sharing residual kernel (csrc/tsf_tile_kernels.h, off unless TSF_TILE=1) must
+    give exactly what fit_kernel gives: same arithmetic, different data movement."""
+    fc, cl = env
+    spec, ds, y, floor, cap, extra, fut, exf = helpers.make_case(case, N=11)   # not a multiple of the 8 waves
+    r0 = fc.fit_aligned(spec, ds, y, floor=floor, cap=cap, extra=extra)
+    monkeypatch.setenv('TSF_TILE', '1')
+    r1 = fc.fit_aligned(spec, ds, y, floor=floor, cap=cap, extra=extra)
+    assert np.array_equal(r0.theta, r1.theta) and np.array_equal(r0.n_eval, r1.n_eval)
+    assert np.array_equal(r0.status, r1.status) and np.array_equal(r0.fval, r1.fval)
+    assert (r1.status > 0).all()
+
+
 def test_truncated_trajectories_match(env):
     """Same iterate after 1, 3, 10, 40 L-BFGS iterations: checks line search, two-loop
     recursion and the history ring step by step rather than only at the end."""
