@@ -27,6 +27,7 @@ struct tsf_ctx {
     void *ws;
     size_t ws_bytes;
     DevSpec *d_spec;
+    int n_cu;               // compute units of the device (persistent kernels: one workgroup each)
     int profiling;
     hipEvent_t ev0[TSF_PROFILE_RING], ev1[TSF_PROFILE_RING];
     int ev_created;
@@ -66,6 +67,10 @@ extern "C" int tsf_create(int device_id, tsf_ctx **out)
     c->device = device_id; c->ws = nullptr; c->ws_bytes = 0; c->d_spec = nullptr;
     c->profiling = 0; c->ev_created = 0; c->ev_count = 0;
     if (hipMalloc((void **)&c->d_spec, sizeof(DevSpec)) != hipSuccess) { delete c; return -2; }
+    {
+        hipDeviceProp_t prop;
+        c->n_cu = (hipGetDeviceProperties(&prop, device_id) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
     *out = c;
     return 0;
 }
@@ -208,15 +213,13 @@ static int ensure_ws(tsf_ctx *ctx, size_t bytes)
 // grid / LDS plan of the quadratic-form kernel for this device
 static int quad_plan(tsf_ctx *ctx, const DevSpec &hs, int64_t N, QuadPlan *qp)
 {
-    hipDeviceProp_t prop;
-    HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
     const int P = 3 + hs.n_cp + hs.K;
     qp->PPL = (hs.KP == 64) ? 2 : 1;
     // rows of M the kernel walks: compile-time 40 / 56 / 64 for the one-slot kernels (zero rows
     // beyond P are bit-neutral), P rounded up to 4 for the two-slot kernel
     qp->P4 = (qp->PPL == 2) ? ((P + 3) & ~3) : (P <= 40 ? 40 : (P <= 56 ? 56 : 64));
     qp->NW = quad_waves_per_block(qp->PPL);
-    int64_t blocks = prop.multiProcessorCount;      // persistent: LDS admits one workgroup per CU
+    int64_t blocks = ctx->n_cu;                     // persistent: LDS admits one workgroup per CU
     const int64_t need = (N + qp->NW - 1) / qp->NW;
     if (blocks > need) blocks = need;
     if (blocks < 1) blocks = 1;
@@ -324,9 +327,7 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
         // serialises eight latency-bound waves.
         int *cnt = (int *)(ws + l.counter);
         HIP_TRY(ctx, hipMemsetAsync(cnt, 0, sizeof(int), st));
-        hipDeviceProp_t prop;
-        HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
-        lrc = pick_tile_launch(hs.growth, mode)(hs.KP, a, cnt, prop.multiProcessorCount, st);
+        lrc = pick_tile_launch(hs.growth, mode)(hs.KP, a, cnt, ctx->n_cu, st);
     } else {
         lrc = pick_launch(hs.growth, mode)(hs.KP, a, theta_in != nullptr, st);
     }

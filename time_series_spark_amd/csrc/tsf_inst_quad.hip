@@ -26,12 +26,9 @@ static int launch_quad_rl(const QuadPlan &qp, const QuadArgs &qa, double *Mg, hi
     if (e != hipSuccess) return (int)e;
     const size_t lds = (MLDS ? sizeof(double) * (size_t)qp.P4 * PPL * W : 0) + sizeof(QuadLds<KP, PPL>) * NW +
                        (RLDS ? sizeof(double) * (size_t)NW * qa.f.NTmax * W : 0);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute((const void *)fit_quad_kernel<KP, PPL, NW, MLDS, PQ, RLDS>,
+    // per launch: the attribute is per device, and a process may drive several GPUs
+    hipFuncSetAttribute((const void *)fit_quad_kernel<KP, PPL, NW, MLDS, PQ, RLDS>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
 #ifdef TSF_QUAD_TIMING      // dev build: per-phase cycle counts (s_memtime) summed per series
     {
         QuadArgs qb = qa;
