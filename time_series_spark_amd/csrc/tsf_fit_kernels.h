@@ -121,23 +121,26 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
 #pragma unroll
         for (int s = 0; s < PPL; ++s) lds.th[lane + s * W] = th[s];
     }
-    // segment tables ks[c], mc[c] (sequential recurrences, wave-uniform)
+    // segment tables ks[c], mc[c]: sequential recurrences over the changepoints.  Every lane
+    // runs the same S steps and lane c stops updating after its first c terms, so lane c ends
+    // with exactly the sequentially rounded ks[c], mc[c] (no per-step LDS write / table load).
     {
         double ksv = k, mcv = m;
-        if (lane == 0) { lds.ks[0] = ksv; lds.mc[0] = mcv; }
+        const double tcl = (lane < S) ? sv.t_change[lane] : 0.0;
         for (int j = 0; j < S; ++j) {
             const double dj = theta_at<PPL>(th, 3 + j);
-            const double tcj = sv.t_change[j];
+            const double tcj = readlane_f64(tcl, j);
             const double ksn = ksv + dj;
+            double mcn;
             if (GROWTH == 0) {
-                mcv = mcv + ((-tcj) * dj);
+                mcn = mcv + ((-tcj) * dj);
             } else {
                 const double gamma = (tcj - mcv) * (1.0 - ksv / ksn);
-                mcv = mcv + gamma;
+                mcn = mcv + gamma;
             }
-            ksv = ksn;
-            if (lane == 0) { lds.ks[j + 1] = ksv; lds.mc[j + 1] = mcv; }
+            if (j < lane) { ksv = ksn; mcv = mcn; }
         }
+        if (lane <= S) { lds.ks[lane] = ksv; lds.mc[lane] = mcv; }
     }
     double bs[(HOLD && !BLDS) ? KP : 1];
     if (HOLD && !BLDS) {

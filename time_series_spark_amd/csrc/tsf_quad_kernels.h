@@ -246,15 +246,16 @@ __device__ __forceinline__ bool resid_eval_q(const SeriesView &sv, QuadLds<KP, P
     const int S = sv.S;
 #pragma unroll
     for (int s = 0; s < PPL; ++s) wl.th[lane + s * W] = th[s];
-    {
+    {   // ks[c], mc[c]: lane c accumulates the first c terms in sequential order (see eval_fg)
         double ksv = readlane_f64(th[0], 0), mcv = readlane_f64(th[0], 1);
-        if (lane == 0) { wl.ks[0] = ksv; wl.mc[0] = mcv; }
+        const double tcl = (lane < S) ? sv.t_change[lane] : 0.0;
         for (int j = 0; j < S; ++j) {
             const double dj = theta_at<PPL>(th, 3 + j);
-            ksv = ksv + dj;
-            mcv = mcv + ((-sv.t_change[j]) * dj);
-            if (lane == 0) { wl.ks[j + 1] = ksv; wl.mc[j + 1] = mcv; }
+            const double ksn = ksv + dj;
+            const double mcn = mcv + ((-readlane_f64(tcl, j)) * dj);
+            if (j < lane) { ksv = ksn; mcv = mcn; }
         }
+        if (lane <= S) { wl.ks[lane] = ksv; wl.mc[lane] = mcv; }
     }
     wave_sync();
     const double *beta = wl.th + 3 + S;
