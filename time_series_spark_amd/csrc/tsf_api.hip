@@ -305,6 +305,13 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     memset(&a, 0, sizeof(a));
     a.sp = ctx->d_spec; a.N = N; a.aligned = aligned; a.NTmax = NTmax;
     a.theta_stride = tsf_theta_stride(spec);
+    {
+        const double eps = 2.220446049250313e-16;
+        a.opt.init_alpha = hs.init_alpha; a.opt.tol_obj = hs.tol_obj;
+        a.opt.tol_rel_obj_eps = hs.tol_rel_obj * eps; a.opt.tol_grad = hs.tol_grad;
+        a.opt.tol_rel_grad_eps = hs.tol_rel_grad * eps; a.opt.tol_param = hs.tol_param;
+        a.opt.max_iter = hs.max_iter; a.opt.history = hs.history;
+    }
     a.gtab = gtab; a.stab = stab; a.tw = tw; a.yw = yw; a.Xw = Xw; a.cw = cw;
     a.theta = out->theta; a.y_scale = out->y_scale; a.fval = out->fval; a.status = out->status;
     a.n_iter = out->n_iter; a.n_eval = out->n_eval; a.grid_out = out->grid;

@@ -424,8 +424,16 @@ __device__ __forceinline__ double cubic_interp6(double df0, double x1, double f1
     return minX;
 }
 
+// optimiser settings by VALUE in the kernel arguments (scalar, invariant): reading them through
+// the DevSpec pointer cost a chain of dependent memory loads in every termination test
+struct LbfgsOpts {
+    double init_alpha, tol_obj, tol_rel_obj_eps, tol_grad, tol_rel_grad_eps, tol_param;
+    int max_iter, history;
+};
+
 struct FitArgs {
     const DevSpec *sp;
+    LbfgsOpts opt;
     int64_t N;
     int aligned, NTmax, theta_stride;
     const GridTab *gtab;
@@ -555,12 +563,12 @@ __global__ __launch_bounds__(64) void fit_kernel(FitArgs a)
         return;
     }
 
-    const int H = sp->history > MAXH ? MAXH : sp->history;
+    const int H = a.opt.history > MAXH ? MAXH : a.opt.history;
     const double eps = 2.220446049250313e-16;
     const double c1 = 1e-4, c2 = 0.9, minAlpha = 1e-12, min_range = 1e-16;
     const int maxLSIts = 20, maxLSRestarts = 10;
 
-    double fk = 0.0, fk1 = 0.0, alpha = sp->init_alpha, gammak = 1.0;
+    double fk = 0.0, fk1 = 0.0, alpha = a.opt.init_alpha, gammak = 1.0;
     int itNum = 0, ret = 0, resetB = 0, hist_len = 0, hist_head = 0;
     // line-search state
     double dfp = 0, c1dfp = 0, c2dfp = 0, alpha0 = 0, prevF = 0, prevDFp = 0;
@@ -585,7 +593,7 @@ __global__ __launch_bounds__(64) void fit_kernel(FitArgs a)
                                                 pdot<PPL>(gk, pk), minAlpha, 1.0);
                 alpha = __builtin_fmin(1.0, 1.01 * ci);
             } else {
-                alpha = sp->init_alpha;
+                alpha = a.opt.init_alpha;
             }
             dfp = pdot<PPL>(gk, pk);
             c1dfp = c1 * dfp; c2dfp = c2 * dfp;
@@ -619,7 +627,7 @@ __global__ __launch_bounds__(64) void fit_kernel(FitArgs a)
         if (!ls_fail) {
             if (stage == ST_LS_EVAL) {
                 // guard against a line search that never settles (oracle cn_lbfgs eval_limit)
-                if (sv.n_eval >= 64 * sp->max_iter + 1024) { ret = TSF_ST_EVAL_LIMIT; break; }
+                if (sv.n_eval >= 64 * a.opt.max_iter + 1024) { ret = TSF_ST_EVAL_LIMIT; break; }
 #pragma unroll
                 for (int s = 0; s < PPL; ++s) xk1[s] = __builtin_fma(alpha, pk[s], xk[s]);
             }
@@ -743,12 +751,12 @@ __global__ __launch_bounds__(64) void fit_kernel(FitArgs a)
                 const double dF = __builtin_fabs(fk1 - fk);
                 const double fmaxv = __builtin_fmax(__builtin_fabs(fk1),
                                                     __builtin_fmax(__builtin_fabs(fk), 1.0));
-                if (dF < sp->tol_obj) ret = TSF_ST_ABSF;
-                else if (dF < sp->tol_rel_obj * eps * fmaxv) ret = TSF_ST_RELF;
-                else if (gradNorm < sp->tol_grad) ret = TSF_ST_ABSGRAD;
-                else if (-pdot<PPL>(gk, pk) / __builtin_fmax(__builtin_fabs(fk), 1.0) < sp->tol_rel_grad * eps) ret = TSF_ST_RELGRAD;
-                else if (stepNorm < sp->tol_param) ret = TSF_ST_ABSX;
-                else if (itNum >= sp->max_iter) ret = TSF_ST_MAXIT;
+                if (dF < a.opt.tol_obj) ret = TSF_ST_ABSF;
+                else if (dF < a.opt.tol_rel_obj_eps * fmaxv) ret = TSF_ST_RELF;
+                else if (gradNorm < a.opt.tol_grad) ret = TSF_ST_ABSGRAD;
+                else if (-pdot<PPL>(gk, pk) / __builtin_fmax(__builtin_fabs(fk), 1.0) < a.opt.tol_rel_grad_eps) ret = TSF_ST_RELGRAD;
+                else if (stepNorm < a.opt.tol_param) ret = TSF_ST_ABSX;
+                else if (itNum >= a.opt.max_iter) ret = TSF_ST_MAXIT;
                 else ret = 0;
                 if (ret != 0) break;
                 stage = ST_START_ITER;

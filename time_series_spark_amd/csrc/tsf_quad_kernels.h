@@ -478,7 +478,7 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
         for (int s = 0; s < PPL; ++s) { Sh[h][s] = 0.0; Yh[h][s] = 0.0; }
     }
 
-    double fk = 0.0, fk1 = 0.0, alpha = sp->init_alpha, gammak = 1.0;
+    double fk = 0.0, fk1 = 0.0, alpha = a.opt.init_alpha, gammak = 1.0;
     int itNum = 0, ret = 0, resetB = 0, hist_len = 0, since_rc = 0;
     double dfp = 0, c1dfp = 0, c2dfp = 0, alpha0 = 0, prevF = 0, prevDFp = 0;
     double alo = 0, aloF = 0, aloDFp = 0, ahi = 0, ahiF = 0, ahiDFp = 0;
@@ -487,7 +487,7 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
     enum { ST_INIT = 0, ST_START_ITER, ST_START_LS, ST_LS_PRE, ST_LS_EVAL, ST_RECENTER, ST_POST };
     int stage = ST_INIT;
     QT_DECL;
-    const int eval_limit = 64 * sp->max_iter + 1024;      // guard, see cn_lbfgs (oracle)
+    const int eval_limit = 64 * a.opt.max_iter + 1024;      // guard, see cn_lbfgs (oracle)
     for (;;) {
         QT_LAP(0);
         if (stage == ST_POST) {
@@ -558,12 +558,12 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
             const double dF = __builtin_fabs(fk1 - fk);
             const double fmaxv = __builtin_fmax(__builtin_fabs(fk1),
                                                 __builtin_fmax(__builtin_fabs(fk), 1.0));
-            if (dF < sp->tol_obj) ret = TSF_ST_ABSF;
-            else if (dF < sp->tol_rel_obj * eps * fmaxv) ret = TSF_ST_RELF;
-            else if (gradNorm < sp->tol_grad) ret = TSF_ST_ABSGRAD;
-            else if (-pdot<PPL>(gk, pk) / __builtin_fmax(__builtin_fabs(fk), 1.0) < sp->tol_rel_grad * eps) ret = TSF_ST_RELGRAD;
-            else if (stepNorm < sp->tol_param) ret = TSF_ST_ABSX;
-            else if (itNum >= sp->max_iter) ret = TSF_ST_MAXIT;
+            if (dF < a.opt.tol_obj) ret = TSF_ST_ABSF;
+            else if (dF < a.opt.tol_rel_obj_eps * fmaxv) ret = TSF_ST_RELF;
+            else if (gradNorm < a.opt.tol_grad) ret = TSF_ST_ABSGRAD;
+            else if (-pdot<PPL>(gk, pk) / __builtin_fmax(__builtin_fabs(fk), 1.0) < a.opt.tol_rel_grad_eps) ret = TSF_ST_RELGRAD;
+            else if (stepNorm < a.opt.tol_param) ret = TSF_ST_ABSX;
+            else if (itNum >= a.opt.max_iter) ret = TSF_ST_MAXIT;
             else ret = 0;
             QT_LAP(1);
             if (ret != 0) break;
@@ -584,7 +584,7 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
                                                 pdot<PPL>(gk, pk), minAlpha, 1.0);
                 alpha = __builtin_fmin(1.0, 1.01 * ci);
             } else {
-                alpha = sp->init_alpha;
+                alpha = a.opt.init_alpha;
             }
             dfp = pdot<PPL>(gk, pk);
             c1dfp = c1 * dfp; c2dfp = c2 * dfp;

@@ -67,11 +67,11 @@ __global__ __launch_bounds__(NW * 64) void fit_tile_kernel(FitArgs a, int *count
     if (threadIdx.x == 0) *n_active = NW;
     __syncthreads();
 
-    const int H = sp->history > MAXH ? MAXH : sp->history;
+    const int H = a.opt.history > MAXH ? MAXH : a.opt.history;
     const double eps = 2.220446049250313e-16;
     const double c1 = 1e-4, c2 = 0.9, minAlpha = 1e-12, min_range = 1e-16;
     const int maxLSIts = 20, maxLSRestarts = 10;
-    const int eval_limit = 64 * sp->max_iter + 1024;
+    const int eval_limit = 64 * a.opt.max_iter + 1024;
 
     // ---- per-wave state (one series at a time) ----
     SeriesView sv;
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(NW * 64) void fit_tile_kernel(FitArgs a, int *count
                     xk[s] = (p == 0) ? st.k0 : (p == 1 ? st.m0 : 0.0);
                     gk[s] = 0.0; pk[s] = 0.0; xk1[s] = xk[s]; gk1[s] = 0.0; pk1[s] = 0.0;
                 }
-                fk = 0.0; fk1 = 0.0; alpha = sp->init_alpha; gammak = 1.0;
+                fk = 0.0; fk1 = 0.0; alpha = a.opt.init_alpha; gammak = 1.0;
                 itNum = 0; ret = 0; resetB = 0; hist_len = 0; hist_head = 0;
                 if (st.status0 != 0) {
                     if (st.status0 == TSF_ST_CONSTANT) {
@@ -198,12 +198,12 @@ __global__ __launch_bounds__(NW * 64) void fit_tile_kernel(FitArgs a, int *count
                 const double dF = __builtin_fabs(fk1 - fk);
                 const double fmaxv = __builtin_fmax(__builtin_fabs(fk1),
                                                     __builtin_fmax(__builtin_fabs(fk), 1.0));
-                if (dF < sp->tol_obj) ret = TSF_ST_ABSF;
-                else if (dF < sp->tol_rel_obj * eps * fmaxv) ret = TSF_ST_RELF;
-                else if (gradNorm < sp->tol_grad) ret = TSF_ST_ABSGRAD;
-                else if (-pdot<PPL>(gk, pk) / __builtin_fmax(__builtin_fabs(fk), 1.0) < sp->tol_rel_grad * eps) ret = TSF_ST_RELGRAD;
-                else if (stepNorm < sp->tol_param) ret = TSF_ST_ABSX;
-                else if (itNum >= sp->max_iter) ret = TSF_ST_MAXIT;
+                if (dF < a.opt.tol_obj) ret = TSF_ST_ABSF;
+                else if (dF < a.opt.tol_rel_obj_eps * fmaxv) ret = TSF_ST_RELF;
+                else if (gradNorm < a.opt.tol_grad) ret = TSF_ST_ABSGRAD;
+                else if (-pdot<PPL>(gk, pk) / __builtin_fmax(__builtin_fabs(fk), 1.0) < a.opt.tol_rel_grad_eps) ret = TSF_ST_RELGRAD;
+                else if (stepNorm < a.opt.tol_param) ret = TSF_ST_ABSX;
+                else if (itNum >= a.opt.max_iter) ret = TSF_ST_MAXIT;
                 else ret = 0;
                 if (ret != 0) { stage = ST_STORE; continue; }
                 stage = ST_START_ITER;
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(NW * 64) void fit_tile_kernel(FitArgs a, int *count
                                                     pdot<PPL>(gk, pk), minAlpha, 1.0);
                     alpha = __builtin_fmin(1.0, 1.01 * ci);
                 } else {
-                    alpha = sp->init_alpha;
+                    alpha = a.opt.init_alpha;
                 }
                 dfp = pdot<PPL>(gk, pk);
                 c1dfp = c1 * dfp; c2dfp = c2 * dfp;
