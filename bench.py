@@ -54,7 +54,7 @@ def oracle_spec(spec):
                         eval_mode=int(spec.lbfgs.get('eval_form', 0) != 1))
 
 
-def cpu_baseline(spec, ds, y, fut, budget_s=12.0):
+def cpu_baseline(spec, ds, y, fut, budget_s=12.0, yhat_gpu=None):
     """The CPU oracle (oracle/prophet_canon.c: same model, same Stan L-BFGS, plain C) timed on
     this box's host cores on a bounded sample of the same panel: one series per task on a
     thread pool of os.cpu_count() threads (ctypes releases the GIL) -- the shape of the
@@ -78,7 +78,14 @@ def cpu_baseline(spec, ds, y, fut, budget_s=12.0):
     with ThreadPoolExecutor(max_workers=cores) as ex:
         evals = list(ex.map(one, range(sample)))
     dt = time.perf_counter() - t0
+    worst = None
+    if yhat_gpu is not None:        # checker use of the same oracle: GPU forecasts vs oracle
+        worst = 0.0
+        for n in range(len(yhat_gpu)):
+            yo, _ = cl.predict(csp, cl.fit(csp, ds, y[n]), fut)
+            worst = max(worst, float(np.max(np.abs(yhat_gpu[n] - yo) / np.abs(yo))))
     return {'value': sample / dt, 'unit': 'series/s', 'cores': cores, 'kind': 'port',
+            'parity_max_rel_err': worst,
             'sample': '%d of %d series of the same panel (fit + %d-step forecast), '
                       'oracle/prophet_canon.c on %d threads, %.1f s wall'
                       % (sample, y.shape[0], len(fut), cores, dt),
@@ -202,22 +209,12 @@ def main():
                       'status_counts': {str(int(k)): int(v) for k, v in
                                         zip(*np.unique(status, return_counts=True))}},
     }
-    # parity spot check against the CPU oracle (checker only; outside the timed region)
-    try:
-        from oracle import canon_lib as cl
-        csp = oracle_spec(spec)
-        yh = yhat[:4].cpu().numpy()
-        worst = 0.0
-        for n in range(4):
-            r = cl.fit(csp, ds_np, y_np[n])
-            yo, _ = cl.predict(csp, r, fut_np)
-            worst = max(worst, float(np.max(np.abs(yh[n] - yo) / np.abs(yo))))
-        res['forecast_max_rel_err_vs_oracle'] = worst
-    except Exception as e:      # the oracle is test infrastructure; never fatal for the bench
-        res['forecast_max_rel_err_vs_oracle'] = 'unavailable: %s' % e
+    # cpu_baseline leg (rank 0, N=1 only): the CPU oracle timed on the host cores, and -- the
+    # same leg, the oracle as checker -- the GPU forecasts of the sampled series compared with it
     if world == 1 and not args.no_cpu_baseline:
         try:
-            res['cpu_baseline'] = cpu_baseline(spec, ds_np, y_np, fut_np)
+            res['cpu_baseline'] = cpu_baseline(spec, ds_np, y_np, fut_np, yhat_gpu=yhat[:4].cpu().numpy())
+            res['forecast_max_rel_err_vs_oracle'] = res['cpu_baseline'].pop('parity_max_rel_err')
         except Exception as e:
             res['cpu_baseline'] = {'value': None, 'unit': 'series/s', 'cores': os.cpu_count(),
                                    'kind': 'port', 'sample': 'failed: %s' % e}

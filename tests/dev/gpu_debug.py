@@ -2,7 +2,7 @@
 Run on the GPU box: `python tools/gpu_debug.py > gpurun_out/debug.log`."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from time_series_spark_amd import forecaster as fc, synth
 from oracle import canon_lib as cl
 

@@ -1,8 +1,9 @@
-"""Dev tool: quadratic-form fit kernel vs the oracle, increasing max_iter.  Run under a short
+"""Dev tool (uses the oracle as checker, hence under tests/): any fit kernel vs the oracle,
+increasing max_iter; `python tests/dev/kernel_vs_oracle.py <case>`.  Run under a short
 `timeout` on the GPU box."""
 import os, sys, time, faulthandler
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 faulthandler.dump_traceback_later(int(os.environ.get('DBG_DUMP_AFTER', '40')), exit=True)
 from tests import helpers
 from time_series_spark_amd import forecaster as fc
