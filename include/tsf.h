@@ -101,7 +101,8 @@ typedef struct {
      * TSF_EVAL_RESIDUAL sums residuals over the T rows at every evaluation; TSF_EVAL_QUADRATIC
      * uses SSE(theta) = s0 - 2 c.D + D.(Z^T Z) D around a re-centred reference point -- only
      * possible where the mean is linear in (k, m, delta, beta): linear growth, every column
-     * additive, aligned panel, history == 5.  TSF_EVAL_AUTO picks QUADRATIC where possible. */
+     * additive (and history == 5).  TSF_EVAL_AUTO picks QUADRATIC where possible; the choice
+     * depends on the MODEL only, never on the shape or composition of the panel. */
     int32_t eval_form;                      /* TSF_EVAL_AUTO */
     int32_t recenter_every;                 /* 32: re-centre at least every n accepted iterations */
     double recenter_ratio;                  /* 0.25: ... and when |Z D|^2 > ratio * s0 */

@@ -20,21 +20,22 @@ def n_bit_diff(a, b):
     return int(np.sum(bits(a) != bits(b)))
 
 
-def uses_quadratic_form(spec, aligned=True):
+def uses_quadratic_form(spec):
     """Whether the product evaluates the data term in quadratic (Gram) form for this spec
     (include/tsf.h eval_form; tsf_api.hip run_fit): linear growth, every column additive,
-    aligned panel, L-BFGS history 5, eval_form not forced to RESIDUAL (1)."""
+    L-BFGS history 5, eval_form not forced to RESIDUAL (1).  A property of the MODEL only:
+    aligned and ragged panels take the same form."""
     modes = [s.get('mode', spec.seasonality_mode) for s in spec.seasonalities]
     modes += [e.get('mode', spec.seasonality_mode) for e in spec.extra]
-    return (aligned and spec.growth == 'linear' and all(m == 'additive' for m in modes)
+    return (spec.growth == 'linear' and all(m == 'additive' for m in modes)
             and spec.lbfgs.get('history', 5) == 5 and spec.lbfgs.get('eval_form', 0) != 1)
 
 
-def oracle_spec(spec, aligned=True):
+def oracle_spec(spec):
     """time_series_spark_amd.forecaster.ModelSpec -> oracle.canon_lib spec."""
     from oracle import canon_lib as cl
     opt = {k: v for k, v in spec.lbfgs.items() if k != 'eval_form'}
-    opt['eval_mode'] = int(uses_quadratic_form(spec, aligned))
+    opt['eval_mode'] = int(uses_quadratic_form(spec))
     seas = [(s['period'], s['fourier_order'], s.get('mode', spec.seasonality_mode),
              s.get('prior_scale', spec.seasonality_prior_scale)) for s in spec.seasonalities]
     ex = [(e.get('mode', spec.seasonality_mode), e.get('prior_scale', spec.holidays_prior_scale))

@@ -187,13 +187,67 @@ def test_edge_cases(env):
     rr = fc.fit_ragged(sp90, off, dsr, yr)
     assert rr.status[0] == _lib.ST_TOO_FEW and (rr.status[1:] > 0).all()
     assert list(rr.grid['S']) == [0, 15, 25, 25]
-    c90 = helpers.oracle_spec(sp90, aligned=False)      # ragged panels use the residual form
+    c90 = helpers.oracle_spec(sp90)      # linear + additive: quadratic form, ragged or not
     for n in (1, 2, 3):
         o = cl.fit(c90, dsr[off[n]:off[n + 1]], yr[off[n]:off[n + 1]])
         S = o['info'].S
         assert rr.n_iter[n] == o['n_iter']
         assert n_bit_diff(rr.theta[n][:3 + S], o['theta'][:3 + S]) == 0
         assert n_bit_diff(rr.theta[n][28:], o['theta'][3 + S:]) == 0
+
+
+def test_ragged_and_aligned_entry_points_agree_bit_for_bit(env):
+    """The evaluation form depends on the model only: the same series fitted through the aligned
+    entry point, or as members of a ragged panel next to unrelated series of other lengths, gives
+    identical bits (quadratic form: per-series Z^T Z built in-kernel vs one shared Z^T Z; residual
+    form likewise)."""
+    fc, cl = env
+    for case in ('cfg2_linear_additive', 'kp16_linear_400', 'ref_logistic_multiplicative',
+                 'linear_additive_holidays'):
+        spec, ds, y, floor, cap, extra, fut, exf = helpers.make_case(case, N=5)
+        ra = fc.fit_aligned(spec, ds, y, floor=floor, cap=cap, extra=extra)
+        T = len(ds)
+        cut = [T, T - 37, T, T - 101, T]     # ragged: two series are truncated copies
+        off = np.concatenate([[0], np.cumsum(cut)]).astype(np.int64)
+        dsr = np.concatenate([ds[:c] for c in cut])
+        yr = np.concatenate([y[i][:c] for i, c in enumerate(cut)])
+        exr = None if extra is None else np.concatenate([extra[:, :c] for c in cut], axis=1)
+        rr = fc.fit_ragged(spec, off, dsr, yr, floor=floor, cap=cap, extra=exr)
+        for i in (0, 2, 4):                  # the full-length members
+            assert np.array_equal(rr.theta[i], ra.theta[i]) and rr.n_eval[i] == ra.n_eval[i], (case, i)
+            assert rr.status[i] == ra.status[i] and rr.fval[i] == ra.fval[i]
+        csp = helpers.oracle_spec(spec)
+        for i in (1, 3):                     # the truncated ones against the oracle
+            o = cl.fit(csp, ds[:cut[i]], y[i][:cut[i]], floor[i], cap[i],
+                       None if extra is None else extra[:, :cut[i]])
+            S = o['info'].S
+            assert rr.n_iter[i] == o['n_iter'] and rr.n_eval[i] == o['n_eval']
+            assert n_bit_diff(rr.theta[i][:3 + S], o['theta'][:3 + S]) == 0
+
+
+def test_batched_job_is_independent_of_how_series_are_grouped(env):
+    """model_panel groups series that share a timestamp vector (aligned kernel path) and fits the
+    rest through the ragged entry point; each series' model must be byte-identical to the one
+    obtained by handing the reference-style UDF that series alone."""
+    from time_series_spark_amd.jobs import prophet_modeler as pm
+    from time_series_spark_amd import synth
+    ds, y = synth.make_panel(5, 400, 'logistic', seed=5)
+    rows = []
+    for sid in range(5):
+        T = [400, 400, 371, 400, 371][sid]                    # {0,1,3} and {2,4} share grids
+        for t, v in zip(ds[:T], y[sid][:T]):
+            rows.append((sid, 7, np.datetime64(int(t), 'ns'), int(v)))
+    rows += [(9, 7, np.datetime64(int(t) + 3600 * 10 ** 9, 'ns'), int(v)) for t, v in zip(ds[:300], y[0][:300])]
+    df = pd.DataFrame(rows, columns=['series_id', 'dim_id', 'ds', 'y'])
+    config = {'model': {'floor': 0, 'cap_multiplier': 1.1}}
+    both = pm.model_panel(config)(df.copy())
+    assert len(both) == 6
+    udf = pm.model_time_series(config)
+    for (sid, did), grp in df.groupby(['series_id', 'dim_id']):
+        one = udf(grp.copy())
+        row = both[(both['series_id'] == sid) & (both['dim_id'] == did)]
+        assert bytes(one['model'].iloc[0]) == bytes(row['model'].iloc[0]), sid
+        assert one['cap'].iloc[0] == row['cap'].iloc[0]
 
 
 def test_full_size_panel_properties(env):

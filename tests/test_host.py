@@ -35,7 +35,6 @@ def test_library_loads_and_exports_every_declared_symbol(built):
                      recenter_every=8).to_c()
     assert (c.eval_form, c.recenter_every) == (_lib.EVAL_RESIDUAL, 8)
     assert helpers.uses_quadratic_form(fc.ModelSpec(growth='linear', seasonalities=[helpers.WEEKLY]))
-    assert not helpers.uses_quadratic_form(fc.ModelSpec(growth='linear', seasonalities=[helpers.WEEKLY]), aligned=False)
     assert not helpers.uses_quadratic_form(fc.ModelSpec(growth='logistic', seasonalities=[helpers.WEEKLY]))
     assert not helpers.uses_quadratic_form(fc.ModelSpec(growth='linear', seasonality_mode='multiplicative',
                                                         seasonalities=[helpers.WEEKLY]))
@@ -190,3 +189,18 @@ def test_drivers_usage_message(capsys):
     from time_series_spark_amd import modeler_driver, scorer_driver
     assert modeler_driver.main(['prog']) == 1 and scorer_driver.main(['prog', 'a', 'b']) == 1
     assert capsys.readouterr().out.count('arg1 must be the config YAML') == 2
+
+
+def test_group_by_grid_partitions_by_identical_timestamps():
+    ds = pd.date_range('2020-01-01', periods=12, freq='D')
+    rows = []
+    grids = [ds, ds, ds + pd.Timedelta(hours=1), ds, ds[:7], ds[:7], ds[2:]]
+    for sid, g in enumerate(grids):
+        rows += [(sid, 0, t, float(sid + 1)) for t in g]
+    p = pk.pack_long_frame(pd.DataFrame(rows, columns=['series_id', 'dim_id', 'ds', 'y']))
+    groups, rest = pk.group_by_grid(p, np.arange(p.N))
+    assert sorted(g.tolist() for g in groups) == [[0, 1, 3], [4, 5]] and rest.tolist() == [2, 6]
+    groups, rest = pk.group_by_grid(p, np.array([0, 2, 4]))          # nobody shares within the subset
+    assert groups == [] and rest.tolist() == [0, 2, 4]
+    groups, rest = pk.group_by_grid(p, np.arange(p.N), min_group=3)
+    assert [g.tolist() for g in groups] == [[0, 1, 3]] and rest.tolist() == [2, 4, 5, 6]

@@ -178,13 +178,13 @@ static int build_devspec(tsf_ctx *ctx, const tsf_spec *s, DevSpec *d, int *mode_
 // ---- workspace ------------------------------------------------------------------------------
 
 struct WsLayout {
-    size_t gtab, stab, tw, cw, Xw, yw, Mg, rbuf, counter, total;
+    size_t gtab, stab, tw, cw, Xw, yw, Mg, Mslot, rbuf, counter, total;
 };
 
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 static WsLayout ws_layout(int64_t N, int64_t n_grids, int NTmax, int KP, int quad_P4 = 0,
-                          int quad_slots = 0)
+                          int quad_slots = 0, int quad_ragged = 0)
 {
     WsLayout l;
     size_t off = 0;
@@ -195,6 +195,7 @@ static WsLayout ws_layout(int64_t N, int64_t n_grids, int NTmax, int KP, int qua
     l.Xw = off; off = align_up(off + sizeof(double) * (size_t)n_grids * NTmax * KP * W);
     l.yw = off; off = align_up(off + sizeof(double) * (size_t)N * NTmax * W);
     l.Mg = off; off = align_up(off + sizeof(double) * (size_t)quad_P4 * 2 * W);
+    l.Mslot = off; off = align_up(off + (quad_ragged ? sizeof(double) * (size_t)quad_slots * quad_P4 * 2 * W : 0));
     l.rbuf = off; off = align_up(off + sizeof(double) * (size_t)quad_slots * NTmax * W);
     l.counter = off; off = align_up(off + 256);
     l.total = off;
@@ -269,10 +270,10 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     const int NTmax = (Tm + W - 1) / W;
     const int64_t n_grids = aligned ? 1 : N;
     // quadratic (Gram) form of the data term: see tsf_quad_kernels.h
-    const bool quad_ok = aligned && hs.growth == TSF_GROWTH_LINEAR && mode == 0 && hs.history == QH &&
+    const bool quad_ok = hs.growth == TSF_GROWTH_LINEAR && mode == 0 && hs.history == QH &&
                          theta_in == nullptr;
     if (spec->eval_form == TSF_EVAL_QUADRATIC && !quad_ok && theta_in == nullptr)
-        return fail(ctx, "eval_form QUADRATIC needs linear growth, additive columns only, an aligned panel and history == 5");
+        return fail(ctx, "eval_form QUADRATIC needs linear growth, additive columns only and history == 5");
     const bool quad = quad_ok && spec->eval_form != TSF_EVAL_RESIDUAL;
     QuadPlan qp;
     memset(&qp, 0, sizeof(qp));
@@ -280,7 +281,7 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
         rc = quad_plan(ctx, hs, N, &qp);
         if (rc) return rc;
     }
-    const WsLayout l = ws_layout(N, n_grids, NTmax, hs.KP, qp.P4, qp.slots);
+    const WsLayout l = ws_layout(N, n_grids, NTmax, hs.KP, qp.P4, qp.slots, quad && !aligned);
     rc = ensure_ws(ctx, l.total);
     if (rc) return rc;
     char *ws = (char *)ctx->ws;
@@ -321,7 +322,8 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     int lrc;
     if (quad) {
         QuadArgs qa;
-        qa.f = a; qa.Mg = (const double *)(ws + l.Mg); qa.rbuf = (double *)(ws + l.rbuf);
+        qa.f = a; qa.Mg = (const double *)(ws + l.Mg); qa.Mslot = (double *)(ws + l.Mslot);
+        qa.rbuf = (double *)(ws + l.rbuf);
         qa.counter = (int *)(ws + l.counter); qa.P4 = qp.P4;
         qa.recenter_every = spec->recenter_every; qa.recenter_ratio = spec->recenter_ratio;
         qa.dbg = nullptr;

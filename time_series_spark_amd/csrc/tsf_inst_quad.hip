@@ -17,17 +17,20 @@ namespace tsf {
 
 int quad_waves_per_block(int PPL) { return PPL == 2 ? TSF_QUAD_NW2 : TSF_QUAD_NW; }
 
-template <int KP, int PPL, bool MLDS, int PQ, bool RLDS>
+template <int KP, int PPL, int MMODE, int PQ, bool RLDS>
 static int launch_quad_rl(const QuadPlan &qp, const QuadArgs &qa, double *Mg, hipStream_t st)
 {
     constexpr int NW = (PPL == 2) ? TSF_QUAD_NW2 : TSF_QUAD_NW;
-    hipLaunchKernelGGL((gram_build_kernel<KP, PPL>), dim3((unsigned)qp.P4), dim3(64), 0, st, qa, Mg);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return (int)e;
+    constexpr bool MLDS = MMODE == QM_LDS;
+    if (MMODE != QM_RAGGED) {       // aligned panel: one M for the whole call
+        hipLaunchKernelGGL((gram_build_kernel<KP, PPL>), dim3((unsigned)qp.P4), dim3(64), 0, st, qa, Mg);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+    }
     const size_t lds = (MLDS ? sizeof(double) * (size_t)qp.P4 * PPL * W : 0) + sizeof(QuadLds<KP, PPL>) * NW +
                        (RLDS ? sizeof(double) * (size_t)NW * qa.f.NTmax * W : 0);
     // per launch: the attribute is per device, and a process may drive several GPUs
-    hipFuncSetAttribute((const void *)fit_quad_kernel<KP, PPL, NW, MLDS, PQ, RLDS>,
+    hipFuncSetAttribute((const void *)fit_quad_kernel<KP, PPL, NW, MMODE, PQ, RLDS>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 #ifdef TSF_QUAD_TIMING      // dev build: per-phase cycle counts (s_memtime) summed per series
     {
@@ -35,7 +38,7 @@ static int launch_quad_rl(const QuadPlan &qp, const QuadArgs &qa, double *Mg, hi
         const size_t nb = sizeof(long long) * 8 * (size_t)qa.f.N;
         hipMalloc((void **)&qb.dbg, nb);
         hipMemsetAsync(qb.dbg, 0, nb, st);
-        hipLaunchKernelGGL((fit_quad_kernel<KP, PPL, NW, MLDS, PQ, RLDS>), dim3((unsigned)qp.blocks), dim3(NW * 64), lds, st, qb);
+        hipLaunchKernelGGL((fit_quad_kernel<KP, PPL, NW, MMODE, PQ, RLDS>), dim3((unsigned)qp.blocks), dim3(NW * 64), lds, st, qb);
         hipStreamSynchronize(st);
         std::vector<long long> h(8 * (size_t)qa.f.N);
         hipMemcpy(h.data(), qb.dbg, nb, hipMemcpyDeviceToHost);
@@ -48,19 +51,28 @@ static int launch_quad_rl(const QuadPlan &qp, const QuadArgs &qa, double *Mg, hi
         return (int)hipGetLastError();
     }
 #endif
-    hipLaunchKernelGGL((fit_quad_kernel<KP, PPL, NW, MLDS, PQ, RLDS>), dim3((unsigned)qp.blocks), dim3(NW * 64), lds, st, qa);
+    hipLaunchKernelGGL((fit_quad_kernel<KP, PPL, NW, MMODE, PQ, RLDS>), dim3((unsigned)qp.blocks), dim3(NW * 64), lds, st, qa);
     return (int)hipGetLastError();
 }
 
 // residual staging in LDS when M + per-wave state + NW x NTmax x 64 doubles fit in 160 KB
-template <int KP, int PPL, bool MLDS, int PQ>
-static int launch_quad_one(const QuadPlan &qp, const QuadArgs &qa, double *Mg, hipStream_t st)
+template <int KP, int PPL, int MMODE, int PQ>
+static int launch_quad_mm(const QuadPlan &qp, const QuadArgs &qa, double *Mg, hipStream_t st)
 {
     constexpr int NW = (PPL == 2) ? TSF_QUAD_NW2 : TSF_QUAD_NW;
-    const size_t base = (MLDS ? sizeof(double) * (size_t)qp.P4 * PPL * W : 0) + sizeof(QuadLds<KP, PPL>) * NW;
+    const size_t base = (MMODE == QM_LDS ? sizeof(double) * (size_t)qp.P4 * PPL * W : 0) + sizeof(QuadLds<KP, PPL>) * NW;
     const size_t rbytes = sizeof(double) * (size_t)NW * qa.f.NTmax * W;
-    if (base + rbytes <= 160 * 1024) return launch_quad_rl<KP, PPL, MLDS, PQ, true>(qp, qa, Mg, st);
-    return launch_quad_rl<KP, PPL, MLDS, PQ, false>(qp, qa, Mg, st);
+    if (base + rbytes <= 160 * 1024) return launch_quad_rl<KP, PPL, MMODE, PQ, true>(qp, qa, Mg, st);
+    return launch_quad_rl<KP, PPL, MMODE, PQ, false>(qp, qa, Mg, st);
+}
+
+// aligned panels share one M (in LDS when it fits: the one-slot kernels); ragged panels build one
+// per series
+template <int KP, int PPL, int PQ>
+static int launch_quad_one(const QuadPlan &qp, const QuadArgs &qa, double *Mg, hipStream_t st)
+{
+    if (!qa.f.aligned) return launch_quad_mm<KP, PPL, QM_RAGGED, PQ>(qp, qa, Mg, st);
+    return launch_quad_mm<KP, PPL, (PPL == 1 ? QM_LDS : QM_GLOBAL), PQ>(qp, qa, Mg, st);
 }
 
 int launch_quad(int KP, const QuadPlan &qp, const QuadArgs &qa, double *Mg, hipStream_t st)
@@ -68,16 +80,16 @@ int launch_quad(int KP, const QuadPlan &qp, const QuadArgs &qa, double *Mg, hipS
     // qp.P4 is the M row count the plan chose: 40 / 56 / 64 (compile-time, P <= 64) or any
     // multiple of 4 for the two-slot kernel
     switch (KP * 100 + (KP == 64 ? 0 : qp.P4)) {
-    case 840: return launch_quad_one<8, 1, true, 40>(qp, qa, Mg, st);
-    case 856: return launch_quad_one<8, 1, true, 56>(qp, qa, Mg, st);
-    case 864: return launch_quad_one<8, 1, true, 64>(qp, qa, Mg, st);
-    case 1640: return launch_quad_one<16, 1, true, 40>(qp, qa, Mg, st);
-    case 1656: return launch_quad_one<16, 1, true, 56>(qp, qa, Mg, st);
-    case 1664: return launch_quad_one<16, 1, true, 64>(qp, qa, Mg, st);
-    case 2840: return launch_quad_one<28, 1, true, 40>(qp, qa, Mg, st);
-    case 2856: return launch_quad_one<28, 1, true, 56>(qp, qa, Mg, st);
-    case 2864: return launch_quad_one<28, 1, true, 64>(qp, qa, Mg, st);
-    case 6400: return launch_quad_one<64, 2, false, 0>(qp, qa, Mg, st);
+    case 840: return launch_quad_one<8, 1, 40>(qp, qa, Mg, st);
+    case 856: return launch_quad_one<8, 1, 56>(qp, qa, Mg, st);
+    case 864: return launch_quad_one<8, 1, 64>(qp, qa, Mg, st);
+    case 1640: return launch_quad_one<16, 1, 40>(qp, qa, Mg, st);
+    case 1656: return launch_quad_one<16, 1, 56>(qp, qa, Mg, st);
+    case 1664: return launch_quad_one<16, 1, 64>(qp, qa, Mg, st);
+    case 2840: return launch_quad_one<28, 1, 40>(qp, qa, Mg, st);
+    case 2856: return launch_quad_one<28, 1, 56>(qp, qa, Mg, st);
+    case 2864: return launch_quad_one<28, 1, 64>(qp, qa, Mg, st);
+    case 6400: return launch_quad_one<64, 2, 0>(qp, qa, Mg, st);
     default: return -1;
     }
 }

@@ -32,7 +32,8 @@ constexpr int QUAD_WAVES_PER_SIMD = TSF_QUAD_WPS;   // register budget: 512 / th
 
 struct QuadArgs {
     FitArgs f;
-    const double *Mg;                   // [P4][PPL][64] Gram matrix, column-major over q
+    const double *Mg;                   // aligned: [P4][PPL][64] Gram matrix, column-major over q
+    double *Mslot;                      // ragged: [slots][P4][PPL][64], one per resident wave
     double *rbuf;                       // [slots][NTmax][64] residual scratch
     int *counter;                       // work queue head (zeroed before the launch)
     int P4;                             // P rounded up to a multiple of 4
@@ -373,13 +374,16 @@ __device__ __forceinline__ bool gram_eval_q(const SeriesView &sv, const LaneCons
 template <int KP, int PPL>
 __device__ __forceinline__ void make_view_q(const FitArgs &a, int64_t n, SeriesView &sv)
 {
-    const GridTab &gt = a.gtab[0];
+    const int64_t g = a.aligned ? 0 : n;            // ragged panels: one grid per series
+    const GridTab &gt = a.gtab[g];
     sv.T = gt.info.T; sv.NT = gt.info.NT; sv.S = gt.info.S;
     sv.P = 3 + sv.S + a.sp->K;
     int cnt = sv.T - lane_id() * sv.NT;
     cnt = cnt < 0 ? 0 : (cnt > sv.NT ? sv.NT : cnt);
     sv.cnt = cnt;
-    sv.tw = a.tw; sv.cw = a.cw; sv.Xw = a.Xw;
+    sv.tw = a.tw + (size_t)g * a.NTmax * W;
+    sv.cw = a.cw + (size_t)g * a.NTmax * W;
+    sv.Xw = a.Xw + (size_t)g * a.NTmax * KP * W;
     sv.yw = a.yw + (size_t)n * a.NTmax * W;
     sv.Lj = gt.Lj;
     sv.t_change = gt.info.t_change;
@@ -389,8 +393,25 @@ __device__ __forceinline__ void make_view_q(const FitArgs &a, int64_t n, SeriesV
 }
 
 // ---------------------------------------------------------------------------------------
-// Gram matrix: block q computes column q of M = Z^T Z as "Z^T r" with r := column q of Z
+// Gram matrix: column q of M = Z^T Z is "Z^T r" of the residual machinery with r := column q
+// of Z (cn_build_gram).  Aligned panels: gram_build_kernel, one workgroup per column, once per
+// grid.  Ragged panels: every wave builds the M of its current series itself (fit_one_quad).
 // ---------------------------------------------------------------------------------------
+template <int KP, int PPL>
+__device__ __forceinline__ void gram_column(const SeriesView &sv, QuadLds<KP, PPL> &wl, double *rb,
+                                            int q, double (&ztr)[PPL])
+{
+    const int lane = lane_id();
+    auto gen = [&](int st, int idx, int c, double ti) -> double {
+        if (q == 0) return ti;
+        if (q == 1) return 1.0;
+        if (q < 3 + sv.S) return (c > q - 3) ? ti - sv.t_change[q - 3] : 0.0;
+        return sv.Xw[((size_t)st * KP + (q - 3 - sv.S)) * W + lane];
+    };
+    double sse;
+    ztr_pass<KP, PPL>(sv, wl, rb, gen, sse, ztr);
+}
+
 template <int KP, int PPL>
 __global__ __launch_bounds__(64) void gram_build_kernel(QuadArgs qa, double *Mout)
 {
@@ -405,14 +426,8 @@ __global__ __launch_bounds__(64) void gram_build_kernel(QuadArgs qa, double *Mou
         return;
     }
     double *rb = qa.rbuf + (size_t)q * qa.f.NTmax * W;
-    auto gen = [&](int st, int idx, int c, double ti) -> double {
-        if (q == 0) return ti;
-        if (q == 1) return 1.0;
-        if (q < 3 + sv.S) return (c > q - 3) ? ti - sv.t_change[q - 3] : 0.0;
-        return sv.Xw[((size_t)st * KP + (q - 3 - sv.S)) * W + lane];
-    };
-    double sse, ztr[PPL];
-    ztr_pass<KP, PPL>(sv, wl, rb, gen, sse, ztr);
+    double ztr[PPL];
+    gram_column<KP, PPL>(sv, wl, rb, q, ztr);
 #pragma unroll
     for (int s = 0; s < PPL; ++s) out[s * W + lane] = ztr[s];
 }
@@ -431,9 +446,9 @@ __global__ __launch_bounds__(64) void gram_build_kernel(QuadArgs qa, double *Mou
 #endif
 
 // One series, start to finish, by one wave.
-template <int KP, int PPL, int PQ>
+template <int KP, int PPL, int PQ, bool RAGGED>
 __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL> &wl, double *rb,
-                                          const double *Mp, int64_t n)
+                                          const double *Mp, double *Mown, int64_t n)
 {
     const FitArgs &a = qa.f;
     const DevSpec *sp = a.sp;
@@ -447,7 +462,7 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
     const SeriesTab st = a.stab[n];
     if (lane == 0) {
         a.y_scale[n] = st.y_scale;
-        if (n == 0) a.grid_out[0] = a.gtab[0].info;
+        if (!a.aligned || n == 0) a.grid_out[a.aligned ? 0 : n] = a.gtab[a.aligned ? 0 : n].info;
     }
     double xk[PPL], gk[PPL], pk[PPL], xk1[PPL], gk1[PPL], pk1[PPL];
 #pragma unroll
@@ -467,6 +482,21 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
     }
     LaneConst<PPL> lk;
     lane_consts<KP, PPL>(sp, sv, wl, lk);
+    if (RAGGED) {
+        // ragged panel: this series has its own grid, hence its own M = Z^T Z.  The wave builds
+        // it column by column into its slot of global memory; lane p writes and later reads only
+        // entries of its own row p, so no fence is needed.
+#pragma unroll 1
+        for (int q = 0; q < P4; ++q) {
+            double col[PPL];
+#pragma unroll
+            for (int s = 0; s < PPL; ++s) col[s] = 0.0;
+            if (q != 2 && q < sv.P) gram_column<KP, PPL>(sv, wl, rb, q, col);
+#pragma unroll
+            for (int s = 0; s < PPL; ++s) Mown[((size_t)q * PPL + s) * W + lane] = col[s];
+        }
+        Mp = Mown;
+    }
 
     double s0 = 0.0, q2 = 0.0;
     // L-BFGS history in registers, age order (index 0 = oldest)
@@ -719,13 +749,18 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
     QT_FLUSH();
 }
 
-template <int KP, int PPL, int NW, bool MLDS, int PQ, bool RLDS>
+// MMODE: where M lives -- 0 aligned panel, shared M in LDS; 1 aligned panel, shared M in global
+// memory (two-slot kernel: too big for LDS); 2 ragged panel, one M per resident wave in global
+enum { QM_LDS = 0, QM_GLOBAL = 1, QM_RAGGED = 2 };
+
+template <int KP, int PPL, int NW, int MMODE, int PQ, bool RLDS>
 __global__ __launch_bounds__(NW * 64, QUAD_WAVES_PER_SIMD) void fit_quad_kernel(QuadArgs qa)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const FitArgs &a = qa.f;
     const int lane = lane_id(), wid = (int)threadIdx.x >> 6;
     const int P4 = qa.P4;
+    constexpr bool MLDS = MMODE == QM_LDS;
     double *Ml = reinterpret_cast<double *>(smem);
     const size_t m_bytes = MLDS ? sizeof(double) * (size_t)P4 * PPL * W : 0;
     QuadLds<KP, PPL> &wl = *reinterpret_cast<QuadLds<KP, PPL> *>(smem + m_bytes + sizeof(QuadLds<KP, PPL>) * wid);
@@ -734,6 +769,8 @@ __global__ __launch_bounds__(NW * 64, QUAD_WAVES_PER_SIMD) void fit_quad_kernel(
         __syncthreads();
     }
     const double *Mp = MLDS ? Ml : qa.Mg;
+    double *Mown = (MMODE == QM_RAGGED) ? qa.Mslot + ((size_t)blockIdx.x * NW + wid) * (size_t)P4 * PPL * W
+                                        : nullptr;
     // residual staging r[q][lane] of the running residual pass: in LDS when the launch found room
     // for NW x NTmax x 64 doubles, else in the global scratch (long series)
     double *rb = RLDS ? reinterpret_cast<double *>(smem + m_bytes + sizeof(QuadLds<KP, PPL>) * NW) + (size_t)wid * a.NTmax * W
@@ -750,7 +787,7 @@ __global__ __launch_bounds__(NW * 64, QUAD_WAVES_PER_SIMD) void fit_quad_kernel(
         n32 = __builtin_amdgcn_readfirstlane(n32);
         const int64_t n = n32;
         if (n >= a.N) break;
-        fit_one_quad<KP, PPL, PQ>(qa, wl, rb, Mp, n);
+        fit_one_quad<KP, PPL, PQ, MMODE == QM_RAGGED>(qa, wl, rb, Mp, Mown, n);
     }
 }
 

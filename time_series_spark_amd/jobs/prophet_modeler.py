@@ -85,24 +85,36 @@ def fit_packed(panel, floor, cap, kw):
             spec = fc.ModelSpec(growth=growth, seasonality_mode=mode, seasonalities=seas,
                                 **_spec_opts(kw))
         sd = spec.to_dict()
-        if panel.aligned and len(members) == N:
-            ex = np.zeros((1, panel.ds_grid.shape[0])) if not seas else None
-            res = fc.fit_aligned(spec, panel.ds_grid, panel.y2d, floor=floor, cap=cap, extra=ex)
-        else:
-            lens = panel.lengths[members]
+        # series that share a timestamp vector are fitted together through the aligned entry
+        # point (one set of design tables for the group); the rest go in one ragged call
+        groups, rest = pk.group_by_grid(panel, members)
+        calls = []
+        for gm in groups:
+            T = int(panel.lengths[gm[0]])
+            a0 = panel.offsets[gm[0]]
+            y2d = np.stack([panel.y[panel.offsets[m]:panel.offsets[m] + T] for m in gm])
+            ex = np.zeros((1, T)) if not seas else None
+            calls.append((gm, fc.fit_aligned(
+                spec, panel.ds_ns[a0:a0 + T], y2d,
+                floor=None if floor is None else np.asarray(floor)[gm],
+                cap=None if cap is None else np.asarray(cap)[gm], extra=ex)))
+        if len(rest):
+            lens = panel.lengths[rest]
             off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
-            idx = np.concatenate([np.arange(panel.offsets[m], panel.offsets[m + 1]) for m in members])
+            idx = np.concatenate([np.arange(panel.offsets[m], panel.offsets[m + 1]) for m in rest])
             ex = np.zeros((1, len(idx))) if not seas else None
-            res = fc.fit_ragged(spec, off, panel.ds_ns[idx], panel.y[idx],
-                                floor=None if floor is None else np.asarray(floor)[members],
-                                cap=None if cap is None else np.asarray(cap)[members], extra=ex)
-        for i, m in enumerate(members):
-            st = int(res.status[i])
-            status[m] = st
-            if st < 0:       # optimiser failure (pystan RuntimeError) or invalid input
-                continue
-            blobs[m] = pk.dump_model(sd, res.theta[i], res.y_scale[i], res.grid_of(i), last_ds[m],
-                                     st, res.n_iter[i])
+            calls.append((rest, fc.fit_ragged(
+                spec, off, panel.ds_ns[idx], panel.y[idx],
+                floor=None if floor is None else np.asarray(floor)[rest],
+                cap=None if cap is None else np.asarray(cap)[rest], extra=ex)))
+        for mem, res in calls:
+            for i, m in enumerate(mem):
+                st = int(res.status[i])
+                status[m] = st
+                if st < 0:       # optimiser failure (pystan RuntimeError) or invalid input
+                    continue
+                blobs[m] = pk.dump_model(sd, res.theta[i], res.y_scale[i], res.grid_of(i), last_ds[m],
+                                         st, res.n_iter[i])
     return blobs, status
 
 

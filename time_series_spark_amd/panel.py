@@ -86,6 +86,46 @@ def pack_long_frame(pdf, y_col='y'):
     return PackedPanel(keys, offsets, np.ascontiguousarray(ds_ns), np.ascontiguousarray(yv))
 
 
+def group_by_grid(panel, members, min_group=2):
+    """Partition `members` (series indices of a PackedPanel) by identical timestamp vector.
+    Returns (groups, rest): groups = list of index arrays (each >= min_group series sharing one
+    grid, to be fitted through the aligned entry point: one set of design tables, shared through
+    L2 / LDS by every series of the group), rest = the series whose grid nobody shares.
+    Results do not depend on the grouping (the evaluation form is a property of the model and the
+    aligned / ragged kernels are bit-identical); only the speed does."""
+    members = np.asarray(members, dtype=np.int64)
+    if len(members) == 0:
+        return [], members
+    off = panel.offsets
+    lens = panel.lengths[members]
+    # 64-bit signature of every grid: length and a position-weighted wrap-around sum of ds
+    pos = np.arange(len(panel.ds_ns), dtype=np.uint64) - np.repeat(off[:-1].astype(np.uint64), panel.lengths)
+    w = (pos * np.uint64(0x9E3779B97F4A7C15) + np.uint64(0xD1B54A32D192ED03))
+    sig_all = np.add.reduceat(panel.ds_ns.astype(np.uint64) * w, off[:-1][panel.lengths > 0]) \
+        if (panel.lengths > 0).all() else None
+    if sig_all is None:                      # empty series present: treat everything as ragged
+        return [], members
+    sig = sig_all[members]
+    order = np.lexsort((sig, lens))
+    ms, ls, ss = members[order], lens[order], sig[order]
+    brk = np.flatnonzero((ls[1:] != ls[:-1]) | (ss[1:] != ss[:-1])) + 1
+    groups, rest = [], []
+    for chunk in np.split(ms, brk):
+        if len(chunk) < min_group:
+            rest.extend(chunk.tolist())
+            continue
+        T = int(panel.lengths[chunk[0]])
+        grid0 = panel.ds_ns[off[chunk[0]]:off[chunk[0]] + T]
+        same = [m for m in chunk if np.array_equal(panel.ds_ns[off[m]:off[m] + T], grid0)]
+        diff = [m for m in chunk if not np.array_equal(panel.ds_ns[off[m]:off[m] + T], grid0)]
+        if len(same) >= min_group:
+            groups.append(np.sort(np.asarray(same, dtype=np.int64)))
+        else:
+            rest.extend(same)
+        rest.extend(diff)                    # signature collision: fit those on their own
+    return groups, np.sort(np.asarray(rest, dtype=np.int64))
+
+
 def per_series_stats(panel):
     """span, smallest non-zero spacing (ns; -1 if none), max y per series -- the inputs of
     fbprophet's set_auto_seasonalities and of the reference's cap = max(y) * cap_multiplier."""
