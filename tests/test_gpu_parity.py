@@ -250,6 +250,50 @@ def test_batched_job_is_independent_of_how_series_are_grouped(env):
         assert one['cap'].iloc[0] == row['cap'].iloc[0]
 
 
+def test_odd_shapes_against_oracle(env):
+    """Small / awkward shapes through both entry points: one series, two rows, no changepoints,
+    a single weekly harmonic, history != 5 (register-resident history needs 5: falls back to the
+    residual kernel), forced evaluation forms, a long series (residual staging outside LDS)."""
+    fc, cl = env
+    from time_series_spark_amd import _lib, synth
+    rng = np.random.default_rng(3)
+
+    def check(spec, ds, y, **kw):
+        r = fc.fit_aligned(spec, ds, y, **kw)
+        csp = helpers.oracle_spec(spec)
+        for n in range(y.shape[0]):
+            o = cl.fit(csp, ds, y[n], kw.get('floor', [0.0] * len(y))[n] if 'floor' in kw else 0.0,
+                       kw['cap'][n] if 'cap' in kw else 0.0)
+            S = o['info'].S
+            assert r.status[n] == o['status'] and r.n_iter[n] == o['n_iter'] and r.n_eval[n] == o['n_eval'], (n, o)
+            assert n_bit_diff(r.theta[n][:3 + S], o['theta'][:3 + S]) == 0
+        return r
+
+    ds, y = synth.make_panel(3, 120, 'linear', seed=4)
+    one = [{'name': 'weekly', 'period': 7, 'fourier_order': 1}]
+    check(fc.ModelSpec(growth='linear', seasonalities=one), ds, y[:1])                    # N = 1, K = 2
+    check(fc.ModelSpec(growth='linear', seasonalities=one, n_changepoints=0), ds, y)      # S = 0
+    check(fc.ModelSpec(growth='linear', seasonalities=one), ds[:2], y[:, :2])             # T = 2 -> S = 0
+    check(fc.ModelSpec(growth='linear', seasonalities=one), ds[:5], y[:, :5])             # T = 5 -> S = 3
+    check(fc.ModelSpec(growth='linear', seasonalities=[helpers.WEEKLY], history=3), ds, y)   # residual kernel
+    check(fc.ModelSpec(growth='linear', seasonalities=[helpers.WEEKLY], max_iter=7), ds, y)
+    check(fc.ModelSpec(growth='linear', seasonalities=[helpers.WEEKLY], eval_form=_lib.EVAL_QUADRATIC), ds, y)
+    check(fc.ModelSpec(growth='linear', seasonalities=[helpers.WEEKLY], eval_form=_lib.EVAL_RESIDUAL), ds, y)
+    check(fc.ModelSpec(growth='logistic', seasonalities=[helpers.WEEKLY]), ds, y,
+          floor=np.zeros(3), cap=y.max(axis=1) * 1.2)
+    with pytest.raises(_lib.TsfError):        # quadratic form needs a model linear in the parameters
+        fc.fit_aligned(fc.ModelSpec(growth='logistic', seasonalities=[helpers.WEEKLY],
+                                    eval_form=_lib.EVAL_QUADRATIC), ds, y, cap=y.max(axis=1) * 1.2)
+    # long series: 3 000 rows (NT = 47: the residual staging of the quadratic kernel leaves LDS)
+    dsl, yl = synth.make_panel(2, 3000, 'linear', seed=8)
+    check(fc.ModelSpec(growth='linear', seasonalities=[helpers.YEARLY, helpers.WEEKLY]), dsl, yl)
+    # noise-free y: the optimiser drives sigma down until something gives; whatever happens must
+    # be the oracle's outcome too
+    t = np.arange(120.0)
+    yc = np.stack([50 + 0.5 * t + 3 * np.sin(2 * np.pi * t / 7), 20 + 0.1 * t])
+    check(fc.ModelSpec(growth='linear', seasonalities=[helpers.WEEKLY]), ds, yc)
+
+
 def test_full_size_panel_properties(env):
     """BASELINE config 2 at full size (10 000 x 730): size-independent properties --
     every series terminates normally, forecasts finite, doubling y doubles the forecast
