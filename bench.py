@@ -209,6 +209,16 @@ def main():
                       'status_counts': {str(int(k)): int(v) for k, v in
                                         zip(*np.unique(status, return_counts=True))}},
     }
+    # host-pointer entry point (what a DataFrame caller uses): the panel crosses PCIe, device
+    # buffers are allocated per call; never part of `value`
+    if world == 1:
+        t0 = time.perf_counter()
+        rh = fc.fit_aligned(spec, ds_np, y_np)
+        fc.predict(spec, rh.theta, rh.y_scale, rh.grid, fut_np)
+        res['host_pointer_entry'] = {'ms_per_call': 1e3 * (time.perf_counter() - t0),
+                                     'note': 'tsf_fit_aligned + tsf_predict with host buffers: H2D of the '
+                                             '%.0f MB panel, per-call hipMalloc, D2H of the results'
+                                             % (y_np.nbytes / 1e6)}
     # cpu_baseline leg (rank 0, N=1 only): the CPU oracle timed on the host cores, and -- the
     # same leg, the oracle as checker -- the GPU forecasts of the sampled series compared with it
     if world == 1 and not args.no_cpu_baseline:
