@@ -178,13 +178,13 @@ static int build_devspec(tsf_ctx *ctx, const tsf_spec *s, DevSpec *d, int *mode_
 // ---- workspace ------------------------------------------------------------------------------
 
 struct WsLayout {
-    size_t gtab, stab, tw, cw, Xw, yw, Mg, Mslot, rbuf, counter, total;
+    size_t gtab, stab, tw, cw, Xw, yw, Mg, Mslot, rbuf, counter, uw, Xu, total;
 };
 
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 static WsLayout ws_layout(int64_t N, int64_t n_grids, int NTmax, int KP, int quad_P4 = 0,
-                          int quad_slots = 0, int quad_ragged = 0)
+                          int quad_slots = 0, int quad_ragged = 0, int64_t lat_U = 0)
 {
     WsLayout l;
     size_t off = 0;
@@ -192,12 +192,16 @@ static WsLayout ws_layout(int64_t N, int64_t n_grids, int NTmax, int KP, int qua
     l.stab = off; off = align_up(off + sizeof(SeriesTab) * (size_t)N);
     l.tw = off; off = align_up(off + sizeof(double) * (size_t)n_grids * NTmax * W);
     l.cw = off; off = align_up(off + sizeof(uint16_t) * (size_t)n_grids * NTmax * W);
-    l.Xw = off; off = align_up(off + sizeof(double) * (size_t)n_grids * NTmax * KP * W);
+    // lattice panels (lat_U > 0) keep one shared table Xu and a row index per series row
+    // instead of a design matrix per grid
+    l.Xw = off; off = align_up(off + (lat_U > 0 ? 0 : sizeof(double) * (size_t)n_grids * NTmax * KP * W));
     l.yw = off; off = align_up(off + sizeof(double) * (size_t)N * NTmax * W);
     l.Mg = off; off = align_up(off + sizeof(double) * (size_t)quad_P4 * 2 * W);
     l.Mslot = off; off = align_up(off + (quad_ragged ? sizeof(double) * (size_t)quad_slots * quad_P4 * 2 * W : 0));
     l.rbuf = off; off = align_up(off + sizeof(double) * (size_t)quad_slots * NTmax * W);
     l.counter = off; off = align_up(off + 256);
+    l.uw = off; off = align_up(off + (lat_U > 0 ? sizeof(int32_t) * (size_t)n_grids * NTmax * W : 0));
+    l.Xu = off; off = align_up(off + (lat_U > 0 ? sizeof(double) * (size_t)lat_U * KP : 0));
     l.total = off;
     return l;
 }
@@ -252,7 +256,8 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
                    const int64_t *offsets, int64_t total_rows, int32_t max_T, const int64_t *ds,
                    const void *y, int32_t y_dtype, const double *floor_, const double *cap,
                    const double *extra, tsf_fit_out *out, const double *theta_in,
-                   double *grad_out, hipStream_t st)
+                   double *grad_out, hipStream_t st, int64_t lat_base = 0, int64_t lat_step = 0,
+                   int64_t lat_U = 0)
 {
     if (!ctx) return -1;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -281,7 +286,9 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
         rc = quad_plan(ctx, hs, N, &qp);
         if (rc) return rc;
     }
-    const WsLayout l = ws_layout(N, n_grids, NTmax, hs.KP, qp.P4, qp.slots, quad && !aligned);
+    // shared lattice table: ragged panel, residual-form kernel, no explicit columns
+    if (aligned || quad || theta_in != nullptr || hs.n_extra > 0 || lat_step <= 0) lat_U = 0;
+    const WsLayout l = ws_layout(N, n_grids, NTmax, hs.KP, qp.P4, qp.slots, quad && !aligned, lat_U);
     rc = ensure_ws(ctx, l.total);
     if (rc) return rc;
     char *ws = (char *)ctx->ws;
@@ -292,11 +299,21 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     double *Xw = (double *)(ws + l.Xw);
     double *yw = (double *)(ws + l.yw);
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_spec, &hs, sizeof(hs), hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipMemsetAsync(Xw, 0, sizeof(double) * (size_t)n_grids * NTmax * hs.KP * W, st));
+    if (lat_U > 0) {
+        double *Xu = (double *)(ws + l.Xu);
+        HIP_TRY(ctx, hipMemsetAsync(Xu, 0, sizeof(double) * (size_t)lat_U * hs.KP, st));
+        const int64_t work = lat_U * (hs.n_pairs > 0 ? hs.n_pairs : 1);
+        hipLaunchKernelGGL(setup_lattice_kernel, dim3((unsigned)((work + 255) / 256 > 65535 ? 65535 : (work + 255) / 256)),
+                           dim3(256), 0, st, ctx->d_spec, lat_U, lat_base, lat_step, Xu);
+        HIP_TRY(ctx, hipGetLastError());
+    } else {
+        HIP_TRY(ctx, hipMemsetAsync(Xw, 0, sizeof(double) * (size_t)n_grids * NTmax * hs.KP * W, st));
+    }
     HIP_TRY(ctx, hipMemsetAsync(gtab, 0, sizeof(GridTab) * (size_t)n_grids, st));
     hipLaunchKernelGGL(setup_grid_kernel, dim3((unsigned)n_grids), dim3(256), 0, st, ctx->d_spec,
                        (int)n_grids, aligned ? nullptr : offsets, T, ds, extra,
-                       aligned ? (int64_t)T : total_rows, NTmax, gtab, tw, cw, Xw);
+                       aligned ? (int64_t)T : total_rows, NTmax, gtab, tw, cw, Xw,
+                       (int32_t *)(ws + l.uw), lat_base, lat_U > 0 ? lat_step : (int64_t)0);
     HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(setup_series_kernel, dim3((unsigned)N), dim3(64), 0, st, ctx->d_spec, N,
                        aligned ? nullptr : offsets, T, ds, y, y_dtype, floor_, cap, NTmax, gtab,
@@ -317,6 +334,7 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     a.theta = out->theta; a.y_scale = out->y_scale; a.fval = out->fval; a.status = out->status;
     a.n_iter = out->n_iter; a.n_eval = out->n_eval; a.grid_out = out->grid;
     a.theta_in = theta_in; a.grad_out = grad_out;
+    a.uw = (const int32_t *)(ws + l.uw); a.Xu = (const double *)(ws + l.Xu); a.xidx = lat_U > 0 ? 1 : 0;
     const int slot = (int)(ctx->ev_count % TSF_PROFILE_RING);
     if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev0[slot], st));
     int lrc;
@@ -451,12 +469,29 @@ static int fit_host(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, 
         HIP_TRY(ctx, hipMemcpy(d_thin.p, theta_in, 8 * (size_t)N * stride, hipMemcpyHostToDevice));
         HIP_TRY(ctx, d_grad.alloc(8 * (size_t)N * stride));
     }
+    // ragged panel: do all timestamps lie on one lattice base + u*step (the usual case: one
+    // sampling grid, different start dates / lengths)?  Then the design rows are computed once
+    // for the lattice and shared by every series instead of being stored per series.
+    int64_t lat_base = 0, lat_step = 0, lat_U = 0;
+    if (!aligned && !theta_in && spec->n_extra == 0 && total > 0) {
+        int64_t lo = ds[0], hi = ds[0];
+        for (int64_t i = 1; i < total; ++i) { lo = ds[i] < lo ? ds[i] : lo; hi = ds[i] > hi ? ds[i] : hi; }
+        uint64_t g = 0;
+        for (int64_t i = 0; i < total && g != 1; ++i) {
+            uint64_t v = (uint64_t)(ds[i] - lo);
+            while (v) { const uint64_t r = g % v; g = v; v = r; }      // gcd(g, v), gcd(0, v) = v
+        }
+        if (g > 0) {
+            const uint64_t U = (uint64_t)(hi - lo) / g + 1;
+            if (U <= (uint64_t)1 << 18) { lat_base = lo; lat_step = (int64_t)g; lat_U = (int64_t)U; }
+        }
+    }
     int rc = run_fit(ctx, spec, N, aligned, T, d_off.as<int64_t>(), total, max_T, d_ds.as<int64_t>(),
                      d_y.p, y_dtype, floor_ ? d_floor.as<double>() : nullptr,
                      cap ? d_cap.as<double>() : nullptr,
                      spec->n_extra > 0 ? d_extra.as<double>() : nullptr, &dout,
                      theta_in ? d_thin.as<double>() : nullptr,
-                     theta_in ? d_grad.as<double>() : nullptr, nullptr);
+                     theta_in ? d_grad.as<double>() : nullptr, nullptr, lat_base, lat_step, lat_U);
     if (rc) return rc;
     HIP_TRY(ctx, hipDeviceSynchronize());
     if (theta_in) {
@@ -616,7 +651,8 @@ extern "C" int tsf_design(tsf_ctx *ctx, const tsf_spec *spec, int32_t T, const i
     HIP_TRY(ctx, hipMemset(ws + l.gtab, 0, sizeof(GridTab)));
     hipLaunchKernelGGL(setup_grid_kernel, dim3(1), dim3(256), 0, nullptr, ctx->d_spec, 1, nullptr, T,
                        d_ds.as<int64_t>(), d_ex.as<double>(), (int64_t)T, NT, (GridTab *)(ws + l.gtab),
-                       (double *)(ws + l.tw), (uint16_t *)(ws + l.cw), (double *)(ws + l.Xw));
+                       (double *)(ws + l.tw), (uint16_t *)(ws + l.cw), (double *)(ws + l.Xw), nullptr,
+                       (int64_t)0, (int64_t)0);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipDeviceSynchronize());
     std::vector<double> Xw((size_t)NT * hs.KP * W), tw((size_t)NT * W);

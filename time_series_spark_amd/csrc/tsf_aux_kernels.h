@@ -19,7 +19,8 @@ __global__ void setup_grid_kernel(const DevSpec *__restrict__ sp, int n_grids,
                                   const double *__restrict__ extra, int64_t extra_stride,
                                   int NTmax, GridTab *__restrict__ gtab,
                                   double *__restrict__ tw_all, uint16_t *__restrict__ cw_all,
-                                  double *__restrict__ Xw_all)
+                                  double *__restrict__ Xw_all, int32_t *__restrict__ uw_all,
+                                  int64_t lat_base, int64_t lat_step)
 {
     const int g = blockIdx.x;
     if (g >= n_grids) return;
@@ -30,6 +31,7 @@ __global__ void setup_grid_kernel(const DevSpec *__restrict__ sp, int n_grids,
     double *tw = tw_all + (size_t)g * NTmax * W;
     uint16_t *cw = cw_all + (size_t)g * NTmax * W;
     double *Xw = Xw_all + (size_t)g * NTmax * sp->KP * W;
+    int32_t *uw = uw_all + (size_t)g * NTmax * W;     // only touched when lat_step > 0
     const int KP = sp->KP;
     __shared__ double tch[NTAB];
     __shared__ int S_sh;
@@ -77,7 +79,9 @@ __global__ void setup_grid_kernel(const DevSpec *__restrict__ sp, int n_grids,
             while (cp < S && tp >= tch[cp]) ++cp;
         }
         cw[q * W + L] = (uint16_t)(c | (cp << 8));
+        if (lat_step > 0) uw[q * W + L] = (int32_t)((ds[i] - lat_base) / lat_step);
     }
+    if (lat_step > 0) return;       // design rows come from the shared lattice table (setup_lattice_kernel)
     // Fourier columns: one (row, harmonic) pair per work item
     const int n_pairs = sp->n_pairs;
     for (int w = threadIdx.x; w < T * n_pairs; w += blockDim.x) {
@@ -96,6 +100,29 @@ __global__ void setup_grid_kernel(const DevSpec *__restrict__ sp, int n_grids,
         const int e = w / T, i = w - e * T;
         const int L = i / NT, q = i - L * NT;
         Xw[((size_t)q * KP + sp->inv_perm[nf + e]) * W + L] = extra[(size_t)e * extra_stride + row0 + i];
+    }
+}
+
+// Design rows of a timestamp lattice base + u*step, u < U: Xu[u][KP] in internal column order,
+// same arithmetic as setup_grid_kernel (explicit columns are not functions of the timestamp:
+// lattice tables are only used when the model has none).  Xu must be zero-filled by the caller.
+__global__ void setup_lattice_kernel(const DevSpec *__restrict__ sp, int64_t U, int64_t lat_base,
+                                     int64_t lat_step, double *__restrict__ Xu)
+{
+    const int n_pairs = sp->n_pairs, KP = sp->KP;
+    const int64_t total = U * n_pairs;
+    for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < total;
+         w += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t u = w / n_pairs;
+        const int pr = (int)(w - u * n_pairs);
+        const int64_t ts = lat_base + u * lat_step;
+        const double tdays = (1e-9 * (double)ts) / 86400.0;
+        const double arg = (sp->pair_mult[pr] * 3.141592653589793 * tdays) / sp->pair_period[pr];
+        double s, c;
+        dm_sincos(arg, s, c);
+        const int col = sp->pair_col[pr];
+        Xu[(size_t)u * KP + sp->inv_perm[col]] = s;
+        Xu[(size_t)u * KP + sp->inv_perm[col + 1]] = c;
     }
 }
 

@@ -12,6 +12,8 @@ namespace tsf {
 struct SeriesView {
     int T, NT, S, P, cnt;               // cnt: valid rows of this lane's chunk
     const double *tw, *yw, *Xw;         // step-major tables
+    const int32_t *uw;                  // (lattice panels) row -> row of the shared table Xu, step-major
+    const double *Xu;                   // (lattice panels) [U][KP] design rows of the timestamp lattice
     const uint16_t *cw;
     const int32_t *Lj;
     const double *t_change;
@@ -97,7 +99,7 @@ __device__ __forceinline__ void column_sums(double (&acc)[KP], WaveLds<KP, PPL> 
 // MODE: 0 all columns additive, 1 all multiplicative, 2 mixed (Ka additive first)
 // NW > 0: called by EVERY wave of an NW-wave workgroup in the same round (workgroup barriers
 // inside); `active` says whether this wave has a point to evaluate, tc is the tile context.
-template <int KP, int GROWTH, int MODE, int PPL, int NW = 0>
+template <int KP, int GROWTH, int MODE, int PPL, int NW = 0, bool XIDX = false>
 __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesView &sv,
                                         WaveLds<KP, PPL> &lds, const double (&th)[PPL],
                                         double &f_out, double (&g)[PPL],
@@ -199,12 +201,23 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
             const int c = (int)(cwv & 0xffu), cprev = (int)(cwv >> 8);
             const double ti = TILED ? tile_t(tc, q & 1)[lane] : sv.tw[idx];
             const double yi = TILED ? y_cur : sv.yw[idx];
-            const double *xp = TILED ? tile_x<KP>(tc, q & 1) + lane : sv.Xw + (size_t)q * KP * W + lane;
+            constexpr int XS = XIDX ? 1 : W;      // stride between the columns of a design row
+            const double *xp = TILED ? tile_x<KP>(tc, q & 1) + lane
+                                     : (XIDX ? sv.Xu + (size_t)sv.uw[idx] * KP : sv.Xw + (size_t)q * KP * W + lane);
             double x[HOLD ? KP : 1];
             double xa = 0.0, xm = 0.0;
             if (HOLD) {
 #pragma unroll
-                for (int j = 0; j < (HOLD ? KP : 1); ++j) x[j] = xp[j * W];
+                for (int j = 0; j < (HOLD ? KP : 1); ++j) {
+                    if (XIDX) {       // gathered row: 16-byte loads (rows are KP*8 bytes, KP even)
+                        if ((j & 1) == 0) {
+                            const double2 v2 = reinterpret_cast<const double2 *>(xp)[j >> 1];
+                            x[j] = v2.x; x[HOLD ? j + 1 : 0] = v2.y;
+                        }
+                    } else {
+                        x[j] = xp[j * XS];
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < (HOLD ? KP : 1); ++j) {
                     const double bj = BLDS ? ((3 + S + j < PPL * W) ? theta_at<PPL>(th, 3 + S + j) : 0.0) : bs[BLDS ? 0 : j];
@@ -215,7 +228,7 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
             } else {
 #pragma unroll 4
                 for (int j = 0; j < KP; ++j) {
-                    const double xv = xp[j * W], bv = lds.th[3 + S + j];
+                    const double xv = xp[j * XS], bv = lds.th[3 + S + j];
                     if (MODE == 0) xa = __builtin_fma(xv, bv, xa);
                     else if (MODE == 1) xm = __builtin_fma(xv, bv, xm);
                     else { if (j < Ka) xa = __builtin_fma(xv, bv, xa); else xm = __builtin_fma(xv, bv, xm); }
@@ -242,7 +255,7 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
             for (int j0 = 0; j0 < KP; j0 += 8) {
                 double xv[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) if (j0 + u < KP) xv[u] = HOLD ? x[HOLD ? j0 + u : 0] : xp[(j0 + u) * W];
+                for (int u = 0; u < 8; ++u) if (j0 + u < KP) xv[u] = HOLD ? x[HOLD ? j0 + u : 0] : xp[(j0 + u) * XS];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     if (j0 + u < KP) {
@@ -447,6 +460,12 @@ struct FitArgs {
     // eval-only mode
     const double *theta_in;
     double *grad_out;
+    // ragged panel whose timestamps all lie on one lattice base + u*step: the design row of a
+    // timestamp is a function of the timestamp only, so ONE table over the lattice serves every
+    // series (L2 resident) instead of a per-series copy streamed from HBM at every evaluation
+    const int32_t *uw;                  // [grid][NTmax][64] lattice row of each series row
+    const double *Xu;                   // [U][KP]
+    int xidx;
 };
 
 template <int KP, int PPL>
@@ -462,6 +481,8 @@ __device__ __forceinline__ void make_view(const FitArgs &a, int64_t n, SeriesVie
     sv.tw = a.tw + (size_t)g * a.NTmax * W;
     sv.cw = a.cw + (size_t)g * a.NTmax * W;
     sv.Xw = a.Xw + (size_t)g * a.NTmax * KP * W;
+    sv.uw = a.uw + (size_t)g * a.NTmax * W;
+    sv.Xu = a.Xu;
     sv.yw = a.yw + (size_t)n * a.NTmax * W;
     sv.Lj = gt.Lj;
     sv.t_change = gt.info.t_change;
@@ -526,7 +547,7 @@ __global__ __launch_bounds__(64) void eval_kernel(FitArgs a)
     if (threadIdx.x == 0) { a.fval[n] = f; a.status[n] = bad ? 1 : 0; }
 }
 
-template <int KP, int GROWTH, int MODE, int PPL>
+template <int KP, int GROWTH, int MODE, int PPL, bool XIDX = false>
 __global__ __launch_bounds__(64) void fit_kernel(FitArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -632,7 +653,7 @@ __global__ __launch_bounds__(64) void fit_kernel(FitArgs a)
                 for (int s = 0; s < PPL; ++s) xk1[s] = __builtin_fma(alpha, pk[s], xk[s]);
             }
             double f1;
-            const bool bad = eval_fg<KP, GROWTH, MODE, PPL>(sp, sv, lds, xk1, f1, gk1);
+            const bool bad = eval_fg<KP, GROWTH, MODE, PPL, 0, XIDX>(sp, sv, lds, xk1, f1, gk1);
             if (stage == ST_INIT) {
                 if (bad) { ret = TSF_ST_INIT_NONFINITE; fk = f1; break; }
                 fk = f1;
