@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libtsf_amd.so')
+LIB_PATH = os.environ.get('TSF_LIB_PATH') or os.path.join(_HERE, 'libtsf_amd.so')   # override: A/B runs of two builds
 
 MAX_SEAS = 8
 MAX_EXTRA = 64

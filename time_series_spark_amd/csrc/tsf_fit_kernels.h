@@ -129,18 +129,29 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
     {
         double ksv = k, mcv = m;
         const double tcl = (lane < S) ? sv.t_change[lane] : 0.0;
-        for (int j = 0; j < S; ++j) {
-            const double dj = theta_at<PPL>(th, 3 + j);
-            const double tcj = readlane_f64(tcl, j);
-            const double ksn = ksv + dj;
-            double mcn;
-            if (GROWTH == 0) {
-                mcn = mcv + ((-tcj) * dj);
-            } else {
-                const double gamma = (tcj - mcv) * (1.0 - ksv / ksn);
-                mcn = mcv + gamma;
+        if (GROWTH == 0) {
+            for (int j = 0; j < S; ++j) {
+                const double dj = theta_at<PPL>(th, 3 + j);
+                const double ksn = ksv + dj;
+                const double mcn = mcv + ((-readlane_f64(tcl, j)) * dj);
+                if (j < lane) { ksv = ksn; mcv = mcn; }
             }
-            if (j < lane) { ksv = ksn; mcv = mcn; }
+        } else {
+            // logistic: gamma_j needs ks[j] / ks[j+1].  ks does not depend on mc, so the ks chain
+            // runs first, the S quotients are ONE lane-parallel division (lane j: ks[j]/ks[j+1],
+            // the operands of the sequential form), and the mc chain reads them by lane.
+            double ks_next = k;
+            for (int j = 0; j < S; ++j) {
+                const double ksn = ksv + theta_at<PPL>(th, 3 + j);
+                if (j == lane) ks_next = ksn;
+                if (j < lane) ksv = ksn;
+            }
+            const double ratio = ksv / ks_next;
+            for (int j = 0; j < S; ++j) {
+                const double gamma = (readlane_f64(tcl, j) - mcv) * (1.0 - readlane_f64(ratio, j));
+                const double mcn = mcv + gamma;
+                if (j < lane) mcv = mcn;
+            }
         }
         if (lane <= S) { lds.ks[lane] = ksv; lds.mc[lane] = mcv; }
     }
@@ -321,11 +332,18 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
         }
         TSF_WAVE_SYNC();
         {
-            double abar = lds.d2[S];
+            // reverse sweep through the gamma recurrence: the per-step operands (ks[c]/ks[c+1],
+            // t_change[c] - mc[c], d2[c]) are prepared lane-parallel (lane c), the sequential
+            // chain itself only multiplies and adds
+            const int cl = lane <= S ? lane : S;
+            const double ratio_l = (lane < S) ? lds.ks[cl] / lds.ks[cl + 1] : 0.0;
+            const double tmc_l = (lane < S) ? sv.t_change[cl] - lds.mc[cl] : 0.0;
+            const double d2_l = lds.d2[cl];
+            double abar = readlane_f64(d2_l, S);
             for (int c = S - 1; c >= 0; --c) {
-                const double ratio = lds.ks[c] / lds.ks[c + 1];
-                if (lane == 0) lds.rb[c] = abar * (sv.t_change[c] - lds.mc[c]);
-                abar = lds.d2[c] + abar * ratio;
+                const double rbc = abar * readlane_f64(tmc_l, c);
+                if (lane == c) lds.rb[c] = rbc;
+                abar = readlane_f64(d2_l, c) + abar * readlane_f64(ratio_l, c);
             }
             gm = nis * abar;
         }
