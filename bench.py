@@ -158,6 +158,23 @@ def main():
 
     if rank != 0:
         return
+    # measured HBM ceiling on this device beside the 8 TB/s spec figure: device-to-device copy of
+    # 1 GiB (reads + writes counted), outside the timed region (torch only moves memory here)
+    try:
+        src = torch.empty(1 << 28, dtype=torch.float32, device=dev).normal_()
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbps = 5 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del src, dst
+    except Exception:
+        copy_gbps = None
     n_eval = out.n_eval.cpu().numpy().astype(np.int64)
     n_iter = out.n_iter.cpu().numpy()
     status = out.status.cpu().numpy()
@@ -192,6 +209,7 @@ def main():
                    'parallelism': 'shard-by-id x%d' % world},
         'roofline': {'bound': 'hbm', 'kernel': kernel, 'achieved': achieved,
                      'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS,
+                     'peak_measured_device_copy': copy_gbps,
                      'traffic': traffic, 'traffic_source': traffic_src,
                      'algorithmic_bytes_per_launch': bytes_per_series * N_SERIES,
                      'kernel_ms_avg': fit_ms, 'launches_timed': len(kernel_ms),
