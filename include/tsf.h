@@ -104,8 +104,8 @@ typedef struct {
      * additive (and history == 5).  TSF_EVAL_AUTO picks QUADRATIC where possible; the choice
      * depends on the MODEL only, never on the shape or composition of the panel. */
     int32_t eval_form;                      /* TSF_EVAL_AUTO */
-    int32_t recenter_every;                 /* 32: re-centre at least every n accepted iterations */
-    double recenter_ratio;                  /* 0.25: ... and when |Z D|^2 > ratio * s0 */
+    int32_t recenter_every;                 /* 128: re-centre at least every n accepted iterations */
+    double recenter_ratio;                  /* 1.0: ... and when |Z D|^2 > ratio * s0 */
 } tsf_spec;
 
 /* What setup derives from one timestamp vector ("grid").  One per call for aligned panels,

@@ -932,7 +932,7 @@ void cn_default_spec(cn_spec *sp)
     sp->growth = 0; sp->n_changepoints = 25; sp->changepoint_range = 0.8; sp->tau = 0.05;
     sp->max_iter = 10000; sp->history = 5; sp->init_alpha = 1e-3; sp->tol_obj = 1e-12;
     sp->tol_rel_obj = 1e4; sp->tol_grad = 1e-8; sp->tol_rel_grad = 1e7; sp->tol_param = 1e-8;
-    sp->eval_mode = 0; sp->recenter_every = 32; sp->recenter_ratio = 0.25;
+    sp->eval_mode = 0; sp->recenter_every = 128; sp->recenter_ratio = 1.0;
 }
 
 int cn_spec_size(void) { return (int)sizeof(cn_spec); }

@@ -29,8 +29,8 @@ def test_library_loads_and_exports_every_declared_symbol(built):
     assert s.changepoint_range == 0.8 and s.changepoint_prior_scale == 0.05
     assert (s.init_alpha, s.tol_obj, s.tol_rel_obj, s.tol_grad, s.tol_rel_grad, s.tol_param) == \
         (1e-3, 1e-12, 1e4, 1e-8, 1e7, 1e-8)
-    # evaluation form of the likelihood (include/tsf.h): auto, re-centre every 32 / at 0.25
-    assert (s.eval_form, s.recenter_every, s.recenter_ratio) == (_lib.EVAL_AUTO, 32, 0.25)
+    # evaluation form of the likelihood (include/tsf.h): auto, re-centre every 128 / at ratio 1
+    assert (s.eval_form, s.recenter_every, s.recenter_ratio) == (_lib.EVAL_AUTO, 128, 1.0)
     c = fc.ModelSpec(growth='linear', seasonalities=[helpers.WEEKLY], eval_form=_lib.EVAL_RESIDUAL,
                      recenter_every=8).to_c()
     assert (c.eval_form, c.recenter_every) == (_lib.EVAL_RESIDUAL, 8)

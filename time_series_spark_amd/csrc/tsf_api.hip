@@ -95,7 +95,7 @@ extern "C" void tsf_spec_default(tsf_spec *s)
     s->changepoint_prior_scale = 0.05;
     s->max_iter = 10000; s->history = 5; s->init_alpha = 1e-3; s->tol_obj = 1e-12;
     s->tol_rel_obj = 1e4; s->tol_grad = 1e-8; s->tol_rel_grad = 1e7; s->tol_param = 1e-8;
-    s->eval_form = TSF_EVAL_AUTO; s->recenter_every = 32; s->recenter_ratio = 0.25;
+    s->eval_form = TSF_EVAL_AUTO; s->recenter_every = 128; s->recenter_ratio = 1.0;
 }
 
 extern "C" int tsf_spec_size(void) { return (int)sizeof(tsf_spec); }
