@@ -513,6 +513,11 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
     double dfp = 0, c1dfp = 0, c2dfp = 0, alpha0 = 0, prevF = 0, prevDFp = 0;
     double alo = 0, aloF = 0, aloDFp = 0, ahi = 0, ahiF = 0, ahiDFp = 0;
     int nits = 0, lsRestarts = 0, zoom = 0, zit = 0;
+    // g.p of the current and of the previous iterate are each needed two or three times per
+    // iteration (termination test, cubic interpolation, line-search slope): same operands, same
+    // bits, so they are computed once and carried
+    double gp = 0.0;
+    bool gp_valid = false, pk1_scaled = false;
 
     enum { ST_INIT = 0, ST_START_ITER, ST_START_LS, ST_LS_PRE, ST_LS_EVAL, ST_RECENTER, ST_POST };
     int stage = ST_INIT;
@@ -538,6 +543,9 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
 #pragma unroll
                 for (int s = 0; s < PPL; ++s) pk1[s] = pk1[s] / B0fact;
                 alpha = alpha * B0fact;
+                pk1_scaled = true;
+            } else {
+                pk1_scaled = false;
             }
             gammak = readlane_f64(qv, 1);
             const double rho_new = readlane_f64(qv, 2);
@@ -588,10 +596,12 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
             const double dF = __builtin_fabs(fk1 - fk);
             const double fmaxv = __builtin_fmax(__builtin_fabs(fk1),
                                                 __builtin_fmax(__builtin_fabs(fk), 1.0));
+            gp = pdot<PPL>(gk, pk);
+            gp_valid = true;
             if (dF < a.opt.tol_obj) ret = TSF_ST_ABSF;
             else if (dF < a.opt.tol_rel_obj_eps * fmaxv) ret = TSF_ST_RELF;
             else if (gradNorm < a.opt.tol_grad) ret = TSF_ST_ABSGRAD;
-            else if (-pdot<PPL>(gk, pk) / __builtin_fmax(__builtin_fabs(fk), 1.0) < a.opt.tol_rel_grad_eps) ret = TSF_ST_RELGRAD;
+            else if (-gp / __builtin_fmax(__builtin_fabs(fk), 1.0) < a.opt.tol_rel_grad_eps) ret = TSF_ST_RELGRAD;
             else if (stepNorm < a.opt.tol_param) ret = TSF_ST_ABSX;
             else if (itNum >= a.opt.max_iter) ret = TSF_ST_MAXIT;
             else ret = 0;
@@ -608,15 +618,20 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
             if (resetB) {
 #pragma unroll
                 for (int s = 0; s < PPL; ++s) pk[s] = -gk[s];
+                gp_valid = false;
             }
+            if (!gp_valid) gp = pdot<PPL>(gk, pk);
+            gp_valid = false;
             if (itNum > 1 && resetB != 2) {
-                const double ci = cubic_interp6(pdot<PPL>(gk1, pk1), alpha, fk - fk1,
-                                                pdot<PPL>(gk, pk), minAlpha, 1.0);
+                // g_{k-1}.p_{k-1} is the slope `dfp` of the previous line search unless p_{k-1}
+                // has been rescaled since
+                const double gp1 = pk1_scaled ? pdot<PPL>(gk1, pk1) : dfp;
+                const double ci = cubic_interp6(gp1, alpha, fk - fk1, gp, minAlpha, 1.0);
                 alpha = __builtin_fmin(1.0, 1.01 * ci);
             } else {
                 alpha = a.opt.init_alpha;
             }
-            dfp = pdot<PPL>(gk, pk);
+            dfp = gp;
             c1dfp = c1 * dfp; c2dfp = c2 * dfp;
             alpha0 = minAlpha; prevF = fk; prevDFp = dfp;
             nits = 0; lsRestarts = 0; zoom = 0; zit = 0;
