@@ -613,6 +613,10 @@ __global__ __launch_bounds__(64) void fit_kernel(FitArgs a)
     double dfp = 0, c1dfp = 0, c2dfp = 0, alpha0 = 0, prevF = 0, prevDFp = 0;
     double alo = 0, aloF = 0, aloDFp = 0, ahi = 0, ahiF = 0, ahiDFp = 0;
     int nits = 0, lsRestarts = 0, zoom = 0, zit = 0;
+    // g.p of the current / previous iterate: computed once per iterate and carried (see
+    // fit_one_quad)
+    double gp = 0.0;
+    bool gp_valid = false, pk1_scaled = false;
 
     enum { ST_INIT = 0, ST_START_ITER, ST_START_LS, ST_LS_PRE, ST_LS_EVAL };
     int stage = ST_INIT;
@@ -626,15 +630,18 @@ __global__ __launch_bounds__(64) void fit_kernel(FitArgs a)
             if (resetB) {
 #pragma unroll
                 for (int s = 0; s < PPL; ++s) pk[s] = -gk[s];
+                gp_valid = false;
             }
+            if (!gp_valid) gp = pdot<PPL>(gk, pk);
+            gp_valid = false;
             if (itNum > 1 && resetB != 2) {
-                const double ci = cubic_interp6(pdot<PPL>(gk1, pk1), alpha, fk - fk1,
-                                                pdot<PPL>(gk, pk), minAlpha, 1.0);
+                const double gp1 = pk1_scaled ? pdot<PPL>(gk1, pk1) : dfp;
+                const double ci = cubic_interp6(gp1, alpha, fk - fk1, gp, minAlpha, 1.0);
                 alpha = __builtin_fmin(1.0, 1.01 * ci);
             } else {
                 alpha = a.opt.init_alpha;
             }
-            dfp = pdot<PPL>(gk, pk);
+            dfp = gp;
             c1dfp = c1 * dfp; c2dfp = c2 * dfp;
             alpha0 = minAlpha; prevF = fk; prevDFp = dfp;
             nits = 0; lsRestarts = 0; zoom = 0; zit = 0;
@@ -731,23 +738,30 @@ __global__ __launch_bounds__(64) void fit_kernel(FitArgs a)
                     sk[s] = xk[s] - xk1[s];
                     yk[s] = gk[s] - gk1[s];
                 }
-                const double gradNorm = __builtin_sqrt(pdot<PPL>(gk, gk));
-                const double stepNorm = __builtin_sqrt(pdot<PPL>(sk, sk));
+                const double gg = pdot<PPL>(gk, gk), ss = pdot<PPL>(sk, sk);
                 const double skyk = pdot<PPL>(yk, sk);
                 const double ykyk = pdot<PPL>(yk, yk);
+                // independent square roots / quotients: one lane each (see fit_one_quad)
+                const double nrm = __builtin_sqrt(lanes4(gg, ss, 0.0, 0.0));
+                const double gradNorm = readlane_f64(nrm, 0), stepNorm = readlane_f64(nrm, 1);
+                const double qv = lanes4(ykyk, skyk, 1.0, 1.0) / lanes4(skyk, ykyk, skyk, 1.0);
                 if (resetB) {
-                    const double B0fact = ykyk / skyk;
+                    const double B0fact = readlane_f64(qv, 0);
                     hist_len = 0; hist_head = 0;
 #pragma unroll
                     for (int s = 0; s < PPL; ++s) pk1[s] = pk1[s] / B0fact;
                     alpha = alpha * B0fact;
+                    pk1_scaled = true;
+                } else {
+                    pk1_scaled = false;
                 }
-                gammak = skyk / ykyk;
+                gammak = readlane_f64(qv, 1);
+                const double rho_new = readlane_f64(qv, 2);
                 {
                     int slot;
                     if (hist_len < H) { slot = (hist_head + hist_len) % H; hist_len++; }
                     else { slot = hist_head; hist_head = (hist_head + 1) % H; }
-                    if (lane == 0) lds.rho[slot] = 1.0 / skyk;
+                    if (lane == 0) lds.rho[slot] = rho_new;
 #pragma unroll
                     for (int s = 0; s < PPL; ++s) {
                         lds.Sb[(slot * PPL + s) * W + lane] = sk[s];
@@ -790,10 +804,12 @@ __global__ __launch_bounds__(64) void fit_kernel(FitArgs a)
                 const double dF = __builtin_fabs(fk1 - fk);
                 const double fmaxv = __builtin_fmax(__builtin_fabs(fk1),
                                                     __builtin_fmax(__builtin_fabs(fk), 1.0));
+                gp = pdot<PPL>(gk, pk);
+                gp_valid = true;
                 if (dF < a.opt.tol_obj) ret = TSF_ST_ABSF;
                 else if (dF < a.opt.tol_rel_obj_eps * fmaxv) ret = TSF_ST_RELF;
                 else if (gradNorm < a.opt.tol_grad) ret = TSF_ST_ABSGRAD;
-                else if (-pdot<PPL>(gk, pk) / __builtin_fmax(__builtin_fabs(fk), 1.0) < a.opt.tol_rel_grad_eps) ret = TSF_ST_RELGRAD;
+                else if (-gp / __builtin_fmax(__builtin_fabs(fk), 1.0) < a.opt.tol_rel_grad_eps) ret = TSF_ST_RELGRAD;
                 else if (stepNorm < a.opt.tol_param) ret = TSF_ST_ABSX;
                 else if (itNum >= a.opt.max_iter) ret = TSF_ST_MAXIT;
                 else ret = 0;
