@@ -285,7 +285,7 @@ __device__ __forceinline__ bool gram_eval_q(const SeriesView &sv, const LaneCons
                                             const double *Ml, int P4, const double (&th)[PPL],
                                             const double *ref_l, const double *cvec_l,
                                             double s0, double &f_out, double (&g)[PPL],
-                                            double &q2_out)
+                                            double &q2_out, double *dl)
 {
     double ref[PPL], cvec[PPL];
 #pragma unroll
@@ -301,6 +301,8 @@ __device__ __forceinline__ bool gram_eval_q(const SeriesView &sv, const LaneCons
     }
     const double *mp = Ml + lane;
     if (PQ > 0) {
+        dl[lane] = D[0];
+        wave_sync();
         static_assert(PQ == 0 || PPL == 1, "compile-time M rows only for P <= 64");
         // batches of MB rows: MB LDS reads in flight, then their fmas; the scheduling barrier
         // keeps the compiler from hoisting every read of M to the top (register pressure)
@@ -310,12 +312,12 @@ __device__ __forceinline__ bool gram_eval_q(const SeriesView &sv, const LaneCons
             double m[MB];
 #pragma unroll
             for (int u = 0; u < MB; ++u) if (q0 + u < PQ) m[u] = mp[(q0 + u) * W];
+            double dq[MB];              // D_q for the whole wave: one broadcast LDS read each
+#pragma unroll
+            for (int u = 0; u < MB; ++u) if (q0 + u < PQ) dq[u] = dl[q0 + u];
 #pragma unroll
             for (int u = 0; u < MB; ++u) {
-                if (q0 + u < PQ) {
-                    const double Dq = readlane_f64(D[0], q0 + u);
-                    a[0][(q0 + u) & 3] = __builtin_fma(m[u], Dq, a[0][(q0 + u) & 3]);
-                }
+                if (q0 + u < PQ) a[0][(q0 + u) & 3] = __builtin_fma(m[u], dq[u], a[0][(q0 + u) & 3]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -697,7 +699,7 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
 #pragma unroll
             for (int s = 0; s < PPL; ++s) { xk1[s] = __builtin_fma(alpha, pk[s], xk[s]); xe[s] = xk1[s]; }
             sv.n_eval++;
-            bad = gram_eval_q<PPL, PQ>(sv, lk, Mp, P4, xe, wl.ref, wl.cvec, s0, fe, ge, q2);
+            bad = gram_eval_q<PPL, PQ>(sv, lk, Mp, P4, xe, wl.ref, wl.cvec, s0, fe, ge, q2, wl.th);
             QT_LAP(4);
 #pragma unroll
             for (int s = 0; s < PPL; ++s) gk1[s] = ge[s];
