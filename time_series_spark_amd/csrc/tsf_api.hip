@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -75,10 +76,13 @@ extern "C" int tsf_create(int device_id, tsf_ctx **out)
     return 0;
 }
 
+namespace { void pool_trim(int device); }    // host-pointer buffer cache, below
+
 extern "C" void tsf_destroy(tsf_ctx *ctx)
 {
     if (!ctx) return;
     hipSetDevice(ctx->device);
+    pool_trim(ctx->device);
     if (ctx->ws) hipFree(ctx->ws);
     if (ctx->d_spec) hipFree(ctx->d_spec);
     if (ctx->ev_created)
@@ -397,10 +401,67 @@ extern "C" int tsf_fit_ragged_dev(tsf_ctx *ctx, const tsf_spec *spec, int64_t N,
 // ---- host-pointer wrappers --------------------------------------------------------------------
 
 namespace {
+// Device buffers of the host-pointer entry points come from a small per-process cache
+// (power-of-two size classes, per device, at most 2 GiB kept): the DataFrame layer calls these
+// entry points once per group of series, and a hipMalloc + hipFree (which synchronises the
+// device) per buffer per call costs more than a small group's fit.
+struct PoolEntry { void *p; size_t bytes; int device; };
+std::mutex g_pool_mu;
+std::vector<PoolEntry> g_pool;
+size_t g_pool_bytes = 0;
+constexpr size_t POOL_LIMIT = (size_t)2 << 30;
+
+size_t pool_class(size_t n)
+{
+    size_t c = 256;
+    while (c < n) c <<= 1;
+    return c;
+}
+
+void pool_trim(int device)
+{
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (size_t i = 0; i < g_pool.size();) {
+        if (g_pool[i].device == device) {
+            hipFree(g_pool[i].p);
+            g_pool_bytes -= g_pool[i].bytes;
+            g_pool[i] = g_pool.back();
+            g_pool.pop_back();
+        } else {
+            ++i;
+        }
+    }
+}
+
 struct DevBuf {
     void *p = nullptr;
-    ~DevBuf() { if (p) hipFree(p); }
-    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 8); }
+    size_t bytes = 0;
+    int device = 0;
+    ~DevBuf()
+    {
+        if (!p) return;
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        if (g_pool_bytes + bytes <= POOL_LIMIT) { g_pool.push_back({p, bytes, device}); g_pool_bytes += bytes; }
+        else hipFree(p);
+    }
+    hipError_t alloc(size_t n)
+    {
+        bytes = pool_class(n ? n : 8);
+        hipGetDevice(&device);
+        {
+            std::lock_guard<std::mutex> lk(g_pool_mu);
+            for (size_t i = 0; i < g_pool.size(); ++i) {
+                if (g_pool[i].device == device && g_pool[i].bytes == bytes) {
+                    p = g_pool[i].p;
+                    g_pool_bytes -= bytes;
+                    g_pool[i] = g_pool.back();
+                    g_pool.pop_back();
+                    return hipSuccess;
+                }
+            }
+        }
+        return hipMalloc(&p, bytes);
+    }
     template <class T> T *as() { return (T *)p; }
 };
 
