@@ -1,7 +1,7 @@
 // tsf_quad_kernels.h -- fit kernel for models that are LINEAR in (k, m, delta, beta): linear
-// growth with only additive design columns (the BASELINE cfg2 / cfg3 / cfg5 shape), aligned
-// panels.  Same model, same Stan L-BFGS as tsf_fit_kernels.h; what changes is how the normal
-// log-likelihood's data term is evaluated.
+// growth with only additive design columns (the BASELINE cfg2 / cfg3 / cfg5 shape), aligned or
+// ragged panels.  Same model, same Stan L-BFGS as tsf_fit_kernels.h; what changes is how the
+// normal log-likelihood's data term is evaluated.
 //
 // With mu = Z theta_L (Z = [t, 1, (t - s_j)+ ..., X], shared by every series of an aligned
 // panel) and a reference point `ref` with residual r_ref = y - Z ref:
@@ -14,10 +14,11 @@
 // error of the quadratic form at the level of the residual form's (measured by
 // oracle/prophet_canon.c cn_fit_checked: f agrees to ~1e-14 relative on every evaluation).
 //
-// Execution model: persistent workgroups of NW waves; M lives once per workgroup in LDS;
-// every wave pulls series indices from a global atomic counter and runs the whole L-BFGS for
-// its series (one wavefront per series, parameter p in lane p%64).  L-BFGS history is held in
-// registers.  oracle/prophet_canon.c (cn_resid_q / cn_eval_gram / cn_assemble_q / cn_lbfgs)
+// Execution model: persistent workgroups of NW waves; on an aligned panel M is shared and lives
+// once per workgroup in LDS, on a ragged panel every wave builds the M of its current series
+// into its own slot of global memory; every wave pulls series indices from a global atomic
+// counter and runs the whole L-BFGS for its series (one wavefront per series, parameter p in
+// lane p%64).  L-BFGS history is held in registers.  oracle/prophet_canon.c (cn_resid_q / cn_eval_gram / cn_assemble_q / cn_lbfgs)
 // performs the identical operation sequence; tests require bit equality.
 #pragma once
 #include "tsf_fit_kernels.h"
