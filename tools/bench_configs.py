@@ -37,6 +37,17 @@ def build(name):
         spec = fc.ModelSpec(growth='logistic', seasonality_mode='multiplicative', seasonalities=[YEARLY, WEEKLY])
         return ('10000 x 730 logistic + multiplicative yearly+weekly (reference settings, aligned)',
                 spec, ds, y, np.zeros(N), y.max(axis=1) * 1.1, None, None, T * 8 + 54 * 8 + H * 8 + 8)
+    if name in ('lin_hol', 'lin_hol_resid'):   # linear + additive with 30 holiday columns: P = 84, two-slot kernels
+        N, T = 10000, 730
+        ds = synth.daily_grid(T)
+        fut = ds[-1] + synth.DAY_NS * np.arange(1, H + 1)
+        allm, names = synth.holiday_matrix(np.concatenate([ds, fut]), 10)
+        extra, exf = np.ascontiguousarray(allm[:, :T]), np.ascontiguousarray(allm[:, T:])
+        ds, y = synth.make_panel(N, T, 'linear', seed=751, holidays=extra)
+        lb = {'eval_form': 1} if name.endswith('resid') else {}
+        spec = fc.ModelSpec(growth='linear', seasonalities=[YEARLY, WEEKLY], extra=[{'name': n} for n in names], **lb)
+        return ('10000 x 730 linear additive + 10 holidays x [-1,+1]' + (' (residual form forced)' if lb else ''),
+                spec, ds, y, None, None, extra, exf, T * 8 + (3 + 25 + spec.K) * 8 + H * 8)
     if name == 'cfg1':
         N, T = 100, 365
         ds, y = synth.make_panel(N, T, 'logistic', seed=751)
