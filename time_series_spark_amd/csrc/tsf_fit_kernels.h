@@ -237,7 +237,7 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
                     else { if (j < Ka) xa = __builtin_fma(x[j], bj, xa); else xm = __builtin_fma(x[j], bj, xm); }
                 }
             } else {
-#pragma unroll 4
+#pragma unroll 8
                 for (int j = 0; j < KP; ++j) {
                     const double xv = xp[j * XS], bv = lds.th[3 + S + j];
                     if (MODE == 0) xa = __builtin_fma(xv, bv, xa);
