@@ -209,6 +209,33 @@ int tsf_set_profiling(tsf_ctx *ctx, int32_t enable);
 int tsf_profile_read(tsf_ctx *ctx, float *ms_out, int32_t max_n, int32_t *n_out);
 int tsf_last_fit_kernel_ms(tsf_ctx *ctx, float *ms_out);
 
+/* ---- host-side panel packing (no device work, no tsf_ctx) ---------------------------------
+ * Regroups a long table (one row per observation) into the contiguous per-series runs
+ * tsf_fit_ragged takes.  Replaces the row movement of
+ *   df.groupby('series_id','dim_id').apply(...)   /root/reference/src/jobs/prophet_modeler.py:139-141
+ * (Spark shuffle + one Arrow->pandas frame per group) and fbprophet's per-group
+ * `history = df[df['y'].notnull()]`, sort by ds (Prophet.fit / setup_dataframe).
+ * Order contract: series ascending by (series_id, dim_id); inside a series ascending ds with
+ * ties in input order; rows whose y is NaN dropped; series left with no row dropped.
+ *
+ *   tsf_pack_rows   builds the plan.  The four input arrays are only read and must stay alive
+ *                   until tsf_pack_fetch returns.  n_threads <= 0: one per core (max 32).
+ *                   *identity = 1 when the input already is in packed order with no NaN
+ *                   (then ds/y need not be copied at all).
+ *   tsf_pack_fetch  fills caller-allocated outputs (any may be NULL): keys [n_series],
+ *                   offsets [n_series+1], ds_out / y_out [n_rows], and per series
+ *                   span = last ds - first ds, min_dt = smallest positive spacing (-1 if none),
+ *                   y_max -- the inputs of fbprophet's set_auto_seasonalities and of
+ *                   cap = max(y) * cap_multiplier (prophet_modeler.py:59-60).
+ * Returns 0, -1 bad arguments, -2 out of memory, -3 other failure. */
+typedef struct tsf_pack tsf_pack;
+int tsf_pack_rows(int64_t n, const int64_t *series_id, const int64_t *dim_id, const int64_t *ds,
+                  const double *y, int32_t n_threads, tsf_pack **out, int64_t *n_rows,
+                  int64_t *n_series, int32_t *identity);
+int tsf_pack_fetch(tsf_pack *p, int64_t *key_series_id, int64_t *key_dim_id, int64_t *offsets,
+                   int64_t *ds_out, double *y_out, int64_t *span, int64_t *min_dt, double *y_max);
+void tsf_pack_free(tsf_pack *p);
+
 #ifdef __cplusplus
 }
 #endif

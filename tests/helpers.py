@@ -97,3 +97,17 @@ def make_case(name, N=6, seed=21):
     floor = np.zeros(N)
     cap = y.max(axis=1) * 1.1
     return spec, ds, y, floor, cap, extra, fut, extra_future
+
+
+def pack_reference(sid, did, ds_ns, y):
+    """numpy statement of the packing order contract (include/tsf.h, tsf_pack_rows): NaN-y rows
+    dropped, stable lexsort by (series_id, dim_id, ds).  Checker for the native packer."""
+    keep = ~np.isnan(y)
+    sid, did, ds_ns, y = sid[keep], did[keep], ds_ns[keep], y[keep]
+    order = np.lexsort((ds_ns, did, sid))
+    sid, did, ds_ns, y = sid[order], did[order], ds_ns[order], y[order]
+    new = np.ones(len(sid), dtype=bool)
+    new[1:] = (sid[1:] != sid[:-1]) | (did[1:] != did[:-1])
+    starts = np.flatnonzero(new)
+    offsets = np.concatenate([starts, [len(sid)]]).astype(np.int64)
+    return sid[starts], did[starts], offsets, ds_ns, y

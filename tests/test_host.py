@@ -204,3 +204,43 @@ def test_group_by_grid_partitions_by_identical_timestamps():
     assert groups == [] and rest.tolist() == [0, 2, 4]
     groups, rest = pk.group_by_grid(p, np.arange(p.N), min_group=3)
     assert [g.tolist() for g in groups] == [[0, 1, 3]] and rest.tolist() == [2, 4, 5, 6]
+
+
+@pytest.mark.parametrize('case', ['shuffled', 'grouped_unsorted', 'packed', 'nan_rows', 'single_rows',
+                                  'empty', 'wide_keys'])
+def test_native_packer_matches_numpy_order_contract(case):
+    rng = np.random.default_rng(11)
+    if case == 'empty':
+        sid = did = ds = np.zeros(0, np.int64); y = np.zeros(0)
+    else:
+        G = 300
+        lens = rng.integers(1, 40, G)
+        if case == 'single_rows':
+            lens[:] = 1
+        sid = np.repeat(rng.integers(-5, 60, G), lens).astype(np.int64)
+        did = np.repeat(rng.integers(0, 4, G), lens).astype(np.int64)
+        if case == 'wide_keys':
+            sid = sid * (1 << 40) + 7
+            did = did - (1 << 50)
+        n = len(sid)
+        ds = rng.integers(0, 50, n).astype(np.int64) * 3600_000_000_000    # many ties
+        y = rng.normal(size=n).round(2)
+        if case in ('nan_rows', 'shuffled'):
+            y[rng.random(n) < 0.2] = np.nan
+            y[sid == sid[0]] = np.nan                                       # a series that vanishes
+        if case in ('shuffled', 'nan_rows', 'wide_keys'):
+            p = rng.permutation(n); sid, did, ds, y = sid[p], did[p], ds[p], y[p]
+        if case == 'packed':
+            o = np.lexsort((ds, did, sid)); sid, did, ds, y = sid[o], did[o], ds[o], y[o]
+    ks, kd, off, dso, yo = helpers.pack_reference(sid, did, ds, y)
+    for nt in (1, 4):
+        p = pk.pack_rows(sid, did, ds, y, n_threads=nt)
+        assert np.array_equal(p.keys['series_id'].values, ks) and np.array_equal(p.keys['dim_id'].values, kd)
+        assert np.array_equal(p.offsets, off) and np.array_equal(p.ds_ns, dso) and np.array_equal(p.y, yo)
+        # the statistics that come with it == the numpy statement of them
+        span, min_dt, ymax = p.stats
+        p.stats = None
+        s2, m2, y2 = pk.per_series_stats(p)
+        assert np.array_equal(span, s2) and np.array_equal(min_dt, m2) and np.array_equal(ymax, y2)
+    if case == 'packed':
+        assert p.ds_ns is ds or np.shares_memory(p.ds_ns, ds)               # no copy made

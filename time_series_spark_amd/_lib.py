@@ -74,7 +74,8 @@ EXPORTS = ['tsf_create', 'tsf_destroy', 'tsf_last_error', 'tsf_device_count', 't
            'tsf_spec_size', 'tsf_grid_info_size', 'tsf_spec_K', 'tsf_theta_stride',
            'tsf_fit_aligned', 'tsf_fit_aligned_dev', 'tsf_fit_ragged', 'tsf_fit_ragged_dev',
            'tsf_predict', 'tsf_predict_dev', 'tsf_eval', 'tsf_design', 'tsf_selftest_math',
-           'tsf_set_profiling', 'tsf_profile_read', 'tsf_last_fit_kernel_ms']
+           'tsf_set_profiling', 'tsf_profile_read', 'tsf_last_fit_kernel_ms',
+           'tsf_pack_rows', 'tsf_pack_fetch', 'tsf_pack_free']
 
 _lib = None
 
@@ -121,6 +122,11 @@ def load():
     L.tsf_set_profiling.argtypes = [vp, i32]
     L.tsf_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_float), i32, ctypes.POINTER(i32)]
     L.tsf_last_fit_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+    L.tsf_pack_rows.argtypes = [i64, vp, vp, vp, vp, i32, ctypes.POINTER(vp), ctypes.POINTER(i64),
+                                ctypes.POINTER(i64), ctypes.POINTER(i32)]
+    L.tsf_pack_fetch.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.tsf_pack_free.argtypes = [vp]
+    L.tsf_pack_free.restype = None
     if L.tsf_spec_size() != ctypes.sizeof(TsfSpec):
         raise TsfError('tsf_spec layout mismatch between _lib.py and libtsf_amd.so')
     if L.tsf_grid_info_size() != ctypes.sizeof(TsfGridInfo) or GRID_DTYPE.itemsize != ctypes.sizeof(TsfGridInfo):

@@ -16,7 +16,7 @@ OBJ = os.path.join(HERE, '_obj')
 LIB = os.path.join(HERE, 'libtsf_amd.so')
 ARCH = 'gfx950'
 FLAGS = ['--offload-arch=' + ARCH, '-O3', '-ffp-contract=off', '-fPIC', '-std=c++17',
-         '-Wno-unused-value'] + os.environ.get('TSF_HIPCC_FLAGS', '').split()
+         '-Wno-unused-value', '-pthread'] + os.environ.get('TSF_HIPCC_FLAGS', '').split()
 
 
 def _hipcc():
@@ -43,9 +43,9 @@ def _compile(src, obj, hdr_mtime, force):
 
 def build_lib(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
-    srcs = sorted(glob.glob(os.path.join(CSRC, '*.hip')))
+    srcs = sorted(glob.glob(os.path.join(CSRC, '*.hip')) + glob.glob(os.path.join(CSRC, '*.cpp')))
     hdr = _newest_header()
-    jobs = [(s, os.path.join(OBJ, os.path.basename(s)[:-4] + '.o')) for s in srcs]
+    jobs = [(s, os.path.join(OBJ, os.path.splitext(os.path.basename(s))[0] + '.o')) for s in srcs]
     changed = False
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
         for obj, did in ex.map(lambda j: _compile(j[0], j[1], hdr, force), jobs):
@@ -53,7 +53,7 @@ def build_lib(force=False, verbose=False):
             if verbose and did:
                 print('compiled', os.path.basename(obj))
     if changed or not os.path.exists(LIB):
-        cmd = [_hipcc(), '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB] + [o for _, o in jobs]
+        cmd = [_hipcc(), '--offload-arch=' + ARCH, '-shared', '-fPIC', '-pthread', '-o', LIB] + [o for _, o in jobs]
         subprocess.check_call(cmd)
         if verbose:
             print('linked', LIB)

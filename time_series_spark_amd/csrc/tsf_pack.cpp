@@ -1,0 +1,367 @@
+// Host-side panel packing behind tsf_pack_rows / tsf_pack_fetch / tsf_pack_free (include/tsf.h).
+//
+// What it replaces in the reference: the row movement of
+//   df.groupby('series_id', 'dim_id').apply(udf)      /root/reference/src/jobs/prophet_modeler.py:139-141
+// (Spark shuffle + one Arrow -> pandas frame per group) and the per-group host steps fbprophet
+// performs before Stan sees the data: history = df[df['y'].notnull()], sort by ds
+// (UPSTREAM-RECALL fbprophet 0.5 Prophet.fit / setup_dataframe).  Here the whole
+// long table is regrouped once into contiguous per-series runs -- the SoA layout
+// tsf_fit_ragged / tsf_fit_aligned take -- plus the three per-series statistics the Python layer
+// needs for fbprophet's 'auto' seasonality rules and the reference's cap = max(y) * multiplier
+// (prophet_modeler.py:59-60).  No device work; plain C++ threads.
+//
+// Order contract (what tests/ compare against numpy's lexsort): series ascending by
+// (series_id, dim_id); within a series ascending ds, ties in input order (stable); rows whose
+// y is NaN dropped.
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <numeric>
+#include <thread>
+#include <vector>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
+#include "../../include/tsf.h"
+
+namespace {
+
+struct Key {
+    int64_t sid, did;
+    bool operator==(const Key &o) const { return sid == o.sid && did == o.did; }
+    bool operator<(const Key &o) const { return sid < o.sid || (sid == o.sid && did < o.did); }
+};
+
+inline uint64_t mix(uint64_t a, uint64_t b) {
+    uint64_t h = a * 0x9E3779B97F4A7C15ull ^ (b + 0xD1B54A32D192ED03ull + (a << 6) + (a >> 2));
+    h ^= h >> 29;
+    h *= 0xBF58476D1CE4E5B9ull;
+    h ^= h >> 32;
+    return h;
+}
+
+// open addressing (series key -> dense id in first-appearance order)
+struct KeyMap {
+    std::vector<int64_t> slot;      // id or -1
+    std::vector<Key> keys;          // by id
+    uint64_t mask = 0;
+
+    void init(size_t cap_pow2) {
+        slot.assign(cap_pow2, -1);
+        mask = cap_pow2 - 1;
+    }
+    void grow() {
+        std::vector<int64_t> ns(slot.size() * 2, -1);
+        uint64_t nm = ns.size() - 1;
+        for (size_t id = 0; id < keys.size(); ++id) {
+            uint64_t h = mix((uint64_t)keys[id].sid, (uint64_t)keys[id].did) & nm;
+            while (ns[h] >= 0) h = (h + 1) & nm;
+            ns[h] = (int64_t)id;
+        }
+        slot.swap(ns);
+        mask = nm;
+    }
+    int64_t get(const Key &k) {
+        uint64_t h = mix((uint64_t)k.sid, (uint64_t)k.did) & mask;
+        for (;;) {
+            int64_t id = slot[h];
+            if (id < 0) break;
+            if (keys[(size_t)id] == k) return id;
+            h = (h + 1) & mask;
+        }
+        if ((keys.size() + 1) * 2 > slot.size()) {
+            grow();
+            h = mix((uint64_t)k.sid, (uint64_t)k.did) & mask;
+            while (slot[h] >= 0) h = (h + 1) & mask;
+        }
+        slot[h] = (int64_t)keys.size();
+        keys.push_back(k);
+        return (int64_t)keys.size() - 1;
+    }
+};
+
+template <class F>
+void parallel_for(int64_t n, int n_threads, F f) {
+    // f(begin, end, thread_index); static contiguous chunks
+    if (n_threads <= 1) {
+        f((int64_t)0, n, 0);
+        return;
+    }
+    std::vector<std::thread> th;
+    int64_t per = (n + n_threads - 1) / n_threads;
+    for (int t = 0; t < n_threads; ++t) {
+        int64_t a = std::min<int64_t>(n, per * t), b = std::min<int64_t>(n, a + per);
+        if (a >= b) break;
+        th.emplace_back([=] { f(a, b, t); });
+    }
+    for (auto &x : th) x.join();
+}
+
+// one packed row; stable scatter + stable sort keep ties in input order, so the input row
+// number itself is not needed
+struct Pair {
+    int64_t ds;
+    double y;
+};
+
+}  // namespace
+
+struct tsf_pack {
+    int64_t n_in = 0, n_rows = 0, n_series = 0;
+    int32_t identity = 0;
+    int n_threads = 1;
+    const int64_t *ds = nullptr;       // caller's arrays; must stay alive until fetch
+    const double *y = nullptr;
+    std::vector<Key> keys;             // [n_series], ascending
+    std::vector<int64_t> offsets;      // [n_series + 1]
+    std::vector<Pair> pairs;           // [n_rows] (ds, y) of each packed row (empty if identity)
+};
+
+extern "C" {
+
+int tsf_pack_rows(int64_t n, const int64_t *series_id, const int64_t *dim_id, const int64_t *ds,
+                  const double *y, int32_t n_threads, tsf_pack **out, int64_t *n_rows,
+                  int64_t *n_series, int32_t *identity) {
+    if (!out || n < 0 || (n > 0 && (!series_id || !dim_id || !ds || !y))) return -1;
+    *out = nullptr;
+    tsf_pack *p = nullptr;
+    try {
+        p = new tsf_pack();
+        int hw = (int)std::thread::hardware_concurrency();
+        if (hw < 1) hw = 1;
+        p->n_threads = n_threads > 0 ? n_threads : std::min(hw, 32);
+        p->n_in = n;
+        p->ds = ds;
+        p->y = y;
+        const int nt = p->n_threads;
+        const bool timing = std::getenv("TSF_PACK_TIMING") != nullptr;
+        auto t_last = std::chrono::steady_clock::now();
+        auto lap = [&](const char *what) {
+            if (!timing) return;
+            auto now = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "tsf_pack_rows %-10s %8.3f ms\n", what,
+                         std::chrono::duration<double, std::milli>(now - t_last).count());
+            t_last = now;
+        };
+
+        // ---- pass 0: is the table already packed? (grouped, keys ascending, ds ascending, no NaN)
+        std::atomic<int> ordered(1);
+        parallel_for(n, nt, [&](int64_t a, int64_t b, int) {
+            bool ok = true;
+            for (int64_t i = a; i < b && ok; ++i) {
+                if (std::isnan(y[i])) ok = false;
+                if (i == 0) continue;
+                Key k0{series_id[i - 1], dim_id[i - 1]}, k1{series_id[i], dim_id[i]};
+                if (k1 < k0) ok = false;
+                else if (k1 == k0 && ds[i] < ds[i - 1]) ok = false;
+            }
+            if (!ok) ordered.store(0);
+        });
+        lap("check");
+        if (ordered.load()) {
+            p->identity = 1;
+            p->n_rows = n;
+            for (int64_t i = 0; i < n; ++i) {
+                if (i == 0 || series_id[i] != series_id[i - 1] || dim_id[i] != dim_id[i - 1]) {
+                    p->keys.push_back(Key{series_id[i], dim_id[i]});
+                    p->offsets.push_back(i);
+                }
+            }
+            p->offsets.push_back(n);
+            p->n_series = (int64_t)p->keys.size();
+        } else {
+            // ---- pass 1 (parallel, one contiguous chunk of rows per thread): chunk-local dense
+            // series ids in first-appearance order (runs of one key reuse the last id), NaN rows
+            // marked -1, rows per local id counted
+            const int64_t per = (n + nt - 1) / nt;
+            const int nchunk = (int)((n + per - 1) / per);
+            struct Chunk {
+                KeyMap map;
+                std::vector<int64_t> count;      // by local id
+                std::vector<int64_t> start;      // by local id: next write position
+                std::vector<int32_t> lid32;      // per row of the chunk (per < 2^31)
+                std::vector<int64_t> lid64;
+            };
+            std::vector<Chunk> ch((size_t)nchunk);
+            const bool small = per < (int64_t)0x7fffffff;
+            parallel_for(n, nt, [&](int64_t a, int64_t b, int t) {
+                Chunk &c = ch[(size_t)t];
+                c.map.init(1 << 10);
+                if (small) c.lid32.resize((size_t)(b - a));
+                else c.lid64.resize((size_t)(b - a));
+                Key last{0, 0};
+                int64_t last_id = -1;
+                for (int64_t i = a; i < b; ++i) {
+                    Key k{series_id[i], dim_id[i]};
+                    if (last_id < 0 || !(k == last)) {
+                        last_id = c.map.get(k);
+                        last = k;
+                        if ((size_t)last_id >= c.count.size()) c.count.resize((size_t)last_id + 1, 0);
+                    }
+                    int64_t v = -1;
+                    if (!std::isnan(y[i])) {
+                        v = last_id;
+                        ++c.count[(size_t)last_id];
+                    }
+                    if (small) c.lid32[(size_t)(i - a)] = (int32_t)v;
+                    else c.lid64[(size_t)(i - a)] = v;
+                }
+            });
+            lap("local ids");
+            // ---- merge: global ids, totals, ascending-key order, run offsets
+            KeyMap map;
+            map.init(1 << 12);
+            std::vector<int64_t> total;
+            std::vector<std::vector<int64_t>> trans((size_t)nchunk);
+            for (int t = 0; t < nchunk; ++t) {
+                Chunk &c = ch[(size_t)t];
+                trans[(size_t)t].resize(c.map.keys.size());
+                for (size_t l = 0; l < c.map.keys.size(); ++l) {
+                    int64_t g = map.get(c.map.keys[l]);
+                    if ((size_t)g >= total.size()) total.resize((size_t)g + 1, 0);
+                    total[(size_t)g] += c.count[l];
+                    trans[(size_t)t][l] = g;
+                }
+            }
+            const size_t G0 = map.keys.size();
+            std::vector<int64_t> by_key(G0);
+            std::iota(by_key.begin(), by_key.end(), (int64_t)0);
+            std::sort(by_key.begin(), by_key.end(),
+                      [&](int64_t a, int64_t b) { return map.keys[(size_t)a] < map.keys[(size_t)b]; });
+            std::vector<int64_t> cursor(G0, -1);
+            int64_t pos = 0;
+            for (int64_t g : by_key) {
+                if (total[(size_t)g] == 0) continue;     // every row NaN: the series disappears
+                p->keys.push_back(map.keys[(size_t)g]);
+                p->offsets.push_back(pos);
+                cursor[(size_t)g] = pos;
+                pos += total[(size_t)g];
+            }
+            p->offsets.push_back(pos);
+            p->n_rows = pos;
+            p->n_series = (int64_t)p->keys.size();
+            // where each chunk writes inside each run: chunks in row order => stable
+            for (int t = 0; t < nchunk; ++t) {
+                Chunk &c = ch[(size_t)t];
+                c.start.resize(c.count.size());
+                for (size_t l = 0; l < c.count.size(); ++l) {
+                    int64_t g = trans[(size_t)t][l];
+                    c.start[l] = cursor[(size_t)g];
+                    cursor[(size_t)g] += c.count[l];
+                }
+            }
+            lap("merge");
+            // ---- pass 2 (parallel): stable scatter of (ds, y) into the runs
+            p->pairs.resize((size_t)pos);
+            parallel_for(n, nt, [&](int64_t a, int64_t b, int t) {
+                Chunk &c = ch[(size_t)t];
+                for (int64_t i = a; i < b; ++i) {
+                    int64_t l = small ? (int64_t)c.lid32[(size_t)(i - a)] : c.lid64[(size_t)(i - a)];
+                    if (l >= 0) p->pairs[(size_t)c.start[(size_t)l]++] = Pair{ds[i], y[i]};
+                }
+            });
+            std::vector<Chunk>().swap(ch);
+            lap("scatter");
+            // ---- pass 3 (parallel over series): stable sort by ds where a run is not ascending
+            const int64_t NS = p->n_series;
+            std::atomic<int64_t> next(0);
+            auto worker = [&]() {
+                for (;;) {
+                    int64_t s0 = next.fetch_add(64);
+                    if (s0 >= NS) break;
+                    int64_t s1 = std::min<int64_t>(NS, s0 + 64);
+                    for (int64_t s = s0; s < s1; ++s) {
+                        Pair *a = p->pairs.data() + p->offsets[(size_t)s];
+                        Pair *b = p->pairs.data() + p->offsets[(size_t)s + 1];
+                        bool asc = true;
+                        for (Pair *q = a + 1; q < b; ++q)
+                            if (q->ds < (q - 1)->ds) { asc = false; break; }
+                        if (!asc)
+                            std::stable_sort(a, b, [](const Pair &u, const Pair &v) { return u.ds < v.ds; });
+                    }
+                }
+            };
+            if (nt <= 1 || NS < 128) {
+                worker();
+            } else {
+                std::vector<std::thread> th;
+                for (int t = 0; t < nt; ++t) th.emplace_back(worker);
+                for (auto &x : th) x.join();
+            }
+            lap("sort");
+        }
+    } catch (const std::bad_alloc &) {
+        delete p;
+        return -2;
+    } catch (...) {
+        delete p;
+        return -3;
+    }
+    *out = p;
+    if (n_rows) *n_rows = p->n_rows;
+    if (n_series) *n_series = p->n_series;
+    if (identity) *identity = p->identity;
+    return 0;
+}
+
+int tsf_pack_fetch(tsf_pack *p, int64_t *key_series_id, int64_t *key_dim_id, int64_t *offsets,
+                   int64_t *ds_out, double *y_out, int64_t *span, int64_t *min_dt, double *y_max) {
+    if (!p) return -1;
+    const int64_t NS = p->n_series;
+    const int64_t *ds = p->ds;
+    const double *y = p->y;
+    const bool ident = p->identity != 0;
+    const Pair *pairs = ident ? nullptr : p->pairs.data();
+    if (offsets) std::memcpy(offsets, p->offsets.data(), sizeof(int64_t) * (size_t)(NS + 1));
+    for (int64_t s = 0; s < NS; ++s) {
+        if (key_series_id) key_series_id[s] = p->keys[(size_t)s].sid;
+        if (key_dim_id) key_dim_id[s] = p->keys[(size_t)s].did;
+    }
+    // gather + statistics, series-parallel
+    std::atomic<int64_t> next(0);
+    auto worker = [&]() {
+        for (;;) {
+            int64_t s0 = next.fetch_add(64);
+            if (s0 >= NS) break;
+            int64_t s1 = std::min<int64_t>(NS, s0 + 64);
+            for (int64_t s = s0; s < s1; ++s) {
+                int64_t a = p->offsets[(size_t)s], b = p->offsets[(size_t)s + 1];
+                int64_t first = 0, prev = 0, md = -1;
+                double ym = -std::numeric_limits<double>::infinity();
+                for (int64_t r = a; r < b; ++r) {
+                    int64_t d = ident ? ds[r] : pairs[r].ds;
+                    double v = ident ? y[r] : pairs[r].y;
+                    if (ds_out && !(ident && ds_out == ds)) ds_out[r] = d;
+                    if (y_out && !(ident && y_out == y)) y_out[r] = v;
+                    if (r == a) first = d;
+                    else {
+                        int64_t dt = d - prev;
+                        if (dt > 0 && (md < 0 || dt < md)) md = dt;
+                    }
+                    prev = d;
+                    if (v > ym) ym = v;
+                }
+                if (span) span[s] = prev - first;
+                if (min_dt) min_dt[s] = md;
+                if (y_max) y_max[s] = ym;
+            }
+        }
+    };
+    if (p->n_threads <= 1 || NS < 128) {
+        worker();
+    } else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < p->n_threads; ++t) th.emplace_back(worker);
+        for (auto &x : th) x.join();
+    }
+    return 0;
+}
+
+void tsf_pack_free(tsf_pack *p) { delete p; }
+
+}  // extern "C"

@@ -92,7 +92,7 @@ def fit_packed(panel, floor, cap, kw):
         for gm in groups:
             T = int(panel.lengths[gm[0]])
             a0 = panel.offsets[gm[0]]
-            y2d = np.stack([panel.y[panel.offsets[m]:panel.offsets[m] + T] for m in gm])
+            y2d = pk.rows_2d(panel.y, panel.offsets, gm, T)
             ex = np.zeros((1, T)) if not seas else None
             calls.append((gm, fc.fit_aligned(
                 spec, panel.ds_ns[a0:a0 + T], y2d,
@@ -101,20 +101,21 @@ def fit_packed(panel, floor, cap, kw):
         if len(rest):
             lens = panel.lengths[rest]
             off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
-            idx = np.concatenate([np.arange(panel.offsets[m], panel.offsets[m + 1]) for m in rest])
+            # rows of the `rest` series, in order: start of each series repeated over its
+            # length plus the position inside the series
+            idx = np.repeat(panel.offsets[rest] - off[:-1], lens) + np.arange(off[-1], dtype=np.int64)
             ex = np.zeros((1, len(idx))) if not seas else None
             calls.append((rest, fc.fit_ragged(
                 spec, off, panel.ds_ns[idx], panel.y[idx],
                 floor=None if floor is None else np.asarray(floor)[rest],
                 cap=None if cap is None else np.asarray(cap)[rest], extra=ex)))
         for mem, res in calls:
-            for i, m in enumerate(mem):
-                st = int(res.status[i])
-                status[m] = st
-                if st < 0:       # optimiser failure (pystan RuntimeError) or invalid input
-                    continue
-                blobs[m] = pk.dump_model(sd, res.theta[i], res.y_scale[i], res.grid_of(i), last_ds[m],
-                                         st, res.n_iter[i])
+            st = np.asarray(res.status)
+            status[mem] = st
+            bl = pk.dump_models(sd, res.theta, res.y_scale, res.grid, last_ds[mem], st, res.n_iter)
+            # optimiser failure (pystan RuntimeError) or invalid input: no model for the series
+            for i in np.flatnonzero(st >= 0):
+                blobs[mem[i]] = bl[i]
     return blobs, status
 
 
@@ -138,7 +139,7 @@ def model_panel(config):
             return _empty_models()
         panel = pk.pack_long_frame(pdf)
         floor = config['model']['floor']                                   # :56-57
-        _, _, ymax = pk.per_series_stats(panel)
+        ymax = pk.per_series_stats(panel)[2]
         cap = ymax * config['model']['cap_multiplier']                     # :59-60
         kw = _prophet_kwargs(config)
         floors = np.full(panel.N, float(floor))
@@ -148,16 +149,18 @@ def model_panel(config):
         if kw['growth'] == 'logistic' and (cap <= floors).any():
             raise ValueError('cap must be greater than floor (which defaults to 0).')
         blobs, status = fit_packed(panel, floors, cap, kw)
-        rows = []
-        for n in range(panel.N):
-            sid, did = int(panel.keys['series_id'].iloc[n]), int(panel.keys['dim_id'].iloc[n])
-            if blobs[n] is None:
-                # pystan RuntimeError -> the reference prints and drops the series (:81-85)
-                print(f"Runtime error {_lib.STATUS_NAMES.get(int(status[n]), status[n])} for "
-                      f"series_id: {sid}, dim_id: {did}")
-                continue
-            rows.append((sid, did, floor, cap[n], blobs[n]))
-        out = pd.DataFrame(rows, columns=MODEL_OUTPUT_COLUMNS)
+        sids = panel.keys['series_id'].to_numpy()
+        dids = panel.keys['dim_id'].to_numpy()
+        ok = np.fromiter((b is not None for b in blobs), dtype=bool, count=panel.N)
+        for n in np.flatnonzero(~ok):
+            # pystan RuntimeError -> the reference prints and drops the series (:81-85)
+            print(f"Runtime error {_lib.STATUS_NAMES.get(int(status[n]), status[n])} for "
+                  f"series_id: {int(sids[n])}, dim_id: {int(dids[n])}")
+        keep = np.flatnonzero(ok)
+        out = pd.DataFrame({'series_id': sids[keep], 'dim_id': dids[keep],
+                            'floor': np.full(len(keep), floor), 'cap': cap[keep],
+                            'model': pd.Series([blobs[n] for n in keep], dtype=object)},
+                           columns=MODEL_OUTPUT_COLUMNS)
         print(f"Modeled {panel.N} series ({len(pdf.index)} rows) in {time.time() - execution_time}")
         return out
 

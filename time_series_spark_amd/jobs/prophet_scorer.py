@@ -38,49 +38,39 @@ def forecast_panel(config):
         if frequency == 'W':
             frequency = pd.offsets.Week()
         periods = int(config['forecast']['periods'])
-        models, rows = [], []
-        for i in range(len(pdf.index)):
-            r = pdf.iloc[i]
-            series_id, dim_id = int(r['series_id']), int(r['dim_id'])
-            m = pk.load_model(r['model']) if r['model'] is not None else None
-            if m is None:
+        sids = pdf['series_id'].to_numpy()
+        dids = pdf['dim_id'].to_numpy()
+        floors = pdf['floor'].to_numpy(dtype=np.float64)
+        caps = pdf['cap'].to_numpy(dtype=np.float64)
+        blobs = [None if (b is None or isinstance(b, float)) else b for b in pdf['model'].tolist()]
+        for i, b in enumerate(blobs):
+            if b is None:
                 # prophet_scorer.py:51-55
-                print(f"For series_id: {series_id}, dim_id: {dim_id}, no model found")
-                continue
-            models.append(m)
-            rows.append((series_id, dim_id, float(r['floor']), float(r['cap'])))
-        if not models:
-            return _empty_forecasts()
-        out = []
+                print(f"For series_id: {int(sids[i])}, dim_id: {int(dids[i])}, no model found")
+        pieces = []
         # one launch per distinct model spec (series fitted together share it)
-        groups = {}
-        for i, m in enumerate(models):
-            groups.setdefault(repr(sorted(m['spec'].items(), key=lambda kv: kv[0])), []).append(i)
-        for _, idx in groups.items():
-            spec = fc.ModelSpec.from_dict(models[idx[0]]['spec'])
-            stride = spec.theta_stride
-            theta = np.zeros((len(idx), stride))
-            for j, i in enumerate(idx):
-                theta[j, :len(models[i]['theta'])] = models[i]['theta']
-            y_scale = np.array([models[i]['y_scale'] for i in idx])
-            grid = pk.grid_from_models([models[i] for i in idx])
-            last = np.array([models[i]['last_ds_ns'] for i in idx], dtype=np.int64)
-            fut = pk.future_dates(last, periods, frequency)              # :64-66
-            floor = np.array([rows[i][2] for i in idx])                  # :67
-            cap = np.array([rows[i][3] for i in idx])                    # :68
+        for spec_dict, idx, rec in pk.load_models(blobs):
+            spec = fc.ModelSpec.from_dict(spec_dict)
+            theta = np.zeros((len(idx), spec.theta_stride))
+            theta[:, :rec['theta'].shape[1]] = rec['theta']
+            grid = pk.grid_from_records(rec)
+            fut = pk.future_dates(rec['last_ds_ns'], periods, frequency)  # :64-66
+            floor, cap = floors[idx], caps[idx]                          # :67-68
             ex = np.zeros((len(idx), len(spec.extra), periods)) if spec.extra else None
-            yhat, yint = fc.predict(spec, theta, y_scale, grid, fut, floor=floor, cap=cap,
+            yhat, yint = fc.predict(spec, theta, rec['y_scale'], grid, fut, floor=floor, cap=cap,
                                     extra_future=ex, want_int=True)      # :70-84
-            for j, i in enumerate(idx):
-                if (np.trunc(yhat[j]) < floor[j]).any():
-                    print(f"Negative forecast values found for series_id: {rows[i][0]}, "
-                          f"dim_id: {rows[i][1]}")                       # :77-79
-                out.append(pd.DataFrame({'series_id': rows[i][0], 'dim_id': rows[i][1],
-                                         'ds': fut[j].astype('datetime64[ns]'), 'yhat': yint[j]}))
-        res = pd.concat(out, ignore_index=True)[FORECAST_COLUMNS]
-        res['series_id'] = res['series_id'].astype('int32')
-        res['dim_id'] = res['dim_id'].astype('int32')
-        res['yhat'] = res['yhat'].astype('int32')
+            for j in np.flatnonzero((np.trunc(yhat) < floor[:, None]).any(axis=1)):
+                print(f"Negative forecast values found for series_id: {int(sids[idx[j]])}, "
+                      f"dim_id: {int(dids[idx[j]])}")                    # :77-79
+            pieces.append((idx, fut, yint))
+        if not pieces:
+            return _empty_forecasts()
+        res = pd.DataFrame({
+            'series_id': np.concatenate([np.repeat(sids[i], periods) for i, _, _ in pieces]).astype('int32'),
+            'dim_id': np.concatenate([np.repeat(dids[i], periods) for i, _, _ in pieces]).astype('int32'),
+            'ds': np.concatenate([f.reshape(-1) for _, f, _ in pieces]).astype('datetime64[ns]'),
+            'yhat': np.concatenate([y.reshape(-1) for _, _, y in pieces]).astype('int32'),
+        }, columns=FORECAST_COLUMNS)
         return res
 
     return forecast_panel_fn
@@ -113,13 +103,16 @@ class ProphetScorer:
     @staticmethod
     def convert_forecasts(forecast_df):
         created_timestamp = datetime.now(timezone.utc).replace(microsecond=0).isoformat()
+        ds = forecast_df['ds'].values.astype('datetime64[ns]')
+        # extract_date per distinct day (the column repeats a few hundred dates)
+        days, inv = np.unique(ds.astype('datetime64[D]'), return_inverse=True)
+        names = np.array([extract_date(pd.Timestamp(d).to_pydatetime()) for d in days], dtype=object)
         out = pd.DataFrame({
             'created_timestamp': created_timestamp,
             'series_id': forecast_df['series_id'].values,
             'dim_id': forecast_df['dim_id'].values,
-            'forecast_date': [extract_date(pd.Timestamp(v).to_pydatetime())
-                              for v in forecast_df['ds'].values],
-            'forecast_timestamp': forecast_df['ds'].values,
+            'forecast_date': names[inv.reshape(-1)] if len(ds) else names,
+            'forecast_timestamp': ds,
             'forecast_quantity': forecast_df['yhat'].values,
         }, columns=CONVERTED_COLUMNS)
         return out

@@ -2,6 +2,7 @@
 takes, and back.  This is the work Spark's shuffle + Arrow grouped-map runner does for the
 reference (/root/reference/src/jobs/prophet_modeler.py:139-141): bring each series' rows
 together; here they end up contiguous in one array instead of one pandas frame per group."""
+import ctypes
 import io
 import json
 import struct
@@ -9,10 +10,10 @@ import struct
 import numpy as np
 import pandas as pd
 
-from . import forecaster as fc
+from . import _lib, forecaster as fc
 
 MAGIC = b'TSFM'
-VERSION = 1
+VERSION = 2
 KEYS = ['series_id', 'dim_id']
 
 
@@ -42,6 +43,7 @@ class PackedPanel(object):
         lens = np.diff(offsets)
         self.lengths = lens
         self.aligned = False
+        self.stats = None
         self.ds_grid = None
         self.y2d = None
         if self.N > 0 and lens.min() == lens.max() and lens[0] > 0:
@@ -53,37 +55,83 @@ class PackedPanel(object):
                 self.y2d = np.ascontiguousarray(y.reshape(self.N, T))
 
 
-def pack_long_frame(pdf, y_col='y'):
+def pack_long_frame(pdf, y_col='y', n_threads=0):
     """fbprophet's setup_dataframe host steps done for every group at once: drop rows whose y
     is NaN (Prophet.fit: history = df[df['y'].notnull()]), sort by ds within the group
-    (stable), and lay the groups out contiguously."""
+    (stable), and lay the groups out contiguously, ascending by (series_id, dim_id).  The row
+    movement runs in the native packer (tsf_pack_rows, include/tsf.h); a frame that already is
+    in packed order is not copied at all."""
     need = KEYS + ['ds', y_col]
     for c in need:
         if c not in pdf.columns:
             raise ValueError("Dataframe must have columns %r" % (need,))
-    df = pdf[need]
-    yv = pd.to_numeric(df[y_col]).to_numpy(dtype=np.float64, na_value=np.nan)
+    yv = pd.to_numeric(pdf[y_col]).to_numpy(dtype=np.float64, na_value=np.nan)
     if np.isinf(yv).any():
         raise ValueError('Found infinity in column y.')
-    ds_ns = ds_to_ns(df['ds'])
+    ds_ns = ds_to_ns(pdf['ds'])
     if (ds_ns == np.iinfo(np.int64).min).any():
         raise ValueError('Found NaN in column ds.')
-    keep = ~np.isnan(yv)
-    sid = df['series_id'].to_numpy()[keep]
-    did = df['dim_id'].to_numpy()[keep]
-    ds_ns = ds_ns[keep]
-    yv = yv[keep]
-    order = np.lexsort((ds_ns, did, sid))      # stable: ties keep input order
-    sid, did, ds_ns, yv = sid[order], did[order], ds_ns[order], yv[order]
-    if len(sid) == 0:
-        return PackedPanel(pd.DataFrame({'series_id': [], 'dim_id': []}), np.zeros(1, np.int64),
-                           ds_ns, yv)
-    new = np.ones(len(sid), dtype=bool)
-    new[1:] = (sid[1:] != sid[:-1]) | (did[1:] != did[:-1])
-    starts = np.flatnonzero(new)
-    offsets = np.concatenate([starts, [len(sid)]]).astype(np.int64)
-    keys = pd.DataFrame({'series_id': sid[starts], 'dim_id': did[starts]})
-    return PackedPanel(keys, offsets, np.ascontiguousarray(ds_ns), np.ascontiguousarray(yv))
+    sid_col, did_col = pdf['series_id'], pdf['dim_id']
+    sid = np.ascontiguousarray(pd.to_numeric(sid_col).to_numpy(dtype=np.int64))
+    did = np.ascontiguousarray(pd.to_numeric(did_col).to_numpy(dtype=np.int64))
+    return pack_rows(sid, did, ds_ns, yv, n_threads=n_threads,
+                     key_dtypes=(_key_dtype(sid_col), _key_dtype(did_col)))
+
+
+def _key_dtype(col):
+    return col.dtype if np.issubdtype(col.dtype, np.integer) else np.dtype(np.int64)
+
+
+def pack_rows(sid, did, ds_ns, y, n_threads=0, key_dtypes=(np.int64, np.int64)):
+    """Arrays form of pack_long_frame: sid, did, ds_ns int64 [n], y float64 [n] (NaN = missing)."""
+    L = _lib.load()
+    sid = np.ascontiguousarray(sid, dtype=np.int64)
+    did = np.ascontiguousarray(did, dtype=np.int64)
+    ds_ns = np.ascontiguousarray(ds_ns, dtype=np.int64)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    n = len(y)
+    if not (len(sid) == len(did) == len(ds_ns) == n):
+        raise ValueError('pack_rows: column lengths differ')
+    h = ctypes.c_void_p()
+    n_rows, n_series, ident = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int32()
+    rc = L.tsf_pack_rows(n, sid.ctypes.data, did.ctypes.data, ds_ns.ctypes.data, y.ctypes.data,
+                         int(n_threads), ctypes.byref(h), ctypes.byref(n_rows),
+                         ctypes.byref(n_series), ctypes.byref(ident))
+    if rc != 0:
+        raise _lib.TsfError('tsf_pack_rows failed (%d)' % rc)
+    try:
+        N, R = n_series.value, n_rows.value
+        ksid, kdid = np.empty(N, np.int64), np.empty(N, np.int64)
+        offsets = np.empty(N + 1, np.int64)
+        span, min_dt, ymax = np.empty(N, np.int64), np.empty(N, np.int64), np.empty(N, np.float64)
+        if ident.value:
+            ds_out, y_out = ds_ns, y
+            rc = L.tsf_pack_fetch(h, ksid.ctypes.data, kdid.ctypes.data, offsets.ctypes.data, None,
+                                  None, span.ctypes.data, min_dt.ctypes.data, ymax.ctypes.data)
+        else:
+            ds_out, y_out = np.empty(R, np.int64), np.empty(R, np.float64)
+            rc = L.tsf_pack_fetch(h, ksid.ctypes.data, kdid.ctypes.data, offsets.ctypes.data,
+                                  ds_out.ctypes.data, y_out.ctypes.data, span.ctypes.data,
+                                  min_dt.ctypes.data, ymax.ctypes.data)
+        if rc != 0:
+            raise _lib.TsfError('tsf_pack_fetch failed (%d)' % rc)
+    finally:
+        L.tsf_pack_free(h)
+    keys = pd.DataFrame({'series_id': ksid.astype(key_dtypes[0]), 'dim_id': kdid.astype(key_dtypes[1])})
+    panel = PackedPanel(keys, offsets, ds_out, y_out)
+    panel.stats = (span, min_dt, ymax)
+    return panel
+
+
+def rows_2d(arr, off, members, T):
+    """[len(members)][T] matrix of the members' rows of a packed column (all of length T):
+    a view when the members are consecutive series, a gathered copy otherwise."""
+    members = np.asarray(members, dtype=np.int64)
+    n = len(members)
+    if n and members[-1] - members[0] + 1 == n and (n == 1 or (np.diff(members) == 1).all()):
+        a0 = int(off[members[0]])
+        return arr[a0:a0 + n * T].reshape(n, T)
+    return arr[off[members][:, None] + np.arange(T, dtype=np.int64)[None, :]]
 
 
 def group_by_grid(panel, members, min_group=2):
@@ -96,17 +144,18 @@ def group_by_grid(panel, members, min_group=2):
     members = np.asarray(members, dtype=np.int64)
     if len(members) == 0:
         return [], members
+    if panel.aligned and len(members) == panel.N and len(members) >= min_group:
+        return [np.sort(members)], np.zeros(0, dtype=np.int64)
     off = panel.offsets
     lens = panel.lengths[members]
+    if (panel.lengths <= 0).any():           # empty series present: treat everything as ragged
+        return [], members
     # 64-bit signature of every grid: length and a position-weighted wrap-around sum of ds
     pos = np.arange(len(panel.ds_ns), dtype=np.uint64) - np.repeat(off[:-1].astype(np.uint64), panel.lengths)
     w = (pos * np.uint64(0x9E3779B97F4A7C15) + np.uint64(0xD1B54A32D192ED03))
-    sig_all = np.add.reduceat(panel.ds_ns.astype(np.uint64) * w, off[:-1][panel.lengths > 0]) \
-        if (panel.lengths > 0).all() else None
-    if sig_all is None:                      # empty series present: treat everything as ragged
-        return [], members
+    sig_all = np.add.reduceat(panel.ds_ns.astype(np.uint64) * w, off[:-1])
     sig = sig_all[members]
-    order = np.lexsort((sig, lens))
+    order = np.lexsort((members, sig, lens))
     ms, ls, ss = members[order], lens[order], sig[order]
     brk = np.flatnonzero((ls[1:] != ls[:-1]) | (ss[1:] != ss[:-1])) + 1
     groups, rest = [], []
@@ -116,35 +165,38 @@ def group_by_grid(panel, members, min_group=2):
             continue
         T = int(panel.lengths[chunk[0]])
         grid0 = panel.ds_ns[off[chunk[0]]:off[chunk[0]] + T]
-        same = [m for m in chunk if np.array_equal(panel.ds_ns[off[m]:off[m] + T], grid0)]
-        diff = [m for m in chunk if not np.array_equal(panel.ds_ns[off[m]:off[m] + T], grid0)]
-        if len(same) >= min_group:
-            groups.append(np.sort(np.asarray(same, dtype=np.int64)))
+        same = np.ones(len(chunk), dtype=bool)
+        step = max(1, (1 << 22) // max(T, 1))                 # <= 32 MB of timestamps at a time
+        for c0 in range(0, len(chunk), step):
+            blk = rows_2d(panel.ds_ns, off, chunk[c0:c0 + step], T)
+            same[c0:c0 + step] = (blk == grid0[None, :]).all(axis=1)
+        if same.sum() >= min_group:
+            groups.append(np.sort(chunk[same]))
         else:
-            rest.extend(same)
-        rest.extend(diff)                    # signature collision: fit those on their own
+            rest.extend(chunk[same].tolist())
+        rest.extend(chunk[~same].tolist())   # signature collision: fit those on their own
     return groups, np.sort(np.asarray(rest, dtype=np.int64))
 
 
 def per_series_stats(panel):
     """span, smallest non-zero spacing (ns; -1 if none), max y per series -- the inputs of
-    fbprophet's set_auto_seasonalities and of the reference's cap = max(y) * cap_multiplier."""
+    fbprophet's set_auto_seasonalities and of the reference's cap = max(y) * cap_multiplier.
+    Panels that came out of the native packer carry them already."""
+    if getattr(panel, 'stats', None) is not None:
+        return panel.stats
     off = panel.offsets
     N = panel.N
+    if N == 0:
+        return np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0)
     first = panel.ds_ns[off[:-1]]
     last = panel.ds_ns[off[1:] - 1]
-    d = np.diff(panel.ds_ns)
     big = np.iinfo(np.int64).max
-    dd = np.where(d > 0, d, big)
-    # mask differences that straddle two series
-    if N > 1:
-        dd[off[1:-1] - 1] = big
-    min_dt = np.full(N, -1, dtype=np.int64)
-    for n in range(N):          # reduceat needs non-empty segments; lengths can be 1
-        a, b = off[n], off[n + 1] - 1
-        if b > a:
-            m = dd[a:b].min()
-            min_dt[n] = m if m != big else -1
+    dd = np.full(len(panel.ds_ns), big, dtype=np.int64)      # dd[i] = ds[i+1]-ds[i] inside a series
+    d = np.diff(panel.ds_ns)
+    dd[:-1] = np.where(d > 0, d, big)
+    dd[off[1:] - 1] = big                                    # last row of every series
+    m = np.minimum.reduceat(dd, off[:-1])
+    min_dt = np.where(m == big, -1, m).astype(np.int64)
     ymax = np.maximum.reduceat(panel.y, off[:-1])
     return last - first, min_dt, ymax
 
@@ -155,52 +207,122 @@ def per_series_stats(panel):
 # written nor read here; the replacement is a small versioned blob holding exactly what
 # predict needs.
 
+def _rec_dtype(n_theta, n_tchange):
+    return np.dtype([('y_scale', '<f8'), ('start_ns', '<i8'), ('t_scale_ns', '<i8'),
+                     ('last_ds_ns', '<i8'), ('T', '<i4'), ('S', '<i4'), ('i1', '<i4'), ('NT', '<i4'),
+                     ('status', '<i4'), ('n_iter', '<i4'), ('n_theta', '<i4'), ('n_tchange', '<i4'),
+                     ('theta', '<f8', (int(n_theta),)), ('t_change', '<f8', (int(n_tchange),))])
+
+
+_REC_FIXED = 64          # bytes before theta in a record
+
+
+def _prefix(spec_dict):
+    hb = json.dumps(spec_dict, sort_keys=True).encode()
+    return MAGIC + struct.pack('<II', VERSION, len(hb)) + hb
+
+
+def dump_models(spec_dict, theta, y_scale, grid, last_ds_ns, status, n_iter):
+    """One blob per series of a fitted batch.  Layout (little endian): 'TSFM', u32 version,
+    u32 len(spec json), spec json (the constructor arguments, shared by the batch), then one
+    fixed record: y_scale, start_ns, t_scale_ns, last_ds_ns, T, S, i1, NT, status, n_iter,
+    n_theta, n_tchange, theta[n_theta], t_change[n_tchange].  grid: 1 entry (aligned batch) or
+    one per series."""
+    theta = np.atleast_2d(np.asarray(theta, dtype=np.float64))
+    N, nth = theta.shape
+    grid = np.asarray(grid)
+    ntc = int(grid['S'].max()) if len(grid) else 0
+    rec = np.zeros(N, dtype=_rec_dtype(nth, ntc))
+    rec['y_scale'] = y_scale
+    for f in ('start_ns', 't_scale_ns', 'T', 'S', 'i1', 'NT'):
+        rec[f] = grid[f]                     # broadcasts the single entry of an aligned batch
+    rec['last_ds_ns'] = last_ds_ns
+    rec['status'] = status
+    rec['n_iter'] = n_iter
+    rec['n_theta'] = nth
+    rec['n_tchange'] = ntc
+    rec['theta'] = theta
+    rec['t_change'] = grid['t_change'][:, :ntc]
+    body = rec.tobytes()
+    L = rec.dtype.itemsize
+    pre = _prefix(spec_dict)
+    return [pre + body[i * L:(i + 1) * L] for i in range(N)]
+
+
 def dump_model(spec_dict, theta, y_scale, grid_row, last_ds_ns, status, n_iter):
-    S = int(grid_row['S'])
-    head = {'spec': spec_dict, 'y_scale': float(y_scale), 'start_ns': int(grid_row['start_ns']),
-            't_scale_ns': int(grid_row['t_scale_ns']), 'T': int(grid_row['T']), 'S': S,
-            'i1': int(grid_row['i1']), 'NT': int(grid_row['NT']), 'last_ds_ns': int(last_ds_ns),
-            'status': int(status), 'n_iter': int(n_iter), 'n_theta': int(len(theta))}
-    hb = json.dumps(head, sort_keys=True).encode()
-    buf = io.BytesIO()
-    buf.write(MAGIC)
-    buf.write(struct.pack('<II', VERSION, len(hb)))
-    buf.write(hb)
-    buf.write(np.asarray(theta, dtype='<f8').tobytes())
-    buf.write(np.asarray(grid_row['t_change'][:S], dtype='<f8').tobytes())
-    return buf.getvalue()
+    g = np.zeros(1, dtype=_lib.GRID_DTYPE)
+    g[0] = grid_row
+    return dump_models(spec_dict, [theta], [y_scale], g, [last_ds_ns], [status], [n_iter])[0]
+
+
+def _split(blob):
+    b = blob if isinstance(blob, bytes) else bytes(blob)
+    if b[:4] != MAGIC:
+        raise ValueError('not a time_series_spark_amd model blob')
+    ver, hl = struct.unpack_from('<II', b, 4)
+    if ver != VERSION:
+        raise ValueError('unsupported model blob version %d' % ver)
+    return b[:12 + hl], b[12 + hl:]
+
+
+def load_models(blobs):
+    """Inverse of dump_models for a whole column: returns a list of
+    (spec_dict, positions, records) -- one entry per distinct (spec, record shape); positions
+    index into `blobs`; records is a structured array (fields as in dump_models).  None
+    entries are skipped."""
+    buckets = {}
+    for i, blob in enumerate(blobs):
+        if blob is None:
+            continue
+        pre, body = _split(blob)
+        buckets.setdefault((pre, len(body)), ([], []))
+        pos, bodies = buckets[(pre, len(body))]
+        pos.append(i)
+        bodies.append(body)
+    out = []
+    for (pre, blen), (pos, bodies) in buckets.items():
+        if blen < _REC_FIXED:
+            raise ValueError('truncated model blob')
+        nth, ntc = struct.unpack_from('<ii', bodies[0], _REC_FIXED - 8)
+        dt = _rec_dtype(nth, ntc)
+        if dt.itemsize != blen:
+            raise ValueError('model blob size does not match its header')
+        rec = np.frombuffer(b''.join(bodies), dtype=dt)
+        if (rec['n_theta'] != nth).any() or (rec['n_tchange'] != ntc).any():
+            raise ValueError('inconsistent model blobs')
+        spec = json.loads(pre[12:].decode())
+        out.append((spec, np.asarray(pos, dtype=np.int64), rec))
+    return out
 
 
 def load_model(blob):
     if blob is None:
         return None
-    b = bytes(blob)
-    if b[:4] != MAGIC:
-        raise ValueError('not a time_series_spark_amd model blob')
-    ver, hl = struct.unpack('<II', b[4:12])
-    if ver != VERSION:
-        raise ValueError('unsupported model blob version %d' % ver)
-    head = json.loads(b[12:12 + hl].decode())
-    p = 12 + hl
-    nt = head['n_theta']
-    theta = np.frombuffer(b, dtype='<f8', count=nt, offset=p).copy()
-    p += 8 * nt
-    tch = np.frombuffer(b, dtype='<f8', count=head['S'], offset=p).copy()
-    head['theta'] = theta
-    head['t_change'] = tch
+    (spec, _, rec), = load_models([blob])
+    r = rec[0]
+    head = {f: (float(r[f]) if f == 'y_scale' else int(r[f]))
+            for f in ('y_scale', 'start_ns', 't_scale_ns', 'last_ds_ns', 'T', 'S', 'i1', 'NT', 'status',
+                      'n_iter', 'n_theta')}
+    head['spec'] = spec
+    head['theta'] = r['theta'].copy()
+    head['t_change'] = r['t_change'][:head['S']].copy()
     return head
 
 
+def grid_from_records(rec):
+    g = np.zeros(len(rec), dtype=_lib.GRID_DTYPE)
+    for f in ('start_ns', 't_scale_ns', 'T', 'S', 'i1', 'NT'):
+        g[f] = rec[f]
+    ntc = rec['t_change'].shape[1]
+    g['t_change'][:, :ntc] = rec['t_change']
+    return g
+
+
 def grid_from_models(models):
-    from . import _lib
     g = np.zeros(len(models), dtype=_lib.GRID_DTYPE)
     for i, m in enumerate(models):
-        g[i]['start_ns'] = m['start_ns']
-        g[i]['t_scale_ns'] = m['t_scale_ns']
-        g[i]['T'] = m['T']
-        g[i]['S'] = m['S']
-        g[i]['i1'] = m['i1']
-        g[i]['NT'] = m['NT']
+        for f in ('start_ns', 't_scale_ns', 'T', 'S', 'i1', 'NT'):
+            g[i][f] = m[f]
         g[i]['t_change'][:m['S']] = m['t_change']
     return g
 
@@ -210,18 +332,14 @@ def future_dates(last_ds_ns, periods, freq):
     date_range(start=last_date, periods=periods+1, freq) minus entries <= last_date, first
     `periods` kept.  Returns int64 [N][periods]."""
     last_ds_ns = np.asarray(last_ds_ns, dtype=np.int64)
-    out = np.zeros((len(last_ds_ns), periods), dtype=np.int64)
-    cache = {}
-    for i, v in enumerate(last_ds_ns):
-        r = cache.get(int(v))
-        if r is None:
-            last = pd.Timestamp(int(v))
-            dates = pd.date_range(start=last, periods=periods + 1, freq=freq)
-            dates = dates[dates > last][:periods]
-            if len(dates) != periods:
-                raise ValueError('frequency %r yields %d future dates, wanted %d'
-                                 % (freq, len(dates), periods))
-            r = dates.values.astype('datetime64[ns]').astype(np.int64)
-            cache[int(v)] = r
-        out[i] = r
-    return out
+    uniq, inv = np.unique(last_ds_ns, return_inverse=True)
+    table = np.zeros((len(uniq), periods), dtype=np.int64)
+    for i, v in enumerate(uniq):
+        last = pd.Timestamp(int(v))
+        dates = pd.date_range(start=last, periods=periods + 1, freq=freq)
+        dates = dates[dates > last][:periods]
+        if len(dates) != periods:
+            raise ValueError('frequency %r yields %d future dates, wanted %d'
+                             % (freq, len(dates), periods))
+        table[i] = dates.values.astype('datetime64[ns]').astype(np.int64)
+    return table[inv.reshape(-1)]
