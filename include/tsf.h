@@ -236,6 +236,28 @@ int tsf_pack_fetch(tsf_pack *p, int64_t *key_series_id, int64_t *key_dim_id, int
                    int64_t *ds_out, double *y_out, int64_t *span, int64_t *min_dt, double *y_max);
 void tsf_pack_free(tsf_pack *p);
 
+/* ---- model-input reader (host side, no device work, no tsf_ctx) ---------------------------
+ * Replaces ProphetModeler.read_input_dataframe's
+ *   spark.read.csv(path, header=False, schema=MODEL_INPUT_SCHEMA)
+ *   /root/reference/src/jobs/prophet_modeler.py:102-116 (schema :12-17)
+ * for header-less CSV files, parsed in parallel straight into the columns tsf_pack_rows takes.
+ *   layout      one letter per column of the FILES: 's' series_id, 'd' dim_id, 't' start_time,
+ *               'q' quantity, 'x' ignored.  Hive-partitioned input (series_id=751/...csv) has
+ *               layout "dtq" and the partition value in series_id[file].
+ *   start_time  yyyy-MM-dd[( |T)HH:mm[:ss[.fffffffff]]][Z], taken as naive wall time
+ *   quantity    integer (the reference's schema) or decimal; an empty field is a null and
+ *               comes out as NaN (the packer drops it as fbprophet drops y.isnull() rows)
+ *   rows come out in file order, files in the order given.
+ * Returns 0; TSF_CSV_E_OPEN / TSF_CSV_E_PARSE with *err_file (index into paths) and *err_line
+ * (1-based) set; -1 bad arguments, -2 out of memory, -3 other failure. */
+enum { TSF_CSV_E_OPEN = -10, TSF_CSV_E_PARSE = -11 };
+typedef struct tsf_csv tsf_csv;
+int tsf_csv_read(int32_t n_files, const char *const *paths, const int64_t *series_id,
+                 const char *layout, int32_t n_threads, tsf_csv **out, int64_t *n_rows,
+                 int32_t *err_file, int64_t *err_line);
+int tsf_csv_fetch(tsf_csv *t, int64_t *series_id, int64_t *dim_id, int64_t *ds, double *y);
+void tsf_csv_free(tsf_csv *t);
+
 #ifdef __cplusplus
 }
 #endif

@@ -244,3 +244,107 @@ def test_native_packer_matches_numpy_order_contract(case):
         assert np.array_equal(span, s2) and np.array_equal(min_dt, m2) and np.array_equal(ymax, y2)
     if case == 'packed':
         assert p.ds_ns is ds or np.shares_memory(p.ds_ns, ds)               # no copy made
+
+
+def test_native_csv_reader_matches_pandas(tmp_path):
+    """tsf_csv_read (the Spark CSV reader's stand-in, prophet_modeler.py:102-116) against
+    pandas.read_csv on the same files: partition directories, timestamp spellings, nulls."""
+    rng = np.random.default_rng(5)
+    root = tmp_path / 'in'
+    want = []
+    spell = ['%Y-%m-%d %H:%M:%S', '%Y-%m-%dT%H:%M:%S', '%Y-%m-%d %H:%M:%S.%f', '%Y-%m-%d', '%Y-%m-%d %H:%M']
+    for k, sid in enumerate([751, 3, -4, 2000000000]):
+        d = root / ('series_id=%d' % sid)
+        d.mkdir(parents=True)
+        n = 50 + 7 * k
+        ts = pd.to_datetime('1969-06-01') + pd.to_timedelta(rng.integers(0, 40000, n) * 3600 + k, unit='s')
+        if spell[k] == '%Y-%m-%d':
+            ts = ts.normalize()
+        if spell[k] == '%Y-%m-%d %H:%M':
+            ts = ts.floor('min')
+        if 'f' in spell[k]:
+            ts = ts + pd.to_timedelta(rng.integers(0, 10 ** 6, n), unit='us')
+        did = rng.integers(1, 4, n)
+        q = rng.integers(-5, 10 ** 6, n).astype(float)
+        if k == 1:
+            q[::9] = np.nan                                  # null quantity
+        lines = ['%d,%s,%s' % (a, b, '' if np.isnan(c) else '%d' % c)
+                 for a, b, c in zip(did, ts.strftime(spell[k]), q)]
+        eol = '\r\n' if k == 2 else '\n'
+        text = eol.join(lines) + (eol if k != 3 else '') + (eol if k == 0 else '')   # blank line / no EOL at EOF
+        (d / 'part-0.csv').write_bytes(text.encode())
+        want.append(pd.DataFrame({'series_id': sid, 'dim_id': did, 'ds': ts.values, 'y': q}))
+    want = pd.concat(want, ignore_index=True)
+    files = sorted(str(p) for p in root.rglob('*.csv'))
+    order = [int(f.split('series_id=')[1].split('/')[0]) for f in files]
+    want = pd.concat([want[want.series_id == s] for s in order], ignore_index=True)
+    for nt in (1, 3):
+        sid, did, ds_ns, y = pm.read_model_input(files, str(root), n_threads=nt)
+        assert np.array_equal(sid, want.series_id.values) and np.array_equal(did, want.dim_id.values)
+        assert np.array_equal(ds_ns, want.ds.values.astype('datetime64[ns]').astype(np.int64))
+        assert np.array_equal(y, want.y.values, equal_nan=True)
+    # and the same bytes through pandas
+    for f, s in zip(files, order):
+        ref = pd.read_csv(f, header=None, names=['dim_id', 'ds', 'y'])
+        got = pm.read_model_input([f], str(root))
+        assert np.array_equal(got[2], pk.ds_to_ns(pd.to_datetime(ref['ds'])))
+        assert np.array_equal(got[3], ref['y'].values.astype(float), equal_nan=True)
+    # a file outside any partition directory carries series_id itself
+    flat = tmp_path / 'flat.csv'
+    flat.write_text('7,1,2020-02-29 00:00:00,5\n7,1,"2020-03-01 12:30:00", 6 \n')
+    sid, did, ds_ns, y = pm.read_model_input([str(flat)], str(flat))
+    assert list(sid) == [7, 7] and list(y) == [5, 6]
+    assert ds_ns[1] == pd.Timestamp('2020-03-01 12:30:00').value
+    df = pm.ProphetModeler({'io': {'input': str(flat)}}).read_input_dataframe()
+    assert str(df['y'].dtype) == 'int32' and len(df) == 2
+    # nulls survive as NaN (fbprophet drops them at fit time); the frame keeps them
+    df = pm.ProphetModeler({'io': {'input': str(root)}}).read_input_dataframe()
+    assert df['y'].isna().sum() == np.isnan(want.y.values).sum() and len(df) == len(want)
+    # errors name the file and the line
+    bad = tmp_path / 'bad' / 'series_id=1'
+    bad.mkdir(parents=True)
+    (bad / 'x.csv').write_text('1,2020-01-01 00:00:00,5\n1,2020-02-30 00:00:00,5\n')
+    with pytest.raises(ValueError, match='line 2'):
+        pm.read_model_input([str(bad / 'x.csv')], str(tmp_path / 'bad'))
+    (bad / 'y.csv').write_text('1,2020-01-01 00:00:00\n')
+    with pytest.raises(ValueError, match='line 1'):
+        pm.read_model_input([str(bad / 'y.csv')], str(tmp_path / 'bad'))
+    with pytest.raises(OSError):
+        pm.read_model_input([str(bad / 'missing.csv')], str(tmp_path / 'bad'))
+
+
+def test_write_forecasts_csv_and_model_parquet_round_trip(tmp_path):
+    # prophet_scorer.py:147-150 (CSV with header) and prophet_modeler.py:118-125 / scorer :123-128
+    cfg = {'io': {'forecasts': str(tmp_path / 'fc'), 'models': str(tmp_path / 'models')}}
+    fdf = pd.DataFrame({'series_id': np.array([5, 5, 9], dtype='int32'), 'dim_id': np.array([1, 1, 2], dtype='int32'),
+                        'ds': pd.to_datetime(['2002-12-28 22:00:00', '2002-12-28 22:15:00', '1969-12-31 23:59:59.5'], format='ISO8601'),
+                        'yhat': np.array([10, -3, 7], dtype='int32')})
+    sc = ps.ProphetScorer(cfg)
+    conv = sc.convert_forecasts(fdf)
+    assert list(conv['forecast_date']) == ['2002-12-28', '2002-12-28', '1969-12-31']
+    sc.write_forecasts(conv)
+    sc.write_forecasts(conv)                                   # overwrite, not append
+    lines = open(tmp_path / 'fc' / 'part-00000.csv').read().splitlines()
+    assert lines[0] == 'created_timestamp,series_id,dim_id,forecast_date,forecast_timestamp,forecast_quantity'
+    assert len(lines) == 4
+    f = lines[2].split(',')
+    assert f[1:] == ['5', '1', '2002-12-28', '2002-12-28T22:15:00.000Z', '-3']
+    assert lines[3].split(',')[4] == '1969-12-31T23:59:59.500Z'
+    back = pd.read_csv(tmp_path / 'fc' / 'part-00000.csv')
+    assert np.array_equal(back['forecast_quantity'].values, [10, -3, 7])
+    # models: blobs survive parquet, floor/cap become float32 (prophet_modeler.py:35-36)
+    spec = fc.ModelSpec(seasonalities=[dict(helpers.WEEKLY)])
+    grid = np.zeros(1, dtype=_lib.GRID_DTYPE); grid['S'] = 3; grid['T'] = 50; grid['t_change'][0, :3] = [.2, .4, .6]
+    blobs = pk.dump_models(spec.to_dict(), np.arange(2 * spec.theta_stride, dtype=float).reshape(2, -1),
+                           [2.0, 3.0], grid, [100, 200], [31, 32], [7, 8])
+    mdf = pd.DataFrame({'series_id': [1, 2], 'dim_id': [1, 1], 'floor': [0, 0], 'cap': [1.1, 16777217.0],
+                        'model': blobs})
+    mo = pm.ProphetModeler(cfg)
+    mo.persist_models(mdf)
+    got = sc.read_model_dataframe()
+    assert str(got['cap'].dtype) == 'float32' and got['cap'][1] == np.float32(16777217.0)
+    (sd, pos, rec), = pk.load_models(list(got['model']) + [None])
+    assert list(pos) == [0, 1] and list(rec['y_scale']) == [2.0, 3.0] and list(rec['last_ds_ns']) == [100, 200]
+    assert list(rec['status']) == [31, 32] and rec['theta'][1, -1] == 2 * spec.theta_stride - 1
+    assert np.array_equal(pk.grid_from_records(rec)['t_change'][:, :3], [[.2, .4, .6]] * 2)
+    assert sd == spec.to_dict()

@@ -75,7 +75,10 @@ EXPORTS = ['tsf_create', 'tsf_destroy', 'tsf_last_error', 'tsf_device_count', 't
            'tsf_fit_aligned', 'tsf_fit_aligned_dev', 'tsf_fit_ragged', 'tsf_fit_ragged_dev',
            'tsf_predict', 'tsf_predict_dev', 'tsf_eval', 'tsf_design', 'tsf_selftest_math',
            'tsf_set_profiling', 'tsf_profile_read', 'tsf_last_fit_kernel_ms',
-           'tsf_pack_rows', 'tsf_pack_fetch', 'tsf_pack_free']
+           'tsf_pack_rows', 'tsf_pack_fetch', 'tsf_pack_free',
+           'tsf_csv_read', 'tsf_csv_fetch', 'tsf_csv_free']
+
+CSV_E_OPEN, CSV_E_PARSE = -10, -11          # TSF_CSV_E_* (include/tsf.h)
 
 _lib = None
 
@@ -127,6 +130,12 @@ def load():
     L.tsf_pack_fetch.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.tsf_pack_free.argtypes = [vp]
     L.tsf_pack_free.restype = None
+    L.tsf_csv_read.argtypes = [i32, ctypes.POINTER(ctypes.c_char_p), vp, ctypes.c_char_p, i32,
+                               ctypes.POINTER(vp), ctypes.POINTER(i64), ctypes.POINTER(i32),
+                               ctypes.POINTER(i64)]
+    L.tsf_csv_fetch.argtypes = [vp, vp, vp, vp, vp]
+    L.tsf_csv_free.argtypes = [vp]
+    L.tsf_csv_free.restype = None
     if L.tsf_spec_size() != ctypes.sizeof(TsfSpec):
         raise TsfError('tsf_spec layout mismatch between _lib.py and libtsf_amd.so')
     if L.tsf_grid_info_size() != ctypes.sizeof(TsfGridInfo) or GRID_DTYPE.itemsize != ctypes.sizeof(TsfGridInfo):

@@ -1,0 +1,338 @@
+// Native reader for the model-input files behind tsf_csv_read / tsf_csv_fetch / tsf_csv_free
+// (include/tsf.h).
+//
+// What it replaces in the reference: ProphetModeler.read_input_dataframe
+//   spark.read.csv(path, header=False, schema=MODEL_INPUT_SCHEMA)
+//   /root/reference/src/jobs/prophet_modeler.py:102-116 (schema :12-17)
+// over a directory of header-less CSV files, Hive-partitioned by series_id
+// (tests/fixtures/model-input/series_id=751/sample-model-input.csv: `91,2001-01-05 11:15:00,36445`).
+// The JVM reader hands Spark rows; this one parses straight into the four columns the packer
+// (tsf_pack_rows) takes: series_id, dim_id, ds [ns since the epoch], y [f64, NaN = null].
+// Files are parsed in parallel (one file at a time per thread) and come out in the order given.
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/tsf.h"
+
+namespace {
+
+struct FileCols {
+    std::vector<int64_t> sid, did, ds;
+    std::vector<double> y;
+    int err = 0;            // TSF_CSV_* code
+    int64_t err_line = 0;   // 1-based
+};
+
+// days from 1970-01-01 of a proleptic Gregorian date (valid for all int years)
+inline int64_t days_from_civil(int64_t y, unsigned m, unsigned d) {
+    y -= m <= 2;
+    const int64_t era = (y >= 0 ? y : y - 399) / 400;
+    const unsigned yoe = (unsigned)(y - era * 400);
+    const unsigned doy = (153 * (m + (m > 2 ? -3 : 9)) + 2) / 5 + d - 1;
+    const unsigned doe = yoe * 365 + yoe / 4 - yoe / 100 + doy;
+    return era * 146097 + (int64_t)doe - 719468;
+}
+
+inline bool digits(const char *p, int n, int64_t *out) {
+    int64_t v = 0;
+    for (int i = 0; i < n; ++i) {
+        unsigned c = (unsigned)(p[i] - '0');
+        if (c > 9) return false;
+        v = v * 10 + c;
+    }
+    *out = v;
+    return true;
+}
+
+// [a, b) trimmed of blanks and one pair of double quotes
+inline void trim(const char *&a, const char *&b) {
+    while (a < b && (*a == ' ' || *a == '\t')) ++a;
+    while (b > a && (b[-1] == ' ' || b[-1] == '\t' || b[-1] == '\r')) --b;
+    if (b - a >= 2 && *a == '"' && b[-1] == '"') {
+        ++a;
+        --b;
+    }
+}
+
+// yyyy-MM-dd[( |T)HH:mm[:ss[.fffffffff]]][Z]  -> ns since the epoch (naive / UTC)
+bool parse_timestamp(const char *a, const char *b, int64_t *out) {
+    trim(a, b);
+    if (b - a < 10) return false;
+    int64_t Y, M, D, h = 0, mi = 0, s = 0, frac = 0;
+    if (!digits(a, 4, &Y) || a[4] != '-' || !digits(a + 5, 2, &M) || a[7] != '-' || !digits(a + 8, 2, &D))
+        return false;
+    if (M < 1 || M > 12 || D < 1 || D > 31) return false;
+    const char *p = a + 10;
+    if (p < b) {
+        if (*p != ' ' && *p != 'T') return false;
+        ++p;
+        if (b - p < 5 || !digits(p, 2, &h) || p[2] != ':' || !digits(p + 3, 2, &mi)) return false;
+        p += 5;
+        if (p < b && *p == ':') {
+            if (b - p < 3 || !digits(p + 1, 2, &s)) return false;
+            p += 3;
+            if (p < b && *p == '.') {
+                ++p;
+                int nd = 0;
+                while (p < b && (unsigned)(*p - '0') <= 9) {
+                    if (nd < 9) {
+                        frac = frac * 10 + (*p - '0');
+                        ++nd;
+                    }
+                    ++p;
+                }
+                if (nd == 0) return false;
+                for (; nd < 9; ++nd) frac *= 10;
+            }
+        }
+        if (p < b && *p == 'Z') ++p;
+        if (p != b) return false;
+        if (h > 23 || mi > 59 || s > 59) return false;
+    }
+    static const int mdays[12] = {31, 29, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31};
+    if (D > mdays[M - 1]) return false;
+    if (M == 2 && D == 29 && !((Y % 4 == 0 && Y % 100 != 0) || Y % 400 == 0)) return false;
+    int64_t days = days_from_civil(Y, (unsigned)M, (unsigned)D);
+    *out = ((days * 24 + h) * 60 + mi) * 60 * 1000000000ll + s * 1000000000ll + frac;
+    return true;
+}
+
+bool parse_int(const char *a, const char *b, int64_t *out) {
+    trim(a, b);
+    if (a >= b) return false;
+    bool neg = false;
+    if (*a == '-' || *a == '+') {
+        neg = *a == '-';
+        ++a;
+    }
+    if (a >= b || b - a > 18) return false;
+    int64_t v = 0;
+    for (; a < b; ++a) {
+        unsigned c = (unsigned)(*a - '0');
+        if (c > 9) return false;
+        v = v * 10 + c;
+    }
+    *out = neg ? -v : v;
+    return true;
+}
+
+// quantity: integer in the reference schema; decimals are accepted too.  Empty = null.
+bool parse_quantity(const char *a, const char *b, double *out) {
+    trim(a, b);
+    if (a >= b) {
+        *out = std::numeric_limits<double>::quiet_NaN();
+        return true;
+    }
+    int64_t iv;
+    if (parse_int(a, b, &iv)) {
+        *out = (double)iv;
+        return true;
+    }
+    std::string tmp(a, b);
+    char *end = nullptr;
+    double v = std::strtod(tmp.c_str(), &end);
+    if (end == tmp.c_str() || *end != '\0' || std::isinf(v)) return false;
+    *out = v;
+    return true;
+}
+
+// layout: one letter per column of the file: s series_id, d dim_id, t start_time, q quantity,
+// x ignored
+void parse_file(const char *path, const char *layout, int ncol, bool has_sid, int64_t sid_const,
+                FileCols &out) {
+    FILE *f = std::fopen(path, "rb");
+    if (!f) {
+        out.err = TSF_CSV_E_OPEN;
+        return;
+    }
+    std::fseek(f, 0, SEEK_END);
+    long sz = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    std::vector<char> buf((size_t)(sz > 0 ? sz : 0) + 1);
+    size_t got = sz > 0 ? std::fread(buf.data(), 1, (size_t)sz, f) : 0;
+    std::fclose(f);
+    if ((long)got != (sz > 0 ? sz : 0)) {
+        out.err = TSF_CSV_E_OPEN;
+        return;
+    }
+    const char *p = buf.data(), *end = p + got;
+    size_t guess = got / 24 + 1;
+    out.did.reserve(guess);
+    out.ds.reserve(guess);
+    out.y.reserve(guess);
+    out.sid.reserve(guess);
+    int64_t line = 0;
+    while (p < end) {
+        const char *eol = (const char *)std::memchr(p, '\n', (size_t)(end - p));
+        if (!eol) eol = end;
+        ++line;
+        const char *le = eol;
+        while (le > p && (le[-1] == '\r' || le[-1] == ' ')) --le;
+        if (le == p) {              // blank line
+            p = eol + 1;
+            continue;
+        }
+        int64_t sid = sid_const, did = 0, ds = 0;
+        double q = 0;
+        const char *fa = p;
+        int col = 0;
+        bool ok = true;
+        for (; col < ncol && ok; ++col) {
+            const char *fb = (col == ncol - 1) ? le : (const char *)std::memchr(fa, ',', (size_t)(le - fa));
+            if (!fb) {
+                ok = false;
+                break;
+            }
+            switch (layout[col]) {
+                case 's': ok = parse_int(fa, fb, &sid); break;
+                case 'd': ok = parse_int(fa, fb, &did); break;
+                case 't': ok = parse_timestamp(fa, fb, &ds); break;
+                case 'q': ok = parse_quantity(fa, fb, &q); break;
+                default: break;
+            }
+            fa = fb + 1;
+        }
+        if (!ok || col != ncol) {
+            out.err = TSF_CSV_E_PARSE;
+            out.err_line = line;
+            return;
+        }
+        out.sid.push_back(sid);
+        out.did.push_back(did);
+        out.ds.push_back(ds);
+        out.y.push_back(q);
+        p = eol + 1;
+    }
+    (void)has_sid;
+}
+
+}  // namespace
+
+struct tsf_csv {
+    std::vector<FileCols> files;
+    std::vector<int64_t> first;     // row offset of each file
+    int64_t n_rows = 0;
+    int n_threads = 1;
+};
+
+extern "C" {
+
+int tsf_csv_read(int32_t n_files, const char *const *paths, const int64_t *series_id,
+                 const char *layout, int32_t n_threads, tsf_csv **out, int64_t *n_rows,
+                 int32_t *err_file, int64_t *err_line) {
+    if (!out || n_files < 0 || (n_files > 0 && !paths) || !layout) return -1;
+    *out = nullptr;
+    int ncol = (int)std::strlen(layout);
+    bool has_s = false, has_d = false, has_t = false, has_q = false;
+    for (int i = 0; i < ncol; ++i) {
+        char c = layout[i];
+        if (c == 's') has_s = true;
+        else if (c == 'd') has_d = true;
+        else if (c == 't') has_t = true;
+        else if (c == 'q') has_q = true;
+        else if (c != 'x') return -1;
+    }
+    if (!has_d || !has_t || !has_q || ncol < 3 || ncol > 16) return -1;
+    if (!has_s && !series_id && n_files > 0) return -1;
+    tsf_csv *t = nullptr;
+    try {
+        t = new tsf_csv();
+        t->files.resize((size_t)n_files);
+        int hw = (int)std::thread::hardware_concurrency();
+        if (hw < 1) hw = 1;
+        t->n_threads = n_threads > 0 ? n_threads : (hw < 32 ? hw : 32);
+        std::atomic<int32_t> next(0);
+        std::atomic<int> oom(0);
+        auto worker = [&]() {
+            for (;;) {
+                int32_t i = next.fetch_add(1);
+                if (i >= n_files) break;
+                try {
+                    parse_file(paths[i], layout, ncol, has_s, series_id ? series_id[i] : 0,
+                               t->files[(size_t)i]);
+                } catch (...) {
+                    oom.store(1);
+                }
+            }
+        };
+        if (t->n_threads <= 1 || n_files < 2) {
+            worker();
+        } else {
+            std::vector<std::thread> th;
+            int k = t->n_threads < n_files ? t->n_threads : n_files;
+            for (int i = 0; i < k; ++i) th.emplace_back(worker);
+            for (auto &x : th) x.join();
+        }
+        if (oom.load()) {
+            delete t;
+            return -2;
+        }
+        t->first.resize((size_t)n_files + 1);
+        int64_t pos = 0;
+        for (int32_t i = 0; i < n_files; ++i) {
+            const FileCols &fc = t->files[(size_t)i];
+            if (fc.err) {
+                if (err_file) *err_file = i;
+                if (err_line) *err_line = fc.err_line;
+                int e = fc.err;
+                delete t;
+                return e;
+            }
+            t->first[(size_t)i] = pos;
+            pos += (int64_t)fc.ds.size();
+        }
+        t->first[(size_t)n_files] = pos;
+        t->n_rows = pos;
+    } catch (const std::bad_alloc &) {
+        delete t;
+        return -2;
+    } catch (...) {
+        delete t;
+        return -3;
+    }
+    *out = t;
+    if (n_rows) *n_rows = t->n_rows;
+    return 0;
+}
+
+int tsf_csv_fetch(tsf_csv *t, int64_t *series_id, int64_t *dim_id, int64_t *ds, double *y) {
+    if (!t) return -1;
+    const int32_t nf = (int32_t)t->files.size();
+    std::atomic<int32_t> next(0);
+    auto worker = [&]() {
+        for (;;) {
+            int32_t i = next.fetch_add(1);
+            if (i >= nf) break;
+            const FileCols &fc = t->files[(size_t)i];
+            size_t n = fc.ds.size();
+            int64_t at = t->first[(size_t)i];
+            if (!n) continue;
+            if (series_id) std::memcpy(series_id + at, fc.sid.data(), n * sizeof(int64_t));
+            if (dim_id) std::memcpy(dim_id + at, fc.did.data(), n * sizeof(int64_t));
+            if (ds) std::memcpy(ds + at, fc.ds.data(), n * sizeof(int64_t));
+            if (y) std::memcpy(y + at, fc.y.data(), n * sizeof(double));
+        }
+    };
+    if (t->n_threads <= 1 || nf < 2) {
+        worker();
+    } else {
+        std::vector<std::thread> th;
+        int k = t->n_threads < nf ? t->n_threads : nf;
+        for (int i = 0; i < k; ++i) th.emplace_back(worker);
+        for (auto &x : th) x.join();
+    }
+    return 0;
+}
+
+void tsf_csv_free(tsf_csv *t) { delete t; }
+
+}  // extern "C"

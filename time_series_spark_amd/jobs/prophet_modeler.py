@@ -195,6 +195,58 @@ def as_pandas_udf(fn, columns=MODEL_OUTPUT_COLUMNS):
     return pandas_udf(schema, PandasUDFType.GROUPED_MAP)(fn)
 
 
+def read_model_input(files, root, n_threads=0):
+    """Parse model-input CSV files into (series_id, dim_id, ds_ns, y) arrays (int64, int64,
+    int64 ns, float64 with NaN for nulls).  A `series_id=<v>` directory between `root` and the
+    file supplies series_id for that file (Spark's partition discovery); the file then holds
+    the remaining MODEL_INPUT_SCHEMA columns in order."""
+    import ctypes
+    L = _lib.load()
+    if not files:
+        z = np.zeros(0, np.int64)
+        return z, z.copy(), z.copy(), np.zeros(0)
+    part_sid = []
+    for f in files:
+        v = None
+        rel = os.path.relpath(os.path.dirname(os.path.abspath(f)),
+                              os.path.abspath(root if os.path.isdir(root) else os.path.dirname(root)))
+        for seg in rel.split(os.sep):
+            if seg.startswith('series_id='):
+                v = int(seg.split('=', 1)[1])
+        part_sid.append(v)
+    out = []
+    # files under a partition directory hold 3 columns, the others all 4
+    for layout, pick in ((b'dtq', [i for i, v in enumerate(part_sid) if v is not None]),
+                         (b'sdtq', [i for i, v in enumerate(part_sid) if v is None])):
+        if not pick:
+            continue
+        paths = (ctypes.c_char_p * len(pick))(*[os.fsencode(files[i]) for i in pick])
+        sids = np.array([part_sid[i] if part_sid[i] is not None else 0 for i in pick], dtype=np.int64)
+        h, n_rows = ctypes.c_void_p(), ctypes.c_int64()
+        ef, el = ctypes.c_int32(-1), ctypes.c_int64(0)
+        rc = L.tsf_csv_read(len(pick), paths, sids.ctypes.data, layout, int(n_threads), ctypes.byref(h),
+                            ctypes.byref(n_rows), ctypes.byref(ef), ctypes.byref(el))
+        if rc == _lib.CSV_E_OPEN:
+            raise OSError('cannot read %s' % files[pick[ef.value]])
+        if rc == _lib.CSV_E_PARSE:
+            raise ValueError('%s line %d does not match the model-input schema %s'
+                             % (files[pick[ef.value]], el.value, layout.decode()))
+        if rc != 0:
+            raise _lib.TsfError('tsf_csv_read failed (%d)' % rc)
+        try:
+            n = n_rows.value
+            cols = (np.empty(n, np.int64), np.empty(n, np.int64), np.empty(n, np.int64), np.empty(n))
+            rc = L.tsf_csv_fetch(h, *[c.ctypes.data for c in cols])
+            if rc != 0:
+                raise _lib.TsfError('tsf_csv_fetch failed (%d)' % rc)
+        finally:
+            L.tsf_csv_free(h)
+        out.append(cols)
+    if len(out) == 1:
+        return out[0]
+    return tuple(np.concatenate([o[k] for o in out]) for k in range(4))
+
+
 class ProphetModeler:
     """Create models to forecast quantities (prophet_modeler.py:90-143), Spark-free: the frames
     are pandas, the IO is pyarrow/pandas, the fit is one batched GPU call."""
@@ -206,32 +258,24 @@ class ProphetModeler:
     def read_input_dataframe(self, spark=None):
         """Header-less CSV files under config['io']['input'], Hive-style partition directories
         (`series_id=751/…csv` supplies the series_id column), schema MODEL_INPUT_SCHEMA;
-        renames start_time -> ds, quantity -> y (:109-114)."""
+        renames start_time -> ds, quantity -> y (:109-114).  The files are parsed by the native
+        reader (tsf_csv_read, include/tsf.h), in parallel, straight into columns."""
         root = self.config['io']['input']
         files = sorted(glob.glob(os.path.join(root, '**', '*.csv'), recursive=True))
         if os.path.isfile(root):
             files = [root]
-        frames = []
-        for f in files:
-            parts = {}
-            for seg in os.path.relpath(os.path.dirname(f), root).split(os.sep):
-                if '=' in seg:
-                    k, v = seg.split('=', 1)
-                    parts[k] = v
-            names = [n for n, _ in MODEL_INPUT_SCHEMA if n not in parts]
-            df = pd.read_csv(f, header=None, names=names)
-            for k, v in parts.items():
-                df[k] = v
-            frames.append(df)
-        if not frames:
-            return pd.DataFrame(columns=['series_id', 'dim_id', 'ds', 'y'])
-        df = pd.concat(frames, ignore_index=True)
-        df['series_id'] = pd.to_numeric(df['series_id']).astype('int32')
-        df['dim_id'] = pd.to_numeric(df['dim_id']).astype('int32')
-        df['start_time'] = pd.to_datetime(df['start_time'])
-        df['quantity'] = pd.to_numeric(df['quantity']).astype('int32')
-        df = df[['series_id', 'dim_id', 'start_time', 'quantity']]
-        return df.rename(columns={'start_time': 'ds', 'quantity': 'y'})
+        sid, did, ds_ns, y = read_model_input(files, root)
+        for name, col in (('series_id', sid), ('dim_id', did)):
+            if len(col) and (col.min() < -2 ** 31 or col.max() >= 2 ** 31):
+                raise ValueError('%s does not fit the int32 column of MODEL_INPUT_SCHEMA' % name)
+        yq = y
+        if not np.isnan(y).any():
+            if len(y) and ((y != np.rint(y)).any() or np.abs(y).max() >= 2 ** 31):
+                raise ValueError('quantity is not an int32 column (MODEL_INPUT_SCHEMA)')
+            yq = y.astype('int32')                       # nulls keep the column float64
+        return pd.DataFrame({'series_id': sid.astype('int32'), 'dim_id': did.astype('int32'),
+                             'ds': ds_ns.astype('datetime64[ns]'), 'y': yq},
+                            columns=['series_id', 'dim_id', 'ds', 'y'])
 
     def persist_models(self, model_df):
         """Parquet, mode='overwrite' (:123-125)."""

@@ -118,14 +118,36 @@ class ProphetScorer:
         return out
 
     def write_forecasts(self, output_df):
-        """CSV with header, mode='overwrite' (:148-150)."""
+        """CSV with header, mode='overwrite' (:148-150).  Timestamps are written the way
+        Spark 2.4's CSV writer does by default (timestampFormat yyyy-MM-dd'T'HH:mm:ss.SSSXXX)
+        with the wall times taken as UTC: 2002-12-28T22:00:00.000Z."""
         import shutil
+        import pyarrow as pa
+        import pyarrow.csv as pacsv
         path = self.config['io']['forecasts']
         if os.path.isdir(path):
             shutil.rmtree(path)
         os.makedirs(path, exist_ok=True)
-        output_df.to_csv(os.path.join(path, 'part-00000.csv'), index=False,
-                         date_format='%Y-%m-%dT%H:%M:%S.%f')
+        def text_column(codes, values):
+            # few distinct strings, many rows: decode a dictionary inside arrow
+            d = pa.DictionaryArray.from_arrays(pa.array(codes.astype(np.int32)), pa.array(values, type=pa.string()))
+            return d.cast(pa.string())
+
+        cols = {}
+        for c in output_df.columns:
+            v = output_df[c].values
+            if np.issubdtype(v.dtype, np.datetime64):
+                u, inv = np.unique(v.astype('datetime64[ns]'), return_inverse=True)
+                cols[c] = text_column(inv.reshape(-1), [t + 'Z' for t in np.datetime_as_string(u, unit='ms')])
+            elif v.dtype == object:
+                codes, uniq = pd.factorize(v)
+                cols[c] = text_column(codes, [str(x) for x in uniq])
+            else:
+                cols[c] = pa.array(v)
+        with open(os.path.join(path, 'part-00000.csv'), 'wb') as f:
+            f.write((','.join(output_df.columns) + '\n').encode())
+            pacsv.write_csv(pa.table(cols), f,
+                            write_options=pacsv.WriteOptions(include_header=False, quoting_style='none'))
 
     @staticmethod
     def score(spark_session, config):
