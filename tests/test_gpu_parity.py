@@ -225,6 +225,35 @@ def test_ragged_and_aligned_entry_points_agree_bit_for_bit(env):
             assert n_bit_diff(rr.theta[i][:3 + S], o['theta'][:3 + S]) == 0
 
 
+def test_one_host_thread_per_device_gives_identical_bits(env, monkeypatch):
+    """SURVEY 8e, in-process arrangement: a call cut into blocks of series, one tsf_ctx + host
+    thread per device (here: three contexts on the one GPU the box has), equals the
+    single-context call bit for bit -- aligned, ragged and predict."""
+    fc, cl = env
+    monkeypatch.setattr(fc, 'MIN_SERIES_PER_DEVICE', 4)
+    for case in ('cfg2_linear_additive', 'ref_logistic_multiplicative'):
+        spec, ds, y, floor, cap, extra, fut, exf = helpers.make_case(case, N=26)
+        one = fc.fit_aligned(spec, ds, y, floor=floor, cap=cap, extra=extra)
+        many = fc.fit_aligned(spec, ds, y, floor=floor, cap=cap, extra=extra, devices=[0, 0, 0])
+        for k in ('theta', 'y_scale', 'fval', 'status', 'n_iter', 'n_eval'):
+            assert np.array_equal(getattr(one, k), getattr(many, k)), (case, k)
+        assert len(many.grid) == 1 and many.grid.tobytes() == one.grid.tobytes()
+        T = len(ds)
+        cut = np.array([T - 7 * (i % 5) for i in range(len(y))])
+        off = np.concatenate([[0], np.cumsum(cut)]).astype(np.int64)
+        dsr = np.concatenate([ds[:c] for c in cut])
+        yr = np.concatenate([y[i][:c] for i, c in enumerate(cut)])
+        r1 = fc.fit_ragged(spec, off, dsr, yr, floor=floor, cap=cap)
+        r3 = fc.fit_ragged(spec, off, dsr, yr, floor=floor, cap=cap, devices='0,0,0')
+        for k in ('theta', 'y_scale', 'fval', 'status', 'n_iter', 'n_eval'):
+            assert np.array_equal(getattr(r1, k), getattr(r3, k)), (case, k)
+        assert r3.grid.tobytes() == r1.grid.tobytes()
+        p1 = fc.predict(spec, r1.theta, r1.y_scale, r1.grid, fut, floor=floor, cap=cap, want_int=True)
+        p3 = fc.predict(spec, r1.theta, r1.y_scale, r1.grid, fut, floor=floor, cap=cap, want_int=True,
+                        devices=[0, 0, 0])
+        assert np.array_equal(p1[0], p3[0]) and np.array_equal(p1[1], p3[1])
+
+
 def test_batched_job_is_independent_of_how_series_are_grouped(env):
     """model_panel groups series that share a timestamp vector (aligned kernel path) and fits the
     rest through the ragged entry point; each series' model must be byte-identical to the one

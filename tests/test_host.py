@@ -348,3 +348,18 @@ def test_write_forecasts_csv_and_model_parquet_round_trip(tmp_path):
     assert list(rec['status']) == [31, 32] and rec['theta'][1, -1] == 2 * spec.theta_stride - 1
     assert np.array_equal(pk.grid_from_records(rec)['t_change'][:, :3], [[.2, .4, .6]] * 2)
     assert sd == spec.to_dict()
+
+
+def test_device_list_and_block_cuts(monkeypatch):
+    monkeypatch.delenv('TSF_DEVICES', raising=False)
+    assert fc.resolve_devices(None) is None and fc.resolve_devices([2]) is None
+    assert fc.resolve_devices('0, 1,3') == [0, 1, 3] and fc.resolve_devices([0, 0]) == [0, 0]
+    monkeypatch.setenv('TSF_DEVICES', '4,5')
+    assert fc.resolve_devices(None) == [4, 5]
+    assert list(fc._cuts(np.ones(10, int), 4)) == [0, 3, 5, 8, 10]
+    c = fc._cuts(np.array([5, 5, 5, 5, 100, 5, 5, 5]), 3)      # one long series: a block may be empty
+    assert c[0] == 0 and c[-1] == 8 and (np.diff(c) >= 0).all()
+    rows = np.random.default_rng(0).integers(2, 900, 5000)
+    c = fc._cuts(rows, 8)
+    per = np.add.reduceat(rows, c[:-1])
+    assert per.max() - per.min() <= 2 * rows.max()

@@ -7,6 +7,7 @@ fbprophet 0.5's ``Prophet.__init__`` / ``set_auto_seasonalities`` (spec in SURVE
 U1-U5); the arithmetic runs in libtsf_amd.so on the GPU -- this module only packs arrays.
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -172,12 +173,73 @@ class FitResult(object):
 _ctx_cache = {}
 
 
-def get_context(device=0):
-    c = _ctx_cache.get(device)
+def get_context(device=0, slot=0):
+    """Cached tsf_ctx for a GPU.  `slot` distinguishes several contexts on one device (each
+    context is single-threaded; the multi-device path gives every worker thread its own)."""
+    c = _ctx_cache.get((device, slot))
     if c is None:
         c = _lib.Context(device)
-        _ctx_cache[device] = c
+        _ctx_cache[(device, slot)] = c
     return c
+
+
+# ---- several GPUs from one process --------------------------------------------------------------
+# SURVEY 8e: series are independent, so a call is cut into contiguous blocks of series, one per
+# device, each driven by its own host thread through its own tsf_ctx (ctypes releases the GIL for
+# the duration of the C call); no data crosses between devices and the pieces are concatenated
+# on the host.  Results are bit-identical to the single-device call.  bench.py measures the
+# other arrangement (one PROCESS per GPU under torch.distributed.run).
+MIN_SERIES_PER_DEVICE = 512
+
+
+def resolve_devices(devices=None):
+    """None -> the TSF_DEVICES environment variable ("all", or "0,1,2"; unset = one device,
+    the default context); 'all' -> every visible GPU; otherwise a list of device ids (an id
+    may repeat: that many contexts on that GPU)."""
+    if devices is None:
+        devices = os.environ.get('TSF_DEVICES') or None
+        if devices is None:
+            return None
+    if isinstance(devices, str):
+        if devices.strip().lower() == 'all':
+            devices = list(range(_lib.load().tsf_device_count()))
+        else:
+            devices = [int(x) for x in devices.split(',') if x.strip() != '']
+    devices = [int(d) for d in devices]
+    return devices if len(devices) > 1 else None
+
+
+def _contexts(devices):
+    seen = {}
+    out = []
+    for d in devices:
+        k = seen.get(d, 0)
+        seen[d] = k + 1
+        out.append(get_context(d, slot=k + 1))
+    return out
+
+
+def _cuts(weights, parts):
+    """Cut points [parts+1] over len(weights) series so that every block carries about the
+    same total weight (rows)."""
+    cum = np.concatenate([[0], np.cumsum(np.asarray(weights, dtype=np.int64))])
+    want = cum[-1] * np.arange(1, parts) / float(parts)
+    inner = np.searchsorted(cum, want, side='left')
+    return np.concatenate([[0], inner, [len(weights)]]).astype(np.int64)
+
+
+def _run_blocks(fn, blocks):
+    import concurrent.futures
+    with concurrent.futures.ThreadPoolExecutor(max_workers=len(blocks)) as ex:
+        futs = [ex.submit(fn, *b) for b in blocks]
+        return [f.result() for f in futs]
+
+
+def _merge_fits(spec, parts, shared_grid):
+    cat = lambda k: np.concatenate([getattr(p, k) for p in parts])   # noqa: E731
+    grid = parts[0].grid if shared_grid else np.concatenate([p.grid for p in parts])
+    return FitResult(spec, cat('theta'), cat('y_scale'), cat('fval'), cat('status'), cat('n_iter'),
+                     cat('n_eval'), grid)
 
 
 def _opt_f64(a, N, name):
@@ -201,8 +263,20 @@ def _alloc_out(N, stride, n_grids):
     return out, (theta, y_scale, fval, status, n_iter, n_eval, grid)
 
 
-def fit_aligned(spec, ds_ns, y, floor=None, cap=None, extra=None, ctx=None):
-    """Fit N series observed on the same T timestamps.  y: [N][T] float64/float32/int32."""
+def fit_aligned(spec, ds_ns, y, floor=None, cap=None, extra=None, ctx=None, devices=None):
+    """Fit N series observed on the same T timestamps.  y: [N][T] float64/float32/int32.
+    devices: see resolve_devices (several GPUs, one host thread each)."""
+    devs = None if ctx is not None else resolve_devices(devices)
+    if devs and len(y) >= 2 * MIN_SERIES_PER_DEVICE:
+        parts = min(len(devs), len(y) // MIN_SERIES_PER_DEVICE)
+        cuts = _cuts(np.ones(len(y), np.int64), parts)
+        fl = _opt_f64(floor, len(y), 'floor')
+        cp = _opt_f64(cap, len(y), 'cap')
+        blocks = [(c, int(a), int(b)) for c, a, b in zip(_contexts(devs[:parts]), cuts[:-1], cuts[1:])]
+        res = _run_blocks(lambda c, a, b: fit_aligned(
+            spec, ds_ns, y[a:b], None if fl is None else fl[a:b], None if cp is None else cp[a:b],
+            extra, ctx=c), blocks)
+        return _merge_fits(spec, res, shared_grid=True)
     ctx = ctx or get_context()
     L = _lib.load()
     ds_ns = np.ascontiguousarray(ds_ns, dtype=np.int64)
@@ -226,9 +300,27 @@ def fit_aligned(spec, ds_ns, y, floor=None, cap=None, extra=None, ctx=None):
     return FitResult(spec, *arrs)
 
 
-def fit_ragged(spec, offsets, ds_ns, y, floor=None, cap=None, extra=None, ctx=None):
+def fit_ragged(spec, offsets, ds_ns, y, floor=None, cap=None, extra=None, ctx=None, devices=None):
     """Fit N series of different lengths / timestamps; series n owns rows
     offsets[n]:offsets[n+1] of ds_ns / y (each slice sorted by ds, NaN rows removed)."""
+    devs = None if ctx is not None else resolve_devices(devices)
+    if devs and len(offsets) - 1 >= 2 * MIN_SERIES_PER_DEVICE:
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        N = len(offsets) - 1
+        parts = min(len(devs), N // MIN_SERIES_PER_DEVICE)
+        cuts = _cuts(np.diff(offsets), parts)
+        fl = _opt_f64(floor, N, 'floor')
+        cp = _opt_f64(cap, N, 'cap')
+        ex = None if extra is None else np.asarray(extra)
+        blocks = [(c, int(a), int(b)) for c, a, b in zip(_contexts(devs[:parts]), cuts[:-1], cuts[1:])
+                  if b > a]
+
+        def one(c, a, b):
+            r0, r1 = int(offsets[a]), int(offsets[b])
+            return fit_ragged(spec, offsets[a:b + 1] - r0, ds_ns[r0:r1], y[r0:r1],
+                              None if fl is None else fl[a:b], None if cp is None else cp[a:b],
+                              None if ex is None else ex[:, r0:r1], ctx=c)
+        return _merge_fits(spec, _run_blocks(one, blocks), shared_grid=False)
     ctx = ctx or get_context()
     L = _lib.load()
     offsets = np.ascontiguousarray(offsets, dtype=np.int64)
@@ -254,9 +346,30 @@ def fit_ragged(spec, offsets, ds_ns, y, floor=None, cap=None, extra=None, ctx=No
 
 
 def predict(spec, theta, y_scale, grid, ds_future_ns, floor=None, cap=None, extra_future=None,
-            want_int=False, ctx=None):
+            want_int=False, ctx=None, devices=None):
     """yhat [N][H] (float64) and, if want_int, the reference's int-truncated + floor-clamped
     column (prophet_scorer.py:73-84).  ds_future_ns: [H] (shared) or [N][H]."""
+    devs = None if ctx is not None else resolve_devices(devices)
+    if devs and len(theta) >= 2 * MIN_SERIES_PER_DEVICE:
+        N = len(theta)
+        parts = min(len(devs), N // MIN_SERIES_PER_DEVICE)
+        cuts = _cuts(np.ones(N, np.int64), parts)
+        fl = _opt_f64(floor, N, 'floor')
+        cp = _opt_f64(cap, N, 'cap')
+        fut = np.asarray(ds_future_ns)
+        exf = None if extra_future is None else np.asarray(extra_future)
+        blocks = [(c, int(a), int(b)) for c, a, b in zip(_contexts(devs[:parts]), cuts[:-1], cuts[1:])]
+
+        def one(c, a, b):
+            return predict(spec, theta[a:b], np.asarray(y_scale)[a:b],
+                           grid if len(grid) == 1 else grid[a:b],
+                           fut if fut.ndim == 1 else fut[a:b],
+                           None if fl is None else fl[a:b], None if cp is None else cp[a:b],
+                           exf if (exf is None or fut.ndim == 1) else exf[a:b], want_int=want_int, ctx=c)
+        res = _run_blocks(one, blocks)
+        if want_int:
+            return np.concatenate([r[0] for r in res]), np.concatenate([r[1] for r in res])
+        return np.concatenate(res)
     ctx = ctx or get_context()
     L = _lib.load()
     theta = np.ascontiguousarray(theta, dtype=np.float64)

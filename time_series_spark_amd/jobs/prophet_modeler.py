@@ -13,7 +13,6 @@ reference's output schema for `df.groupby('series_id','dim_id').apply(...)`.  A 
 that hands over ONE series per call cannot batch; `model_panel(config)` takes a frame holding
 many groups (e.g. grouped by a shard key) and is what ProphetModeler.model uses.
 """
-import glob
 import logging
 import os
 import time
@@ -129,6 +128,34 @@ def _spec_opts(kw):
     return out
 
 
+def _model_packed(config, panel, n_rows, execution_time):
+    floor = config['model']['floor']                                   # :56-57
+    ymax = pk.per_series_stats(panel)[2]
+    cap = ymax * config['model']['cap_multiplier']                     # :59-60
+    kw = _prophet_kwargs(config)
+    floors = np.full(panel.N, float(floor))
+    # ValueError cases propagate exactly as fbprophet's would (SURVEY 8b error convention)
+    if (panel.lengths < 2).any():
+        raise ValueError('Dataframe has less than 2 non-NaN rows.')
+    if kw['growth'] == 'logistic' and (cap <= floors).any():
+        raise ValueError('cap must be greater than floor (which defaults to 0).')
+    blobs, status = fit_packed(panel, floors, cap, kw)
+    sids = panel.keys['series_id'].to_numpy()
+    dids = panel.keys['dim_id'].to_numpy()
+    ok = np.fromiter((b is not None for b in blobs), dtype=bool, count=panel.N)
+    for n in np.flatnonzero(~ok):
+        # pystan RuntimeError -> the reference prints and drops the series (:81-85)
+        print(f"Runtime error {_lib.STATUS_NAMES.get(int(status[n]), status[n])} for "
+              f"series_id: {int(sids[n])}, dim_id: {int(dids[n])}")
+    keep = np.flatnonzero(ok)
+    out = pd.DataFrame({'series_id': sids[keep], 'dim_id': dids[keep],
+                        'floor': np.full(len(keep), floor), 'cap': cap[keep],
+                        'model': pd.Series([blobs[n] for n in keep], dtype=object)},
+                       columns=MODEL_OUTPUT_COLUMNS)
+    print(f"Modeled {panel.N} series ({n_rows} rows) in {time.time() - execution_time}")
+    return out
+
+
 def model_panel(config):
     """Batched form of model_time_series: the frame may hold any number of
     (series_id, dim_id) groups; one output row per fitted group."""
@@ -137,34 +164,25 @@ def model_panel(config):
         execution_time = time.time()
         if len(pdf.index) == 0:
             return _empty_models()
-        panel = pk.pack_long_frame(pdf)
-        floor = config['model']['floor']                                   # :56-57
-        ymax = pk.per_series_stats(panel)[2]
-        cap = ymax * config['model']['cap_multiplier']                     # :59-60
-        kw = _prophet_kwargs(config)
-        floors = np.full(panel.N, float(floor))
-        # ValueError cases propagate exactly as fbprophet's would (SURVEY 8b error convention)
-        if (panel.lengths < 2).any():
-            raise ValueError('Dataframe has less than 2 non-NaN rows.')
-        if kw['growth'] == 'logistic' and (cap <= floors).any():
-            raise ValueError('cap must be greater than floor (which defaults to 0).')
-        blobs, status = fit_packed(panel, floors, cap, kw)
-        sids = panel.keys['series_id'].to_numpy()
-        dids = panel.keys['dim_id'].to_numpy()
-        ok = np.fromiter((b is not None for b in blobs), dtype=bool, count=panel.N)
-        for n in np.flatnonzero(~ok):
-            # pystan RuntimeError -> the reference prints and drops the series (:81-85)
-            print(f"Runtime error {_lib.STATUS_NAMES.get(int(status[n]), status[n])} for "
-                  f"series_id: {int(sids[n])}, dim_id: {int(dids[n])}")
-        keep = np.flatnonzero(ok)
-        out = pd.DataFrame({'series_id': sids[keep], 'dim_id': dids[keep],
-                            'floor': np.full(len(keep), floor), 'cap': cap[keep],
-                            'model': pd.Series([blobs[n] for n in keep], dtype=object)},
-                           columns=MODEL_OUTPUT_COLUMNS)
-        print(f"Modeled {panel.N} series ({len(pdf.index)} rows) in {time.time() - execution_time}")
-        return out
+        return _model_packed(config, pk.pack_long_frame(pdf), len(pdf.index), execution_time)
 
     return model_panel_fn
+
+
+def model_arrays(config):
+    """model_panel for columns that never were a DataFrame (what read_model_input returns):
+    series_id, dim_id int64; ds_ns int64 ns; y float64 with NaN for nulls."""
+
+    def model_arrays_fn(sid, did, ds_ns, y):
+        execution_time = time.time()
+        if len(y) == 0:
+            return _empty_models()
+        if np.isinf(y).any():
+            raise ValueError('Found infinity in column y.')
+        panel = pk.pack_rows(sid, did, ds_ns, y, key_dtypes=(np.int32, np.int32))
+        return _model_packed(config, panel, len(y), execution_time)
+
+    return model_arrays_fn
 
 
 def model_time_series(config):
@@ -195,18 +213,46 @@ def as_pandas_udf(fn, columns=MODEL_OUTPUT_COLUMNS):
     return pandas_udf(schema, PandasUDFType.GROUPED_MAP)(fn)
 
 
-def read_model_input(files, root, n_threads=0):
+def find_model_input(root):
+    """CSV files under `root` with the series_id of the `series_id=<v>` directory above them
+    (None if there is none), ordered by (series_id, path): partition directories in numeric
+    order hand the packer a table that is already grouped."""
+    if os.path.isfile(root):
+        return [root], [None]
+    found = []
+
+    def walk(d, sid):
+        with os.scandir(d) as it:
+            entries = sorted(it, key=lambda e: e.name)
+        for e in entries:
+            if e.is_dir(follow_symlinks=True):
+                v = sid
+                if e.name.startswith('series_id='):
+                    v = int(e.name.split('=', 1)[1])
+                walk(e.path, v)
+            elif e.name.endswith('.csv'):
+                found.append((sid, e.path))
+
+    if os.path.isdir(root):
+        walk(root, None)
+    found.sort(key=lambda t: ((0, t[0]) if t[0] is not None else (1, 0), t[1]))
+    return [f for _, f in found], [v for v, _ in found]
+
+
+def read_model_input(files, root, n_threads=0, part_sid=None):
     """Parse model-input CSV files into (series_id, dim_id, ds_ns, y) arrays (int64, int64,
     int64 ns, float64 with NaN for nulls).  A `series_id=<v>` directory between `root` and the
     file supplies series_id for that file (Spark's partition discovery); the file then holds
-    the remaining MODEL_INPUT_SCHEMA columns in order."""
+    the remaining MODEL_INPUT_SCHEMA columns in order.  part_sid: the partition values if the
+    caller knows them already (find_model_input)."""
     import ctypes
     L = _lib.load()
     if not files:
         z = np.zeros(0, np.int64)
         return z, z.copy(), z.copy(), np.zeros(0)
-    part_sid = []
-    for f in files:
+    known = part_sid is not None
+    part_sid = list(part_sid) if known else []
+    for f in ([] if known else files):
         v = None
         rel = os.path.relpath(os.path.dirname(os.path.abspath(f)),
                               os.path.abspath(root if os.path.isdir(root) else os.path.dirname(root)))
@@ -260,11 +306,7 @@ class ProphetModeler:
         (`series_id=751/…csv` supplies the series_id column), schema MODEL_INPUT_SCHEMA;
         renames start_time -> ds, quantity -> y (:109-114).  The files are parsed by the native
         reader (tsf_csv_read, include/tsf.h), in parallel, straight into columns."""
-        root = self.config['io']['input']
-        files = sorted(glob.glob(os.path.join(root, '**', '*.csv'), recursive=True))
-        if os.path.isfile(root):
-            files = [root]
-        sid, did, ds_ns, y = read_model_input(files, root)
+        sid, did, ds_ns, y = self.read_input_columns()
         for name, col in (('series_id', sid), ('dim_id', did)):
             if len(col) and (col.min() < -2 ** 31 or col.max() >= 2 ** 31):
                 raise ValueError('%s does not fit the int32 column of MODEL_INPUT_SCHEMA' % name)
@@ -276,6 +318,12 @@ class ProphetModeler:
         return pd.DataFrame({'series_id': sid.astype('int32'), 'dim_id': did.astype('int32'),
                              'ds': ds_ns.astype('datetime64[ns]'), 'y': yq},
                             columns=['series_id', 'dim_id', 'ds', 'y'])
+
+    def read_input_columns(self):
+        """The same rows as read_input_dataframe, as (series_id, dim_id, ds_ns, y) arrays."""
+        root = self.config['io']['input']
+        files, part = find_model_input(root)
+        return read_model_input(files, root, part_sid=part)
 
     def persist_models(self, model_df):
         """Parquet, mode='overwrite' (:123-125)."""
@@ -294,7 +342,8 @@ class ProphetModeler:
         """Create the trained time series models (:127-143).  spark_session is accepted for
         signature compatibility and may be None."""
         scorer = ProphetModeler(config)
-        input_df = scorer.read_input_dataframe(spark_session)
-        model_df = model_panel(scorer.config)(input_df)
+        # the columns go from the reader to the packer as arrays; read_input_dataframe gives the
+        # same rows as a frame for callers that want one
+        model_df = model_arrays(scorer.config)(*scorer.read_input_columns())
         scorer.persist_models(model_df)
         return model_df

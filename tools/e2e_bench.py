@@ -1,5 +1,5 @@
 """End-to-end run of the reference's two jobs through the drop-in entry points, from files to
-files: Hive-partitioned model-input CSV -> ProphetModeler.model (read, pack, GPU fit, model
+files: Hive-partitioned model-input CSV -> ProphetModeler.model's steps (read, pack, GPU fit, model
 parquet) -> ProphetScorer.score (read models, GPU predict, convert, forecast CSV).  Prints the
 wall time of every stage and the series/s of the whole thing (host IO included -- this is NOT
 bench.py's `value`, which times the hot path with inputs resident in HBM).
@@ -71,8 +71,8 @@ def main():
     try:
         for rep in ('warm-up ', ''):              # first pass pays library load + HIP init
             mo = pm.ProphetModeler(mcfg)
-            df = stage(rep + 'read_input_dataframe', mo.read_input_dataframe)
-            models = stage(rep + 'model_panel (pack + fit + blobs)', pm.model_panel(mcfg), df)
+            cols = stage(rep + 'read_input_columns', mo.read_input_columns)
+            models = stage(rep + 'model_arrays (pack + fit + blobs)', lambda c: pm.model_arrays(mcfg)(*c), cols)
             stage(rep + 'persist_models', mo.persist_models, models)
             sc = ps.ProphetScorer(scfg)
             mdf = stage(rep + 'read_model_dataframe', sc.read_model_dataframe)
