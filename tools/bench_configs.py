@@ -31,11 +31,11 @@ def build(name):
         ds, y = synth.make_panel(N, T, 'linear', seed=751)
         return ('10000 x 730 linear additive yearly+weekly' + (' (residual form forced)' if lb else ''),
                 spec, ds, y, None, None, None, None, T * 8 + 54 * 8 + H * 8)
-    if name == 'ref10k':       # the reference's own model settings on a cfg2-sized aligned panel
-        N, T = 10000, 730
+    if name in ('ref10k', 'ref100k'):   # the reference's own model settings on an aligned panel
+        N, T = (10000 if name == 'ref10k' else 100000), 730
         ds, y = synth.make_panel(N, T, 'logistic', seed=751)
         spec = fc.ModelSpec(growth='logistic', seasonality_mode='multiplicative', seasonalities=[YEARLY, WEEKLY])
-        return ('10000 x 730 logistic + multiplicative yearly+weekly (reference settings, aligned)',
+        return ('%d x 730 logistic + multiplicative yearly+weekly (reference settings, aligned)' % N,
                 spec, ds, y, np.zeros(N), y.max(axis=1) * 1.1, None, None, T * 8 + 54 * 8 + H * 8 + 8)
     if name in ('lin_hol', 'lin_hol_resid'):   # linear + additive with 30 holiday columns: P = 84, two-slot kernels
         N, T = 10000, 730
