@@ -258,6 +258,18 @@ int tsf_csv_read(int32_t n_files, const char *const *paths, const int64_t *serie
 int tsf_csv_fetch(tsf_csv *t, int64_t *series_id, int64_t *dim_id, int64_t *ds, double *y);
 void tsf_csv_free(tsf_csv *t);
 
+/* ---- forecast sink (host side) -------------------------------------------------------------
+ * ProphetScorer.convert_forecasts + write_forecasts in one pass
+ * (/root/reference/src/jobs/prophet_scorer.py:130-150): a CSV with header
+ *   created_timestamp,series_id,dim_id,forecast_date,forecast_timestamp,forecast_quantity
+ * forecast_date = the date of ds as %Y-%m-%d (:107-108); forecast_timestamp in Spark 2.4's default
+ * CSV timestampFormat yyyy-MM-dd'T'HH:mm:ss.SSSXXX with the wall time taken as UTC
+ * (2002-12-28T22:00:00.000Z).  ds: int64 ns since the epoch.  Overwrites `path`.
+ * Returns 0, TSF_CSV_E_OPEN if the file cannot be written, -1 bad arguments, -2 out of memory. */
+int tsf_csv_write_forecasts(const char *path, const char *created_timestamp, int64_t n,
+                            const int64_t *series_id, const int64_t *dim_id, const int64_t *ds,
+                            const int64_t *quantity, int32_t n_threads);
+
 #ifdef __cplusplus
 }
 #endif

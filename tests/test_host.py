@@ -363,3 +363,22 @@ def test_device_list_and_block_cuts(monkeypatch):
     c = fc._cuts(rows, 8)
     per = np.add.reduceat(rows, c[:-1])
     assert per.max() - per.min() <= 2 * rows.max()
+
+
+def test_native_forecast_sink_writes_the_same_file_as_the_frame_path(tmp_path):
+    rng = np.random.default_rng(2)
+    n = 200000                                               # several 65 536-row blocks, 2+ threads
+    ds = (np.datetime64('1965-03-01T00:00:00', 'ns')
+          + rng.integers(0, 70 * 365 * 86400, n).astype('timedelta64[s]')
+          + rng.integers(0, 1000, n).astype('timedelta64[ms]'))
+    fdf = pd.DataFrame({'series_id': rng.integers(-3, 2 ** 31 - 1, n).astype('int32'),
+                        'dim_id': rng.integers(0, 500, n).astype('int32'), 'ds': ds,
+                        'yhat': rng.integers(-2 ** 31, 2 ** 31 - 1, n).astype('int32')})
+    a = ps.ProphetScorer({'io': {'forecasts': str(tmp_path / 'a')}})
+    b = ps.ProphetScorer({'io': {'forecasts': str(tmp_path / 'b')}})
+    conv = a.convert_forecasts(fdf)
+    a.write_forecasts(conv)
+    b.write_converted(fdf, conv['created_timestamp'].iloc[0])
+    assert open(tmp_path / 'a' / 'part-00000.csv', 'rb').read() == open(tmp_path / 'b' / 'part-00000.csv', 'rb').read()
+    b.write_converted(fdf.iloc[:0])                          # empty: header only
+    assert open(tmp_path / 'b' / 'part-00000.csv').read().count('\n') == 1

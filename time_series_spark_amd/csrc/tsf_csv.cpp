@@ -335,4 +335,140 @@ int tsf_csv_fetch(tsf_csv *t, int64_t *series_id, int64_t *dim_id, int64_t *ds, 
 
 void tsf_csv_free(tsf_csv *t) { delete t; }
 
+// ---- forecast sink ----------------------------------------------------------------------------
+// ProphetScorer.convert_forecasts + write_forecasts (/root/reference/src/jobs/prophet_scorer.py:
+// 130-150): one CSV with header
+//   created_timestamp,series_id,dim_id,forecast_date,forecast_timestamp,forecast_quantity
+// forecast_date = ds.date() as %Y-%m-%d (:107-108), forecast_timestamp in Spark 2.4's default
+// CSV timestampFormat yyyy-MM-dd'T'HH:mm:ss.SSSXXX with the wall time taken as UTC.
+namespace {
+
+inline void civil_from_days(int64_t z, int64_t *y, unsigned *m, unsigned *d) {
+    z += 719468;
+    const int64_t era = (z >= 0 ? z : z - 146096) / 146097;
+    const unsigned doe = (unsigned)(z - era * 146097);
+    const unsigned yoe = (doe - doe / 1460 + doe / 36524 - doe / 146096) / 365;
+    const int64_t yy = (int64_t)yoe + era * 400;
+    const unsigned doy = doe - (365 * yoe + yoe / 4 - yoe / 100);
+    const unsigned mp = (5 * doy + 2) / 153;
+    *d = doy - (153 * mp + 2) / 5 + 1;
+    *m = mp < 10 ? mp + 3 : mp - 9;
+    *y = yy + (*m <= 2);
+}
+
+inline char *put2(char *p, unsigned v) {
+    p[0] = (char)('0' + v / 10);
+    p[1] = (char)('0' + v % 10);
+    return p + 2;
+}
+
+inline char *put_int(char *p, int64_t v) {
+    char tmp[24];
+    int n = 0;
+    uint64_t u = v < 0 ? (uint64_t)(-(v + 1)) + 1 : (uint64_t)v;
+    if (v < 0) *p++ = '-';
+    do {
+        tmp[n++] = (char)('0' + u % 10);
+        u /= 10;
+    } while (u);
+    while (n) *p++ = tmp[--n];
+    return p;
+}
+
+// yyyy-MM-dd (returns end); years outside 0..9999 are not expected from datetime64[ns]
+inline char *put_date(char *p, int64_t days) {
+    int64_t y;
+    unsigned m, d;
+    civil_from_days(days, &y, &m, &d);
+    p = put2(p, (unsigned)(y / 100));
+    p = put2(p, (unsigned)(y % 100));
+    *p++ = '-';
+    p = put2(p, m);
+    *p++ = '-';
+    return put2(p, d);
+}
+
+}  // namespace
+
+int tsf_csv_write_forecasts(const char *path, const char *created_timestamp, int64_t n,
+                            const int64_t *series_id, const int64_t *dim_id, const int64_t *ds,
+                            const int64_t *quantity, int32_t n_threads) {
+    if (!path || !created_timestamp || n < 0 || (n > 0 && (!series_id || !dim_id || !ds || !quantity)))
+        return -1;
+    const size_t clen = std::strlen(created_timestamp);
+    if (clen > 64) return -1;
+    FILE *f = std::fopen(path, "wb");
+    if (!f) return TSF_CSV_E_OPEN;
+    static const char header[] =
+        "created_timestamp,series_id,dim_id,forecast_date,forecast_timestamp,forecast_quantity\n";
+    bool ok = std::fwrite(header, 1, sizeof(header) - 1, f) == sizeof(header) - 1;
+    int hw = (int)std::thread::hardware_concurrency();
+    if (hw < 1) hw = 1;
+    int nt = n_threads > 0 ? n_threads : (hw < 16 ? hw : 16);
+    const size_t row_max = clen + 1 + 21 + 21 + 11 + 25 + 21 + 1;
+    const int64_t block = 1 << 16;                 // rows formatted per thread per turn
+    try {
+        std::vector<std::vector<char>> bufs((size_t)nt);
+        std::vector<size_t> used((size_t)nt);
+        for (auto &b : bufs) b.resize((size_t)block * row_max);
+        for (int64_t base = 0; base < n && ok; base += block * nt) {
+            auto work = [&](int t) {
+                int64_t a = base + (int64_t)t * block, b = a + block < n ? a + block : n;
+                char *p = bufs[(size_t)t].data();
+                for (int64_t r = a; r < b; ++r) {
+                    std::memcpy(p, created_timestamp, clen);
+                    p += clen;
+                    *p++ = ',';
+                    p = put_int(p, series_id[r]);
+                    *p++ = ',';
+                    p = put_int(p, dim_id[r]);
+                    *p++ = ',';
+                    const int64_t v = ds[r];
+                    int64_t days = v / 86400000000000ll, rem = v % 86400000000000ll;
+                    if (rem < 0) {
+                        rem += 86400000000000ll;
+                        --days;
+                    }
+                    p = put_date(p, days);
+                    *p++ = ',';
+                    p = put_date(p, days);
+                    *p++ = 'T';
+                    const int64_t secs = rem / 1000000000ll;
+                    const unsigned ms = (unsigned)((rem % 1000000000ll) / 1000000ll);
+                    p = put2(p, (unsigned)(secs / 3600));
+                    *p++ = ':';
+                    p = put2(p, (unsigned)(secs / 60 % 60));
+                    *p++ = ':';
+                    p = put2(p, (unsigned)(secs % 60));
+                    *p++ = '.';
+                    *p++ = (char)('0' + ms / 100);
+                    p = put2(p, ms % 100);
+                    *p++ = 'Z';
+                    *p++ = ',';
+                    p = put_int(p, quantity[r]);
+                    *p++ = '\n';
+                }
+                used[(size_t)t] = a < b ? (size_t)(p - bufs[(size_t)t].data()) : 0;
+            };
+            int live = 0;
+            for (int t = 0; t < nt; ++t)
+                if (base + (int64_t)t * block < n) live = t + 1;
+            if (live <= 1) {
+                work(0);
+            } else {
+                std::vector<std::thread> th;
+                for (int t = 0; t < live; ++t) th.emplace_back(work, t);
+                for (auto &x : th) x.join();
+            }
+            for (int t = 0; t < live && ok; ++t)
+                ok = std::fwrite(bufs[(size_t)t].data(), 1, used[(size_t)t], f) == used[(size_t)t];
+        }
+    } catch (...) {
+        std::fclose(f);
+        return -2;
+    }
+    if (std::fclose(f) != 0) ok = false;
+    return ok ? 0 : TSF_CSV_E_OPEN;
+}
+
 }  // extern "C"

@@ -105,8 +105,9 @@ class ProphetScorer:
         created_timestamp = datetime.now(timezone.utc).replace(microsecond=0).isoformat()
         ds = forecast_df['ds'].values.astype('datetime64[ns]')
         # extract_date per distinct day (the column repeats a few hundred dates)
-        days, inv = np.unique(ds.astype('datetime64[D]'), return_inverse=True)
-        names = np.array([extract_date(pd.Timestamp(d).to_pydatetime()) for d in days], dtype=object)
+        inv, days = pd.factorize(ds.astype('datetime64[D]').astype(np.int64))
+        names = np.array([extract_date(pd.Timestamp(int(d), unit='D').to_pydatetime()) for d in days],
+                         dtype=object)
         out = pd.DataFrame({
             'created_timestamp': created_timestamp,
             'series_id': forecast_df['series_id'].values,
@@ -149,11 +150,35 @@ class ProphetScorer:
             pacsv.write_csv(pa.table(cols), f,
                             write_options=pacsv.WriteOptions(include_header=False, quoting_style='none'))
 
+    def write_converted(self, forecast_df, created_timestamp=None):
+        """convert_forecasts + write_forecasts in one native pass (tsf_csv_write_forecasts):
+        the same file write_forecasts(convert_forecasts(forecast_df)) produces, formatted by
+        threads straight from the forecast columns."""
+        import ctypes
+        import shutil
+        from .. import _lib
+        if created_timestamp is None:
+            created_timestamp = datetime.now(timezone.utc).replace(microsecond=0).isoformat()
+        path = self.config['io']['forecasts']
+        if os.path.isdir(path):
+            shutil.rmtree(path)
+        os.makedirs(path, exist_ok=True)
+        cols = [np.ascontiguousarray(forecast_df[c].values, dtype=np.int64) for c in ('series_id', 'dim_id')]
+        cols.append(np.ascontiguousarray(forecast_df['ds'].values.astype('datetime64[ns]').astype(np.int64)))
+        cols.append(np.ascontiguousarray(forecast_df['yhat'].values, dtype=np.int64))
+        rc = _lib.load().tsf_csv_write_forecasts(
+            os.fsencode(os.path.join(path, 'part-00000.csv')), created_timestamp.encode(),
+            len(forecast_df.index), *[c.ctypes.data for c in cols], 0)
+        if rc != 0:
+            raise OSError('tsf_csv_write_forecasts failed (%d) for %s' % (rc, path))
+        return created_timestamp
+
     @staticmethod
     def score(spark_session, config):
         scorer = ProphetScorer(config)
         model_df = scorer.read_model_dataframe(spark_session)
         forecast_df = forecast_panel(scorer.config)(model_df)
         converted_df = scorer.convert_forecasts(forecast_df)
-        scorer.write_forecasts(converted_df)
+        created = converted_df['created_timestamp'].iloc[0] if len(converted_df.index) else None
+        scorer.write_converted(forecast_df, created)
         return converted_df

@@ -78,7 +78,7 @@ def main():
             mdf = stage(rep + 'read_model_dataframe', sc.read_model_dataframe)
             fdf = stage(rep + 'forecast_panel (predict)', ps.forecast_panel(scfg), mdf)
             conv = stage(rep + 'convert_forecasts', sc.convert_forecasts, fdf)
-            stage(rep + 'write_forecasts', sc.write_forecasts, conv)
+            stage(rep + 'write_converted (native sink)', sc.write_converted, fdf, conv['created_timestamp'].iloc[0])
     finally:
         sys.stdout = out
     total = sum(v for k, v in t.items() if not k.startswith(('warm-up', '(')))
