@@ -11,14 +11,14 @@ exact arithmetic) -- the point of the table is that on these ill-conditioned pro
 (25 Laplace-penalised slope changes on 72 points) the stopping point moves the forecast by
 per cent, whichever optimiser or spelling is used.  CPU only; test infrastructure.
 
-    python tools/newton_vs_lbfgs.py [n_series]
+    python tests/dev/newton_vs_lbfgs.py [n_series]
 """
 import os
 import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import canon_lib as cl  # noqa: E402
 from tests import helpers  # noqa: E402
 from time_series_spark_amd import forecaster as fc, synth  # noqa: E402
