@@ -43,7 +43,7 @@ def _empty_models():
     return pd.DataFrame(columns=MODEL_OUTPUT_COLUMNS)
 
 
-def fit_packed(panel, floor, cap, kw):
+def fit_packed(panel, floor, cap, kw, devices=None):
     """Fit every series of a PackedPanel.  Series are bucketed by the seasonality set
     fbprophet's 'auto' rules give their own history (each Prophet object decides alone), one
     kernel launch per bucket.  Returns per-series (blob | None, status)."""
@@ -96,7 +96,7 @@ def fit_packed(panel, floor, cap, kw):
             calls.append((gm, fc.fit_aligned(
                 spec, panel.ds_ns[a0:a0 + T], y2d,
                 floor=None if floor is None else np.asarray(floor)[gm],
-                cap=None if cap is None else np.asarray(cap)[gm], extra=ex)))
+                cap=None if cap is None else np.asarray(cap)[gm], extra=ex, devices=devices)))
         if len(rest):
             lens = panel.lengths[rest]
             off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
@@ -107,7 +107,7 @@ def fit_packed(panel, floor, cap, kw):
             calls.append((rest, fc.fit_ragged(
                 spec, off, panel.ds_ns[idx], panel.y[idx],
                 floor=None if floor is None else np.asarray(floor)[rest],
-                cap=None if cap is None else np.asarray(cap)[rest], extra=ex)))
+                cap=None if cap is None else np.asarray(cap)[rest], extra=ex, devices=devices)))
         for mem, res in calls:
             st = np.asarray(res.status)
             status[mem] = st
@@ -139,7 +139,9 @@ def _model_packed(config, panel, n_rows, execution_time):
         raise ValueError('Dataframe has less than 2 non-NaN rows.')
     if kw['growth'] == 'logistic' and (cap <= floors).any():
         raise ValueError('cap must be greater than floor (which defaults to 0).')
-    blobs, status = fit_packed(panel, floors, cap, kw)
+    # config['devices'] (not in the reference): GPUs to spread the series over, e.g. [0, 1, 2, 3]
+    # or 'all'; default: TSF_DEVICES, else one GPU
+    blobs, status = fit_packed(panel, floors, cap, kw, devices=config.get('devices'))
     sids = panel.keys['series_id'].to_numpy()
     dids = panel.keys['dim_id'].to_numpy()
     ok = np.fromiter((b is not None for b in blobs), dtype=bool, count=panel.N)

@@ -58,7 +58,8 @@ def forecast_panel(config):
             floor, cap = floors[idx], caps[idx]                          # :67-68
             ex = np.zeros((len(idx), len(spec.extra), periods)) if spec.extra else None
             yhat, yint = fc.predict(spec, theta, rec['y_scale'], grid, fut, floor=floor, cap=cap,
-                                    extra_future=ex, want_int=True)      # :70-84
+                                    extra_future=ex, want_int=True,      # :70-84
+                                    devices=config.get('devices'))
             for j in np.flatnonzero((np.trunc(yhat) < floor[:, None]).any(axis=1)):
                 print(f"Negative forecast values found for series_id: {int(sids[idx[j]])}, "
                       f"dim_id: {int(dids[idx[j]])}")                    # :77-79

@@ -27,14 +27,14 @@ def _grid(spec, ds_ns, n=1):
     return g
 
 
-def fake_fit_aligned(spec, ds_ns, y, floor=None, cap=None, extra=None, ctx=None):
+def fake_fit_aligned(spec, ds_ns, y, floor=None, cap=None, extra=None, ctx=None, devices=None):
     N = y.shape[0]
     return fc.FitResult(spec, np.zeros((N, spec.theta_stride)), np.ones(N), np.zeros(N),
                         np.zeros(N, np.int32), np.ones(N, np.int32), np.ones(N, np.int32),
                         _grid(spec, ds_ns))
 
 
-def fake_fit_ragged(spec, offsets, ds_ns, y, floor=None, cap=None, extra=None, ctx=None):
+def fake_fit_ragged(spec, offsets, ds_ns, y, floor=None, cap=None, extra=None, ctx=None, devices=None):
     N = len(offsets) - 1
     return fc.FitResult(spec, np.zeros((N, spec.theta_stride)), np.ones(N), np.zeros(N),
                         np.zeros(N, np.int32), np.ones(N, np.int32), np.ones(N, np.int32),
@@ -42,7 +42,7 @@ def fake_fit_ragged(spec, offsets, ds_ns, y, floor=None, cap=None, extra=None, c
 
 
 def fake_predict(spec, theta, y_scale, grid, fut, floor=None, cap=None, extra_future=None,
-                 want_int=False, ctx=None):
+                 want_int=False, ctx=None, devices=None):
     yh = np.full(fut.shape, 5.5)
     return (yh, yh.astype(np.int32)) if want_int else yh
 
