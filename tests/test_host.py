@@ -382,3 +382,24 @@ def test_native_forecast_sink_writes_the_same_file_as_the_frame_path(tmp_path):
     assert open(tmp_path / 'a' / 'part-00000.csv', 'rb').read() == open(tmp_path / 'b' / 'part-00000.csv', 'rb').read()
     b.write_converted(fdf.iloc[:0])                          # empty: header only
     assert open(tmp_path / 'b' / 'part-00000.csv').read().count('\n') == 1
+
+
+def test_native_packer_property_random_tables():
+    """Random small tables (few keys, many ties, NaNs anywhere, any thread count): the native
+    packer equals the numpy statement of the order contract."""
+    from hypothesis import given, settings, strategies as st
+
+    row = st.tuples(st.integers(-2, 3), st.integers(0, 2), st.integers(-3, 3),
+                    st.one_of(st.just(float('nan')), st.floats(-5, 5, allow_nan=False, width=32)))
+
+    @settings(max_examples=150, deadline=None)
+    @given(st.lists(row, min_size=0, max_size=60), st.integers(1, 5))
+    def check(rows, nt):
+        a = np.array(rows, dtype=np.float64).reshape(-1, 4)
+        sid, did, ds, y = a[:, 0].astype(np.int64), a[:, 1].astype(np.int64), a[:, 2].astype(np.int64), a[:, 3].copy()
+        ks, kd, off, dso, yo = helpers.pack_reference(sid, did, ds, y)
+        p = pk.pack_rows(sid, did, ds, y, n_threads=nt)
+        assert np.array_equal(p.keys['series_id'].values, ks) and np.array_equal(p.keys['dim_id'].values, kd)
+        assert np.array_equal(p.offsets, off) and np.array_equal(p.ds_ns, dso) and np.array_equal(p.y, yo)
+
+    check()
