@@ -403,3 +403,25 @@ def test_native_packer_property_random_tables():
         assert np.array_equal(p.offsets, off) and np.array_equal(p.ds_ns, dso) and np.array_equal(p.y, yo)
 
     check()
+
+
+def test_c_abi_is_plain_c_and_host_stages_run_from_c(built, tmp_path):
+    """include/tsf.h compiles as strict C99 and a C program (no Python, no GPU) drives
+    reader -> packer -> sink through the shared library."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / 'abi_host_stages')
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call(['gcc', '-std=c99', '-pedantic', '-Wall', '-Wextra', '-Werror',
+                           '-I', os.path.join(root, 'include'), os.path.join(root, 'tests', 'c', 'abi_host_stages.c'),
+                           '-o', exe, '-L', libdir, '-ltsf_amd', '-Wl,-rpath,' + libdir])
+    (tmp_path / 'in.csv').write_text('2,2020-01-03 00:00:00,5\n1,2020-01-02 00:00:00,9\n2,2020-01-01 12:00:00,\n'
+                                     '1,2020-01-01 00:00:00,4\n2,2020-01-01 00:00:00,6\n')
+    out = subprocess.check_output([exe, str(tmp_path / 'in.csv'), str(tmp_path / 'out.csv')]).decode()
+    assert out.split() == ['rows_in=5', 'rows=4', 'series=2', 'identity=0', 'first_key=7/1',
+                           'span0=86400000000000', 'min_dt0=86400000000000', 'ymax0=9.0']
+    lines = (tmp_path / 'out.csv').read_text().splitlines()
+    assert lines[1:] == ['2020-01-01T00:00:00+00:00,7,1,2020-01-01,2020-01-01T00:00:00.000Z,4',
+                         '2020-01-01T00:00:00+00:00,7,1,2020-01-02,2020-01-02T00:00:00.000Z,9',
+                         '2020-01-01T00:00:00+00:00,7,2,2020-01-01,2020-01-01T00:00:00.000Z,6',
+                         '2020-01-01T00:00:00+00:00,7,2,2020-01-03,2020-01-03T00:00:00.000Z,5']
