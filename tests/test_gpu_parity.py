@@ -254,6 +254,44 @@ def test_one_host_thread_per_device_gives_identical_bits(env, monkeypatch):
         assert np.array_equal(p1[0], p3[0]) and np.array_equal(p1[1], p3[1])
 
 
+def test_c_program_through_the_abi_matches_the_python_binding(env, tmp_path):
+    """The boundary is the C-ABI, not Python: a plain C99 program (tests/c/abi_fit.c, no torch,
+    no numpy in the process) fits and predicts the same panel and returns the same bits as the
+    ctypes binding -- and therefore as the oracle."""
+    import os
+    import subprocess
+    from time_series_spark_amd import _lib, synth
+    fc, cl = env
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / 'abi_fit')
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call(['gcc', '-std=c99', '-pedantic', '-Wall', '-Wextra', '-Werror',
+                           '-I', os.path.join(root, 'include'), os.path.join(root, 'tests', 'c', 'abi_fit.c'),
+                           '-o', exe, '-L', libdir, '-ltsf_amd', '-Wl,-rpath,' + libdir])
+    N, T, H = 12, 200, 30
+    ds, y = synth.make_panel(N, T, 'linear', seed=5)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    fut = ds[-1] + synth.DAY_NS * np.arange(1, H + 1)
+    ds.astype('<i8').tofile(tmp_path / 'ds.bin')
+    y.astype('<f8').tofile(tmp_path / 'y.bin')
+    fut.astype('<i8').tofile(tmp_path / 'fut.bin')
+    msg = subprocess.check_output([exe, str(N), str(T), str(H), str(tmp_path / 'ds.bin'), str(tmp_path / 'y.bin'),
+                                   str(tmp_path / 'fut.bin'), str(tmp_path / 'out.bin')]).decode()
+    spec = fc.ModelSpec(growth='linear', seasonalities=[dict(helpers.WEEKLY)])
+    assert msg.split()[0] == 'stride=%d' % spec.theta_stride
+    raw = np.fromfile(tmp_path / 'out.bin', dtype='<f8')
+    st = spec.theta_stride
+    theta, yhat, tail = raw[:N * st].reshape(N, st), raw[N * st:N * st + N * H].reshape(N, H), raw[N * st + N * H:].reshape(N, 3)
+    res = fc.fit_aligned(spec, ds, y)
+    assert np.array_equal(theta, res.theta) and np.array_equal(tail[:, 0], res.status)
+    assert np.array_equal(tail[:, 1], res.n_iter) and np.array_equal(tail[:, 2], res.n_eval)
+    assert np.array_equal(yhat, fc.predict(spec, res.theta, res.y_scale, res.grid, fut))
+    csp = helpers.oracle_spec(spec)
+    o = cl.fit(csp, ds, y[0])
+    S = o['info'].S
+    assert n_bit_diff(theta[0][:3 + S], o['theta'][:3 + S]) == 0 and tail[0, 2] == o['n_eval']
+
+
 def test_batched_job_is_independent_of_how_series_are_grouped(env):
     """model_panel groups series that share a timestamp vector (aligned kernel path) and fits the
     rest through the ragged entry point; each series' model must be byte-identical to the one
