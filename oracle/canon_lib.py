@@ -22,7 +22,8 @@ MAX_EXTRA = 64
 
 STATUS_NAMES = {0: 'SUCCESS', 10: 'ABSX', 20: 'ABSF', 21: 'RELF', 30: 'ABSGRAD', 31: 'RELGRAD',
                 40: 'MAXIT', -1: 'LSFAIL', -2: 'INIT_NONFINITE', -3: 'EVAL_LIMIT', 50: 'CONSTANT',
-                -10: 'ERR_TOO_FEW', -11: 'ERR_CAP', -12: 'ERR_SIZE'}
+                -10: 'ERR_TOO_FEW', -11: 'ERR_CAP', -12: 'ERR_SIZE',
+                60: 'NEWTON_CONVERGED', -4: 'NEWTON_FAIL', -13: 'NEWTON_TOO_WIDE'}
 
 
 class CnSpec(ctypes.Structure):
@@ -80,6 +81,8 @@ def lib():
                                  ctypes.POINTER(f64), vp]
         L.cn_fit.argtypes = [ctypes.POINTER(CnSpec), i32, vp, vp, f64, f64, vp, vp, vp,
                              ctypes.POINTER(CnFitInfo)]
+        L.cn_fit_newton.argtypes = L.cn_fit.argtypes
+        L.cn_jacobi_eigh.argtypes = [i32, vp, vp, vp]
         L.cn_fit_checked.argtypes = [ctypes.POINTER(CnSpec), i32, vp, vp, f64, f64, vp, vp,
                                      ctypes.POINTER(CnFitInfo), vp]
         L.cn_predict.argtypes = [ctypes.POINTER(CnSpec), ctypes.POINTER(CnFitInfo), vp, vp, i32,
@@ -197,6 +200,35 @@ def fit(sp, ds_ns, y, floor=0.0, cap=0.0, extra=None):
     return {'theta': theta[:P].copy(), 't_change': tch[:info.S].copy(), 'info': info,
             'status': info.status, 'status_name': STATUS_NAMES.get(info.status, '?'),
             'n_iter': info.n_iter, 'n_eval': info.n_eval, 'n_resid': info.pad_, 'f': info.f}
+
+
+def fit_newton(sp, ds_ns, y, floor=0.0, cap=0.0, extra=None):
+    """cn_fit with Stan's Newton optimiser (what fbprophet uses for T < 100); same dict."""
+    ds_ns, y = _i64(ds_ns), _f64(y)
+    T = len(ds_ns)
+    theta = np.zeros(128)
+    tch = np.zeros(64)
+    info = CnFitInfo()
+    ekeep, eptr = _extra_ptr(sp, extra, T)
+    lib().cn_fit_newton(ctypes.byref(sp), T, ds_ns.ctypes.data, y.ctypes.data, float(floor), float(cap),
+                        eptr, theta.ctypes.data, tch.ctypes.data, ctypes.byref(info))
+    P = 3 + info.S + info.K
+    return {'theta': theta[:P].copy(), 't_change': tch[:info.S].copy(), 'info': info,
+            'status': info.status, 'status_name': STATUS_NAMES.get(info.status, '?'),
+            'n_iter': info.n_iter, 'n_eval': info.n_eval, 'f': info.f}
+
+
+def jacobi_eigh(A):
+    """The oracle's canonical symmetric eigen-solver: (eigenvalues, eigenvectors in columns,
+    sweeps)."""
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    n = A.shape[0]
+    V = np.zeros((n, n))
+    lam = np.zeros(n)
+    sweeps = lib().cn_jacobi_eigh(n, A.ctypes.data, V.ctypes.data, lam.ctypes.data)
+    if sweeps < 0:
+        raise ValueError('cn_jacobi_eigh: n out of range')
+    return lam, V, sweeps
 
 
 def fit_checked(sp, ds_ns, y):

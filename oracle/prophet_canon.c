@@ -905,6 +905,185 @@ done:
     return 0;
 }
 
+/* ---- Stan's Newton optimiser ------------------------------------------------------------
+ * fbprophet 0.5 calls optimizing(algorithm='Newton') when T < 100 and as the retry after an
+ * L-BFGS RuntimeError (forecaster.py fit).  Restated from stan 2.19
+ * (UPSTREAM-RECALL, not in /root/reference):
+ *   model/grad_hess_log_prob.hpp   Hessian by finite differences of the gradient: epsilon 1e-3,
+ *       perturbations {-2e,-e,+e,+2e} of one coordinate at a time, coefficients
+ *       {1/12,-2/3,2/3,-1/12}, increment = half_epsilon * coefficient * gradient added to
+ *       H[d][dd] and H[dd][d]  (half_epsilon = 0.5 * epsilon MULTIPLIES in the recalled source,
+ *       where the finite-difference formula divides: the Hessian comes out 1e-6 of its value,
+ *       the Newton step 1e6 too long and the step-halving loop absorbs it -- kept as recalled,
+ *       see tests/dev/newton_vs_lbfgs.py for what the other spelling changes);
+ *   optimization/newton.hpp        make_negative_definite_and_solve (eigen-decomposition,
+ *       eigenvalues replaced by -|lambda|), newton_step (step halving from 1 until
+ *       f1 >= f0, give up below 1e-50);
+ *   services/optimize/newton.hpp   iterate until |lp - lastlp| < 1e-8 or num_iterations.
+ * NOT pinned against Stan output (parity unpinned); it exists so that a GPU Newton has a
+ * checker.  Canonical order (lane = parameter p < 64):
+ *   A[d][p]   = fma chain over the 4 perturbations of coordinate d, H[a][b] = A[a][b] + A[b][a];
+ *   eigen-decomposition by a round-robin Jacobi (cn_jacobi);
+ *   proj[j]   = fma chain over i of V[i][j] * g[i];  proj[j] = -proj[j] / |lambda_j|;
+ *   step[i]   = fma chain over j of V[i][j] * proj[j];  new[i] = th[i] - size * step[i]. */
+
+#define CN_NEWTON_MAX_P 64
+enum { TERM_NEWTON_CONVERGED = 60, CN_NEWTON_FAIL = -4, CN_NEWTON_TOO_WIDE = -13 };
+
+/* Symmetric eigen-decomposition, parallel-order Jacobi.  Every round applies n/2 rotations on
+ * disjoint index pairs at once (angles all taken from the matrix before the round), pairs from
+ * the round-robin tournament: in round r index m-1 meets r and every other i meets
+ * (2r - i) mod (m-1), m = n rounded up to even (an odd n plays against a dummy = no rotation).
+ * A: [n][n] row-major (destroyed), V: eigenvectors in columns, lam: eigenvalues (unsorted). */
+static int cn_jacobi(int n, double *A, double *V, double *lam)
+{
+    const int m = n + (n & 1);
+    double B[CN_NEWTON_MAX_P * CN_NEWTON_MAX_P], W[CN_NEWTON_MAX_P * CN_NEWTON_MAX_P];
+    double c[CN_NEWTON_MAX_P], kap[CN_NEWTON_MAX_P];
+    int par[CN_NEWTON_MAX_P];
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) V[i * n + j] = (i == j) ? 1.0 : 0.0;
+    int sweep = 0;
+    for (; sweep < 30; ++sweep) {
+        /* relative off-diagonal weight, columns summed first, then the 64-slot butterfly */
+        double offp[CN_W], diap[CN_W];
+        for (int j = 0; j < CN_W; ++j) {
+            double so = 0.0, sd = 0.0;
+            if (j < n)
+                for (int i = 0; i < n; ++i) {
+                    const double a = A[i * n + j];
+                    if (i == j) sd = a * a; else so = fma(a, a, so);
+                }
+            offp[j] = so; diap[j] = sd;
+        }
+        const double off2 = bfly(offp), dia2 = bfly(diap);
+        if (off2 <= 1e-26 * dia2) break;
+        for (int r = 0; r < m - 1; ++r) {
+            for (int i = 0; i < n; ++i) {
+                int q;
+                if (i == m - 1) q = r;
+                else if (i == r) q = m - 1;
+                else { q = (2 * r - i) % (m - 1); if (q < 0) q += m - 1; }
+                par[i] = q;
+                if (q >= n) { c[i] = 1.0; kap[i] = 0.0; continue; }
+                const int lo = i < q ? i : q, hi = i < q ? q : i;
+                const double apq = A[lo * n + hi];
+                if (apq == 0.0) { c[i] = 1.0; kap[i] = 0.0; continue; }
+                const double tau = (A[hi * n + hi] - A[lo * n + lo]) / (2.0 * apq);
+                const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                const double cc = 1.0 / sqrt(1.0 + t * t);
+                const double ss = t * cc;
+                c[i] = cc;
+                kap[i] = (i == lo) ? -ss : ss;
+            }
+            /* B = A J, W = V J (column i mixes with column par[i]); A = J^T B */
+            for (int rr = 0; rr < n; ++rr)
+                for (int i = 0; i < n; ++i) {
+                    const int q = par[i];
+                    const double aq = q < n ? A[rr * n + q] : 0.0, vq = q < n ? V[rr * n + q] : 0.0;
+                    B[rr * n + i] = fma(aq, kap[i], A[rr * n + i] * c[i]);
+                    W[rr * n + i] = fma(vq, kap[i], V[rr * n + i] * c[i]);
+                }
+            for (int i = 0; i < n; ++i) {
+                const int q = par[i];
+                for (int j = 0; j < n; ++j) {
+                    const double bq = q < n ? B[q * n + j] : 0.0;
+                    A[i * n + j] = fma(kap[i], bq, c[i] * B[i * n + j]);
+                }
+            }
+            memcpy(V, W, sizeof(double) * (size_t)(n * n));
+        }
+    }
+    for (int i = 0; i < n; ++i) lam[i] = A[i * n + i];
+    return sweep;
+}
+
+static int cn_newton(cn_series *se, const cn_spec *o, const double *theta0, double *theta_out,
+                     cn_fitinfo *res)
+{
+    const int P = 3 + se->S + se->K;
+    const double epsilon = 1e-3, half_epsilon = 0.5 * epsilon;
+    const double pert[4] = {-2 * epsilon, -1 * epsilon, epsilon, 2 * epsilon};
+    const double coef[4] = {1.0 / 12.0, -2.0 / 3.0, 2.0 / 3.0, -1.0 / 12.0};
+    double th[CN_MAX_P], x[CN_MAX_P], g[CN_MAX_P], tg[CN_MAX_P], step[CN_MAX_P];
+    double A[CN_NEWTON_MAX_P * CN_NEWTON_MAX_P], H[CN_NEWTON_MAX_P * CN_NEWTON_MAX_P];
+    double V[CN_NEWTON_MAX_P * CN_NEWTON_MAX_P], lam[CN_NEWTON_MAX_P], proj[CN_NEWTON_MAX_P];
+    double f, lp, lastlp;
+    int it = 0, ret = TERM_MAXIT;
+    memcpy(th, theta0, sizeof(th));
+    se->n_eval = 0;
+    if (P > CN_NEWTON_MAX_P) {
+        memcpy(theta_out, theta0, sizeof(th));
+        res->status = CN_NEWTON_TOO_WIDE; res->n_iter = 0; res->n_eval = 0; res->f = 0.0;
+        return 0;
+    }
+    if (cn_eval(se, th, &f, g)) {
+        /* services/optimize/newton.hpp carries on with lp = -inf and the first
+         * grad_hess_log_prob throws: pystan raises RuntimeError */
+        memcpy(theta_out, theta0, sizeof(th));
+        res->status = CN_INIT_NONFINITE; res->n_iter = 0; res->n_eval = se->n_eval; res->f = f;
+        return 0;
+    }
+    lp = -f;
+    for (int mI = 0; mI < o->max_iter; ++mI) {
+        lastlp = lp;
+        /* ---- newton_step: grad_hess_log_prob ---- */
+        double f0;
+        if (cn_eval(se, th, &f, g)) { ret = CN_NEWTON_FAIL; break; }
+        f0 = -f;
+        int bad = 0;
+        for (int d = 0; d < P && !bad; ++d) {
+            double acc[CN_NEWTON_MAX_P];
+            for (int p = 0; p < P; ++p) acc[p] = 0.0;
+            for (int i = 0; i < 4; ++i) {
+                memcpy(x, th, sizeof(x));
+                x[d] = th[d] + pert[i];
+                double fp;
+                if (cn_eval(se, x, &fp, tg)) { bad = 1; break; }   /* Stan: exception leaves newton_step */
+                const double w = half_epsilon * coef[i];
+                for (int p = 0; p < P; ++p) acc[p] = fma(w, -tg[p], acc[p]);
+            }
+            for (int p = 0; p < P; ++p) A[d * P + p] = acc[p];
+        }
+        if (bad) { ret = CN_NEWTON_FAIL; break; }
+        for (int a = 0; a < P; ++a)
+            for (int b = 0; b < P; ++b) H[a * P + b] = A[a * P + b] + A[b * P + a];
+        /* ---- make_negative_definite_and_solve (gradient of lp = -g) ---- */
+        cn_jacobi(P, H, V, lam);
+        for (int j = 0; j < P; ++j) {
+            double a = 0.0;
+            for (int i = 0; i < P; ++i) a = fma(V[i * P + j], -g[i], a);
+            proj[j] = -a / fabs(lam[j]);
+        }
+        memset(step, 0, sizeof(step));
+        for (int i = 0; i < P; ++i) {
+            double a = 0.0;
+            for (int j = 0; j < P; ++j) a = fma(V[i * P + j], proj[j], a);
+            step[i] = a;
+        }
+        /* ---- step halving ---- */
+        double size = 2.0, f1 = -1e100;
+        int moved = 1;
+        memcpy(x, th, sizeof(x));
+        while (f1 < f0) {
+            size *= 0.5;
+            if (size < 1e-50) { moved = 0; break; }
+            for (int i = 0; i < P; ++i) x[i] = th[i] - size * step[i];
+            double fn;
+            f1 = cn_eval(se, x, &fn, tg) ? -1e100 : -fn;
+        }
+        it++;
+        if (moved) { memcpy(th, x, sizeof(th)); lp = f1; }
+        else lp = f0;
+        /* the first comparison in Stan is against the initial lp computed WITH the constant
+         * terms (log_prob<false,false>) and therefore never fires */
+        if (mI > 0 && fabs(lp - lastlp) < 1e-8) { ret = TERM_NEWTON_CONVERGED; break; }
+    }
+    memcpy(theta_out, th, sizeof(th));
+    res->status = ret; res->n_iter = it; res->n_eval = se->n_eval; res->f = -lp;
+    return 0;
+}
+
 /* ---- exported entry points (theta in ORIGINAL column order) ----------------------------- */
 
 static void to_internal(const cn_series *se, const double *th_orig, double *th_int)
@@ -1003,6 +1182,41 @@ int cn_fit(const cn_spec *sp, int T, const int64_t *ds, const double *y, double 
     if (tchange_out) memcpy(tchange_out, se->t_change, sizeof(double) * se->S);
     free_series(se);
     return 0;
+}
+
+/* Full fit with Stan's Newton optimiser (cn_newton).  Same outputs as cn_fit. */
+int cn_fit_newton(const cn_spec *sp, int T, const int64_t *ds, const double *y, double floor_,
+                  double cap, const double *extra, double *theta_out, double *tchange_out,
+                  cn_fitinfo *info)
+{
+    int err;
+    memset(info, 0, sizeof(*info));
+    cn_series *se = cn_prepare(sp, T, ds, y, floor_, cap, extra, &err);
+    if (!se) { info->status = err; return 0; }
+    fill_info(se, info);
+    double th0[CN_MAX_P], th[CN_MAX_P];
+    memset(th0, 0, sizeof(th0));
+    th0[0] = se->k0; th0[1] = se->m0; th0[2] = 0.0;
+    if (se->constant_y) {
+        memcpy(th, th0, sizeof(th));
+        th[2] = -20.72326583694641;
+        info->status = CN_CONSTANT; info->n_iter = 0; info->n_eval = 0; info->f = 0.0;
+    } else {
+        cn_newton(se, sp, th0, th, info);
+    }
+    to_original(se, th, theta_out);
+    if (tchange_out) memcpy(tchange_out, se->t_change, sizeof(double) * se->S);
+    free_series(se);
+    return 0;
+}
+
+/* Eigen-decomposition hook for tests: A [n][n] symmetric (copied), V [n][n], lam [n]. */
+int cn_jacobi_eigh(int n, const double *A_in, double *V, double *lam)
+{
+    double A[CN_NEWTON_MAX_P * CN_NEWTON_MAX_P];
+    if (n < 1 || n > CN_NEWTON_MAX_P) return -1;
+    memcpy(A, A_in, sizeof(double) * (size_t)(n * n));
+    return cn_jacobi(n, A, V, lam);
 }
 
 /* Point forecast.  theta original order; extra_future [n_extra][H]. */

@@ -240,3 +240,48 @@ def test_forecast_sensitivity_quadratic_form_within_the_optimisers_own_chaos():
     # both are the same kind of object: O(1e-4 .. 1e-2) trajectory noise
     assert np.median(form) < 50 * max(np.median(pert), 1e-6) or np.median(form) < 5e-3
     assert np.median(form) < 0.05
+
+
+def test_canonical_jacobi_eigensolver_against_lapack():
+    rng = np.random.default_rng(3)
+    for n in (1, 2, 7, 33, 34, 64):
+        M = rng.normal(size=(n, n))
+        A = M + M.T
+        if n == 34:
+            A[:, 5] = 0.0
+            A[5, :] = 0.0                                     # a flat direction (lambda = 0)
+        lam, V, sweeps = cl.jacobi_eigh(A)
+        assert sweeps <= 12
+        assert np.abs(np.sort(lam) - np.linalg.eigvalsh(A)).max() < 1e-12 * max(1.0, np.abs(A).max()) * n
+        assert np.abs(V @ np.diag(lam) @ V.T - A).max() < 1e-12 * n
+        assert np.abs(V.T @ V - np.eye(n)).max() < 1e-13 * n
+
+
+def test_newton_restatement_for_short_series():
+    """Stan's Newton (what fbprophet runs for T < 100), C oracle vs an independent numpy
+    statement of the same algorithm (different eigen-solver, different summation order): unlike
+    L-BFGS the iteration is not chaotic, the two agree to 1e-6.  It ends at a log-posterior at or
+    above L-BFGS's stopping point.  (Neither is pinned against real Stan: parity unpinned.)"""
+    import importlib.util
+    import os
+    from time_series_spark_amd import forecaster as fc, synth
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'dev', 'newton_vs_lbfgs.py')
+    spec_ = importlib.util.spec_from_file_location('newton_vs_lbfgs', path)
+    nv = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(nv)
+    ds, y = synth.make_panel(2, 60, 'linear', seed=751)
+    spec = fc.ModelSpec(growth='linear', seasonalities=fc.ModelSpec.auto_seasonalities(ds))
+    csp = helpers.oracle_spec(spec)
+    csp.eval_mode = 0
+    r = cl.fit_newton(csp, ds, y[0])
+    assert r['status_name'] == 'NEWTON_CONVERGED' and r['n_iter'] > 2
+    th, lp, it, ne, nh, lb = nv.newton(csp, ds, y[0], True)
+    assert abs(-r['f'] - lp) < 1e-5 and np.abs(th - r['theta']).max() < 1e-4
+    assert abs(r['n_iter'] - it) <= max(3, it // 10)
+    assert -r['f'] >= -lb['f'] - 1e-6                         # at least as good as L-BFGS's point
+    # the objective at the returned point is what the fit reports
+    f, g, rc = cl.eval_at(csp, ds, y[0], r['theta'])
+    assert rc == 0 and f == r['f']
+    # constant series: fbprophet skips optimisation whatever the algorithm
+    c = cl.fit_newton(csp, ds, np.full(60, 7.0))
+    assert c['status_name'] == 'CONSTANT'
