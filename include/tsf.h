@@ -59,6 +59,11 @@ enum { TSF_GROWTH_LINEAR = 0, TSF_GROWTH_LOGISTIC = 1 };
 enum { TSF_MODE_ADDITIVE = 0, TSF_MODE_MULTIPLICATIVE = 1 };
 enum { TSF_Y_F64 = 0, TSF_Y_F32 = 1, TSF_Y_I32 = 2 };
 enum { TSF_EVAL_AUTO = 0, TSF_EVAL_RESIDUAL = 1, TSF_EVAL_QUADRATIC = 2 };
+/* Which of Stan's optimisers runs the MAP fit.  fbprophet 0.5 chooses
+ * `'Newton' if T < 100 else 'LBFGS'` (TSF_ALGO_AUTO: decided per CALL from the longest series of
+ * the call -- callers split panels at 100 rows).  Default TSF_ALGO_LBFGS. */
+enum { TSF_ALGO_LBFGS = 0, TSF_ALGO_NEWTON = 1, TSF_ALGO_AUTO = 2 };
+#define TSF_NEWTON_BELOW_T 100
 
 /* per-series status: >= 0 are Stan's optimiser termination codes */
 enum {
@@ -66,6 +71,8 @@ enum {
     TSF_ST_ABSX = 10, TSF_ST_ABSF = 20, TSF_ST_RELF = 21, TSF_ST_ABSGRAD = 30,
     TSF_ST_RELGRAD = 31, TSF_ST_MAXIT = 40,
     TSF_ST_CONSTANT = 50,      /* constant y, linear growth: fbprophet skips optimisation */
+    TSF_ST_NEWTON_CONVERGED = 60, /* Newton: |lp - last lp| < 1e-8 */
+    TSF_ST_NEWTON_FAIL = -4,   /* Newton: log_prob threw inside the finite-difference Hessian */
     TSF_ST_LSFAIL = -1,        /* line search failed (pystan raises RuntimeError) */
     TSF_ST_INIT_NONFINITE = -2,/* log_prob non-finite at the initial point (RuntimeError) */
     TSF_ST_EVAL_LIMIT = -3,    /* > 64*max_iter+1024 evaluations: the line search never settled
@@ -106,6 +113,8 @@ typedef struct {
     int32_t eval_form;                      /* TSF_EVAL_AUTO */
     int32_t recenter_every;                 /* 128: re-centre at least every n accepted iterations */
     double recenter_ratio;                  /* 1.0: ... and when |Z D|^2 > ratio * s0 */
+    int32_t algorithm;                      /* TSF_ALGO_LBFGS */
+    int32_t reserved_;                      /* 0 */
 } tsf_spec;
 
 /* What setup derives from one timestamp vector ("grid").  One per call for aligned panels,

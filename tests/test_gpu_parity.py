@@ -292,6 +292,54 @@ def test_c_program_through_the_abi_matches_the_python_binding(env, tmp_path):
     assert n_bit_diff(theta[0][:3 + S], o['theta'][:3 + S]) == 0 and tail[0, 2] == o['n_eval']
 
 
+def test_newton_kernel_matches_oracle(env):
+    """Stan's Newton optimiser (fbprophet's choice for T < 100; tsf_newton_kernels.h) against the
+    oracle's cn_newton: same status, iteration and evaluation counts, identical theta bits --
+    aligned and ragged entry points, linear/additive and the reference's logistic/multiplicative
+    settings; TSF_ALGO_AUTO picks it by the length of the call's longest series."""
+    from time_series_spark_amd import _lib, synth
+    fc, cl = env
+    for growth, mode, T in (('linear', 'additive', 60), ('logistic', 'multiplicative', 90)):
+        ds, y = synth.make_panel(4, T, growth, seed=751)
+        seas = fc.ModelSpec.auto_seasonalities(ds, seasonality_mode=mode)
+        spec = fc.ModelSpec(growth=growth, seasonality_mode=mode, seasonalities=seas,
+                            algorithm=_lib.ALGO_NEWTON)
+        floor, cap = np.zeros(len(y)), y.max(axis=1) * 1.1
+        res = fc.fit_aligned(spec, ds, y, floor=floor, cap=cap)
+        csp = helpers.oracle_spec(spec)
+        for n in range(len(y)):
+            o = cl.fit_newton(csp, ds, y[n], floor[n], cap[n])
+            S = o['info'].S
+            assert (res.status[n], res.n_iter[n], res.n_eval[n]) == (o['status'], o['n_iter'], o['n_eval']), (growth, n)
+            assert n_bit_diff(res.theta[n][:3 + S], o['theta'][:3 + S]) == 0, (growth, n)
+            assert n_bit_diff(res.theta[n][3 + spec.n_changepoints:], o['theta'][3 + S:]) == 0
+            assert res.fval[n] == o['f']
+        assert (res.status == _lib.ST_NEWTON_CONVERGED).all()
+        # ragged: truncated copies, each its own grid (and its own number of changepoints)
+        cut = [T, T - 11, T - 25, 31]
+        off = np.concatenate([[0], np.cumsum(cut)]).astype(np.int64)
+        rr = fc.fit_ragged(spec, off, np.concatenate([ds[:c] for c in cut]),
+                           np.concatenate([y[i][:c] for i, c in enumerate(cut)]), floor=floor, cap=cap)
+        assert np.array_equal(rr.theta[0], res.theta[0]) and rr.n_eval[0] == res.n_eval[0]
+        for i in (1, 3):
+            o = cl.fit_newton(csp, ds[:cut[i]], y[i][:cut[i]], floor[i], cap[i])
+            S = o['info'].S
+            assert (rr.status[i], rr.n_iter[i], rr.n_eval[i]) == (o['status'], o['n_iter'], o['n_eval'])
+            assert n_bit_diff(rr.theta[i][:3 + S], o['theta'][:3 + S]) == 0
+    # fbprophet's rule: Newton below 100 rows, L-BFGS from 100 rows on
+    ds, y = synth.make_panel(3, 120, 'linear', seed=3)
+    auto = dict(growth='linear', seasonalities=[dict(helpers.WEEKLY)], algorithm=_lib.ALGO_AUTO)
+    long_ = fc.fit_aligned(fc.ModelSpec(**auto), ds, y)
+    short = fc.fit_aligned(fc.ModelSpec(**auto), ds[:99], y[:, :99])
+    assert (short.status == _lib.ST_NEWTON_CONVERGED).all() and (long_.status != _lib.ST_NEWTON_CONVERGED).all()
+    lb = fc.fit_aligned(fc.ModelSpec(growth='linear', seasonalities=[dict(helpers.WEEKLY)]), ds, y)
+    assert np.array_equal(long_.theta, lb.theta)
+    with pytest.raises(_lib.TsfError, match='Newton needs'):
+        fc.fit_aligned(fc.ModelSpec(growth='linear', seasonalities=[dict(helpers.YEARLY), dict(helpers.WEEKLY)],
+                                    extra=[{'name': 'x%d' % i} for i in range(12)], algorithm=_lib.ALGO_NEWTON),
+                       ds[:60], y[:, :60], extra=np.zeros((12, 60)))
+
+
 def test_batched_job_is_independent_of_how_series_are_grouped(env):
     """model_panel groups series that share a timestamp vector (aligned kernel path) and fits the
     rest through the ragged entry point; each series' model must be byte-identical to the one

@@ -21,13 +21,15 @@ GROWTH_LINEAR, GROWTH_LOGISTIC = 0, 1
 MODE_ADDITIVE, MODE_MULTIPLICATIVE = 0, 1
 Y_F64, Y_F32, Y_I32 = 0, 1, 2
 EVAL_AUTO, EVAL_RESIDUAL, EVAL_QUADRATIC = 0, 1, 2
+ALGO_LBFGS, ALGO_NEWTON, ALGO_AUTO = 0, 1, 2
 
 ST_ABSX, ST_ABSF, ST_RELF, ST_ABSGRAD, ST_RELGRAD, ST_MAXIT = 10, 20, 21, 30, 31, 40
 ST_CONSTANT, ST_LSFAIL, ST_INIT_NONFINITE, ST_TOO_FEW, ST_CAP = 50, -1, -2, -10, -11
 ST_EVAL_LIMIT = -3
+ST_NEWTON_CONVERGED, ST_NEWTON_FAIL = 60, -4
 STATUS_NAMES = {10: 'ABSX', 20: 'ABSF', 21: 'RELF', 30: 'ABSGRAD', 31: 'RELGRAD', 40: 'MAXIT',
                 50: 'CONSTANT', -1: 'LSFAIL', -2: 'INIT_NONFINITE', -3: 'EVAL_LIMIT', -10: 'TOO_FEW',
-                -11: 'CAP'}
+                -11: 'CAP', 60: 'NEWTON_CONVERGED', -4: 'NEWTON_FAIL'}
 
 
 class TsfSpec(ctypes.Structure):
@@ -47,7 +49,8 @@ class TsfSpec(ctypes.Structure):
                 ('tol_rel_obj', ctypes.c_double), ('tol_grad', ctypes.c_double),
                 ('tol_rel_grad', ctypes.c_double), ('tol_param', ctypes.c_double),
                 ('eval_form', ctypes.c_int32), ('recenter_every', ctypes.c_int32),
-                ('recenter_ratio', ctypes.c_double)]
+                ('recenter_ratio', ctypes.c_double),
+                ('algorithm', ctypes.c_int32), ('reserved_', ctypes.c_int32)]
 
 
 class TsfGridInfo(ctypes.Structure):

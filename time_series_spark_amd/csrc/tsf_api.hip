@@ -99,7 +99,9 @@ extern "C" void tsf_spec_default(tsf_spec *s)
     s->changepoint_prior_scale = 0.05;
     s->max_iter = 10000; s->history = 5; s->init_alpha = 1e-3; s->tol_obj = 1e-12;
     s->tol_rel_obj = 1e4; s->tol_grad = 1e-8; s->tol_rel_grad = 1e7; s->tol_param = 1e-8;
-    s->eval_form = TSF_EVAL_AUTO; s->recenter_every = 128; s->recenter_ratio = 1.0;
+    s->eval_form = TSF_EVAL_AUTO;
+    s->algorithm = TSF_ALGO_LBFGS;
+    s->reserved_ = 0; s->recenter_every = 128; s->recenter_ratio = 1.0;
 }
 
 extern "C" int tsf_spec_size(void) { return (int)sizeof(tsf_spec); }
@@ -137,6 +139,7 @@ static int build_devspec(tsf_ctx *ctx, const tsf_spec *s, DevSpec *d, int *mode_
     if (!(s->changepoint_prior_scale > 0.0)) return fail(ctx, "changepoint_prior_scale must be > 0");
     if (s->history < 1 || s->history > MAXH) return fail(ctx, "history must be in [1,8]");
     if (s->eval_form < TSF_EVAL_AUTO || s->eval_form > TSF_EVAL_QUADRATIC) return fail(ctx, "bad eval_form");
+    if (s->algorithm < TSF_ALGO_LBFGS || s->algorithm > TSF_ALGO_AUTO) return fail(ctx, "bad algorithm");
     if (s->eval_form != TSF_EVAL_RESIDUAL && (s->recenter_every < 1 || !(s->recenter_ratio > 0.0)))
         return fail(ctx, "recenter_every must be >= 1 and recenter_ratio > 0");
     const int K = tsf_spec_K(s);
@@ -248,6 +251,14 @@ static launch_tile_t pick_tile_launch(int growth, int mode)
     return tab[growth][mode];
 }
 
+typedef int (*launch_newton_t)(int, const FitArgs &, int, hipStream_t);
+static launch_newton_t pick_newton_launch(int growth, int mode)
+{
+    static const launch_newton_t tab[2][3] = {{launch_newton_g0m0, launch_newton_g0m1, launch_newton_g0m2},
+                                              {launch_newton_g1m0, launch_newton_g1m1, launch_newton_g1m2}};
+    return tab[growth][mode];
+}
+
 static launch_t pick_launch(int growth, int mode)
 {
     static const launch_t tab[2][3] = {{launch_g0m0, launch_g0m1, launch_g0m2},
@@ -279,8 +290,15 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     const int NTmax = (Tm + W - 1) / W;
     const int64_t n_grids = aligned ? 1 : N;
     // quadratic (Gram) form of the data term: see tsf_quad_kernels.h
+    // Stan's Newton optimiser (tsf_newton_kernels.h): explicitly, or by fbprophet's rule on the
+    // longest series of the call
+    const bool newton = theta_in == nullptr &&
+                        (spec->algorithm == TSF_ALGO_NEWTON ||
+                         (spec->algorithm == TSF_ALGO_AUTO && Tm < TSF_NEWTON_BELOW_T));
+    if (newton && (3 + hs.n_cp + hs.K > W || mode == 2 || hs.KP > 28))
+        return fail(ctx, "Newton needs 3 + n_changepoints + K <= 64 and all columns of one mode");
     const bool quad_ok = hs.growth == TSF_GROWTH_LINEAR && mode == 0 && hs.history == QH &&
-                         theta_in == nullptr;
+                         theta_in == nullptr && !newton;
     if (spec->eval_form == TSF_EVAL_QUADRATIC && !quad_ok && theta_in == nullptr)
         return fail(ctx, "eval_form QUADRATIC needs linear growth, additive columns only and history == 5");
     const bool quad = quad_ok && spec->eval_form != TSF_EVAL_RESIDUAL;
@@ -291,7 +309,7 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
         if (rc) return rc;
     }
     // shared lattice table: ragged panel, residual-form kernel, no explicit columns
-    if (aligned || quad || theta_in != nullptr || hs.n_extra > 0 || lat_step <= 0) lat_U = 0;
+    if (aligned || quad || newton || theta_in != nullptr || hs.n_extra > 0 || lat_step <= 0) lat_U = 0;
     const WsLayout l = ws_layout(N, n_grids, NTmax, hs.KP, qp.P4, qp.slots, quad && !aligned, lat_U);
     rc = ensure_ws(ctx, l.total);
     if (rc) return rc;
@@ -342,7 +360,9 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     const int slot = (int)(ctx->ev_count % TSF_PROFILE_RING);
     if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev0[slot], st));
     int lrc;
-    if (quad) {
+    if (newton) {
+        lrc = pick_newton_launch(hs.growth, mode)(hs.KP, a, (3 + hs.n_cp + hs.K) | 1, st);
+    } else if (quad) {
         QuadArgs qa;
         qa.f = a; qa.Mg = (const double *)(ws + l.Mg); qa.Mslot = (double *)(ws + l.Mslot);
         qa.rbuf = (double *)(ws + l.rbuf);

@@ -21,4 +21,11 @@ int launch_tile_g0m2(int KP, const FitArgs &a, int *counter, int n_cu, hipStream
 int launch_tile_g1m0(int KP, const FitArgs &a, int *counter, int n_cu, hipStream_t st);
 int launch_tile_g1m1(int KP, const FitArgs &a, int *counter, int n_cu, hipStream_t st);
 int launch_tile_g1m2(int KP, const FitArgs &a, int *counter, int n_cu, hipStream_t st);
+// newton_kernel (Stan's Newton optimiser; P <= 64, one explicit-mode kernels only)
+int launch_newton_g0m0(int KP, const FitArgs &a, int PM, hipStream_t st);
+int launch_newton_g0m1(int KP, const FitArgs &a, int PM, hipStream_t st);
+int launch_newton_g0m2(int KP, const FitArgs &a, int PM, hipStream_t st);
+int launch_newton_g1m0(int KP, const FitArgs &a, int PM, hipStream_t st);
+int launch_newton_g1m1(int KP, const FitArgs &a, int PM, hipStream_t st);
+int launch_newton_g1m2(int KP, const FitArgs &a, int PM, hipStream_t st);
 }  // namespace tsf

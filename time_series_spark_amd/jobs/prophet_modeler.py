@@ -122,7 +122,8 @@ def _spec_opts(kw):
     out = {}
     for k in ('n_changepoints', 'changepoint_range', 'changepoint_prior_scale',
               'seasonality_prior_scale', 'holidays_prior_scale', 'max_iter', 'history',
-              'init_alpha', 'tol_obj', 'tol_rel_obj', 'tol_grad', 'tol_rel_grad', 'tol_param'):
+              'init_alpha', 'tol_obj', 'tol_rel_obj', 'tol_grad', 'tol_rel_grad', 'tol_param',
+              'algorithm'):
         if k in kw:
             out[k] = kw[k]
     return out
