@@ -425,3 +425,54 @@ def test_c_abi_is_plain_c_and_host_stages_run_from_c(built, tmp_path):
                          '2020-01-01T00:00:00+00:00,7,1,2020-01-02,2020-01-02T00:00:00.000Z,9',
                          '2020-01-01T00:00:00+00:00,7,2,2020-01-01,2020-01-01T00:00:00.000Z,6',
                          '2020-01-01T00:00:00+00:00,7,2,2020-01-03,2020-01-03T00:00:00.000Z,5']
+
+
+def test_job_layer_follows_fbprophets_optimiser_rule(monkeypatch):
+    """Prophet.fit: Newton below 100 rows, L-BFGS from 100 rows on, and Newton once more for the
+    series whose L-BFGS run ended in a RuntimeError (UPSTREAM-RECALL fbprophet 0.5).
+    GPU calls replaced by recorders (the kernels themselves are compared with the oracle in
+    tests/test_gpu_parity.py)."""
+    calls = []
+
+    def result(spec, N, grid_n, status):
+        g = np.zeros(grid_n, dtype=_lib.GRID_DTYPE)
+        g['S'] = 3
+        return fc.FitResult(spec, np.zeros((N, spec.theta_stride)), np.ones(N), np.zeros(N),
+                            np.asarray(status, np.int32), np.ones(N, np.int32), np.ones(N, np.int32), g)
+
+    def fake_aligned(spec, ds_ns, y, floor=None, cap=None, extra=None, ctx=None, devices=None):
+        algo = spec.lbfgs.get('algorithm')
+        calls.append(('aligned', algo, y.shape))
+        st = np.full(len(y), 31 if algo == _lib.ALGO_LBFGS else 60)
+        if algo == _lib.ALGO_LBFGS:
+            st[0] = -1                                       # first series: line search failed
+        return result(spec, len(y), 1, st)
+
+    def fake_ragged(spec, offsets, ds_ns, y, floor=None, cap=None, extra=None, ctx=None, devices=None):
+        algo = spec.lbfgs.get('algorithm')
+        calls.append(('ragged', algo, tuple(np.diff(offsets))))
+        return result(spec, len(offsets) - 1, len(offsets) - 1, np.full(len(offsets) - 1, 60 if algo else 31))
+
+    monkeypatch.setattr(fc, 'fit_aligned', fake_aligned)
+    monkeypatch.setattr(fc, 'fit_ragged', fake_ragged)
+    day = np.datetime64('2020-01-01', 'ns') + np.arange(150).astype('timedelta64[D]')
+    rows = []
+    for sid, T in enumerate([150, 150, 150, 60, 60, 99]):
+        rows += [(sid, 1, d, 5 + (i * (sid + 1)) % 7) for i, d in enumerate(day[:T])]
+    df = pd.DataFrame(rows, columns=['series_id', 'dim_id', 'ds', 'y'])
+    cfg = {'model': {'floor': 0, 'cap_multiplier': 1.1, 'prophet': {'growth': 'linear', 'seasonality_mode': 'additive'}}}
+    out = pm.model_panel(cfg)(df)
+    assert len(out) == 6                                     # the failed L-BFGS series came back through Newton
+    assert calls == [('aligned', _lib.ALGO_LBFGS, (3, 150)),       # T >= 100 together
+                     ('ragged', _lib.ALGO_NEWTON, (150,)),         # ... retry of the RuntimeError
+                     ('aligned', _lib.ALGO_NEWTON, (2, 60)),       # T < 100: Newton, grouped by grid
+                     ('ragged', _lib.ALGO_NEWTON, (99,))]
+    (sd, pos, rec), = pk.load_models(list(out['model']))     # one spec for all: no optimiser in it
+    assert 'algorithm' not in sd['lbfgs'] and list(rec['status']) == [60, 31, 31, 60, 60, 60]
+    calls.clear()
+    cfg['model']['prophet']['algorithm'] = 'lbfgs'
+    out = pm.model_panel(cfg)(df)
+    assert len(out) == 4 and all(c[1] == _lib.ALGO_LBFGS for c in calls)   # one failure per aligned call, no retry
+    cfg['model']['prophet']['algorithm'] = 'bfgs'
+    with pytest.raises(ValueError):
+        pm.model_panel(cfg)(df)

@@ -27,6 +27,9 @@ MODEL_INPUT_SCHEMA = [('series_id', 'int32'), ('dim_id', 'int32'), ('start_time'
                       ('quantity', 'int32')]
 # prophet_modeler.py:32-38
 MODEL_OUTPUT_COLUMNS = ['series_id', 'dim_id', 'floor', 'cap', 'model']
+# fbprophet switches optimiser at this history length; these statuses are pystan RuntimeErrors
+NEWTON_BELOW_T = 100
+RUNTIME_ERROR_STATUS = (_lib.ST_LSFAIL, _lib.ST_INIT_NONFINITE, _lib.ST_EVAL_LIMIT)
 MODEL_OUTPUT_DTYPES = {'series_id': 'int32', 'dim_id': 'int32', 'floor': 'float32', 'cap': 'float32'}
 
 
@@ -73,19 +76,15 @@ def fit_packed(panel, floor, cap, kw, devices=None):
     blobs = [None] * N
     status = np.zeros(N, dtype=np.int32)
     last_ds = panel.ds_ns[panel.offsets[1:] - 1] if N else np.zeros(0, np.int64)
-    for key, (seas, members) in specs.items():
-        members = np.sort(np.asarray(members))
-        if not seas:
-            # fbprophet adds a zero column when there is no seasonality at all
-            spec = fc.ModelSpec(growth=growth, seasonality_mode=mode, seasonalities=[],
-                                extra=[{'name': 'zeros', 'prior_scale': 1.0, 'mode': 'additive'}],
-                                **_spec_opts(kw))
-        else:
-            spec = fc.ModelSpec(growth=growth, seasonality_mode=mode, seasonalities=seas,
-                                **_spec_opts(kw))
-        sd = spec.to_dict()
-        # series that share a timestamp vector are fitted together through the aligned entry
-        # point (one set of design tables for the group); the rest go in one ragged call
+    algo = str(kw.get('algorithm', 'auto')).lower()
+    if algo not in ('auto', 'lbfgs', 'newton'):
+        raise ValueError("algorithm must be 'auto', 'lbfgs' or 'newton'")
+    opts = _spec_opts(kw)
+
+    def run(spec, sd, seas, members):
+        """One optimiser over `members`: series that share a timestamp vector are fitted
+        together through the aligned entry point (one set of design tables for the group), the
+        rest go in one ragged call."""
         groups, rest = pk.group_by_grid(panel, members)
         calls = []
         for gm in groups:
@@ -115,6 +114,39 @@ def fit_packed(panel, floor, cap, kw, devices=None):
             # optimiser failure (pystan RuntimeError) or invalid input: no model for the series
             for i in np.flatnonzero(st >= 0):
                 blobs[mem[i]] = bl[i]
+
+    for key, (seas, members) in specs.items():
+        members = np.sort(np.asarray(members))
+        if not seas:
+            # fbprophet adds a zero column when there is no seasonality at all
+            model = dict(growth=growth, seasonality_mode=mode, seasonalities=[],
+                         extra=[{'name': 'zeros', 'prior_scale': 1.0, 'mode': 'additive'}])
+        else:
+            model = dict(growth=growth, seasonality_mode=mode, seasonalities=seas)
+        lbfgs = fc.ModelSpec(algorithm=_lib.ALGO_LBFGS, **model, **opts)
+        newton = fc.ModelSpec(algorithm=_lib.ALGO_NEWTON, **model, **opts)
+        sd = fc.ModelSpec(**model, **opts).to_dict()      # what predict needs: no optimiser choice
+        # fbprophet 0.5: optimizing(algorithm='Newton' if T < 100 else 'LBFGS'), and Newton once
+        # more after an L-BFGS RuntimeError (UPSTREAM-RECALL forecaster.py fit).  The
+        # Newton kernel holds one parameter per lane: wider models stay on L-BFGS.
+        modes = {s_.get('mode', mode) for s_ in seas}
+        newton_ok = 3 + lbfgs.n_changepoints + lbfgs.K <= 64 and lbfgs.K <= 28 and len(modes) <= 1
+        if algo == 'newton' and not newton_ok:
+            raise ValueError('algorithm newton needs 3 + n_changepoints + K <= 64 and one seasonality mode')
+        short = panel.lengths[members] < NEWTON_BELOW_T
+        if algo == 'newton':
+            first_newton, first_lbfgs = members, members[:0]
+        elif algo == 'auto' and newton_ok:
+            first_newton, first_lbfgs = members[short], members[~short]
+        else:
+            first_newton, first_lbfgs = members[:0], members
+        if len(first_lbfgs):
+            run(lbfgs, sd, seas, first_lbfgs)
+            failed = first_lbfgs[np.isin(status[first_lbfgs], RUNTIME_ERROR_STATUS)]
+            if len(failed) and newton_ok and algo == 'auto':
+                run(newton, sd, seas, failed)
+        if len(first_newton):
+            run(newton, sd, seas, first_newton)
     return blobs, status
 
 
@@ -122,8 +154,7 @@ def _spec_opts(kw):
     out = {}
     for k in ('n_changepoints', 'changepoint_range', 'changepoint_prior_scale',
               'seasonality_prior_scale', 'holidays_prior_scale', 'max_iter', 'history',
-              'init_alpha', 'tol_obj', 'tol_rel_obj', 'tol_grad', 'tol_rel_grad', 'tol_param',
-              'algorithm'):
+              'init_alpha', 'tol_obj', 'tol_rel_obj', 'tol_grad', 'tol_rel_grad', 'tol_param'):
         if k in kw:
             out[k] = kw[k]
     return out
