@@ -10,8 +10,8 @@
  *       /root/reference/src/jobs/prophet_modeler.py:56-66 (floor :56-57, cap :59-60,
  *       constructor :65, fit :66), i.e. fbprophet 0.5 setup_dataframe / set_changepoints /
  *       make_all_seasonality_features / *_growth_init and pystan 2.19.1.1
- *       StanModel.optimizing(algorithm='LBFGS') on prophet.stan -- for a whole panel of
- *       series in one call.
+ *       StanModel.optimizing(algorithm='LBFGS' | 'Newton', see tsf_spec.algorithm) on
+ *       prophet.stan -- for a whole panel of series in one call.
  *   tsf_predict (+ _dev)
  *       `model.predict(future_df)` + the int cast + floor clamp of
  *       /root/reference/src/jobs/prophet_scorer.py:64-84 (future frame :64-68, predict :70,
@@ -135,7 +135,7 @@ typedef struct {
     double *y_scale;        /* [N] */
     double *fval;           /* [N] -log posterior at the returned theta */
     int32_t *status;        /* [N] TSF_ST_* */
-    int32_t *n_iter;        /* [N] L-BFGS iterations */
+    int32_t *n_iter;        /* [N] L-BFGS / Newton iterations */
     int32_t *n_eval;        /* [N] log_prob+gradient evaluations */
     tsf_grid_info *grid;    /* [1] aligned, [N] ragged */
 } tsf_fit_out;
