@@ -7,6 +7,7 @@
                       cap = 1.1 max(y), multiplicative, auto seasonalities; 40 x 15min horizon as in
                       /root/reference/tests/unit/prophet_scorer_test.py:38-39).
   synthetic_cases.npz canonical-oracle outputs for the small synthetic cases of tests/helpers.CASES.
+  newton_cases.npz    canonical-oracle outputs of Stan's Newton optimiser on two short panels.
 
 PARITY UNPINNED: outputs come from the restated oracle, NOT from fbprophet/pystan (which cannot
 be installed here); the reference's tests pin no numeric value.
@@ -78,6 +79,37 @@ def synthetic():
     np.savez_compressed(os.path.join(HERE, 'synthetic_cases.npz'), **out)
 
 
+def newton_cases():
+    """Stan's Newton optimiser (fbprophet's choice below 100 rows) on two short panels:
+    newton_cases.npz = canonical-oracle (cn_newton) outputs.  Inputs are regenerated from the seed
+    by the tests (synth.make_panel(4, T, growth, seed=751))."""
+    from time_series_spark_amd import synth
+    out = {}
+    for growth, mode, T in (('linear', 'additive', 60), ('logistic', 'multiplicative', 90)):
+        ds, y = synth.make_panel(4, T, growth, seed=751)
+        seas = fc.ModelSpec.auto_seasonalities(ds, seasonality_mode=mode)
+        spec = fc.ModelSpec(growth=growth, seasonality_mode=mode, seasonalities=seas)
+        csp = helpers.oracle_spec(spec)
+        fut = ds[-1] + helpers.DAY_NS * np.arange(1, 31)
+        cap = y.max(axis=1) * 1.1
+        th, yh, it, ev, st = [], [], [], [], []
+        for n in range(4):
+            r = cl.fit_newton(csp, ds, y[n], 0.0, cap[n])
+            yo, _ = cl.predict(csp, r, fut, 0.0, cap[n])
+            pad = np.zeros(spec.theta_stride); S = r['info'].S
+            pad[:3 + S] = r['theta'][:3 + S]; pad[3 + spec.n_changepoints:] = r['theta'][3 + S:]
+            th.append(pad); yh.append(yo); it.append(r['n_iter']); ev.append(r['n_eval']); st.append(r['status'])
+        key = '%s_%d' % (growth, T)
+        out[key + '/theta'] = np.array(th); out[key + '/yhat'] = np.array(yh)
+        out[key + '/n_iter'] = np.array(it); out[key + '/n_eval'] = np.array(ev); out[key + '/status'] = np.array(st)
+        print('newton', key, 'iters', it, 'status', st)
+    np.savez_compressed(os.path.join(HERE, 'newton_cases.npz'), **out)
+
+
 if __name__ == '__main__':
-    fixture()
-    synthetic()
+    if len(sys.argv) > 1 and sys.argv[1] == 'newton':
+        newton_cases()
+    else:
+        fixture()
+        synthetic()
+        newton_cases()

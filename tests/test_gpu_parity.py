@@ -315,6 +315,13 @@ def test_newton_kernel_matches_oracle(env):
             assert n_bit_diff(res.theta[n][3 + spec.n_changepoints:], o['theta'][3 + S:]) == 0
             assert res.fval[n] == o['f']
         assert (res.status == _lib.ST_NEWTON_CONVERGED).all()
+        # committed golden vectors (oracle outputs, tests/golden/make_golden.py newton_cases)
+        gold = np.load(helpers.GOLDEN + '/newton_cases.npz')
+        key = '%s_%d' % (growth, T)
+        assert np.array_equal(res.theta, gold[key + '/theta']) and np.array_equal(res.n_eval, gold[key + '/n_eval'])
+        fut = ds[-1] + helpers.DAY_NS * np.arange(1, 31)
+        yhat = fc.predict(spec, res.theta, res.y_scale, res.grid, fut, floor=floor, cap=cap)
+        assert np.array_equal(yhat, gold[key + '/yhat'])
         # ragged: truncated copies, each its own grid (and its own number of changepoints)
         cut = [T, T - 11, T - 25, 31]
         off = np.concatenate([[0], np.cumsum(cut)]).astype(np.int64)

@@ -285,3 +285,19 @@ def test_newton_restatement_for_short_series():
     # constant series: fbprophet skips optimisation whatever the algorithm
     c = cl.fit_newton(csp, ds, np.full(60, 7.0))
     assert c['status_name'] == 'CONSTANT'
+
+
+def test_newton_golden_vectors_reproduce():
+    from time_series_spark_amd import forecaster as fc, synth
+    g = np.load(helpers.GOLDEN + '/newton_cases.npz')
+    for growth, mode, T in (('linear', 'additive', 60), ('logistic', 'multiplicative', 90)):
+        ds, y = synth.make_panel(4, T, growth, seed=751)
+        spec = fc.ModelSpec(growth=growth, seasonality_mode=mode,
+                            seasonalities=fc.ModelSpec.auto_seasonalities(ds, seasonality_mode=mode))
+        csp = helpers.oracle_spec(spec)
+        key = '%s_%d' % (growth, T)
+        n = 2
+        r = cl.fit_newton(csp, ds, y[n], 0.0, y[n].max() * 1.1)
+        yo, _ = cl.predict(csp, r, ds[-1] + helpers.DAY_NS * np.arange(1, 31), 0.0, y[n].max() * 1.1)
+        assert (r['n_iter'], r['n_eval'], r['status']) == (g[key + '/n_iter'][n], g[key + '/n_eval'][n], g[key + '/status'][n])
+        assert np.array_equal(yo, g[key + '/yhat'][n])
