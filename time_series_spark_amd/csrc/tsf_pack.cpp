@@ -85,21 +85,31 @@ struct KeyMap {
     }
 };
 
+// f(begin, end, thread_index) over static contiguous chunks.  An exception inside a worker
+// (allocation failure) is carried back to the caller as std::bad_alloc instead of terminating
+// the process.
 template <class F>
 void parallel_for(int64_t n, int n_threads, F f) {
-    // f(begin, end, thread_index); static contiguous chunks
     if (n_threads <= 1) {
         f((int64_t)0, n, 0);
         return;
     }
     std::vector<std::thread> th;
+    std::atomic<int> failed(0);
     int64_t per = (n + n_threads - 1) / n_threads;
     for (int t = 0; t < n_threads; ++t) {
         int64_t a = std::min<int64_t>(n, per * t), b = std::min<int64_t>(n, a + per);
         if (a >= b) break;
-        th.emplace_back([=] { f(a, b, t); });
+        th.emplace_back([=, &failed] {
+            try {
+                f(a, b, t);
+            } catch (...) {
+                failed.store(1);
+            }
+        });
     }
     for (auto &x : th) x.join();
+    if (failed.load()) throw std::bad_alloc();
 }
 
 // one packed row; stable scatter + stable sort keep ties in input order, so the input row
