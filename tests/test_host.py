@@ -476,3 +476,26 @@ def test_job_layer_follows_fbprophets_optimiser_rule(monkeypatch):
     cfg['model']['prophet']['algorithm'] = 'bfgs'
     with pytest.raises(ValueError):
         pm.model_panel(cfg)(df)
+
+
+def test_native_csv_reader_cuts_big_files_into_segments(tmp_path):
+    """One 10 MB file is parsed by several threads (cut at line ends); same rows, same order,
+    and a parse error deep inside still reports its line number in the file."""
+    n = 400000
+    rng = np.random.default_rng(9)
+    ts = pd.Timestamp('2015-01-01') + pd.to_timedelta(np.arange(n) * 900, unit='s')
+    q = rng.integers(0, 10 ** 6, n)
+    sid = rng.integers(1, 50, n)
+    text = '\n'.join('%d,7,%s,%d' % t for t in zip(sid, ts.strftime('%Y-%m-%d %H:%M:%S'), q)) + '\n'
+    f = tmp_path / 'big.csv'
+    f.write_text(text)
+    assert f.stat().st_size > 9 * 2 ** 20
+    for nt in (1, 4):
+        s, d, ds_ns, y = pm.read_model_input([str(f)], str(f), n_threads=nt)
+        assert np.array_equal(s, sid) and (d == 7).all() and np.array_equal(y, q.astype(float))
+        assert np.array_equal(ds_ns, ts.values.astype('datetime64[ns]').astype(np.int64))
+    lines = text.split('\n')
+    lines[n - 5] = lines[n - 5].replace('-', '/', 1)         # a bad timestamp near the end
+    f.write_text('\n'.join(lines))
+    with pytest.raises(ValueError, match='line %d ' % (n - 4)):
+        pm.read_model_input([str(f)], str(f), n_threads=4)

@@ -146,26 +146,10 @@ bool parse_quantity(const char *a, const char *b, double *out) {
 }
 
 // layout: one letter per column of the file: s series_id, d dim_id, t start_time, q quantity,
-// x ignored
-void parse_file(const char *path, const char *layout, int ncol, bool has_sid, int64_t sid_const,
-                FileCols &out) {
-    FILE *f = std::fopen(path, "rb");
-    if (!f) {
-        out.err = TSF_CSV_E_OPEN;
-        return;
-    }
-    std::fseek(f, 0, SEEK_END);
-    long sz = std::ftell(f);
-    std::fseek(f, 0, SEEK_SET);
-    std::vector<char> buf((size_t)(sz > 0 ? sz : 0) + 1);
-    size_t got = sz > 0 ? std::fread(buf.data(), 1, (size_t)sz, f) : 0;
-    std::fclose(f);
-    if ((long)got != (sz > 0 ? sz : 0)) {
-        out.err = TSF_CSV_E_OPEN;
-        return;
-    }
-    const char *p = buf.data(), *end = p + got;
-    size_t guess = got / 24 + 1;
+// x ignored.  Parses the lines of [p, end) (whole lines); line numbers in errors are relative to p.
+void parse_range(const char *p, const char *end, const char *layout, int ncol, int64_t sid_const,
+                 FileCols &out) {
+    size_t guess = (size_t)(end - p) / 24 + 1;
     out.did.reserve(guess);
     out.ds.reserve(guess);
     out.y.reserve(guess);
@@ -212,17 +196,65 @@ void parse_file(const char *path, const char *layout, int ncol, bool has_sid, in
         out.y.push_back(q);
         p = eol + 1;
     }
-    (void)has_sid;
 }
+
+bool read_whole(const char *path, std::vector<char> &buf) {
+    FILE *f = std::fopen(path, "rb");
+    if (!f) return false;
+    std::fseek(f, 0, SEEK_END);
+    long sz = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    if (sz < 0) sz = 0;
+    buf.resize((size_t)sz);
+    size_t got = sz > 0 ? std::fread(buf.data(), 1, (size_t)sz, f) : 0;
+    std::fclose(f);
+    return got == (size_t)sz;
+}
+
+// a file larger than this is cut at line ends into pieces parsed by different threads
+constexpr size_t SEGMENT_BYTES = (size_t)4 << 20;
+
+struct Segment {
+    int32_t file;
+    size_t begin, end;      // byte range of whole lines inside the file's buffer
+};
 
 }  // namespace
 
 struct tsf_csv {
-    std::vector<FileCols> files;
-    std::vector<int64_t> first;     // row offset of each file
+    std::vector<FileCols> files;    // one entry per SEGMENT, in file order then byte order
+    std::vector<int64_t> first;     // row offset of each segment
     int64_t n_rows = 0;
     int n_threads = 1;
 };
+
+namespace {
+
+template <class F>
+void run_workers(int n_threads, int64_t n_items, std::atomic<int> &oom, F item) {
+    std::atomic<int64_t> next(0);
+    auto worker = [&]() {
+        for (;;) {
+            int64_t i = next.fetch_add(1);
+            if (i >= n_items) break;
+            try {
+                item(i);
+            } catch (...) {
+                oom.store(1);
+            }
+        }
+    };
+    if (n_threads <= 1 || n_items < 2) {
+        worker();
+        return;
+    }
+    std::vector<std::thread> th;
+    int k = (int64_t)n_threads < n_items ? n_threads : (int)n_items;
+    for (int i = 0; i < k; ++i) th.emplace_back(worker);
+    for (auto &x : th) x.join();
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -246,51 +278,74 @@ int tsf_csv_read(int32_t n_files, const char *const *paths, const int64_t *serie
     tsf_csv *t = nullptr;
     try {
         t = new tsf_csv();
-        t->files.resize((size_t)n_files);
         int hw = (int)std::thread::hardware_concurrency();
         if (hw < 1) hw = 1;
         t->n_threads = n_threads > 0 ? n_threads : (hw < 32 ? hw : 32);
-        std::atomic<int32_t> next(0);
         std::atomic<int> oom(0);
-        auto worker = [&]() {
-            for (;;) {
-                int32_t i = next.fetch_add(1);
-                if (i >= n_files) break;
-                try {
-                    parse_file(paths[i], layout, ncol, has_s, series_id ? series_id[i] : 0,
-                               t->files[(size_t)i]);
-                } catch (...) {
-                    oom.store(1);
-                }
-            }
-        };
-        if (t->n_threads <= 1 || n_files < 2) {
-            worker();
-        } else {
-            std::vector<std::thread> th;
-            int k = t->n_threads < n_files ? t->n_threads : n_files;
-            for (int i = 0; i < k; ++i) th.emplace_back(worker);
-            for (auto &x : th) x.join();
-        }
+        // ---- phase 1: the files into memory (parallel)
+        std::vector<std::vector<char>> bufs((size_t)n_files);
+        std::vector<char> opened((size_t)n_files, 0);
+        run_workers(t->n_threads, n_files, oom, [&](int64_t i) {
+            opened[(size_t)i] = read_whole(paths[i], bufs[(size_t)i]) ? 1 : 0;
+        });
         if (oom.load()) {
             delete t;
             return -2;
         }
-        t->first.resize((size_t)n_files + 1);
-        int64_t pos = 0;
-        for (int32_t i = 0; i < n_files; ++i) {
-            const FileCols &fc = t->files[(size_t)i];
-            if (fc.err) {
+        for (int32_t i = 0; i < n_files; ++i)
+            if (!opened[(size_t)i]) {
                 if (err_file) *err_file = i;
-                if (err_line) *err_line = fc.err_line;
+                if (err_line) *err_line = 0;
+                delete t;
+                return TSF_CSV_E_OPEN;
+            }
+        // ---- segments: small files whole, big ones cut after a line end every SEGMENT_BYTES
+        std::vector<Segment> segs;
+        for (int32_t i = 0; i < n_files; ++i) {
+            const std::vector<char> &b = bufs[(size_t)i];
+            size_t at = 0;
+            while (b.size() - at > SEGMENT_BYTES + SEGMENT_BYTES / 2) {
+                const char *nl = (const char *)std::memchr(b.data() + at + SEGMENT_BYTES, '\n',
+                                                           b.size() - at - SEGMENT_BYTES);
+                if (!nl) break;
+                size_t stop = (size_t)(nl - b.data()) + 1;
+                segs.push_back(Segment{i, at, stop});
+                at = stop;
+            }
+            segs.push_back(Segment{i, at, b.size()});
+        }
+        t->files.resize(segs.size());
+        // ---- phase 2: parse (parallel over segments)
+        run_workers(t->n_threads, (int64_t)segs.size(), oom, [&](int64_t k) {
+            const Segment &sg = segs[(size_t)k];
+            const char *base = bufs[(size_t)sg.file].data();
+            parse_range(base + sg.begin, base + sg.end, layout, ncol,
+                        series_id ? series_id[sg.file] : 0, t->files[(size_t)k]);
+        });
+        if (oom.load()) {
+            delete t;
+            return -2;
+        }
+        t->first.resize(segs.size() + 1);
+        int64_t pos = 0;
+        for (size_t k = 0; k < segs.size(); ++k) {
+            const FileCols &fc = t->files[k];
+            if (fc.err) {
+                // line number inside the file = lines of the earlier segments + line in this one
+                const Segment &sg = segs[k];
+                const char *base = bufs[(size_t)sg.file].data();
+                int64_t before = 0;
+                for (const char *q = base; q < base + sg.begin; ++q) before += (*q == '\n');
+                if (err_file) *err_file = sg.file;
+                if (err_line) *err_line = before + fc.err_line;
                 int e = fc.err;
                 delete t;
                 return e;
             }
-            t->first[(size_t)i] = pos;
+            t->first[k] = pos;
             pos += (int64_t)fc.ds.size();
         }
-        t->first[(size_t)n_files] = pos;
+        t->first[segs.size()] = pos;
         t->n_rows = pos;
     } catch (const std::bad_alloc &) {
         delete t;
