@@ -8,7 +8,9 @@
 // (tests/fixtures/model-input/series_id=751/sample-model-input.csv: `91,2001-01-05 11:15:00,36445`).
 // The JVM reader hands Spark rows; this one parses straight into the four columns the packer
 // (tsf_pack_rows) takes: series_id, dim_id, ds [ns since the epoch], y [f64, NaN = null].
-// Files are parsed in parallel (one file at a time per thread) and come out in the order given.
+// The files are read into memory by a pool of threads, then parsed by the pool in segments
+// (a small file is one segment, a big one is cut at line ends every 4 MB); rows come out in
+// file order, files in the order given.
 #include <atomic>
 #include <cmath>
 #include <cstdint>
