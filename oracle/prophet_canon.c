@@ -94,6 +94,9 @@ enum { TERM_SUCCESS = 0, TERM_ABSX = 10, TERM_ABSF = 20, TERM_RELF = 21, TERM_AB
 
 typedef struct {
     int T, NT, S, K, Ka, P, growth;
+    int S_out;               /* changepoints the caller sees; S = 1 > S_out = 0 when the fit runs on
+                                fbprophet's dummy changepoint (set_changepoints: `changepoints_t =
+                                np.array([0.])` when there are none) */
     double *t, *y, *X;       /* X: [T][K] internal column order (additive first) */
     int *cidx;
     int perm[CN_MAX_P];      /* internal column -> original column */
@@ -258,8 +261,16 @@ static cn_series *cn_prepare(const cn_spec *sp, int T, const int64_t *ds, const 
     if (S + 1 > hist) S = hist - 1;
     if (S < 0) S = 0;
     if (S > CN_MAX_S) { *err = CN_ERR_SIZE; free_series(se); return NULL; }
+    se->S_out = S;
+    if (S == 0) {
+        /* fbprophet set_changepoints: no changepoints -> one dummy changepoint at t = 0.  The
+         * Stan model is fitted with S = 1 (delta_1 under the Laplace prior, A[:, 0] = 1 for every
+         * row); Prophet.fit then folds it away: k += delta, delta = 0 (to_original). */
+        S = 1;
+        se->t_change[0] = 0.0;
+    }
     se->S = S;
-    if (S > 0) {
+    if (se->S_out > 0) {
         const double step = (double)(hist - 1) / (double)S;
         for (int j = 1; j <= S; ++j) {
             double v = (j == S) ? (double)(hist - 1) : (double)j * step;
@@ -1086,22 +1097,27 @@ static int cn_newton(cn_series *se, const cn_spec *o, const double *theta0, doub
 
 /* ---- exported entry points (theta in ORIGINAL column order) ----------------------------- */
 
+/* Caller layout: [k, m, log sigma, delta[S_out], beta[K]] -- the dummy changepoint of a series
+ * without changepoints (S = 1, S_out = 0) has no slot there. */
 static void to_internal(const cn_series *se, const double *th_orig, double *th_int)
 {
     memset(th_int, 0, sizeof(double) * CN_MAX_P);
-    for (int p = 0; p < 3 + se->S; ++p) th_int[p] = th_orig[p];
-    for (int j = 0; j < se->K; ++j) th_int[3 + se->S + j] = th_orig[3 + se->S + se->perm[j]];
+    for (int p = 0; p < 3 + se->S_out; ++p) th_int[p] = th_orig[p];
+    for (int j = 0; j < se->K; ++j) th_int[3 + se->S + j] = th_orig[3 + se->S_out + se->perm[j]];
 }
 
-static void to_original(const cn_series *se, const double *th_int, double *th_orig)
+/* fold: fitted parameters -- Prophet.fit's `if len(self.changepoints) == 0: k = k + delta;
+ * delta = 0`; gradients are returned without their dummy-delta entry instead (fold = 0). */
+static void to_original(const cn_series *se, const double *th_int, double *th_orig, int fold)
 {
-    for (int p = 0; p < 3 + se->S; ++p) th_orig[p] = th_int[p];
-    for (int j = 0; j < se->K; ++j) th_orig[3 + se->S + se->perm[j]] = th_int[3 + se->S + j];
+    for (int p = 0; p < 3 + se->S_out; ++p) th_orig[p] = th_int[p];
+    if (fold && se->S_out == 0) th_orig[0] = th_int[0] + th_int[3];
+    for (int j = 0; j < se->K; ++j) th_orig[3 + se->S_out + se->perm[j]] = th_int[3 + se->S + j];
 }
 
 static void fill_info(const cn_series *se, cn_fitinfo *info)
 {
-    info->S = se->S; info->K = se->K; info->y_scale = se->y_scale; info->floor_ = se->floor_;
+    info->S = se->S_out; info->K = se->K; info->y_scale = se->y_scale; info->floor_ = se->floor_;
     info->cap_scaled = se->cap; info->start_ns = se->start_ns; info->t_scale_ns = se->tscale_ns;
 }
 
@@ -1133,7 +1149,7 @@ int cn_design(const cn_spec *sp, int T, const int64_t *ds, const double *y, doub
                 X_out[(size_t)i * se->K + se->perm[j]] = se->X[(size_t)i * se->K + j];
     if (t_out) memcpy(t_out, se->t, sizeof(double) * T);
     if (y_out) memcpy(y_out, se->y, sizeof(double) * T);
-    if (tchange_out) memcpy(tchange_out, se->t_change, sizeof(double) * se->S);
+    if (tchange_out) memcpy(tchange_out, se->t_change, sizeof(double) * se->S_out);
     if (init_out) { init_out[0] = se->k0; init_out[1] = se->m0; }
     free_series(se);
     return 0;
@@ -1150,7 +1166,7 @@ int cn_eval_at(const cn_spec *sp, int T, const int64_t *ds, const double *y, dou
     double th[CN_MAX_P], g[CN_MAX_P];
     to_internal(se, theta, th);
     const int rc = cn_eval(se, th, f_out, g);
-    to_original(se, g, g_out);
+    to_original(se, g, g_out, 0);
     free_series(se);
     return rc;
 }
@@ -1178,8 +1194,8 @@ int cn_fit(const cn_spec *sp, int T, const int64_t *ds, const double *y, double 
         cn_lbfgs(se, sp, th0, th, info);
         info->pad_ = se->n_resid;       /* residual-form evaluations (quadratic form only) */
     }
-    to_original(se, th, theta_out);
-    if (tchange_out) memcpy(tchange_out, se->t_change, sizeof(double) * se->S);
+    to_original(se, th, theta_out, 1);
+    if (tchange_out) memcpy(tchange_out, se->t_change, sizeof(double) * se->S_out);
     free_series(se);
     return 0;
 }
@@ -1204,8 +1220,8 @@ int cn_fit_newton(const cn_spec *sp, int T, const int64_t *ds, const double *y, 
     } else {
         cn_newton(se, sp, th0, th, info);
     }
-    to_original(se, th, theta_out);
-    if (tchange_out) memcpy(tchange_out, se->t_change, sizeof(double) * se->S);
+    to_original(se, th, theta_out, 1);
+    if (tchange_out) memcpy(tchange_out, se->t_change, sizeof(double) * se->S_out);
     free_series(se);
     return 0;
 }
@@ -1291,7 +1307,7 @@ int cn_fit_checked(const cn_spec *sp, int T, const int64_t *ds, const double *y,
     cn_lbfgs(se, sp, th0, th, info);
     info->pad_ = se->n_resid;
     chk_out[0] = se->chk_f; chk_out[1] = se->chk_g;
-    to_original(se, th, theta_out);
+    to_original(se, th, theta_out, 1);
     free_series(se);
     return 0;
 }

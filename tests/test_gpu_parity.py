@@ -100,21 +100,6 @@ def test_fit_predict_against_oracle_and_golden(env, case):
     assert np.array_equal(yint, np.maximum(np.trunc(yhat), floor[:, None]).astype(np.int32))
 
 
-@pytest.mark.parametrize('case', ['ref_logistic_multiplicative', 'cfg2_linear_additive@resid',
-                                  'cfg4_holidays', 'linear_multiplicative_365'])
-def test_experimental_tile_kernel_is_bit_identical(env, case, monkeypatch):
-    """The LDS tile-sharing residual kernel (csrc/tsf_tile_kernels.h, off unless TSF_TILE=1) must
-    give exactly what fit_kernel gives: same arithmetic, different data movement."""
-    fc, cl = env
-    spec, ds, y, floor, cap, extra, fut, exf = helpers.make_case(case, N=11)   # not a multiple of the 8 waves
-    r0 = fc.fit_aligned(spec, ds, y, floor=floor, cap=cap, extra=extra)
-    monkeypatch.setenv('TSF_TILE', '1')
-    r1 = fc.fit_aligned(spec, ds, y, floor=floor, cap=cap, extra=extra)
-    assert np.array_equal(r0.theta, r1.theta) and np.array_equal(r0.n_eval, r1.n_eval)
-    assert np.array_equal(r0.status, r1.status) and np.array_equal(r0.fval, r1.fval)
-    assert (r1.status > 0).all()
-
-
 def test_truncated_trajectories_match(env):
     """Same iterate after 1, 3, 10, 40 L-BFGS iterations: checks line search, two-loop
     recursion and the history ring step by step rather than only at the end."""
@@ -389,6 +374,9 @@ def test_odd_shapes_against_oracle(env):
             S = o['info'].S
             assert r.status[n] == o['status'] and r.n_iter[n] == o['n_iter'] and r.n_eval[n] == o['n_eval'], (n, o)
             assert n_bit_diff(r.theta[n][:3 + S], o['theta'][:3 + S]) == 0
+            assert not r.theta[n][3 + S:3 + spec.n_changepoints].any()                     # unused deltas
+            assert n_bit_diff(r.theta[n][3 + spec.n_changepoints:], o['theta'][3 + S:]) == 0   # beta
+            assert r.grid['S'][0] == S
         return r
 
     ds, y = synth.make_panel(3, 120, 'linear', seed=4)
@@ -396,6 +384,21 @@ def test_odd_shapes_against_oracle(env):
     check(fc.ModelSpec(growth='linear', seasonalities=one), ds, y[:1])                    # N = 1, K = 2
     check(fc.ModelSpec(growth='linear', seasonalities=one, n_changepoints=0), ds, y)      # S = 0
     check(fc.ModelSpec(growth='linear', seasonalities=one), ds[:2], y[:, :2])             # T = 2 -> S = 0
+    # no changepoints: fitted on fbprophet's dummy changepoint (one Laplace-penalised delta at
+    # t = 0, folded into k afterwards; oracle test_no_changepoints_is_fitted_on_...): every kernel
+    lg = dict(floor=np.zeros(3), cap=y.max(axis=1) * 1.2)
+    check(fc.ModelSpec(growth='logistic', seasonalities=[helpers.WEEKLY], n_changepoints=0), ds, y, **lg)
+    check(fc.ModelSpec(growth='logistic', seasonality_mode='multiplicative', seasonalities=[helpers.WEEKLY],
+                       n_changepoints=0), ds, y, **lg)
+    check(fc.ModelSpec(growth='linear', seasonalities=[helpers.WEEKLY], n_changepoints=0,
+                       eval_form=_lib.EVAL_RESIDUAL), ds, y)
+    r0 = check(fc.ModelSpec(growth='linear', seasonalities=[helpers.WEEKLY], n_changepoints=0), ds, y)
+    yh0 = fc.predict(fc.ModelSpec(growth='linear', seasonalities=[helpers.WEEKLY], n_changepoints=0),
+                     r0.theta, r0.y_scale, r0.grid, ds[-1] + helpers.DAY_NS * np.arange(1, 8))
+    c0 = cl.make_spec(n_changepoints=0, seasonalities=[(7, 3, 'additive', 10.0)], eval_mode=1)
+    for n in range(3):
+        o = cl.fit(c0, ds, y[n])
+        assert np.array_equal(yh0[n], cl.predict(c0, o, ds[-1] + helpers.DAY_NS * np.arange(1, 8))[0])
     check(fc.ModelSpec(growth='linear', seasonalities=one), ds[:5], y[:, :5])             # T = 5 -> S = 3
     check(fc.ModelSpec(growth='linear', seasonalities=[helpers.WEEKLY], history=3), ds, y)   # residual kernel
     check(fc.ModelSpec(growth='linear', seasonalities=[helpers.WEEKLY], max_iter=7), ds, y)
@@ -475,6 +478,68 @@ def test_full_size_other_baseline_configs(env, cfg):
         assert r.n_iter[n] == o['n_iter'] and r.n_eval[n] == o['n_eval'] and r.status[n] == o['status']
         assert np.max(np.abs(yh[i] - yo) / np.abs(yo)) <= REL_TOL
         assert np.array_equal(yh[i], yo)
+
+
+def test_full_size_cfg4_logistic_holidays(env):
+    """BASELINE config 4 at full size (50 000 x 730, logistic growth + floor, multiplicative
+    yearly + weekly, 25 changepoints, 10 holidays x window [-1, +1] = 30 indicator columns, P = 84:
+    the two-slot residual kernel): every series ends in one of Stan's termination codes (or, for a
+    handful, a failed line search / iteration cap -- what pystan reports too), forecasts finite and
+    inside (floor, cap * (1 + multiplicative terms)), and a random sample is bit-identical to the
+    oracle, forecasts included."""
+    fc, cl = env
+    from time_series_spark_amd import synth
+    N, T, H = 50000, 730, 90
+    ds = synth.daily_grid(T)
+    fut = ds[-1] + helpers.DAY_NS * np.arange(1, H + 1)
+    allm, names = synth.holiday_matrix(np.concatenate([ds, fut]), 10)
+    extra, exf = np.ascontiguousarray(allm[:, :T]), np.ascontiguousarray(allm[:, T:])
+    ds, y = synth.make_panel(N, T, 'logistic', seed=751, holidays=extra)
+    spec = fc.ModelSpec(growth='logistic', seasonality_mode='multiplicative',
+                        seasonalities=[helpers.YEARLY, helpers.WEEKLY], extra=[{'name': n} for n in names])
+    assert spec.K == 56 and spec.theta_stride == 84
+    floor, cap = np.zeros(N), y.max(axis=1) * 1.1
+    r = fc.fit_aligned(spec, ds, y, floor=floor, cap=cap, extra=extra)
+    bad = r.status <= 0
+    assert bad.sum() <= N // 5000 and np.isin(r.status[bad], [-1, -3]).all() and (r.n_iter >= 1).all()
+    assert np.isin(r.status[~bad], [10, 20, 21, 30, 31, 40]).all()
+    yh = fc.predict(spec, r.theta, r.y_scale, r.grid, fut, floor=floor, cap=cap, extra_future=exf)
+    assert np.isfinite(yh[~bad]).all()
+    sub = np.random.default_rng(4).choice(np.flatnonzero(~bad & (r.n_eval < 3000)), 6, replace=False)
+    csp = helpers.oracle_spec(spec)
+    for n in sub:
+        o = cl.fit(csp, ds, y[n], floor[n], cap[n], extra)
+        yo, _ = cl.predict(csp, o, fut, floor[n], cap[n], exf)
+        assert (r.n_iter[n], r.n_eval[n], r.status[n]) == (o['n_iter'], o['n_eval'], o['status'])
+        assert np.max(np.abs(yh[n] - yo) / np.abs(yo)) <= REL_TOL
+        assert np.array_equal(yh[n], yo) and n_bit_diff(r.fval[n], o['f']) == 0
+
+
+def test_upstream_known_answer_vectors_through_predict_kernel(env):
+    """fbprophet's own piecewise_linear / piecewise_logistic known-answer vectors
+    (tests/golden/upstream_recall.json) through tsf_predict: scaled time = days, y_scale 1,
+    one all-zero design column."""
+    fc, cl = env
+    import json
+    from time_series_spark_amd import _lib
+    with open(helpers.GOLDEN + '/upstream_recall.json') as fh:
+        up = json.load(fh)
+    for growth, key in (('linear', 'piecewise_linear'), ('logistic', 'piecewise_logistic')):
+        u = up[key]
+        spec = fc.ModelSpec(growth=growth, n_changepoints=len(u['deltas']), extra=[{'name': 'zero'}])
+        theta = np.concatenate([[u['k'], u['m'], 0.0], u['deltas'], [0.0]])[None, :]
+        grid = np.zeros(1, dtype=_lib.GRID_DTYPE)
+        grid['start_ns'], grid['t_scale_ns'], grid['T'], grid['S'] = 0, helpers.DAY_NS, 11, len(u['deltas'])
+        grid['NT'] = 1
+        grid['t_change'][0, :len(u['deltas'])] = u['changepoint_ts']
+        fut = np.asarray(u['t'], dtype=np.int64) * helpers.DAY_NS
+        yh = fc.predict(spec, theta, np.ones(1), grid, fut, floor=np.zeros(1), cap=np.full(1, u.get('cap', 1.0)),
+                        extra_future=np.zeros((1, len(fut))))[0]
+        y_true = np.asarray(u['y_true'])
+        if growth == 'linear':
+            assert np.array_equal(yh, y_true)
+        else:
+            assert abs((yh - y_true).sum()) < 0.5e-5 and np.max(np.abs(yh - y_true)) < 0.6e-6
 
 
 def test_reference_contract_fit_and_forecast_udfs(env, tmp_path):

@@ -301,3 +301,173 @@ def test_newton_golden_vectors_reproduce():
         yo, _ = cl.predict(csp, r, ds[-1] + helpers.DAY_NS * np.arange(1, 31), 0.0, y[n].max() * 1.1)
         assert (r['n_iter'], r['n_eval'], r['status']) == (g[key + '/n_iter'][n], g[key + '/n_eval'][n], g[key + '/status'][n])
         assert np.array_equal(yo, g[key + '/yhat'][n])
+
+
+# ---------------------------------------------------------------------------------------------
+# fbprophet's own known-answer vectors (tests/golden/upstream_recall.json, provenance inside)
+# ---------------------------------------------------------------------------------------------
+
+def _upstream():
+    import json
+    import os
+    with open(os.path.join(helpers.GOLDEN, 'upstream_recall.json')) as fh:
+        return json.load(fh)
+
+
+def _canon_trend(kind, u):
+    """cn_predict (oracle/prophet_canon.c) on an upstream trend vector: scaled time = days,
+    y_scale 1, floor 0, one all-zero design column (fbprophet's own filler when K would be 0)."""
+    sp = cl.make_spec(growth=kind, n_changepoints=len(u['deltas']), extra=[('additive', 10.0)])
+    info = cl.CnFitInfo()
+    info.S, info.K, info.y_scale, info.floor_ = len(u['deltas']), 1, 1.0, 0.0
+    info.start_ns, info.t_scale_ns = 0, helpers.DAY_NS
+    theta = np.concatenate([[u['k'], u['m'], 0.0], u['deltas'], [0.0]])
+    ds = (np.asarray(u['t'], dtype=np.int64) * helpers.DAY_NS)
+    fitres = {'theta': theta, 't_change': np.asarray(u['changepoint_ts'], dtype=np.float64), 'info': info}
+    yhat, trend = cl.predict(sp, fitres, ds, 0.0, u.get('cap', 0.0), extra_future=np.zeros((1, len(ds))))
+    assert np.array_equal(yhat, trend)
+    return yhat
+
+
+def test_upstream_known_answer_vectors_trend_functions():
+    from oracle.fbprophet_restated import piecewise_linear, piecewise_logistic
+    up = _upstream()
+    u = up['piecewise_linear']
+    t = np.asarray(u['t'], dtype=np.float64)
+    y_true = np.asarray(u['y_true'])
+    lit = piecewise_linear(t, np.asarray(u['deltas']), u['k'], u['m'], np.asarray(u['changepoint_ts']))
+    assert (lit - y_true).sum() == 0.0 and np.array_equal(lit, y_true)
+    assert np.array_equal(piecewise_linear(t[8:], np.asarray(u['deltas']), u['k'], u['m'],
+                                           np.asarray(u['changepoint_ts'])), y_true[8:])
+    assert np.array_equal(_canon_trend('linear', u), y_true)            # exact: halves and integers
+    u = up['piecewise_logistic']
+    y_true = np.asarray(u['y_true'])
+    lit = piecewise_logistic(t, np.full(len(t), u['cap']), np.asarray(u['deltas']), u['k'], u['m'],
+                             np.asarray(u['changepoint_ts']))
+    assert abs((lit - y_true).sum()) < 0.5e-5                           # upstream's assertion
+    assert np.max(np.abs(lit - y_true)) < 0.6e-6                        # the vector has 6 decimals
+    can = _canon_trend('logistic', u)
+    assert abs((can - y_true).sum()) < 0.5e-5 and np.max(np.abs(can - y_true)) < 0.6e-6
+    assert np.max(np.abs(can - lit) / lit) <= 4 * ULP
+
+
+def test_upstream_known_answer_vectors_fourier_series():
+    up = _upstream()
+    for key in ('fourier_series_weekly', 'fourier_series_yearly'):
+        u = up[key]
+        ds = pd.date_range(u['first_date'], periods=5, freq='D')
+        true = np.asarray(u['row0'])
+        lit = fourier_series(ds, u['period'], u['order'])
+        assert lit.shape == (5, 2 * u['order'])
+        assert np.sum((lit[0] - true) ** 2) < 1e-13                      # the vectors have 7 digits
+        # the canonical C oracle's design row for the same date (det_sincos, internal order undone)
+        sp = cl.make_spec(seasonalities=[(u['period'], u['order'], 'additive', 10.0)])
+        des = cl.design(sp, ds.asi8, np.arange(5.0))
+        assert np.sum((des['X'][0] - true) ** 2) < 1e-13
+        assert np.max(np.abs(des['X'] - lit)) <= 2 * ULP
+
+
+def test_upstream_auto_weekly_seasonality_and_zero_changepoints():
+    from time_series_spark_amd import forecaster as fc
+    up = _upstream()
+    u = up['auto_weekly_seasonality']
+    for rows, on in ((u['daily_rows_on'], True), (u['daily_rows_off'], False)):
+        ds = pd.date_range('2012-05-18', periods=rows, freq='D')
+        m = ProphetOracle()
+        m.stan_data(pd.DataFrame({'ds': ds, 'y': np.arange(float(rows))}))
+        assert ('weekly' in m.seasonalities) == on
+        prod = fc.ModelSpec.auto_seasonalities(ds.asi8)                  # the product's host rule
+        assert ([s['name'] for s in prod] == ['weekly']) == on
+        if on:
+            s = m.seasonalities['weekly']
+            assert (s['period'], s['fourier_order'], s['prior_scale'], s['mode']) == \
+                   (u['spec']['period'], u['spec']['fourier_order'], u['spec']['prior_scale'], u['spec']['mode'])
+            assert (prod[0]['period'], prod[0]['fourier_order']) == (7, 3)
+    z = up['zero_changepoints']
+    m = ProphetOracle(n_changepoints=z['n_changepoints'])
+    m.stan_data(pd.DataFrame({'ds': pd.date_range('2012-05-18', periods=60, freq='D'), 'y': np.arange(60.0)}))
+    assert m.changepoints_t.shape[0] == 1 and m.changepoints_t[0] == z['changepoints_t'][0]
+
+
+def test_upstream_constant_history_forecasts_the_constant():
+    up = _upstream()['constant_history']
+    ds = pd.date_range('2012-05-18', periods=up['rows'], freq='D').asi8
+    sp = cl.make_spec(seasonalities=[(365.25, 10, 'additive', 10.0), (7, 3, 'additive', 10.0)])
+    for c in up['y']:
+        o = cl.fit(sp, ds, np.full(len(ds), c))
+        assert o['status_name'] == 'CONSTANT'
+        fut = ds[-1] + helpers.DAY_NS * np.arange(1, 31)
+        yhat, _ = cl.predict(sp, o, fut)
+        assert abs(yhat[-1] - c) < 1e-7                                  # assertAlmostEqual: 7 places
+
+
+# ---------------------------------------------------------------------------------------------
+# cn_predict against the literal Prophet.predict restatement; the dummy changepoint
+# ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize('case', ['cfg2_linear_additive', 'ref_logistic_multiplicative',
+                                  'linear_multiplicative_365', 'logistic_additive_400', 'cfg4_holidays'])
+def test_canonical_predict_matches_literal_predict(case):
+    """cn_predict (what the GPU predict_kernel is compared with bit for bit) == the method-by-method
+    restatement of Prophet.predict at the SAME parameters, to a few ulp of the forecast."""
+    m, dat, th0, (spec, ds, y, floor, cap, extra, fut, exf) = _literal(case)
+    csp = helpers.oracle_spec(spec)
+    o = cl.fit(csp, ds, y[0], floor[0], cap[0], extra)
+    S, K = dat['S'], dat['K']
+    assert (o['info'].S, o['info'].K) == (S, K)
+    df = pd.DataFrame({'ds': pd.to_datetime(ds), 'y': y[0]})
+    if spec.growth == 'logistic':
+        df['floor'], df['cap'] = floor[0], cap[0]
+    m2 = type(m)(growth=spec.growth, seasonality_mode=spec.seasonality_mode,
+                 yearly_seasonality=m.yearly_seasonality, weekly_seasonality=True, daily_seasonality=False,
+                 holidays=m.holidays)
+    m2.fit(df, optimizer=lambda dat_, th0_, **kw: (o['theta'].copy(), {'status': o['status']}))
+    fdf = pd.DataFrame({'ds': pd.to_datetime(fut)})
+    if spec.growth == 'logistic':
+        fdf['floor'], fdf['cap'] = floor[0], cap[0]
+    lit = m2.predict(fdf)
+    yhat, trend = cl.predict(csp, o, fut, floor[0], cap[0], exf)
+    assert np.max(np.abs(yhat - lit['yhat'].values) / np.abs(lit['yhat'].values)) <= 16 * ULP
+    assert np.max(np.abs(trend - lit['trend'].values) / np.abs(lit['trend'].values)) <= 16 * ULP
+
+
+@pytest.mark.parametrize('growth', ['linear', 'logistic'])
+def test_no_changepoints_is_fitted_on_fbprophets_dummy_changepoint(growth):
+    """with no changepoints fbprophet fits S = 1 on a dummy changepoint at t = 0
+    (one Laplace-penalised delta that is 1 on every row) and folds it into k afterwards.  The
+    canonical oracle does the same: per-evaluation parity with the literal restatement at
+    delta != 0, and the folded k of a fit."""
+    from time_series_spark_amd import synth
+    T = 120
+    ds, y = synth.make_panel(2, T, growth, seed=5)
+    cap = float(y[0].max() * 1.1)
+    m = ProphetOracle(growth=growth, n_changepoints=0, yearly_seasonality=False, weekly_seasonality=True,
+                      daily_seasonality=False)
+    df = pd.DataFrame({'ds': pd.to_datetime(ds), 'y': y[0]})
+    if growth == 'logistic':
+        df['floor'], df['cap'] = 0.0, cap
+    dat, th0 = m.stan_data(df)
+    assert dat['S'] == 1 and dat['t_change'][0] == 0.0 and np.all(dat['A'] == 1.0)
+    sp = cl.make_spec(growth=growth, n_changepoints=0, seasonalities=[(7, 3, 'additive', 10.0)])
+    des = cl.design(sp, ds, y[0], 0.0, cap)
+    assert des['info'].S == 0 and len(des['t_change']) == 0             # what the caller sees
+    # evaluation at delta = 0 (the caller layout has no slot for the dummy delta)
+    rng = np.random.default_rng(3)
+    th = th0 + rng.normal(0, 0.02, th0.size)
+    th[3] = 0.0
+    f1, g1 = stan_neg_log_prob_grad(dat, th)
+    f2, g2, rc = cl.eval_at(sp, ds, y[0], np.delete(th, 3), 0.0, cap)
+    assert rc == 0 and abs(f1 - f2) <= 1e-12 * abs(f1)
+    assert np.max(np.abs(np.delete(g1, 3) - g2) / (1 + np.abs(np.delete(g1, 3)))) <= 1e-11
+    # a short fit moves delta away from 0: compare with the literal model driven by the literal
+    # optimiser restatement (stan_lbfgs.c) after the same few iterations (trajectories agree to
+    # rounding before the chaos of long runs sets in), folded k included
+    sp3 = cl.make_spec(growth=growth, n_changepoints=0, seasonalities=[(7, 3, 'additive', 10.0)], max_iter=3)
+    o = cl.fit(sp3, ds, y[0], 0.0, cap)
+    assert len(o['theta']) == 3 + 0 + 6
+    th_lit, info = oracle_lib.stan_lbfgs(dat, th0, max_iter=3)
+    assert abs(th_lit[3]) > 1e-9                                         # the dummy delta was active
+    folded = np.concatenate([[th_lit[0] + th_lit[3]], th_lit[1:3], th_lit[4:]])
+    assert np.max(np.abs(o['theta'] - folded) / (1e-3 + np.abs(folded))) <= 1e-7
+    # and the fit without the dummy changepoint would have been a different model
+    assert abs(th_lit[3]) > 100 * np.max(np.abs(o['theta'] - folded))

@@ -118,9 +118,13 @@ extern "C" int tsf_theta_stride(const tsf_spec *s) { return 3 + s->n_changepoint
 
 // ---- spec validation + device form ---------------------------------------------------------
 
+// parameters of the FIT: with no changepoints the model is fitted on one dummy changepoint
+// (GridTab::S_fit), so there is always at least one delta
+static int fit_P(int n_cp, int K) { return 3 + (n_cp > 0 ? n_cp : 1) + K; }
+
 static int pick_KP(int K, int n_cp, int mixed)
 {
-    const int P = 3 + n_cp + K;
+    const int P = fit_P(n_cp, K);
     if (mixed || P > 64) return 64;
     if (K <= 8) return 8;
     if (K <= 16) return 16;
@@ -144,7 +148,7 @@ static int build_devspec(tsf_ctx *ctx, const tsf_spec *s, DevSpec *d, int *mode_
         return fail(ctx, "recenter_every must be >= 1 and recenter_ratio > 0");
     const int K = tsf_spec_K(s);
     if (K < 1) return fail(ctx, "model needs at least one design column (fbprophet adds a zero column; pass one extra column of zeros)");
-    if (K > TSF_MAX_K || 3 + s->n_changepoints + K > TSF_MAX_P) return fail(ctx, "too many parameters (3+S+K must be <= 128, K <= 64)");
+    if (K > TSF_MAX_K || fit_P(s->n_changepoints, K) > TSF_MAX_P) return fail(ctx, "too many parameters (3+S+K must be <= 128, K <= 64)");
     memset(d, 0, sizeof(*d));
     int mode[TSF_MAX_P];
     double pr[TSF_MAX_P];
@@ -225,7 +229,7 @@ static int ensure_ws(tsf_ctx *ctx, size_t bytes)
 // grid / LDS plan of the quadratic-form kernel for this device
 static int quad_plan(tsf_ctx *ctx, const DevSpec &hs, int64_t N, QuadPlan *qp)
 {
-    const int P = 3 + hs.n_cp + hs.K;
+    const int P = fit_P(hs.n_cp, hs.K);
     qp->PPL = (hs.KP == 64) ? 2 : 1;
     // rows of M the kernel walks: compile-time 40 / 56 / 64 for the one-slot kernels (zero rows
     // beyond P are bit-neutral), P rounded up to 4 for the two-slot kernel
@@ -242,15 +246,6 @@ static int quad_plan(tsf_ctx *ctx, const DevSpec &hs, int64_t N, QuadPlan *qp)
 }
 
 typedef int (*launch_t)(int, const FitArgs &, int, hipStream_t);
-typedef int (*launch_tile_t)(int, const FitArgs &, int *, int, hipStream_t);
-
-static launch_tile_t pick_tile_launch(int growth, int mode)
-{
-    static const launch_tile_t tab[2][3] = {{launch_tile_g0m0, launch_tile_g0m1, launch_tile_g0m2},
-                                            {launch_tile_g1m0, launch_tile_g1m1, launch_tile_g1m2}};
-    return tab[growth][mode];
-}
-
 typedef int (*launch_newton_t)(int, const FitArgs &, int, hipStream_t);
 static launch_newton_t pick_newton_launch(int growth, int mode)
 {
@@ -295,7 +290,7 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     const bool newton = theta_in == nullptr &&
                         (spec->algorithm == TSF_ALGO_NEWTON ||
                          (spec->algorithm == TSF_ALGO_AUTO && Tm < TSF_NEWTON_BELOW_T));
-    if (newton && (3 + hs.n_cp + hs.K > W || mode == 2 || hs.KP > 28))
+    if (newton && (fit_P(hs.n_cp, hs.K) > W || mode == 2 || hs.KP > 28))
         return fail(ctx, "Newton needs 3 + n_changepoints + K <= 64 and all columns of one mode");
     const bool quad_ok = hs.growth == TSF_GROWTH_LINEAR && mode == 0 && hs.history == QH &&
                          theta_in == nullptr && !newton;
@@ -361,7 +356,7 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev0[slot], st));
     int lrc;
     if (newton) {
-        lrc = pick_newton_launch(hs.growth, mode)(hs.KP, a, (3 + hs.n_cp + hs.K) | 1, st);
+        lrc = pick_newton_launch(hs.growth, mode)(hs.KP, a, fit_P(hs.n_cp, hs.K) | 1, st);
     } else if (quad) {
         QuadArgs qa;
         qa.f = a; qa.Mg = (const double *)(ws + l.Mg); qa.Mslot = (double *)(ws + l.Mslot);
@@ -371,14 +366,6 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
         qa.dbg = nullptr;
         HIP_TRY(ctx, hipMemsetAsync(qa.counter, 0, sizeof(int), st));
         lrc = launch_quad(hs.KP, qp, qa, (double *)(ws + l.Mg), st);
-    } else if (aligned && theta_in == nullptr && getenv("TSF_TILE")) {
-        // EXPERIMENT (off by default, TSF_TILE=1): aligned panel, residual form, persistent
-        // workgroups sharing the design tiles in LDS.  Bit-identical to fit_kernel, but measured
-        // SLOWER on cfg2 (92 ms vs 64 ms): one workgroup barrier per step
-        // serialises eight latency-bound waves.
-        int *cnt = (int *)(ws + l.counter);
-        HIP_TRY(ctx, hipMemsetAsync(cnt, 0, sizeof(int), st));
-        lrc = pick_tile_launch(hs.growth, mode)(hs.KP, a, cnt, ctx->n_cu, st);
     } else {
         lrc = pick_launch(hs.growth, mode)(hs.KP, a, theta_in != nullptr, st);
     }

@@ -49,9 +49,15 @@ __global__ void setup_grid_kernel(const DevSpec *__restrict__ sp, int n_grids,
     int S = sp->n_cp;
     if (S + 1 > hist) S = hist - 1;
     if (S < 0) S = 0;
+    const int S_out = S;
     if (threadIdx.x == 0) S_sh = S;
     const double step = (S > 0) ? (double)(hist - 1) / (double)S : 0.0;
-    for (int j = threadIdx.x; j < S; j += blockDim.x) {
+    if (S_out == 0) {
+        // no changepoints: the dummy changepoint at t = 0 (see GridTab::S_fit)
+        S = 1;
+        if (threadIdx.x == 0) { tch[0] = 0.0; gt.Lj[0] = 0; gt.info.t_change[0] = 0.0; }
+    }
+    for (int j = threadIdx.x; j < S_out; j += blockDim.x) {
         const double v = (j + 1 == S) ? (double)(hist - 1) : (double)(j + 1) * step;
         const int idx = (int)__builtin_rint(v);
         tch[j] = (double)(ds[idx] - start) / tsc;
@@ -64,7 +70,8 @@ __global__ void setup_grid_kernel(const DevSpec *__restrict__ sp, int n_grids,
         int i1 = T - 1;
         while (i1 > 0 && ds[i1 - 1] == ds[T - 1]) --i1;
         gt.info.start_ns = start; gt.info.t_scale_ns = ds[T - 1] - ds[0];
-        gt.info.T = T; gt.info.S = S; gt.info.i1 = i1; gt.info.NT = NT;
+        gt.info.T = T; gt.info.S = S_out; gt.info.i1 = i1; gt.info.NT = NT;
+        gt.S_fit = S;
     }
     __syncthreads();
     for (int i = threadIdx.x; i < T; i += blockDim.x) {

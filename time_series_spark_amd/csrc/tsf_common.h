@@ -51,6 +51,11 @@ struct DevSpec {
 struct GridTab {
     tsf_grid_info info;
     int32_t Lj[NTAB];                   // chunk holding the first row with t >= t_change[j]
+    // changepoints the FIT runs with: info.S, or 1 when info.S == 0 -- fbprophet then fits the Stan
+    // model on a dummy changepoint at t = 0 (set_changepoints: `changepoints_t = np.array([0.])`)
+    // and folds its delta into k afterwards (store_theta); the caller never sees it
+    int32_t S_fit;
+    int32_t pad_;
 };
 
 struct SeriesTab {

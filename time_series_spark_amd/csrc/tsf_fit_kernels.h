@@ -11,6 +11,7 @@ namespace tsf {
 
 struct SeriesView {
     int T, NT, S, P, cnt;               // cnt: valid rows of this lane's chunk
+    int S_out;                          // changepoints in the caller's layout (S = 1 > S_out = 0: dummy changepoint)
     const double *tw, *yw, *Xw;         // step-major tables
     const int32_t *uw;                  // (lattice panels) row -> row of the shared table Xu, step-major
     const double *Xu;                   // (lattice panels) [U][KP] design rows of the timestamp lattice
@@ -39,23 +40,6 @@ struct WaveLds {
 #define TSF_WAVE_SYNC() wave_sync()
 
 __device__ __forceinline__ int lane_id() { return (int)threadIdx.x & (W - 1); }
-
-// Shared design tiles of a multi-wave workgroup (fit_tile_kernel): step q of the step-major
-// tables -- Xw[q] (KP x 64 doubles), tw[q], cw[q] -- is staged ONCE per workgroup in LDS,
-// double buffered, while the waves (one series each) work on step q+1.
-// The LDS buffers are described by BYTE OFFSETS into the workgroup's dynamic LDS and turned
-// into pointers at the point of use (pointers kept in a struct would decay to generic/flat
-// accesses).
-struct TileCtx {
-    unsigned xoff, toff, coff;  // two buffers each: [2][KP][64] f64, [2][64] f64, [2][64] u16
-    const double *Xg, *tg;      // global step-major tables of the (aligned) grid
-    const uint16_t *cg;
-};
-extern __shared__ __align__(16) unsigned char tsf_dyn_lds[];
-template <int KP>
-__device__ __forceinline__ double *tile_x(const TileCtx &tc, int b) { return reinterpret_cast<double *>(tsf_dyn_lds + tc.xoff) + b * KP * W; }
-__device__ __forceinline__ double *tile_t(const TileCtx &tc, int b) { return reinterpret_cast<double *>(tsf_dyn_lds + tc.toff) + b * W; }
-__device__ __forceinline__ uint16_t *tile_c(const TileCtx &tc, int b) { return reinterpret_cast<uint16_t *>(tsf_dyn_lds + tc.coff) + b * W; }
 
 // theta[p] for a wave-uniform p, straight from the owning lane's register
 template <int PPL>
@@ -97,25 +81,17 @@ __device__ __forceinline__ void column_sums(double (&acc)[KP], WaveLds<KP, PPL> 
 }
 
 // MODE: 0 all columns additive, 1 all multiplicative, 2 mixed (Ka additive first)
-// NW > 0: called by EVERY wave of an NW-wave workgroup in the same round (workgroup barriers
-// inside); `active` says whether this wave has a point to evaluate, tc is the tile context.
-template <int KP, int GROWTH, int MODE, int PPL, int NW = 0, bool XIDX = false>
+template <int KP, int GROWTH, int MODE, int PPL, bool XIDX = false>
 __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesView &sv,
                                         WaveLds<KP, PPL> &lds, const double (&th)[PPL],
-                                        double &f_out, double (&g)[PPL],
-                                        const TileCtx tc = TileCtx(), bool active = true)
+                                        double &f_out, double (&g)[PPL])
 {
-    constexpr bool TILED = NW > 0;
     const int lane = lane_id();
     const int S = sv.S, NT = sv.NT, T = sv.T;
     const int Ka = (MODE == 0) ? KP : (MODE == 1 ? 0 : sp->Ka);
-    // design row + coefficients held in registers / SGPRs; from LDS tiles re-reading the row is
-    // cheap, and the tiled kernel needs the registers for its longer-lived state
-    // design row + coefficients held in registers / SGPRs; the tiled kernel re-reads the row and
-    // the coefficients from LDS instead (it needs the registers for its longer-lived state)
-    constexpr bool HOLD = TILED ? (KP <= 16) : (KP <= 32);
-    constexpr bool BLDS = false;
-    if (active) sv.n_eval++;
+    // design row + coefficients held in registers / SGPRs where they fit
+    constexpr bool HOLD = KP <= 32;
+    sv.n_eval++;
     const double k = theta_at<PPL>(th, 0), m = theta_at<PPL>(th, 1), ls = theta_at<PPL>(th, 2);
     const double sigma = dm_exp(ls);
     const double inv_s2 = 1.0 / (sigma * sigma);
@@ -155,8 +131,8 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
         }
         if (lane <= S) { lds.ks[lane] = ksv; lds.mc[lane] = mcv; }
     }
-    double bs[(HOLD && !BLDS) ? KP : 1];
-    if (HOLD && !BLDS) {
+    double bs[HOLD ? KP : 1];
+    if (HOLD) {
 #pragma unroll
         for (int j = 0; j < (HOLD ? KP : 1); ++j) bs[j] = (3 + S + j < PPL * W) ? theta_at<PPL>(th, 3 + S + j) : 0.0;
     }
@@ -166,55 +142,15 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
     double acc[KP];
 #pragma unroll
     for (int j = 0; j < KP; ++j) acc[j] = 0.0;
-    // ---- tile pipeline (TILED): every thread of the workgroup moves its share of step q-1 from
-    // global memory to the other LDS buffer while the waves compute step q ----
-    constexpr int NTH = TILED ? NW * W : 1;
-    constexpr int TL = TILED ? (KP * W + NTH - 1) / NTH : 1;
-    const int tid = (int)threadIdx.x;
-    double tr[TL], tt = 0.0;
-    unsigned tcv = 0;
-    auto tile_issue = [&](int q) {
-#pragma unroll
-        for (int i = 0; i < TL; ++i) {
-            const int e = tid + i * NTH;
-            tr[i] = (e < KP * W) ? tc.Xg[(size_t)q * KP * W + e] : 0.0;
-        }
-        if (tid < W) tt = tc.tg[q * W + tid];
-        else if (tid < 2 * W) tcv = tc.cg[q * W + tid - W];
-    };
-    auto tile_commit = [&](int q) {
-        double *xb = tile_x<KP>(tc, q & 1);
-#pragma unroll
-        for (int i = 0; i < TL; ++i) {
-            const int e = tid + i * NTH;
-            if (e < KP * W) xb[e] = tr[i];
-        }
-        if (tid < W) tile_t(tc, q & 1)[tid] = tt;
-        else if (tid < 2 * W) tile_c(tc, q & 1)[tid - W] = (uint16_t)tcv;
-    };
-    // (TILED) y of the NEXT step is requested one step ahead: it comes from HBM / Infinity Cache
-    // and a step between two workgroup barriers is too short to hide that latency
-    double y_next = 0.0;
-    if (TILED) {
-        tile_issue(NT - 1); tile_commit(NT - 1);
-        if (active && NT - 1 < sv.cnt) y_next = sv.yw[(NT - 1) * W + lane];
-        __syncthreads();
-    }
     for (int q = NT - 1; q >= 0; --q) {
-        const double y_cur = y_next;
-        if (TILED && q > 0) {
-            tile_issue(q - 1);
-            if (active && q - 1 < sv.cnt) y_next = sv.yw[(q - 1) * W + lane];
-        }
-        if (active && q < sv.cnt) {
+        if (q < sv.cnt) {
             const int idx = q * W + lane;
-            const unsigned cwv = TILED ? (unsigned)tile_c(tc, q & 1)[lane] : (unsigned)sv.cw[idx];
+            const unsigned cwv = (unsigned)sv.cw[idx];
             const int c = (int)(cwv & 0xffu), cprev = (int)(cwv >> 8);
-            const double ti = TILED ? tile_t(tc, q & 1)[lane] : sv.tw[idx];
-            const double yi = TILED ? y_cur : sv.yw[idx];
+            const double ti = sv.tw[idx];
+            const double yi = sv.yw[idx];
             constexpr int XS = XIDX ? 1 : W;      // stride between the columns of a design row
-            const double *xp = TILED ? tile_x<KP>(tc, q & 1) + lane
-                                     : (XIDX ? sv.Xu + (size_t)sv.uw[idx] * KP : sv.Xw + (size_t)q * KP * W + lane);
+            const double *xp = XIDX ? sv.Xu + (size_t)sv.uw[idx] * KP : sv.Xw + (size_t)q * KP * W + lane;
             double x[HOLD ? KP : 1];
             double xa = 0.0, xm = 0.0;
             if (HOLD) {
@@ -231,7 +167,7 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
                 }
 #pragma unroll
                 for (int j = 0; j < (HOLD ? KP : 1); ++j) {
-                    const double bj = BLDS ? ((3 + S + j < PPL * W) ? theta_at<PPL>(th, 3 + S + j) : 0.0) : bs[BLDS ? 0 : j];
+                    const double bj = bs[j];
                     if (MODE == 0) xa = __builtin_fma(x[j], bj, xa);
                     else if (MODE == 1) xm = __builtin_fma(x[j], bj, xm);
                     else { if (j < Ka) xa = __builtin_fma(x[j], bj, xa); else xm = __builtin_fma(x[j], bj, xm); }
@@ -284,12 +220,7 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
             rt2 = rt2 + v;
             for (int j = cprev; j < c; ++j) { lds.tp1[j] = rt1; lds.tp2[j] = rt2; }
         }
-        if (TILED) {
-            if (q > 0) tile_commit(q - 1);
-            __syncthreads();
-        }
     }
-    if (!active) { f_out = 0.0; return false; }
     // reductions over the time axis
     const double sse_t = bfly_sum(sse);
     const double s1 = suffix_scan(rt1), s2v = suffix_scan(rt2);
@@ -491,7 +422,7 @@ __device__ __forceinline__ void make_view(const FitArgs &a, int64_t n, SeriesVie
 {
     const int g = a.aligned ? 0 : (int)n;
     const GridTab &gt = a.gtab[g];
-    sv.T = gt.info.T; sv.NT = gt.info.NT; sv.S = gt.info.S;
+    sv.T = gt.info.T; sv.NT = gt.info.NT; sv.S = gt.S_fit; sv.S_out = gt.info.S;
     sv.P = 3 + sv.S + a.sp->K;
     int cnt = sv.T - lane_id() * sv.NT;
     cnt = cnt < 0 ? 0 : (cnt > sv.NT ? sv.NT : cnt);
@@ -510,23 +441,29 @@ __device__ __forceinline__ void make_view(const FitArgs &a, int64_t n, SeriesVie
 }
 
 // theta (internal order, registers) -> caller layout [k,m,log sigma,delta[n_cp],beta[K]]
-// (every slot of the row is written exactly once: fitted entries, zeros elsewhere)
-template <int PPL>
+// (every slot of the row is written exactly once: fitted entries, zeros elsewhere).
+// A series fitted on the dummy changepoint (sv.S = 1, sv.S_out = 0) has no delta slot there:
+// FOLD = true (fitted parameters) stores k + delta as k -- Prophet.fit's `k = k + delta;
+// delta = 0` when there are no changepoints --, FOLD = false (a gradient) just drops the entry.
+template <int PPL, bool FOLD = true>
 __device__ __forceinline__ void store_theta(const FitArgs &a, const SeriesView &sv, int64_t n,
                                             const double (&x)[PPL], double *dst)
 {
     const int n_cp = a.sp->n_cp;
     double *out = dst + (size_t)n * a.theta_stride;
     for (int i = lane_id(); i < a.theta_stride; i += W) {
-        bool fitted = i < 3 + sv.S;
+        bool fitted = i < 3 + sv.S_out;
         if (i >= 3 + n_cp && i < 3 + n_cp + a.sp->K) fitted = true;
         if (!fitted) out[i] = 0.0;
     }
+    const double d0 = readlane_f64(x[0], 3);
 #pragma unroll
     for (int s = 0; s < PPL; ++s) {
         const int p = lane_id() + s * W;
-        if (p < 3 + sv.S) out[p] = x[s];
-        else if (p < sv.P) out[3 + n_cp + a.sp->perm[p - 3 - sv.S]] = x[s];
+        double v = x[s];
+        if (FOLD && p == 0 && sv.S_out != sv.S) v = v + d0;
+        if (p < 3 + sv.S_out) out[p] = v;
+        else if (p >= 3 + sv.S && p < sv.P) out[3 + n_cp + a.sp->perm[p - 3 - sv.S]] = v;
     }
 }
 
@@ -540,8 +477,8 @@ __device__ __forceinline__ void load_theta(const FitArgs &a, const SeriesView &s
     for (int s = 0; s < PPL; ++s) {
         const int p = lane_id() + s * W;
         double v = 0.0;
-        if (p < 3 + sv.S) v = in[p];
-        else if (p < sv.P) v = in[3 + n_cp + a.sp->perm[p - 3 - sv.S]];
+        if (p < 3 + sv.S_out) v = in[p];
+        else if (p >= 3 + sv.S && p < sv.P) v = in[3 + n_cp + a.sp->perm[p - 3 - sv.S]];
         x[s] = v;
     }
 }
@@ -561,7 +498,7 @@ __global__ __launch_bounds__(64) void eval_kernel(FitArgs a)
     double x[PPL], g[PPL], f;
     load_theta<PPL>(a, sv, n, a.theta_in, x);
     const bool bad = eval_fg<KP, GROWTH, MODE, PPL>(a.sp, sv, lds, x, f, g);
-    store_theta<PPL>(a, sv, n, g, a.grad_out);
+    store_theta<PPL, false>(a, sv, n, g, a.grad_out);
     if (threadIdx.x == 0) { a.fval[n] = f; a.status[n] = bad ? 1 : 0; }
 }
 
@@ -678,7 +615,7 @@ __global__ __launch_bounds__(64) void fit_kernel(FitArgs a)
                 for (int s = 0; s < PPL; ++s) xk1[s] = __builtin_fma(alpha, pk[s], xk[s]);
             }
             double f1;
-            const bool bad = eval_fg<KP, GROWTH, MODE, PPL, 0, XIDX>(sp, sv, lds, xk1, f1, gk1);
+            const bool bad = eval_fg<KP, GROWTH, MODE, PPL, XIDX>(sp, sv, lds, xk1, f1, gk1);
             if (stage == ST_INIT) {
                 if (bad) { ret = TSF_ST_INIT_NONFINITE; fk = f1; break; }
                 fk = f1;

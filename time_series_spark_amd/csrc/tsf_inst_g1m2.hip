@@ -2,6 +2,5 @@
 #define TSF_G 1
 #define TSF_M 2
 #define TSF_LAUNCH_NAME launch_g1m2
-#define TSF_TILE_LAUNCH_NAME launch_tile_g1m2
 #define TSF_NEWTON_LAUNCH_NAME launch_newton_g1m2
 #include "tsf_inst.inc"

@@ -14,13 +14,6 @@ int launch_g0m2(int KP, const FitArgs &a, int eval_only, hipStream_t st);
 int launch_g1m0(int KP, const FitArgs &a, int eval_only, hipStream_t st);
 int launch_g1m1(int KP, const FitArgs &a, int eval_only, hipStream_t st);
 int launch_g1m2(int KP, const FitArgs &a, int eval_only, hipStream_t st);
-// fit_tile_kernel (aligned panels, residual form, design tiles shared through LDS)
-int launch_tile_g0m0(int KP, const FitArgs &a, int *counter, int n_cu, hipStream_t st);
-int launch_tile_g0m1(int KP, const FitArgs &a, int *counter, int n_cu, hipStream_t st);
-int launch_tile_g0m2(int KP, const FitArgs &a, int *counter, int n_cu, hipStream_t st);
-int launch_tile_g1m0(int KP, const FitArgs &a, int *counter, int n_cu, hipStream_t st);
-int launch_tile_g1m1(int KP, const FitArgs &a, int *counter, int n_cu, hipStream_t st);
-int launch_tile_g1m2(int KP, const FitArgs &a, int *counter, int n_cu, hipStream_t st);
 // newton_kernel (Stan's Newton optimiser; P <= 64, one explicit-mode kernels only)
 int launch_newton_g0m0(int KP, const FitArgs &a, int PM, hipStream_t st);
 int launch_newton_g0m1(int KP, const FitArgs &a, int PM, hipStream_t st);

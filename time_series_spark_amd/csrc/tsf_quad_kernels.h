@@ -379,7 +379,7 @@ __device__ __forceinline__ void make_view_q(const FitArgs &a, int64_t n, SeriesV
 {
     const int64_t g = a.aligned ? 0 : n;            // ragged panels: one grid per series
     const GridTab &gt = a.gtab[g];
-    sv.T = gt.info.T; sv.NT = gt.info.NT; sv.S = gt.info.S;
+    sv.T = gt.info.T; sv.NT = gt.info.NT; sv.S = gt.S_fit; sv.S_out = gt.info.S;
     sv.P = 3 + sv.S + a.sp->K;
     int cnt = sv.T - lane_id() * sv.NT;
     cnt = cnt < 0 ? 0 : (cnt > sv.NT ? sv.NT : cnt);
