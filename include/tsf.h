@@ -54,6 +54,8 @@ extern "C" {
 #define TSF_MAX_S 60          /* max changepoints */
 #define TSF_MAX_K 64          /* max design columns */
 #define TSF_MAX_P 128         /* 3 + S + K */
+#define TSF_MAX_T 1048576     /* rows per series (a series is one wavefront's work: 64 chunks of
+                                 ceil(T/64) rows); every fit entry point rejects longer input */
 
 enum { TSF_GROWTH_LINEAR = 0, TSF_GROWTH_LOGISTIC = 1 };
 enum { TSF_MODE_ADDITIVE = 0, TSF_MODE_MULTIPLICATIVE = 1 };

@@ -412,6 +412,14 @@ def test_odd_shapes_against_oracle(env):
     # long series: 3 000 rows (NT = 47: the residual staging of the quadratic kernel leaves LDS)
     dsl, yl = synth.make_panel(2, 3000, 'linear', seed=8)
     check(fc.ModelSpec(growth='linear', seasonalities=[helpers.YEARLY, helpers.WEEKLY]), dsl, yl)
+    # 15-minute data, 20 000 rows (208 days; the reference's example config forecasts on a 15-minute
+    # grid): NT = 313 rows per lane, far past one LDS staging buffer
+    ds15 = synth.START_NS + (15 * 60 * 10 ** 9) * np.arange(20000, dtype=np.int64)
+    y15 = synth.make_panel(2, 20000, 'linear', seed=9)[1]
+    check(fc.ModelSpec(growth='linear', seasonalities=[helpers.WEEKLY, helpers.DAILY]), ds15, y15)
+    check(fc.ModelSpec(growth='logistic', seasonality_mode='multiplicative',
+                       seasonalities=[helpers.WEEKLY, helpers.DAILY]), ds15, y15,
+          floor=np.zeros(2), cap=y15.max(axis=1) * 1.1)
     # noise-free y: the optimiser drives sigma down until something gives; whatever happens must
     # be the oracle's outcome too
     t = np.arange(120.0)

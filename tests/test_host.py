@@ -70,6 +70,40 @@ def test_pack_long_frame_sorts_drops_nan_keeps_duplicates():
                                          'ds': pd.to_datetime(['2020-01-01']), 'y': [np.inf]}))
 
 
+def test_trailing_null_rows_count_for_the_last_history_date_and_all_null_groups_are_reported():
+    """fbprophet keeps null-y rows in history_dates (Prophet.fit) and make_future_dataframe starts
+    at history_dates.max() (oracle/fbprophet_restated.py make_future_dataframe), so a series that
+    ends in null-y rows forecasts from the LAST row, not from the last non-null one; a group with
+    no non-null y at all makes Prophet.fit raise ValueError."""
+    from oracle.fbprophet_restated import ProphetOracle
+    days = pd.date_range('2020-01-01', periods=8)
+    df = pd.DataFrame({
+        'series_id': [1] * 8 + [2] * 3 + [3] * 2,
+        'dim_id': 0,
+        'ds': list(days) + list(days[:3]) + list(days[:2]),
+        'y': [1.0, 2.0, 3.0, np.nan, 5.0, 6.0, np.nan, np.nan] + [1.0, np.nan, 3.0] + [np.nan, np.nan]})
+    p = pk.pack_long_frame(df)
+    assert p.N == 2 and list(p.lengths) == [5, 2]
+    assert list(p.last_ds_all) == [days[7].value, days[2].value]          # not days[5] for series 1
+    assert p.dropped_keys == [(3, 0)]
+    m = ProphetOracle()
+    m.stan_data(df[df['series_id'] == 1][['ds', 'y']])
+    lit = m.make_future_dataframe(3, freq='D', include_history=False)['ds']
+    assert list(pk.future_dates(p.last_ds_all[:1], 3, 'D')[0]) == [t.value for t in lit]
+    # packed input without nulls: nothing to merge
+    p2 = pk.pack_long_frame(df.dropna())
+    assert list(p2.last_ds_all) == [days[5].value, days[2].value] and p2.dropped_keys == []
+
+
+def test_group_with_only_null_y_raises_like_prophet_fit():
+    from time_series_spark_amd.jobs import prophet_modeler as pm
+    days = pd.date_range('2020-01-01', periods=4)
+    df = pd.DataFrame({'series_id': [1] * 4 + [2] * 4, 'dim_id': 7, 'ds': list(days) * 2,
+                       'y': [1.0, 2.0, 3.0, 4.0] + [np.nan] * 4})
+    with pytest.raises(ValueError, match='less than 2 non-NaN rows'):
+        pm.model_panel({'model': {'floor': 0, 'cap_multiplier': 1.1}})(df)
+
+
 def test_auto_seasonality_rules():
     day = fc.DAY_NS
     names = lambda s: [x['name'] for x in s]

@@ -282,6 +282,7 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     if (hs.growth == TSF_GROWTH_LOGISTIC && !cap) return fail(ctx, "logistic growth needs cap");
     const int Tm = aligned ? T : max_T;
     if (Tm < 1) return fail(ctx, "no rows");
+    if (Tm > TSF_MAX_T) return fail(ctx, "series too long (TSF_MAX_T rows per series)");
     const int NTmax = (Tm + W - 1) / W;
     const int64_t n_grids = aligned ? 1 : N;
     // quadratic (Gram) form of the data term: see tsf_quad_kernels.h
@@ -496,12 +497,12 @@ static int fit_host(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, 
         if (offsets[0] != 0) return fail(ctx, "offsets[0] must be 0");
         for (int64_t n = 0; n < N; ++n) {
             const int64_t len = offsets[n + 1] - offsets[n];
-            if (len < 0 || len > (int64_t)W * 255) return fail(ctx, "series length out of range");
+            if (len < 0 || len > (int64_t)TSF_MAX_T) return fail(ctx, "series length out of range (0 .. TSF_MAX_T rows)");
             if (len > max_T) max_T = (int32_t)len;
         }
     }
     if (max_T < 1) return fail(ctx, "no rows");
-    if (max_T > W * 255) return fail(ctx, "series too long (max 16320 rows)");
+    if (max_T > TSF_MAX_T) return fail(ctx, "series too long (TSF_MAX_T rows per series)");
     const int64_t n_ds = aligned ? T : total;
     const int64_t n_grids = aligned ? 1 : N;
     DevBuf d_ds, d_y, d_off, d_floor, d_cap, d_extra, d_theta, d_ys, d_f, d_st, d_it, d_ev, d_grid, d_thin, d_grad;

@@ -75,7 +75,9 @@ def fit_packed(panel, floor, cap, kw, devices=None):
             specs[key] = (seas, members)
     blobs = [None] * N
     status = np.zeros(N, dtype=np.int32)
-    last_ds = panel.ds_ns[panel.offsets[1:] - 1] if N else np.zeros(0, np.int64)
+    # make_future_dataframe starts at history_dates.max(): the last ds of the group INCLUDING rows
+    # whose y is null (fbprophet Prophet.fit keeps them in history_dates)
+    last_ds = panel.last_ds_all
     algo = str(kw.get('algorithm', 'auto')).lower()
     if algo not in ('auto', 'lbfgs', 'newton'):
         raise ValueError("algorithm must be 'auto', 'lbfgs' or 'newton'")
@@ -166,8 +168,9 @@ def _model_packed(config, panel, n_rows, execution_time):
     cap = ymax * config['model']['cap_multiplier']                     # :59-60
     kw = _prophet_kwargs(config)
     floors = np.full(panel.N, float(floor))
-    # ValueError cases propagate exactly as fbprophet's would (SURVEY 8b error convention)
-    if (panel.lengths < 2).any():
+    # ValueError cases propagate exactly as fbprophet's would (SURVEY 8b error convention);
+    # a group whose every y is null never reaches the packed panel but fails the same way
+    if panel.dropped_keys or (panel.lengths < 2).any():
         raise ValueError('Dataframe has less than 2 non-NaN rows.')
     if kw['growth'] == 'logistic' and (cap <= floors).any():
         raise ValueError('cap must be greater than floor (which defaults to 0).')

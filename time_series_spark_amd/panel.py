@@ -44,6 +44,12 @@ class PackedPanel(object):
         self.lengths = lens
         self.aligned = False
         self.stats = None
+        # fbprophet's history_dates = ALL ds of the group, null-y rows included (Prophet.fit sets
+        # it before dropping them), and make_future_dataframe starts from its max: last_ds_all is
+        # that max per series (pack_rows fills it in when rows were dropped); dropped_keys are
+        # the (series_id, dim_id) groups whose every y is null (Prophet.fit raises for them)
+        self.last_ds_all = ds_ns[offsets[1:] - 1] if self.N > 0 else np.zeros(0, np.int64)
+        self.dropped_keys = []
         self.ds_grid = None
         self.y2d = None
         if self.N > 0 and lens.min() == lens.max() and lens[0] > 0:
@@ -120,6 +126,17 @@ def pack_rows(sid, did, ds_ns, y, n_threads=0, key_dtypes=(np.int64, np.int64)):
     keys = pd.DataFrame({'series_id': ksid.astype(key_dtypes[0]), 'dim_id': kdid.astype(key_dtypes[1])})
     panel = PackedPanel(keys, offsets, ds_out, y_out)
     panel.stats = (span, min_dt, ymax)
+    if R < n:
+        # rows with a null y were dropped: they still count for the last history date
+        nan = np.isnan(y)
+        nmax = pd.DataFrame({'s': sid[nan], 'd': did[nan], 'ds': ds_ns[nan]}).groupby(['s', 'd'])['ds'].max()
+        idx = pd.MultiIndex.from_arrays([ksid, kdid], names=['s', 'd'])
+        m = nmax.reindex(idx).to_numpy(dtype=np.float64, na_value=np.nan)
+        have = ~np.isnan(m)
+        last = panel.last_ds_all.copy()
+        last[have] = np.maximum(last[have], nmax.reindex(idx[have]).to_numpy(dtype=np.int64))
+        panel.last_ds_all = last
+        panel.dropped_keys = [k for k in nmax.index.difference(idx)]
     return panel
 
 
