@@ -65,6 +65,7 @@ enum { TSF_EVAL_AUTO = 0, TSF_EVAL_RESIDUAL = 1, TSF_EVAL_QUADRATIC = 2 };
  * `'Newton' if T < 100 else 'LBFGS'` (TSF_ALGO_AUTO: decided per CALL from the longest series of
  * the call -- callers split panels at 100 rows).  Default TSF_ALGO_LBFGS. */
 enum { TSF_ALGO_LBFGS = 0, TSF_ALGO_NEWTON = 1, TSF_ALGO_AUTO = 2 };
+enum { TSF_RK_AUTO = 0, TSF_RK_WAVE = 1, TSF_RK_MFMA = 2 };
 #define TSF_NEWTON_BELOW_T 100
 
 /* per-series status: >= 0 are Stan's optimiser termination codes */
@@ -116,7 +117,11 @@ typedef struct {
     int32_t recenter_every;                 /* 128: re-centre at least every n accepted iterations */
     double recenter_ratio;                  /* 1.0: ... and when |Z D|^2 > ratio * s0 */
     int32_t algorithm;                      /* TSF_ALGO_LBFGS */
-    int32_t reserved_;                      /* 0 */
+    /* Which kernel runs a RESIDUAL-form L-BFGS fit (same arithmetic, same bits): TSF_RK_WAVE one
+     * wavefront per series; TSF_RK_MFMA 16 series per workgroup evaluated together on the matrix
+     * cores (aligned panels, one parameter per lane, <= 28 changepoints; faster per evaluation on
+     * saturated panels, slower while a launch waits for one long series); TSF_RK_AUTO = WAVE. */
+    int32_t residual_kernel;                /* TSF_RK_AUTO */
 } tsf_spec;
 
 /* What setup derives from one timestamp vector ("grid").  One per call for aligned panels,

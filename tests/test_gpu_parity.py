@@ -100,6 +100,39 @@ def test_fit_predict_against_oracle_and_golden(env, case):
     assert np.array_equal(yint, np.maximum(np.trunc(yhat), floor[:, None]).astype(np.int32))
 
 
+@pytest.mark.parametrize('case', ['ref_logistic_multiplicative', 'cfg2_linear_additive@resid',
+                                  'linear_multiplicative_365', 'logistic_additive_400', 'short_90@resid'])
+def test_matrix_core_kernel_is_bit_identical_to_the_one_wave_kernel(env, case):
+    """Residual-form fits of an aligned panel run 16 series per workgroup on the matrix cores
+    (csrc/tsf_mfma_kernels.h: v_mfma_f64_16x16x4_f64 chains in the canonical order); the one-wave
+    kernel (residual_kernel = WAVE) and the oracle must give the same bits.  N = 37: two full tiles,
+    one partial, slots refilled from the queue."""
+    fc, cl = env
+    from time_series_spark_amd import _lib
+    spec, ds, y, floor, cap, extra, fut, exf = helpers.make_case(case, N=37)
+    kw = dict(growth=spec.growth, seasonality_mode=spec.seasonality_mode, seasonalities=spec.seasonalities,
+              **spec.lbfgs)
+    r_m = fc.fit_aligned(fc.ModelSpec(residual_kernel=_lib.RK_MFMA, **kw), ds, y, floor=floor, cap=cap)
+    r_w = fc.fit_aligned(fc.ModelSpec(residual_kernel=_lib.RK_WAVE, **kw), ds, y, floor=floor, cap=cap)
+    assert np.array_equal(r_m.status, r_w.status) and (r_m.status > 0).all()
+    assert np.array_equal(r_m.n_iter, r_w.n_iter) and np.array_equal(r_m.n_eval, r_w.n_eval)
+    assert np.array_equal(r_m.theta, r_w.theta) and np.array_equal(r_m.fval, r_w.fval)
+    assert np.array_equal(r_m.y_scale, r_w.y_scale)
+    csp = helpers.oracle_spec(spec)
+    for n in (0, 17, 36):
+        o = cl.fit(csp, ds, y[n], floor[n], cap[n])
+        S = o['info'].S
+        assert (r_m.n_iter[n], r_m.n_eval[n], r_m.status[n]) == (o['n_iter'], o['n_eval'], o['status'])
+        assert n_bit_diff(r_m.theta[n][:3 + S], o['theta'][:3 + S]) == 0 and n_bit_diff(r_m.fval[n], o['f']) == 0
+    # a single series (what a per-group UDF call hands over) and an odd truncation
+    r1 = fc.fit_aligned(fc.ModelSpec(residual_kernel=_lib.RK_MFMA, **kw), ds, y[5:6], floor=floor[5:6], cap=cap[5:6])
+    assert np.array_equal(r1.theta[0], r_w.theta[5]) and r1.n_eval[0] == r_w.n_eval[5]
+    kw7 = dict(kw, max_iter=7)
+    r7m = fc.fit_aligned(fc.ModelSpec(residual_kernel=_lib.RK_MFMA, **kw7), ds, y[:20], floor=floor[:20], cap=cap[:20])
+    r7w = fc.fit_aligned(fc.ModelSpec(residual_kernel=_lib.RK_WAVE, **kw7), ds, y[:20], floor=floor[:20], cap=cap[:20])
+    assert np.array_equal(r7m.theta, r7w.theta) and np.array_equal(r7m.n_eval, r7w.n_eval)
+
+
 def test_truncated_trajectories_match(env):
     """Same iterate after 1, 3, 10, 40 L-BFGS iterations: checks line search, two-loop
     recursion and the history ring step by step rather than only at the end."""

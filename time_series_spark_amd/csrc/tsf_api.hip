@@ -17,6 +17,7 @@
 #include "tsf_aux_kernels.h"
 #include "tsf_fit_kernels.h"
 #include "tsf_quad_kernels.h"
+#include "tsf_mfma_tabs.h"
 #include "tsf_launch.h"
 
 using namespace tsf;
@@ -101,7 +102,7 @@ extern "C" void tsf_spec_default(tsf_spec *s)
     s->tol_rel_obj = 1e4; s->tol_grad = 1e-8; s->tol_rel_grad = 1e7; s->tol_param = 1e-8;
     s->eval_form = TSF_EVAL_AUTO;
     s->algorithm = TSF_ALGO_LBFGS;
-    s->reserved_ = 0; s->recenter_every = 128; s->recenter_ratio = 1.0;
+    s->residual_kernel = TSF_RK_AUTO; s->recenter_every = 128; s->recenter_ratio = 1.0;
 }
 
 extern "C" int tsf_spec_size(void) { return (int)sizeof(tsf_spec); }
@@ -144,6 +145,7 @@ static int build_devspec(tsf_ctx *ctx, const tsf_spec *s, DevSpec *d, int *mode_
     if (s->history < 1 || s->history > MAXH) return fail(ctx, "history must be in [1,8]");
     if (s->eval_form < TSF_EVAL_AUTO || s->eval_form > TSF_EVAL_QUADRATIC) return fail(ctx, "bad eval_form");
     if (s->algorithm < TSF_ALGO_LBFGS || s->algorithm > TSF_ALGO_AUTO) return fail(ctx, "bad algorithm");
+    if (s->residual_kernel < TSF_RK_AUTO || s->residual_kernel > TSF_RK_MFMA) return fail(ctx, "bad residual_kernel");
     if (s->eval_form != TSF_EVAL_RESIDUAL && (s->recenter_every < 1 || !(s->recenter_ratio > 0.0)))
         return fail(ctx, "recenter_every must be >= 1 and recenter_ratio > 0");
     const int K = tsf_spec_K(s);
@@ -189,13 +191,19 @@ static int build_devspec(tsf_ctx *ctx, const tsf_spec *s, DevSpec *d, int *mode_
 // ---- workspace ------------------------------------------------------------------------------
 
 struct WsLayout {
-    size_t gtab, stab, tw, cw, Xw, yw, Mg, Mslot, rbuf, counter, uw, Xu, total;
+    size_t gtab, stab, tw, cw, Xw, yw, Mg, Mslot, rbuf, counter, uw, Xu;
+    size_t mXF, mXB, mXT, mtq, mcq, mcpof, myq, mhist;      // matrix-core path (tsf_mfma_kernels.h)
+    size_t total;
 };
+
+// launch plan of the matrix-core residual kernel
+struct MfmaPlan { int on, NG, KF, NCB, rr0, blocks; };
 
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 static WsLayout ws_layout(int64_t N, int64_t n_grids, int NTmax, int KP, int quad_P4 = 0,
-                          int quad_slots = 0, int quad_ragged = 0, int64_t lat_U = 0)
+                          int quad_slots = 0, int quad_ragged = 0, int64_t lat_U = 0,
+                          const MfmaPlan *mp = nullptr)
 {
     WsLayout l;
     size_t off = 0;
@@ -213,6 +221,16 @@ static WsLayout ws_layout(int64_t N, int64_t n_grids, int NTmax, int KP, int qua
     l.counter = off; off = align_up(off + 256);
     l.uw = off; off = align_up(off + (lat_U > 0 ? sizeof(int32_t) * (size_t)n_grids * NTmax * W : 0));
     l.Xu = off; off = align_up(off + (lat_U > 0 ? sizeof(double) * (size_t)lat_U * KP : 0));
+    const bool mf = mp && mp->on;
+    const size_t tiles = mf ? (size_t)W * mp->NG : 0;
+    l.mXF = off; off = align_up(off + (mf ? sizeof(double) * tiles * mp->KF * W : 0));
+    l.mXB = off; off = align_up(off + (mf ? sizeof(double) * tiles * 4 * mp->NCB * W : 0));
+    l.mXT = off; off = align_up(off + (mf ? sizeof(double) * tiles * 4 * W : 0));
+    l.mtq = off; off = align_up(off + (mf ? sizeof(double) * tiles * 16 : 0));
+    l.mcq = off; off = align_up(off + (mf ? sizeof(uint16_t) * tiles * 16 : 0));
+    l.mcpof = off; off = align_up(off + (mf ? (size_t)W * 8 : 0));
+    l.myq = off; off = align_up(off + (mf ? sizeof(double) * (size_t)N * tiles * 16 : 0));
+    l.mhist = off; off = align_up(off + (mf ? sizeof(double) * (size_t)mp->blocks * MT_NS * 2 * MAXH * W : 0));
     l.total = off;
     return l;
 }
@@ -306,7 +324,38 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     }
     // shared lattice table: ragged panel, residual-form kernel, no explicit columns
     if (aligned || quad || newton || theta_in != nullptr || hs.n_extra > 0 || lat_step <= 0) lat_U = 0;
-    const WsLayout l = ws_layout(N, n_grids, NTmax, hs.KP, qp.P4, qp.slots, quad && !aligned, lat_U);
+    // matrix-core residual kernel (tsf_mfma_kernels.h): aligned panel, L-BFGS, one parameter per lane
+    // (KP <= 28 implies one column mode and P <= 64), at most MT_SP changepoints, and an upper bound
+    // on the changepoint rows one chunk can hold (the exact count is checked on the device:
+    // MfmaTabs::overflow routes the call to the one-wave kernel)
+    MfmaPlan mp;
+    memset(&mp, 0, sizeof(mp));
+    // TSF_RK_AUTO takes the one-wave kernel: measured (profiles/r02_mfma_vs_wave.txt) the matrix-core
+    // kernel evaluates 1.3x more points per second when every slot is busy (100 000 x 730, iteration
+    // cap 150: 62.7 vs 48.1 M evaluations/s) but a launch that waits for one long series is slower
+    // (a round with one busy slot costs what a round with 16 does), and panels below 16 series per CU
+    // leave CUs idle.
+    if (aligned && !quad && !newton && theta_in == nullptr && hs.KP <= 28 && spec->residual_kernel == TSF_RK_MFMA) {
+        const int hist_rows = (int)floor((double)Tm * hs.cp_range);
+        int S = hs.n_cp;
+        if (S + 1 > hist_rows) S = hist_rows - 1;
+        if (S < 1) S = 1;
+        const double step = (hs.n_cp > 0 && S > 0) ? (double)(hist_rows - 1) / (double)S : 1e30;
+        const int per_chunk = (int)ceil((double)NTmax / (step > 1.0 ? step : 1.0)) + 2;
+        if (S <= MT_SP && per_chunk <= MT_MAXCP && mfma_lds_bytes(hs.KP) <= 160 * 1024) {
+            mp.on = 1;
+            mp.NG = (NTmax + 15) / 16;
+            mp.KF = hs.KP / 4;
+            mp.NCB = (hs.KP + 15) / 16;
+            mp.rr0 = (16 * mp.NG - NTmax) / 4;
+            int64_t blocks = (N + MT_NS - 1) / MT_NS;
+            if (blocks > ctx->n_cu) blocks = ctx->n_cu;
+            mp.blocks = (int)blocks;
+        }
+    }
+    if (spec->residual_kernel == TSF_RK_MFMA && !mp.on && theta_in == nullptr && !quad && !newton)
+        return fail(ctx, "residual_kernel MFMA needs an aligned panel, K <= 28 columns of one mode, 3+S+K <= 64 and S <= 28");
+    const WsLayout l = ws_layout(N, n_grids, NTmax, hs.KP, qp.P4, qp.slots, quad && !aligned, lat_U, &mp);
     rc = ensure_ws(ctx, l.total);
     if (rc) return rc;
     char *ws = (char *)ctx->ws;
@@ -367,6 +416,31 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
         qa.dbg = nullptr;
         HIP_TRY(ctx, hipMemsetAsync(qa.counter, 0, sizeof(int), st));
         lrc = launch_quad(hs.KP, qp, qa, (double *)(ws + l.Mg), st);
+    } else if (mp.on) {
+        MfmaTabs mt;
+        memset(&mt, 0, sizeof(mt));
+        int *flags = (int *)(ws + l.counter);        // [0] work queue head, [1] changepoint-row overflow
+        HIP_TRY(ctx, hipMemsetAsync(flags, 0, 2 * sizeof(int), st));
+        mt.XF = (const double *)(ws + l.mXF); mt.XB = (const double *)(ws + l.mXB);
+        mt.XT = (const double *)(ws + l.mXT); mt.tq = (const double *)(ws + l.mtq);
+        mt.cq = (const uint16_t *)(ws + l.mcq); mt.cpof = (const int8_t *)(ws + l.mcpof);
+        mt.yq = (const double *)(ws + l.myq); mt.hist = (double *)(ws + l.mhist);
+        mt.counter = flags; mt.overflow = flags + 1;
+        mt.NG = mp.NG; mt.KF = mp.KF; mt.NCB = mp.NCB; mt.rr0 = mp.rr0; mt.run_if_overflow = 0;
+        lrc = launch_mfma_layout(a, hs.KP, mt, (double *)(ws + l.mXF), (double *)(ws + l.mXB),
+                                 (double *)(ws + l.mXT), (double *)(ws + l.mtq), (uint16_t *)(ws + l.mcq),
+                                 (int8_t *)(ws + l.mcpof), (double *)(ws + l.myq), flags + 1, st);
+        if (lrc == 0) {
+            if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev0[slot], st));   // the fit kernel proper
+            lrc = launch_mfma(hs.KP, hs.growth, mode, a, mt, mp.blocks, st);
+        }
+        if (lrc == 0) {
+            // fallback, decided on the device: runs only if the layout kernel found a chunk with more
+            // changepoint rows than the trend block holds (long runs of equal timestamps)
+            FitArgs fb = a;
+            fb.run_flag = flags + 1; fb.run_if = 1;
+            lrc = pick_launch(hs.growth, mode)(hs.KP, fb, 0, st);
+        }
     } else {
         lrc = pick_launch(hs.growth, mode)(hs.KP, a, theta_in != nullptr, st);
     }

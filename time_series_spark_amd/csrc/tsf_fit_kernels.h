@@ -80,6 +80,169 @@ __device__ __forceinline__ void column_sums(double (&acc)[KP], WaveLds<KP, PPL> 
     }
 }
 
+// Segment tables ks[c], mc[c] (slope and offset of trend segment c): sequential recurrences over
+// the changepoints.  Every lane runs the same S steps and lane c stops updating after its first c
+// terms, so lane c ends with exactly the sequentially rounded ks[c], mc[c] (no per-step LDS write /
+// table load).  Writes lds.ks / lds.mc; the caller synchronises.
+template <int GROWTH, int PPL, class L>
+__device__ __forceinline__ void segment_tables(const SeriesView &sv, L &lds, const double (&th)[PPL])
+{
+    const int lane = lane_id();
+    const int S = sv.S;
+    const double k = theta_at<PPL>(th, 0), m = theta_at<PPL>(th, 1);
+    double ksv = k, mcv = m;
+    const double tcl = (lane < S) ? sv.t_change[lane] : 0.0;
+    if (GROWTH == 0) {
+        for (int j = 0; j < S; ++j) {
+            const double dj = theta_at<PPL>(th, 3 + j);
+            const double ksn = ksv + dj;
+            const double mcn = mcv + ((-readlane_f64(tcl, j)) * dj);
+            if (j < lane) { ksv = ksn; mcv = mcn; }
+        }
+    } else {
+        // logistic: gamma_j needs ks[j] / ks[j+1].  ks does not depend on mc, so the ks chain
+        // runs first, the S quotients are ONE lane-parallel division (lane j: ks[j]/ks[j+1],
+        // the operands of the sequential form), and the mc chain reads them by lane.
+        double ks_next = k;
+        for (int j = 0; j < S; ++j) {
+            const double ksn = ksv + theta_at<PPL>(th, 3 + j);
+            if (j == lane) ks_next = ksn;
+            if (j < lane) ksv = ksn;
+        }
+        const double ratio = ksv / ks_next;
+        for (int j = 0; j < S; ++j) {
+            const double gamma = (readlane_f64(tcl, j) - mcv) * (1.0 - readlane_f64(ratio, j));
+            const double mcn = mcv + gamma;
+            if (j < lane) mcv = mcn;
+        }
+    }
+    if (lane <= S) { lds.ks[lane] = ksv; lds.mc[lane] = mcv; }
+}
+
+// f and the gradient from the time-axis sums of one evaluation: lds.tot1 / tot2 (suffix sums of the
+// per-chunk trend sums, [W] = 0), lds.tp1 / tp2 (chunk-local partial sums at the changepoint rows),
+// lds.accR (per-column sums X^T r), lds.ks / mc, and sse_t.  scr: d1, d2, rb, ab scratch (logistic
+// growth).  The caller has synchronised the wave after writing those.
+template <int GROWTH, int PPL, class L, class D>
+__device__ __forceinline__ bool eval_tail(const DevSpec *__restrict__ sp, const SeriesView &sv, L &lds,
+                                          D &scr, const double (&th)[PPL], double sigma,
+                                          double inv_s2, double sse_t, double &f_out,
+                                          double (&g)[PPL])
+{
+    const int lane = lane_id();
+    const int S = sv.S, T = sv.T;
+    const double k = theta_at<PPL>(th, 0), m = theta_at<PPL>(th, 1), ls = theta_at<PPL>(th, 2);
+    const double TA = lds.tot1[0], TB = lds.tot2[0];
+
+    // prior terms
+    double pa = 0.0, pb = 0.0;
+#pragma unroll
+    for (int s = 0; s < PPL; ++s) {
+        const int p = lane + s * W;
+        if (p >= 3 && p < 3 + S) pa = pa + __builtin_fabs(th[s]);
+        if (p >= 3 + S && p < sv.P) { const double qq = th[s] / sp->prior[p - 3 - S]; pb = __builtin_fma(qq, qq, pb); }
+    }
+    const double sabs = bfly_sum(pa), sb = bfly_sum(pb);
+    const double s2 = sigma * sigma;
+    double f = ((0.5 * k) * k) / 25.0 + ((0.5 * m) * m) / 25.0;
+    f = f + sabs / sv.tau;
+    f = f + 2.0 * s2;
+    f = f + 0.5 * sb;
+    f = f + (double)T * ls;
+    f = f + (0.5 * sse_t) * inv_s2;
+
+    const double nis = -inv_s2;
+    double gk = 0.0, gm = 0.0;
+    if (GROWTH == 1) {
+        // per-segment sums from suffix sums, then reverse sweep through the gamma recurrence
+        for (int c = lane; c <= S; c += W) {
+            const int Ljm = (c > 0) ? sv.Lj[c - 1] : 0, Ljc = (c < S) ? sv.Lj[c] : 0;
+            const double hiA = (c == 0) ? TA : lds.tp1[c - 1] + lds.tot1[Ljm + 1];
+            const double hiB = (c == 0) ? TB : lds.tp2[c - 1] + lds.tot2[Ljm + 1];
+            const double loA = (c == S) ? 0.0 : lds.tp1[c] + lds.tot1[Ljc + 1];
+            const double loB = (c == S) ? 0.0 : lds.tp2[c] + lds.tot2[Ljc + 1];
+            const double A = hiA - loA, B = hiB - loB;
+            scr.d1[c] = A - lds.mc[c] * B;
+            scr.d2[c] = -(lds.ks[c] * B);
+        }
+        TSF_WAVE_SYNC();
+        {
+            // reverse sweep through the gamma recurrence: the per-step operands (ks[c]/ks[c+1],
+            // t_change[c] - mc[c], d2[c]) are prepared lane-parallel (lane c), the sequential
+            // chain itself only multiplies and adds
+            const int cl = lane <= S ? lane : S;
+            const double ratio_l = (lane < S) ? lds.ks[cl] / lds.ks[cl + 1] : 0.0;
+            const double tmc_l = (lane < S) ? sv.t_change[cl] - lds.mc[cl] : 0.0;
+            const double d2_l = scr.d2[cl];
+            double abar = readlane_f64(d2_l, S);
+            for (int c = S - 1; c >= 0; --c) {
+                const double rbc = abar * readlane_f64(tmc_l, c);
+                if (lane == c) scr.rb[c] = rbc;
+                abar = readlane_f64(d2_l, c) + abar * readlane_f64(ratio_l, c);
+            }
+            gm = nis * abar;
+        }
+        TSF_WAVE_SYNC();
+        for (int c = lane; c <= S; c += W) {
+            double d = scr.d1[c];
+            if (c < S) d = d + scr.rb[c] * (-1.0 / lds.ks[c + 1]);
+            if (c >= 1) d = d + scr.rb[c - 1] * ((lds.ks[c - 1] / lds.ks[c]) / lds.ks[c]);
+            scr.ab[c] = d;
+        }
+        TSF_WAVE_SYNC();
+    }
+
+#pragma unroll
+    for (int s = 0; s < PPL; ++s) g[s] = 0.0;
+    if (GROWTH == 1) {
+        // sequential suffix of the adjusted per-segment sums: gd[c-1] = nis * sum_{c'>=c} D1[c']
+        double sK = 0.0;
+        for (int c = S; c >= 1; --c) {
+            sK = sK + scr.ab[c];
+#pragma unroll
+            for (int s = 0; s < PPL; ++s)
+                if (lane + s * W == 3 + (c - 1)) g[s] = nis * sK;
+        }
+        gk = nis * (sK + scr.ab[0]);
+    } else {
+        gk = nis * TA;
+        gm = nis * TB;
+    }
+    bool bad = !finite_f64(f);
+#pragma unroll
+    for (int s = 0; s < PPL; ++s) {
+        const int p = lane + s * W;
+        double gv = 0.0;
+        if (p == 0) gv = gk + k / 25.0;
+        else if (p == 1) gv = gm + m / 25.0;
+        else if (p == 2) gv = ((double)T - sse_t * inv_s2) + 4.0 * s2;
+        else if (p < 3 + S) {
+            const int j = p - 3;
+            double gd;
+            if (GROWTH == 0) {
+                const int Lj = sv.Lj[j];
+                const double SA = lds.tp1[j] + lds.tot1[Lj + 1];
+                const double SB = lds.tp2[j] + lds.tot2[Lj + 1];
+                gd = nis * (SA - sv.t_change[j] * SB);
+            } else {
+                gd = g[s];
+            }
+            const double dj = th[s];
+            const double sgn = (double)((dj > 0.0) - (dj < 0.0));
+            gv = gd + sgn / sv.tau;
+        } else if (p < sv.P) {
+            const int j = p - 3 - S;
+            const double pr = sp->prior[j];
+            gv = nis * lds.accR[j] + th[s] / (pr * pr);
+        }
+        g[s] = gv;
+        bad = bad || !finite_f64(gv);
+    }
+    f_out = f;
+    TSF_WAVE_SYNC();
+    return __any(bad);
+}
+
 // MODE: 0 all columns additive, 1 all multiplicative, 2 mixed (Ka additive first)
 template <int KP, int GROWTH, int MODE, int PPL, bool XIDX = false>
 __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesView &sv,
@@ -99,38 +262,7 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
 #pragma unroll
         for (int s = 0; s < PPL; ++s) lds.th[lane + s * W] = th[s];
     }
-    // segment tables ks[c], mc[c]: sequential recurrences over the changepoints.  Every lane
-    // runs the same S steps and lane c stops updating after its first c terms, so lane c ends
-    // with exactly the sequentially rounded ks[c], mc[c] (no per-step LDS write / table load).
-    {
-        double ksv = k, mcv = m;
-        const double tcl = (lane < S) ? sv.t_change[lane] : 0.0;
-        if (GROWTH == 0) {
-            for (int j = 0; j < S; ++j) {
-                const double dj = theta_at<PPL>(th, 3 + j);
-                const double ksn = ksv + dj;
-                const double mcn = mcv + ((-readlane_f64(tcl, j)) * dj);
-                if (j < lane) { ksv = ksn; mcv = mcn; }
-            }
-        } else {
-            // logistic: gamma_j needs ks[j] / ks[j+1].  ks does not depend on mc, so the ks chain
-            // runs first, the S quotients are ONE lane-parallel division (lane j: ks[j]/ks[j+1],
-            // the operands of the sequential form), and the mc chain reads them by lane.
-            double ks_next = k;
-            for (int j = 0; j < S; ++j) {
-                const double ksn = ksv + theta_at<PPL>(th, 3 + j);
-                if (j == lane) ks_next = ksn;
-                if (j < lane) ksv = ksn;
-            }
-            const double ratio = ksv / ks_next;
-            for (int j = 0; j < S; ++j) {
-                const double gamma = (readlane_f64(tcl, j) - mcv) * (1.0 - readlane_f64(ratio, j));
-                const double mcn = mcv + gamma;
-                if (j < lane) mcv = mcn;
-            }
-        }
-        if (lane <= S) { lds.ks[lane] = ksv; lds.mc[lane] = mcv; }
-    }
+    segment_tables<GROWTH, PPL>(sv, lds, th);
     double bs[HOLD ? KP : 1];
     if (HOLD) {
 #pragma unroll
@@ -228,115 +360,7 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
     if (lane == 0) { lds.tot1[W] = 0.0; lds.tot2[W] = 0.0; }
     column_sums<KP, PPL>(acc, lds);
     TSF_WAVE_SYNC();
-    const double TA = lds.tot1[0], TB = lds.tot2[0];
-
-    // prior terms
-    double pa = 0.0, pb = 0.0;
-#pragma unroll
-    for (int s = 0; s < PPL; ++s) {
-        const int p = lane + s * W;
-        if (p >= 3 && p < 3 + S) pa = pa + __builtin_fabs(th[s]);
-        if (p >= 3 + S && p < sv.P) { const double qq = th[s] / sp->prior[p - 3 - S]; pb = __builtin_fma(qq, qq, pb); }
-    }
-    const double sabs = bfly_sum(pa), sb = bfly_sum(pb);
-    const double s2 = sigma * sigma;
-    double f = ((0.5 * k) * k) / 25.0 + ((0.5 * m) * m) / 25.0;
-    f = f + sabs / sv.tau;
-    f = f + 2.0 * s2;
-    f = f + 0.5 * sb;
-    f = f + (double)T * ls;
-    f = f + (0.5 * sse_t) * inv_s2;
-
-    const double nis = -inv_s2;
-    double gk = 0.0, gm = 0.0;
-    if (GROWTH == 1) {
-        // per-segment sums from suffix sums, then reverse sweep through the gamma recurrence
-        for (int c = lane; c <= S; c += W) {
-            const int Ljm = (c > 0) ? sv.Lj[c - 1] : 0, Ljc = (c < S) ? sv.Lj[c] : 0;
-            const double hiA = (c == 0) ? TA : lds.tp1[c - 1] + lds.tot1[Ljm + 1];
-            const double hiB = (c == 0) ? TB : lds.tp2[c - 1] + lds.tot2[Ljm + 1];
-            const double loA = (c == S) ? 0.0 : lds.tp1[c] + lds.tot1[Ljc + 1];
-            const double loB = (c == S) ? 0.0 : lds.tp2[c] + lds.tot2[Ljc + 1];
-            const double A = hiA - loA, B = hiB - loB;
-            lds.d1[c] = A - lds.mc[c] * B;
-            lds.d2[c] = -(lds.ks[c] * B);
-        }
-        TSF_WAVE_SYNC();
-        {
-            // reverse sweep through the gamma recurrence: the per-step operands (ks[c]/ks[c+1],
-            // t_change[c] - mc[c], d2[c]) are prepared lane-parallel (lane c), the sequential
-            // chain itself only multiplies and adds
-            const int cl = lane <= S ? lane : S;
-            const double ratio_l = (lane < S) ? lds.ks[cl] / lds.ks[cl + 1] : 0.0;
-            const double tmc_l = (lane < S) ? sv.t_change[cl] - lds.mc[cl] : 0.0;
-            const double d2_l = lds.d2[cl];
-            double abar = readlane_f64(d2_l, S);
-            for (int c = S - 1; c >= 0; --c) {
-                const double rbc = abar * readlane_f64(tmc_l, c);
-                if (lane == c) lds.rb[c] = rbc;
-                abar = readlane_f64(d2_l, c) + abar * readlane_f64(ratio_l, c);
-            }
-            gm = nis * abar;
-        }
-        TSF_WAVE_SYNC();
-        for (int c = lane; c <= S; c += W) {
-            double d = lds.d1[c];
-            if (c < S) d = d + lds.rb[c] * (-1.0 / lds.ks[c + 1]);
-            if (c >= 1) d = d + lds.rb[c - 1] * ((lds.ks[c - 1] / lds.ks[c]) / lds.ks[c]);
-            lds.ab[c] = d;
-        }
-        TSF_WAVE_SYNC();
-    }
-
-#pragma unroll
-    for (int s = 0; s < PPL; ++s) g[s] = 0.0;
-    if (GROWTH == 1) {
-        // sequential suffix of the adjusted per-segment sums: gd[c-1] = nis * sum_{c'>=c} D1[c']
-        double sK = 0.0;
-        for (int c = S; c >= 1; --c) {
-            sK = sK + lds.ab[c];
-#pragma unroll
-            for (int s = 0; s < PPL; ++s)
-                if (lane + s * W == 3 + (c - 1)) g[s] = nis * sK;
-        }
-        gk = nis * (sK + lds.ab[0]);
-    } else {
-        gk = nis * TA;
-        gm = nis * TB;
-    }
-    bool bad = !finite_f64(f);
-#pragma unroll
-    for (int s = 0; s < PPL; ++s) {
-        const int p = lane + s * W;
-        double gv = 0.0;
-        if (p == 0) gv = gk + k / 25.0;
-        else if (p == 1) gv = gm + m / 25.0;
-        else if (p == 2) gv = ((double)T - sse_t * inv_s2) + 4.0 * s2;
-        else if (p < 3 + S) {
-            const int j = p - 3;
-            double gd;
-            if (GROWTH == 0) {
-                const int Lj = sv.Lj[j];
-                const double SA = lds.tp1[j] + lds.tot1[Lj + 1];
-                const double SB = lds.tp2[j] + lds.tot2[Lj + 1];
-                gd = nis * (SA - sv.t_change[j] * SB);
-            } else {
-                gd = g[s];
-            }
-            const double dj = th[s];
-            const double sgn = (double)((dj > 0.0) - (dj < 0.0));
-            gv = gd + sgn / sv.tau;
-        } else if (p < sv.P) {
-            const int j = p - 3 - S;
-            const double pr = sp->prior[j];
-            gv = nis * lds.accR[j] + th[s] / (pr * pr);
-        }
-        g[s] = gv;
-        bad = bad || !finite_f64(gv);
-    }
-    f_out = f;
-    TSF_WAVE_SYNC();
-    return __any(bad);
+    return eval_tail<GROWTH, PPL>(sp, sv, lds, lds, th, sigma, inv_s2, sse_t, f_out, g);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -415,6 +439,10 @@ struct FitArgs {
     const int32_t *uw;                  // [grid][NTmax][64] lattice row of each series row
     const double *Xu;                   // [U][KP]
     int xidx;
+    // launch guard: when run_flag is set the kernel runs only if (*run_flag != 0) == (run_if != 0)
+    // (the one-wave kernel as the fallback of the matrix-core kernel, decided on the device)
+    const int *run_flag;
+    int run_if;
 };
 
 template <int KP, int PPL>
@@ -509,6 +537,7 @@ __global__ __launch_bounds__(64) void fit_kernel(FitArgs a)
     WaveLds<KP, PPL> &lds = *reinterpret_cast<WaveLds<KP, PPL> *>(smem);
     const int64_t n = blockIdx.x;
     if (n >= a.N) return;
+    if (a.run_flag && (*a.run_flag != 0) != (a.run_if != 0)) return;
     const int lane = threadIdx.x;
     const DevSpec *sp = a.sp;
     SeriesView sv;

@@ -1,9 +1,12 @@
 // tsf_launch.h -- launcher entry points of the per-(GROWTH, MODE) kernel translation units.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
 namespace tsf {
 struct FitArgs;
 struct QuadArgs;
+struct MfmaTabs;
 struct QuadPlan { int P4, PPL, NW, blocks, slots; };
 int quad_waves_per_block(int PPL);
 // gram_build_kernel + fit_quad_kernel (tsf_inst_quad.hip)
@@ -14,6 +17,12 @@ int launch_g0m2(int KP, const FitArgs &a, int eval_only, hipStream_t st);
 int launch_g1m0(int KP, const FitArgs &a, int eval_only, hipStream_t st);
 int launch_g1m1(int KP, const FitArgs &a, int eval_only, hipStream_t st);
 int launch_g1m2(int KP, const FitArgs &a, int eval_only, hipStream_t st);
+// fit_mfma_kernel (aligned panels, residual form, 16 series per workgroup on the matrix cores;
+// tsf_inst_mfma.hip)
+size_t mfma_lds_bytes(int KP);
+int launch_mfma_layout(const FitArgs &a, int KP, const MfmaTabs &mt, double *XF, double *XB, double *XT,
+                       double *tq, uint16_t *cq, int8_t *cpof, double *yq, int *overflow, hipStream_t st);
+int launch_mfma(int KP, int growth, int mode, const FitArgs &a, const MfmaTabs &mt, int blocks, hipStream_t st);
 // newton_kernel (Stan's Newton optimiser; P <= 64, one explicit-mode kernels only)
 int launch_newton_g0m0(int KP, const FitArgs &a, int PM, hipStream_t st);
 int launch_newton_g0m1(int KP, const FitArgs &a, int PM, hipStream_t st);

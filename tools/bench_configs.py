@@ -37,6 +37,30 @@ def build(name):
         spec = fc.ModelSpec(growth='logistic', seasonality_mode='multiplicative', seasonalities=[YEARLY, WEEKLY])
         return ('%d x 730 logistic + multiplicative yearly+weekly (reference settings, aligned)' % N,
                 spec, ds, y, np.zeros(N), y.max(axis=1) * 1.1, None, None, T * 8 + 54 * 8 + H * 8 + 8)
+    if name.startswith('cap'):
+        # throughput without stragglers: the reference's settings, max_iter capped.  cap<N>_<wave|mfma>
+        parts = name.split('_')
+        N, T = int(parts[0][3:]), 730
+        from time_series_spark_amd import _lib
+        rk = {'wave': _lib.RK_WAVE, 'mfma': _lib.RK_MFMA}[parts[1]]
+        ds, y = synth.make_panel(N, T, 'logistic', seed=751)
+        spec = fc.ModelSpec(growth='logistic', seasonality_mode='multiplicative', seasonalities=[YEARLY, WEEKLY],
+                            residual_kernel=rk, max_iter=150)
+        return ('%d x 730 reference settings, max_iter 150, residual kernel %s' % (N, parts[1]),
+                spec, ds, y, np.zeros(N), y.max(axis=1) * 1.1, None, None, T * 8 + 54 * 8 + H * 8 + 8)
+    if name.startswith('long'):
+        # long histories (the reference's example config is 15-minute data): which residual kernel?
+        # long<T>_<wave|mfma>[_<N>], e.g. long8760_mfma_2048
+        parts = name.split('_')
+        T = int(parts[0][4:])
+        N = int(parts[2]) if len(parts) > 2 else 2048
+        from time_series_spark_amd import _lib
+        rk = {'wave': _lib.RK_WAVE, 'mfma': _lib.RK_MFMA}[parts[1]]
+        ds, y = synth.make_panel(N, T, 'logistic', seed=751)
+        spec = fc.ModelSpec(growth='logistic', seasonality_mode='multiplicative', seasonalities=[YEARLY, WEEKLY],
+                            residual_kernel=rk)
+        return ('%d x %d logistic + multiplicative yearly+weekly, residual kernel %s' % (N, T, parts[1]),
+                spec, ds, y, np.zeros(N), y.max(axis=1) * 1.1, None, None, T * 8 + 54 * 8 + H * 8 + 8)
     if name in ('lin_hol', 'lin_hol_resid'):   # linear + additive with 30 holiday columns: P = 84, two-slot kernels
         N, T = 10000, 730
         ds = synth.daily_grid(T)
