@@ -10,9 +10,11 @@ of that fit + predict over the whole panel with the panel already resident in HB
   python bench.py --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-Multi-GPU: series are sharded by id, one rank per GPU, every rank fits its own 10 000-series
-panel (weak scaling), no data-path collective; torch.distributed (RCCL) only brackets the
-timed region.  Rank 0 prints one JSON line.
+Multi-GPU: series are sharded by id, one rank per GPU, no data-path collective;
+torch.distributed (RCCL) only brackets the timed regions.  `value` is WEAK scaling (every rank
+fits its own 10 000-series panel); for N > 1 the same line also carries `strong_scaling`: the
+BASELINE metric's "10k x 730 panel at 1/2/4/8 GPUs" read literally -- ONE 10 000-series panel
+split over the ranks (series i on rank i mod N), timed the same way.  Rank 0 prints one JSON line.
 """
 import argparse
 import json
@@ -67,8 +69,8 @@ def cpu_baseline(spec, ds, y, fut, budget_s=12.0, yhat_gpu=None):
 
     def one(n):
         r = cl.fit(csp, ds, y[n])
-        cl.predict(csp, r, fut)
-        return r['n_eval']
+        yo, _ = cl.predict(csp, r, fut)
+        return r['n_eval'], yo
 
     t0 = time.perf_counter()
     one(0)
@@ -76,20 +78,65 @@ def cpu_baseline(spec, ds, y, fut, budget_s=12.0, yhat_gpu=None):
     sample = int(min(y.shape[0], max(cores * 2, budget_s * cores / per)))
     t0 = time.perf_counter()
     with ThreadPoolExecutor(max_workers=cores) as ex:
-        evals = list(ex.map(one, range(sample)))
+        done = list(ex.map(one, range(sample)))
     dt = time.perf_counter() - t0
-    worst = None
+    evals = [d[0] for d in done]
+    worst, checked = None, 0
     if yhat_gpu is not None:        # checker use of the same oracle: GPU forecasts vs oracle
-        worst = 0.0
-        for n in range(len(yhat_gpu)):
-            yo, _ = cl.predict(csp, cl.fit(csp, ds, y[n]), fut)
-            worst = max(worst, float(np.max(np.abs(yhat_gpu[n] - yo) / np.abs(yo))))
+        checked = min(len(yhat_gpu), sample)
+        worst = max(float(np.max(np.abs(yhat_gpu[n] - done[n][1]) / np.abs(done[n][1]))) for n in range(checked))
     return {'value': sample / dt, 'unit': 'series/s', 'cores': cores, 'kind': 'port',
-            'parity_max_rel_err': worst,
+            'parity_max_rel_err': worst, 'parity_series_checked': checked,
             'sample': '%d of %d series of the same panel (fit + %d-step forecast), '
                       'oracle/prophet_canon.c on %d threads, %.1f s wall'
                       % (sample, y.shape[0], len(fut), cores, dt),
             'mean_evals': float(np.mean(evals))}
+
+
+def kernel_sources_digest():
+    """sha256 (first 16 hex digits) over the HIP sources + the C-ABI header, in name order."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, 'time_series_spark_amd', 'csrc', '*')))
+    files.append(os.path.join(ROOT, 'include', 'tsf.h'))
+    for f in files:
+        if f.endswith(('.h', '.hip', '.inc', '.cpp')):
+            h.update(os.path.basename(f).encode())
+            with open(f, 'rb') as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def parity_context(f, spec, ds, y, fut, yhat_quad, n=256):
+    """What "identical to the oracle" does and does not mean: Stan's L-BFGS at
+    Stan's tolerances stops far from the optimum, so the forecast is a chaotic function of rounding.
+    Two measurements on the first n series of the panel, both on the GPU: (a) the same series
+    fitted in the residual evaluation form (Stan's own order of operations) instead of the
+    quadratic form, (b) the quadratic form with ONE input value per series moved by one ulp.
+    Reported as {median, p90} over series of the per-series median relative forecast difference:
+    the level at which ANY implementation -- including another build of Stan -- reproduces the
+    reference's output."""
+    import torch
+    from time_series_spark_amd import _lib
+    n = min(n, y.shape[0])
+    out = {}
+    for key, sp, yy in (
+            ('forecast_rel_err_quadratic_vs_residual',
+             fc.ModelSpec.from_dict(dict(spec.to_dict(), lbfgs=dict(spec.lbfgs, eval_form=_lib.EVAL_RESIDUAL))), y[:n]),
+            ('forecast_rel_err_one_ulp_perturbation', spec, None)):
+        if yy is None:
+            yy = y[:n].clone()
+            mid = yy.shape[1] // 2
+            yy[:, mid] = torch.nextafter(yy[:, mid], torch.full_like(yy[:, mid], float('inf')))
+        g = DeviceForecaster(sp, f.device_index)
+        o = g.alloc_fit_output(n)
+        yh = torch.zeros((n, len(fut)), dtype=torch.float64, device=y.device)
+        g.fit_aligned(ds, yy.contiguous(), o)
+        g.predict(o, fut, yh, None)
+        rel = (torch.abs(yh - yhat_quad[:n]) / torch.abs(yhat_quad[:n])).median(dim=1).values.cpu().numpy()
+        out[key] = {'median': float(np.median(rel)), 'p90': float(np.quantile(rel, 0.9)), 'series': int(n)}
+    return out
 
 
 def pmc_traffic(kernel):
@@ -105,6 +152,11 @@ def pmc_traffic(kernel):
         k = d['kernels'][kernel]
         if d.get('series_per_launch') != N_SERIES or d.get('points') != T_POINTS:
             return None, 'profiles/pmc_latest.json is for another workload size'
+        # counters are only as current as the kernels they were collected on: the profile records a
+        # digest of the kernel sources (tools/pmc_summary.py) and a stale one is refused
+        if d.get('kernel_sources_sha16') != kernel_sources_digest():
+            return None, ('profiles/pmc_latest.json was collected on other kernel sources (%s, now %s): '
+                          're-run tools/gpu_round.sh' % (d.get('kernel_sources_sha16'), kernel_sources_digest()))
         return (2.0 * k['FETCH_SIZE_KiB'] + k['WRITE_SIZE_KiB']) * 1024.0, d.get('source', path)
     except Exception as e:       # no profile committed for this kernel
         return None, 'unavailable: %s' % e
@@ -122,6 +174,7 @@ def main():
     rank, world, local = parallel.init_process_group()
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (no CPU fallback in the product path)')
+    local = local % torch.cuda.device_count()      # one visible device per rank (ROCR_VISIBLE_DEVICES) or all
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
 
@@ -155,6 +208,37 @@ def main():
     dt = parallel.max_over_ranks(dt, dev if world > 1 else None)
     kernel_ms = f.profile_read()
     f.set_profiling(False)
+
+    # strong scaling: ONE N_SERIES panel (rank 0's) split over the ranks, series i on rank i mod world
+    strong = None
+    if world > 1:
+        ds0, y0 = synth.make_panel(N_SERIES, T_POINTS, 'linear', seed=751)
+        ys = torch.from_numpy(np.ascontiguousarray(y0[rank::world])).to(dev)
+        ns = ys.shape[0]
+        outs = f.alloc_fit_output(ns)
+        yhs = torch.zeros((ns, HORIZON), dtype=torch.float64, device=dev)
+        yis = torch.zeros((ns, HORIZON), dtype=torch.int32, device=dev)
+
+        def sstep():
+            f.fit_aligned(ds, ys, outs)
+            f.predict(outs, fut, yhs, yis)
+
+        for _ in range(max(args.warmup, 1)):
+            sstep()
+        torch.cuda.synchronize()
+        parallel.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            sstep()
+        torch.cuda.synchronize()
+        parallel.barrier()
+        dts = parallel.max_over_ranks(time.perf_counter() - t1, dev)
+        strong = {'value': N_SERIES * args.steps / dts, 'unit': 'series/s', 'ms_per_step': 1e3 * dts / args.steps,
+                  'series_total': N_SERIES, 'series_per_gpu': int(ns), 'scaling': 'strong',
+                  'note': 'one %d-series panel split over %d GPUs (series i on rank i mod %d); a launch is '
+                          'bounded below by its longest series, so strong scaling of a 10k panel saturates '
+                          'early (DESIGN.md section 7)' % (N_SERIES, world, world)}
 
     if rank != 0:
         return
@@ -227,22 +311,36 @@ def main():
                       'status_counts': {str(int(k)): int(v) for k, v in
                                         zip(*np.unique(status, return_counts=True))}},
     }
+    if strong is not None:
+        res['strong_scaling'] = strong
     # host-pointer entry point (what a DataFrame caller uses): the panel crosses PCIe, device
-    # buffers are allocated per call; never part of `value`
+    # buffers are allocated per call; never part of `value`, reported beside it
     if world == 1:
+        fc.fit_aligned(spec, ds_np, y_np[:64])          # context + buffer pool warm
         t0 = time.perf_counter()
         rh = fc.fit_aligned(spec, ds_np, y_np)
         fc.predict(spec, rh.theta, rh.y_scale, rh.grid, fut_np)
-        res['host_pointer_entry'] = {'ms_per_call': 1e3 * (time.perf_counter() - t0),
+        th = time.perf_counter() - t0
+        res['value_end_to_end_host_pointer'] = N_SERIES / th
+        res['host_pointer_entry'] = {'ms_per_call': 1e3 * th,
                                      'note': 'tsf_fit_aligned + tsf_predict with host buffers: H2D of the '
-                                             '%.0f MB panel, per-call hipMalloc, D2H of the results'
+                                             '%.0f MB panel over PCIe, D2H of the results'
                                              % (y_np.nbytes / 1e6)}
+        try:
+            res['parity_context'] = parity_context(f, spec, ds, y, fut, yhat)
+        except Exception as e:
+            res['parity_context'] = {'error': str(e)}
     # cpu_baseline leg (rank 0, N=1 only): the CPU oracle timed on the host cores, and -- the
     # same leg, the oracle as checker -- the GPU forecasts of the sampled series compared with it
     if world == 1 and not args.no_cpu_baseline:
         try:
-            res['cpu_baseline'] = cpu_baseline(spec, ds_np, y_np, fut_np, yhat_gpu=yhat[:4].cpu().numpy())
+            res['cpu_baseline'] = cpu_baseline(spec, ds_np, y_np, fut_np, yhat_gpu=yhat[:512].cpu().numpy())
             res['forecast_max_rel_err_vs_oracle'] = res['cpu_baseline'].pop('parity_max_rel_err')
+            res['forecast_series_checked_vs_oracle'] = res['cpu_baseline'].pop('parity_series_checked')
+            res['parity_note'] = ('oracle = oracle/prophet_canon.c in the SAME evaluation form and arithmetic order '
+                                  '(bit-identical by construction: a regression guard); it restates fbprophet 0.5 / '
+                                  'Stan 2.19 from recall and is NOT pinned to real fbprophet output (none can be '
+                                  'produced here).  parity_context = how far two correct runs differ.')
         except Exception as e:
             res['cpu_baseline'] = {'value': None, 'unit': 'series/s', 'cores': os.cpu_count(),
                                    'kind': 'port', 'sample': 'failed: %s' % e}

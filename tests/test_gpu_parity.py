@@ -642,3 +642,44 @@ def test_reference_contract_fit_and_forecast_udfs(env, tmp_path):
     assert scorer_driver.main(['x', str(tmp_path / 's.yaml')]) == 0
     conv = ps.ProphetScorer.score(None, sconfig)
     assert len(conv) == 80 and np.array_equal(np.sort(conv['forecast_quantity'].values), np.sort(fdf['yhat'].values))
+
+
+def test_holidays_through_the_job_layer(env):
+    """SURVEY 8a U5 / BASELINE cfg4 shape through the reference-shaped functions: Prophet(holidays=...)
+    via config['model']['prophet'], model_panel -> model blobs (which carry the holidays) ->
+    forecast_panel, against the oracle fed with the LITERAL make_holiday_features columns."""
+    fc, cl = env
+    from time_series_spark_amd import synth
+    from time_series_spark_amd.jobs import prophet_modeler as pm, prophet_scorer as ps
+    from oracle.fbprophet_restated import ProphetOracle
+    T, H = 400, 30
+    ds, y = synth.make_panel(3, T, 'logistic', seed=12)
+    days = pd.to_datetime(ds)
+    hol = pd.DataFrame({'holiday': ['a'] * 3 + ['b'] * 2,
+                        'ds': [days[40], days[200], days[-1] + pd.Timedelta(days=10), days[120], days[390]],
+                        'lower_window': [-1] * 3 + [0] * 2, 'upper_window': [1] * 3 + [2] * 2})
+    frames = [pd.DataFrame({'series_id': 7, 'dim_id': n, 'ds': days, 'y': y[n]}) for n in range(2)]
+    frames.append(pd.DataFrame({'series_id': 7, 'dim_id': 2, 'ds': days[:350], 'y': y[2][:350]}))   # other grid
+    df = pd.concat(frames, ignore_index=True)
+    config = {'model': {'floor': 0, 'cap_multiplier': 1.1, 'prophet': {'holidays': hol, 'yearly_seasonality': False}},
+              'forecast': {'periods': H, 'frequency': 'D'}}
+    models = pm.model_panel(config)(df)
+    assert len(models) == 3
+    fcst = ps.forecast_panel(config)(models)
+    assert len(fcst) == 3 * H
+    m = ProphetOracle(holidays=hol)
+    for n, Tn in ((0, T), (1, T), (2, 350)):
+        dsn = ds[:Tn]
+        fut = dsn[-1] + helpers.DAY_NS * np.arange(1, H + 1)
+        cols, scales, _ = m.make_holiday_features(pd.Series(pd.to_datetime(dsn)), hol)
+        colsf, _, _ = m.make_holiday_features(pd.Series(pd.to_datetime(fut)), hol)
+        assert list(cols.columns) == sorted(cols.columns) and len(cols.columns) == 3 + 3
+        csp = cl.make_spec(growth='logistic', seasonalities=[(7, 3, 'multiplicative', 10.0)],
+                           extra=[('multiplicative', s) for s in scales])
+        cap = float(np.float32(y[n][:Tn].max() * 1.1))          # the scorer reads cap back as float32
+        o = cl.fit(csp, dsn, y[n][:Tn], 0.0, y[n][:Tn].max() * 1.1, cols.values.T)
+        yo, _ = cl.predict(csp, o, fut, 0.0, cap, colsf.values.T)
+        got = fcst[fcst['dim_id'] == n]
+        assert np.array_equal(got['ds'].values.astype('datetime64[ns]').astype(np.int64), fut)
+        assert np.array_equal(got['yhat'].values, np.maximum(np.trunc(yo), 0).astype(np.int32))
+        assert colsf.values.any() or n == 2                     # the future window holds a holiday

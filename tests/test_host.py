@@ -399,6 +399,23 @@ def test_device_list_and_block_cuts(monkeypatch):
     assert per.max() - per.min() <= 2 * rows.max()
 
 
+def test_interleaved_device_split_round_trips():
+    """In-process multi-GPU: series i -> device i mod G, merged back in series order."""
+    N, G = 11, 3
+    spec = fc.ModelSpec(seasonalities=[{'name': 'weekly', 'period': 7, 'fourier_order': 3}])
+    full = np.arange(N, dtype=np.float64)
+    parts = []
+    for d in range(G):
+        idx = full[d::G]
+        parts.append(fc.FitResult(spec, np.stack([idx, idx + 0.5], axis=1), idx * 2, idx * 3,
+                                  idx.astype(np.int32), idx.astype(np.int32) + 1, idx.astype(np.int32) + 2,
+                                  np.zeros(1, dtype=_lib.GRID_DTYPE)))
+    m = fc._merge_interleaved(spec, parts, N, G)
+    assert np.array_equal(m.theta[:, 0], full) and np.array_equal(m.theta[:, 1], full + 0.5)
+    assert np.array_equal(m.y_scale, 2 * full) and np.array_equal(m.status, full.astype(np.int32))
+    assert np.array_equal(m.n_eval, full.astype(np.int32) + 2) and len(m.grid) == 1
+
+
 def test_native_forecast_sink_writes_the_same_file_as_the_frame_path(tmp_path):
     rng = np.random.default_rng(2)
     n = 200000                                               # several 65 536-row blocks, 2+ threads
@@ -533,3 +550,55 @@ def test_native_csv_reader_cuts_big_files_into_segments(tmp_path):
     f.write_text('\n'.join(lines))
     with pytest.raises(ValueError, match='line %d ' % (n - 4)):
         pm.read_model_input([str(f)], str(f), n_threads=4)
+
+
+def test_holiday_columns_match_the_literal_make_holiday_features():
+    """time_series_spark_amd/features.py against the method-by-method restatement of
+    Prophet.make_holiday_features (oracle/fbprophet_restated.py): names, order, prior scales,
+    indicator values -- intraday timestamps, duplicate timestamps, windows, a holiday with no
+    matching row, dates before 1970."""
+    from time_series_spark_amd import features
+    from oracle.fbprophet_restated import ProphetOracle
+    rng = np.random.default_rng(5)
+    ds = pd.to_datetime(np.sort(rng.integers(-40, 400, 300)) * 86400 * 10 ** 9 + rng.integers(0, 86400, 300) * 10 ** 9)
+    hol = pd.DataFrame({'holiday': ['xmas', 'xmas', 'sale', 'sale', 'never', 'old'],
+                        'ds': pd.to_datetime(['1970-12-25', '1971-12-25', '1970-03-01', '1970-06-01', '1990-01-01',
+                                              '1969-12-20']),
+                        'lower_window': [-2, -2, 0, 0, -1, 0], 'upper_window': [1, 1, 3, 3, 1, 2],
+                        'prior_scale': [5.0, 5.0, np.nan, np.nan, 2.0, 10.0]})
+    m = ProphetOracle(holidays=hol, holidays_prior_scale=7.0)
+    lit, lit_scales, _names = m.make_holiday_features(pd.Series(ds), hol)
+    norm = features.normalize_holidays(hol, 7.0)
+    names, scales, days = features.holiday_columns(norm)
+    assert names == list(lit.columns) and scales == list(lit_scales)
+    X = features.holiday_matrix(ds.asi8, days)
+    assert np.array_equal(X, lit.values.T)
+    assert X.sum() > 0 and not X[names.index('never_delim_+0')].any()
+    # the normalised form survives JSON (it travels in the model blob) and a list-of-dicts config
+    import json
+    again = features.normalize_holidays(json.loads(json.dumps(norm)))
+    assert features.holiday_columns(again)[0] == names
+    cfg = [{'holiday': 'xmas', 'ds': ['1970-12-25', '1971-12-25'], 'lower_window': -2, 'upper_window': 1,
+            'prior_scale': 5.0}]
+    n2, s2, d2 = features.holiday_columns(features.normalize_holidays(cfg))
+    i = [names.index(n) for n in n2]
+    assert np.array_equal(features.holiday_matrix(ds.asi8, d2), X[i]) and s2 == [5.0] * 4
+    with pytest.raises(ValueError, match='consistent prior scale'):
+        features.normalize_holidays(pd.DataFrame({'holiday': ['a', 'a'], 'ds': pd.to_datetime(['2020-01-01'] * 2),
+                                                  'prior_scale': [1.0, 2.0]}))
+
+
+def test_regressor_standardisation_rule():
+    from time_series_spark_amd import features
+    from oracle.fbprophet_restated import ProphetOracle
+    rng = np.random.default_rng(6)
+    ds = pd.date_range('2020-01-01', periods=50)
+    for vals in (rng.normal(3, 2, 50), rng.integers(0, 2, 50).astype(float), np.full(50, 4.0),
+                 rng.integers(0, 3, 50).astype(float)):
+        m = ProphetOracle()
+        m.add_regressor('x')
+        df = pd.DataFrame({'ds': ds, 'y': rng.normal(10, 1, 50), 'x': vals})
+        out = m.setup_dataframe(df.copy(), initialize_scales=True)
+        mu, sd = features.standardize_regressor(vals)
+        assert np.allclose(out['x'].values, (vals - mu) / sd, rtol=0, atol=1e-15)
+        assert (mu, sd) == (m.extra_regressors['x']['mu'], m.extra_regressors['x']['std'])

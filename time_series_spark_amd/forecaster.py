@@ -27,7 +27,7 @@ class ModelSpec(object):
     def __init__(self, growth='linear', seasonality_mode='additive', n_changepoints=25,
                  changepoint_range=0.8, changepoint_prior_scale=0.05,
                  seasonality_prior_scale=10.0, holidays_prior_scale=10.0,
-                 seasonalities=None, extra=None, **lbfgs):
+                 seasonalities=None, extra=None, holidays=None, **lbfgs):
         if growth not in ('linear', 'logistic'):
             raise ValueError("Parameter 'growth' should be 'linear' or 'logistic'.")
         if seasonality_mode not in ('additive', 'multiplicative'):
@@ -43,6 +43,10 @@ class ModelSpec(object):
         self.holidays_prior_scale = float(holidays_prior_scale)
         self.seasonalities = [dict(s) for s in (seasonalities or [])]
         self.extra = [dict(e) for e in (extra or [])]
+        # normalised holidays (features.normalize_holidays) whose indicator columns are the FIRST
+        # len(features.holiday_columns(holidays)[0]) entries of `extra`: carried so that the scorer
+        # can rebuild the columns for future dates (fbprophet keeps the holidays frame in the model)
+        self.holidays = list(holidays) if holidays else None
         self.lbfgs = dict(lbfgs)
         for k in self.lbfgs:
             if k not in ('max_iter', 'history', 'init_alpha', 'tol_obj', 'tol_rel_obj',
@@ -139,7 +143,8 @@ class ModelSpec(object):
                 'changepoint_prior_scale': self.changepoint_prior_scale,
                 'seasonality_prior_scale': self.seasonality_prior_scale,
                 'holidays_prior_scale': self.holidays_prior_scale,
-                'seasonalities': self.seasonalities, 'extra': self.extra, 'lbfgs': self.lbfgs}
+                'seasonalities': self.seasonalities, 'extra': self.extra, 'lbfgs': self.lbfgs,
+                **({'holidays': self.holidays} if self.holidays else {})}
 
     @classmethod
     def from_dict(cls, d):
@@ -242,6 +247,18 @@ def _merge_fits(spec, parts, shared_grid):
                      cat('n_eval'), grid)
 
 
+def _merge_interleaved(spec, parts_res, N, parts):
+    """Inverse of the i mod parts split of an aligned panel."""
+    def put(k):
+        first = getattr(parts_res[0], k)
+        out = np.zeros((N,) + first.shape[1:], dtype=first.dtype)
+        for d, p in enumerate(parts_res):
+            out[d::parts] = getattr(p, k)
+        return out
+    return FitResult(spec, put('theta'), put('y_scale'), put('fval'), put('status'), put('n_iter'),
+                     put('n_eval'), parts_res[0].grid)
+
+
 def _opt_f64(a, N, name):
     if a is None:
         return None
@@ -269,14 +286,17 @@ def fit_aligned(spec, ds_ns, y, floor=None, cap=None, extra=None, ctx=None, devi
     devs = None if ctx is not None else resolve_devices(devices)
     if devs and len(y) >= 2 * MIN_SERIES_PER_DEVICE:
         parts = min(len(devs), len(y) // MIN_SERIES_PER_DEVICE)
-        cuts = _cuts(np.ones(len(y), np.int64), parts)
         fl = _opt_f64(floor, len(y), 'floor')
         cp = _opt_f64(cap, len(y), 'cap')
-        blocks = [(c, int(a), int(b)) for c, a, b in zip(_contexts(devs[:parts]), cuts[:-1], cuts[1:])]
-        res = _run_blocks(lambda c, a, b: fit_aligned(
-            spec, ds_ns, y[a:b], None if fl is None else fl[a:b], None if cp is None else cp[a:b],
-            extra, ctx=c), blocks)
-        return _merge_fits(spec, res, shared_grid=True)
+        # series i goes to device i mod parts (evaluation counts vary 3-40x per series and
+        # neighbours in a panel tend to be alike; interleaving evens the devices out where contiguous
+        # blocks would not)
+        y = np.asarray(y)
+        blocks = [(c, d) for d, c in enumerate(_contexts(devs[:parts]))]
+        res = _run_blocks(lambda c, d: fit_aligned(
+            spec, ds_ns, np.ascontiguousarray(y[d::parts]), None if fl is None else fl[d::parts],
+            None if cp is None else cp[d::parts], extra, ctx=c), blocks)
+        return _merge_interleaved(spec, res, len(y), parts)
     ctx = ctx or get_context()
     L = _lib.load()
     ds_ns = np.ascontiguousarray(ds_ns, dtype=np.int64)

@@ -20,7 +20,7 @@ import time
 import numpy as np
 import pandas as pd
 
-from .. import _lib, forecaster as fc, panel as pk
+from .. import _lib, features, forecaster as fc, panel as pk
 
 # prophet_modeler.py:12-17 (names and nullability; types: int, int, timestamp, int)
 MODEL_INPUT_SCHEMA = [('series_id', 'int32'), ('dim_id', 'int32'), ('start_time', 'datetime64[ns]'),
@@ -73,6 +73,11 @@ def fit_packed(panel, floor, cap, kw, devices=None):
             specs[key] = (seas, np.concatenate([specs[key][1], members]))
         else:
             specs[key] = (seas, members)
+    # holidays: Prophet(holidays=...) -> indicator columns after the seasonalities,
+    # sorted by name, one prior scale per holiday, mode = seasonality_mode
+    hol = features.normalize_holidays(kw.get('holidays'), float(kw.get('holidays_prior_scale', 10.0)))
+    hol_names, hol_scales, hol_days = features.holiday_columns(hol)
+    hol_extra = [{'name': n, 'prior_scale': p, 'mode': mode} for n, p in zip(hol_names, hol_scales)]
     blobs = [None] * N
     status = np.zeros(N, dtype=np.int32)
     # make_future_dataframe starts at history_dates.max(): the last ds of the group INCLUDING rows
@@ -93,7 +98,8 @@ def fit_packed(panel, floor, cap, kw, devices=None):
             T = int(panel.lengths[gm[0]])
             a0 = panel.offsets[gm[0]]
             y2d = pk.rows_2d(panel.y, panel.offsets, gm, T)
-            ex = np.zeros((1, T)) if not seas else None
+            ex = features.holiday_matrix(panel.ds_ns[a0:a0 + T], hol_days) if hol_extra else (
+                np.zeros((1, T)) if not seas else None)
             calls.append((gm, fc.fit_aligned(
                 spec, panel.ds_ns[a0:a0 + T], y2d,
                 floor=None if floor is None else np.asarray(floor)[gm],
@@ -104,7 +110,8 @@ def fit_packed(panel, floor, cap, kw, devices=None):
             # rows of the `rest` series, in order: start of each series repeated over its
             # length plus the position inside the series
             idx = np.repeat(panel.offsets[rest] - off[:-1], lens) + np.arange(off[-1], dtype=np.int64)
-            ex = np.zeros((1, len(idx))) if not seas else None
+            ex = features.holiday_matrix(panel.ds_ns[idx], hol_days) if hol_extra else (
+                np.zeros((1, len(idx))) if not seas else None)
             calls.append((rest, fc.fit_ragged(
                 spec, off, panel.ds_ns[idx], panel.y[idx],
                 floor=None if floor is None else np.asarray(floor)[rest],
@@ -119,7 +126,9 @@ def fit_packed(panel, floor, cap, kw, devices=None):
 
     for key, (seas, members) in specs.items():
         members = np.sort(np.asarray(members))
-        if not seas:
+        if hol_extra:
+            model = dict(growth=growth, seasonality_mode=mode, seasonalities=seas, extra=hol_extra, holidays=hol)
+        elif not seas:
             # fbprophet adds a zero column when there is no seasonality at all
             model = dict(growth=growth, seasonality_mode=mode, seasonalities=[],
                          extra=[{'name': 'zeros', 'prior_scale': 1.0, 'mode': 'additive'}])
@@ -131,7 +140,7 @@ def fit_packed(panel, floor, cap, kw, devices=None):
         # fbprophet 0.5: optimizing(algorithm='Newton' if T < 100 else 'LBFGS'), and Newton once
         # more after an L-BFGS RuntimeError (UPSTREAM-RECALL forecaster.py fit).  The
         # Newton kernel holds one parameter per lane: wider models stay on L-BFGS.
-        modes = {s_.get('mode', mode) for s_ in seas}
+        modes = {s_.get('mode', mode) for s_ in seas} | ({mode} if hol_extra else set())
         newton_ok = 3 + lbfgs.n_changepoints + lbfgs.K <= 64 and lbfgs.K <= 28 and len(modes) <= 1
         if algo == 'newton' and not newton_ok:
             raise ValueError('algorithm newton needs 3 + n_changepoints + K <= 64 and one seasonality mode')

@@ -15,7 +15,7 @@ from datetime import datetime, timezone
 import numpy as np
 import pandas as pd
 
-from .. import forecaster as fc, panel as pk
+from .. import features, forecaster as fc, panel as pk
 
 FORECAST_COLUMNS = ['series_id', 'dim_id', 'ds', 'yhat']          # prophet_scorer.py:27-32
 CONVERTED_COLUMNS = ['created_timestamp', 'series_id', 'dim_id', 'forecast_date',
@@ -56,7 +56,16 @@ def forecast_panel(config):
             grid = pk.grid_from_records(rec)
             fut = pk.future_dates(rec['last_ds_ns'], periods, frequency)  # :64-66
             floor, cap = floors[idx], caps[idx]                          # :67-68
-            ex = np.zeros((len(idx), len(spec.extra), periods)) if spec.extra else None
+            ex = None
+            if spec.extra:
+                # holiday columns for the future dates (fbprophet rebuilds them from the holidays
+                # frame it keeps in the model); any other explicit column has no future values in
+                # the reference's scorer (its future frame holds ds, floor, cap only): zeros
+                ex = np.zeros((len(idx), len(spec.extra), periods))
+                if spec.holidays:
+                    names, _scales, days = features.holiday_columns(features.normalize_holidays(spec.holidays))
+                    assert [e['name'] for e in spec.extra[:len(names)]] == names
+                    ex[:, :len(names), :] = np.moveaxis(features.holiday_matrix(fut, days), 0, 1)
             yhat, yint = fc.predict(spec, theta, rec['y_scale'], grid, fut, floor=floor, cap=cap,
                                     extra_future=ex, want_int=True,      # :70-84
                                     devices=config.get('devices'))

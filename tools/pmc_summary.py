@@ -36,7 +36,10 @@ for f in sorted(glob.glob(os.path.join(out, 'prof_*', '**', '*counter_collection
     for (k, c), d in per.items():
         want.setdefault(k, {})[c + '_KiB'] = sum(d.values()) / len(d)
 if want:
-    js = {'kernels': want, 'series_per_launch': int(os.environ.get('BENCH_N', '10000')),
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    js = {'kernels': want, 'kernel_sources_sha16': bench.kernel_sources_digest(),
+          'series_per_launch': int(os.environ.get('BENCH_N', '10000')),
           'points': int(os.environ.get('BENCH_T', '730')),
           'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) around bench.py, '
                     'tools/gpu_round.sh %s' % os.path.basename(os.path.normpath(out))}
