@@ -83,6 +83,7 @@ def lib():
                              ctypes.POINTER(CnFitInfo)]
         L.cn_fit_newton.argtypes = L.cn_fit.argtypes
         L.cn_jacobi_eigh.argtypes = [i32, vp, vp, vp]
+        L.cn_ql_eigh.argtypes = [i32, vp, vp, vp]
         L.cn_fit_checked.argtypes = [ctypes.POINTER(CnSpec), i32, vp, vp, f64, f64, vp, vp,
                                      ctypes.POINTER(CnFitInfo), vp]
         L.cn_predict.argtypes = [ctypes.POINTER(CnSpec), ctypes.POINTER(CnFitInfo), vp, vp, i32,
@@ -229,6 +230,19 @@ def jacobi_eigh(A):
     if sweeps < 0:
         raise ValueError('cn_jacobi_eigh: n out of range')
     return lam, V, sweeps
+
+
+def ql_eigh(A):
+    """The eigen-solver of the oracle's Newton restatement (Householder tridiagonalisation +
+    implicit QL): (eigenvalues, eigenvectors in columns, QL iterations)."""
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    n = A.shape[0]
+    V = np.zeros((n, n))
+    lam = np.zeros(n)
+    its = lib().cn_ql_eigh(n, A.ctypes.data, V.ctypes.data, lam.ctypes.data)
+    if its < 0:
+        raise ValueError('cn_ql_eigh: n out of range')
+    return lam, V, its
 
 
 def fit_checked(sp, ds_ns, y):

@@ -934,7 +934,8 @@ done:
  * NOT pinned against Stan output (parity unpinned); it exists so that a GPU Newton has a
  * checker.  Canonical order (lane = parameter p < 64):
  *   A[d][p]   = fma chain over the 4 perturbations of coordinate d, H[a][b] = A[a][b] + A[b][a];
- *   eigen-decomposition by a round-robin Jacobi (cn_jacobi);
+ *   eigen-decomposition by Householder tridiagonalisation + implicit QL (cn_tridiag_ql; the
+ *   round-robin Jacobi of round 1, cn_jacobi, is kept as an independent cross-check);
  *   proj[j]   = fma chain over i of V[i][j] * g[i];  proj[j] = -proj[j] / |lambda_j|;
  *   step[i]   = fma chain over j of V[i][j] * proj[j];  new[i] = th[i] - size * step[i]. */
 
@@ -1009,6 +1010,111 @@ static int cn_jacobi(int n, double *A, double *V, double *lam)
     return sweep;
 }
 
+/* Symmetric eigen-decomposition by Householder tridiagonalisation + implicit QL with shifts (the
+ * method behind Eigen's SelfAdjointEigenSolver that Stan's newton_step calls, restated in the
+ * classical tred2 / tql2 form) in an operation order that one wavefront can follow: every "for all
+ * j" below is one lane per j, sums over lanes are the 64-slot butterfly, sums over k inside a lane
+ * are sequential fma chains, scalars are computed identically by every lane.
+ * A: [n][n] row-major, full symmetric (destroyed); V: eigenvectors in columns; lam: eigenvalues
+ * (in the order the QL iteration leaves them).  Returns the number of QL iterations. */
+static double cn_pythag(double a, double b)
+{
+    const double absa = fabs(a), absb = fabs(b);
+    if (absa > absb) { const double r = absb / absa; return absa * sqrt(1.0 + r * r); }
+    if (absb == 0.0) return 0.0;
+    { const double r = absa / absb; return absb * sqrt(1.0 + r * r); }
+}
+
+static int cn_tridiag_ql(int n, double *A, double *V, double *lam)
+{
+    double d[CN_NEWTON_MAX_P], e[CN_NEWTON_MAX_P], hh[CN_NEWTON_MAX_P];
+    double u[CN_NEWTON_MAX_P], pv[CN_NEWTON_MAX_P], qv[CN_NEWTON_MAX_P], part[CN_W];
+    for (int i = 0; i < n; ++i) { e[i] = 0.0; hh[i] = 0.0; }
+    /* ---- Householder: zero A[i][0..i-2] for i = n-1 .. 2; reflector u kept in row i, u.u/2 in hh[i] */
+    for (int i = n - 1; i >= 2; --i) {
+        const int l = i - 1;
+        for (int j = 0; j < CN_W; ++j) part[j] = (j < l) ? A[i * n + j] * A[i * n + j] : 0.0;
+        const double sigma = bfly(part);
+        const double alpha = A[i * n + l];
+        if (sigma == 0.0) { e[i] = alpha; hh[i] = 0.0; continue; }
+        const double mu = sqrt(sigma + alpha * alpha);
+        const double beta = (alpha >= 0.0) ? -mu : mu;
+        for (int k = 0; k <= l; ++k) u[k] = A[i * n + k];
+        u[l] = alpha - beta;
+        const double H = 0.5 * (sigma + u[l] * u[l]);
+        for (int j = 0; j <= l; ++j) {                      /* p = A u / H */
+            double a = 0.0;
+            for (int k = 0; k <= l; ++k) a = fma(A[j * n + k], u[k], a);
+            pv[j] = a / H;
+        }
+        for (int j = 0; j < CN_W; ++j) part[j] = (j <= l) ? u[j] * pv[j] : 0.0;
+        const double K = bfly(part) / (2.0 * H);
+        for (int j = 0; j <= l; ++j) qv[j] = pv[j] - K * u[j];
+        for (int j = 0; j <= l; ++j)                        /* A <- A - u q^T - q u^T */
+            for (int k = 0; k <= l; ++k)
+                A[j * n + k] = fma(-qv[j], u[k], fma(-u[j], qv[k], A[j * n + k]));
+        for (int k = 0; k <= l; ++k) A[i * n + k] = u[k];
+        e[i] = beta; hh[i] = H;
+    }
+    if (n > 1) e[1] = A[1 * n + 0];
+    for (int i = 0; i < n; ++i) d[i] = A[i * n + i];
+    /* ---- Q = H_{n-1} ... H_2: start from the identity, apply H_2, H_3, ... from the left */
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) V[i * n + j] = (i == j) ? 1.0 : 0.0;
+    for (int i = 2; i < n; ++i) {
+        if (hh[i] == 0.0) continue;
+        const int l = i - 1;
+        for (int c = 0; c <= l; ++c) {                      /* lane = column c */
+            double w = 0.0;
+            for (int k = 0; k <= l; ++k) w = fma(A[i * n + k], V[k * n + c], w);
+            w = w / hh[i];
+            for (int r = 0; r <= l; ++r) V[r * n + c] = fma(-A[i * n + r], w, V[r * n + c]);
+        }
+    }
+    /* ---- implicit QL on (d, e), rotations applied to the columns of V (lane = row) */
+    for (int i = 1; i < n; ++i) e[i - 1] = e[i];
+    e[n - 1] = 0.0;
+    int iters = 0;
+    for (int l = 0; l < n; ++l) {
+        for (int guard = 0; guard < 60; ++guard) {
+            int m = l;
+            for (; m < n - 1; ++m) {
+                const double dd = fabs(d[m]) + fabs(d[m + 1]);
+                if (fabs(e[m]) + dd == dd) break;
+            }
+            if (m == l) break;
+            ++iters;
+            double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+            double r = cn_pythag(g, 1.0);
+            g = d[m] - d[l] + e[l] / (g + (g >= 0.0 ? fabs(r) : -fabs(r)));
+            double s = 1.0, c = 1.0, p = 0.0;
+            int i = m - 1, underflow = 0;
+            for (; i >= l; --i) {
+                double f = s * e[i];
+                const double b = c * e[i];
+                r = cn_pythag(f, g);
+                e[i + 1] = r;
+                if (r == 0.0) { d[i + 1] -= p; e[m] = 0.0; underflow = 1; break; }
+                s = f / r; c = g / r;
+                g = d[i + 1] - p;
+                r = (d[i] - g) * s + 2.0 * c * b;
+                p = s * r;
+                d[i + 1] = g + p;
+                g = c * r - b;
+                for (int k = 0; k < n; ++k) {               /* lane = row k */
+                    f = V[k * n + i + 1];
+                    V[k * n + i + 1] = fma(s, V[k * n + i], c * f);
+                    V[k * n + i] = fma(c, V[k * n + i], -(s * f));
+                }
+            }
+            if (underflow) continue;
+            d[l] -= p; e[l] = g; e[m] = 0.0;
+        }
+    }
+    for (int i = 0; i < n; ++i) lam[i] = d[i];
+    return iters;
+}
+
 static int cn_newton(cn_series *se, const cn_spec *o, const double *theta0, double *theta_out,
                      cn_fitinfo *res)
 {
@@ -1060,7 +1166,7 @@ static int cn_newton(cn_series *se, const cn_spec *o, const double *theta0, doub
         for (int a = 0; a < P; ++a)
             for (int b = 0; b < P; ++b) H[a * P + b] = A[a * P + b] + A[b * P + a];
         /* ---- make_negative_definite_and_solve (gradient of lp = -g) ---- */
-        cn_jacobi(P, H, V, lam);
+        cn_tridiag_ql(P, H, V, lam);
         for (int j = 0; j < P; ++j) {
             double a = 0.0;
             for (int i = 0; i < P; ++i) a = fma(V[i * P + j], -g[i], a);
@@ -1233,6 +1339,15 @@ int cn_jacobi_eigh(int n, const double *A_in, double *V, double *lam)
     if (n < 1 || n > CN_NEWTON_MAX_P) return -1;
     memcpy(A, A_in, sizeof(double) * (size_t)(n * n));
     return cn_jacobi(n, A, V, lam);
+}
+
+/* The eigen-solver cn_newton uses (tridiagonalisation + implicit QL), for tests. */
+int cn_ql_eigh(int n, const double *A_in, double *V, double *lam)
+{
+    double A[CN_NEWTON_MAX_P * CN_NEWTON_MAX_P];
+    if (n < 1 || n > CN_NEWTON_MAX_P) return -1;
+    memcpy(A, A_in, sizeof(double) * (size_t)(n * n));
+    return cn_tridiag_ql(n, A, V, lam);
 }
 
 /* Point forecast.  theta original order; extra_future [n_extra][H]. */

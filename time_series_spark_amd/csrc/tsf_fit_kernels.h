@@ -53,8 +53,8 @@ __device__ __forceinline__ double theta_at(const double (&th)[PPL], int p)
 // 32, 16, 1, 2, 4, 8, done for all KP columns at once: the 32- and 16-stages transpose pairs of
 // registers with v_permlane32_swap / v_permlane16_swap (halving the register count each time),
 // the last four stages are DPP butterflies inside the 16-lane rows.  Results go to lds.accR.
-template <int KP, int PPL>
-__device__ __forceinline__ void column_sums(double (&acc)[KP], WaveLds<KP, PPL> &lds)
+template <int KP, int PPL, class L>
+__device__ __forceinline__ void column_sums(double (&acc)[KP], L &lds)
 {
     static_assert(KP % 4 == 0, "KP must be a multiple of 4");
     const int lane = lane_id();
@@ -244,9 +244,11 @@ __device__ __forceinline__ bool eval_tail(const DevSpec *__restrict__ sp, const 
 }
 
 // MODE: 0 all columns additive, 1 all multiplicative, 2 mixed (Ka additive first)
-template <int KP, int GROWTH, int MODE, int PPL, bool XIDX = false>
+// L: the wave's LDS carve-up (WaveLds, or NewtonLds: any struct with th, ks, mc, tp1, tp2, tot1,
+// tot2, d1, d2, rb, ab, accR)
+template <int KP, int GROWTH, int MODE, int PPL, bool XIDX = false, class L = WaveLds<KP, PPL>>
 __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesView &sv,
-                                        WaveLds<KP, PPL> &lds, const double (&th)[PPL],
+                                        L &lds, const double (&th)[PPL],
                                         double &f_out, double (&g)[PPL])
 {
     const int lane = lane_id();
@@ -358,7 +360,7 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
     const double s1 = suffix_scan(rt1), s2v = suffix_scan(rt2);
     lds.tot1[lane] = s1; lds.tot2[lane] = s2v;
     if (lane == 0) { lds.tot1[W] = 0.0; lds.tot2[W] = 0.0; }
-    column_sums<KP, PPL>(acc, lds);
+    column_sums<KP, PPL, L>(acc, lds);
     TSF_WAVE_SYNC();
     return eval_tail<GROWTH, PPL>(sp, sv, lds, lds, th, sigma, inv_s2, sse_t, f_out, g);
 }

@@ -5,7 +5,7 @@
 // U9); the reference reaches it through Prophet().fit(pdf) at
 // /root/reference/src/jobs/prophet_modeler.py:65-66.  The algorithm (stan 2.19
 // model/grad_hess_log_prob.hpp, optimization/newton.hpp, services/optimize/newton.hpp) and its
-// canonical operation order are stated in oracle/prophet_canon.c (cn_newton, cn_jacobi); this
+// canonical operation order are stated in oracle/prophet_canon.c (cn_newton, cn_tridiag_ql); this
 // file executes exactly that sequence:
 //
 //   lane p                = parameter p (P <= 64: Newton is for short series, K is small)
@@ -13,9 +13,8 @@
 //                           Hessian, the perturbed coordinate selected by lane
 //   A[d][p]               = fma chain over the 4 perturbations, lane p, written to LDS row d
 //   H = A + A^T           in place, pair (a, b) handled by lane b
-//   eigen-decomposition   = round-robin Jacobi in LDS: per round n/2 disjoint rotations, angles
-//                           computed by the lanes of each pair, A <- A J and V <- V J row by row
-//                           (lane = column), A <- J^T A pair of rows by pair of rows
+//   eigen-decomposition   = Householder tridiagonalisation + implicit QL in LDS (ql_lds; round 1
+//                           used a round-robin Jacobi: ten times the arithmetic)
 //   proj, step            = lane-parallel fma chains with the other operand broadcast by readlane
 //   step halving          = Stan's loop, one evaluation per trial
 //
@@ -26,88 +25,154 @@
 
 namespace tsf {
 
-// Symmetric eigen-decomposition of the n x n matrix in Am (row stride PM, destroyed: its
-// diagonal ends as the eigenvalues), eigenvectors to the columns of Vm.  One wave; lane j owns
-// column j in the row passes.  Returns the eigenvalue of lane j (0 for j >= n).
-__device__ __forceinline__ double jacobi_lds(int n, int PM, double *Am, double *Vm)
+// Symmetric eigen-decomposition by Householder tridiagonalisation + implicit QL with shifts, in the
+// operation order of oracle cn_tridiag_ql (every "for all j" there is one lane per j here, sums
+// over lanes are bfly_sum, sums over k inside a lane are sequential fma chains, scalars are
+// computed identically by every lane).  About a tenth of the Jacobi's arithmetic for P = 34 and a
+// far shorter dependent chain (round 1: ~0.5 M dependent instructions per decomposition).
+// Am: n x n symmetric, row stride PM (destroyed), Vm: eigenvectors in columns, sc: d, e, hh, q
+// scratch of 64 doubles each.  Returns the eigenvalue of lane j (0 for j >= n).
+struct QlScratch { double d[W], e[W], hh[W], q[W]; };
+
+__device__ __forceinline__ double ql_pythag(double a, double b)
+{
+    const double absa = __builtin_fabs(a), absb = __builtin_fabs(b);
+    if (absa > absb) { const double r = absb / absa; return absa * __builtin_sqrt(1.0 + r * r); }
+    if (absb == 0.0) return 0.0;
+    const double r = absa / absb;
+    return absb * __builtin_sqrt(1.0 + r * r);
+}
+
+__device__ __forceinline__ double ql_lds(int n, int PM, double *Am, double *Vm, QlScratch &sc)
 {
     const int lane = lane_id();
-    const int m = n + (n & 1);
-    const bool live = lane < n;
-    for (int i = 0; i < n; ++i)
-        if (live) Vm[i * PM + lane] = (i == lane) ? 1.0 : 0.0;
+    sc.e[lane] = 0.0; sc.hh[lane] = 0.0;
     TSF_WAVE_SYNC();
-    for (int sweep = 0; sweep < 30; ++sweep) {
-        double so = 0.0, sd = 0.0;
-        if (live) {
-            for (int i = 0; i < n; ++i) {
-                const double v = Am[i * PM + lane];
-                if (i == lane) sd = v * v;
-                else so = __builtin_fma(v, v, so);
-            }
+    // ---- Householder: zero A[i][0..i-2] for i = n-1 .. 2; reflector u kept in row i, u.u/2 in hh[i]
+    for (int i = n - 1; i >= 2; --i) {
+        const int l = i - 1;
+        const double xj = (lane <= l) ? Am[i * PM + lane] : 0.0;
+        const double sigma = bfly_sum((lane < l) ? xj * xj : 0.0);
+        const double alpha = readlane_f64(xj, l);
+        if (sigma == 0.0) {
+            if (lane == 0) { sc.e[i] = alpha; sc.hh[i] = 0.0; }
+            continue;
         }
-        const double off2 = bfly_sum(so), dia2 = bfly_sum(sd);
-        if (off2 <= 1e-26 * dia2) break;
-        for (int r = 0; r < m - 1; ++r) {
-            // rotation of the pair this lane's index belongs to
-            int q;
-            if (lane == m - 1) q = r;
-            else if (lane == r) q = m - 1;
-            else { q = (2 * r - lane) % (m - 1); if (q < 0) q += m - 1; }
-            double c = 1.0, kap = 0.0;
-            if (live && q < n) {
-                const int lo = lane < q ? lane : q, hi = lane < q ? q : lane;
-                const double apq = Am[lo * PM + hi];
-                if (apq != 0.0) {
-                    const double tau = (Am[hi * PM + hi] - Am[lo * PM + lo]) / (2.0 * apq);
-                    const double t = (tau >= 0.0 ? 1.0 : -1.0) / (__builtin_fabs(tau) + __builtin_sqrt(1.0 + tau * tau));
-                    c = 1.0 / __builtin_sqrt(1.0 + t * t);
-                    const double s = t * c;
-                    kap = (lane == lo) ? -s : s;
-                }
-            }
-            if (!live) q = lane;
-            TSF_WAVE_SYNC();
-            // A <- A J, V <- V J: column `lane` mixes with column q, row by row (in place: both
-            // operands are read before either result is written)
-            const bool mix = live && q < n;
-            for (int rr = 0; rr < n; ++rr) {
-                double ai = 0.0, aq = 0.0, vi = 0.0, vq = 0.0;
-                if (live) { ai = Am[rr * PM + lane]; vi = Vm[rr * PM + lane]; }
-                if (mix) { aq = Am[rr * PM + q]; vq = Vm[rr * PM + q]; }
-                TSF_WAVE_SYNC();
-                if (live) {
-                    Am[rr * PM + lane] = __builtin_fma(aq, kap, ai * c);
-                    Vm[rr * PM + lane] = __builtin_fma(vq, kap, vi * c);
-                }
-                TSF_WAVE_SYNC();
-            }
-            // A <- J^T A: rows i and q(i) mix; lane = column
-            for (int i = 0; i < n; ++i) {
-                const int qi = __builtin_amdgcn_readlane(q, i);
-                if (qi >= n || qi < i) continue;          // dummy partner: unchanged; pair done at its lower index
-                const double ci = readlane_f64(c, i), ki = readlane_f64(kap, i);
-                const double cq = readlane_f64(c, qi), kq = readlane_f64(kap, qi);
-                double bi = 0.0, bq = 0.0;
-                if (live) { bi = Am[i * PM + lane]; bq = Am[qi * PM + lane]; }
-                TSF_WAVE_SYNC();
-                if (live) {
-                    Am[i * PM + lane] = __builtin_fma(ki, bq, ci * bi);
-                    Am[qi * PM + lane] = __builtin_fma(kq, bi, cq * bq);
-                }
-                TSF_WAVE_SYNC();
-            }
+        const double mu = __builtin_sqrt(sigma + alpha * alpha);
+        const double beta = (alpha >= 0.0) ? -mu : mu;
+        const double ul = alpha - beta;
+        const double uj = (lane == l) ? ul : xj;
+        const double H = 0.5 * (sigma + ul * ul);
+        if (lane == l) Am[i * PM + l] = ul;
+        TSF_WAVE_SYNC();
+        double a = 0.0;                                     // p = A u / H, lane = row j
+        if (lane <= l)
+            for (int k = 0; k <= l; ++k) a = __builtin_fma(Am[lane * PM + k], Am[i * PM + k], a);
+        const double pj = a / H;
+        const double K = bfly_sum((lane <= l) ? uj * pj : 0.0) / (2.0 * H);
+        const double qj = pj - K * uj;
+        sc.q[lane] = qj;
+        TSF_WAVE_SYNC();
+        if (lane <= l)                                      // A <- A - u q^T - q u^T
+            for (int k = 0; k <= l; ++k)
+                Am[lane * PM + k] = __builtin_fma(-qj, Am[i * PM + k], __builtin_fma(-uj, sc.q[k], Am[lane * PM + k]));
+        if (lane == 0) { sc.e[i] = beta; sc.hh[i] = H; }
+        TSF_WAVE_SYNC();
+    }
+    if (lane == 0 && n > 1) sc.e[1] = Am[1 * PM + 0];
+    if (lane < n) sc.d[lane] = Am[lane * PM + lane];
+    // ---- Q = H_{n-1} ... H_2 applied to the identity; lane = column c
+    for (int r = 0; r < n; ++r)
+        if (lane < n) Vm[r * PM + lane] = (r == lane) ? 1.0 : 0.0;
+    TSF_WAVE_SYNC();
+    for (int i = 2; i < n; ++i) {
+        const double Hi = sc.hh[i];
+        if (Hi == 0.0) continue;
+        const int l = i - 1;
+        if (lane <= l) {
+            double w = 0.0;
+            for (int k = 0; k <= l; ++k) w = __builtin_fma(Am[i * PM + k], Vm[k * PM + lane], w);
+            w = w / Hi;
+            for (int r = 0; r <= l; ++r) Vm[r * PM + lane] = __builtin_fma(-Am[i * PM + r], w, Vm[r * PM + lane]);
         }
     }
     TSF_WAVE_SYNC();
-    return live ? Am[lane * PM + lane] : 0.0;
+    // ---- implicit QL on (d, e); rotations applied to the columns of V, lane = row k
+    {
+        const double en = (lane >= 1 && lane < n) ? sc.e[lane] : 0.0;
+        TSF_WAVE_SYNC();
+        if (lane >= 1 && lane < n) sc.e[lane - 1] = en;
+        if (lane == 0) sc.e[n - 1] = 0.0;
+        TSF_WAVE_SYNC();
+    }
+    for (int l = 0; l < n; ++l) {
+        for (int guard = 0; guard < 60; ++guard) {
+            int m = l;
+            for (; m < n - 1; ++m) {
+                const double dd = __builtin_fabs(sc.d[m]) + __builtin_fabs(sc.d[m + 1]);
+                if (__builtin_fabs(sc.e[m]) + dd == dd) break;
+            }
+            if (m == l) break;
+            const double dl = sc.d[l], el = sc.e[l];
+            double g = (sc.d[l + 1] - dl) / (2.0 * el);
+            double r = ql_pythag(g, 1.0);
+            g = sc.d[m] - dl + el / (g + (g >= 0.0 ? __builtin_fabs(r) : -__builtin_fabs(r)));
+            double s = 1.0, c = 1.0, p = 0.0;
+            int i = m - 1;
+            bool underflow = false;
+            for (; i >= l; --i) {
+                const double ei = sc.e[i], di = sc.d[i], di1 = sc.d[i + 1];
+                double f = s * ei;
+                const double b = c * ei;
+                r = ql_pythag(f, g);
+                TSF_WAVE_SYNC();
+                if (lane == 0) sc.e[i + 1] = r;
+                if (r == 0.0) {
+                    if (lane == 0) { sc.d[i + 1] = di1 - p; sc.e[m] = 0.0; }
+                    underflow = true;
+                    TSF_WAVE_SYNC();
+                    break;
+                }
+                s = f / r; c = g / r;
+                g = di1 - p;
+                r = (di - g) * s + 2.0 * c * b;
+                p = s * r;
+                if (lane == 0) sc.d[i + 1] = g + p;
+                g = c * r - b;
+                if (lane < n) {
+                    f = Vm[lane * PM + i + 1];
+                    const double v0 = Vm[lane * PM + i];
+                    Vm[lane * PM + i + 1] = __builtin_fma(s, v0, c * f);
+                    Vm[lane * PM + i] = __builtin_fma(c, v0, -(s * f));
+                }
+                TSF_WAVE_SYNC();
+            }
+            if (underflow) continue;
+            if (lane == 0) { sc.d[l] = sc.d[l] - p; sc.e[l] = g; sc.e[m] = 0.0; }
+            TSF_WAVE_SYNC();
+        }
+    }
+    TSF_WAVE_SYNC();
+    return (lane < n) ? sc.d[lane] : 0.0;
 }
 
-// LDS after WaveLds: Am [PM][PM], Vm [PM][PM] doubles
+// LDS of one Newton wave: the evaluation tables of eval_fg (no L-BFGS history), the QL scratch,
+// then Am [PM][PM], Vm [PM][PM]
+template <int KP>
+struct NewtonLds {
+    double th[TSF_MAX_P + W];
+    double ks[NTAB + 1], mc[NTAB + 1];
+    double tp1[NTAB], tp2[NTAB];
+    double tot1[W + 1], tot2[W + 1];
+    double d1[NTAB + 1], d2[NTAB + 1], rb[NTAB + 1], ab[NTAB + 1];
+    double accR[KP];
+    QlScratch ql;
+};
+
 template <int KP>
 constexpr size_t newton_lds_bytes(int PM)
 {
-    return ((sizeof(WaveLds<KP, 1>) + 15) & ~(size_t)15) + 2 * (size_t)PM * PM * sizeof(double);
+    return ((sizeof(NewtonLds<KP>) + 15) & ~(size_t)15) + 2 * (size_t)PM * PM * sizeof(double);
 }
 
 template <int KP, int GROWTH, int MODE>
@@ -115,8 +180,8 @@ __global__ __launch_bounds__(64) void newton_kernel(FitArgs a, int PM)
 {
     constexpr int PPL = 1;
     extern __shared__ __align__(16) unsigned char smem[];
-    WaveLds<KP, PPL> &lds = *reinterpret_cast<WaveLds<KP, PPL> *>(smem);
-    double *Am = reinterpret_cast<double *>(smem + ((sizeof(WaveLds<KP, PPL>) + 15) & ~(size_t)15));
+    NewtonLds<KP> &lds = *reinterpret_cast<NewtonLds<KP> *>(smem);
+    double *Am = reinterpret_cast<double *>(smem + ((sizeof(NewtonLds<KP>) + 15) & ~(size_t)15));
     double *Vm = Am + (size_t)PM * PM;
     const int64_t n = blockIdx.x;
     if (n >= a.N) return;
@@ -147,7 +212,7 @@ __global__ __launch_bounds__(64) void newton_kernel(FitArgs a, int PM)
     int stage = S_INIT, ret = TSF_ST_MAXIT, it = 0, mI = 0, d = 0, pi = 0;
     double lp = 0.0, lastlp = 0.0, f0 = 0.0, f1 = 0.0, size = 2.0, acc = 0.0, fx = 0.0;
     for (;;) {
-        const bool bad = eval_fg<KP, GROWTH, MODE, PPL>(sp, sv, lds, x, fx, gx);
+        const bool bad = eval_fg<KP, GROWTH, MODE, PPL, false, NewtonLds<KP>>(sp, sv, lds, x, fx, gx);
         bool finish_iter = false, moved = false;
         if (stage == S_INIT) {
             if (bad) { ret = TSF_ST_INIT_NONFINITE; lp = -fx; break; }
@@ -190,7 +255,7 @@ __global__ __launch_bounds__(64) void newton_kernel(FitArgs a, int PM)
                 TSF_WAVE_SYNC();
             }
             // ---- make_negative_definite_and_solve
-            const double lam = jacobi_lds(P, PM, Am, Vm);
+            const double lam = ql_lds(P, PM, Am, Vm, lds.ql);
             double pa = 0.0;
             for (int i = 0; i < P; ++i) {
                 const double gi = -readlane_f64(g[0], i);
