@@ -1134,7 +1134,13 @@ static int cn_newton(cn_series *se, const cn_spec *o, const double *theta0, doub
         res->status = CN_NEWTON_TOO_WIDE; res->n_iter = 0; res->n_eval = 0; res->f = 0.0;
         return 0;
     }
-    if (cn_eval(se, th, &f, g)) {
+    /* Evaluation form (cn_spec.eval_mode, as for L-BFGS): models that are linear in (k, m, delta,
+     * beta) evaluate the accepted point of every Newton iteration in residual form -- which also
+     * re-centres the quadratic form there -- and the 4 P finite-difference points and the halving
+     * trials of that iteration in quadratic (Gram) form around it. */
+#define CN_NEWTON_EVAL_RES(th_, f_, g_) (se->gram ? cn_resid_q(se, th_, f_, g_) : cn_eval(se, th_, f_, g_))
+#define CN_NEWTON_EVAL(th_, f_, g_) (se->gram ? cn_eval_gram(se, th_, f_, g_) : cn_eval(se, th_, f_, g_))
+    if (CN_NEWTON_EVAL_RES(th, &f, g)) {
         /* services/optimize/newton.hpp carries on with lp = -inf and the first
          * grad_hess_log_prob throws: pystan raises RuntimeError */
         memcpy(theta_out, theta0, sizeof(th));
@@ -1146,7 +1152,8 @@ static int cn_newton(cn_series *se, const cn_spec *o, const double *theta0, doub
         lastlp = lp;
         /* ---- newton_step: grad_hess_log_prob ---- */
         double f0;
-        if (cn_eval(se, th, &f, g)) { ret = CN_NEWTON_FAIL; break; }
+        if (CN_NEWTON_EVAL_RES(th, &f, g)) { ret = CN_NEWTON_FAIL; break; }
+        if (se->gram) cn_set_ref(se, th);
         f0 = -f;
         int bad = 0;
         for (int d = 0; d < P && !bad; ++d) {
@@ -1156,7 +1163,7 @@ static int cn_newton(cn_series *se, const cn_spec *o, const double *theta0, doub
                 memcpy(x, th, sizeof(x));
                 x[d] = th[d] + pert[i];
                 double fp;
-                if (cn_eval(se, x, &fp, tg)) { bad = 1; break; }   /* Stan: exception leaves newton_step */
+                if (CN_NEWTON_EVAL(x, &fp, tg)) { bad = 1; break; }   /* Stan: exception leaves newton_step */
                 const double w = half_epsilon * coef[i];
                 for (int p = 0; p < P; ++p) acc[p] = fma(w, -tg[p], acc[p]);
             }
@@ -1187,7 +1194,7 @@ static int cn_newton(cn_series *se, const cn_spec *o, const double *theta0, doub
             if (size < 1e-50) { moved = 0; break; }
             for (int i = 0; i < P; ++i) x[i] = th[i] - size * step[i];
             double fn;
-            f1 = cn_eval(se, x, &fn, tg) ? -1e100 : -fn;
+            f1 = CN_NEWTON_EVAL(x, &fn, tg) ? -1e100 : -fn;
         }
         it++;
         if (moved) { memcpy(th, x, sizeof(th)); lp = f1; }
@@ -1324,6 +1331,7 @@ int cn_fit_newton(const cn_spec *sp, int T, const int64_t *ds, const double *y, 
         th[2] = -20.72326583694641;
         info->status = CN_CONSTANT; info->n_iter = 0; info->n_eval = 0; info->f = 0.0;
     } else {
+        if (sp->eval_mode == 1 && sp->growth == 0 && se->Ka == se->K) { se->gram = 1; cn_build_gram(se); }
         cn_newton(se, sp, th0, th, info);
     }
     to_original(se, th, theta_out, 1);

@@ -316,11 +316,19 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     if (spec->eval_form == TSF_EVAL_QUADRATIC && !quad_ok && theta_in == nullptr)
         return fail(ctx, "eval_form QUADRATIC needs linear growth, additive columns only and history == 5");
     const bool quad = quad_ok && spec->eval_form != TSF_EVAL_RESIDUAL;
+    // Newton on the same models: residual form at the accepted points, quadratic form for the
+    // finite-difference and halving evaluations (tsf_newton_quad.h); aligned panels
+    const bool newton_quad = newton && hs.growth == TSF_GROWTH_LINEAR && mode == 0 &&
+                             spec->eval_form != TSF_EVAL_RESIDUAL && NTmax <= 16;
     QuadPlan qp;
     memset(&qp, 0, sizeof(qp));
-    if (quad) {
+    if (quad || newton_quad) {
         rc = quad_plan(ctx, hs, N, &qp);
         if (rc) return rc;
+        if (newton_quad) {          // one-wave workgroups, up to 8 per CU: that many Z^T Z slots (ragged)
+            qp.slots = ctx->n_cu * 8;
+            if (qp.slots < qp.P4) qp.slots = qp.P4;
+        }
     }
     // shared lattice table: ragged panel, residual-form kernel, no explicit columns
     if (aligned || quad || newton || theta_in != nullptr || hs.n_extra > 0 || lat_step <= 0) lat_U = 0;
@@ -355,7 +363,7 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     }
     if (spec->residual_kernel == TSF_RK_MFMA && !mp.on && theta_in == nullptr && !quad && !newton)
         return fail(ctx, "residual_kernel MFMA needs an aligned panel, K <= 28 columns of one mode, 3+S+K <= 64 and S <= 28");
-    const WsLayout l = ws_layout(N, n_grids, NTmax, hs.KP, qp.P4, qp.slots, quad && !aligned, lat_U, &mp);
+    const WsLayout l = ws_layout(N, n_grids, NTmax, hs.KP, qp.P4, qp.slots, (quad || newton_quad) && !aligned, lat_U, &mp);
     rc = ensure_ws(ctx, l.total);
     if (rc) return rc;
     char *ws = (char *)ctx->ws;
@@ -405,7 +413,15 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     const int slot = (int)(ctx->ev_count % TSF_PROFILE_RING);
     if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev0[slot], st));
     int lrc;
-    if (newton) {
+    if (newton_quad) {
+        QuadArgs qa;
+        memset(&qa, 0, sizeof(qa));
+        qa.f = a; qa.Mg = (const double *)(ws + l.Mg); qa.Mslot = (double *)(ws + l.Mslot);
+        qa.rbuf = (double *)(ws + l.rbuf);
+        qa.counter = (int *)(ws + l.counter); qa.P4 = qp.P4;
+        HIP_TRY(ctx, hipMemsetAsync(qa.counter, 0, sizeof(int), st));
+        lrc = launch_newton_quad(hs.KP, qp, qa, (double *)(ws + l.Mg), fit_P(hs.n_cp, hs.K) | 1, ctx->n_cu, st);
+    } else if (newton) {
         lrc = pick_newton_launch(hs.growth, mode)(hs.KP, a, fit_P(hs.n_cp, hs.K) | 1, st);
     } else if (quad) {
         QuadArgs qa;

@@ -1,5 +1,6 @@
 // tsf_inst_quad.hip -- instantiates the quadratic-form fit path (tsf_quad_kernels.h).
 #include "tsf_quad_kernels.h"
+#include "tsf_newton_quad.h"
 #include "tsf_launch.h"
 #include <cstdio>
 #include <cstdlib>
@@ -90,6 +91,46 @@ int launch_quad(int KP, const QuadPlan &qp, const QuadArgs &qa, double *Mg, hipS
     case 2856: return launch_quad_one<28, 1, 56>(qp, qa, Mg, st);
     case 2864: return launch_quad_one<28, 1, 64>(qp, qa, Mg, st);
     case 6400: return launch_quad_one<64, 2, 0>(qp, qa, Mg, st);
+    default: return -1;
+    }
+}
+
+// Newton with quadratic-form evaluations (tsf_newton_quad.h): Z^T Z once per grid, then one wave
+// per series.  Aligned panels, one parameter per lane.
+template <int KP, bool RAGGED>
+static int launch_newton_quad_rg(const QuadPlan &qp, const QuadArgs &qa, double *Mg, int PM, int n_cu, hipStream_t st)
+{
+    if (!RAGGED) {
+        hipLaunchKernelGGL((gram_build_kernel<KP, 1>), dim3((unsigned)qp.P4), dim3(64), 0, st, qa, Mg);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+    }
+    const size_t lds = newton_quad_lds_bytes<KP>(PM, qa.f.NTmax);
+    if (lds > 160 * 1024) return -1;
+    hipFuncSetAttribute((const void *)newton_quad_kernel<KP, RAGGED>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    int per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, newton_quad_kernel<KP, RAGGED>, 64, lds) != hipSuccess || per_cu < 1)
+        per_cu = 1;
+    int64_t blocks = (int64_t)per_cu * n_cu;
+    if (blocks > qp.slots) blocks = qp.slots;         // one Z^T Z slot per resident block (ragged)
+    if (blocks > qa.f.N) blocks = qa.f.N;
+    hipLaunchKernelGGL((newton_quad_kernel<KP, RAGGED>), dim3((unsigned)blocks), dim3(64), lds, st, qa, PM);
+    return (int)hipGetLastError();
+}
+
+template <int KP>
+static int launch_newton_quad_one(const QuadPlan &qp, const QuadArgs &qa, double *Mg, int PM, int n_cu, hipStream_t st)
+{
+    if (qa.f.aligned) return launch_newton_quad_rg<KP, false>(qp, qa, Mg, PM, n_cu, st);
+    return launch_newton_quad_rg<KP, true>(qp, qa, Mg, PM, n_cu, st);
+}
+
+int launch_newton_quad(int KP, const QuadPlan &qp, const QuadArgs &qa, double *Mg, int PM, int n_cu, hipStream_t st)
+{
+    switch (KP) {
+    case 8: return launch_newton_quad_one<8>(qp, qa, Mg, PM, n_cu, st);
+    case 16: return launch_newton_quad_one<16>(qp, qa, Mg, PM, n_cu, st);
+    case 28: return launch_newton_quad_one<28>(qp, qa, Mg, PM, n_cu, st);
     default: return -1;
     }
 }

@@ -30,8 +30,8 @@ namespace tsf {
 // over lanes are bfly_sum, sums over k inside a lane are sequential fma chains, scalars are
 // computed identically by every lane).  About a tenth of the Jacobi's arithmetic for P = 34 and a
 // far shorter dependent chain (round 1: ~0.5 M dependent instructions per decomposition).
-// Am: n x n symmetric, row stride PM (destroyed), Vm: eigenvectors in columns, sc: d, e, hh, q
-// scratch of 64 doubles each.  Returns the eigenvalue of lane j (0 for j >= n).
+// Am: n x n symmetric, row stride PM; the eigenvectors replace it (columns; Vm must be Am: one
+// matrix in LDS instead of two), sc: d, e, hh, q scratch of 64 doubles each.  Returns the eigenvalue of lane j (0 for j >= n).
 struct QlScratch { double d[W], e[W], hh[W], q[W]; };
 
 __device__ __forceinline__ double ql_pythag(double a, double b)
@@ -81,22 +81,29 @@ __device__ __forceinline__ double ql_lds(int n, int PM, double *Am, double *Vm, 
     }
     if (lane == 0 && n > 1) sc.e[1] = Am[1 * PM + 0];
     if (lane < n) sc.d[lane] = Am[lane * PM + lane];
-    // ---- Q = H_{n-1} ... H_2 applied to the identity; lane = column c
-    for (int r = 0; r < n; ++r)
-        if (lane < n) Vm[r * PM + lane] = (r == lane) ? 1.0 : 0.0;
+    TSF_WAVE_SYNC();
+    // ---- Q = H_{n-1} ... H_2 applied to the identity, IN PLACE (Vm == Am): H_i only mixes the
+    // leading i x i block, which by then holds the product of the earlier reflectors (their own
+    // rows, inside that block, have been consumed), while row i still holds u_i; lane = column c.
+    // Same values as the oracle's separate V: outside the leading block V is the identity.
+    if (lane < 2 && n > 0) {
+        Vm[0 * PM + lane] = (lane == 0) ? 1.0 : 0.0;
+        if (n > 1) Vm[1 * PM + lane] = (lane == 1) ? 1.0 : 0.0;
+    }
     TSF_WAVE_SYNC();
     for (int i = 2; i < n; ++i) {
         const double Hi = sc.hh[i];
-        if (Hi == 0.0) continue;
         const int l = i - 1;
-        if (lane <= l) {
+        if (Hi != 0.0 && lane <= l) {
             double w = 0.0;
             for (int k = 0; k <= l; ++k) w = __builtin_fma(Am[i * PM + k], Vm[k * PM + lane], w);
             w = w / Hi;
             for (int r = 0; r <= l; ++r) Vm[r * PM + lane] = __builtin_fma(-Am[i * PM + r], w, Vm[r * PM + lane]);
         }
+        TSF_WAVE_SYNC();
+        if (lane <= i) { Vm[i * PM + lane] = (lane == i) ? 1.0 : 0.0; Vm[lane * PM + i] = (lane == i) ? 1.0 : 0.0; }
+        TSF_WAVE_SYNC();
     }
-    TSF_WAVE_SYNC();
     // ---- implicit QL on (d, e); rotations applied to the columns of V, lane = row k
     {
         const double en = (lane >= 1 && lane < n) ? sc.e[lane] : 0.0;
@@ -172,7 +179,7 @@ struct NewtonLds {
 template <int KP>
 constexpr size_t newton_lds_bytes(int PM)
 {
-    return ((sizeof(NewtonLds<KP>) + 15) & ~(size_t)15) + 2 * (size_t)PM * PM * sizeof(double);
+    return ((sizeof(NewtonLds<KP>) + 15) & ~(size_t)15) + (size_t)PM * PM * sizeof(double);
 }
 
 template <int KP, int GROWTH, int MODE>
@@ -182,7 +189,7 @@ __global__ __launch_bounds__(64) void newton_kernel(FitArgs a, int PM)
     extern __shared__ __align__(16) unsigned char smem[];
     NewtonLds<KP> &lds = *reinterpret_cast<NewtonLds<KP> *>(smem);
     double *Am = reinterpret_cast<double *>(smem + ((sizeof(NewtonLds<KP>) + 15) & ~(size_t)15));
-    double *Vm = Am + (size_t)PM * PM;
+    double *Vm = Am;          // ql_lds leaves the eigenvectors where the matrix was
     const int64_t n = blockIdx.x;
     if (n >= a.N) return;
     const int lane = threadIdx.x;

@@ -1,0 +1,201 @@
+// tsf_newton_quad.h -- Stan's Newton optimiser (tsf_newton_kernels.h) for models that are LINEAR in
+// (k, m, delta, beta): linear growth, additive columns -- the BASELINE cfg5 shape, which fbprophet
+// fits with Newton because its histories have fewer than 100 rows.
+//
+// A Newton iteration costs 4 P + 1 + ~30 log_prob/gradient evaluations (finite-difference Hessian,
+// step halving).  Here the accepted point of every iteration is evaluated in residual form, which
+// also re-centres the quadratic (Gram) form of tsf_quad_kernels.h there, and the 4 P perturbed
+// points and the halving trials are P x P mat-vecs against the shared Z^T Z (read from L2: it is
+// the same for every series of an aligned panel).  oracle cn_newton does the same when
+// cn_spec.eval_mode = 1; bit-identical.
+#pragma once
+#include "tsf_quad_kernels.h"
+#include "tsf_newton_kernels.h"
+
+namespace tsf {
+
+template <int KP>
+struct NewtonQuadLds {
+    QuadLds<KP, 1> q;
+    QlScratch ql;
+};
+
+template <int KP>
+constexpr size_t newton_quad_lds_bytes(int PM, int NTmax)
+{
+    return ((sizeof(NewtonQuadLds<KP>) + 15) & ~(size_t)15) + sizeof(double) * (size_t)NTmax * W +
+           (size_t)PM * PM * sizeof(double);
+}
+
+// One series, start to finish, by one wave.  Mp: Z^T Z of the series' grid (aligned panels: the
+// shared one; ragged panels: built here into Mown, this block's slot of global memory).
+template <int KP, bool RAGGED>
+__device__ __forceinline__ void newton_one_quad(const QuadArgs &qa, NewtonQuadLds<KP> &lds, double *rb,
+                                                double *Am, double *Vm, int PM, const double *Mp,
+                                                double *Mown, int64_t n)
+{
+    constexpr int PPL = 1;
+    const FitArgs &a = qa.f;
+    QuadLds<KP, PPL> &wl = lds.q;
+    const int lane = lane_id();
+    const DevSpec *sp = a.sp;
+    SeriesView sv;
+    make_view_q<KP, PPL>(a, n, sv);
+    const SeriesTab st = a.stab[n];
+    if (lane == 0) {
+        a.y_scale[n] = st.y_scale;
+        if (!a.aligned || n == 0) a.grid_out[a.aligned ? 0 : n] = a.gtab[a.aligned ? 0 : n].info;
+    }
+    double th[PPL], x[PPL], g[PPL], gx[PPL], step[PPL];
+    th[0] = (lane == 0) ? st.k0 : (lane == 1 ? st.m0 : 0.0);
+    x[0] = th[0]; g[0] = 0.0; gx[0] = 0.0; step[0] = 0.0;
+    if (st.status0 != 0) {
+        if (st.status0 == TSF_ST_CONSTANT && lane == 2) th[0] = -20.72326583694641;
+        store_theta<PPL>(a, sv, n, th, a.theta);
+        if (lane == 0) { a.status[n] = st.status0; a.n_iter[n] = 0; a.n_eval[n] = 0; a.fval[n] = 0.0; }
+        return;
+    }
+    LaneConst<PPL> lk;
+    lane_consts<KP, PPL>(sp, sv, wl, lk);
+    if (RAGGED) {
+        // this series has its own grid, hence its own Z^T Z: built column by column as fit_one_quad does
+#pragma unroll 1
+        for (int q = 0; q < qa.P4; ++q) {
+            double col[PPL] = {0.0};
+            if (q != 2 && q < sv.P) gram_column<KP, PPL>(sv, wl, rb, q, col);
+            Mown[(size_t)q * W + lane] = col[0];
+        }
+        Mp = Mown;
+    }
+    const int P = sv.P;
+    const double epsilon = 1e-3, half_epsilon = 0.5 * epsilon;
+
+    enum { S_INIT = 0, S_F0, S_FD, S_HALVE };
+    int stage = S_INIT, ret = TSF_ST_MAXIT, it = 0, mI = 0, d = 0, pi = 0;
+    double lp = 0.0, lastlp = 0.0, f0 = 0.0, f1 = 0.0, size = 2.0, acc = 0.0, fx = 0.0, s0 = 0.0, q2 = 0.0;
+    for (;;) {
+        bool bad;
+        sv.n_eval++;
+        if (stage == S_INIT || stage == S_F0) {
+            double sse_e, ztr_e[PPL];
+            bad = resid_eval_q<KP, PPL>(sv, wl, lk, rb, x, fx, gx, sse_e, ztr_e);
+            if (!bad && stage == S_F0) {
+                // the accepted point becomes the reference of the quadratic form (cn_set_ref)
+                wl.ref[lane] = (lane == 2) ? 0.0 : x[0];
+                wl.cvec[lane] = (lane == 2) ? 0.0 : ztr_e[0];
+                s0 = sse_e;
+                wave_sync();
+            }
+        } else {
+            bad = gram_eval_q<PPL, 0>(sv, lk, Mp, qa.P4, x, wl.ref, wl.cvec, s0, fx, gx, q2, wl.th);
+        }
+        bool finish_iter = false, moved = false;
+        if (stage == S_INIT) {
+            if (bad) { ret = TSF_ST_INIT_NONFINITE; lp = -fx; break; }
+            lp = -fx;
+            stage = S_F0;
+            x[0] = th[0];
+            continue;
+        }
+        if (stage == S_F0) {
+            if (bad) { ret = TSF_ST_NEWTON_FAIL; break; }
+            lastlp = lp;
+            f0 = -fx;
+            g[0] = gx[0];
+            d = 0; pi = 0; acc = 0.0;
+            stage = S_FD;
+            x[0] = (lane == 0) ? th[0] + (-2 * epsilon) : th[0];
+            continue;
+        }
+        if (stage == S_FD) {
+            if (bad) { ret = TSF_ST_NEWTON_FAIL; break; }
+            const double coef = (pi == 0) ? 1.0 / 12.0 : (pi == 1 ? -2.0 / 3.0 : (pi == 2 ? 2.0 / 3.0 : -1.0 / 12.0));
+            acc = __builtin_fma(half_epsilon * coef, -gx[0], acc);
+            if (++pi == 4) {
+                if (lane < P) Am[d * PM + lane] = acc;
+                acc = 0.0; pi = 0; ++d;
+            }
+            if (d < P) {
+                const double pert = (pi == 0) ? -2 * epsilon : (pi == 1 ? -1 * epsilon : (pi == 2 ? epsilon : 2 * epsilon));
+                x[0] = (lane == d) ? th[0] + pert : th[0];
+                continue;
+            }
+            // ---- H = A + A^T (in place; lane b owns the pairs (a, b), a < b, and its diagonal)
+            wave_sync();
+            for (int r = 0; r < P; ++r) {
+                double u = 0.0, v = 0.0;
+                const bool mine = lane < P && r <= lane;
+                if (mine) { u = Am[r * PM + lane]; v = Am[lane * PM + r]; }
+                wave_sync();
+                if (mine) { const double h = u + v; Am[r * PM + lane] = h; Am[lane * PM + r] = h; }
+                wave_sync();
+            }
+            // ---- make_negative_definite_and_solve
+            const double lam = ql_lds(P, PM, Am, Vm, lds.ql);
+            double pa = 0.0;
+            for (int i = 0; i < P; ++i) {
+                const double gi = -readlane_f64(g[0], i);
+                const double vij = (lane < P) ? Vm[i * PM + lane] : 0.0;
+                pa = __builtin_fma(vij, gi, pa);
+            }
+            const double proj = (lane < P) ? -pa / __builtin_fabs(lam) : 0.0;
+            double sa = 0.0;
+            for (int j = 0; j < P; ++j) {
+                const double pj = readlane_f64(proj, j);
+                const double vij = (lane < P) ? Vm[lane * PM + j] : 0.0;
+                sa = __builtin_fma(vij, pj, sa);
+            }
+            step[0] = (lane < P) ? sa : 0.0;
+            x[0] = th[0];
+            size = 2.0; f1 = -1e100;
+            stage = S_HALVE;
+        } else {   // S_HALVE: a trial point was evaluated
+            f1 = bad ? -1e100 : -fx;
+        }
+        // ---- Stan's `while (f1 < f0)` step-halving loop
+        if (f1 < f0) {
+            size *= 0.5;
+            if (size < 1e-50) { finish_iter = true; moved = false; }
+            else { x[0] = th[0] - size * step[0]; continue; }
+        } else {
+            finish_iter = true; moved = true;
+        }
+        if (finish_iter) {
+            ++it;
+            if (moved) { th[0] = x[0]; lp = f1; }
+            else lp = f0;
+            if (mI > 0 && __builtin_fabs(lp - lastlp) < 1e-8) { ret = TSF_ST_NEWTON_CONVERGED; break; }
+            if (++mI >= a.opt.max_iter) { ret = TSF_ST_MAXIT; break; }
+            stage = S_F0;
+            x[0] = th[0];
+        }
+    }
+    store_theta<PPL>(a, sv, n, th, a.theta);
+    if (lane == 0) { a.status[n] = ret; a.n_iter[n] = it; a.n_eval[n] = sv.n_eval; a.fval[n] = -lp; }
+}
+
+// persistent one-wave workgroups pulling series from a queue (the longest series needs ~7x the
+// mean number of evaluations)
+template <int KP, bool RAGGED>
+__global__ __launch_bounds__(64) void newton_quad_kernel(QuadArgs qa, int PM)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const FitArgs &a = qa.f;
+    NewtonQuadLds<KP> &lds = *reinterpret_cast<NewtonQuadLds<KP> *>(smem);
+    double *rb = reinterpret_cast<double *>(smem + ((sizeof(NewtonQuadLds<KP>) + 15) & ~(size_t)15));
+    double *Am = rb + (size_t)a.NTmax * W;
+    double *Vm = Am;          // ql_lds leaves the eigenvectors where the matrix was
+    const int lane = lane_id();
+    double *Mown = RAGGED ? qa.Mslot + (size_t)blockIdx.x * qa.P4 * W : nullptr;
+    for (int i = lane; i < 2 * W; i += W) lds.q.th[i] = 0.0;
+    wave_sync();
+    for (;;) {
+        // every lane takes part in the fetch (see fit_quad_kernel)
+        int n32 = atomicAdd(qa.counter, lane == 0 ? 1 : 0);
+        n32 = __builtin_amdgcn_readfirstlane(n32);
+        if (n32 >= a.N) break;
+        newton_one_quad<KP, RAGGED>(qa, lds, rb, Am, Vm, PM, qa.Mg, Mown, n32);
+    }
+}
+
+}  // namespace tsf
