@@ -1092,10 +1092,10 @@ static int cn_tridiag_ql(int n, double *A, double *V, double *lam)
             for (; i >= l; --i) {
                 double f = s * e[i];
                 const double b = c * e[i];
-                r = cn_pythag(f, g);
+                r = sqrt(fma(f, f, g * g));     /* entries of a Hessian: nowhere near over/underflow */
                 e[i + 1] = r;
                 if (r == 0.0) { d[i + 1] -= p; e[m] = 0.0; underflow = 1; break; }
-                s = f / r; c = g / r;
+                { const double ri = 1.0 / r; s = f * ri; c = g * ri; }
                 g = d[i + 1] - p;
                 r = (d[i] - g) * s + 2.0 * c * b;
                 p = s * r;

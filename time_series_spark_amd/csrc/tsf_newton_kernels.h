@@ -131,7 +131,7 @@ __device__ __forceinline__ double ql_lds(int n, int PM, double *Am, double *Vm, 
                 const double ei = sc.e[i], di = sc.d[i], di1 = sc.d[i + 1];
                 double f = s * ei;
                 const double b = c * ei;
-                r = ql_pythag(f, g);
+                r = __builtin_sqrt(__builtin_fma(f, f, g * g));
                 TSF_WAVE_SYNC();
                 if (lane == 0) sc.e[i + 1] = r;
                 if (r == 0.0) {
@@ -140,7 +140,7 @@ __device__ __forceinline__ double ql_lds(int n, int PM, double *Am, double *Vm, 
                     TSF_WAVE_SYNC();
                     break;
                 }
-                s = f / r; c = g / r;
+                { const double ri = 1.0 / r; s = f * ri; c = g * ri; }
                 g = di1 - p;
                 r = (di - g) * s + 2.0 * c * b;
                 p = s * r;

@@ -70,9 +70,9 @@ __device__ __forceinline__ void newton_one_quad(const QuadArgs &qa, NewtonQuadLd
     const int P = sv.P;
     const double epsilon = 1e-3, half_epsilon = 0.5 * epsilon;
 
-    enum { S_INIT = 0, S_F0, S_FD, S_HALVE };
+    enum { S_INIT = 0, S_F0, S_HALVE };
     int stage = S_INIT, ret = TSF_ST_MAXIT, it = 0, mI = 0, d = 0, pi = 0;
-    double lp = 0.0, lastlp = 0.0, f0 = 0.0, f1 = 0.0, size = 2.0, acc = 0.0, fx = 0.0, s0 = 0.0, q2 = 0.0;
+    double lp = 0.0, lastlp = 0.0, f0 = 0.0, f1 = 0.0, size = 2.0, fx = 0.0, s0 = 0.0, q2 = 0.0;
     for (;;) {
         bool bad;
         sv.n_eval++;
@@ -102,23 +102,55 @@ __device__ __forceinline__ void newton_one_quad(const QuadArgs &qa, NewtonQuadLd
             lastlp = lp;
             f0 = -fx;
             g[0] = gx[0];
-            d = 0; pi = 0; acc = 0.0;
-            stage = S_FD;
-            x[0] = (lane == 0) ? th[0] + (-2 * epsilon) : th[0];
-            continue;
-        }
-        if (stage == S_FD) {
-            if (bad) { ret = TSF_ST_NEWTON_FAIL; break; }
-            const double coef = (pi == 0) ? 1.0 / 12.0 : (pi == 1 ? -2.0 / 3.0 : (pi == 2 ? 2.0 / 3.0 : -1.0 / 12.0));
-            acc = __builtin_fma(half_epsilon * coef, -gx[0], acc);
-            if (++pi == 4) {
-                if (lane < P) Am[d * PM + lane] = acc;
-                acc = 0.0; pi = 0; ++d;
-            }
-            if (d < P) {
-                const double pert = (pi == 0) ? -2 * epsilon : (pi == 1 ? -1 * epsilon : (pi == 2 ? epsilon : 2 * epsilon));
-                x[0] = (lane == d) ? th[0] + pert : th[0];
-                continue;
+            // ---- finite-difference Hessian: 4 P gradient evaluations at th + pert e_d.  The
+            // quadratic form has just been re-centred at th, so D = x - ref has ONE non-zero entry
+            // and cn_eval_gram's mat-vec, dot products and butterflies collapse to what is
+            // written here -- bit for bit: fma(m, 0, a) = a, x + 0 = x (a -0 product becomes +0
+            // in the sums, hence the "+ 0.0").  Only the gradient is formed: for finite theta a
+            // non-finite log_prob value comes with a non-finite gradient entry (sigma = 0 or inf).
+            {
+                const double thl = th[0], refl = wl.ref[lane], cvl = wl.cvec[lane];
+                const double lcl = lk.lc[lane], scl = lk.sc[lane];
+                const double Td = (double)sv.T;
+                // sigma terms of the centre (every point except the four that perturb log sigma)
+                const double ls0 = readlane_f64(thl, 2);
+                const double sigma0 = dm_exp(ls0);
+                const double s2_0 = sigma0 * sigma0;
+                const double inv_s2_0 = 1.0 / s2_0;
+                bool fd_bad = false;
+                for (d = 0; d < P; ++d) {
+                    const double mcol = (d == 2) ? 0.0 : Mp[(size_t)d * W + lane];
+                    const double cvd = readlane_f64(cvl, d);
+                    double accd = 0.0;
+#pragma unroll
+                    for (pi = 0; pi < 4; ++pi) {
+                        const double pert = (pi == 0) ? -2 * epsilon : (pi == 1 ? -1 * epsilon : (pi == 2 ? epsilon : 2 * epsilon));
+                        const double coef = (pi == 0) ? 1.0 / 12.0 : (pi == 1 ? -2.0 / 3.0 : (pi == 2 ? 2.0 / 3.0 : -1.0 / 12.0));
+                        const double thp = (lane == d) ? thl + pert : thl;
+                        const double Dd = (d == 2) ? 0.0 : readlane_f64(thp - refl, d);
+                        const double v = mcol * Dd + 0.0;
+                        const double q2d = Dd * readlane_f64(v, d) + 0.0;
+                        const double cd = cvd * Dd + 0.0;
+                        const double sse = __builtin_fma(-2.0, cd, s0) + q2d;
+                        const double ztr = cvl - v;
+                        double s2 = s2_0, inv_s2 = inv_s2_0;
+                        if (d == 2) {
+                            const double sigma = dm_exp(ls0 + pert);
+                            s2 = sigma * sigma;
+                            inv_s2 = 1.0 / s2;
+                        }
+                        const double nis = -inv_s2;
+                        const double sgn = (double)((thp > 0.0) - (thp < 0.0));
+                        double gv = __builtin_fma(thp, lcl, nis * ztr) + sgn * scl;
+                        if (lane == 2) gv = (Td - sse * inv_s2) + 4.0 * s2;
+                        if (lane >= P) gv = 0.0;
+                        fd_bad = fd_bad || !finite_f64(gv);
+                        accd = __builtin_fma(half_epsilon * coef, -gv, accd);
+                    }
+                    if (lane < P) Am[d * PM + lane] = accd;
+                }
+                sv.n_eval += 4 * P;
+                if (__any(fd_bad)) { ret = TSF_ST_NEWTON_FAIL; break; }
             }
             // ---- H = A + A^T (in place; lane b owns the pairs (a, b), a < b, and its diagonal)
             wave_sync();

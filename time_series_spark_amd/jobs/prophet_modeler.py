@@ -145,6 +145,12 @@ def fit_packed(panel, floor, cap, kw, devices=None):
         if algo == 'newton' and not newton_ok:
             raise ValueError('algorithm newton needs 3 + n_changepoints + K <= 64 and one seasonality mode')
         short = panel.lengths[members] < NEWTON_BELOW_T
+        if algo == 'auto' and not newton_ok and short.any():
+            # fbprophet would run Stan's Newton here (and retry failed L-BFGS fits with it); the Newton
+            # kernel holds one parameter per lane, so these models stay on L-BFGS: said, not hidden
+            print(f"Newton optimiser unavailable for this model (3 + n_changepoints + K = "
+                  f"{3 + lbfgs.n_changepoints + lbfgs.K}, K = {lbfgs.K}, modes {sorted(modes)}): "
+                  f"{int(short.sum())} series shorter than {NEWTON_BELOW_T} rows are fitted with L-BFGS")
         if algo == 'newton':
             first_newton, first_lbfgs = members, members[:0]
         elif algo == 'auto' and newton_ok:
