@@ -18,6 +18,24 @@ namespace tsf {
 
 int quad_waves_per_block(int PPL) { return PPL == 2 ? TSF_QUAD_NW2 : TSF_QUAD_NW; }
 
+// ragged panel, Z^T Z of every resident wave in LDS: NWR waves per workgroup (tsf_quad_kernels.h
+// QM_RAGGED_LDS); -2 when it does not fit (the caller falls back to M in global memory)
+template <int KP, int PQ>
+static int launch_quad_ragged_lds(const QuadPlan &qp, const QuadArgs &qa, hipStream_t st)
+{
+    constexpr int NWR = 4;
+    if (qp.P4 != PQ) return -2;
+    const size_t lds = (sizeof(QuadLds<KP, 1>) + sizeof(double) * ((size_t)qa.f.NTmax * W + (size_t)(PQ * PQ + W))) * NWR;
+    if (lds > 160 * 1024) return -2;
+    hipFuncSetAttribute((const void *)fit_quad_kernel<KP, 1, NWR, QM_RAGGED_LDS, PQ, true>,
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    int64_t blocks = qp.blocks;     // one workgroup per CU
+    const int64_t need = (qa.f.N + NWR - 1) / NWR;
+    if (blocks > need) blocks = need;
+    hipLaunchKernelGGL((fit_quad_kernel<KP, 1, NWR, QM_RAGGED_LDS, PQ, true>), dim3((unsigned)blocks), dim3(NWR * 64), lds, st, qa);
+    return (int)hipGetLastError();
+}
+
 template <int KP, int PPL, int MMODE, int PQ, bool RLDS>
 static int launch_quad_rl(const QuadPlan &qp, const QuadArgs &qa, double *Mg, hipStream_t st)
 {
@@ -72,7 +90,13 @@ static int launch_quad_mm(const QuadPlan &qp, const QuadArgs &qa, double *Mg, hi
 template <int KP, int PPL, int PQ>
 static int launch_quad_one(const QuadPlan &qp, const QuadArgs &qa, double *Mg, hipStream_t st)
 {
-    if (!qa.f.aligned) return launch_quad_mm<KP, PPL, QM_RAGGED, PQ>(qp, qa, Mg, st);
+    if (!qa.f.aligned) {
+        if constexpr (PPL == 1 && PQ > 0) {
+            const int rc = launch_quad_ragged_lds<KP, PQ>(qp, qa, st);
+            if (rc != -2) return rc;
+        }
+        return launch_quad_mm<KP, PPL, QM_RAGGED, PQ>(qp, qa, Mg, st);
+    }
     return launch_quad_mm<KP, PPL, (PPL == 1 ? QM_LDS : QM_GLOBAL), PQ>(qp, qa, Mg, st);
 }
 

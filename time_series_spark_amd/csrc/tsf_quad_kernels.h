@@ -281,7 +281,9 @@ __device__ __forceinline__ bool resid_eval_q(const SeriesView &sv, QuadLds<KP, P
 // PQ > 0: compile-time row count of M (PPL == 1; rows >= P are zero, which is bit-neutral), the
 // whole evaluation is then ONE basic block and the scheduler can run the exp / division /
 // prior-sum chains of assemble_q underneath the LDS reads and the four fma chains.
-template <int PPL, int PQ>
+// MRS: doubles between consecutive rows of Ml (64, or PQ for the compact per-wave copies of ragged
+// panels: lanes >= MRS then read finite entries of the next row, which only ever meet D = 0)
+template <int PPL, int PQ, int MRS = W>
 __device__ __forceinline__ bool gram_eval_q(const SeriesView &sv, const LaneConst<PPL> &lk,
                                             const double *Ml, int P4, const double (&th)[PPL],
                                             const double *ref_l, const double *cvec_l,
@@ -312,7 +314,7 @@ __device__ __forceinline__ bool gram_eval_q(const SeriesView &sv, const LaneCons
         for (int q0 = 0; q0 < PQ; q0 += MB) {
             double m[MB];
 #pragma unroll
-            for (int u = 0; u < MB; ++u) if (q0 + u < PQ) m[u] = mp[(q0 + u) * W];
+            for (int u = 0; u < MB; ++u) if (q0 + u < PQ) m[u] = mp[(q0 + u) * MRS];
             double dq[MB];              // D_q for the whole wave: one broadcast LDS read each
 #pragma unroll
             for (int u = 0; u < MB; ++u) if (q0 + u < PQ) dq[u] = dl[q0 + u];
@@ -449,7 +451,7 @@ __global__ __launch_bounds__(64) void gram_build_kernel(QuadArgs qa, double *Mou
 #endif
 
 // One series, start to finish, by one wave.
-template <int KP, int PPL, int PQ, bool RAGGED>
+template <int KP, int PPL, int PQ, bool RAGGED, int MRS = W>
 __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL> &wl, double *rb,
                                           const double *Mp, double *Mown, int64_t n)
 {
@@ -495,8 +497,12 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
 #pragma unroll
             for (int s = 0; s < PPL; ++s) col[s] = 0.0;
             if (q != 2 && q < sv.P) gram_column<KP, PPL>(sv, wl, rb, q, col);
+            if (MRS == W) {
 #pragma unroll
-            for (int s = 0; s < PPL; ++s) Mown[((size_t)q * PPL + s) * W + lane] = col[s];
+                for (int s = 0; s < PPL; ++s) Mown[((size_t)q * PPL + s) * W + lane] = col[s];
+            } else if (lane < MRS) {
+                Mown[(size_t)q * MRS + lane] = col[0];
+            }
         }
         Mp = Mown;
     }
@@ -700,7 +706,7 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
 #pragma unroll
             for (int s = 0; s < PPL; ++s) { xk1[s] = __builtin_fma(alpha, pk[s], xk[s]); xe[s] = xk1[s]; }
             sv.n_eval++;
-            bad = gram_eval_q<PPL, PQ>(sv, lk, Mp, P4, xe, wl.ref, wl.cvec, s0, fe, ge, q2, wl.th);
+            bad = gram_eval_q<PPL, PQ, MRS>(sv, lk, Mp, P4, xe, wl.ref, wl.cvec, s0, fe, ge, q2, wl.th);
             QT_LAP(4);
 #pragma unroll
             for (int s = 0; s < PPL; ++s) gk1[s] = ge[s];
@@ -769,7 +775,10 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
 
 // MMODE: where M lives -- 0 aligned panel, shared M in LDS; 1 aligned panel, shared M in global
 // memory (two-slot kernel: too big for LDS); 2 ragged panel, one M per resident wave in global
-enum { QM_LDS = 0, QM_GLOBAL = 1, QM_RAGGED = 2 };
+// 3 ragged panel, one M per resident wave in LDS (fewer waves per workgroup: an evaluation reads all
+// of M, and eight private 28 KB matrices per CU do not fit the 32 KB L1: from global memory the
+// ragged fit ran at the L2's pace, 5x the aligned time)
+enum { QM_LDS = 0, QM_GLOBAL = 1, QM_RAGGED = 2, QM_RAGGED_LDS = 3 };
 
 template <int KP, int PPL, int NW, int MMODE, int PQ, bool RLDS>
 __global__ __launch_bounds__(NW * 64, QUAD_WAVES_PER_SIMD) void fit_quad_kernel(QuadArgs qa)
@@ -787,8 +796,16 @@ __global__ __launch_bounds__(NW * 64, QUAD_WAVES_PER_SIMD) void fit_quad_kernel(
         __syncthreads();
     }
     const double *Mp = MLDS ? Ml : qa.Mg;
+    const size_t rb_bytes = RLDS ? sizeof(double) * (size_t)NW * a.NTmax * W : 0;
     double *Mown = (MMODE == QM_RAGGED) ? qa.Mslot + ((size_t)blockIdx.x * NW + wid) * (size_t)P4 * PPL * W
-                                        : nullptr;
+                 : (MMODE == QM_RAGGED_LDS) ? reinterpret_cast<double *>(smem + m_bytes + sizeof(QuadLds<KP, PPL>) * NW + rb_bytes) +
+                                               (size_t)wid * (PQ * PQ + W)
+                                            : nullptr;
+    constexpr int MRS = (MMODE == QM_RAGGED_LDS) ? PQ : W;
+    if (MMODE == QM_RAGGED_LDS) {       // the spill-over reads past the last row must meet finite numbers
+        Mown[PQ * PQ + lane] = 0.0;
+        wave_sync();
+    }
     // residual staging r[q][lane] of the running residual pass: in LDS when the launch found room
     // for NW x NTmax x 64 doubles, else in the global scratch (long series)
     double *rb = RLDS ? reinterpret_cast<double *>(smem + m_bytes + sizeof(QuadLds<KP, PPL>) * NW) + (size_t)wid * a.NTmax * W
@@ -805,7 +822,7 @@ __global__ __launch_bounds__(NW * 64, QUAD_WAVES_PER_SIMD) void fit_quad_kernel(
         n32 = __builtin_amdgcn_readfirstlane(n32);
         const int64_t n = n32;
         if (n >= a.N) break;
-        fit_one_quad<KP, PPL, PQ, MMODE == QM_RAGGED>(qa, wl, rb, Mp, Mown, n);
+        fit_one_quad<KP, PPL, PQ, MMODE == QM_RAGGED || MMODE == QM_RAGGED_LDS, MRS>(qa, wl, rb, Mp, Mown, n);
     }
 }
 
