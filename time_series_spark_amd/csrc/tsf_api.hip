@@ -338,12 +338,14 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     // MfmaTabs::overflow routes the call to the one-wave kernel)
     MfmaPlan mp;
     memset(&mp, 0, sizeof(mp));
-    // TSF_RK_AUTO takes the one-wave kernel: measured (profiles/r02_mfma_vs_wave.txt) the matrix-core
-    // kernel evaluates 1.3x more points per second when every slot is busy (100 000 x 730, iteration
-    // cap 150: 62.7 vs 48.1 M evaluations/s) but a launch that waits for one long series is slower
-    // (a round with one busy slot costs what a round with 16 does), and panels below 16 series per CU
-    // leave CUs idle.
-    if (aligned && !quad && !newton && theta_in == nullptr && hs.KP <= 28 && spec->residual_kernel == TSF_RK_MFMA) {
+    // TSF_RK_AUTO: measured (profiles/r02_mfma_vs_wave.txt) the matrix-core kernel evaluates 1.3x more
+    // points per second when its slots are busy (100 000 x 730, iteration cap 150: 62.7 vs 48.1 M
+    // evaluations/s) and matches the one-wave kernel while a launch waits for one long series
+    // (rounds with up to three requests are shared by all waves of the workgroup), but a panel below
+    // 16 series per CU leaves CUs idle: AUTO takes it from 64 series per CU on.
+    const bool want_mfma = spec->residual_kernel == TSF_RK_MFMA ||
+                           (spec->residual_kernel == TSF_RK_AUTO && N >= (int64_t)64 * ctx->n_cu);
+    if (aligned && !quad && !newton && theta_in == nullptr && hs.KP <= 28 && want_mfma) {
         const int hist_rows = (int)floor((double)Tm * hs.cp_range);
         int S = hs.n_cp;
         if (S + 1 > hist_rows) S = hist_rows - 1;

@@ -541,9 +541,135 @@ __global__ __launch_bounds__(MT_NW * W) void fit_mfma_kernel(FitArgs a, MfmaTabs
 #endif
 
         // =====================================================================================
-        // evaluation phase: all waves, all slots.  lane = (slot row k = lane / 16, series j = lane % 16)
+        // few requests (the tail of a launch: one long series keeps its workgroup alive): a tile
+        // evaluation would do 16 series' work for one.  Instead the 8 waves share ONE series'
+        // evaluation the way eval_fg orders it -- rows by (chunk = lane, step q): the steps are
+        // dealt to the waves for the forward pass (r, r g, v per row -> LDS), then the design
+        // columns are dealt to the waves for the per-chunk fma chains and the butterflies over the
+        // chunks, and one wave runs the sse / trend chains.  Same operations, same order, same bits.
         // =====================================================================================
-        {
+        int n_act = 0;
+#pragma unroll
+        for (int s2 = 0; s2 < MT_NS; ++s2) n_act += states[s2].v.waiting;
+        const bool solo = n_act <= MT_SOLO_MAX && (size_t)sv.NT * 3 * W * sizeof(double) <= MtLayout<KP>::stage_bytes;
+        if (solo) {
+#pragma unroll 1
+            for (int sj = 0; sj < MT_NS; ++sj) {
+                if (!states[sj].v.waiting) continue;
+                MtSlot<KP> &so = slots[sj];
+                const MtVars &vo = states[sj].v;
+                const int NT = sv.NT;
+                int cnt = sv.T - lane * NT;
+                cnt = cnt < 0 ? 0 : (cnt > NT ? NT : cnt);
+                double *rbR = stg, *rbU = stg + (size_t)NT * W, *rbV = stg + (size_t)2 * NT * W;   // r, r or r g, v
+                const double *ywn = a.yw + (size_t)vo.n * a.NTmax * W;
+                // ---- forward: wave w takes steps q = w, w + 8, ...
+                {
+                    double bs[KP];
+#pragma unroll
+                    for (int jc = 0; jc < KP; ++jc) bs[jc] = Bm[sj * MT_BSTR + 3 + S + jc];
+#pragma unroll 2
+                    for (int q = wid; q < NT; q += MT_NW) {
+                        double r0 = 0.0, ru = 0.0, vt = 0.0;
+                        if (q < cnt) {
+                            const int idx = q * W + lane;
+                            const int c = (int)(a.cw[idx] & 0xffu);
+                            const double ti = a.tw[idx], yi = ywn[idx];
+                            const double *xp = a.Xw + (size_t)q * KP * W + lane;
+                            double xa = 0.0, xm = 0.0;
+#pragma unroll
+                            for (int jc = 0; jc < KP; ++jc) {
+                                if (MODE == 0) xa = __builtin_fma(xp[jc * W], bs[jc], xa);
+                                else xm = __builtin_fma(xp[jc * W], bs[jc], xm);
+                            }
+                            const double ksc = so.ks[c], mcc = so.mc[c];
+                            double gtr, qv = 0.0;
+                            if (GROWTH == 0) {
+                                gtr = __builtin_fma(ksc, ti, mcc);
+                            } else {
+                                const double z = ksc * (ti - mcc);
+                                const double e = dm_exp(-z);
+                                const double sg = 1.0 / (1.0 + e);
+                                gtr = vo.cap * sg;
+                                qv = gtr * (1.0 - sg);
+                            }
+                            const double opm = 1.0 + xm;
+                            const double mu = __builtin_fma(gtr, opm, xa);
+                            r0 = yi - mu;
+                            ru = (MODE == 0) ? r0 : r0 * gtr;
+                            vt = r0 * opm;
+                            if (GROWTH == 1) vt = vt * qv;
+                        }
+                        rbR[q * W + lane] = r0; rbU[q * W + lane] = ru; rbV[q * W + lane] = vt;
+                    }
+                }
+                __syncthreads();
+                // ---- backward: wave w takes the design columns w, w + 8, w + 16, w + 24; lane = chunk
+                {
+                    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+                    // four steps' loads in flight at a time (a step-by-step loop would wait for L2 at
+                    // every step); steps past NT - 1 rounded up read row 0 again with weight 0
+                    const int NT4 = (NT + 3) & ~3;
+#pragma unroll 1
+                    for (int q0 = NT4 - 4; q0 >= 0; q0 -= 4) {
+                        double xv[4][4], rv4[4];
+#pragma unroll
+                        for (int k = 3; k >= 0; --k) {
+                            const int q = q0 + k, qc = q < NT ? q : 0;
+                            rv4[k] = q < NT ? rbU[qc * W + lane] : 0.0;
+                            const double *xp = a.Xw + (size_t)qc * KP * W + lane;
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const int jc = wid + MT_NW * u;
+                                xv[k][u] = (jc < KP) ? xp[jc * W] : 0.0;
+                            }
+                        }
+#pragma unroll
+                        for (int k = 3; k >= 0; --k)
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                if (q0 + k < NT) acc[u] = __builtin_fma(xv[k][u], rv4[k], acc[u]);   // rows past the end of a chunk: X = 0, r = 0
+                    }
+                    // butterfly 32, 16, 1, 2, 4, 8 over the chunks (column_sums, one group of 4 columns)
+                    double c2[2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        double x0 = acc[2 * i], x1 = acc[2 * i + 1];
+                        swap32(x0, x1);
+                        c2[i] = x0 + x1;
+                    }
+                    double x0 = c2[0], x1 = c2[1];
+                    swap16(x0, x1);
+                    const double dsum = row_bfly_sum(x0 + x1);
+                    if ((lane & 15) == 0) {
+                        const int r = lane >> 4;
+                        const int sub = (r == 0) ? 0 : (r == 1 ? 2 : (r == 2 ? 1 : 3));
+                        const int jc = wid + MT_NW * sub;
+                        if (jc < KP) so.accR[jc] = dsum;
+                    }
+                }
+                if (wid == MT_NW - 1) {
+                    // ---- per-chunk sum of squares and trend sums with their changepoint-row values
+                    double sse = 0.0, rt1 = 0.0, rt2 = 0.0;
+#pragma unroll 4
+                    for (int q = NT - 1; q >= 0; --q) {
+                        const int idx = q * W + lane;
+                        const unsigned cwv = (unsigned)a.cw[idx];       // (loads for every lane: no divergent wait)
+                        const double ti = a.tw[idx];
+                        if (q < cnt) {
+                            const int c = (int)(cwv & 0xffu), cprev = (int)(cwv >> 8);
+                            const double r0 = rbR[idx], vt = rbV[idx];
+                            sse = __builtin_fma(r0, r0, sse);
+                            rt1 = __builtin_fma(vt, ti, rt1);
+                            rt2 = rt2 + vt;
+                            for (int jj = cprev; jj < c; ++jj) { so.tp1[jj] = rt1; so.tp2[jj] = rt2; }
+                        }
+                    }
+                    so.sse[lane] = sse; so.tot1[lane] = rt1; so.tot2[lane] = rt2;
+                }
+                __syncthreads();        // the row buffers are free for the next requested slot
+            }
+        } else {
             const int j = lane & 15, kq = lane >> 4;
             MtSlot<KP> &sj = slots[j];
             const MtVars &vj = states[j].v;
@@ -730,6 +856,7 @@ __global__ __launch_bounds__(MT_NW * W) void fit_mfma_kernel(FitArgs a, MfmaTabs
         __syncthreads();
         MT_LAP(3);
         // ---- the remaining 16-leaf balanced tree (butterfly stages 1, 2, 4, 8) over the chunk classes
+        if (!solo)
         for (int o = (int)threadIdx.x; o < KP * MT_NS; o += MT_NW * W) {
             const int col = o / MT_NS, jx = o % MT_NS;
             double x[MT_LEAVES];

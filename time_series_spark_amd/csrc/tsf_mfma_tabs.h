@@ -13,6 +13,7 @@ constexpr int MT_SPW = MT_NS / MT_NW;   // slots owned by one wave
 constexpr int MT_LEAVES = 16;   // leaves of the cross-wave column tree: chunk classes L mod 16
 constexpr int MT_BSTR = 73;     // row stride (doubles) of the point / gradient matrices in LDS
 constexpr int MT_SP = 28;       // changepoints this kernel handles (fbprophet's default: 25)
+constexpr int MT_SOLO_MAX = 3;  // at most this many requests in a round: the waves share each evaluation instead
 constexpr int MT_MAXCP = 7;     // changepoint rows one chunk may hold (2 + 2*7 = 16 trend columns)
 
 // Re-laid tables of ONE aligned grid (mfma_layout_kernel).  L: chunk 0..63; g: group of 16 row
