@@ -556,6 +556,31 @@ def test_full_size_cfg4_logistic_holidays(env):
         assert np.array_equal(yh[n], yo) and n_bit_diff(r.fval[n], o['f']) == 0
 
 
+def test_full_size_reference_model_takes_the_matrix_core_kernel(env):
+    """The reference's own settings (logistic growth, multiplicative yearly + weekly) on a
+    20 000 x 730 aligned panel: TSF_RK_AUTO routes it to the matrix-core kernel (>= 64 series per
+    CU); every series ends normally and a random sample is bit-identical to the oracle."""
+    fc, cl = env
+    from time_series_spark_amd import synth
+    N, T, H = 20000, 730, 90
+    ds, y = synth.make_panel(N, T, 'logistic', seed=752)
+    spec = fc.ModelSpec(growth='logistic', seasonality_mode='multiplicative',
+                        seasonalities=[helpers.YEARLY, helpers.WEEKLY])
+    floor, cap = np.zeros(N), y.max(axis=1) * 1.1
+    r = fc.fit_aligned(spec, ds, y, floor=floor, cap=cap)
+    bad = r.status <= 0
+    assert bad.sum() <= 4 and np.isin(r.status[bad], [-1, -3]).all() and (r.n_iter >= 1).all()
+    fut = ds[-1] + helpers.DAY_NS * np.arange(1, H + 1)
+    sub = np.random.default_rng(7).choice(np.flatnonzero(~bad & (r.n_eval < 2500)), 8, replace=False)
+    yh = fc.predict(spec, r.theta[sub], r.y_scale[sub], r.grid, fut, floor=floor[sub], cap=cap[sub])
+    csp = helpers.oracle_spec(spec)
+    for i, n in enumerate(sub):
+        o = cl.fit(csp, ds, y[n], floor[n], cap[n])
+        yo, _ = cl.predict(csp, o, fut, floor[n], cap[n])
+        assert (r.n_iter[n], r.n_eval[n], r.status[n]) == (o['n_iter'], o['n_eval'], o['status'])
+        assert np.array_equal(yh[i], yo) and n_bit_diff(r.fval[n], o['f']) == 0
+
+
 def test_upstream_known_answer_vectors_through_predict_kernel(env):
     """fbprophet's own piecewise_linear / piecewise_logistic known-answer vectors
     (tests/golden/upstream_recall.json) through tsf_predict: scaled time = days, y_scale 1,
