@@ -200,6 +200,31 @@ int tsf_predict_dev(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int32_t H,
                     const double *floor, const double *cap, const double *extra_future,
                     double *yhat, int32_t *yhat_int, void *stream);
 
+/* ---- uncertainty intervals ----------------------------------------------------------------
+ * yhat_lower / yhat_upper of fbprophet's Prophet.predict_uncertainty -- computed by
+ * model.predict(future_df) at /root/reference/src/jobs/prophet_scorer.py:70 and dropped at :86:
+ * n_samples simulated futures per series (new trend changepoints ~ Poisson(S (T - 1)) on [1, T] with
+ * Laplace(0, mean|delta| + 1e-8) slope changes, observation noise N(0, sigma_obs)), then the
+ * (1 -+ interval_width) / 2 percentiles per future row.  fbprophet uses numpy's unseeded global
+ * generator; here the draws come from a counter-based generator keyed by (seed, series_key[n],
+ * sample, stream), so results are reproducible and independent of how series are batched
+ * (series_key NULL: the index of the series in this call).  Also returns the point forecast.
+ * Arguments as tsf_predict; n_samples in [2, 4096] (fbprophet: 1000), interval_width in (0, 1)
+ * (fbprophet: 0.8). */
+int tsf_predict_intervals(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int32_t H,
+                          const double *theta, const double *y_scale, const tsf_grid_info *grid,
+                          int32_t n_grids, const int64_t *ds_future, int32_t shared_future,
+                          const double *floor, const double *cap, const double *extra_future,
+                          const int64_t *series_key, int32_t n_samples, double interval_width,
+                          uint64_t seed, double *yhat, double *yhat_lower, double *yhat_upper);
+int tsf_predict_intervals_dev(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int32_t H,
+                              const double *theta, const double *y_scale, const tsf_grid_info *grid,
+                              int32_t n_grids, const int64_t *ds_future, int32_t shared_future,
+                              const double *floor, const double *cap, const double *extra_future,
+                              const int64_t *series_key, int32_t n_samples, double interval_width,
+                              uint64_t seed, double *yhat, double *yhat_lower, double *yhat_upper,
+                              void *stream);
+
 /* ---- test / diagnostics hooks (host pointers) -------------------------------------------
  * tsf_eval: f = -log posterior and gradient [N][stride] at theta [N][stride] for an aligned
  * panel.  tsf_design: X [T][K] (row-major, original column order), scaled t [T]. */

@@ -88,6 +88,8 @@ def lib():
                                      ctypes.POINTER(CnFitInfo), vp]
         L.cn_predict.argtypes = [ctypes.POINTER(CnSpec), ctypes.POINTER(CnFitInfo), vp, vp, i32,
                                  vp, f64, f64, vp, vp, vp]
+        L.cn_predict_intervals.argtypes = [ctypes.POINTER(CnSpec), ctypes.POINTER(CnFitInfo), vp, vp, i32,
+                                           vp, f64, f64, vp, i32, f64, ctypes.c_uint64, ctypes.c_uint64, vp, vp]
         L.cn_det_exp.argtypes = [f64]
         L.cn_det_exp.restype = f64
         L.cn_det_log.argtypes = [f64]
@@ -271,3 +273,20 @@ def predict(sp, fitres, ds_future_ns, floor=0.0, cap=0.0, extra_future=None):
                      tch.ctypes.data, H, ds.ctypes.data, float(floor), float(cap), eptr,
                      yhat.ctypes.data, trend.ctypes.data)
     return yhat, trend
+
+
+def predict_intervals(sp, fitres, ds_future_ns, floor=0.0, cap=0.0, extra_future=None, n_samples=1000,
+                      interval_width=0.8, seed=0, series_key=0):
+    """Seeded restatement of Prophet.predict_uncertainty (yhat_lower, yhat_upper); see
+    cn_predict_intervals."""
+    ds = _i64(ds_future_ns)
+    H = len(ds)
+    lo, hi = np.zeros(H), np.zeros(H)
+    theta = _f64(fitres['theta'])
+    tch = _f64(np.concatenate([fitres['t_change'], [0.0]]))
+    ekeep, eptr = _extra_ptr(sp, extra_future, H)
+    lib().cn_predict_intervals(ctypes.byref(sp), ctypes.byref(fitres['info']), theta.ctypes.data,
+                               tch.ctypes.data, H, ds.ctypes.data, float(floor), float(cap), eptr,
+                               int(n_samples), float(interval_width), int(seed), int(series_key),
+                               lo.ctypes.data, hi.ctypes.data)
+    return lo, hi

@@ -647,3 +647,50 @@ class ProphetOracle(object):
                             'multiplicative_terms': multiplicative})
         out['yhat'] = out['trend'] * (1 + out['multiplicative_terms']) + out['additive_terms']
         return out
+
+    # ---- Prophet.predict_uncertainty (literal: numpy's global generator, as fbprophet) ---------
+    def sample_predictive_trend(self, df):
+        k = self.params['k'][0]
+        m = self.params['m'][0]
+        deltas = self.params['delta'][0]
+        t = np.array(df['t'])
+        T = t.max()
+        if T > 1:
+            S = len(self.changepoints_t)
+            n_changes = np.random.poisson(S * (T - 1))
+        else:
+            n_changes = 0
+        if n_changes > 0:
+            changepoint_ts_new = 1 + np.random.rand(n_changes) * (T - 1)
+            changepoint_ts_new.sort()
+        else:
+            changepoint_ts_new = []
+        lambda_ = np.mean(np.abs(deltas)) + 1e-8
+        deltas_new = np.random.laplace(0, lambda_, n_changes)
+        changepoint_ts = np.concatenate((self.changepoints_t, changepoint_ts_new))
+        deltas = np.concatenate((deltas, deltas_new))
+        if self.growth == 'linear':
+            trend = piecewise_linear(t, deltas, k, m, changepoint_ts)
+        else:
+            trend = piecewise_logistic(t, np.array(df['cap_scaled']), deltas, k, m, changepoint_ts)
+        return trend * self.y_scale + df['floor'].values
+
+    def predict_uncertainty(self, df, uncertainty_samples=1000, interval_width=0.8):
+        """yhat_lower / yhat_upper as fbprophet computes them (sample_posterior_predictive with MAP
+        parameters, sample_model, np.nanpercentile)."""
+        df = self.setup_dataframe(df.copy())
+        seasonal_features, _, s_a, s_m = self.make_all_seasonality_features(df)
+        X = seasonal_features.values
+        beta = self.params['beta'][0]
+        Xb_a = (X @ (beta * s_a)) * self.y_scale
+        Xb_m = X @ (beta * s_m)
+        sigma = self.params['sigma_obs'][0]
+        sims = np.empty((df.shape[0], uncertainty_samples))
+        for i in range(uncertainty_samples):
+            trend = self.sample_predictive_trend(df)
+            noise = np.random.normal(0, sigma, df.shape[0]) * self.y_scale
+            sims[:, i] = trend * (1 + Xb_m) + Xb_a + noise
+        lower_p = 100 * (1.0 - interval_width) / 2
+        upper_p = 100 * (1.0 + interval_width) / 2
+        return np.nanpercentile(sims, lower_p, axis=1), np.nanpercentile(sims, upper_p, axis=1)
+

@@ -1408,6 +1408,164 @@ int cn_predict(const cn_spec *sp, const cn_fitinfo *info, const double *theta,
     return 0;
 }
 
+/* ---- uncertainty intervals (Prophet.predict_uncertainty), seeded -------------------------------
+ * fbprophet 0.5: sample_posterior_predictive draws uncertainty_samples (1000) futures per series
+ * -- sample_predictive_trend: n ~ Poisson(S (T - 1)) new changepoints uniform on [1, T] (T = largest
+ * scaled future time), slope changes Laplace(0, mean|delta| + 1e-8), appended to the fitted ones;
+ * sample_model: yhat = trend (1 + Xb_m) + Xb_a + N(0, sigma_obs) y_scale -- and predict_uncertainty
+ * takes the (1 -+ interval_width) / 2 percentiles per future row (np.nanpercentile, linear).
+ * The reference computes them (prophet_scorer.py:70) and drops them (:86).  numpy's global generator
+ * is unseeded there, so parity is DEFINED here: a counter-based generator keyed by
+ * (seed, series key, sample, stream) -- stream 0: changepoints, consumed in order; stream 1: the
+ * noise of future row h at counters 2h, 2h + 1 -- with every transcendental from det_math.h.  The
+ * n uniform changepoint times are generated already sorted (order statistics by the spacing
+ * recurrence): the same joint distribution as numpy's draw-then-sort, without storing them.  The HIP
+ * kernels (tsf_interval_kernels.h) consume the same stream in the same order: bit-identical. */
+static uint64_t cn_mix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+static uint64_t cn_rng_key(uint64_t seed, uint64_t series_key, uint64_t sample, uint64_t stream)
+{
+    return cn_mix64(cn_mix64(cn_mix64(cn_mix64(seed) ^ series_key) ^ sample) ^ stream);
+}
+static double cn_u01(uint64_t key, uint64_t ctr)        /* in (0, 1) */
+{
+    const uint64_t x = cn_mix64(key + 0x9E3779B97F4A7C15ULL * ctr);
+    return ((double)(x >> 11) + 0.5) * 1.1102230246251565e-16;
+}
+static int cn_poisson(double lam, uint64_t key, uint64_t *ctr)
+{
+    int n = 0;
+    double rest = lam;
+    while (rest > 0.0 && n < 100000) {       /* Knuth's product method on pieces of at most 8 */
+        const double piece = rest < 8.0 ? rest : 8.0;
+        const double L = det_exp(-piece);
+        double p = 1.0;
+        int k = 0;
+        do { p = p * cn_u01(key, (*ctr)++); ++k; } while (p > L);
+        n += k - 1;
+        rest = rest - piece;
+    }
+    return n;
+}
+
+typedef struct {            /* trend state swept along increasing t */
+    double k, m;
+    int ih;                 /* fitted changepoints already passed */
+    int inew, n_new;        /* sampled changepoints already passed / in total */
+    double u_prev;          /* last order statistic */
+    double next_t, next_delta;
+    uint64_t ctr;
+} cn_trend_sweep;
+
+int cn_predict_intervals(const cn_spec *sp, const cn_fitinfo *info, const double *theta,
+                         const double *t_change, int H, const int64_t *ds, double floor_, double cap,
+                         const double *extra_future, int n_samples, double interval_width,
+                         uint64_t seed, uint64_t series_key, double *lower, double *upper)
+{
+    const int S = info->S, K = info->K;
+    const double *delta = theta + 3, *beta = theta + 3 + S;
+    const double fl = (sp->growth == 1) ? floor_ : 0.0;
+    const double ys = info->y_scale;
+    const double cap_sc = (sp->growth == 1) ? (cap - fl) / ys : 0.0;
+    const double sigma = det_exp(theta[2]);
+    int perm[CN_MAX_P], Ka;
+    double prior[CN_MAX_P];
+    build_perm(sp, K, perm, prior, &Ka);
+    const double tsc = (double)info->t_scale_ns;
+    const int nf = K - sp->n_extra;
+    double *t = (double *)malloc(sizeof(double) * H), *xa = (double *)malloc(sizeof(double) * H);
+    double *opm = (double *)malloc(sizeof(double) * H);
+    double *samp = (double *)malloc(sizeof(double) * (size_t)H * n_samples);
+    double Tm = -INFINITY;
+    for (int h = 0; h < H; ++h) {
+        t[h] = (double)(ds[h] - info->start_ns) / tsc;
+        if (t[h] > Tm) Tm = t[h];
+        double row[CN_MAX_P], a = 0.0, mm = 0.0;
+        fourier_row(sp, ds[h], row);
+        for (int e = 0; e < sp->n_extra; ++e) row[nf + e] = extra_future[(size_t)e * H + h];
+        for (int j = 0; j < Ka; ++j) a = fma(row[perm[j]], beta[perm[j]], a);
+        for (int j = Ka; j < K; ++j) mm = fma(row[perm[j]], beta[perm[j]], mm);
+        xa[h] = a * ys; opm[h] = 1.0 + mm;
+    }
+    /* fbprophet: S = len(changepoints_t) (1 with the dummy changepoint), lambda = mean|delta| + 1e-8 */
+    const int S_cp = S > 0 ? S : 1;
+    double lam_sum = 0.0;
+    for (int j = 0; j < S; ++j) lam_sum = lam_sum + fabs(delta[j]);
+    const double lambda_ = lam_sum / (double)S_cp + 1e-8;
+    const double rate = (Tm > 1.0) ? (double)S_cp * (Tm - 1.0) : 0.0;
+    for (int s = 0; s < n_samples; ++s) {
+        const uint64_t kcp = cn_rng_key(seed, series_key, (uint64_t)s, 0);
+        const uint64_t knz = cn_rng_key(seed, series_key, (uint64_t)s, 1);
+        cn_trend_sweep w;
+        double t_last = -INFINITY;
+        memset(&w, 0, sizeof(w));
+        for (int h = 0; h < H; ++h) {
+            if (h == 0 || t[h] < t_last) {       /* (re)start the sweep: the stream is replayed from 0 */
+                w.k = theta[0]; w.m = theta[1]; w.ih = 0; w.inew = 0; w.ctr = 0; w.u_prev = 0.0;
+                w.n_new = (rate > 0.0) ? cn_poisson(rate, kcp, &w.ctr) : 0;
+                w.next_t = INFINITY;
+            }
+            t_last = t[h];
+            while (w.ih < S && t[h] >= t_change[w.ih]) {           /* fitted changepoints */
+                const double dj = delta[w.ih], kn = w.k + dj;
+                if (sp->growth == 0) w.m = w.m + ((-t_change[w.ih]) * dj);
+                else w.m = w.m + (t_change[w.ih] - w.m) * (1.0 - w.k / kn);
+                w.k = kn; w.ih++;
+            }
+            for (;;) {                                               /* sampled changepoints */
+                if (w.next_t == INFINITY && w.inew < w.n_new) {
+                    const double v = cn_u01(kcp, w.ctr++);
+                    const double rem = (double)(w.n_new - w.inew);
+                    const double pw = det_exp(det_log(v) / rem);
+                    w.u_prev = 1.0 - (1.0 - w.u_prev) * pw;
+                    w.next_t = 1.0 + w.u_prev * (Tm - 1.0);
+                    const double ul = cn_u01(kcp, w.ctr++);
+                    w.next_delta = (ul < 0.5) ? lambda_ * det_log(2.0 * ul) : -(lambda_ * det_log(2.0 * (1.0 - ul)));
+                }
+                if (!(w.next_t <= t[h])) break;
+                const double dj = w.next_delta, kn = w.k + dj;
+                if (sp->growth == 0) w.m = w.m + ((-w.next_t) * dj);
+                else w.m = w.m + (w.next_t - w.m) * (1.0 - w.k / kn);
+                w.k = kn; w.inew++; w.next_t = INFINITY;
+            }
+            double gtr;
+            if (sp->growth == 0) gtr = fma(w.k, t[h], w.m);
+            else gtr = cap_sc * (1.0 / (1.0 + det_exp(-(w.k * (t[h] - w.m)))));
+            const double trend = gtr * ys + fl;
+            const double u1 = cn_u01(knz, 2 * (uint64_t)h), u2 = cn_u01(knz, 2 * (uint64_t)h + 1);
+            double sn, cs;
+            det_sincos(6.283185307179586 * u2, &sn, &cs);
+            const double z = sqrt(-2.0 * det_log(u1)) * cs;
+            samp[(size_t)h * n_samples + s] = trend * opm[h] + xa[h] + (z * sigma) * ys;
+        }
+    }
+    const double pl = (1.0 - interval_width) / 2.0, pu = (1.0 + interval_width) / 2.0;
+    for (int h = 0; h < H; ++h) {
+        double *v = samp + (size_t)h * n_samples;
+        for (int i = 1; i < n_samples; ++i) {       /* insertion sort: exact, n is ~1000 */
+            const double x = v[i];
+            int j = i - 1;
+            while (j >= 0 && v[j] > x) { v[j + 1] = v[j]; --j; }
+            v[j + 1] = x;
+        }
+        for (int which = 0; which < 2; ++which) {
+            const double pos = (which ? pu : pl) * (double)(n_samples - 1);
+            int lo = (int)floor(pos);
+            if (lo > n_samples - 1) lo = n_samples - 1;
+            const int hi = lo + 1 < n_samples ? lo + 1 : n_samples - 1;
+            const double val = v[lo] + (v[hi] - v[lo]) * (pos - (double)lo);
+            if (which) upper[h] = val; else lower[h] = val;
+        }
+    }
+    free(t); free(xa); free(opm); free(samp);
+    return 0;
+}
+
 /* Quadratic-form fit with every evaluation cross-checked against the residual form.
  * chk_out[0] = max |f_quad - f_resid| / max(1, |f_resid|), chk_out[1] = max relative 2-norm
  * gradient difference, over all evaluations of the fit. */

@@ -708,3 +708,41 @@ def test_holidays_through_the_job_layer(env):
         assert np.array_equal(got['ds'].values.astype('datetime64[ns]').astype(np.int64), fut)
         assert np.array_equal(got['yhat'].values, np.maximum(np.trunc(yo), 0).astype(np.int32))
         assert colsf.values.any() or n == 2                     # the future window holds a holiday
+
+
+@pytest.mark.parametrize('case', ['cfg2_linear_additive', 'ref_logistic_multiplicative', 'cfg4_holidays'])
+def test_uncertainty_intervals_match_the_seeded_oracle(env, case):
+    """yhat_lower / yhat_upper (Prophet.predict_uncertainty; computed and dropped by the
+    reference, prophet_scorer.py:70, :86).  Parity is defined with a seeded counter-based generator
+    (oracle cn_predict_intervals): the GPU kernels draw the same streams in the same order, so the
+    percentiles are identical; the streams are keyed by series_key, so a series gets the same
+    interval in any batch; and the interval behaves like one (contains the point forecast, ~80 %
+    wide as 2 x 1.28 sigma plus the trend's uncertainty)."""
+    fc, cl = env
+    spec, ds, y, floor, cap, extra, fut, exf = helpers.make_case(case)
+    csp = helpers.oracle_spec(spec)
+    r = fc.fit_aligned(spec, ds, y, floor=floor, cap=cap, extra=extra)
+    keys = np.array([1000 + 7 * n for n in range(len(y))], dtype=np.int64)
+    yhat, lo, hi = fc.predict_intervals(spec, r.theta, r.y_scale, r.grid, fut, floor=floor, cap=cap,
+                                        extra_future=exf, series_key=keys, uncertainty_samples=1000,
+                                        interval_width=0.8, seed=42)
+    assert np.array_equal(yhat, fc.predict(spec, r.theta, r.y_scale, r.grid, fut, floor=floor, cap=cap,
+                                           extra_future=exf))
+    for n in range(len(y)):
+        o = cl.fit(csp, ds, y[n], floor[n], cap[n], extra)
+        lo_o, hi_o = cl.predict_intervals(csp, o, fut, floor[n], cap[n], exf, n_samples=1000,
+                                          interval_width=0.8, seed=42, series_key=int(keys[n]))
+        assert np.array_equal(lo[n], lo_o) and np.array_equal(hi[n], hi_o), n
+        sig = np.exp(o['theta'][2]) * o['info'].y_scale
+        assert ((lo[n] < yhat[n]) & (yhat[n] < hi[n])).all()
+        assert 2 * 1.2 * sig < (hi[n] - lo[n]).mean() < 2 * 1.2816 * sig * 1.6
+    # batching does not matter: a sub-batch in another order gives the same intervals
+    sub = np.array([4, 1])
+    _, lo2, hi2 = fc.predict_intervals(spec, r.theta[sub], r.y_scale[sub], r.grid, fut, floor=floor[sub],
+                                       cap=cap[sub], extra_future=exf, series_key=keys[sub], seed=42)
+    assert np.array_equal(lo2, lo[sub]) and np.array_equal(hi2, hi[sub])
+    # another seed gives other draws; 200 samples and a 95 % interval work too
+    _, lo3, hi3 = fc.predict_intervals(spec, r.theta, r.y_scale, r.grid, fut, floor=floor, cap=cap,
+                                       extra_future=exf, series_key=keys, uncertainty_samples=200,
+                                       interval_width=0.95, seed=43)
+    assert not np.array_equal(lo3, lo) and ((hi3 - lo3).mean(axis=1) > (hi - lo).mean(axis=1)).all()

@@ -502,3 +502,30 @@ def test_real_fbprophet_goldens_if_present():
     print('oracle vs real fbprophet %s: per-series median forecast rel err: median %.3g p90 %.3g max %.3g'
           % (g['fbprophet_version'], np.median(errs), np.quantile(errs, 0.9), errs.max()))
     assert np.median(errs) <= 5e-3 and np.quantile(errs, 0.9) <= 5e-2
+
+
+@pytest.mark.parametrize('case', ['cfg2_linear_additive', 'ref_logistic_multiplicative'])
+def test_seeded_intervals_agree_with_the_literal_sampler(case):
+    """cn_predict_intervals (seeded, what the GPU kernels are compared with bit for bit) against the
+    literal restatement of Prophet.predict_uncertainty driven by numpy's generator at the same
+    parameters: two Monte-Carlo estimates of the same percentiles -- they must agree within sampling
+    error (a few per cent of the interval's width), row by row."""
+    m, dat, th0, (spec, ds, y, floor, cap, extra, fut, exf) = _literal(case)
+    csp = helpers.oracle_spec(spec)
+    o = cl.fit(csp, ds, y[0], floor[0], cap[0], extra)
+    df = pd.DataFrame({'ds': pd.to_datetime(ds), 'y': y[0]})
+    if spec.growth == 'logistic':
+        df['floor'], df['cap'] = floor[0], cap[0]
+    m2 = type(m)(growth=spec.growth, seasonality_mode=spec.seasonality_mode,
+                 yearly_seasonality=m.yearly_seasonality, weekly_seasonality=True, daily_seasonality=False)
+    m2.fit(df, optimizer=lambda dat_, th0_, **kw: (o['theta'].copy(), {'status': o['status']}))
+    fdf = pd.DataFrame({'ds': pd.to_datetime(fut)})
+    if spec.growth == 'logistic':
+        fdf['floor'], fdf['cap'] = floor[0], cap[0]
+    np.random.seed(3)
+    lo_l, hi_l = m2.predict_uncertainty(fdf, uncertainty_samples=3000)
+    lo_c, hi_c = cl.predict_intervals(csp, o, fut, floor[0], cap[0], exf, n_samples=3000, seed=5, series_key=1)
+    width = (hi_l - lo_l).mean()
+    assert np.max(np.abs(lo_c - lo_l)) < 0.12 * width and np.max(np.abs(hi_c - hi_l)) < 0.12 * width
+    assert abs((lo_c - lo_l).mean()) < 0.02 * width and abs((hi_c - hi_l).mean()) < 0.02 * width
+    assert abs((hi_c - lo_c).mean() / width - 1.0) < 0.03

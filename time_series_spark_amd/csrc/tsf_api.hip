@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "tsf_aux_kernels.h"
+#include "tsf_interval_kernels.h"
 #include "tsf_fit_kernels.h"
 #include "tsf_quad_kernels.h"
 #include "tsf_mfma_tabs.h"
@@ -727,6 +728,7 @@ extern "C" int tsf_predict_dev(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, in
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_spec, &hs, sizeof(hs), hipMemcpyHostToDevice, st));
     PredictArgs a;
+    memset(&a, 0, sizeof(a));
     a.sp = ctx->d_spec; a.N = N; a.H = H; a.theta_stride = tsf_theta_stride(spec);
     a.n_grids = n_grids; a.shared_future = shared_future; a.theta = theta; a.y_scale = y_scale;
     a.grid = grid; a.ds_future = ds_future; a.floor_ = floor_; a.cap = cap;
@@ -778,6 +780,124 @@ extern "C" int tsf_predict(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int32_
     HIP_TRY(ctx, hipDeviceSynchronize());
     HIP_TRY(ctx, hipMemcpy(yhat, d_yh.p, 8 * (size_t)N * H, hipMemcpyDeviceToHost));
     if (yhat_int) HIP_TRY(ctx, hipMemcpy(yhat_int, d_yi.p, 4 * (size_t)N * H, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---- uncertainty intervals ------------------------------------------------------------------------
+
+extern "C" int tsf_predict_intervals_dev(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int32_t H,
+                                         const double *theta, const double *y_scale,
+                                         const tsf_grid_info *grid, int32_t n_grids,
+                                         const int64_t *ds_future, int32_t shared_future,
+                                         const double *floor_, const double *cap,
+                                         const double *extra_future, const int64_t *series_key,
+                                         int32_t n_samples, double interval_width, uint64_t seed,
+                                         double *yhat, double *yhat_lower, double *yhat_upper, void *stream)
+{
+    if (!ctx) return -1;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (N <= 0 || H <= 0) return fail(ctx, "N and H must be > 0");
+    if (!theta || !y_scale || !grid || !ds_future || !yhat || !yhat_lower || !yhat_upper) return fail(ctx, "NULL input");
+    if (n_grids != 1 && n_grids != N) return fail(ctx, "n_grids must be 1 or N");
+    if (n_samples < 2 || n_samples > 4096) return fail(ctx, "n_samples must be in [2, 4096]");
+    if (!(interval_width > 0.0 && interval_width < 1.0)) return fail(ctx, "interval_width must be in (0, 1)");
+    DevSpec hs;
+    int mode = 0;
+    int rc = build_devspec(ctx, spec, &hs, &mode);
+    if (rc) return rc;
+    if (hs.n_extra > 0 && !extra_future) return fail(ctx, "extra_future is NULL");
+    if (hs.growth == TSF_GROWTH_LOGISTIC && !cap) return fail(ctx, "logistic growth needs cap");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_spec, &hs, sizeof(hs), hipMemcpyHostToDevice, st));
+    // per-row pieces: the point forecast kernel, with its optional outputs
+    DevBuf d_t, d_xa, d_opm, d_samp;
+    const size_t nh = (size_t)N * H;
+    HIP_TRY(ctx, d_t.alloc(8 * nh)); HIP_TRY(ctx, d_xa.alloc(8 * nh)); HIP_TRY(ctx, d_opm.alloc(8 * nh));
+    PredictArgs p;
+    memset(&p, 0, sizeof(p));
+    p.sp = ctx->d_spec; p.N = N; p.H = H; p.theta_stride = tsf_theta_stride(spec);
+    p.n_grids = n_grids; p.shared_future = shared_future; p.theta = theta; p.y_scale = y_scale;
+    p.grid = grid; p.ds_future = ds_future; p.floor_ = floor_; p.cap = cap;
+    p.extra_future = extra_future; p.yhat = yhat; p.yhat_int = nullptr;
+    p.t_out = d_t.as<double>(); p.xa_out = d_xa.as<double>(); p.opm_out = d_opm.as<double>();
+    hipLaunchKernelGGL(predict_kernel, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, st, p);
+    HIP_TRY(ctx, hipGetLastError());
+    // samples in chunks of series (at most 512 MB at a time)
+    int64_t chunk = (int64_t)(((size_t)512 << 20) / ((size_t)H * n_samples * 8));
+    if (chunk < 1) chunk = 1;
+    if (chunk > N) chunk = N;
+    HIP_TRY(ctx, d_samp.alloc(8 * (size_t)chunk * H * n_samples));
+    int NSP = 2;
+    while (NSP < n_samples) NSP <<= 1;
+    IntervalArgs a;
+    memset(&a, 0, sizeof(a));
+    a.sp = ctx->d_spec; a.H = H; a.theta_stride = tsf_theta_stride(spec); a.n_grids = n_grids; a.NS = n_samples;
+    a.theta = theta; a.y_scale = y_scale; a.grid = grid; a.floor_ = floor_; a.cap = cap;
+    a.t = d_t.as<double>(); a.xa = d_xa.as<double>(); a.opm = d_opm.as<double>();
+    a.series_key = series_key; a.seed = seed;
+    a.lo_frac = (1.0 - interval_width) / 2.0; a.hi_frac = (1.0 + interval_width) / 2.0;
+    a.samples = d_samp.as<double>(); a.lower = yhat_lower; a.upper = yhat_upper;
+    for (int64_t n0 = 0; n0 < N; n0 += chunk) {
+        a.n0 = n0; a.n_chunk = (N - n0 < chunk) ? N - n0 : chunk;
+        hipLaunchKernelGGL(interval_sample_kernel, dim3((unsigned)a.n_chunk, (unsigned)((n_samples + 255) / 256)),
+                           dim3(256), 0, st, a);
+        HIP_TRY(ctx, hipGetLastError());
+        hipLaunchKernelGGL(interval_percentile_kernel, dim3((unsigned)(a.n_chunk * H)), dim3(256),
+                           sizeof(double) * NSP, st, a, NSP);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    // the scratch buffers go back to the pool when this returns: wait for the kernels that use them
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    return 0;
+}
+
+extern "C" int tsf_predict_intervals(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int32_t H,
+                                     const double *theta, const double *y_scale,
+                                     const tsf_grid_info *grid, int32_t n_grids,
+                                     const int64_t *ds_future, int32_t shared_future,
+                                     const double *floor_, const double *cap,
+                                     const double *extra_future, const int64_t *series_key,
+                                     int32_t n_samples, double interval_width, uint64_t seed,
+                                     double *yhat, double *yhat_lower, double *yhat_upper)
+{
+    if (!ctx) return -1;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (N <= 0 || H <= 0) return fail(ctx, "N and H must be > 0");
+    if (!spec || !theta || !y_scale || !grid || !ds_future || !yhat || !yhat_lower || !yhat_upper) return fail(ctx, "NULL input");
+    if (n_grids != 1 && n_grids != N) return fail(ctx, "n_grids must be 1 or N");
+    const int stride = tsf_theta_stride(spec);
+    const size_t nfut = shared_future ? (size_t)H : (size_t)N * H;
+    DevBuf d_th, d_ys, d_grid, d_ds, d_fl, d_cap, d_ex, d_key, d_yh, d_lo, d_hi;
+    HIP_TRY(ctx, d_th.alloc(8 * (size_t)N * stride));
+    HIP_TRY(ctx, hipMemcpy(d_th.p, theta, 8 * (size_t)N * stride, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, d_ys.alloc(8 * N));
+    HIP_TRY(ctx, hipMemcpy(d_ys.p, y_scale, 8 * N, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, d_grid.alloc(sizeof(tsf_grid_info) * n_grids));
+    HIP_TRY(ctx, hipMemcpy(d_grid.p, grid, sizeof(tsf_grid_info) * n_grids, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, d_ds.alloc(8 * nfut));
+    HIP_TRY(ctx, hipMemcpy(d_ds.p, ds_future, 8 * nfut, hipMemcpyHostToDevice));
+    if (floor_) { HIP_TRY(ctx, d_fl.alloc(8 * N)); HIP_TRY(ctx, hipMemcpy(d_fl.p, floor_, 8 * N, hipMemcpyHostToDevice)); }
+    if (cap) { HIP_TRY(ctx, d_cap.alloc(8 * N)); HIP_TRY(ctx, hipMemcpy(d_cap.p, cap, 8 * N, hipMemcpyHostToDevice)); }
+    if (series_key) { HIP_TRY(ctx, d_key.alloc(8 * N)); HIP_TRY(ctx, hipMemcpy(d_key.p, series_key, 8 * N, hipMemcpyHostToDevice)); }
+    if (spec->n_extra > 0) {
+        if (!extra_future) return fail(ctx, "extra_future is NULL");
+        const size_t nb = 8 * (size_t)spec->n_extra * nfut;
+        HIP_TRY(ctx, d_ex.alloc(nb));
+        HIP_TRY(ctx, hipMemcpy(d_ex.p, extra_future, nb, hipMemcpyHostToDevice));
+    }
+    const size_t nh = 8 * (size_t)N * H;
+    HIP_TRY(ctx, d_yh.alloc(nh)); HIP_TRY(ctx, d_lo.alloc(nh)); HIP_TRY(ctx, d_hi.alloc(nh));
+    int rc = tsf_predict_intervals_dev(ctx, spec, N, H, d_th.as<double>(), d_ys.as<double>(),
+                                       d_grid.as<tsf_grid_info>(), n_grids, d_ds.as<int64_t>(), shared_future,
+                                       floor_ ? d_fl.as<double>() : nullptr, cap ? d_cap.as<double>() : nullptr,
+                                       spec->n_extra > 0 ? d_ex.as<double>() : nullptr,
+                                       series_key ? d_key.as<int64_t>() : nullptr, n_samples, interval_width, seed,
+                                       d_yh.as<double>(), d_lo.as<double>(), d_hi.as<double>(), nullptr);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    HIP_TRY(ctx, hipMemcpy(yhat, d_yh.p, nh, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(yhat_lower, d_lo.p, nh, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(yhat_upper, d_hi.p, nh, hipMemcpyDeviceToHost));
     return 0;
 }
 

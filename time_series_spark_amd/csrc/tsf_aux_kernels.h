@@ -230,6 +230,9 @@ struct PredictArgs {
     const double *floor_, *cap, *extra_future;
     double *yhat;
     int32_t *yhat_int;
+    // optional per-row pieces for the interval kernels (tsf_interval_kernels.h): scaled time,
+    // additive term * y_scale, 1 + multiplicative term
+    double *t_out, *xa_out, *opm_out;
 };
 
 __global__ void predict_kernel(PredictArgs a)
@@ -289,6 +292,7 @@ __global__ void predict_kernel(PredictArgs a)
     const double trend = gtr * ys + fl;
     const double yh = trend * (1.0 + xm) + xa * ys;
     a.yhat[gid] = yh;
+    if (a.t_out) { a.t_out[gid] = t; a.xa_out[gid] = xa * ys; a.opm_out[gid] = 1.0 + xm; }
     if (a.yhat_int) {
         // prophet_scorer.py:73 astype(int) truncates toward zero; :76-84 clamp to floor
         double tr = __builtin_trunc(yh);

@@ -420,6 +420,46 @@ def predict(spec, theta, y_scale, grid, ds_future_ns, floor=None, cap=None, extr
     return (yhat, yint) if want_int else yhat
 
 
+def predict_intervals(spec, theta, y_scale, grid, ds_future_ns, floor=None, cap=None, extra_future=None,
+                      series_key=None, uncertainty_samples=1000, interval_width=0.8, seed=0, ctx=None):
+    """(yhat, yhat_lower, yhat_upper), each [N][H]: fbprophet's predict_uncertainty -- which the
+    reference computes inside model.predict (prophet_scorer.py:70) and drops (:86) -- with a seeded
+    counter-based generator (include/tsf.h tsf_predict_intervals).  series_key [N] int64: what the
+    random streams are keyed by (e.g. a hash of (series_id, dim_id)), so that a series gets the same
+    interval whatever batch it is in; default: its index in this call."""
+    ctx = ctx or get_context()
+    L = _lib.load()
+    theta = np.ascontiguousarray(theta, dtype=np.float64)
+    N = theta.shape[0]
+    y_scale = np.ascontiguousarray(y_scale, dtype=np.float64)
+    grid = np.ascontiguousarray(grid, dtype=_lib.GRID_DTYPE)
+    ds_future_ns = np.ascontiguousarray(ds_future_ns, dtype=np.int64)
+    shared = ds_future_ns.ndim == 1
+    H = ds_future_ns.shape[-1]
+    if not shared and ds_future_ns.shape != (N, H):
+        raise ValueError('ds_future must be [H] or [N][H]')
+    cs = spec.to_c()
+    floor = _opt_f64(floor, N, 'floor')
+    cap = _opt_f64(cap, N, 'cap')
+    ex = None
+    if spec.extra:
+        ex = np.ascontiguousarray(extra_future, dtype=np.float64)
+        want = (len(spec.extra), H) if shared else (N, len(spec.extra), H)
+        if ex.shape != want:
+            raise ValueError('extra_future must be %r' % (want,))
+    key = None if series_key is None else np.ascontiguousarray(series_key, dtype=np.int64)
+    if key is not None and key.shape != (N,):
+        raise ValueError('series_key must be [N]')
+    yhat, lo, hi = np.zeros((N, H)), np.zeros((N, H)), np.zeros((N, H))
+    rc = L.tsf_predict_intervals(ctx.handle, ctypes.byref(cs), N, H, theta.ctypes.data, y_scale.ctypes.data,
+                                 grid.ctypes.data, len(grid), ds_future_ns.ctypes.data, int(shared),
+                                 _lib._ptr(floor), _lib._ptr(cap), _lib._ptr(ex), _lib._ptr(key),
+                                 int(uncertainty_samples), float(interval_width), int(seed),
+                                 yhat.ctypes.data, lo.ctypes.data, hi.ctypes.data)
+    ctx.check(rc)
+    return yhat, lo, hi
+
+
 # ---- diagnostics used by the parity tests -----------------------------------------------------
 
 def eval_aligned(spec, ds_ns, y, theta, floor=None, cap=None, extra=None, ctx=None):

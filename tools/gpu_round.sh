@@ -17,12 +17,12 @@ timeout 600 python bench.py --steps $STEPS --warmup 1 > $OUT/bench.json 2> $OUT/
 cat $OUT/bench.json | tee -a $OUT/summary.txt
 if [ -z "$SKIP_PROF" ]; then
 echo "== rocprofv3 kernel stats" | tee -a $OUT/summary.txt
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_stats -o stats --output-format csv -- python $OLDPWD/bench.py --steps $STEPS --warmup 1 --no-cpu-baseline > $OUT/prof_stats.log 2>&1 ); echo "rocprof rc=$?" | tee -a $OUT/summary.txt
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_stats -o stats --output-format csv -- python $OLDPWD/bench.py --steps $STEPS --warmup 1 --timed-only > $OUT/prof_stats.log 2>&1 ); echo "rocprof rc=$?" | tee -a $OUT/summary.txt
 find $OUT/prof_stats -name '*kernel_stats.csv' | head -1 | xargs -r head -12 | tee -a $OUT/summary.txt
 echo "== rocprofv3 pmc FETCH_SIZE" | tee -a $OUT/summary.txt
-( cd /tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/prof_fetch -o fetch --output-format csv -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/prof_fetch.log 2>&1 ); echo "pmc fetch rc=$?" | tee -a $OUT/summary.txt
-( cd /tmp && timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/prof_write -o write --output-format csv -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/prof_write.log 2>&1 ); echo "pmc write rc=$?" | tee -a $OUT/summary.txt
-( cd /tmp && timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD --kernel-trace -d $OUT/prof_sq -o sq --output-format csv -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/prof_sq.log 2>&1 ); echo "pmc sq rc=$?" | tee -a $OUT/summary.txt
+( cd /tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/prof_fetch -o fetch --output-format csv -- python $OLDPWD/bench.py --steps 2 --warmup 1 --timed-only > $OUT/prof_fetch.log 2>&1 ); echo "pmc fetch rc=$?" | tee -a $OUT/summary.txt
+( cd /tmp && timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/prof_write -o write --output-format csv -- python $OLDPWD/bench.py --steps 2 --warmup 1 --timed-only > $OUT/prof_write.log 2>&1 ); echo "pmc write rc=$?" | tee -a $OUT/summary.txt
+( cd /tmp && timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD --kernel-trace -d $OUT/prof_sq -o sq --output-format csv -- python $OLDPWD/bench.py --steps 2 --warmup 1 --timed-only > $OUT/prof_sq.log 2>&1 ); echo "pmc sq rc=$?" | tee -a $OUT/summary.txt
 python tools/pmc_summary.py $OUT | tee -a $OUT/summary.txt
 # keep only the small csv files
 find $OUT -name '*.db' -delete 2>/dev/null
