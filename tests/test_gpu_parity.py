@@ -708,6 +708,16 @@ def test_holidays_through_the_job_layer(env):
         assert np.array_equal(got['ds'].values.astype('datetime64[ns]').astype(np.int64), fut)
         assert np.array_equal(got['yhat'].values, np.maximum(np.trunc(yo), 0).astype(np.int32))
         assert colsf.values.any() or n == 2                     # the future window holds a holiday
+    # opt-in interval columns (the reference drops them): same point forecast, lower < yhat < upper
+    cfg_iv = dict(config, forecast=dict(config['forecast'], intervals=True, uncertainty_samples=300, seed=1))
+    fi = ps.forecast_panel(cfg_iv)(models)
+    assert list(fi.columns) == ['series_id', 'dim_id', 'ds', 'yhat', 'yhat_lower', 'yhat_upper']
+    assert np.array_equal(fi['yhat'].values, fcst['yhat'].values)
+    assert (fi['yhat_lower'] < fi['yhat'] + 1).all() and (fi['yhat_upper'] > fi['yhat']).all()
+    fi2 = ps.forecast_panel(cfg_iv)(models.iloc[::-1].reset_index(drop=True))   # other batch order, same streams
+    a = fi.sort_values(['dim_id', 'ds']).reset_index(drop=True)
+    b = fi2.sort_values(['dim_id', 'ds']).reset_index(drop=True)
+    assert np.array_equal(a['yhat_lower'].values, b['yhat_lower'].values)
 
 
 @pytest.mark.parametrize('case', ['cfg2_linear_additive', 'ref_logistic_multiplicative', 'cfg4_holidays'])

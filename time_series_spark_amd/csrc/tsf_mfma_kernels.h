@@ -847,7 +847,9 @@ __global__ __launch_bounds__(MT_NW * W) void fit_mfma_kernel(FitArgs a, MfmaTabs
                 }
             };
 #pragma unroll 1
-            for (int it = 0; it < n_tiles; it += 2) {
+            for (int it = 0; it < n_tiles; it += 4) {       // n_tiles = 8 NG
+                tile_body(p_yA, std::integral_constant<int, -1>());
+                tile_body(p_yB, std::integral_constant<int, -1>());
                 tile_body(p_yA, std::integral_constant<int, -1>());
                 tile_body(p_yB, std::integral_constant<int, -1>());
             }

@@ -69,18 +69,33 @@ def forecast_panel(config):
             yhat, yint = fc.predict(spec, theta, rec['y_scale'], grid, fut, floor=floor, cap=cap,
                                     extra_future=ex, want_int=True,      # :70-84
                                     devices=config.get('devices'))
+            iv = None
+            if (config.get('forecast') or {}).get('intervals'):
+                # not in the reference's output (it drops yhat_lower / yhat_upper, :86): opt-in extra
+                # columns; the random streams are keyed by (series_id, dim_id), so a series gets the
+                # same interval whatever frame it arrives in
+                fcfg = config['forecast']
+                key = (sids[idx].astype(np.int64) << 32) ^ (dids[idx].astype(np.int64) & 0xffffffff)
+                _, lo, hi = fc.predict_intervals(
+                    spec, theta, rec['y_scale'], grid, fut, floor=floor, cap=cap, extra_future=ex,
+                    series_key=key, uncertainty_samples=int(fcfg.get('uncertainty_samples', 1000)),
+                    interval_width=float(fcfg.get('interval_width', 0.8)), seed=int(fcfg.get('seed', 0)))
+                iv = (lo, hi)
             for j in np.flatnonzero((np.trunc(yhat) < floor[:, None]).any(axis=1)):
                 print(f"Negative forecast values found for series_id: {int(sids[idx[j]])}, "
                       f"dim_id: {int(dids[idx[j]])}")                    # :77-79
-            pieces.append((idx, fut, yint))
+            pieces.append((idx, fut, yint, iv))
         if not pieces:
             return _empty_forecasts()
         res = pd.DataFrame({
-            'series_id': np.concatenate([np.repeat(sids[i], periods) for i, _, _ in pieces]).astype('int32'),
-            'dim_id': np.concatenate([np.repeat(dids[i], periods) for i, _, _ in pieces]).astype('int32'),
-            'ds': np.concatenate([f.reshape(-1) for _, f, _ in pieces]).astype('datetime64[ns]'),
-            'yhat': np.concatenate([y.reshape(-1) for _, _, y in pieces]).astype('int32'),
+            'series_id': np.concatenate([np.repeat(sids[p[0]], periods) for p in pieces]).astype('int32'),
+            'dim_id': np.concatenate([np.repeat(dids[p[0]], periods) for p in pieces]).astype('int32'),
+            'ds': np.concatenate([p[1].reshape(-1) for p in pieces]).astype('datetime64[ns]'),
+            'yhat': np.concatenate([p[2].reshape(-1) for p in pieces]).astype('int32'),
         }, columns=FORECAST_COLUMNS)
+        if pieces[0][3] is not None:
+            res['yhat_lower'] = np.concatenate([p[3][0].reshape(-1) for p in pieces])
+            res['yhat_upper'] = np.concatenate([p[3][1].reshape(-1) for p in pieces])
         return res
 
     return forecast_panel_fn
