@@ -133,6 +133,44 @@ def test_matrix_core_kernel_is_bit_identical_to_the_one_wave_kernel(env, case):
     assert np.array_equal(r7m.theta, r7w.theta) and np.array_equal(r7m.n_eval, r7w.n_eval)
 
 
+def test_matrix_core_kernel_other_shapes(env):
+    """fit_mfma_kernel beyond the five standard cases: two row groups per chunk (T = 1 400: 22 rows per
+    chunk), 16 design columns, no changepoints (the dummy changepoint), 28 changepoints, a panel of
+    3 series, duplicate timestamps around changepoints -- against the one-wave kernel, bit for bit."""
+    fc, cl = env
+    from time_series_spark_amd import _lib, synth
+
+    def both(kw, ds, y, **fit_kw):
+        r_m = fc.fit_aligned(fc.ModelSpec(residual_kernel=_lib.RK_MFMA, eval_form=_lib.EVAL_RESIDUAL, **kw), ds, y, **fit_kw)
+        r_w = fc.fit_aligned(fc.ModelSpec(residual_kernel=_lib.RK_WAVE, eval_form=_lib.EVAL_RESIDUAL, **kw), ds, y, **fit_kw)
+        assert np.array_equal(r_m.status, r_w.status) and np.array_equal(r_m.n_eval, r_w.n_eval)
+        assert np.array_equal(r_m.theta, r_w.theta) and np.array_equal(r_m.fval, r_w.fval)
+        assert np.array_equal(r_m.grid['S'], r_w.grid['S'])
+        return r_m
+
+    ds, y = synth.make_panel(19, 1400, 'logistic', seed=31)
+    lg = dict(floor=np.zeros(19), cap=y.max(axis=1) * 1.1)
+    both(dict(growth='logistic', seasonality_mode='multiplicative',
+              seasonalities=[helpers.YEARLY, helpers.WEEKLY]), ds, y, **lg)                  # NG = 2, KP = 28
+    both(dict(growth='linear', seasonalities=[helpers.YEARLY5, helpers.WEEKLY]), ds, y)       # KP = 16, NG = 2
+    ds4, y4 = synth.make_panel(3, 400, 'logistic', seed=32)
+    lg4 = dict(floor=np.zeros(3), cap=y4.max(axis=1) * 1.2)
+    both(dict(growth='logistic', seasonalities=[helpers.YEARLY5, helpers.WEEKLY]), ds4, y4, **lg4)   # KP = 16, 3 series
+    r0 = both(dict(growth='logistic', seasonality_mode='multiplicative', seasonalities=[helpers.WEEKLY],
+                   n_changepoints=0), ds4, y4, **lg4)                                       # dummy changepoint
+    assert r0.grid['S'][0] == 0
+    both(dict(growth='linear', seasonalities=[helpers.WEEKLY], n_changepoints=28), ds4, y4)   # S = 28 (the kernel's limit)
+    both(dict(growth='linear', seasonality_mode='multiplicative', seasonalities=[helpers.WEEKLY], max_iter=25),
+         ds4[:100], y4[:, :100])                                                            # 2 rows per chunk
+    # duplicate timestamps (the reference's fixture has them): runs of equal ds across changepoint rows
+    dsd = np.sort(np.concatenate([ds4, ds4[40:44], ds4[200:203]]))
+    yd = np.concatenate([y4, y4[:, 40:44], y4[:, 200:203]], axis=1)
+    both(dict(growth='logistic', seasonality_mode='multiplicative', seasonalities=[helpers.WEEKLY]), dsd, yd, **lg4)
+    with pytest.raises(_lib.TsfError, match='residual_kernel MFMA'):
+        fc.fit_aligned(fc.ModelSpec(residual_kernel=_lib.RK_MFMA, growth='linear', n_changepoints=40,
+                                    seasonalities=[helpers.WEEKLY], eval_form=_lib.EVAL_RESIDUAL), ds4, y4)
+
+
 def test_truncated_trajectories_match(env):
     """Same iterate after 1, 3, 10, 40 L-BFGS iterations: checks line search, two-loop
     recursion and the history ring step by step rather than only at the end."""
