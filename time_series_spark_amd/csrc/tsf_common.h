@@ -68,6 +68,8 @@ struct SeriesTab {
 // cross-lane helpers (wave64)
 // ---------------------------------------------------------------------------------------
 
+__device__ __forceinline__ double readlane_f64(double v, int lane);
+
 // ---- DPP / permlane primitives (wave64, gfx950) -------------------------------------------
 // All of these only MOVE data; the arithmetic tree they implement is written next to each use.
 
@@ -102,17 +104,65 @@ __device__ __forceinline__ void swap32(double &a, double &b)
     b = __hiloint2double((int)r1[1], (int)r0[1]);
 }
 
-// xor-butterfly sum, offsets 1,2,4,8,16,32; every lane ends with the same bits.
-// (a + b is commutative, so exchanging through mirrors / swaps gives the butterfly's values.)
+// DPP move that only writes the rows of ROW_MASK / banks of BANK_MASK (4 lanes each); the other
+// lanes keep `old`
+template <int CTRL, int ROW_MASK, int BANK_MASK = 0xF>
+__device__ __forceinline__ double dpp_mov_masked(double old, double v)
+{
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, ROW_MASK, BANK_MASK, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, ROW_MASK, BANK_MASK, false);
+    return __hiloint2double(hi, lo);
+}
+constexpr int DPP_ROW_BCAST15 = 0x142;  // lane 15 of each row -> every lane of the next row
+constexpr int DPP_ROW_BCAST31 = 0x143;  // lane 31 -> every lane of rows 2 and 3
+constexpr int DPP_ROW_ROR8 = 0x128;     // lane i reads lane (i + 8) mod 16 of its row  (== xor 8)
+
+// xor-butterfly sum, offsets 1,2,4,8,16,32, returned as a wave-uniform scalar (v_readlane).
+// (a + b is commutative, so in the butterfly every lane of a 2^k block holds the same bits after
+// stage k; exchanging through mirrors gives the butterfly's values.)  After the four in-row stages
+// every lane of row r holds R_r.  Stage 16 is then needed in rows 1 and 3 only (R1 + R0, R3 + R2,
+// operands in the butterfly's own/partner order for those lanes) and stage 32 in row 3 only
+// ((R3 + R2) + (R1 + R0)): two row-broadcast moves instead of two full swaps, and lane 63 holds
+// exactly what the butterfly leaves in every lane.
 __device__ __forceinline__ double bfly_sum(double v)
 {
     v = v + dpp_mov<DPP_XOR1>(v);
     v = v + dpp_mov<DPP_XOR2>(v);
     v = v + dpp_mov<DPP_HALF_MIRROR>(v);
     v = v + dpp_mov<DPP_MIRROR>(v);
-    { double a = v, b = v; swap16(a, b); v = a + b; }
-    { double a = v, b = v; swap32(a, b); v = a + b; }
-    return v;
+    v = v + dpp_mov_masked<DPP_ROW_BCAST15, 0xA>(0.0, v);
+    v = v + dpp_mov_masked<DPP_ROW_BCAST31, 0xC>(0.0, v);
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+
+// Four butterfly sums at once, bit-identical to four bfly_sum calls.  Stage 1 and 2 are done
+// "transposed": a lane keeps two (then one) of the four quantities and sends the others to its
+// partner, which needs exactly those -- each partial sum of the butterfly is formed once instead
+// of in every lane of its block (own + partner order as in the lane that keeps it).  From stage 4
+// on the lanes = 0, 2, 1, 3 (mod 4) carry a, b, c, d.
+__device__ __forceinline__ void bfly_sum4(double a, double b, double c, double d,
+                                          double &sa, double &sb, double &sc, double &sd)
+{
+    const int lane = (int)threadIdx.x & (W - 1);
+    const bool odd = lane & 1, hi2 = lane & 2;
+    const double k0 = odd ? c : a, k1 = odd ? d : b;
+    const double s0 = odd ? a : c, s1 = odd ? b : d;
+    const double r0 = k0 + dpp_mov<DPP_XOR1>(s0);
+    const double r1 = k1 + dpp_mov<DPP_XOR1>(s1);
+    const double kk = hi2 ? r1 : r0, ss = hi2 ? r0 : r1;
+    double v = kk + dpp_mov<DPP_XOR2>(ss);
+    // xor 4: banks 0 and 2 (lanes 0-3, 8-11 of a row) read lane + 4, banks 1 and 3 lane - 4
+    {
+        double t = dpp_mov_masked<DPP_ROW_SHL(4), 0xF, 0x5>(0.0, v);
+        t = dpp_mov_masked<0x110 + 4, 0xF, 0xA>(t, v);          // row_shr:4
+        v = v + t;
+    }
+    v = v + dpp_mov<DPP_ROW_ROR8>(v);
+    { double x = v, y = v; swap16(x, y); v = x + y; }
+    { double x = v, y = v; swap32(x, y); v = x + y; }
+    sa = readlane_f64(v, 0); sc = readlane_f64(v, 1); sb = readlane_f64(v, 2); sd = readlane_f64(v, 3);
 }
 
 // within-row butterfly 1,2,4,8 (used after the 32/16 stages of the column network)
@@ -160,11 +210,16 @@ __device__ __forceinline__ double suffix_scan(double v)
 
 // dot product over the parameter axis: slot 0 product, slot 1 fma'd in, then butterfly
 template <int PPL>
-__device__ __forceinline__ double pdot(const double (&a)[PPL], const double (&b)[PPL])
+__device__ __forceinline__ double pdot_part(const double (&a)[PPL], const double (&b)[PPL])
 {
     double part = a[0] * b[0];
     if (PPL == 2) part = __builtin_fma(a[PPL - 1], b[PPL - 1], part);
-    return bfly_sum(part);
+    return part;
+}
+template <int PPL>
+__device__ __forceinline__ double pdot(const double (&a)[PPL], const double (&b)[PPL])
+{
+    return bfly_sum(pdot_part<PPL>(a, b));
 }
 
 // LDS hand-off between the lanes of ONE wave (multi-wave workgroups must not use s_barrier for

@@ -50,6 +50,37 @@ __device__ __forceinline__ double dm_exp(double x)
     return (p * dm_pow2i(n1)) * dm_pow2i(n2);
 }
 
+// dm_exp without branches (the three special cases are selects on the finished result): the
+// same value for every input, and a straight-line chain the scheduler can place under other work
+__device__ __forceinline__ double dm_exp_sel(double x)
+{
+    const double n = __builtin_rint(x * 1.4426950408889634);
+    double r = __builtin_fma(-n, 6.93147180369123816490e-01, x);
+    r = __builtin_fma(-n, 1.90821492927058770002e-10, r);
+    double p = 1.6059043836821613e-10;
+    p = __builtin_fma(p, r, 2.08767569878681e-09);
+    p = __builtin_fma(p, r, 2.505210838544172e-08);
+    p = __builtin_fma(p, r, 2.755731922398589e-07);
+    p = __builtin_fma(p, r, 2.7557319223985893e-06);
+    p = __builtin_fma(p, r, 2.48015873015873e-05);
+    p = __builtin_fma(p, r, 1.984126984126984e-04);
+    p = __builtin_fma(p, r, 1.388888888888889e-03);
+    p = __builtin_fma(p, r, 8.333333333333333e-03);
+    p = __builtin_fma(p, r, 4.1666666666666664e-02);
+    p = __builtin_fma(p, r, 1.6666666666666666e-01);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    const bool in_range = (x <= 709.782712893384) && (x >= -745.2);
+    const int ni = in_range ? (int)n : 0;
+    const int n1 = ni / 2, n2 = ni - n1;
+    double e = (p * dm_pow2i(n1)) * dm_pow2i(n2);
+    if (x > 709.782712893384) e = __builtin_huge_val();
+    if (x < -745.2) e = 0.0;
+    if (x != x) e = x;
+    return e;
+}
+
 __device__ __forceinline__ double dm_log(double x)
 {
     unsigned long long bits = (unsigned long long)__double_as_longlong(x);

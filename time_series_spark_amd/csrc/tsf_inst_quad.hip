@@ -41,15 +41,16 @@ static int launch_quad_rl(const QuadPlan &qp, const QuadArgs &qa, double *Mg, hi
 {
     constexpr int NW = (PPL == 2) ? TSF_QUAD_NW2 : TSF_QUAD_NW;
     constexpr bool MLDS = MMODE == QM_LDS;
+    constexpr bool HL = MLDS && (TSF_QUAD_HLDS != 0);
     if (MMODE != QM_RAGGED) {       // aligned panel: one M for the whole call
         hipLaunchKernelGGL((gram_build_kernel<KP, PPL>), dim3((unsigned)qp.P4), dim3(64), 0, st, qa, Mg);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
     }
-    const size_t lds = (MLDS ? sizeof(double) * (size_t)qp.P4 * PPL * W : 0) + sizeof(QuadLds<KP, PPL>) * NW +
+    const size_t lds = (MLDS ? sizeof(double) * (size_t)qp.P4 * PPL * W : 0) + (sizeof(QuadLds<KP, PPL>) + quad_hist_bytes<PPL>(HL)) * NW +
                        (RLDS ? sizeof(double) * (size_t)NW * qa.f.NTmax * W : 0);
     // per launch: the attribute is per device, and a process may drive several GPUs
-    hipFuncSetAttribute((const void *)fit_quad_kernel<KP, PPL, NW, MMODE, PQ, RLDS>,
+    hipFuncSetAttribute((const void *)fit_quad_kernel<KP, PPL, NW, MMODE, PQ, RLDS, HL>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 #ifdef TSF_QUAD_TIMING      // dev build: per-phase cycle counts (s_memtime) summed per series
     {
@@ -57,7 +58,7 @@ static int launch_quad_rl(const QuadPlan &qp, const QuadArgs &qa, double *Mg, hi
         const size_t nb = sizeof(long long) * 8 * (size_t)qa.f.N;
         hipMalloc((void **)&qb.dbg, nb);
         hipMemsetAsync(qb.dbg, 0, nb, st);
-        hipLaunchKernelGGL((fit_quad_kernel<KP, PPL, NW, MMODE, PQ, RLDS>), dim3((unsigned)qp.blocks), dim3(NW * 64), lds, st, qb);
+        hipLaunchKernelGGL((fit_quad_kernel<KP, PPL, NW, MMODE, PQ, RLDS, HL>), dim3((unsigned)qp.blocks), dim3(NW * 64), lds, st, qb);
         hipStreamSynchronize(st);
         std::vector<long long> h(8 * (size_t)qa.f.N);
         hipMemcpy(h.data(), qb.dbg, nb, hipMemcpyDeviceToHost);
@@ -70,7 +71,7 @@ static int launch_quad_rl(const QuadPlan &qp, const QuadArgs &qa, double *Mg, hi
         return (int)hipGetLastError();
     }
 #endif
-    hipLaunchKernelGGL((fit_quad_kernel<KP, PPL, NW, MMODE, PQ, RLDS>), dim3((unsigned)qp.blocks), dim3(NW * 64), lds, st, qa);
+    hipLaunchKernelGGL((fit_quad_kernel<KP, PPL, NW, MMODE, PQ, RLDS, HL>), dim3((unsigned)qp.blocks), dim3(NW * 64), lds, st, qa);
     return (int)hipGetLastError();
 }
 
@@ -79,7 +80,9 @@ template <int KP, int PPL, int MMODE, int PQ>
 static int launch_quad_mm(const QuadPlan &qp, const QuadArgs &qa, double *Mg, hipStream_t st)
 {
     constexpr int NW = (PPL == 2) ? TSF_QUAD_NW2 : TSF_QUAD_NW;
-    const size_t base = (MMODE == QM_LDS ? sizeof(double) * (size_t)qp.P4 * PPL * W : 0) + sizeof(QuadLds<KP, PPL>) * NW;
+    constexpr bool HL = (MMODE == QM_LDS) && (TSF_QUAD_HLDS != 0);
+    const size_t base = (MMODE == QM_LDS ? sizeof(double) * (size_t)qp.P4 * PPL * W : 0) +
+                        (sizeof(QuadLds<KP, PPL>) + quad_hist_bytes<PPL>(HL)) * NW;
     const size_t rbytes = sizeof(double) * (size_t)NW * qa.f.NTmax * W;
     if (base + rbytes <= 160 * 1024) return launch_quad_rl<KP, PPL, MMODE, PQ, true>(qp, qa, Mg, st);
     return launch_quad_rl<KP, PPL, MMODE, PQ, false>(qp, qa, Mg, st);

@@ -25,9 +25,21 @@
 
 namespace tsf {
 
+// Wave-uniform scalars (every lane holds the same bits) are passed through v_readfirstlane where
+// they are produced: the value is unchanged, but the compiler then KNOWS it is uniform -- the
+// branches of the line search become scalar branches (no exec masking, no per-lane copies of the
+// optimiser state at every join) and the state lives in SGPRs instead of one VGPR pair per scalar.
+#define UQ(x) uniform_f64(x)
+
 constexpr int QH = 5;                   // L-BFGS history of the register-resident path
 #ifndef TSF_QUAD_WPS
 #define TSF_QUAD_WPS 2
+#endif
+#ifndef TSF_QUAD_HLDS
+#define TSF_QUAD_HLDS 0                 // L-BFGS history of the shared-M kernel in LDS (fit_one_quad HLDS)
+#endif
+#ifndef TSF_QUAD_MB
+#define TSF_QUAD_MB 16                  // rows of M per batch of LDS reads in gram_eval_q
 #endif
 constexpr int QUAD_WAVES_PER_SIMD = TSF_QUAD_WPS;   // register budget: 512 / this per lane
 
@@ -191,49 +203,80 @@ __device__ __forceinline__ void lane_consts(const DevSpec *sp, const SeriesView 
     wave_sync();
 }
 
-// f and gradient from (SSE, Z^T r): cn_assemble_q
+// f and gradient from (SSE, Z^T r): cn_assemble_q, in two parts -- everything that does not depend
+// on (SSE, Z^T r) first, so that the exp / division / prior-sum chains can run underneath the
+// mat-vec of gram_eval_q; the floating-point operations and their order are those of cn_assemble_q
 template <int PPL>
-__device__ __forceinline__ bool assemble_q(const SeriesView &sv, const LaneConst<PPL> &lk,
-                                           const double (&th)[PPL], double sse,
-                                           const double (&ztr)[PPL], double &f_out,
-                                           double (&g)[PPL])
+struct AsmPre {
+    double inv_s2, s2, f0, tls, pa, pb;         // pa, pb: per-lane partials of the two prior sums
+    double lc[PPL], sc[PPL];
+};
+
+template <int PPL>
+__device__ __forceinline__ void assemble_pre(const SeriesView &sv, const LaneConst<PPL> &lk,
+                                             const double (&th)[PPL], AsmPre<PPL> &ap)
 {
     const int lane = lane_id();
     const double k = readlane_f64(th[0], 0), m = readlane_f64(th[0], 1), ls = readlane_f64(th[0], 2);
     const double C25 = 1.0 / 25.0;
-    const double sigma = dm_exp(ls);
+    const double sigma = dm_exp_sel(ls);
     const double s2 = sigma * sigma;
-    const double inv_s2 = 1.0 / s2;
+    ap.inv_s2 = 1.0 / s2;
+    ap.s2 = s2;
+    ap.tls = (double)sv.T * ls;
     double pa = 0.0, pb = 0.0;
-    double lc[PPL], sc[PPL];
 #pragma unroll
     for (int s = 0; s < PPL; ++s) {
-        lc[s] = lk.lc[s * W + lane]; sc[s] = lk.sc[s * W + lane];
-        if (sc[s] != 0.0) pa = pa + __builtin_fabs(th[s]);          // delta lanes
+        ap.lc[s] = lk.lc[s * W + lane]; ap.sc[s] = lk.sc[s * W + lane];
+        if (ap.sc[s] != 0.0) pa = pa + __builtin_fabs(th[s]);          // delta lanes
         const double qq = th[s] * lk.qc[s * W + lane];
         pb = __builtin_fma(qq, qq, pb);
     }
-    const double sabs = bfly_sum(pa), sb = bfly_sum(pb);
-    double f = ((0.5 * k) * k) * C25 + ((0.5 * m) * m) * C25;
+    ap.pa = pa; ap.pb = pb;
+    ap.f0 = ((0.5 * k) * k) * C25 + ((0.5 * m) * m) * C25;
+}
+
+// sabs, sb: the butterfly sums of ap.pa, ap.pb
+template <int PPL>
+__device__ __forceinline__ bool assemble_post(const SeriesView &sv, const LaneConst<PPL> &lk,
+                                              const AsmPre<PPL> &ap, double sabs, double sb,
+                                              const double (&th)[PPL], double sse,
+                                              const double (&ztr)[PPL], double &f_out,
+                                              double (&g)[PPL])
+{
+    const int lane = lane_id();
+    double f = ap.f0;
     f = f + sabs * lk.inv_tau;
-    f = f + 2.0 * s2;
+    f = f + 2.0 * ap.s2;
     f = f + 0.5 * sb;
-    f = f + (double)sv.T * ls;
-    f = f + (0.5 * sse) * inv_s2;
-    const double nis = -inv_s2;
-    const double g2 = ((double)sv.T - sse * inv_s2) + 4.0 * s2;
-    bool bad = !finite_f64(f);
+    f = f + ap.tls;
+    f = f + (0.5 * sse) * ap.inv_s2;
+    const double nis = -ap.inv_s2;
+    const double g2 = ((double)sv.T - sse * ap.inv_s2) + 4.0 * ap.s2;
+    bool bad = false;
 #pragma unroll
     for (int s = 0; s < PPL; ++s) {
         const double sgn = (double)((th[s] > 0.0) - (th[s] < 0.0));
-        double gv = __builtin_fma(th[s], lc[s], nis * ztr[s]) + sgn * sc[s];
+        double gv = __builtin_fma(th[s], ap.lc[s], nis * ztr[s]) + sgn * ap.sc[s];
         if (s == 0 && lane == 2) gv = g2;
         if (lane + s * W >= sv.P) gv = 0.0;
         g[s] = gv;
         bad = bad || !finite_f64(gv);
     }
     f_out = f;
-    return __any(bad);
+    return !finite_f64(f) || __any(bad);
+}
+
+template <int PPL>
+__device__ __forceinline__ bool assemble_q(const SeriesView &sv, const LaneConst<PPL> &lk,
+                                           const double (&th)[PPL], double sse,
+                                           const double (&ztr)[PPL], double &f_out,
+                                           double (&g)[PPL])
+{
+    AsmPre<PPL> ap;
+    assemble_pre<PPL>(sv, lk, th, ap);
+    const double sabs = bfly_sum(ap.pa), sb = bfly_sum(ap.pb);
+    return assemble_post<PPL>(sv, lk, ap, sabs, sb, th, sse, ztr, f_out, g);
 }
 
 // residual-form evaluation (cn_resid_q): r -> rb, then Z^T r, then assemble_q
@@ -302,14 +345,15 @@ __device__ __forceinline__ bool gram_eval_q(const SeriesView &sv, const LaneCons
 #pragma unroll
         for (int u = 0; u < 4; ++u) a[s][u] = 0.0;
     }
+    if (PQ > 0) { dl[lane] = D[0]; wave_sync(); }
+    AsmPre<PPL> ap;
+    assemble_pre<PPL>(sv, lk, th, ap);
     const double *mp = Ml + lane;
     if (PQ > 0) {
-        dl[lane] = D[0];
-        wave_sync();
         static_assert(PQ == 0 || PPL == 1, "compile-time M rows only for P <= 64");
         // batches of MB rows: MB LDS reads in flight, then their fmas; the scheduling barrier
         // keeps the compiler from hoisting every read of M to the top (register pressure)
-        constexpr int MB = 16;
+        constexpr int MB = TSF_QUAD_MB;
 #pragma unroll
         for (int q0 = 0; q0 < PQ; q0 += MB) {
             double m[MB];
@@ -365,14 +409,15 @@ __device__ __forceinline__ bool gram_eval_q(const SeriesView &sv, const LaneCons
     }
 #pragma unroll
     for (int s = 0; s < PPL; ++s) v[s] = (a[s][0] + a[s][1]) + (a[s][2] + a[s][3]);
-    const double q2 = pdot<PPL>(D, v);
-    const double cd = pdot<PPL>(cvec, D);
+    // D.(M D), c.D and the two prior sums: one four-fold butterfly (bit-identical to four)
+    double q2, cd, sabs, sb;
+    bfly_sum4(pdot_part<PPL>(D, v), pdot_part<PPL>(cvec, D), ap.pa, ap.pb, q2, cd, sabs, sb);
     const double sse = __builtin_fma(-2.0, cd, s0) + q2;
     q2_out = q2;
     double ztr[PPL];
 #pragma unroll
     for (int s = 0; s < PPL; ++s) ztr[s] = cvec[s] - v[s];
-    return assemble_q<PPL>(sv, lk, th, sse, ztr, f_out, g);
+    return assemble_post<PPL>(sv, lk, ap, sabs, sb, th, sse, ztr, f_out, g);
 }
 
 // lane-id based variants of make_view / store_theta for multi-wave workgroups
@@ -451,9 +496,12 @@ __global__ __launch_bounds__(64) void gram_build_kernel(QuadArgs qa, double *Mou
 #endif
 
 // One series, start to finish, by one wave.
-template <int KP, int PPL, int PQ, bool RAGGED, int MRS = W>
+// HLDS: the L-BFGS history lives in the wave's LDS ring `hist` ([2][QH][PPL][64]: s then y, slot of
+// age h = (h0 + h) mod QH) instead of 4 QH PPL registers per lane -- what lets a third wave per
+// SIMD fit the register file (tsf_inst_quad.hip); same values, same operation order.
+template <int KP, int PPL, int PQ, bool RAGGED, int MRS = W, bool HLDS = false>
 __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL> &wl, double *rb,
-                                          const double *Mp, double *Mown, int64_t n)
+                                          const double *Mp, double *Mown, int64_t n, double *hist = nullptr)
 {
     const FitArgs &a = qa.f;
     const DevSpec *sp = a.sp;
@@ -508,14 +556,18 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
     }
 
     double s0 = 0.0, q2 = 0.0;
-    // L-BFGS history in registers, age order (index 0 = oldest)
-    double Sh[QH][PPL], Yh[QH][PPL], rh[QH];
+    // L-BFGS history in registers (or in LDS: HLDS), age order (index 0 = oldest)
+    constexpr int QHR = HLDS ? 1 : QH;
+    double ShR[QHR][PPL], YhR[QHR][PPL], rh[QH];
 #pragma unroll
-    for (int h = 0; h < QH; ++h) {
-        rh[h] = 0.0;
+    for (int h = 0; h < QH; ++h) rh[h] = 0.0;
 #pragma unroll
-        for (int s = 0; s < PPL; ++s) { Sh[h][s] = 0.0; Yh[h][s] = 0.0; }
+    for (int h = 0; h < QHR; ++h) {
+#pragma unroll
+        for (int s = 0; s < PPL; ++s) { ShR[h][s] = 0.0; YhR[h][s] = 0.0; }
     }
+    int h0 = 0;                          // HLDS: ring slot of the oldest pair
+    double *const histS = hist, *const histY = hist + QH * PPL * W;
 
     double fk = 0.0, fk1 = 0.0, alpha = a.opt.init_alpha, gammak = 1.0;
     int itNum = 0, ret = 0, resetB = 0, hist_len = 0, since_rc = 0;
@@ -539,9 +591,9 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
             double sk[PPL], yk[PPL];
 #pragma unroll
             for (int s = 0; s < PPL; ++s) { sk[s] = xk[s] - xk1[s]; yk[s] = gk[s] - gk1[s]; }
-            const double gg = pdot<PPL>(gk, gk), ss = pdot<PPL>(sk, sk);
-            const double skyk = pdot<PPL>(yk, sk);
-            const double ykyk = pdot<PPL>(yk, yk);
+            double gg, ss, skyk, ykyk;
+            bfly_sum4(pdot_part<PPL>(gk, gk), pdot_part<PPL>(sk, sk), pdot_part<PPL>(yk, sk), pdot_part<PPL>(yk, yk),
+                      gg, ss, skyk, ykyk);
             // the two square roots and the three quotients are independent: one lane each
             const double nrm = __builtin_sqrt(lanes4(gg, ss, 0.0, 0.0));
             const double gradNorm = readlane_f64(nrm, 0), stepNorm = readlane_f64(nrm, 1);
@@ -551,20 +603,51 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
                 hist_len = 0;
 #pragma unroll
                 for (int s = 0; s < PPL; ++s) pk1[s] = pk1[s] / B0fact;
-                alpha = alpha * B0fact;
+                alpha = UQ(alpha * B0fact);
                 pk1_scaled = true;
             } else {
                 pk1_scaled = false;
             }
             gammak = readlane_f64(qv, 1);
             const double rho_new = readlane_f64(qv, 2);
+            double Sh[QH][PPL], Yh[QH][PPL];        // age order; HLDS: this iteration's copy of the ring
+            if (HLDS) {
+                if (resetB) h0 = 0;
+                int slot;
+                if (hist_len < QH) {
+                    slot = h0 + hist_len; if (slot >= QH) slot -= QH;
+#pragma unroll
+                    for (int h = 0; h < QH; ++h) if (h == hist_len) rh[h] = rho_new;
+                    hist_len++;
+                } else {
+                    slot = h0; h0 = (h0 + 1 == QH) ? 0 : h0 + 1;
+#pragma unroll
+                    for (int h = 0; h + 1 < QH; ++h) rh[h] = rh[h + 1];
+                    rh[QH - 1] = rho_new;
+                }
+#pragma unroll
+                for (int s = 0; s < PPL; ++s) {
+                    histS[(slot * PPL + s) * W + lane] = sk[s];
+                    histY[(slot * PPL + s) * W + lane] = yk[s];
+                }
+                wave_sync();
+#pragma unroll
+                for (int h = 0; h < QH; ++h) {
+                    int sl = h0 + h; if (sl >= QH) sl -= QH;
+#pragma unroll
+                    for (int s = 0; s < PPL; ++s) {
+                        Sh[h][s] = histS[(sl * PPL + s) * W + lane];
+                        Yh[h][s] = histY[(sl * PPL + s) * W + lane];
+                    }
+                }
+            } else {
             if (hist_len < QH) {
 #pragma unroll
                 for (int h = 0; h < QH; ++h) {
                     if (h == hist_len) {
                         rh[h] = rho_new;
 #pragma unroll
-                        for (int s = 0; s < PPL; ++s) { Sh[h][s] = sk[s]; Yh[h][s] = yk[s]; }
+                        for (int s = 0; s < PPL; ++s) { ShR[h][s] = sk[s]; YhR[h][s] = yk[s]; }
                     }
                 }
                 hist_len++;
@@ -573,11 +656,17 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
                 for (int h = 0; h + 1 < QH; ++h) {
                     rh[h] = rh[h + 1];
 #pragma unroll
-                    for (int s = 0; s < PPL; ++s) { Sh[h][s] = Sh[h + 1][s]; Yh[h][s] = Yh[h + 1][s]; }
+                    for (int s = 0; s < PPL; ++s) { ShR[h][s] = ShR[h + 1][s]; YhR[h][s] = YhR[h + 1][s]; }
                 }
                 rh[QH - 1] = rho_new;
 #pragma unroll
-                for (int s = 0; s < PPL; ++s) { Sh[QH - 1][s] = sk[s]; Yh[QH - 1][s] = yk[s]; }
+                for (int s = 0; s < PPL; ++s) { ShR[QH - 1][s] = sk[s]; YhR[QH - 1][s] = yk[s]; }
+            }
+#pragma unroll
+            for (int h = 0; h < QH; ++h) {
+#pragma unroll
+                for (int s = 0; s < PPL; ++s) { Sh[h][s] = ShR[HLDS ? 0 : h][s]; Yh[h][s] = YhR[HLDS ? 0 : h][s]; }
+            }
             }
             double alphas[QH];
 #pragma unroll
@@ -636,12 +725,12 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
                 // has been rescaled since
                 const double gp1 = pk1_scaled ? pdot<PPL>(gk1, pk1) : dfp;
                 const double ci = cubic_interp6(gp1, alpha, fk - fk1, gp, minAlpha, 1.0);
-                alpha = __builtin_fmin(1.0, 1.01 * ci);
+                alpha = UQ(__builtin_fmin(1.0, 1.01 * ci));
             } else {
                 alpha = a.opt.init_alpha;
             }
             dfp = gp;
-            c1dfp = c1 * dfp; c2dfp = c2 * dfp;
+            c1dfp = UQ(c1 * dfp); c2dfp = UQ(c2 * dfp);
             alpha0 = minAlpha; prevF = fk; prevDFp = dfp;
             nits = 0; lsRestarts = 0; zoom = 0; zit = 0;
             stage = ST_LS_PRE;
@@ -655,7 +744,7 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
                 if (__builtin_fabs(alo - ahi) < min_range) {
                     ls_fail = true;
                 } else if (zit % 5 == 0) {
-                    alpha = 0.5 * (alo + ahi);
+                    alpha = UQ(0.5 * (alo + ahi));
                 } else {
                     const double d1 = aloDFp + ahiDFp - 3.0 * (aloF - ahiF) / (alo - ahi);
                     double d2 = __builtin_sqrt(d1 * d1 - aloDFp * ahiDFp);
@@ -665,6 +754,7 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
                                  w = __builtin_fabs(alo - ahi);
                     if (!finite_f64(alpha) || alpha < lo + 0.01 * w || alpha > hi - 0.01 * w)
                         alpha = 0.5 * (alo + ahi);
+                    alpha = UQ(alpha);
                 }
             }
             if (!ls_fail) stage = ST_LS_EVAL;
@@ -689,11 +779,11 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
                         wl.cvec[p] = ztr_e[s];
                         gk[s] = ge[s];
                     }
-                    s0 = sse_e; since_rc = 0; fk = fe;
+                    s0 = sse_e; since_rc = 0; fk = UQ(fe);
                     wave_sync();
                 }
                 if (stage == ST_INIT) {
-                    if (bad) { ret = TSF_ST_INIT_NONFINITE; fk = fe; break; }
+                    if (bad) { ret = TSF_ST_INIT_NONFINITE; fk = UQ(fe); break; }
 #pragma unroll
                     for (int s = 0; s < PPL; ++s) { pk[s] = -gk[s]; gk1[s] = 0.0; xk1[s] = 0.0; }
                     stage = ST_START_ITER;
@@ -710,13 +800,13 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
             QT_LAP(4);
 #pragma unroll
             for (int s = 0; s < PPL; ++s) gk1[s] = ge[s];
-            const double f1 = fe;
+            const double f1 = UQ(fe);
             if (bad) {
                 if (!zoom) {
                     if (lsRestarts >= maxLSRestarts) ls_fail = true;
-                    else { alpha = 0.5 * (alpha0 + alpha); lsRestarts++; }
+                    else { alpha = UQ(0.5 * (alpha0 + alpha)); lsRestarts++; }
                 } else {
-                    alpha = 0.5 * (alpha + __builtin_fmin(alo, ahi));
+                    alpha = UQ(0.5 * (alpha + __builtin_fmin(alo, ahi)));
                     if (__builtin_fabs(__builtin_fmin(alo, ahi) - alpha) < min_range) ls_fail = true;
                 }
                 if (!ls_fail) continue;            // re-evaluate at the shortened step
@@ -736,7 +826,7 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
                         ahi = alpha0; ahiF = prevF; ahiDFp = prevDFp;
                     } else {
                         alpha0 = alpha; prevF = f1; prevDFp = newDFp;
-                        alpha *= 10.0;
+                        alpha = UQ(alpha * 10.0);
                         nits++;
                     }
                 } else {
@@ -780,7 +870,10 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
 // ragged fit ran at the L2's pace, 5x the aligned time)
 enum { QM_LDS = 0, QM_GLOBAL = 1, QM_RAGGED = 2, QM_RAGGED_LDS = 3 };
 
-template <int KP, int PPL, int NW, int MMODE, int PQ, bool RLDS>
+template <int PPL>
+constexpr size_t quad_hist_bytes(bool hlds) { return hlds ? sizeof(double) * 2 * QH * PPL * W : 0; }
+
+template <int KP, int PPL, int NW, int MMODE, int PQ, bool RLDS, bool HLDS = false>
 __global__ __launch_bounds__(NW * 64, QUAD_WAVES_PER_SIMD) void fit_quad_kernel(QuadArgs qa)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -788,6 +881,8 @@ __global__ __launch_bounds__(NW * 64, QUAD_WAVES_PER_SIMD) void fit_quad_kernel(
     const int lane = lane_id(), wid = (int)threadIdx.x >> 6;
     const int P4 = qa.P4;
     constexpr bool MLDS = MMODE == QM_LDS;
+    // LDS: [M (aligned, P <= 64)] [QuadLds x NW] [history ring x NW (HLDS)] [r staging x NW (RLDS)]
+    //      [per-wave compact M (QM_RAGGED_LDS)]
     double *Ml = reinterpret_cast<double *>(smem);
     const size_t m_bytes = MLDS ? sizeof(double) * (size_t)P4 * PPL * W : 0;
     QuadLds<KP, PPL> &wl = *reinterpret_cast<QuadLds<KP, PPL> *>(smem + m_bytes + sizeof(QuadLds<KP, PPL>) * wid);
@@ -796,9 +891,13 @@ __global__ __launch_bounds__(NW * 64, QUAD_WAVES_PER_SIMD) void fit_quad_kernel(
         __syncthreads();
     }
     const double *Mp = MLDS ? Ml : qa.Mg;
+    constexpr size_t HB = quad_hist_bytes<PPL>(HLDS);
+    const size_t off_hist = m_bytes + sizeof(QuadLds<KP, PPL>) * NW;
+    double *hist = HLDS ? reinterpret_cast<double *>(smem + off_hist + HB * wid) : nullptr;
+    const size_t off_rb = off_hist + HB * NW;
     const size_t rb_bytes = RLDS ? sizeof(double) * (size_t)NW * a.NTmax * W : 0;
     double *Mown = (MMODE == QM_RAGGED) ? qa.Mslot + ((size_t)blockIdx.x * NW + wid) * (size_t)P4 * PPL * W
-                 : (MMODE == QM_RAGGED_LDS) ? reinterpret_cast<double *>(smem + m_bytes + sizeof(QuadLds<KP, PPL>) * NW + rb_bytes) +
+                 : (MMODE == QM_RAGGED_LDS) ? reinterpret_cast<double *>(smem + off_rb + rb_bytes) +
                                                (size_t)wid * (PQ * PQ + W)
                                             : nullptr;
     constexpr int MRS = (MMODE == QM_RAGGED_LDS) ? PQ : W;
@@ -808,7 +907,7 @@ __global__ __launch_bounds__(NW * 64, QUAD_WAVES_PER_SIMD) void fit_quad_kernel(
     }
     // residual staging r[q][lane] of the running residual pass: in LDS when the launch found room
     // for NW x NTmax x 64 doubles, else in the global scratch (long series)
-    double *rb = RLDS ? reinterpret_cast<double *>(smem + m_bytes + sizeof(QuadLds<KP, PPL>) * NW) + (size_t)wid * a.NTmax * W
+    double *rb = RLDS ? reinterpret_cast<double *>(smem + off_rb) + (size_t)wid * a.NTmax * W
                       : qa.rbuf + ((size_t)blockIdx.x * NW + wid) * a.NTmax * W;
     for (int i = lane; i < PPL * W + W; i += W) wl.th[i] = 0.0;
     wave_sync();
@@ -822,7 +921,7 @@ __global__ __launch_bounds__(NW * 64, QUAD_WAVES_PER_SIMD) void fit_quad_kernel(
         n32 = __builtin_amdgcn_readfirstlane(n32);
         const int64_t n = n32;
         if (n >= a.N) break;
-        fit_one_quad<KP, PPL, PQ, MMODE == QM_RAGGED || MMODE == QM_RAGGED_LDS, MRS>(qa, wl, rb, Mp, Mown, n);
+        fit_one_quad<KP, PPL, PQ, MMODE == QM_RAGGED || MMODE == QM_RAGGED_LDS, MRS, HLDS>(qa, wl, rb, Mp, Mown, n, hist);
     }
 }
 
