@@ -32,11 +32,15 @@ def _newest_header():
     return max(os.path.getmtime(h) for h in hs)
 
 
+# per-file flags (the reason is at the top of the file named)
+EXTRA = {'tsf_inst_quad3.hip': ['-mllvm', '-disable-machine-licm']}
+
+
 def _compile(src, obj, hdr_mtime, force):
     if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(src)
             and os.path.getmtime(obj) >= hdr_mtime):
         return obj, False
-    cmd = [_hipcc()] + FLAGS + ['-c', src, '-o', obj]
+    cmd = [_hipcc()] + FLAGS + EXTRA.get(os.path.basename(src), []) + ['-c', src, '-o', obj]
     subprocess.check_call(cmd)
     return obj, True
 

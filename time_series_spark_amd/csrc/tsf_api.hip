@@ -253,13 +253,18 @@ static int quad_plan(tsf_ctx *ctx, const DevSpec &hs, int64_t N, QuadPlan *qp)
     // rows of M the kernel walks: compile-time 40 / 56 / 64 for the one-slot kernels (zero rows
     // beyond P are bit-neutral), P rounded up to 4 for the two-slot kernel
     qp->P4 = (qp->PPL == 2) ? ((P + 3) & ~3) : (P <= 40 ? 40 : (P <= 56 ? 56 : 64));
-    qp->NW = quad_waves_per_block(qp->PPL);
+    qp->NW = quad_waves_per_block(qp->PPL);       // the most any variant launches: sizes the slots
+    qp->n_cu = ctx->n_cu;
     int64_t blocks = ctx->n_cu;                     // persistent: LDS admits one workgroup per CU
     const int64_t need = (N + qp->NW - 1) / qp->NW;
     if (blocks > need) blocks = need;
     if (blocks < 1) blocks = 1;
     qp->blocks = (int)blocks;
-    qp->slots = (int)blocks * qp->NW;
+    // resident waves over all kernel variants (their workgroups hold 4, 8 or 12 waves; each launcher
+    // sizes its own grid): at most n_cu x NW, and no more than one per series rounded up to a workgroup
+    int64_t slots = (int64_t)ctx->n_cu * qp->NW;
+    if (slots > N + qp->NW) slots = N + qp->NW;
+    qp->slots = (int)slots;
     if (qp->slots < qp->P4) qp->slots = qp->P4;
     return 0;
 }

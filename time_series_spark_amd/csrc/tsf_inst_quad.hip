@@ -1,22 +1,11 @@
 // tsf_inst_quad.hip -- instantiates the quadratic-form fit path (tsf_quad_kernels.h).
-#include "tsf_quad_kernels.h"
+#include "tsf_quad_launch.h"
 #include "tsf_newton_quad.h"
-#include "tsf_launch.h"
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <vector>
-
-#ifndef TSF_QUAD_NW
-#define TSF_QUAD_NW 8
-#endif
-#ifndef TSF_QUAD_NW2
-#define TSF_QUAD_NW2 4      // two-slot kernel (P > 64): twice the per-wave LDS
-#endif
 
 namespace tsf {
 
-int quad_waves_per_block(int PPL) { return PPL == 2 ? TSF_QUAD_NW2 : TSF_QUAD_NW; }
+// the most waves per workgroup any variant for this PPL launches (workspace slots: tsf_api.hip quad_plan)
+int quad_waves_per_block(int PPL) { return PPL == 2 ? TSF_QUAD_NW2 : (TSF_QUAD_NW3 > TSF_QUAD_NW ? TSF_QUAD_NW3 : TSF_QUAD_NW); }
 
 // ragged panel, Z^T Z of every resident wave in LDS: NWR waves per workgroup (tsf_quad_kernels.h
 // QM_RAGGED_LDS); -2 when it does not fit (the caller falls back to M in global memory)
@@ -25,67 +14,15 @@ static int launch_quad_ragged_lds(const QuadPlan &qp, const QuadArgs &qa, hipStr
 {
     constexpr int NWR = 4;
     if (qp.P4 != PQ) return -2;
-    const size_t lds = (sizeof(QuadLds<KP, 1>) + sizeof(double) * ((size_t)qa.f.NTmax * W + (size_t)(PQ * PQ + W))) * NWR;
+    const size_t lds = (quad_lanec_bytes<1>() + sizeof(QuadLds<KP, 1>) + sizeof(double) * ((size_t)qa.f.NTmax * W + (size_t)(PQ * PQ + W))) * NWR;
     if (lds > 160 * 1024) return -2;
     hipFuncSetAttribute((const void *)fit_quad_kernel<KP, 1, NWR, QM_RAGGED_LDS, PQ, true>,
                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    int64_t blocks = qp.blocks;     // one workgroup per CU
+    int64_t blocks = qp.n_cu;       // one workgroup per CU
     const int64_t need = (qa.f.N + NWR - 1) / NWR;
     if (blocks > need) blocks = need;
     hipLaunchKernelGGL((fit_quad_kernel<KP, 1, NWR, QM_RAGGED_LDS, PQ, true>), dim3((unsigned)blocks), dim3(NWR * 64), lds, st, qa);
     return (int)hipGetLastError();
-}
-
-template <int KP, int PPL, int MMODE, int PQ, bool RLDS>
-static int launch_quad_rl(const QuadPlan &qp, const QuadArgs &qa, double *Mg, hipStream_t st)
-{
-    constexpr int NW = (PPL == 2) ? TSF_QUAD_NW2 : TSF_QUAD_NW;
-    constexpr bool MLDS = MMODE == QM_LDS;
-    constexpr bool HL = MLDS && (TSF_QUAD_HLDS != 0);
-    if (MMODE != QM_RAGGED) {       // aligned panel: one M for the whole call
-        hipLaunchKernelGGL((gram_build_kernel<KP, PPL>), dim3((unsigned)qp.P4), dim3(64), 0, st, qa, Mg);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return (int)e;
-    }
-    const size_t lds = (MLDS ? sizeof(double) * (size_t)qp.P4 * PPL * W : 0) + (sizeof(QuadLds<KP, PPL>) + quad_hist_bytes<PPL>(HL)) * NW +
-                       (RLDS ? sizeof(double) * (size_t)NW * qa.f.NTmax * W : 0);
-    // per launch: the attribute is per device, and a process may drive several GPUs
-    hipFuncSetAttribute((const void *)fit_quad_kernel<KP, PPL, NW, MMODE, PQ, RLDS, HL>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-#ifdef TSF_QUAD_TIMING      // dev build: per-phase cycle counts (s_memtime) summed per series
-    {
-        QuadArgs qb = qa;
-        const size_t nb = sizeof(long long) * 8 * (size_t)qa.f.N;
-        hipMalloc((void **)&qb.dbg, nb);
-        hipMemsetAsync(qb.dbg, 0, nb, st);
-        hipLaunchKernelGGL((fit_quad_kernel<KP, PPL, NW, MMODE, PQ, RLDS, HL>), dim3((unsigned)qp.blocks), dim3(NW * 64), lds, st, qb);
-        hipStreamSynchronize(st);
-        std::vector<long long> h(8 * (size_t)qa.f.N);
-        hipMemcpy(h.data(), qb.dbg, nb, hipMemcpyDeviceToHost);
-        double sum[8] = {0};
-        long long mx = 0;
-        for (int64_t i = 0; i < qa.f.N; ++i) { for (int k = 0; k < 8; ++k) sum[k] += (double)h[i * 8 + k]; if (h[i * 8 + 7] > mx) mx = h[i * 8 + 7]; }
-        fprintf(stderr, "[quad-timing] N %lld mean cycles/series: misc %.0f post %.0f ls %.0f resid %.0f gram %.0f | total %.0f max %lld\n",
-                (long long)qa.f.N, sum[0] / qa.f.N, sum[1] / qa.f.N, sum[2] / qa.f.N, sum[3] / qa.f.N, sum[4] / qa.f.N, sum[7] / qa.f.N, mx);
-        hipFree(qb.dbg);
-        return (int)hipGetLastError();
-    }
-#endif
-    hipLaunchKernelGGL((fit_quad_kernel<KP, PPL, NW, MMODE, PQ, RLDS, HL>), dim3((unsigned)qp.blocks), dim3(NW * 64), lds, st, qa);
-    return (int)hipGetLastError();
-}
-
-// residual staging in LDS when M + per-wave state + NW x NTmax x 64 doubles fit in 160 KB
-template <int KP, int PPL, int MMODE, int PQ>
-static int launch_quad_mm(const QuadPlan &qp, const QuadArgs &qa, double *Mg, hipStream_t st)
-{
-    constexpr int NW = (PPL == 2) ? TSF_QUAD_NW2 : TSF_QUAD_NW;
-    constexpr bool HL = (MMODE == QM_LDS) && (TSF_QUAD_HLDS != 0);
-    const size_t base = (MMODE == QM_LDS ? sizeof(double) * (size_t)qp.P4 * PPL * W : 0) +
-                        (sizeof(QuadLds<KP, PPL>) + quad_hist_bytes<PPL>(HL)) * NW;
-    const size_t rbytes = sizeof(double) * (size_t)NW * qa.f.NTmax * W;
-    if (base + rbytes <= 160 * 1024) return launch_quad_rl<KP, PPL, MMODE, PQ, true>(qp, qa, Mg, st);
-    return launch_quad_rl<KP, PPL, MMODE, PQ, false>(qp, qa, Mg, st);
 }
 
 // aligned panels share one M (in LDS when it fits: the one-slot kernels); ragged panels build one
@@ -100,7 +37,8 @@ static int launch_quad_one(const QuadPlan &qp, const QuadArgs &qa, double *Mg, h
         }
         return launch_quad_mm<KP, PPL, QM_RAGGED, PQ>(qp, qa, Mg, st);
     }
-    return launch_quad_mm<KP, PPL, (PPL == 1 ? QM_LDS : QM_GLOBAL), PQ>(qp, qa, Mg, st);
+    if constexpr (PPL == 1) return launch_quad_aligned1(KP, qp, qa, Mg, st);   // tsf_inst_quad3.hip
+    else return launch_quad_mm<KP, PPL, QM_GLOBAL, PQ>(qp, qa, Mg, st);
 }
 
 int launch_quad(int KP, const QuadPlan &qp, const QuadArgs &qa, double *Mg, hipStream_t st)

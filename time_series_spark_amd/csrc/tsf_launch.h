@@ -7,10 +7,11 @@ namespace tsf {
 struct FitArgs;
 struct QuadArgs;
 struct MfmaTabs;
-struct QuadPlan { int P4, PPL, NW, blocks, slots; };
+struct QuadPlan { int P4, PPL, NW, blocks, slots, n_cu; };
 int quad_waves_per_block(int PPL);
 // gram_build_kernel + fit_quad_kernel (tsf_inst_quad.hip)
 int launch_quad(int KP, const QuadPlan &qp, const QuadArgs &qa, double *Mg, hipStream_t st);
+int launch_quad_aligned1(int KP, const QuadPlan &qp, const QuadArgs &qa, double *Mg, hipStream_t st);
 // gram_build_kernel + newton_quad_kernel (Stan's Newton, quadratic-form evaluations; tsf_inst_quad.hip)
 int launch_newton_quad(int KP, const QuadPlan &qp, const QuadArgs &qa, double *Mg, int PM, int n_cu, hipStream_t st);
 int launch_g0m0(int KP, const FitArgs &a, int eval_only, hipStream_t st);

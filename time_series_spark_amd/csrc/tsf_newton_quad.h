@@ -18,6 +18,7 @@ template <int KP>
 struct NewtonQuadLds {
     QuadLds<KP, 1> q;
     QlScratch ql;
+    double lanec[3 * W];            // cn_assemble_q lane constants (lane_consts)
 };
 
 template <int KP>
@@ -56,7 +57,7 @@ __device__ __forceinline__ void newton_one_quad(const QuadArgs &qa, NewtonQuadLd
         return;
     }
     LaneConst<PPL> lk;
-    lane_consts<KP, PPL>(sp, sv, wl, lk);
+    lane_consts<PPL>(sp, sv, lds.lanec, lk);
     if (RAGGED) {
         // this series has its own grid, hence its own Z^T Z: built column by column as fit_one_quad does
 #pragma unroll 1

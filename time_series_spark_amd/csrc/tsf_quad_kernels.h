@@ -32,16 +32,9 @@ namespace tsf {
 #define UQ(x) uniform_f64(x)
 
 constexpr int QH = 5;                   // L-BFGS history of the register-resident path
-#ifndef TSF_QUAD_WPS
-#define TSF_QUAD_WPS 2
-#endif
-#ifndef TSF_QUAD_HLDS
-#define TSF_QUAD_HLDS 0                 // L-BFGS history of the shared-M kernel in LDS (fit_one_quad HLDS)
-#endif
-#ifndef TSF_QUAD_MB
-#define TSF_QUAD_MB 16                  // rows of M per batch of LDS reads in gram_eval_q
-#endif
-constexpr int QUAD_WAVES_PER_SIMD = TSF_QUAD_WPS;   // register budget: 512 / this per lane
+// waves per SIMD the kernels are compiled for (register budget 512 / this per lane): 3 for the
+// shared-M kernel with its L-BFGS history in LDS (HLDS: <= 168 VGPRs, 12 waves per CU), else 2
+constexpr int quad_waves_per_simd(bool hlds) { return hlds ? 3 : 2; }
 
 struct QuadArgs {
     FitArgs f;
@@ -63,9 +56,14 @@ struct QuadLds {
     double tot1[W + 1], tot2[W + 1];
     double accR[KP];
     // per-series vectors that are cold during an evaluation live here, not in registers
-    double lc[PPL * W], sc[PPL * W], qc[PPL * W];      // cn_assemble_q lane constants
     double ref[PPL * W], cvec[PPL * W];                // reference point and c = Z^T r_ref
 };
+
+// cn_assemble_q lane constants (lc, sc, qc: [3][PPL][64] doubles).  They depend on the model and
+// on the number of changepoints only: one copy per workgroup on an aligned panel (every wave
+// writes the same bits), one per wave on a ragged one.
+template <int PPL>
+constexpr size_t quad_lanec_bytes() { return sizeof(double) * 3 * PPL * W; }
 
 
 // G-column slice of the register transpose network of column_sums (tsf_fit_kernels.h)
@@ -180,13 +178,14 @@ struct LaneConst {
     double inv_tau;
 };
 
-template <int KP, int PPL>
+template <int PPL>
 __device__ __forceinline__ void lane_consts(const DevSpec *sp, const SeriesView &sv,
-                                            QuadLds<KP, PPL> &wl, LaneConst<PPL> &k)
+                                            double *dst, LaneConst<PPL> &k)
 {
     const double C25 = 1.0 / 25.0;
     k.inv_tau = 1.0 / sv.tau;
-    k.lc = wl.lc; k.sc = wl.sc; k.qc = wl.qc;
+    double *lcp = dst, *scp = dst + PPL * W, *qcp = dst + 2 * PPL * W;
+    k.lc = lcp; k.sc = scp; k.qc = qcp;
 #pragma unroll
     for (int s = 0; s < PPL; ++s) {
         const int p = lane_id() + s * W;
@@ -198,7 +197,7 @@ __device__ __forceinline__ void lane_consts(const DevSpec *sp, const SeriesView 
             lc = 1.0 / (pr * pr);
             qc = 1.0 / pr;
         }
-        wl.lc[p] = lc; wl.sc[p] = sc; wl.qc[p] = qc;
+        lcp[p] = lc; scp[p] = sc; qcp[p] = qc;
     }
     wave_sync();
 }
@@ -326,7 +325,7 @@ __device__ __forceinline__ bool resid_eval_q(const SeriesView &sv, QuadLds<KP, P
 // prior-sum chains of assemble_q underneath the LDS reads and the four fma chains.
 // MRS: doubles between consecutive rows of Ml (64, or PQ for the compact per-wave copies of ragged
 // panels: lanes >= MRS then read finite entries of the next row, which only ever meet D = 0)
-template <int PPL, int PQ, int MRS = W>
+template <int PPL, int PQ, int MRS = W, int MB_ = 16>
 __device__ __forceinline__ bool gram_eval_q(const SeriesView &sv, const LaneConst<PPL> &lk,
                                             const double *Ml, int P4, const double (&th)[PPL],
                                             const double *ref_l, const double *cvec_l,
@@ -351,9 +350,9 @@ __device__ __forceinline__ bool gram_eval_q(const SeriesView &sv, const LaneCons
     const double *mp = Ml + lane;
     if (PQ > 0) {
         static_assert(PQ == 0 || PPL == 1, "compile-time M rows only for P <= 64");
-        // batches of MB rows: MB LDS reads in flight, then their fmas; the scheduling barrier
+        // batches of MB rows (16, or 8 in the three-waves-per-SIMD kernel): MB LDS reads in flight, then their fmas; the scheduling barrier
         // keeps the compiler from hoisting every read of M to the top (register pressure)
-        constexpr int MB = TSF_QUAD_MB;
+        constexpr int MB = MB_;
 #pragma unroll
         for (int q0 = 0; q0 < PQ; q0 += MB) {
             double m[MB];
@@ -501,7 +500,8 @@ __global__ __launch_bounds__(64) void gram_build_kernel(QuadArgs qa, double *Mou
 // SIMD fit the register file (tsf_inst_quad.hip); same values, same operation order.
 template <int KP, int PPL, int PQ, bool RAGGED, int MRS = W, bool HLDS = false>
 __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL> &wl, double *rb,
-                                          const double *Mp, double *Mown, int64_t n, double *hist = nullptr)
+                                          const double *Mp, double *Mown, int64_t n, double *lanec,
+                                          double *hist = nullptr)
 {
     const FitArgs &a = qa.f;
     const DevSpec *sp = a.sp;
@@ -534,7 +534,7 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
         return;
     }
     LaneConst<PPL> lk;
-    lane_consts<KP, PPL>(sp, sv, wl, lk);
+    lane_consts<PPL>(sp, sv, lanec, lk);
     if (RAGGED) {
         // ragged panel: this series has its own grid, hence its own M = Z^T Z.  The wave builds
         // it column by column into its slot of global memory; lane p writes and later reads only
@@ -796,7 +796,7 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
 #pragma unroll
             for (int s = 0; s < PPL; ++s) { xk1[s] = __builtin_fma(alpha, pk[s], xk[s]); xe[s] = xk1[s]; }
             sv.n_eval++;
-            bad = gram_eval_q<PPL, PQ, MRS>(sv, lk, Mp, P4, xe, wl.ref, wl.cvec, s0, fe, ge, q2, wl.th);
+            bad = gram_eval_q<PPL, PQ, MRS, (HLDS ? 8 : 16)>(sv, lk, Mp, P4, xe, wl.ref, wl.cvec, s0, fe, ge, q2, wl.th);
             QT_LAP(4);
 #pragma unroll
             for (int s = 0; s < PPL; ++s) gk1[s] = ge[s];
@@ -874,25 +874,29 @@ template <int PPL>
 constexpr size_t quad_hist_bytes(bool hlds) { return hlds ? sizeof(double) * 2 * QH * PPL * W : 0; }
 
 template <int KP, int PPL, int NW, int MMODE, int PQ, bool RLDS, bool HLDS = false>
-__global__ __launch_bounds__(NW * 64, QUAD_WAVES_PER_SIMD) void fit_quad_kernel(QuadArgs qa)
+__global__ __launch_bounds__(NW * 64, quad_waves_per_simd(HLDS)) void fit_quad_kernel(QuadArgs qa)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const FitArgs &a = qa.f;
     const int lane = lane_id(), wid = (int)threadIdx.x >> 6;
     const int P4 = qa.P4;
     constexpr bool MLDS = MMODE == QM_LDS;
-    // LDS: [M (aligned, P <= 64)] [QuadLds x NW] [history ring x NW (HLDS)] [r staging x NW (RLDS)]
-    //      [per-wave compact M (QM_RAGGED_LDS)]
+    // LDS: [M (aligned, P <= 64)] [lane constants: one (aligned) or NW (ragged)] [QuadLds x NW]
+    //      [history ring x NW (HLDS)] [r staging x NW (RLDS)] [per-wave compact M (QM_RAGGED_LDS)]
     double *Ml = reinterpret_cast<double *>(smem);
     const size_t m_bytes = MLDS ? sizeof(double) * (size_t)P4 * PPL * W : 0;
-    QuadLds<KP, PPL> &wl = *reinterpret_cast<QuadLds<KP, PPL> *>(smem + m_bytes + sizeof(QuadLds<KP, PPL>) * wid);
+    constexpr bool RAGGED_K = MMODE == QM_RAGGED || MMODE == QM_RAGGED_LDS;
+    constexpr size_t LCB = quad_lanec_bytes<PPL>();
+    double *lanec = reinterpret_cast<double *>(smem + m_bytes + (RAGGED_K ? LCB * wid : 0));
+    const size_t off_wl = m_bytes + LCB * (RAGGED_K ? NW : 1);
+    QuadLds<KP, PPL> &wl = *reinterpret_cast<QuadLds<KP, PPL> *>(smem + off_wl + sizeof(QuadLds<KP, PPL>) * wid);
     if (MLDS) {
         for (int i = threadIdx.x; i < P4 * PPL * W; i += NW * 64) Ml[i] = qa.Mg[i];
         __syncthreads();
     }
     const double *Mp = MLDS ? Ml : qa.Mg;
     constexpr size_t HB = quad_hist_bytes<PPL>(HLDS);
-    const size_t off_hist = m_bytes + sizeof(QuadLds<KP, PPL>) * NW;
+    const size_t off_hist = off_wl + sizeof(QuadLds<KP, PPL>) * NW;
     double *hist = HLDS ? reinterpret_cast<double *>(smem + off_hist + HB * wid) : nullptr;
     const size_t off_rb = off_hist + HB * NW;
     const size_t rb_bytes = RLDS ? sizeof(double) * (size_t)NW * a.NTmax * W : 0;
@@ -921,7 +925,7 @@ __global__ __launch_bounds__(NW * 64, QUAD_WAVES_PER_SIMD) void fit_quad_kernel(
         n32 = __builtin_amdgcn_readfirstlane(n32);
         const int64_t n = n32;
         if (n >= a.N) break;
-        fit_one_quad<KP, PPL, PQ, MMODE == QM_RAGGED || MMODE == QM_RAGGED_LDS, MRS, HLDS>(qa, wl, rb, Mp, Mown, n, hist);
+        fit_one_quad<KP, PPL, PQ, MMODE == QM_RAGGED || MMODE == QM_RAGGED_LDS, MRS, HLDS>(qa, wl, rb, Mp, Mown, n, lanec, hist);
     }
 }
 
