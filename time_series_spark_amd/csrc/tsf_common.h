@@ -117,33 +117,43 @@ constexpr int DPP_ROW_BCAST15 = 0x142;  // lane 15 of each row -> every lane of 
 constexpr int DPP_ROW_BCAST31 = 0x143;  // lane 31 -> every lane of rows 2 and 3
 constexpr int DPP_ROW_ROR8 = 0x128;     // lane i reads lane (i + 8) mod 16 of its row  (== xor 8)
 
-// xor-butterfly sum, offsets 1,2,4,8,16,32, returned as a wave-uniform scalar (v_readlane).
+// xor-butterfly sum, offsets 1,2,4,8,16,32.
 // (a + b is commutative, so in the butterfly every lane of a 2^k block holds the same bits after
 // stage k; exchanging through mirrors gives the butterfly's values.)  After the four in-row stages
 // every lane of row r holds R_r.  Stage 16 is then needed in rows 1 and 3 only (R1 + R0, R3 + R2,
 // operands in the butterfly's own/partner order for those lanes) and stage 32 in row 3 only
 // ((R3 + R2) + (R1 + R0)): two row-broadcast moves instead of two full swaps, and lane 63 holds
-// exactly what the butterfly leaves in every lane.
-__device__ __forceinline__ double bfly_sum(double v)
+// exactly what the butterfly leaves in every lane.  (The broadcasts also write rows that do not need
+// them -- row 0 reads nothing and gets 0 -- so that no `old` operand has to be set up.)
+// bfly_sum_l63: the sum in LANE 63 of the returned register (the other lanes hold partial sums);
+// lane63(): that lane as a wave-uniform scalar.  Arithmetic on the lane-63 value before the
+// v_readlane (a scale factor, say) saves moving the scalar back into a vector register.
+__device__ __forceinline__ double bfly_sum_l63(double v)
 {
     v = v + dpp_mov<DPP_XOR1>(v);
     v = v + dpp_mov<DPP_XOR2>(v);
     v = v + dpp_mov<DPP_HALF_MIRROR>(v);
     v = v + dpp_mov<DPP_MIRROR>(v);
-    v = v + dpp_mov_masked<DPP_ROW_BCAST15, 0xA>(0.0, v);
-    v = v + dpp_mov_masked<DPP_ROW_BCAST31, 0xC>(0.0, v);
+    v = v + dpp_mov<DPP_ROW_BCAST15>(v);
+    v = v + dpp_mov<DPP_ROW_BCAST31>(v);
+    return v;
+}
+__device__ __forceinline__ double lane63(double v)
+{
     int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
     int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
     return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ double bfly_sum(double v) { return lane63(bfly_sum_l63(v)); }
 
 // Four butterfly sums at once, bit-identical to four bfly_sum calls.  Stage 1 and 2 are done
 // "transposed": a lane keeps two (then one) of the four quantities and sends the others to its
 // partner, which needs exactly those -- each partial sum of the butterfly is formed once instead
 // of in every lane of its block (own + partner order as in the lane that keeps it).  From stage 4
 // on the lanes = 0, 2, 1, 3 (mod 4) carry a, b, c, d.
-__device__ __forceinline__ void bfly_sum4(double a, double b, double c, double d,
-                                          double &sa, double &sb, double &sc, double &sd)
+// bfly_sum4_lanes: the register whose lanes 0, 1, 2, 3 (and every lane = 0..3 mod 4) hold the sums of
+// a, c, b, d
+__device__ __forceinline__ double bfly_sum4_lanes(double a, double b, double c, double d)
 {
     const int lane = (int)threadIdx.x & (W - 1);
     const bool odd = lane & 1, hi2 = lane & 2;
@@ -162,6 +172,12 @@ __device__ __forceinline__ void bfly_sum4(double a, double b, double c, double d
     v = v + dpp_mov<DPP_ROW_ROR8>(v);
     { double x = v, y = v; swap16(x, y); v = x + y; }
     { double x = v, y = v; swap32(x, y); v = x + y; }
+    return v;
+}
+__device__ __forceinline__ void bfly_sum4(double a, double b, double c, double d,
+                                          double &sa, double &sb, double &sc, double &sd)
+{
+    const double v = bfly_sum4_lanes(a, b, c, d);
     sa = readlane_f64(v, 0); sc = readlane_f64(v, 1); sb = readlane_f64(v, 2); sd = readlane_f64(v, 3);
 }
 
@@ -220,6 +236,12 @@ template <int PPL>
 __device__ __forceinline__ double pdot(const double (&a)[PPL], const double (&b)[PPL])
 {
     return bfly_sum(pdot_part<PPL>(a, b));
+}
+// the dot product in lane 63 of the result (bfly_sum_l63)
+template <int PPL>
+__device__ __forceinline__ double pdot_l63(const double (&a)[PPL], const double (&b)[PPL])
+{
+    return bfly_sum_l63(pdot_part<PPL>(a, b));
 }
 
 // LDS hand-off between the lanes of ONE wave (multi-wave workgroups must not use s_barrier for

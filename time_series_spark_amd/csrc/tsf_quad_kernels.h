@@ -591,13 +591,17 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
             double sk[PPL], yk[PPL];
 #pragma unroll
             for (int s = 0; s < PPL; ++s) { sk[s] = xk[s] - xk1[s]; yk[s] = gk[s] - gk1[s]; }
-            double gg, ss, skyk, ykyk;
-            bfly_sum4(pdot_part<PPL>(gk, gk), pdot_part<PPL>(sk, sk), pdot_part<PPL>(yk, sk), pdot_part<PPL>(yk, yk),
-                      gg, ss, skyk, ykyk);
-            // the two square roots and the three quotients are independent: one lane each
-            const double nrm = __builtin_sqrt(lanes4(gg, ss, 0.0, 0.0));
-            const double gradNorm = readlane_f64(nrm, 0), stepNorm = readlane_f64(nrm, 1);
-            const double qv = lanes4(ykyk, skyk, 1.0, 1.0) / lanes4(skyk, ykyk, skyk, 1.0);
+            // g.g, s.s, y.s, y.y in one four-fold butterfly that leaves them in lanes 0, 2, 1, 3; the two
+            // square roots and the three quotients (y.y / y.s, y.s / y.y, 1 / y.s) are independent:
+            // one lane each, operands moved into place inside the quad
+            const double dots = bfly_sum4_lanes(pdot_part<PPL>(gk, gk), pdot_part<PPL>(sk, sk),
+                                                pdot_part<PPL>(yk, sk), pdot_part<PPL>(yk, yk));
+            const double nrm = __builtin_sqrt(dots);
+            const double gradNorm = readlane_f64(nrm, 0), stepNorm = readlane_f64(nrm, 2);
+            double qnum = dpp_mov<0x07>(dots);          // quad_perm [3,1,0,0]: y.y, y.s, -, -
+            if ((lane & 3) >= 2) qnum = 1.0;
+            const double qden = dpp_mov<0x5D>(dots);    // quad_perm [1,3,1,1]: y.s, y.y, y.s, y.s
+            const double qv = qnum / qden;
             if (resetB) {
                 const double B0fact = readlane_f64(qv, 0);
                 hist_len = 0;
@@ -674,7 +678,7 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
 #pragma unroll
             for (int h = QH - 1; h >= 0; --h) {
                 if (h < hist_len) {
-                    const double aa = rh[h] * pdot<PPL>(Sh[h], pk);
+                    const double aa = lane63(rh[h] * pdot_l63<PPL>(Sh[h], pk));
 #pragma unroll
                     for (int s = 0; s < PPL; ++s) pk[s] = __builtin_fma(-aa, Yh[h][s], pk[s]);
                     alphas[h] = aa;
@@ -685,8 +689,7 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
 #pragma unroll
             for (int h = 0; h < QH; ++h) {
                 if (h < hist_len) {
-                    const double bb = rh[h] * pdot<PPL>(Yh[h], pk);
-                    const double cc = alphas[h] - bb;
+                    const double cc = lane63(alphas[h] - rh[h] * pdot_l63<PPL>(Yh[h], pk));
 #pragma unroll
                     for (int s = 0; s < PPL; ++s) pk[s] = __builtin_fma(cc, Sh[h][s], pk[s]);
                 }
