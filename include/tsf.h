@@ -119,8 +119,8 @@ typedef struct {
     int32_t algorithm;                      /* TSF_ALGO_LBFGS */
     /* Which kernel runs a RESIDUAL-form L-BFGS fit (same arithmetic, same bits): TSF_RK_WAVE one
      * wavefront per series; TSF_RK_MFMA 16 series per workgroup evaluated together on the matrix
-     * cores (aligned panels, one parameter per lane, <= 28 changepoints; 1.3x the evaluations per
-     * second on saturated panels); TSF_RK_AUTO = MFMA from 64 series per compute unit on, else WAVE. */
+     * cores (aligned panels, one parameter per lane, <= 28 changepoints); TSF_RK_AUTO = the faster
+     * one as measured on MI355X, currently WAVE on every panel shape. */
     int32_t residual_kernel;                /* TSF_RK_AUTO */
 } tsf_spec;
 

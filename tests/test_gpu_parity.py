@@ -594,16 +594,19 @@ def test_full_size_cfg4_logistic_holidays(env):
         assert np.array_equal(yh[n], yo) and n_bit_diff(r.fval[n], o['f']) == 0
 
 
-def test_full_size_reference_model_takes_the_matrix_core_kernel(env):
+@pytest.mark.parametrize('kernel', ['auto', 'mfma'])
+def test_full_size_reference_model_on_both_residual_kernels(env, kernel):
     """The reference's own settings (logistic growth, multiplicative yearly + weekly) on a
-    20 000 x 730 aligned panel: TSF_RK_AUTO routes it to the matrix-core kernel (>= 64 series per
-    CU); every series ends normally and a random sample is bit-identical to the oracle."""
+    20 000 x 730 aligned panel, on the kernel TSF_RK_AUTO picks (the one-wave kernel) and on the
+    matrix-core kernel: every series ends normally and a random sample is bit-identical to the
+    oracle."""
     fc, cl = env
-    from time_series_spark_amd import synth
+    from time_series_spark_amd import _lib, synth
     N, T, H = 20000, 730, 90
     ds, y = synth.make_panel(N, T, 'logistic', seed=752)
     spec = fc.ModelSpec(growth='logistic', seasonality_mode='multiplicative',
-                        seasonalities=[helpers.YEARLY, helpers.WEEKLY])
+                        seasonalities=[helpers.YEARLY, helpers.WEEKLY],
+                        residual_kernel=_lib.RK_MFMA if kernel == 'mfma' else _lib.RK_AUTO)
     floor, cap = np.zeros(N), y.max(axis=1) * 1.1
     r = fc.fit_aligned(spec, ds, y, floor=floor, cap=cap)
     bad = r.status <= 0

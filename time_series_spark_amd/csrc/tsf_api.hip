@@ -344,13 +344,14 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     // MfmaTabs::overflow routes the call to the one-wave kernel)
     MfmaPlan mp;
     memset(&mp, 0, sizeof(mp));
-    // TSF_RK_AUTO: measured (profiles/r02_mfma_vs_wave.txt) the matrix-core kernel evaluates 1.3x more
-    // points per second when its slots are busy (100 000 x 730, iteration cap 150: 62.7 vs 48.1 M
-    // evaluations/s) and matches the one-wave kernel while a launch waits for one long series
-    // (rounds with up to three requests are shared by all waves of the workgroup), but a panel below
-    // 16 series per CU leaves CUs idle: AUTO takes it from 64 series per CU on.
-    const bool want_mfma = spec->residual_kernel == TSF_RK_MFMA ||
-                           (spec->residual_kernel == TSF_RK_AUTO && N >= (int64_t)64 * ctx->n_cu);
+    // TSF_RK_AUTO = the one-wave kernel.  Measured (profiles/r02_mfma_vs_wave.txt): both kernels issue
+    // the same number of vector instructions per evaluation and are bound by them -- fp64 MFMA has
+    // the vector unit's rate, and the 672 multiply-adds it takes over are 16 % of an evaluation --
+    // so once the reductions of the optimiser were cut (uniform butterflies) the one-wave kernel,
+    // which has no rounds to synchronise, is ahead on every panel measured (100 000 x 730, iteration
+    // cap 150: 271 vs 326 ms; reference settings with their stragglers: 1.27 vs 1.62 s).  The
+    // matrix-core kernel stays available (TSF_RK_MFMA), bit-identical.
+    const bool want_mfma = spec->residual_kernel == TSF_RK_MFMA;
     if (aligned && !quad && !newton && theta_in == nullptr && hs.KP <= 28 && want_mfma) {
         const int hist_rows = (int)floor((double)Tm * hs.cp_range);
         int S = hs.n_cp;

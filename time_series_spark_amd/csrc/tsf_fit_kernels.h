@@ -175,11 +175,13 @@ __device__ __forceinline__ bool eval_tail(const DevSpec *__restrict__ sp, const 
             const double tmc_l = (lane < S) ? sv.t_change[cl] - lds.mc[cl] : 0.0;
             const double d2_l = scr.d2[cl];
             double abar = readlane_f64(d2_l, S);
+            double rb_l = 0.0;                  // lane c keeps rb[c]; one LDS write after the chain
             for (int c = S - 1; c >= 0; --c) {
                 const double rbc = abar * readlane_f64(tmc_l, c);
-                if (lane == c) scr.rb[c] = rbc;
+                if (lane == c) rb_l = rbc;
                 abar = readlane_f64(d2_l, c) + abar * readlane_f64(ratio_l, c);
             }
+            if (lane < S) scr.rb[lane] = rb_l;
             gm = nis * abar;
         }
         TSF_WAVE_SYNC();
@@ -196,14 +198,16 @@ __device__ __forceinline__ bool eval_tail(const DevSpec *__restrict__ sp, const 
     for (int s = 0; s < PPL; ++s) g[s] = 0.0;
     if (GROWTH == 1) {
         // sequential suffix of the adjusted per-segment sums: gd[c-1] = nis * sum_{c'>=c} D1[c']
+        // (ab[c] read once, lane c holding ab[c]; the chain takes it from there with v_readlane)
+        const double ab_l = scr.ab[lane <= S ? lane : S];
         double sK = 0.0;
         for (int c = S; c >= 1; --c) {
-            sK = sK + scr.ab[c];
+            sK = sK + readlane_f64(ab_l, c);
 #pragma unroll
             for (int s = 0; s < PPL; ++s)
                 if (lane + s * W == 3 + (c - 1)) g[s] = nis * sK;
         }
-        gk = nis * (sK + scr.ab[0]);
+        gk = nis * (sK + readlane_f64(ab_l, 0));
     } else {
         gk = nis * TA;
         gm = nis * TB;
@@ -532,8 +536,11 @@ __global__ __launch_bounds__(64) void eval_kernel(FitArgs a)
     if (threadIdx.x == 0) { a.fval[n] = f; a.status[n] = bad ? 1 : 0; }
 }
 
+#ifndef TSF_FIT_WPS
+#define TSF_FIT_WPS 1
+#endif
 template <int KP, int GROWTH, int MODE, int PPL, bool XIDX = false>
-__global__ __launch_bounds__(64) void fit_kernel(FitArgs a)
+__global__ __launch_bounds__(64, TSF_FIT_WPS) void fit_kernel(FitArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     WaveLds<KP, PPL> &lds = *reinterpret_cast<WaveLds<KP, PPL> *>(smem);
@@ -605,12 +612,12 @@ __global__ __launch_bounds__(64) void fit_kernel(FitArgs a)
             if (itNum > 1 && resetB != 2) {
                 const double gp1 = pk1_scaled ? pdot<PPL>(gk1, pk1) : dfp;
                 const double ci = cubic_interp6(gp1, alpha, fk - fk1, gp, minAlpha, 1.0);
-                alpha = __builtin_fmin(1.0, 1.01 * ci);
+                alpha = uniform_f64(__builtin_fmin(1.0, 1.01 * ci));
             } else {
                 alpha = a.opt.init_alpha;
             }
             dfp = gp;
-            c1dfp = c1 * dfp; c2dfp = c2 * dfp;
+            c1dfp = uniform_f64(c1 * dfp); c2dfp = uniform_f64(c2 * dfp);
             alpha0 = minAlpha; prevF = fk; prevDFp = dfp;
             nits = 0; lsRestarts = 0; zoom = 0; zit = 0;
             stage = ST_LS_PRE;
@@ -624,7 +631,7 @@ __global__ __launch_bounds__(64) void fit_kernel(FitArgs a)
                 if (__builtin_fabs(alo - ahi) < min_range) {
                     ls_fail = true;
                 } else if (zit % 5 == 0) {
-                    alpha = 0.5 * (alo + ahi);
+                    alpha = uniform_f64(0.5 * (alo + ahi));
                 } else {
                     const double d1 = aloDFp + ahiDFp - 3.0 * (aloF - ahiF) / (alo - ahi);
                     double d2 = __builtin_sqrt(d1 * d1 - aloDFp * ahiDFp);
@@ -634,6 +641,7 @@ __global__ __launch_bounds__(64) void fit_kernel(FitArgs a)
                                  w = __builtin_fabs(alo - ahi);
                     if (!finite_f64(alpha) || alpha < lo + 0.01 * w || alpha > hi - 0.01 * w)
                         alpha = 0.5 * (alo + ahi);
+                    alpha = uniform_f64(alpha);
                 }
             }
             if (!ls_fail) stage = ST_LS_EVAL;
@@ -647,6 +655,7 @@ __global__ __launch_bounds__(64) void fit_kernel(FitArgs a)
             }
             double f1;
             const bool bad = eval_fg<KP, GROWTH, MODE, PPL, XIDX>(sp, sv, lds, xk1, f1, gk1);
+            f1 = uniform_f64(f1);       // every lane holds the same bits: let the compiler know (scalar branches)
             if (stage == ST_INIT) {
                 if (bad) { ret = TSF_ST_INIT_NONFINITE; fk = f1; break; }
                 fk = f1;
@@ -658,9 +667,9 @@ __global__ __launch_bounds__(64) void fit_kernel(FitArgs a)
             if (bad) {
                 if (!zoom) {
                     if (lsRestarts >= maxLSRestarts) ls_fail = true;
-                    else { alpha = 0.5 * (alpha0 + alpha); lsRestarts++; }
+                    else { alpha = uniform_f64(0.5 * (alpha0 + alpha)); lsRestarts++; }
                 } else {
-                    alpha = 0.5 * (alpha + __builtin_fmin(alo, ahi));
+                    alpha = uniform_f64(0.5 * (alpha + __builtin_fmin(alo, ahi)));
                     if (__builtin_fabs(__builtin_fmin(alo, ahi) - alpha) < min_range) ls_fail = true;
                 }
                 if (!ls_fail) continue;            // re-evaluate at the shortened step
@@ -680,7 +689,7 @@ __global__ __launch_bounds__(64) void fit_kernel(FitArgs a)
                         ahi = alpha0; ahiF = prevF; ahiDFp = prevDFp;
                     } else {
                         alpha0 = alpha; prevF = f1; prevDFp = newDFp;
-                        alpha *= 10.0;
+                        alpha = uniform_f64(alpha * 10.0);
                         nits++;
                     }
                 } else {
@@ -706,19 +715,22 @@ __global__ __launch_bounds__(64) void fit_kernel(FitArgs a)
                     sk[s] = xk[s] - xk1[s];
                     yk[s] = gk[s] - gk1[s];
                 }
-                const double gg = pdot<PPL>(gk, gk), ss = pdot<PPL>(sk, sk);
-                const double skyk = pdot<PPL>(yk, sk);
-                const double ykyk = pdot<PPL>(yk, yk);
-                // independent square roots / quotients: one lane each (see fit_one_quad)
-                const double nrm = __builtin_sqrt(lanes4(gg, ss, 0.0, 0.0));
-                const double gradNorm = readlane_f64(nrm, 0), stepNorm = readlane_f64(nrm, 1);
-                const double qv = lanes4(ykyk, skyk, 1.0, 1.0) / lanes4(skyk, ykyk, skyk, 1.0);
+                // g.g, s.s, y.s, y.y: one four-fold butterfly (lanes 0, 2, 1, 3); the two square roots
+                // and the three quotients one lane each (see fit_one_quad)
+                const double dots = bfly_sum4_lanes(pdot_part<PPL>(gk, gk), pdot_part<PPL>(sk, sk),
+                                                    pdot_part<PPL>(yk, sk), pdot_part<PPL>(yk, yk));
+                const double nrm = __builtin_sqrt(dots);
+                const double gradNorm = readlane_f64(nrm, 0), stepNorm = readlane_f64(nrm, 2);
+                double qnum = dpp_mov<0x07>(dots);          // quad_perm [3,1,0,0]: y.y, y.s, -, -
+                if ((lane & 3) >= 2) qnum = 1.0;
+                const double qden = dpp_mov<0x5D>(dots);    // quad_perm [1,3,1,1]: y.s, y.y, y.s, y.s
+                const double qv = qnum / qden;
                 if (resetB) {
                     const double B0fact = readlane_f64(qv, 0);
                     hist_len = 0; hist_head = 0;
 #pragma unroll
                     for (int s = 0; s < PPL; ++s) pk1[s] = pk1[s] / B0fact;
-                    alpha = alpha * B0fact;
+                    alpha = uniform_f64(alpha * B0fact);
                     pk1_scaled = true;
                 } else {
                     pk1_scaled = false;
@@ -747,7 +759,7 @@ __global__ __launch_bounds__(64) void fit_kernel(FitArgs a)
                         si[s] = lds.Sb[(slot * PPL + s) * W + lane];
                         yi[s] = lds.Yb[(slot * PPL + s) * W + lane];
                     }
-                    const double aa = lds.rho[slot] * pdot<PPL>(si, pk);
+                    const double aa = lane63(lds.rho[slot] * pdot_l63<PPL>(si, pk));
 #pragma unroll
                     for (int s = 0; s < PPL; ++s) pk[s] = __builtin_fma(-aa, yi[s], pk[s]);
                     if (lane == 0) lds.alphas[h] = aa;
@@ -763,8 +775,7 @@ __global__ __launch_bounds__(64) void fit_kernel(FitArgs a)
                         si[s] = lds.Sb[(slot * PPL + s) * W + lane];
                         yi[s] = lds.Yb[(slot * PPL + s) * W + lane];
                     }
-                    const double bb = lds.rho[slot] * pdot<PPL>(yi, pk);
-                    const double cc = lds.alphas[h] - bb;
+                    const double cc = lane63(lds.alphas[h] - lds.rho[slot] * pdot_l63<PPL>(yi, pk));
 #pragma unroll
                     for (int s = 0; s < PPL; ++s) pk[s] = __builtin_fma(cc, si[s], pk[s]);
                 }

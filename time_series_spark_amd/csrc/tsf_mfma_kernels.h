@@ -409,12 +409,16 @@ __global__ __launch_bounds__(MT_NW * W) void fit_mfma_kernel(FitArgs a, MfmaTabs
                         { const double tg = gk; gk = gk1; gk1 = tg; }
                         { const double tp = pk; pk = pk1; pk1 = tp; }
                         double sk[1] = {xk - xk1}, yk[1] = {gk - gk1}, gkv[1] = {gk};
-                        const double gg = pdot<PPL>(gkv, gkv), ss = pdot<PPL>(sk, sk);
-                        const double skyk = pdot<PPL>(yk, sk);
-                        const double ykyk = pdot<PPL>(yk, yk);
-                        const double nrm = __builtin_sqrt(lanes4(gg, ss, 0.0, 0.0));
-                        const double gradNorm = readlane_f64(nrm, 0), stepNorm = readlane_f64(nrm, 1);
-                        const double qv = lanes4(ykyk, skyk, 1.0, 1.0) / lanes4(skyk, ykyk, skyk, 1.0);
+                        // g.g, s.s, y.s, y.y: one four-fold butterfly (lanes 0, 2, 1, 3), square roots and
+                        // quotients one lane each (see fit_one_quad)
+                        const double dots = bfly_sum4_lanes(pdot_part<PPL>(gkv, gkv), pdot_part<PPL>(sk, sk),
+                                                            pdot_part<PPL>(yk, sk), pdot_part<PPL>(yk, yk));
+                        const double nrm = __builtin_sqrt(dots);
+                        const double gradNorm = readlane_f64(nrm, 0), stepNorm = readlane_f64(nrm, 2);
+                        double qnum = dpp_mov<0x07>(dots);          // quad_perm [3,1,0,0]: y.y, y.s, -, -
+                        if ((lane & 3) >= 2) qnum = 1.0;
+                        const double qden = dpp_mov<0x5D>(dots);    // quad_perm [1,3,1,1]: y.s, y.y, y.s, y.s
+                        const double qv = qnum / qden;
                         if (v.resetB) {
                             const double B0fact = readlane_f64(qv, 0);
                             v.hist_len = 0; v.hist_head = 0;
@@ -452,7 +456,7 @@ __global__ __launch_bounds__(MT_NW * W) void fit_mfma_kernel(FitArgs a, MfmaTabs
                             if (h < v.hist_len) {
                                 const int hs = (v.hist_head + h) % H;
                                 double x2[1] = {si[h]}, y2[1] = {pk};
-                                const double aa = st.rho[hs] * pdot<PPL>(x2, y2);
+                                const double aa = lane63(st.rho[hs] * pdot_l63<PPL>(x2, y2));
                                 pk = __builtin_fma(-aa, yi[h], pk);
                                 if (lane == 0) st.alphas[h] = aa;
                             }
@@ -464,8 +468,7 @@ __global__ __launch_bounds__(MT_NW * W) void fit_mfma_kernel(FitArgs a, MfmaTabs
                             if (h < v.hist_len) {
                                 const int hs = (v.hist_head + h) % H;
                                 double x2[1] = {yi[h]}, y2[1] = {pk};
-                                const double bb = st.rho[hs] * pdot<PPL>(x2, y2);
-                                const double cc = st.alphas[h] - bb;
+                                const double cc = lane63(st.alphas[h] - st.rho[hs] * pdot_l63<PPL>(x2, y2));
                                 pk = __builtin_fma(cc, si[h], pk);
                             }
                         }

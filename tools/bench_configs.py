@@ -24,14 +24,14 @@ H = 90
 
 def build(name):
     """-> (description, spec, ds, y, floor, cap, extra, extra_future, bytes_per_series)"""
-    if name.endswith('_mfma') and not name.startswith(('cap', 'long')):
-        # the same configuration on the matrix-core residual kernel (residual_kernel = MFMA)
+    if name.endswith(('_mfma', '_wave')) and not name.startswith(('cap', 'long')):
+        # the same configuration with the residual kernel forced (residual_kernel = MFMA / WAVE)
         from time_series_spark_amd import _lib
         out = list(build(name[:-5]))
         d = out[1].to_dict()
-        d['lbfgs'] = dict(d['lbfgs'], residual_kernel=_lib.RK_MFMA)
+        d['lbfgs'] = dict(d['lbfgs'], residual_kernel=_lib.RK_MFMA if name.endswith('_mfma') else _lib.RK_WAVE)
         out[1] = fc.ModelSpec.from_dict(d)
-        out[0] += ' [matrix-core residual kernel]'
+        out[0] += ' [matrix-core residual kernel]' if name.endswith('_mfma') else ' [one-wave residual kernel]'
         return tuple(out)
     if name in ('cfg2', 'cfg2_resid'):
         N, T = 10000, 730
