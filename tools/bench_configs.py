@@ -33,12 +33,13 @@ def build(name):
         out[1] = fc.ModelSpec.from_dict(d)
         out[0] += ' [matrix-core residual kernel]' if name.endswith('_mfma') else ' [one-wave residual kernel]'
         return tuple(out)
-    if name in ('cfg2', 'cfg2_resid'):
-        N, T = 10000, 730
+    if name in ('cfg2', 'cfg2_resid', 'cfg2x4', 'cfg2x16'):
+        # cfg2x4 / cfg2x16: the cfg2 model on 40 000 / 160 000 series (throughput, not the longest series)
+        N, T = {'cfg2x4': 40000, 'cfg2x16': 160000}.get(name, 10000), 730
         lb = {'eval_form': 1} if name.endswith('resid') else {}
         spec = fc.ModelSpec(growth='linear', seasonalities=[YEARLY, WEEKLY], **lb)
         ds, y = synth.make_panel(N, T, 'linear', seed=751)
-        return ('10000 x 730 linear additive yearly+weekly' + (' (residual form forced)' if lb else ''),
+        return ('%d x 730 linear additive yearly+weekly' % N + (' (residual form forced)' if lb else ''),
                 spec, ds, y, None, None, None, None, T * 8 + 54 * 8 + H * 8)
     if name in ('ref10k', 'ref100k'):   # the reference's own model settings on an aligned panel
         N, T = (10000 if name == 'ref10k' else 100000), 730
