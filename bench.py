@@ -301,9 +301,11 @@ def main():
                      'algorithmic_bytes_per_launch': bytes_per_series * N_SERIES,
                      'kernel_ms_avg': fit_ms, 'launches_timed': len(kernel_ms),
                      'note': 'HBM sees each series once in and once out; the fit itself is a '
-                             'dependent-latency-bound fp64 L-BFGS loop on registers/LDS '
+                             'vector-issue- and latency-bound fp64 L-BFGS loop on registers/LDS '
                              '(SURVEY 8d, DESIGN.md section 5), so the HBM fraction is small by '
-                             'construction; evaluation rate and fp64 figure alongside',
+                             'construction; at 12 waves per CU the r staging of the residual passes '
+                             'goes through the global scratch, which is most of the measured traffic; '
+                             'evaluation rate and fp64 figure alongside',
                      'evaluations_per_s': float(n_eval.sum()) / (fit_ms * 1e-3),
                      'flops_per_evaluation_algorithmic': flops_per_eval,
                      'fp64_tflops_algorithmic': tflops,

@@ -18,7 +18,8 @@
 // once per workgroup in LDS, on a ragged panel every wave builds the M of its current series
 // into its own slot of global memory; every wave pulls series indices from a global atomic
 // counter and runs the whole L-BFGS for its series (one wavefront per series, parameter p in
-// lane p%64).  L-BFGS history is held in registers.  oracle/prophet_canon.c (cn_resid_q / cn_eval_gram / cn_assemble_q / cn_lbfgs)
+// lane p%64).  The L-BFGS history is held in registers, or -- the shared-M kernel, compiled for three
+// waves per SIMD (12 per CU) -- in an LDS ring.  oracle/prophet_canon.c (cn_resid_q / cn_eval_gram / cn_assemble_q / cn_lbfgs)
 // performs the identical operation sequence; tests require bit equality.
 #pragma once
 #include "tsf_fit_kernels.h"
