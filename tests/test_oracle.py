@@ -11,7 +11,7 @@ import pytest
 from tests import helpers
 from oracle import canon_lib as cl, oracle_lib
 from oracle.fbprophet_restated import (ProphetOracle, stan_log_prob, stan_neg_log_prob_grad,
-                                       fourier_series)
+                                       fourier_series, stan_trend, unpack_theta)
 
 ULP = 2.220446049250313e-16
 
@@ -529,3 +529,36 @@ def test_seeded_intervals_agree_with_the_literal_sampler(case):
     assert np.max(np.abs(lo_c - lo_l)) < 0.12 * width and np.max(np.abs(hi_c - hi_l)) < 0.12 * width
     assert abs((lo_c - lo_l).mean()) < 0.02 * width and abs((hi_c - hi_l).mean()) < 0.02 * width
     assert abs((hi_c - lo_c).mean() / width - 1.0) < 0.03
+
+
+@pytest.mark.parametrize('case', ['cfg2_linear_additive', 'ref_logistic_multiplicative', 'short_90',
+                                  'logistic_additive_400'])
+def test_map_estimate_against_an_independent_optimiser(case):
+    """A pin that does not go through this repo's restatement of Stan's optimiser: scipy's L-BFGS-B
+    (its own line search, its own stopping rule, run to a tight tolerance) on the LITERAL numpy
+    prophet.stan log-posterior, from fbprophet's initial values.  Stan stops on loose relative
+    tolerances, so the canonical fit ends a little above the exact MAP: its objective must lie within
+    a small gap of scipy's minimum (never far below it: same function), and the in-sample fitted
+    curve of the two end points must agree to a fraction of the noise level."""
+    from scipy.optimize import minimize
+    m, dat, th0, (spec, ds, y, floor, cap, extra, fut, exf) = _literal(case)
+    csp = helpers.oracle_spec(spec)
+    r = cl.fit(csp, ds, y[0], floor[0], cap[0], extra)
+    assert r['status'] > 0
+    res = minimize(lambda th: stan_neg_log_prob_grad(dat, th), th0, jac=True, method='L-BFGS-B',
+                   options=dict(maxiter=50000, maxfun=200000, ftol=1e-15, gtol=1e-7, maxcor=20))
+    f_canon, _ = stan_neg_log_prob_grad(dat, r['theta'])
+    assert abs(f_canon - r['f']) <= 1e-9 * abs(f_canon)
+    gap = f_canon - res.fun
+    T = dat['T']
+    # measured: 0.01 .. 0.26 on objectives of -270 .. -2240
+    assert -1e-6 * abs(res.fun) <= gap <= 0.5, (case, gap, res.fun, res.message)
+
+    def fitted(th):
+        k, mm, ls, delta, beta = unpack_theta(th, dat['S'], dat['K'])
+        X = dat['X']
+        return stan_trend(dat, k, mm, delta) * (1 + X @ (beta * dat['s_m'])) + X @ (beta * dat['s_a'])
+    a, b = fitted(r['theta']), fitted(res.x)
+    sigma = np.exp(res.x[2])
+    # measured: 0.1 % .. 1.2 % of the fitted noise level
+    assert np.sqrt(np.mean((a - b) ** 2)) <= 0.05 * sigma, (case, np.sqrt(np.mean((a - b) ** 2)), sigma)
