@@ -532,7 +532,7 @@ def test_seeded_intervals_agree_with_the_literal_sampler(case):
 
 
 @pytest.mark.parametrize('case', ['cfg2_linear_additive', 'ref_logistic_multiplicative', 'short_90',
-                                  'logistic_additive_400'])
+                                  'logistic_additive_400', 'cfg4_holidays', 'short_90@newton'])
 def test_map_estimate_against_an_independent_optimiser(case):
     """A pin that does not go through this repo's restatement of Stan's optimiser: scipy's L-BFGS-B
     (its own line search, its own stopping rule, run to a tight tolerance) on the LITERAL numpy
@@ -541,9 +541,10 @@ def test_map_estimate_against_an_independent_optimiser(case):
     a small gap of scipy's minimum (never far below it: same function), and the in-sample fitted
     curve of the two end points must agree to a fraction of the noise level."""
     from scipy.optimize import minimize
-    m, dat, th0, (spec, ds, y, floor, cap, extra, fut, exf) = _literal(case)
+    newton = case.endswith('@newton')      # Stan's Newton (fbprophet's choice below 100 rows)
+    m, dat, th0, (spec, ds, y, floor, cap, extra, fut, exf) = _literal(case.split('@')[0])
     csp = helpers.oracle_spec(spec)
-    r = cl.fit(csp, ds, y[0], floor[0], cap[0], extra)
+    r = (cl.fit_newton if newton else cl.fit)(csp, ds, y[0], floor[0], cap[0], extra)
     assert r['status'] > 0
     res = minimize(lambda th: stan_neg_log_prob_grad(dat, th), th0, jac=True, method='L-BFGS-B',
                    options=dict(maxiter=50000, maxfun=200000, ftol=1e-15, gtol=1e-7, maxcor=20))
@@ -551,8 +552,10 @@ def test_map_estimate_against_an_independent_optimiser(case):
     assert abs(f_canon - r['f']) <= 1e-9 * abs(f_canon)
     gap = f_canon - res.fun
     T = dat['T']
-    # measured: 0.01 .. 0.26 on objectives of -270 .. -2240
-    assert -1e-6 * abs(res.fun) <= gap <= 0.5, (case, gap, res.fun, res.message)
+    # measured: 0.01 .. 0.27 above scipy's end point on objectives of -270 .. -2240 for L-BFGS; Stan's
+    # Newton ends 0.20 BELOW it on the 90-row series (L-BFGS-B stalls on the |delta| kinks; f_canon
+    # above is the literal function's own value, so "below" is a better point, not a different function)
+    assert -0.5 <= gap <= 0.5, (case, gap, res.fun, res.message)
 
     def fitted(th):
         k, mm, ls, delta, beta = unpack_theta(th, dat['S'], dat['K'])
@@ -560,5 +563,5 @@ def test_map_estimate_against_an_independent_optimiser(case):
         return stan_trend(dat, k, mm, delta) * (1 + X @ (beta * dat['s_m'])) + X @ (beta * dat['s_a'])
     a, b = fitted(r['theta']), fitted(res.x)
     sigma = np.exp(res.x[2])
-    # measured: 0.1 % .. 1.2 % of the fitted noise level
+    # measured: 0.1 % .. 2.3 % of the fitted noise level
     assert np.sqrt(np.mean((a - b) ** 2)) <= 0.05 * sigma, (case, np.sqrt(np.mean((a - b) ** 2)), sigma)
