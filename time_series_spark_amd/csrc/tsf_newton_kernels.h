@@ -104,47 +104,48 @@ __device__ __forceinline__ double ql_lds(int n, int PM, double *Am, double *Vm, 
         if (lane <= i) { Vm[i * PM + lane] = (lane == i) ? 1.0 : 0.0; Vm[lane * PM + i] = (lane == i) ? 1.0 : 0.0; }
         TSF_WAVE_SYNC();
     }
-    // ---- implicit QL on (d, e); rotations applied to the columns of V, lane = row k
-    {
-        const double en = (lane >= 1 && lane < n) ? sc.e[lane] : 0.0;
-        TSF_WAVE_SYNC();
-        if (lane >= 1 && lane < n) sc.e[lane - 1] = en;
-        if (lane == 0) sc.e[n - 1] = 0.0;
-        TSF_WAVE_SYNC();
-    }
+    // ---- implicit QL on (d, e); rotations applied to the columns of V, lane = row k.
+    // d and e live in REGISTERS here, entry j in lane j (n <= 64): the scalar rotation chain reads
+    // them with v_readlane instead of waiting for an LDS round trip in every step, the search for
+    // the first negligible off-diagonal element is one lane-parallel test + ballot instead of up to
+    // n dependent LDS reads, and no LDS hand-off is left inside the chain (a lane only touches its
+    // own row of V).  Same operations on the same operands as the oracle's sequential loops.
+    TSF_WAVE_SYNC();
+    double dv = (lane < n) ? sc.d[lane] : 0.0;
+    double ev = (lane + 1 < n) ? sc.e[lane + 1] : 0.0;      // e shifted down by one, e[n-1] = 0
     for (int l = 0; l < n; ++l) {
         for (int guard = 0; guard < 60; ++guard) {
-            int m = l;
-            for (; m < n - 1; ++m) {
-                const double dd = __builtin_fabs(sc.d[m]) + __builtin_fabs(sc.d[m + 1]);
-                if (__builtin_fabs(sc.e[m]) + dd == dd) break;
-            }
+            // m: first index in [l, n-2] whose off-diagonal element is negligible, else n-1
+            const double dn = __shfl_down(dv, 1, W);
+            const double dd = __builtin_fabs(dv) + __builtin_fabs(dn);
+            const bool tiny = lane >= l && lane < n - 1 && (__builtin_fabs(ev) + dd == dd);
+            const unsigned long long mask = __ballot(tiny);
+            const int m = mask ? (int)__builtin_ctzll(mask) : n - 1;
             if (m == l) break;
-            const double dl = sc.d[l], el = sc.e[l];
-            double g = (sc.d[l + 1] - dl) / (2.0 * el);
+            const double dl = readlane_f64(dv, l), el = readlane_f64(ev, l);
+            double g = (readlane_f64(dv, l + 1) - dl) / (2.0 * el);
             double r = ql_pythag(g, 1.0);
-            g = sc.d[m] - dl + el / (g + (g >= 0.0 ? __builtin_fabs(r) : -__builtin_fabs(r)));
+            g = readlane_f64(dv, m) - dl + el / (g + (g >= 0.0 ? __builtin_fabs(r) : -__builtin_fabs(r)));
             double s = 1.0, c = 1.0, p = 0.0;
             int i = m - 1;
             bool underflow = false;
             for (; i >= l; --i) {
-                const double ei = sc.e[i], di = sc.d[i], di1 = sc.d[i + 1];
+                const double ei = readlane_f64(ev, i), di = readlane_f64(dv, i), di1 = readlane_f64(dv, i + 1);
                 double f = s * ei;
                 const double b = c * ei;
                 r = __builtin_sqrt(__builtin_fma(f, f, g * g));
-                TSF_WAVE_SYNC();
-                if (lane == 0) sc.e[i + 1] = r;
+                if (lane == i + 1) ev = r;
                 if (r == 0.0) {
-                    if (lane == 0) { sc.d[i + 1] = di1 - p; sc.e[m] = 0.0; }
+                    if (lane == i + 1) dv = di1 - p;
+                    if (lane == m) ev = 0.0;
                     underflow = true;
-                    TSF_WAVE_SYNC();
                     break;
                 }
                 { const double ri = 1.0 / r; s = f * ri; c = g * ri; }
                 g = di1 - p;
                 r = (di - g) * s + 2.0 * c * b;
                 p = s * r;
-                if (lane == 0) sc.d[i + 1] = g + p;
+                if (lane == i + 1) dv = g + p;
                 g = c * r - b;
                 if (lane < n) {
                     f = Vm[lane * PM + i + 1];
@@ -152,15 +153,14 @@ __device__ __forceinline__ double ql_lds(int n, int PM, double *Am, double *Vm, 
                     Vm[lane * PM + i + 1] = __builtin_fma(s, v0, c * f);
                     Vm[lane * PM + i] = __builtin_fma(c, v0, -(s * f));
                 }
-                TSF_WAVE_SYNC();
             }
             if (underflow) continue;
-            if (lane == 0) { sc.d[l] = sc.d[l] - p; sc.e[l] = g; sc.e[m] = 0.0; }
-            TSF_WAVE_SYNC();
+            if (lane == l) { dv = dv - p; ev = g; }
+            if (lane == m) ev = 0.0;
         }
     }
     TSF_WAVE_SYNC();
-    return (lane < n) ? sc.d[lane] : 0.0;
+    return (lane < n) ? dv : 0.0;
 }
 
 // LDS of one Newton wave: the evaluation tables of eval_fg (no L-BFGS history), the QL scratch,
