@@ -331,8 +331,8 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     if (quad || newton_quad) {
         rc = quad_plan(ctx, hs, N, &qp);
         if (rc) return rc;
-        if (newton_quad) {          // one-wave workgroups, up to 8 per CU: that many Z^T Z slots (ragged)
-            qp.slots = ctx->n_cu * 8;
+        if (newton_quad) {          // one-wave workgroups, up to 16 per CU: that many Z^T Z slots (ragged)
+            qp.slots = ctx->n_cu * 16;
             if (qp.slots < qp.P4) qp.slots = qp.P4;
         }
     }

@@ -14,30 +14,47 @@
 
 namespace tsf {
 
+#ifndef TSF_NEWTON_QUAD_WPS
+#define TSF_NEWTON_QUAD_WPS 3        // waves per SIMD the compiler budgets registers for (KP <= 16: 162 VGPRs, no scratch)
+#endif
+
+// LDS of one Newton wave.  What must survive a whole iteration: the reference point and c of the
+// quadratic form, the lane constants, the eigen-solver's scratch.  The matrix (finite-difference
+// Hessian, then its eigenvectors: PM x PM doubles) and the scratch of a residual pass (tables + r
+// staging) are never live at the same time -- the pass is the first thing of an iteration, the
+// Hessian is built after it and dead once the step is formed -- so they SHARE one region: 14.4
+// instead of 19.6 KB per wave at T = 90, 11 instead of 8 waves per CU.
 template <int KP>
 struct NewtonQuadLds {
-    QuadLds<KP, 1> q;
-    QlScratch ql;
+    double ref[W], cvec[W];         // reference point and c = Z^T r_ref
     double lanec[3 * W];            // cn_assemble_q lane constants (lane_consts)
+    QlScratch ql;
 };
+
+template <int KP>
+constexpr size_t newton_quad_shared_bytes(int PM, int NTmax)
+{
+    const size_t pass = sizeof(QuadLds<KP, 1>) + sizeof(double) * (size_t)NTmax * W;
+    const size_t mat = (size_t)PM * PM * sizeof(double);
+    return ((pass > mat ? pass : mat) + 15) & ~(size_t)15;
+}
 
 template <int KP>
 constexpr size_t newton_quad_lds_bytes(int PM, int NTmax)
 {
-    return ((sizeof(NewtonQuadLds<KP>) + 15) & ~(size_t)15) + sizeof(double) * (size_t)NTmax * W +
-           (size_t)PM * PM * sizeof(double);
+    return ((sizeof(NewtonQuadLds<KP>) + 15) & ~(size_t)15) + newton_quad_shared_bytes<KP>(PM, NTmax);
 }
 
 // One series, start to finish, by one wave.  Mp: Z^T Z of the series' grid (aligned panels: the
 // shared one; ragged panels: built here into Mown, this block's slot of global memory).
 template <int KP, bool RAGGED>
-__device__ __forceinline__ void newton_one_quad(const QuadArgs &qa, NewtonQuadLds<KP> &lds, double *rb,
+__device__ __forceinline__ void newton_one_quad(const QuadArgs &qa, NewtonQuadLds<KP> &lds,
+                                                QuadLds<KP, 1> &wl, double *rb,
                                                 double *Am, double *Vm, int PM, const double *Mp,
                                                 double *Mown, int64_t n)
 {
     constexpr int PPL = 1;
     const FitArgs &a = qa.f;
-    QuadLds<KP, PPL> &wl = lds.q;
     const int lane = lane_id();
     const DevSpec *sp = a.sp;
     SeriesView sv;
@@ -79,16 +96,17 @@ __device__ __forceinline__ void newton_one_quad(const QuadArgs &qa, NewtonQuadLd
         sv.n_eval++;
         if (stage == S_INIT || stage == S_F0) {
             double sse_e, ztr_e[PPL];
+            wl.th[W + lane] = 0.0;      // theta of a pass is zero beyond P (the region held the matrix)
             bad = resid_eval_q<KP, PPL>(sv, wl, lk, rb, x, fx, gx, sse_e, ztr_e);
             if (!bad && stage == S_F0) {
                 // the accepted point becomes the reference of the quadratic form (cn_set_ref)
-                wl.ref[lane] = (lane == 2) ? 0.0 : x[0];
-                wl.cvec[lane] = (lane == 2) ? 0.0 : ztr_e[0];
+                lds.ref[lane] = (lane == 2) ? 0.0 : x[0];
+                lds.cvec[lane] = (lane == 2) ? 0.0 : ztr_e[0];
                 s0 = sse_e;
                 wave_sync();
             }
         } else {
-            bad = gram_eval_q<PPL, 0>(sv, lk, Mp, qa.P4, x, wl.ref, wl.cvec, s0, fx, gx, q2, wl.th);
+            bad = gram_eval_q<PPL, 0>(sv, lk, Mp, qa.P4, x, lds.ref, lds.cvec, s0, fx, gx, q2, nullptr);
         }
         bool finish_iter = false, moved = false;
         if (stage == S_INIT) {
@@ -110,7 +128,7 @@ __device__ __forceinline__ void newton_one_quad(const QuadArgs &qa, NewtonQuadLd
             // in the sums, hence the "+ 0.0").  Only the gradient is formed: for finite theta a
             // non-finite log_prob value comes with a non-finite gradient entry (sigma = 0 or inf).
             {
-                const double thl = th[0], refl = wl.ref[lane], cvl = wl.cvec[lane];
+                const double thl = th[0], refl = lds.ref[lane], cvl = lds.cvec[lane];
                 const double lcl = lk.lc[lane], scl = lk.sc[lane];
                 const double Td = (double)sv.T;
                 // sigma terms of the centre (every point except the four that perturb log sigma)
@@ -210,24 +228,24 @@ __device__ __forceinline__ void newton_one_quad(const QuadArgs &qa, NewtonQuadLd
 // persistent one-wave workgroups pulling series from a queue (the longest series needs ~7x the
 // mean number of evaluations)
 template <int KP, bool RAGGED>
-__global__ __launch_bounds__(64) void newton_quad_kernel(QuadArgs qa, int PM)
+__global__ __launch_bounds__(64, (KP <= 16 ? TSF_NEWTON_QUAD_WPS : 1)) void newton_quad_kernel(QuadArgs qa, int PM)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const FitArgs &a = qa.f;
     NewtonQuadLds<KP> &lds = *reinterpret_cast<NewtonQuadLds<KP> *>(smem);
-    double *rb = reinterpret_cast<double *>(smem + ((sizeof(NewtonQuadLds<KP>) + 15) & ~(size_t)15));
-    double *Am = rb + (size_t)a.NTmax * W;
+    unsigned char *shared = smem + ((sizeof(NewtonQuadLds<KP>) + 15) & ~(size_t)15);
+    QuadLds<KP, 1> &wl = *reinterpret_cast<QuadLds<KP, 1> *>(shared);      // residual-pass scratch ...
+    double *rb = reinterpret_cast<double *>(shared + sizeof(QuadLds<KP, 1>));
+    double *Am = reinterpret_cast<double *>(shared);                          // ... and the matrix, same bytes
     double *Vm = Am;          // ql_lds leaves the eigenvectors where the matrix was
     const int lane = lane_id();
     double *Mown = RAGGED ? qa.Mslot + (size_t)blockIdx.x * qa.P4 * W : nullptr;
-    for (int i = lane; i < 2 * W; i += W) lds.q.th[i] = 0.0;
-    wave_sync();
     for (;;) {
         // every lane takes part in the fetch (see fit_quad_kernel)
         int n32 = atomicAdd(qa.counter, lane == 0 ? 1 : 0);
         n32 = __builtin_amdgcn_readfirstlane(n32);
         if (n32 >= a.N) break;
-        newton_one_quad<KP, RAGGED>(qa, lds, rb, Am, Vm, PM, qa.Mg, Mown, n32);
+        newton_one_quad<KP, RAGGED>(qa, lds, wl, rb, Am, Vm, PM, qa.Mg, Mown, n32);
     }
 }
 
