@@ -797,3 +797,130 @@ def test_uncertainty_intervals_match_the_seeded_oracle(env, case):
                                        extra_future=exf, series_key=keys, uncertainty_samples=200,
                                        interval_width=0.95, seed=43)
     assert not np.array_equal(lo3, lo) and ((hi3 - lo3).mean(axis=1) > (hi - lo).mean(axis=1)).all()
+
+
+def test_randomised_model_shapes_against_oracle(env):
+    """A seeded sweep over model shapes the fixed cases do not enumerate: history length 8 .. 1 500
+    rows (1 .. 24 rows per lane), 0 .. 30 changepoints, any subset of daily / weekly / yearly terms of
+    random order (8-, 16-, 28- and 64-column kernels, one and two parameters per lane), both growths,
+    both column modes, forced and automatic evaluation forms, both residual kernels, truncated and
+    full runs: status, iteration and evaluation counts, objective and parameters bit for bit."""
+    fc, cl = env
+    from time_series_spark_amd import _lib, synth
+    rng = np.random.default_rng(20260923)
+    n_cases = 0
+    for trial in range(36):
+        growth = 'logistic' if rng.random() < 0.5 else 'linear'
+        mode = 'multiplicative' if rng.random() < 0.5 else 'additive'
+        T = int(rng.choice([8, 30, 64, 65, 99, 128, 200, 365, 513, 730, 1100, 1500]))
+        seas = []
+        if rng.random() < 0.8:
+            seas.append({'name': 'weekly', 'period': 7, 'fourier_order': int(rng.integers(1, 4))})
+        if T >= 200 and rng.random() < 0.6:
+            seas.append({'name': 'yearly', 'period': 365.25, 'fourier_order': int(rng.integers(1, 13))})
+        if rng.random() < 0.25:
+            seas.append({'name': 'monthly', 'period': 30.5, 'fourier_order': int(rng.integers(1, 6))})
+        if not seas:
+            seas.append({'name': 'weekly', 'period': 7, 'fourier_order': 2})
+        n_cp = int(rng.choice([0, 1, 3, 10, 25, 30]))
+        if trial % 9 == 4:      # 40 design columns, 68 parameters: the two-parameters-per-lane kernels
+            T = max(T, 365)
+            seas = [{'name': 'weekly', 'period': 7, 'fourier_order': 3},
+                    {'name': 'yearly', 'period': 365.25, 'fourier_order': 12},
+                    {'name': 'monthly', 'period': 30.5, 'fourier_order': 5}]
+            n_cp = 25
+        kw = dict(growth=growth, seasonality_mode=mode, seasonalities=seas, n_changepoints=n_cp,
+                  max_iter=int(rng.choice([5, 40, 10000])))
+        K = 2 * sum(s['fourier_order'] for s in seas)
+        linear_additive = growth == 'linear' and mode == 'additive'
+        if linear_additive and rng.random() < 0.3:
+            kw['eval_form'] = _lib.EVAL_RESIDUAL
+        residual = not linear_additive or kw.get('eval_form') == _lib.EVAL_RESIDUAL
+        if residual and K <= 28 and 3 + n_cp + K <= 64 and n_cp <= 28 and rng.random() < 0.4:
+            kw['residual_kernel'] = _lib.RK_MFMA
+        N = int(rng.integers(1, 5))
+        ds, y = synth.make_panel(N, T, growth, seed=1000 + trial)
+        fit_kw = {}
+        if growth == 'logistic':
+            fit_kw = dict(floor=np.zeros(N), cap=y.max(axis=1) * (1.05 + 0.5 * rng.random()))
+        spec = fc.ModelSpec(**kw)
+        try:
+            r = fc.fit_aligned(spec, ds, y, **fit_kw)
+        except _lib.TsfError as e:          # a shape the matrix-core kernel declines: the one-wave kernel takes it
+            assert 'MFMA' in str(e), e
+            kw.pop('residual_kernel')
+            spec = fc.ModelSpec(**kw)
+            r = fc.fit_aligned(spec, ds, y, **fit_kw)
+        csp = helpers.oracle_spec(spec)
+        for n in range(N):
+            o = cl.fit(csp, ds, y[n], 0.0, fit_kw['cap'][n] if fit_kw else 0.0)
+            S = o['info'].S
+            ctx = (trial, n, kw, T)
+            assert (r.status[n], r.n_iter[n], r.n_eval[n]) == (o['status'], o['n_iter'], o['n_eval']), ctx
+            assert n_bit_diff(r.fval[n], o['f']) == 0, ctx
+            assert n_bit_diff(r.theta[n][:3 + S], o['theta'][:3 + S]) == 0, ctx
+            assert n_bit_diff(r.theta[n][3 + spec.n_changepoints:], o['theta'][3 + S:]) == 0, ctx
+            n_cases += 1
+        # the same series through the ragged entry point (own timestamps per series: drop a few rows)
+        if trial % 3 == 0 and T >= 30:
+            keep = [np.sort(rng.choice(T, size=T - int(rng.integers(0, 4)), replace=False)) for _ in range(N)]
+            offs = np.concatenate([[0], np.cumsum([len(k) for k in keep])]).astype(np.int64)
+            dsr = np.concatenate([ds[k] for k in keep])
+            yr = np.concatenate([y[n][k] for n, k in enumerate(keep)])
+            kwr = {k: v for k, v in kw.items() if k != 'residual_kernel'}
+            specr = fc.ModelSpec(**kwr)
+            rr = fc.fit_ragged(specr, offs, dsr, yr, **fit_kw)
+            cspr = helpers.oracle_spec(specr)
+            for n in range(N):
+                o = cl.fit(cspr, ds[keep[n]], y[n][keep[n]], 0.0, fit_kw['cap'][n] if fit_kw else 0.0)
+                S = o['info'].S
+                assert (rr.status[n], rr.n_iter[n], rr.n_eval[n]) == (o['status'], o['n_iter'], o['n_eval']), (trial, n, 'ragged')
+                assert n_bit_diff(rr.theta[n][:3 + S], o['theta'][:3 + S]) == 0, (trial, n, 'ragged')
+                n_cases += 1
+    assert n_cases >= 80
+
+
+def test_randomised_newton_shapes_against_oracle(env):
+    """The same for Stan's Newton (fbprophet's optimiser below 100 rows): 12 .. 99 rows, 0 .. 25
+    changepoints (3 .. 46 parameters: eigen-problems of every size), weekly terms of any order, both
+    growths and modes (quadratic-form and residual-form kernels), aligned and ragged."""
+    fc, cl = env
+    from time_series_spark_amd import _lib, synth
+    rng = np.random.default_rng(90)
+    n_cases = 0
+    for trial in range(14):
+        growth = 'logistic' if trial % 3 == 1 else 'linear'
+        mode = 'multiplicative' if trial % 4 == 2 else 'additive'
+        T = int(rng.choice([12, 25, 40, 60, 77, 99]))
+        seas = [{'name': 'weekly', 'period': 7, 'fourier_order': int(rng.integers(1, 4))}]
+        if rng.random() < 0.3:
+            seas.append({'name': 'monthly', 'period': 30.5, 'fourier_order': int(rng.integers(1, 4))})
+        n_cp = int(rng.choice([0, 2, 8, 25]))
+        spec = fc.ModelSpec(growth=growth, seasonality_mode=mode, seasonalities=seas, n_changepoints=n_cp,
+                            algorithm=_lib.ALGO_NEWTON, max_iter=int(rng.choice([3, 40, 10000])))
+        N = int(rng.integers(1, 4))
+        ds, y = synth.make_panel(N, T, growth, seed=2000 + trial)
+        floor, cap = np.zeros(N), y.max(axis=1) * 1.15
+        res = fc.fit_aligned(spec, ds, y, floor=floor, cap=cap)
+        csp = helpers.oracle_spec(spec)
+        for n in range(N):
+            o = cl.fit_newton(csp, ds, y[n], floor[n], cap[n])
+            S = o['info'].S
+            ctx = (trial, n, growth, mode, T, n_cp)
+            assert (res.status[n], res.n_iter[n], res.n_eval[n]) == (o['status'], o['n_iter'], o['n_eval']), ctx
+            assert n_bit_diff(res.theta[n][:3 + S], o['theta'][:3 + S]) == 0, ctx
+            assert n_bit_diff(res.theta[n][3 + spec.n_changepoints:], o['theta'][3 + S:]) == 0, ctx
+            assert res.fval[n] == o['f'], ctx
+            n_cases += 1
+        if trial % 2 == 0 and T >= 25:      # ragged: truncated copies, each its own grid
+            cut = [T - int(rng.integers(0, 9)) for _ in range(N)]
+            off = np.concatenate([[0], np.cumsum(cut)]).astype(np.int64)
+            rr = fc.fit_ragged(spec, off, np.concatenate([ds[:c] for c in cut]),
+                               np.concatenate([y[i][:c] for i, c in enumerate(cut)]), floor=floor, cap=cap)
+            for n in range(N):
+                o = cl.fit_newton(csp, ds[:cut[n]], y[n][:cut[n]], floor[n], cap[n])
+                S = o['info'].S
+                assert (rr.status[n], rr.n_iter[n], rr.n_eval[n]) == (o['status'], o['n_iter'], o['n_eval']), (trial, n, 'ragged')
+                assert n_bit_diff(rr.theta[n][:3 + S], o['theta'][:3 + S]) == 0, (trial, n, 'ragged')
+                n_cases += 1
+    assert n_cases >= 30
