@@ -1,4 +1,6 @@
-// tsf_inst_quad.hip -- instantiates the quadratic-form fit path (tsf_quad_kernels.h).
+// tsf_inst_quad.hip -- instantiates the quadratic-form fit path (tsf_quad_kernels.h): ragged panels,
+// the two-slot kernel, Newton.  Built with -mllvm -disable-machine-licm like tsf_inst_quad3.hip (the
+// reason is at the top of that file: hoisted fp64 literals end up in scratch).
 #include "tsf_quad_launch.h"
 #include "tsf_newton_quad.h"
 

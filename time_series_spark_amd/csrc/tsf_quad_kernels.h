@@ -34,8 +34,12 @@ namespace tsf {
 
 constexpr int QH = 5;                   // L-BFGS history of the register-resident path
 // waves per SIMD the kernels are compiled for (register budget 512 / this per lane): 3 for the
-// shared-M kernel with its L-BFGS history in LDS (HLDS: <= 168 VGPRs, 12 waves per CU), else 2
-constexpr int quad_waves_per_simd(bool hlds) { return hlds ? 3 : 2; }
+// shared-M one-slot kernel (<= 168 VGPRs, 12 waves per CU), else 2.  Every variant with LDS to spare
+// keeps its L-BFGS history in an LDS ring (HLDS); the ragged variant with a private Z^T Z per wave in
+// LDS has none left and keeps it in registers
+constexpr int quad_waves_per_simd(bool w3) { return w3 ? 3 : 2; }
+// the kernel variant that is: shared M in LDS, one parameter per lane, L-BFGS history in LDS
+constexpr bool quad_three_waves(int mmode, int ppl, bool hlds) { return hlds && mmode == 0 && ppl == 1; }
 
 struct QuadArgs {
     FitArgs f;
@@ -499,7 +503,7 @@ __global__ __launch_bounds__(64) void gram_build_kernel(QuadArgs qa, double *Mou
 // HLDS: the L-BFGS history lives in the wave's LDS ring `hist` ([2][QH][PPL][64]: s then y, slot of
 // age h = (h0 + h) mod QH) instead of 4 QH PPL registers per lane -- what lets a third wave per
 // SIMD fit the register file (tsf_inst_quad.hip); same values, same operation order.
-template <int KP, int PPL, int PQ, bool RAGGED, int MRS = W, bool HLDS = false>
+template <int KP, int PPL, int PQ, bool RAGGED, int MRS = W, bool HLDS = false, int MBATCH = 16>
 __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL> &wl, double *rb,
                                           const double *Mp, double *Mown, int64_t n, double *lanec,
                                           double *hist = nullptr)
@@ -581,13 +585,51 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
     double gp = 0.0;
     bool gp_valid = false, pk1_scaled = false;
 
-    enum { ST_INIT = 0, ST_START_ITER, ST_START_LS, ST_LS_PRE, ST_LS_EVAL, ST_RECENTER, ST_POST };
-    int stage = ST_INIT;
     QT_DECL;
     const int eval_limit = 64 * a.opt.max_iter + 1024;      // guard, see cn_lbfgs (oracle)
+    // Residual-form evaluation at xk (cn_resid_q): the initial point, and a re-centring of the
+    // quadratic form at an accepted iterate.  When it is finite it becomes the reference point.
+    auto recenter = [&](double &fe_out) -> bool {
+        double xe[PPL], ge[PPL], fe, sse_e, ztr_e[PPL];
+#pragma unroll
+        for (int s = 0; s < PPL; ++s) xe[s] = xk[s];
+        sv.n_eval++;
+        QT_LAP(2);
+        const bool bad = resid_eval_q<KP, PPL>(sv, wl, lk, rb, xe, fe, ge, sse_e, ztr_e);
+        QT_LAP(3);
+        if (!bad) {
+#pragma unroll
+            for (int s = 0; s < PPL; ++s) {
+                const int p = lane + s * W;
+                wl.ref[p] = (p == 2) ? 0.0 : xe[s];
+                wl.cvec[p] = ztr_e[s];
+                gk[s] = ge[s];
+            }
+            s0 = sse_e; since_rc = 0; fk = UQ(fe);
+            wave_sync();
+        }
+        fe_out = fe;
+        return bad;
+    };
+    // Structured as Stan's loops are (iterations > line searches > trials) rather than as a state
+    // machine around one evaluation site: the compiler then keeps the optimiser state in place
+    // instead of shuffling ~40 registers at the joins of the state machine's edges.  One pass of
+    // the outer loop = [residual pass at x_k: the initial point, or a re-centring] + [the L-BFGS
+    // update and the termination tests for x_k] + the line search from x_k; each evaluation form
+    // still has a single call site.
+    bool first = true, do_resid = true;
     for (;;) {
         QT_LAP(0);
-        if (stage == ST_POST) {
+        if (do_resid) {
+            double fe0;
+            const bool bad0 = recenter(fe0);
+            if (first && bad0) { ret = TSF_ST_INIT_NONFINITE; fk = UQ(fe0); break; }
+        }
+        if (first) {
+            first = false;
+#pragma unroll
+            for (int s = 0; s < PPL; ++s) { pk[s] = -gk[s]; gk1[s] = 0.0; xk1[s] = 0.0; }
+        } else {
             // ---- accepted step: k is the most recent iterate ----
             double sk[PPL], yk[PPL];
 #pragma unroll
@@ -707,16 +749,14 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
             else if (stepNorm < a.opt.tol_param) ret = TSF_ST_ABSX;
             else if (itNum >= a.opt.max_iter) ret = TSF_ST_MAXIT;
             else ret = 0;
+
             QT_LAP(1);
             if (ret != 0) break;
-            stage = ST_START_ITER;
         }
-        if (stage == ST_START_ITER) {
-            itNum++;
-            resetB = (itNum == 1) ? 1 : 0;
-            stage = ST_START_LS;
-        }
-        if (stage == ST_START_LS) {
+        itNum++;
+        resetB = (itNum == 1) ? 1 : 0;
+        bool accepted = false;
+        for (;;) {                                      // line search; once more from -g if it fails
             if (resetB) {
 #pragma unroll
                 for (int s = 0; s < PPL; ++s) pk[s] = -gk[s];
@@ -737,85 +777,57 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
             c1dfp = UQ(c1 * dfp); c2dfp = UQ(c2 * dfp);
             alpha0 = minAlpha; prevF = fk; prevDFp = dfp;
             nits = 0; lsRestarts = 0; zoom = 0; zit = 0;
-            stage = ST_LS_PRE;
-        }
-        bool ls_fail = false;
-        if (stage == ST_LS_PRE) {
-            if (!zoom) {
-                if (nits >= maxLSIts) ls_fail = true;
-            } else {
-                zit++;
-                if (__builtin_fabs(alo - ahi) < min_range) {
-                    ls_fail = true;
-                } else if (zit % 5 == 0) {
-                    alpha = UQ(0.5 * (alo + ahi));
-                } else {
-                    const double d1 = aloDFp + ahiDFp - 3.0 * (aloF - ahiF) / (alo - ahi);
-                    double d2 = __builtin_sqrt(d1 * d1 - aloDFp * ahiDFp);
-                    if (ahi < alo) d2 = -d2;
-                    alpha = ahi - (ahi - alo) * (ahiDFp + d2 - d1) / (ahiDFp - aloDFp + 2.0 * d2);
-                    const double lo = __builtin_fmin(alo, ahi), hi = __builtin_fmax(alo, ahi),
-                                 w = __builtin_fabs(alo - ahi);
-                    if (!finite_f64(alpha) || alpha < lo + 0.01 * w || alpha > hi - 0.01 * w)
-                        alpha = 0.5 * (alo + ahi);
-                    alpha = UQ(alpha);
-                }
-            }
-            if (!ls_fail) stage = ST_LS_EVAL;
-        }
-        if (!ls_fail) {
-            // ---- the single evaluation site ----
-            double xe[PPL], ge[PPL], fe;
-            bool bad;
-            QT_LAP(2);
-            if (stage == ST_INIT || stage == ST_RECENTER) {
-                double sse_e, ztr_e[PPL];
-#pragma unroll
-                for (int s = 0; s < PPL; ++s) xe[s] = xk[s];
-                sv.n_eval++;
-                bad = resid_eval_q<KP, PPL>(sv, wl, lk, rb, xe, fe, ge, sse_e, ztr_e);
-                QT_LAP(3);
-                if (!bad) {
-#pragma unroll
-                    for (int s = 0; s < PPL; ++s) {
-                        const int p = lane + s * W;
-                        wl.ref[p] = (p == 2) ? 0.0 : xe[s];
-                        wl.cvec[p] = ztr_e[s];
-                        gk[s] = ge[s];
+
+            bool ls_fail = false, pre = true;
+            for (;;) {                                  // trial points
+                if (pre) {
+                    if (!zoom) {
+                        if (nits >= maxLSIts) ls_fail = true;
+                    } else {
+                        zit++;
+                        if (__builtin_fabs(alo - ahi) < min_range) {
+                            ls_fail = true;
+                        } else if (zit % 5 == 0) {
+                            alpha = UQ(0.5 * (alo + ahi));
+                        } else {
+                            const double d1 = aloDFp + ahiDFp - 3.0 * (aloF - ahiF) / (alo - ahi);
+                            double d2 = __builtin_sqrt(d1 * d1 - aloDFp * ahiDFp);
+                            if (ahi < alo) d2 = -d2;
+                            alpha = ahi - (ahi - alo) * (ahiDFp + d2 - d1) / (ahiDFp - aloDFp + 2.0 * d2);
+                            const double lo = __builtin_fmin(alo, ahi), hi = __builtin_fmax(alo, ahi),
+                                         w = __builtin_fabs(alo - ahi);
+                            if (!finite_f64(alpha) || alpha < lo + 0.01 * w || alpha > hi - 0.01 * w)
+                                alpha = 0.5 * (alo + ahi);
+                            alpha = UQ(alpha);
+                        }
                     }
-                    s0 = sse_e; since_rc = 0; fk = UQ(fe);
-                    wave_sync();
+
+                    if (ls_fail) break;
                 }
-                if (stage == ST_INIT) {
-                    if (bad) { ret = TSF_ST_INIT_NONFINITE; fk = UQ(fe); break; }
+                pre = true;
+                if (sv.n_eval >= eval_limit) { ret = TSF_ST_EVAL_LIMIT; break; }
+                double xe[PPL], ge[PPL], fe;
 #pragma unroll
-                    for (int s = 0; s < PPL; ++s) { pk[s] = -gk[s]; gk1[s] = 0.0; xk1[s] = 0.0; }
-                    stage = ST_START_ITER;
-                } else {
-                    stage = ST_POST;
+                for (int s = 0; s < PPL; ++s) { xk1[s] = __builtin_fma(alpha, pk[s], xk[s]); xe[s] = xk1[s]; }
+                sv.n_eval++;
+                QT_LAP(2);
+                const bool bad = gram_eval_q<PPL, PQ, MRS, MBATCH>(sv, lk, Mp, P4, xe, wl.ref, wl.cvec, s0, fe, ge, q2, wl.th);
+                QT_LAP(4);
+#pragma unroll
+                for (int s = 0; s < PPL; ++s) gk1[s] = ge[s];
+                const double f1 = UQ(fe);
+                if (bad) {
+                    if (!zoom) {
+                        if (lsRestarts >= maxLSRestarts) ls_fail = true;
+                        else { alpha = UQ(0.5 * (alpha0 + alpha)); lsRestarts++; }
+                    } else {
+                        alpha = UQ(0.5 * (alpha + __builtin_fmin(alo, ahi)));
+                        if (__builtin_fabs(__builtin_fmin(alo, ahi) - alpha) < min_range) ls_fail = true;
+                    }
+                    if (ls_fail) break;
+                    pre = false;                        // re-evaluate at the shortened step
+                    continue;
                 }
-                continue;
-            }
-            if (sv.n_eval >= eval_limit) { ret = TSF_ST_EVAL_LIMIT; break; }
-#pragma unroll
-            for (int s = 0; s < PPL; ++s) { xk1[s] = __builtin_fma(alpha, pk[s], xk[s]); xe[s] = xk1[s]; }
-            sv.n_eval++;
-            bad = gram_eval_q<PPL, PQ, MRS, (HLDS ? 8 : 16)>(sv, lk, Mp, P4, xe, wl.ref, wl.cvec, s0, fe, ge, q2, wl.th);
-            QT_LAP(4);
-#pragma unroll
-            for (int s = 0; s < PPL; ++s) gk1[s] = ge[s];
-            const double f1 = UQ(fe);
-            if (bad) {
-                if (!zoom) {
-                    if (lsRestarts >= maxLSRestarts) ls_fail = true;
-                    else { alpha = UQ(0.5 * (alpha0 + alpha)); lsRestarts++; }
-                } else {
-                    alpha = UQ(0.5 * (alpha + __builtin_fmin(alo, ahi)));
-                    if (__builtin_fabs(__builtin_fmin(alo, ahi) - alpha) < min_range) ls_fail = true;
-                }
-                if (!ls_fail) continue;            // re-evaluate at the shortened step
-            }
-            if (!ls_fail) {
                 const double newDFp = pdot<PPL>(gk1, pk);
                 bool ls_ok = false;
                 if (!zoom) {
@@ -843,24 +855,24 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
                         alo = alpha; aloF = f1; aloDFp = newDFp;
                     }
                 }
-                if (!ls_ok) { stage = ST_LS_PRE; continue; }
-                fk1 = f1;
-                { const double tf = fk; fk = fk1; fk1 = tf; }
-#pragma unroll
-                for (int s = 0; s < PPL; ++s) {
-                    const double tx = xk[s]; xk[s] = xk1[s]; xk1[s] = tx;
-                    const double tg = gk[s]; gk[s] = gk1[s]; gk1[s] = tg;
-                    const double tp = pk[s]; pk[s] = pk1[s]; pk1[s] = tp;
-                }
-                since_rc++;
-                stage = (q2 > qa.recenter_ratio * s0 || since_rc >= qa.recenter_every) ? ST_RECENTER : ST_POST;
-                continue;
+                if (ls_ok) { fk1 = f1; accepted = true; break; }
             }
+            if (accepted || ret != 0) break;
+            // line search failed
+            if (resetB) { ret = TSF_ST_LSFAIL; break; }
+            resetB = 2;
         }
-        // line search failed
-        if (resetB) { ret = TSF_ST_LSFAIL; break; }
-        resetB = 2;
-        stage = ST_START_LS;
+        if (!accepted) break;
+        // ---- accepted step: k becomes the most recent iterate ----
+        { const double tf = fk; fk = fk1; fk1 = tf; }
+#pragma unroll
+        for (int s = 0; s < PPL; ++s) {
+            const double tx = xk[s]; xk[s] = xk1[s]; xk1[s] = tx;
+            const double tg = gk[s]; gk[s] = gk1[s]; gk1[s] = tg;
+            const double tp = pk[s]; pk[s] = pk1[s]; pk1[s] = tp;
+        }
+        since_rc++;
+        do_resid = q2 > qa.recenter_ratio * s0 || since_rc >= qa.recenter_every;
     }
     store_theta<PPL>(a, sv, n, xk, a.theta);
     if (lane == 0) { a.status[n] = ret; a.n_iter[n] = itNum; a.n_eval[n] = sv.n_eval; a.fval[n] = fk; }
@@ -878,7 +890,7 @@ template <int PPL>
 constexpr size_t quad_hist_bytes(bool hlds) { return hlds ? sizeof(double) * 2 * QH * PPL * W : 0; }
 
 template <int KP, int PPL, int NW, int MMODE, int PQ, bool RLDS, bool HLDS = false>
-__global__ __launch_bounds__(NW * 64, quad_waves_per_simd(HLDS)) void fit_quad_kernel(QuadArgs qa)
+__global__ __launch_bounds__(NW * 64, quad_waves_per_simd(quad_three_waves(MMODE, PPL, HLDS))) void fit_quad_kernel(QuadArgs qa)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const FitArgs &a = qa.f;
@@ -929,7 +941,8 @@ __global__ __launch_bounds__(NW * 64, quad_waves_per_simd(HLDS)) void fit_quad_k
         n32 = __builtin_amdgcn_readfirstlane(n32);
         const int64_t n = n32;
         if (n >= a.N) break;
-        fit_one_quad<KP, PPL, PQ, MMODE == QM_RAGGED || MMODE == QM_RAGGED_LDS, MRS, HLDS>(qa, wl, rb, Mp, Mown, n, lanec, hist);
+        fit_one_quad<KP, PPL, PQ, MMODE == QM_RAGGED || MMODE == QM_RAGGED_LDS, MRS, HLDS,
+                     (quad_three_waves(MMODE, PPL, HLDS) ? 8 : 16)>(qa, wl, rb, Mp, Mown, n, lanec, hist);
     }
 }
 

@@ -21,12 +21,12 @@
 
 namespace tsf {
 
-// waves per workgroup of the kernel variant: the shared-M one-slot kernel keeps its L-BFGS history
-// in LDS and runs 12 waves per CU; the others (registers: 2 waves per SIMD) 8, the two-slot kernel 4
+// waves per workgroup of the kernel variant: the shared-M one-slot kernel runs 12 waves per CU (three
+// per SIMD); the others (two per SIMD) 8, the two-slot kernel 4
 template <int PPL, int MMODE>
 struct QuadShape {
-    static constexpr bool HL = (MMODE == QM_LDS) && PPL == 1;
-    static constexpr int NW = (PPL == 2) ? TSF_QUAD_NW2 : (HL ? TSF_QUAD_NW3 : TSF_QUAD_NW);
+    static constexpr bool HL = true;        // L-BFGS history in LDS (these variants have the room)
+    static constexpr int NW = (PPL == 2) ? TSF_QUAD_NW2 : (quad_three_waves(MMODE, PPL, HL) ? TSF_QUAD_NW3 : TSF_QUAD_NW);
 };
 
 template <int KP, int PPL, int MMODE, int PQ, bool RLDS>
