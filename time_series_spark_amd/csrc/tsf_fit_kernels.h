@@ -20,7 +20,35 @@ struct SeriesView {
     const double *t_change;
     double cap, tau;
     int n_eval;
+    // Lane-resident copies of the per-series tables an evaluation needs (set_lane_tables): read from
+    // global memory once per series -- inside the evaluation each of them was a dependent load at the
+    // head of a serial chain (measured on a lone wave: 18 k of the 46 k cycles of an evaluation were
+    // the set-up and the tail, section 5 of DESIGN.md).  p = lane + 64 s.
+    double tc_l;                        // t_change[lane]            (0 for lane >= S)
+    int Lj_l, Ljm1_l;                   // Lj[lane] (lane < S), Lj[lane - 1] (1 <= lane <= S); else 0
+    double prior_l[2];                  // prior scale of design column p - 3 - S (1 where p is no beta)
+    int Ljp_l[2];                       // Lj[p - 3], t_change[p - 3] where p is a delta (else 0)
+    double tcp_l[2];
 };
+
+template <int PPL>
+__device__ __forceinline__ void set_lane_tables(const DevSpec *sp, SeriesView &sv)
+{
+    const int lane = (int)threadIdx.x & (W - 1);
+    const int S = sv.S;
+    sv.tc_l = (lane < S) ? sv.t_change[lane] : 0.0;
+    sv.Lj_l = (lane < S) ? sv.Lj[lane] : 0;
+    sv.Ljm1_l = (lane >= 1 && lane <= S) ? sv.Lj[lane - 1] : 0;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        sv.prior_l[s] = 1.0; sv.Ljp_l[s] = 0; sv.tcp_l[s] = 0.0;
+        if (s < PPL) {
+            const int p = lane + s * W;
+            if (p >= 3 + S && p < sv.P) sv.prior_l[s] = sp->prior[p - 3 - S];
+            if (p >= 3 && p < 3 + S) { sv.Ljp_l[s] = sv.Lj[p - 3]; sv.tcp_l[s] = sv.t_change[p - 3]; }
+        }
+    }
+}
 
 // LDS carve-up for one wave
 template <int KP, int PPL>
@@ -48,6 +76,20 @@ __device__ __forceinline__ double theta_at(const double (&th)[PPL], int p)
     if (PPL == 1) return readlane_f64(th[0], p);
     return (p < W) ? readlane_f64(th[0], p) : readlane_f64(th[PPL - 1], p - W);
 }
+
+#ifdef TSF_FIT_TIMING      // dev only: cycles per phase of fit_kernel (s_memtime), summed per series
+#define FT_DECL long long ft_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long ft_t0 = __builtin_readcyclecounter(), ft_start = ft_t0
+#define FT_LAP(k) do { const long long t_ = __builtin_readcyclecounter(); ft_acc[k] += t_ - ft_t0; ft_t0 = t_; } while (0)
+#define FT_FLUSH(dst, n) do { if ((dst) && lane_id() == 0) { ft_acc[7] = __builtin_readcyclecounter() - ft_start; for (int k_ = 0; k_ < 8; ++k_) ((long long *)(dst))[(size_t)(n) * 8 + k_] = ft_acc[k_]; } } while (0)
+#define FT_ARGS , long long (&ft_acc)[8], long long &ft_t0
+#define FT_PASS , ft_acc, ft_t0
+#else
+#define FT_DECL do { } while (0)
+#define FT_LAP(k) do { } while (0)
+#define FT_FLUSH(dst, n) do { } while (0)
+#define FT_ARGS
+#define FT_PASS
+#endif
 
 // Column sums ACC_j = sum over the 64 chunk partials acc[j], as a butterfly with offsets
 // 32, 16, 1, 2, 4, 8, done for all KP columns at once: the 32- and 16-stages transpose pairs of
@@ -80,6 +122,13 @@ __device__ __forceinline__ void column_sums(double (&acc)[KP], L &lds)
     }
 }
 
+// Ascending / descending loop over a run-time range, body written out four times per trip: the
+// recurrences over the changepoints read lanes (v_readlane is convergent, so the compiler does not
+// unroll such loops by itself); unrolled, the lane reads of the next steps issue ahead of the chain
+// and three of four taken branches disappear.
+#define TSF_UNROLL4_UP(j, lo, hi, BODY) do { int j = (lo); for (; j + 4 <= (hi); ) { BODY; ++j; BODY; ++j; BODY; ++j; BODY; ++j; } for (; j < (hi); ++j) { BODY; } } while (0)
+#define TSF_UNROLL4_DOWN(c, hi, lo, BODY) do { int c = (hi); for (; c - 3 >= (lo); ) { BODY; --c; BODY; --c; BODY; --c; BODY; --c; } for (; c >= (lo); --c) { BODY; } } while (0)
+
 // Segment tables ks[c], mc[c] (slope and offset of trend segment c): sequential recurrences over
 // the changepoints.  Every lane runs the same S steps and lane c stops updating after its first c
 // terms, so lane c ends with exactly the sequentially rounded ks[c], mc[c] (no per-step LDS write /
@@ -91,30 +140,30 @@ __device__ __forceinline__ void segment_tables(const SeriesView &sv, L &lds, con
     const int S = sv.S;
     const double k = theta_at<PPL>(th, 0), m = theta_at<PPL>(th, 1);
     double ksv = k, mcv = m;
-    const double tcl = (lane < S) ? sv.t_change[lane] : 0.0;
+    const double tcl = sv.tc_l;
     if (GROWTH == 0) {
-        for (int j = 0; j < S; ++j) {
+        TSF_UNROLL4_UP(j, 0, S, {
             const double dj = theta_at<PPL>(th, 3 + j);
             const double ksn = ksv + dj;
             const double mcn = mcv + ((-readlane_f64(tcl, j)) * dj);
             if (j < lane) { ksv = ksn; mcv = mcn; }
-        }
+        });
     } else {
         // logistic: gamma_j needs ks[j] / ks[j+1].  ks does not depend on mc, so the ks chain
         // runs first, the S quotients are ONE lane-parallel division (lane j: ks[j]/ks[j+1],
         // the operands of the sequential form), and the mc chain reads them by lane.
         double ks_next = k;
-        for (int j = 0; j < S; ++j) {
+        TSF_UNROLL4_UP(j, 0, S, {
             const double ksn = ksv + theta_at<PPL>(th, 3 + j);
             if (j == lane) ks_next = ksn;
             if (j < lane) ksv = ksn;
-        }
+        });
         const double ratio = ksv / ks_next;
-        for (int j = 0; j < S; ++j) {
+        TSF_UNROLL4_UP(j, 0, S, {
             const double gamma = (readlane_f64(tcl, j) - mcv) * (1.0 - readlane_f64(ratio, j));
             const double mcn = mcv + gamma;
             if (j < lane) mcv = mcn;
-        }
+        });
     }
     if (lane <= S) { lds.ks[lane] = ksv; lds.mc[lane] = mcv; }
 }
@@ -140,7 +189,7 @@ __device__ __forceinline__ bool eval_tail(const DevSpec *__restrict__ sp, const 
     for (int s = 0; s < PPL; ++s) {
         const int p = lane + s * W;
         if (p >= 3 && p < 3 + S) pa = pa + __builtin_fabs(th[s]);
-        if (p >= 3 + S && p < sv.P) { const double qq = th[s] / sp->prior[p - 3 - S]; pb = __builtin_fma(qq, qq, pb); }
+        if (p >= 3 + S && p < sv.P) { const double qq = th[s] / sv.prior_l[s]; pb = __builtin_fma(qq, qq, pb); }
     }
     const double sabs = bfly_sum(pa), sb = bfly_sum(pb);
     const double s2 = sigma * sigma;
@@ -156,7 +205,7 @@ __device__ __forceinline__ bool eval_tail(const DevSpec *__restrict__ sp, const 
     if (GROWTH == 1) {
         // per-segment sums from suffix sums, then reverse sweep through the gamma recurrence
         for (int c = lane; c <= S; c += W) {
-            const int Ljm = (c > 0) ? sv.Lj[c - 1] : 0, Ljc = (c < S) ? sv.Lj[c] : 0;
+            const int Ljm = (c > 0) ? sv.Ljm1_l : 0, Ljc = (c < S) ? sv.Lj_l : 0;     // c == lane (S < 64)
             const double hiA = (c == 0) ? TA : lds.tp1[c - 1] + lds.tot1[Ljm + 1];
             const double hiB = (c == 0) ? TB : lds.tp2[c - 1] + lds.tot2[Ljm + 1];
             const double loA = (c == S) ? 0.0 : lds.tp1[c] + lds.tot1[Ljc + 1];
@@ -172,15 +221,15 @@ __device__ __forceinline__ bool eval_tail(const DevSpec *__restrict__ sp, const 
             // chain itself only multiplies and adds
             const int cl = lane <= S ? lane : S;
             const double ratio_l = (lane < S) ? lds.ks[cl] / lds.ks[cl + 1] : 0.0;
-            const double tmc_l = (lane < S) ? sv.t_change[cl] - lds.mc[cl] : 0.0;
+            const double tmc_l = (lane < S) ? sv.tc_l - lds.mc[cl] : 0.0;
             const double d2_l = scr.d2[cl];
             double abar = readlane_f64(d2_l, S);
             double rb_l = 0.0;                  // lane c keeps rb[c]; one LDS write after the chain
-            for (int c = S - 1; c >= 0; --c) {
+            TSF_UNROLL4_DOWN(c, S - 1, 0, {
                 const double rbc = abar * readlane_f64(tmc_l, c);
                 if (lane == c) rb_l = rbc;
                 abar = readlane_f64(d2_l, c) + abar * readlane_f64(ratio_l, c);
-            }
+            });
             if (lane < S) scr.rb[lane] = rb_l;
             gm = nis * abar;
         }
@@ -201,12 +250,11 @@ __device__ __forceinline__ bool eval_tail(const DevSpec *__restrict__ sp, const 
         // (ab[c] read once, lane c holding ab[c]; the chain takes it from there with v_readlane)
         const double ab_l = scr.ab[lane <= S ? lane : S];
         double sK = 0.0;
-        for (int c = S; c >= 1; --c) {
+        TSF_UNROLL4_DOWN(c, S, 1, {
             sK = sK + readlane_f64(ab_l, c);
-#pragma unroll
-            for (int s = 0; s < PPL; ++s)
-                if (lane + s * W == 3 + (c - 1)) g[s] = nis * sK;
-        }
+            if (lane == 3 + (c - 1)) g[0] = nis * sK;
+            if (PPL == 2 && lane + W == 3 + (c - 1)) g[PPL - 1] = nis * sK;
+        });
         gk = nis * (sK + readlane_f64(ab_l, 0));
     } else {
         gk = nis * TA;
@@ -224,10 +272,10 @@ __device__ __forceinline__ bool eval_tail(const DevSpec *__restrict__ sp, const 
             const int j = p - 3;
             double gd;
             if (GROWTH == 0) {
-                const int Lj = sv.Lj[j];
+                const int Lj = sv.Ljp_l[s];
                 const double SA = lds.tp1[j] + lds.tot1[Lj + 1];
                 const double SB = lds.tp2[j] + lds.tot2[Lj + 1];
-                gd = nis * (SA - sv.t_change[j] * SB);
+                gd = nis * (SA - sv.tcp_l[s] * SB);
             } else {
                 gd = g[s];
             }
@@ -236,7 +284,7 @@ __device__ __forceinline__ bool eval_tail(const DevSpec *__restrict__ sp, const 
             gv = gd + sgn / sv.tau;
         } else if (p < sv.P) {
             const int j = p - 3 - S;
-            const double pr = sp->prior[j];
+            const double pr = sv.prior_l[s];
             gv = nis * lds.accR[j] + th[s] / (pr * pr);
         }
         g[s] = gv;
@@ -253,7 +301,7 @@ __device__ __forceinline__ bool eval_tail(const DevSpec *__restrict__ sp, const 
 template <int KP, int GROWTH, int MODE, int PPL, bool XIDX = false, class L = WaveLds<KP, PPL>>
 __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesView &sv,
                                         L &lds, const double (&th)[PPL],
-                                        double &f_out, double (&g)[PPL])
+                                        double &f_out, double (&g)[PPL] FT_ARGS)
 {
     const int lane = lane_id();
     const int S = sv.S, NT = sv.NT, T = sv.T;
@@ -275,6 +323,7 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
         for (int j = 0; j < (HOLD ? KP : 1); ++j) bs[j] = (3 + S + j < PPL * W) ? theta_at<PPL>(th, 3 + S + j) : 0.0;
     }
     TSF_WAVE_SYNC();
+    FT_LAP(1);
 
     double sse = 0.0, rt1 = 0.0, rt2 = 0.0;
     double acc[KP];
@@ -359,6 +408,7 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
             for (int j = cprev; j < c; ++j) { lds.tp1[j] = rt1; lds.tp2[j] = rt2; }
         }
     }
+    FT_LAP(2);
     // reductions over the time axis
     const double sse_t = bfly_sum(sse);
     const double s1 = suffix_scan(rt1), s2v = suffix_scan(rt2);
@@ -366,7 +416,10 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
     if (lane == 0) { lds.tot1[W] = 0.0; lds.tot2[W] = 0.0; }
     column_sums<KP, PPL, L>(acc, lds);
     TSF_WAVE_SYNC();
-    return eval_tail<GROWTH, PPL>(sp, sv, lds, lds, th, sigma, inv_s2, sse_t, f_out, g);
+    FT_LAP(3);
+    const bool bad_ = eval_tail<GROWTH, PPL>(sp, sv, lds, lds, th, sigma, inv_s2, sse_t, f_out, g);
+    FT_LAP(4);
+    return bad_;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -472,6 +525,7 @@ __device__ __forceinline__ void make_view(const FitArgs &a, int64_t n, SeriesVie
     sv.cap = a.stab[n].cap;
     sv.tau = a.sp->tau;
     sv.n_eval = 0;
+    set_lane_tables<PPL>(a.sp, sv);
 }
 
 // theta (internal order, registers) -> caller layout [k,m,log sigma,delta[n_cp],beta[K]]
@@ -531,7 +585,8 @@ __global__ __launch_bounds__(64) void eval_kernel(FitArgs a)
     TSF_WAVE_SYNC();
     double x[PPL], g[PPL], f;
     load_theta<PPL>(a, sv, n, a.theta_in, x);
-    const bool bad = eval_fg<KP, GROWTH, MODE, PPL>(a.sp, sv, lds, x, f, g);
+    FT_DECL;
+    const bool bad = eval_fg<KP, GROWTH, MODE, PPL>(a.sp, sv, lds, x, f, g FT_PASS);
     store_theta<PPL, false>(a, sv, n, g, a.grad_out);
     if (threadIdx.x == 0) { a.fval[n] = f; a.status[n] = bad ? 1 : 0; }
 }
@@ -595,6 +650,7 @@ __global__ __launch_bounds__(64, TSF_FIT_WPS) void fit_kernel(FitArgs a)
 
     enum { ST_INIT = 0, ST_START_ITER, ST_START_LS, ST_LS_PRE, ST_LS_EVAL };
     int stage = ST_INIT;
+    FT_DECL;
     for (;;) {
         if (stage == ST_START_ITER) {
             itNum++;
@@ -654,7 +710,8 @@ __global__ __launch_bounds__(64, TSF_FIT_WPS) void fit_kernel(FitArgs a)
                 for (int s = 0; s < PPL; ++s) xk1[s] = __builtin_fma(alpha, pk[s], xk[s]);
             }
             double f1;
-            const bool bad = eval_fg<KP, GROWTH, MODE, PPL, XIDX>(sp, sv, lds, xk1, f1, gk1);
+            FT_LAP(0);
+            const bool bad = eval_fg<KP, GROWTH, MODE, PPL, XIDX>(sp, sv, lds, xk1, f1, gk1 FT_PASS);
             f1 = uniform_f64(f1);       // every lane holds the same bits: let the compiler know (scalar branches)
             if (stage == ST_INIT) {
                 if (bad) { ret = TSF_ST_INIT_NONFINITE; fk = f1; break; }
@@ -804,6 +861,8 @@ __global__ __launch_bounds__(64, TSF_FIT_WPS) void fit_kernel(FitArgs a)
     }
     store_theta<PPL>(a, sv, n, xk, a.theta);
     if (lane == 0) { a.status[n] = ret; a.n_iter[n] = itNum; a.n_eval[n] = sv.n_eval; a.fval[n] = fk; }
+    FT_LAP(0);
+    FT_FLUSH(a.grad_out, n);
 }
 
 }  // namespace tsf

@@ -205,6 +205,7 @@ __global__ __launch_bounds__(MT_NW * W) void fit_mfma_kernel(FitArgs a, MfmaTabs
     sv.P = 3 + sv.S + sp->K;
     sv.cnt = 0; sv.tw = nullptr; sv.yw = nullptr; sv.Xw = nullptr; sv.uw = nullptr; sv.Xu = nullptr; sv.cw = nullptr;
     sv.Lj = gt.Lj; sv.t_change = gt.info.t_change; sv.cap = 0.0; sv.tau = sp->tau; sv.n_eval = 0;
+    set_lane_tables<1>(sp, sv);
     const int S = sv.S, NG = mt.NG;
 
     // slot start: nothing fetched yet

@@ -219,7 +219,8 @@ __global__ __launch_bounds__(64) void newton_kernel(FitArgs a, int PM)
     int stage = S_INIT, ret = TSF_ST_MAXIT, it = 0, mI = 0, d = 0, pi = 0;
     double lp = 0.0, lastlp = 0.0, f0 = 0.0, f1 = 0.0, size = 2.0, acc = 0.0, fx = 0.0;
     for (;;) {
-        const bool bad = eval_fg<KP, GROWTH, MODE, PPL, false, NewtonLds<KP>>(sp, sv, lds, x, fx, gx);
+        FT_DECL;
+        const bool bad = eval_fg<KP, GROWTH, MODE, PPL, false, NewtonLds<KP>>(sp, sv, lds, x, fx, gx FT_PASS);
         bool finish_iter = false, moved = false;
         if (stage == S_INIT) {
             if (bad) { ret = TSF_ST_INIT_NONFINITE; lp = -fx; break; }

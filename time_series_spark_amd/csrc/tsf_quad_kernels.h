@@ -164,10 +164,10 @@ __device__ __forceinline__ void ztr_pass(const SeriesView &sv, QuadLds<KP, PPL> 
         if (p == 0) v = wl.tot1[0];
         else if (p == 1) v = wl.tot2[0];
         else if (p >= 3 && p < 3 + S) {
-            const int j = p - 3, Lj = sv.Lj[j];
+            const int j = p - 3, Lj = sv.Ljp_l[s];
             const double SA = wl.tp1[j] + wl.tot1[Lj + 1];
             const double SB = wl.tp2[j] + wl.tot2[Lj + 1];
-            v = SA - sv.t_change[j] * SB;
+            v = SA - sv.tcp_l[s] * SB;
         } else if (p >= 3 + S && p < sv.P) {
             v = wl.accR[p - 3 - S];
         }
@@ -297,7 +297,7 @@ __device__ __forceinline__ bool resid_eval_q(const SeriesView &sv, QuadLds<KP, P
     for (int s = 0; s < PPL; ++s) wl.th[lane + s * W] = th[s];
     {   // ks[c], mc[c]: lane c accumulates the first c terms in sequential order (see eval_fg)
         double ksv = readlane_f64(th[0], 0), mcv = readlane_f64(th[0], 1);
-        const double tcl = (lane < S) ? sv.t_change[lane] : 0.0;
+        const double tcl = sv.tc_l;
         for (int j = 0; j < S; ++j) {
             const double dj = theta_at<PPL>(th, 3 + j);
             const double ksn = ksv + dj;
@@ -444,6 +444,7 @@ __device__ __forceinline__ void make_view_q(const FitArgs &a, int64_t n, SeriesV
     sv.cap = 0.0;
     sv.tau = a.sp->tau;
     sv.n_eval = 0;
+    set_lane_tables<PPL>(a.sp, sv);
 }
 
 // ---------------------------------------------------------------------------------------
