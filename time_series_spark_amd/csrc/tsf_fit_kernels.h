@@ -310,7 +310,7 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
     constexpr bool HOLD = KP <= 32;
     sv.n_eval++;
     const double k = theta_at<PPL>(th, 0), m = theta_at<PPL>(th, 1), ls = theta_at<PPL>(th, 2);
-    const double sigma = dm_exp(ls);
+    const double sigma = dm_exp_sel(ls);
     const double inv_s2 = 1.0 / (sigma * sigma);
     if (!HOLD) {
 #pragma unroll
@@ -374,7 +374,7 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
                 gtr = __builtin_fma(ksc, ti, mcc);
             } else {
                 const double z = ksc * (ti - mcc);
-                const double e = dm_exp(-z);
+                const double e = dm_exp_sel(-z);     // branch-free: the chain can run beside the X.beta chain
                 const double sg = 1.0 / (1.0 + e);
                 gtr = sv.cap * sg;
                 qv = gtr * (1.0 - sg);

@@ -522,7 +522,7 @@ __global__ __launch_bounds__(MT_NW * W) void fit_mfma_kernel(FitArgs a, MfmaTabs
                 v.n_eval++;
                 double th[1] = {xk1};
                 const double ls = readlane_f64(xk1, 2);
-                v.sigma = dm_exp(ls);
+                v.sigma = dm_exp_sel(ls);
                 v.inv_s2 = 1.0 / (v.sigma * v.sigma);
                 segment_tables<GROWTH, PPL>(sv, slot, th);
             }
@@ -592,7 +592,7 @@ __global__ __launch_bounds__(MT_NW * W) void fit_mfma_kernel(FitArgs a, MfmaTabs
                                 gtr = __builtin_fma(ksc, ti, mcc);
                             } else {
                                 const double z = ksc * (ti - mcc);
-                                const double e = dm_exp(-z);
+                                const double e = dm_exp_sel(-z);
                                 const double sg = 1.0 / (1.0 + e);
                                 gtr = vo.cap * sg;
                                 qv = gtr * (1.0 - sg);
@@ -779,7 +779,7 @@ __global__ __launch_bounds__(MT_NW * W) void fit_mfma_kernel(FitArgs a, MfmaTabs
                         gtr = __builtin_fma(ksc, ti, mcc);
                     } else {
                         const double z = ksc * (ti - mcc);
-                        const double e = dm_exp(-z);
+                        const double e = dm_exp_sel(-z);
                         const double sg = 1.0 / (1.0 + e);
                         gtr = capj * sg;
                         qv = gtr * (1.0 - sg);
