@@ -195,6 +195,30 @@ def test_read_input_dataframe_hive_layout(tmp_path):
     assert str(df['y'].dtype) == 'int32' and str(df['ds'].dtype).startswith('datetime64')
 
 
+def test_input_discovery_follows_spark_rules(tmp_path):
+    """spark.read.csv(path) reads every non-hidden file under the path (prophet_modeler.py:102-116):
+    part files without an extension count, `_SUCCESS` / `.crc` files and `_temporary` directories do
+    not; a compressed part raises instead of being skipped silently."""
+    root = tmp_path / 'in'
+    for sid in (7, 12):
+        d = root / ('series_id=%d' % sid)
+        d.mkdir(parents=True)
+        (d / 'part-00000').write_text('1,2020-01-01 00:00:00,5\n1,2020-01-02 00:00:00,6\n')
+        (d / 'part-00001.csv').write_text('1,2020-01-03 00:00:00,7\n')
+        (d / '.part-00000.crc').write_text('x')
+    (root / '_SUCCESS').write_text('')
+    (root / '_temporary').mkdir()
+    (root / '_temporary' / 'part-00009').write_text('garbage')
+    files, part = pm.find_model_input(str(root))
+    assert [os.path.basename(f) for f in files] == ['part-00000', 'part-00001.csv'] * 2
+    assert part == [7, 7, 12, 12]
+    sid, did, ds, y = pm.read_model_input(files, str(root), part_sid=part)
+    assert sorted(set(sid.tolist())) == [7, 12] and len(y) == 6 and y.sum() == 36
+    (root / 'series_id=7' / 'part-00002.csv.gz').write_bytes(b'\x1f\x8b')
+    with pytest.raises(ValueError, match='compressed input file'):
+        pm.find_model_input(str(root))
+
+
 def test_shard_bounds_partition():
     for n, w in [(10, 3), (10000, 8), (7, 8), (100000, 8), (1, 1)]:
         cuts = [parallel.shard_bounds(n, r, w) for r in range(w)]

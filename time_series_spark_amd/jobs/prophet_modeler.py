@@ -265,10 +265,15 @@ def as_pandas_udf(fn, columns=MODEL_OUTPUT_COLUMNS):
     return pandas_udf(schema, PandasUDFType.GROUPED_MAP)(fn)
 
 
+_COMPRESSED = ('.gz', '.bz2', '.snappy', '.lz4', '.zst', '.deflate', '.xz')
+
+
 def find_model_input(root):
-    """CSV files under `root` with the series_id of the `series_id=<v>` directory above them
+    """Data files under `root` with the series_id of the `series_id=<v>` directory above them
     (None if there is none), ordered by (series_id, path): partition directories in numeric
-    order hand the packer a table that is already grouped."""
+    order hand the packer a table that is already grouped.  As `spark.read.csv(path)` does, every
+    non-hidden file counts (names starting with `_` or `.` -- `_SUCCESS`, `.part-0.crc` -- are
+    skipped); a compressed file raises (Spark would decompress it; this reader does not)."""
     if os.path.isfile(root):
         return [root], [None]
     found = []
@@ -278,11 +283,18 @@ def find_model_input(root):
             entries = sorted(it, key=lambda e: e.name)
         for e in entries:
             if e.is_dir(follow_symlinks=True):
+                if e.name.startswith(('_', '.')):
+                    continue
                 v = sid
                 if e.name.startswith('series_id='):
                     v = int(e.name.split('=', 1)[1])
                 walk(e.path, v)
-            elif e.name.endswith('.csv'):
+            elif e.name.startswith(('_', '.')):
+                continue
+            elif e.name.endswith(_COMPRESSED):
+                raise ValueError('compressed input file %s: decompress it first (Spark reads it, '
+                                 'this reader does not)' % e.path)
+            else:
                 found.append((sid, e.path))
 
     if os.path.isdir(root):
