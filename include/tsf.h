@@ -65,7 +65,7 @@ enum { TSF_EVAL_AUTO = 0, TSF_EVAL_RESIDUAL = 1, TSF_EVAL_QUADRATIC = 2 };
  * `'Newton' if T < 100 else 'LBFGS'` (TSF_ALGO_AUTO: decided per CALL from the longest series of
  * the call -- callers split panels at 100 rows).  Default TSF_ALGO_LBFGS. */
 enum { TSF_ALGO_LBFGS = 0, TSF_ALGO_NEWTON = 1, TSF_ALGO_AUTO = 2 };
-enum { TSF_RK_AUTO = 0, TSF_RK_WAVE = 1, TSF_RK_MFMA = 2 };
+enum { TSF_RK_AUTO = 0, TSF_RK_WAVE = 1, TSF_RK_MFMA = 2, TSF_RK_COOP = 3 };
 #define TSF_NEWTON_BELOW_T 100
 
 /* per-series status: >= 0 are Stan's optimiser termination codes */
@@ -119,9 +119,16 @@ typedef struct {
     int32_t algorithm;                      /* TSF_ALGO_LBFGS */
     /* Which kernel runs a RESIDUAL-form L-BFGS fit (same arithmetic, same bits): TSF_RK_WAVE one
      * wavefront per series; TSF_RK_MFMA 16 series per workgroup evaluated together on the matrix
-     * cores (aligned panels, one parameter per lane, <= 28 changepoints); TSF_RK_AUTO = the faster
-     * one as measured on MI355X, currently WAVE on every panel shape. */
+     * cores (aligned panels, one parameter per lane, <= 28 changepoints); TSF_RK_AUTO = WAVE with
+     * the cooperative tail: the series still running when the launch has handed out its last series
+     * are suspended and finished by one WORKGROUP each (16 waves sharing every evaluation; series of
+     * at most 4096 rows); TSF_RK_COOP = every series goes to a workgroup after its first evaluation
+     * (lowest latency for panels smaller than the GPU). */
     int32_t residual_kernel;                /* TSF_RK_AUTO */
+    /* test / tuning hook of the cooperative tail: >= 0 suspends a fit once it has used that many
+     * evaluations instead of at the tail of the launch; -1 = the default rule.  Results do not depend
+     * on where a fit is suspended. */
+    int32_t coop_after;                     /* -1 */
 } tsf_spec;
 
 /* What setup derives from one timestamp vector ("grid").  One per call for aligned panels,

@@ -34,7 +34,7 @@ def uses_quadratic_form(spec):
 def oracle_spec(spec):
     """time_series_spark_amd.forecaster.ModelSpec -> oracle.canon_lib spec."""
     from oracle import canon_lib as cl
-    opt = {k: v for k, v in spec.lbfgs.items() if k not in ('eval_form', 'algorithm', 'residual_kernel')}
+    opt = {k: v for k, v in spec.lbfgs.items() if k not in ('eval_form', 'algorithm', 'residual_kernel', 'coop_after')}
     opt['eval_mode'] = int(uses_quadratic_form(spec))
     seas = [(s['period'], s['fourier_order'], s.get('mode', spec.seasonality_mode),
              s.get('prior_scale', spec.seasonality_prior_scale)) for s in spec.seasonalities]

@@ -133,6 +133,111 @@ def test_matrix_core_kernel_is_bit_identical_to_the_one_wave_kernel(env, case):
     assert np.array_equal(r7m.theta, r7w.theta) and np.array_equal(r7m.n_eval, r7w.n_eval)
 
 
+@pytest.mark.parametrize('case', ['ref_logistic_multiplicative', 'cfg2_linear_additive@resid',
+                                  'linear_multiplicative_365', 'logistic_additive_400', 'short_90@resid',
+                                  'cfg4_holidays'])
+def test_cooperative_tail_is_bit_identical_to_the_one_wave_kernel(env, case):
+    """A residual-form fit can be suspended at any line-search evaluation and finished by a whole
+    workgroup (csrc/tsf_coop_kernels.h: 16 waves share every evaluation in eval_fg's order).  The
+    one-wave kernel alone (residual_kernel = WAVE), every series handed over after its first
+    evaluation (COOP), hand-overs after 2 / 7 / 40 / 300 evaluations (coop_after) and the default
+    rule (AUTO: whatever still runs when the launch has started its last series) must give the same
+    bits -- and those of the oracle."""
+    fc, cl = env
+    from time_series_spark_amd import _lib
+    spec, ds, y, floor, cap, extra, fut, exf = helpers.make_case(case, N=21)
+    kw = dict(growth=spec.growth, seasonality_mode=spec.seasonality_mode, seasonalities=spec.seasonalities,
+              extra=spec.extra, **spec.lbfgs)
+    fit = lambda **o: fc.fit_aligned(fc.ModelSpec(**dict(kw, **o)), ds, y, floor=floor, cap=cap, extra=extra)  # noqa: E731
+    r_w = fit(residual_kernel=_lib.RK_WAVE)
+    assert (r_w.status > 0).all()
+    variants = [dict(residual_kernel=_lib.RK_COOP), dict(residual_kernel=_lib.RK_AUTO)]
+    variants += [dict(coop_after=k) for k in (2, 7, 40, 300)]
+    for o in variants:
+        r = fit(**o)
+        assert np.array_equal(r.status, r_w.status) and np.array_equal(r.n_iter, r_w.n_iter), o
+        assert np.array_equal(r.n_eval, r_w.n_eval) and np.array_equal(r.fval, r_w.fval), o
+        assert np.array_equal(r.theta, r_w.theta) and np.array_equal(r.y_scale, r_w.y_scale), o
+    csp = helpers.oracle_spec(spec)
+    r_c = fit(residual_kernel=_lib.RK_COOP)
+    for n in (0, 9, 20):
+        o = cl.fit(csp, ds, y[n], floor[n], cap[n], extra)
+        S = o['info'].S
+        assert (r_c.n_iter[n], r_c.n_eval[n], r_c.status[n]) == (o['n_iter'], o['n_eval'], o['status'])
+        assert n_bit_diff(r_c.theta[n][:3 + S], o['theta'][:3 + S]) == 0 and n_bit_diff(r_c.fval[n], o['f']) == 0
+    # truncated runs: the iteration cap is hit inside the cooperative kernel
+    r7w, r7c = fit(residual_kernel=_lib.RK_WAVE, max_iter=7), fit(residual_kernel=_lib.RK_COOP, max_iter=7)
+    assert np.array_equal(r7w.theta, r7c.theta) and np.array_equal(r7w.n_eval, r7c.n_eval)
+    assert np.array_equal(r7w.status, r7c.status)
+
+
+def test_cooperative_tail_other_shapes(env):
+    """The cooperative kernel beyond the standard cases: ragged panels on a timestamp lattice (shared
+    design table) and with private grids, mixed additive / multiplicative columns (two parameters per
+    lane), no changepoints (the dummy changepoint), T = 1 400 (22 steps per chunk: two steps per wave),
+    a single series, more series than checkpoint waves can hold at once -- against the one-wave kernel."""
+    fc, cl = env
+    from time_series_spark_amd import _lib, synth
+    rng = np.random.default_rng(11)
+
+    def same(a, b, ctx):
+        assert np.array_equal(a.status, b.status) and np.array_equal(a.n_iter, b.n_iter), ctx
+        assert np.array_equal(a.n_eval, b.n_eval) and np.array_equal(a.fval, b.fval), ctx
+        assert np.array_equal(a.theta, b.theta), ctx
+
+    # aligned shapes
+    shapes = [
+        dict(growth='logistic', seasonality_mode='multiplicative', T=1400, seas=[helpers.YEARLY, helpers.WEEKLY], n_cp=25),
+        dict(growth='linear', seasonality_mode='multiplicative', T=200, seas=[helpers.WEEKLY], n_cp=0),
+        dict(growth='logistic', seasonality_mode='additive', T=64, seas=[helpers.WEEKLY], n_cp=10),
+        dict(growth='logistic', seasonality_mode='multiplicative', T=365, n_cp=25,       # mixed modes, P = 68
+             seas=[dict(helpers.WEEKLY, mode='additive'), {'name': 'yearly', 'period': 365.25, 'fourier_order': 12},
+                   {'name': 'monthly', 'period': 30.5, 'fourier_order': 5, 'mode': 'additive'}]),
+        dict(growth='linear', seasonality_mode='additive', T=3000, seas=[helpers.YEARLY5, helpers.WEEKLY], n_cp=25,
+             eval_form=_lib.EVAL_RESIDUAL, max_iter=60),
+    ]
+    for sh in shapes:
+        sh = dict(sh)
+        T, seas, n_cp = sh.pop('T'), sh.pop('seas'), sh.pop('n_cp')
+        N = 5
+        ds, y = synth.make_panel(N, T, sh['growth'], seed=300 + T)
+        fit_kw = dict(floor=np.zeros(N), cap=y.max(axis=1) * 1.2) if sh['growth'] == 'logistic' else {}
+        kw = dict(sh, seasonalities=seas, n_changepoints=n_cp)
+        r_w = fc.fit_aligned(fc.ModelSpec(residual_kernel=_lib.RK_WAVE, **kw), ds, y, **fit_kw)
+        for o in (dict(residual_kernel=_lib.RK_COOP), dict(coop_after=int(rng.integers(1, 60)))):
+            same(fc.fit_aligned(fc.ModelSpec(**dict(kw, **o)), ds, y, **fit_kw), r_w, (T, o))
+        same(fc.fit_aligned(fc.ModelSpec(residual_kernel=_lib.RK_COOP, **kw), ds, y[2:3],
+                            **{k: v[2:3] for k, v in fit_kw.items()}),
+             fc.fit_aligned(fc.ModelSpec(residual_kernel=_lib.RK_WAVE, **kw), ds, y[2:3],
+                            **{k: v[2:3] for k, v in fit_kw.items()}), (T, 'single'))
+    # ragged: one sampling lattice with different starts / lengths (shared design table), and
+    # private timestamps (rows dropped at random: no common lattice step beyond the day ... still a
+    # lattice; irregular seconds break it)
+    spec_kw = dict(growth='logistic', seasonality_mode='multiplicative', seasonalities=[helpers.YEARLY, helpers.WEEKLY])
+    N, T = 9, 730
+    ds, y = synth.make_panel(N, T, 'logistic', seed=77)
+    for jitter in (False, True):
+        keep = [np.sort(rng.choice(T, size=T - int(rng.integers(0, 90)), replace=False)) for _ in range(N)]
+        offs = np.concatenate([[0], np.cumsum([len(k) for k in keep])]).astype(np.int64)
+        dsr = np.concatenate([ds[k] for k in keep])
+        if jitter:
+            dsr = dsr + rng.integers(0, 3600, size=dsr.shape) * 1000000007     # irregular: no lattice
+            dsr = np.concatenate([np.sort(dsr[offs[i]:offs[i + 1]]) for i in range(N)])
+        yr = np.concatenate([y[n][k] for n, k in enumerate(keep)])
+        fit_kw = dict(floor=np.zeros(N), cap=y.max(axis=1) * 1.1)
+        r_w = fc.fit_ragged(fc.ModelSpec(residual_kernel=_lib.RK_WAVE, **spec_kw), offs, dsr, yr, **fit_kw)
+        for o in (dict(residual_kernel=_lib.RK_COOP), dict(coop_after=25)):
+            same(fc.fit_ragged(fc.ModelSpec(**dict(spec_kw, **o)), offs, dsr, yr, **fit_kw), r_w, ('ragged', jitter, o))
+    # series longer than the cooperative kernel stages in LDS stay on the one-wave kernel (AUTO), and
+    # asking for COOP there is an error
+    ds, y = synth.make_panel(2, 4200, 'linear', seed=5)
+    long_kw = dict(growth='linear', seasonality_mode='multiplicative', seasonalities=[helpers.WEEKLY], max_iter=30)
+    same(fc.fit_aligned(fc.ModelSpec(**long_kw), ds, y),
+         fc.fit_aligned(fc.ModelSpec(residual_kernel=_lib.RK_WAVE, **long_kw), ds, y), 'long')
+    with pytest.raises(_lib.TsfError, match='residual_kernel COOP'):
+        fc.fit_aligned(fc.ModelSpec(residual_kernel=_lib.RK_COOP, **long_kw), ds, y)
+
+
 def test_matrix_core_kernel_other_shapes(env):
     """fit_mfma_kernel beyond the five standard cases: two row groups per chunk (T = 1 400: 22 rows per
     chunk), 16 design columns, no changepoints (the dummy changepoint), 28 changepoints, a panel of

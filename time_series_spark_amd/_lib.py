@@ -22,7 +22,7 @@ MODE_ADDITIVE, MODE_MULTIPLICATIVE = 0, 1
 Y_F64, Y_F32, Y_I32 = 0, 1, 2
 EVAL_AUTO, EVAL_RESIDUAL, EVAL_QUADRATIC = 0, 1, 2
 ALGO_LBFGS, ALGO_NEWTON, ALGO_AUTO = 0, 1, 2
-RK_AUTO, RK_WAVE, RK_MFMA = 0, 1, 2
+RK_AUTO, RK_WAVE, RK_MFMA, RK_COOP = 0, 1, 2, 3
 
 ST_ABSX, ST_ABSF, ST_RELF, ST_ABSGRAD, ST_RELGRAD, ST_MAXIT = 10, 20, 21, 30, 31, 40
 ST_CONSTANT, ST_LSFAIL, ST_INIT_NONFINITE, ST_TOO_FEW, ST_CAP = 50, -1, -2, -10, -11
@@ -51,7 +51,8 @@ class TsfSpec(ctypes.Structure):
                 ('tol_rel_grad', ctypes.c_double), ('tol_param', ctypes.c_double),
                 ('eval_form', ctypes.c_int32), ('recenter_every', ctypes.c_int32),
                 ('recenter_ratio', ctypes.c_double),
-                ('algorithm', ctypes.c_int32), ('residual_kernel', ctypes.c_int32)]
+                ('algorithm', ctypes.c_int32), ('residual_kernel', ctypes.c_int32),
+                ('coop_after', ctypes.c_int32)]
 
 
 class TsfGridInfo(ctypes.Structure):

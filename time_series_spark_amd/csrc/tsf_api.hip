@@ -104,6 +104,7 @@ extern "C" void tsf_spec_default(tsf_spec *s)
     s->eval_form = TSF_EVAL_AUTO;
     s->algorithm = TSF_ALGO_LBFGS;
     s->residual_kernel = TSF_RK_AUTO; s->recenter_every = 128; s->recenter_ratio = 1.0;
+    s->coop_after = -1;
 }
 
 extern "C" int tsf_spec_size(void) { return (int)sizeof(tsf_spec); }
@@ -146,7 +147,7 @@ static int build_devspec(tsf_ctx *ctx, const tsf_spec *s, DevSpec *d, int *mode_
     if (s->history < 1 || s->history > MAXH) return fail(ctx, "history must be in [1,8]");
     if (s->eval_form < TSF_EVAL_AUTO || s->eval_form > TSF_EVAL_QUADRATIC) return fail(ctx, "bad eval_form");
     if (s->algorithm < TSF_ALGO_LBFGS || s->algorithm > TSF_ALGO_AUTO) return fail(ctx, "bad algorithm");
-    if (s->residual_kernel < TSF_RK_AUTO || s->residual_kernel > TSF_RK_MFMA) return fail(ctx, "bad residual_kernel");
+    if (s->residual_kernel < TSF_RK_AUTO || s->residual_kernel > TSF_RK_COOP) return fail(ctx, "bad residual_kernel");
     if (s->eval_form != TSF_EVAL_RESIDUAL && (s->recenter_every < 1 || !(s->recenter_ratio > 0.0)))
         return fail(ctx, "recenter_every must be >= 1 and recenter_ratio > 0");
     const int K = tsf_spec_K(s);
@@ -194,8 +195,13 @@ static int build_devspec(tsf_ctx *ctx, const tsf_spec *s, DevSpec *d, int *mode_
 struct WsLayout {
     size_t gtab, stab, tw, cw, Xw, yw, Mg, Mslot, rbuf, counter, uw, Xu;
     size_t mXF, mXB, mXT, mtq, mcq, mcpof, myq, mhist;      // matrix-core path (tsf_mfma_kernels.h)
+    size_t clist, cslots;                                   // cooperative tail (tsf_coop_kernels.h)
     size_t total;
 };
+
+// checkpoint slots of the cooperative tail: one per fit that can be suspended at a time -- the blocks
+// resident when the launch runs dry (a few thousand), all series of a small call
+static int coop_slots_for(int64_t N) { return (int)(N < 8192 ? N : 8192); }
 
 // launch plan of the matrix-core residual kernel
 struct MfmaPlan { int on, NG, KF, NCB, rr0, blocks; };
@@ -204,7 +210,7 @@ static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 static WsLayout ws_layout(int64_t N, int64_t n_grids, int NTmax, int KP, int quad_P4 = 0,
                           int quad_slots = 0, int quad_ragged = 0, int64_t lat_U = 0,
-                          const MfmaPlan *mp = nullptr)
+                          const MfmaPlan *mp = nullptr, int coop_slots = 0, int coop_stride = 0)
 {
     WsLayout l;
     size_t off = 0;
@@ -232,6 +238,8 @@ static WsLayout ws_layout(int64_t N, int64_t n_grids, int NTmax, int KP, int qua
     l.mcpof = off; off = align_up(off + (mf ? (size_t)W * 8 : 0));
     l.myq = off; off = align_up(off + (mf ? sizeof(double) * (size_t)N * tiles * 16 : 0));
     l.mhist = off; off = align_up(off + (mf ? sizeof(double) * (size_t)mp->blocks * MT_NS * 2 * MAXH * W : 0));
+    l.clist = off; off = align_up(off + sizeof(int32_t) * (size_t)coop_slots);
+    l.cslots = off; off = align_up(off + sizeof(double) * (size_t)coop_slots * coop_stride);
     l.total = off;
     return l;
 }
@@ -372,7 +380,16 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     }
     if (spec->residual_kernel == TSF_RK_MFMA && !mp.on && theta_in == nullptr && !quad && !newton)
         return fail(ctx, "residual_kernel MFMA needs an aligned panel, K <= 28 columns of one mode, 3+S+K <= 64 and S <= 28");
-    const WsLayout l = ws_layout(N, n_grids, NTmax, hs.KP, qp.P4, qp.slots, (quad || newton_quad) && !aligned, lat_U, &mp);
+    // cooperative tail of the one-wave residual kernel: series of at most COOP_MAX_NT steps per chunk
+    // (the rows of one evaluation are staged in the workgroup's LDS)
+    const bool coop_ok = !quad && !newton && theta_in == nullptr && !mp.on && NTmax <= COOP_MAX_NT;
+    if (spec->residual_kernel == TSF_RK_COOP && !coop_ok && theta_in == nullptr)
+        return fail(ctx, "residual_kernel COOP needs a residual-form L-BFGS fit of series of at most 4096 rows");
+    const bool coop = coop_ok && spec->residual_kernel != TSF_RK_WAVE;
+    const int coop_slots = coop ? coop_slots_for(N) : 0;
+    const int coop_stride = coop ? coop_slot_doubles(hs.KP == 64 ? 2 : 1) : 0;
+    const WsLayout l = ws_layout(N, n_grids, NTmax, hs.KP, qp.P4, qp.slots, (quad || newton_quad) && !aligned, lat_U, &mp,
+                                 coop_slots, coop_stride);
     rc = ensure_ws(ctx, l.total);
     if (rc) return rc;
     char *ws = (char *)ctx->ws;
@@ -467,6 +484,15 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
             lrc = pick_launch(hs.growth, mode)(hs.KP, fb, 0, st);
         }
     } else {
+        if (coop) {
+            a.coop_ctl = (int *)(ws + l.counter);
+            a.coop_list = (int32_t *)(ws + l.clist);
+            a.coop_slots = (double *)(ws + l.cslots);
+            a.coop_max = coop_slots; a.coop_stride = coop_stride;
+            a.coop_after = spec->residual_kernel == TSF_RK_COOP ? 0 : spec->coop_after;
+            a.coop_blocks = ctx->n_cu;
+            HIP_TRY(ctx, hipMemsetAsync(a.coop_ctl, 0, 4 * sizeof(int), st));
+        }
         lrc = pick_launch(hs.growth, mode)(hs.KP, a, theta_in != nullptr, st);
     }
     if (ctx->profiling) { HIP_TRY(ctx, hipEventRecord(ctx->ev1[slot], st)); ctx->ev_count++; }

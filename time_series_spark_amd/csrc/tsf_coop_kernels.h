@@ -1,0 +1,514 @@
+// tsf_coop_kernels.h -- the cooperative tail of a residual-form L-BFGS launch.
+//
+// fit_kernel (tsf_fit_kernels.h) runs one wavefront per series; a launch of the reference's own
+// model (/root/reference/src/jobs/prophet_modeler.py:65-66: logistic growth, multiplicative
+// seasonality) ends with a few series that need 10-50 x the mean number of evaluations, each
+// evaluated by ONE wave at ~40 k cycles per evaluation while 255 CUs idle.  Here a suspended
+// series (checkpoint written by fit_kernel, see coop_checkpoint) is continued by a whole workgroup
+// of NW waves on one CU:
+//
+//   wave 0, the OWNER, runs the same L-BFGS state machine as fit_kernel from the restored state;
+//   an evaluation is split over the waves in the order eval_fg fixes (canonical arithmetic,
+//   tsf_common.h) -- same operations, same operand order, same bits:
+//     A  rows: step q of the 64 chunks (lane = chunk) -> wave 1 + q mod (NW-1): X.beta chain, trend,
+//        r, r g, v of the row into LDS;
+//     B  design column j -> wave 1 + j mod (NW-2): the chunk-partial fma chain over the steps (last
+//        row first) and the 32,16,1,2,4,8 butterfly over the chunks; wave NW-1: the trend sums with
+//        their changepoint-row snapshots and the suffix scans; the owner: the sum of squares;
+//     C  the owner: eval_tail (priors, reverse sweep through the gamma recurrence, gradient).
+//   Three workgroup barriers per evaluation; nothing but the design matrix (L2) is read from
+//   global memory inside the loop.
+#pragma once
+#include "tsf_fit_kernels.h"
+
+namespace tsf {
+
+// ---- LDS of a cooperative workgroup -----------------------------------------------------------
+template <int KP, int PPL>
+struct CoopLds {
+    WaveLds<KP, PPL> w;         // the owner's tables: theta, segment tables, time-axis sums, history
+    int cmd, item;
+    long long pad_;
+};
+enum { COOP_EVAL = 1, COOP_EXIT = 2 };
+#ifndef COOP_NW
+#define COOP_NW 16              // waves per cooperative workgroup (one workgroup per CU)
+#endif
+
+template <int KP, int PPL>
+__host__ __device__ constexpr size_t coop_lds_bytes(int NTmax)
+{
+    return sizeof(CoopLds<KP, PPL>) + sizeof(double) * 3 * (size_t)NTmax * W;
+}
+
+#ifdef TSF_COOP_TIMING      // dev only: owner-wave cycles per phase, summed per series
+#define CT_DECL long long ct_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long ct_t0 = __builtin_readcyclecounter(), ct_start = ct_t0
+#define CT_LAP(k) do { const long long t_ = __builtin_readcyclecounter(); ct_acc[k] += t_ - ct_t0; ct_t0 = t_; } while (0)
+#define CT_FLUSH(dst, n) do { if ((dst) && lane_id() == 0) { ct_acc[7] = __builtin_readcyclecounter() - ct_start; for (int k_ = 0; k_ < 8; ++k_) ((long long *)(dst))[(size_t)(n) * 8 + k_] = ct_acc[k_]; } } while (0)
+#else
+#define CT_DECL do { } while (0)
+#define CT_LAP(k) do { } while (0)
+#define CT_FLUSH(dst, n) do { } while (0)
+#endif
+
+// ---- phase A: the rows of steps q0, q0 + qstep, ... -------------------------------------------
+// eval_fg's row body (X.beta chain over the columns from 0, trend, mu, r) with beta read from the
+// owner's LDS copy of theta; r, r g and v of every (step, chunk) go to rbR / rbU / rbV (0 for the
+// rows past the end of a chunk: fma(x, 0, acc) leaves the chains of phase B unchanged).
+template <int KP, int GROWTH, int MODE, int PPL, bool XIDX, class L>
+__device__ __forceinline__ void coop_rows(const DevSpec *__restrict__ sp, const SeriesView &sv, const L &w,
+                                          double *rbR, double *rbU, double *rbV, int q0, int qstep)
+{
+    const int lane = lane_id();
+    const int S = sv.S, NT = sv.NT, K = sp->K;
+    const int Ka = (MODE == 0) ? K : (MODE == 1 ? 0 : sp->Ka);
+    const double *beta = &w.th[3 + S];
+    for (int q = q0; q < NT; q += qstep) {
+        const int idx = q * W + lane;
+        double r = 0.0, rg = 0.0, v = 0.0;
+        if (q < sv.cnt) {
+            const unsigned cwv = (unsigned)sv.cw[idx];
+            const int c = (int)(cwv & 0xffu);
+            const double ti = sv.tw[idx];
+            const double yi = sv.yw[idx];
+            constexpr int XS = XIDX ? 1 : W;
+            const double *xp = XIDX ? sv.Xu + (size_t)sv.uw[idx] * KP : sv.Xw + (size_t)q * KP * W + lane;
+            double xa = 0.0, xm = 0.0;
+            // columns beyond K are zero columns with zero coefficients: fma(0, 0, x) = x
+            if (MODE == 0) {
+#pragma unroll 8
+                for (int j = 0; j < K; ++j) xa = __builtin_fma(xp[j * XS], beta[j], xa);
+            } else if (MODE == 1) {
+#pragma unroll 8
+                for (int j = 0; j < K; ++j) xm = __builtin_fma(xp[j * XS], beta[j], xm);
+            } else {
+#pragma unroll 4
+                for (int j = 0; j < Ka; ++j) xa = __builtin_fma(xp[j * XS], beta[j], xa);
+#pragma unroll 4
+                for (int j = Ka; j < K; ++j) xm = __builtin_fma(xp[j * XS], beta[j], xm);
+            }
+            const double ksc = w.ks[c], mcc = w.mc[c];
+            double gtr, qv = 0.0;
+            if (GROWTH == 0) {
+                gtr = __builtin_fma(ksc, ti, mcc);
+            } else {
+                const double z = ksc * (ti - mcc);
+                const double e = dm_exp_sel(-z);
+                const double sg = 1.0 / (1.0 + e);
+                gtr = sv.cap * sg;
+                qv = gtr * (1.0 - sg);
+            }
+            const double opm = 1.0 + xm;
+            const double mu = __builtin_fma(gtr, opm, xa);
+            r = yi - mu;
+            rg = r * gtr;
+            v = r * opm;
+            if (GROWTH == 1) v = v * qv;
+        }
+        rbR[idx] = r; rbU[idx] = rg; rbV[idx] = v;
+    }
+}
+
+// sum over the 64 chunk partials of ONE column, butterfly offsets 32, 16, 1, 2, 4, 8 (column_sums
+// for a single register: every lane ends with the sum)
+__device__ __forceinline__ double chunk_sum_1(double v)
+{
+    { double x = v, y = v; swap32(x, y); v = x + y; }
+    { double x = v, y = v; swap16(x, y); v = x + y; }
+    return row_bfly_sum(v);
+}
+
+// ---- phase B -----------------------------------------------------------------------------------
+// design columns j0, j0 + jstep, ...: acc_j = fma chain over the steps of a chunk, last row first,
+// against r (additive column) or r g (multiplicative column), then the butterfly over the chunks
+template <int KP, int MODE, bool XIDX, class L>
+__device__ __forceinline__ void coop_columns(const DevSpec *__restrict__ sp, const SeriesView &sv, L &w,
+                                             const double *rbR, const double *rbU, int j0, int jstep)
+{
+    const int lane = lane_id();
+    const int NT = sv.NT, K = sp->K;
+    const int Ka = (MODE == 0) ? K : (MODE == 1 ? 0 : sp->Ka);
+    for (int j = j0; j < K; j += jstep) {
+        const double *ru = (MODE == 0 || (MODE == 2 && j < Ka)) ? rbR : rbU;
+        double acc = 0.0;
+        int q = NT - 1;
+        // four steps' loads in flight at a time
+        for (; q >= 3; q -= 4) {
+            double xv[4], rv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int qq = q - u, idx = qq * W + lane;
+                rv[u] = ru[idx];
+                if (XIDX) xv[u] = (qq < sv.cnt) ? sv.Xu[(size_t)sv.uw[idx] * KP + j] : 0.0;
+                else xv[u] = sv.Xw[((size_t)qq * KP + j) * W + lane];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = __builtin_fma(xv[u], rv[u], acc);
+        }
+        for (; q >= 0; --q) {
+            const int idx = q * W + lane;
+            double xv;
+            if (XIDX) xv = (q < sv.cnt) ? sv.Xu[(size_t)sv.uw[idx] * KP + j] : 0.0;
+            else xv = sv.Xw[((size_t)q * KP + j) * W + lane];
+            acc = __builtin_fma(xv, ru[idx], acc);
+        }
+        acc = chunk_sum_1(acc);
+        if (lane == 0) w.accR[j] = acc;
+    }
+}
+
+// per-chunk trend sums with their values at the changepoint rows, then the suffix sums over the
+// chunks (eval_fg: rt1, rt2, tp1, tp2, tot1, tot2)
+template <class L>
+__device__ __forceinline__ void coop_trend(const SeriesView &sv, L &w, const double *rbV)
+{
+    const int lane = lane_id();
+    double rt1 = 0.0, rt2 = 0.0;
+    for (int q = sv.NT - 1; q >= 0; --q) {
+        if (q < sv.cnt) {
+            const int idx = q * W + lane;
+            const unsigned cwv = (unsigned)sv.cw[idx];
+            const int c = (int)(cwv & 0xffu), cprev = (int)(cwv >> 8);
+            const double ti = sv.tw[idx];
+            const double v = rbV[idx];
+            rt1 = __builtin_fma(v, ti, rt1);
+            rt2 = rt2 + v;
+            for (int j = cprev; j < c; ++j) { w.tp1[j] = rt1; w.tp2[j] = rt2; }
+        }
+    }
+    const double s1 = suffix_scan(rt1), s2v = suffix_scan(rt2);
+    w.tot1[lane] = s1; w.tot2[lane] = s2v;
+    if (lane == 0) { w.tot1[W] = 0.0; w.tot2[W] = 0.0; }
+}
+
+__device__ __forceinline__ double coop_sse(const SeriesView &sv, const double *rbR)
+{
+    const int lane = lane_id();
+    double sse = 0.0;
+    for (int q = sv.NT - 1; q >= 0; --q) {
+        if (q < sv.cnt) { const double r = rbR[q * W + lane]; sse = __builtin_fma(r, r, sse); }
+    }
+    return bfly_sum(sse);
+}
+
+// ---- the helpers' loop -------------------------------------------------------------------------
+template <int KP, int GROWTH, int MODE, int PPL, int NW, bool XIDX>
+__device__ __forceinline__ void coop_helper(const DevSpec *__restrict__ sp, const SeriesView &sv,
+                                            CoopLds<KP, PPL> &cl, double *rbR, double *rbU, double *rbV, int wid)
+{
+    for (;;) {
+        __syncthreads();                                    // A: the owner has published theta / ks / mc / cmd
+        if (cl.cmd == COOP_EXIT) break;
+        coop_rows<KP, GROWTH, MODE, PPL, XIDX>(sp, sv, cl.w, rbR, rbU, rbV, wid - 1, NW - 1);
+        __syncthreads();                                    // B: rows complete
+        if (wid == NW - 1) coop_trend(sv, cl.w, rbV);
+        else coop_columns<KP, MODE, XIDX>(sp, sv, cl.w, rbR, rbU, wid - 1, NW - 2);
+        __syncthreads();                                    // C: sums complete
+    }
+}
+
+// ---- one evaluation, the owner's side ---------------------------------------------------------
+template <int KP, int GROWTH, int MODE, int PPL, int NW, bool XIDX>
+__device__ __forceinline__ bool coop_eval_owner(const DevSpec *__restrict__ sp, SeriesView &sv,
+                                                CoopLds<KP, PPL> &cl, double *rbR, double *rbU, double *rbV,
+                                                const double (&th)[PPL], double &f_out, double (&g)[PPL])
+{
+    const int lane = lane_id();
+    sv.n_eval++;
+#pragma unroll
+    for (int s = 0; s < PPL; ++s) cl.w.th[lane + s * W] = th[s];
+    segment_tables<GROWTH, PPL>(sv, cl.w, th);
+    if (lane == 0) cl.cmd = COOP_EVAL;
+    __syncthreads();                                        // A
+    const double ls = theta_at<PPL>(th, 2);
+    const double sigma = dm_exp_sel(ls);
+    const double inv_s2 = 1.0 / (sigma * sigma);
+    __syncthreads();                                        // B
+    const double sse_t = coop_sse(sv, rbR);
+    __syncthreads();                                        // C
+    return eval_tail<GROWTH, PPL>(sp, sv, cl.w, cl.w, th, sigma, inv_s2, sse_t, f_out, g);
+}
+
+// ---- the owner: fit_kernel's L-BFGS loop, resumed at a line-search evaluation -----------------
+// (Stan's BFGSMinimizer<LBFGSUpdate>::step / WolfeLineSearch / WolfLSZoom as restated in fit_kernel;
+// the text below is that loop with the state restored from the checkpoint and eval_fg replaced by
+// coop_eval_owner -- keep the two in step.)
+template <int KP, int GROWTH, int MODE, int PPL, int NW, bool XIDX>
+__device__ __forceinline__ void coop_owner(const FitArgs &a, SeriesView &sv, int64_t n, const double *slot,
+                                           CoopLds<KP, PPL> &cl, double *rbR, double *rbU, double *rbV)
+{
+    const int lane = lane_id();
+    const DevSpec *sp = a.sp;
+    auto &lds = cl.w;
+    const CoopVars cv = *reinterpret_cast<const CoopVars *>(slot);
+
+    double xk[PPL], gk[PPL], pk[PPL], xk1[PPL], gk1[PPL], pk1[PPL];
+    coop_get_vec<PPL>(slot, 0, xk); coop_get_vec<PPL>(slot, 1, gk); coop_get_vec<PPL>(slot, 2, pk);
+#pragma unroll
+    for (int s = 0; s < PPL; ++s) { xk1[s] = 0.0; gk1[s] = 0.0; pk1[s] = 0.0; }     // dead at a line-search evaluation
+    const int H = a.opt.history > MAXH ? MAXH : a.opt.history;
+    for (int h = 0; h < H; ++h) {
+        double sv_[PPL], yv_[PPL];
+        coop_get_vec<PPL>(slot, 6 + h, sv_); coop_get_vec<PPL>(slot, 6 + MAXH + h, yv_);
+#pragma unroll
+        for (int s = 0; s < PPL; ++s) { lds.Sb[(h * PPL + s) * W + lane] = sv_[s]; lds.Yb[(h * PPL + s) * W + lane] = yv_[s]; }
+    }
+    if (lane < MAXH) lds.rho[lane] = slot[COOP_VARS_D + lane];
+    TSF_WAVE_SYNC();
+
+    const double c1 = 1e-4, c2 = 0.9, minAlpha = 1e-12, min_range = 1e-16;
+    const int maxLSIts = 20, maxLSRestarts = 10;
+    (void)c1; (void)c2;
+
+    double fk = cv.fk, fk1 = cv.fk1, alpha = cv.alpha, gammak = cv.gammak;
+    int itNum = cv.itNum, ret = 0, resetB = cv.resetB, hist_len = cv.hist_len, hist_head = cv.hist_head;
+    double dfp = cv.dfp, c1dfp = cv.c1dfp, c2dfp = cv.c2dfp, alpha0 = cv.alpha0, prevF = cv.prevF, prevDFp = cv.prevDFp;
+    double alo = cv.alo, aloF = cv.aloF, aloDFp = cv.aloDFp, ahi = cv.ahi, ahiF = cv.ahiF, ahiDFp = cv.ahiDFp;
+    int nits = cv.nits, lsRestarts = cv.lsRestarts, zoom = cv.zoom, zit = cv.zit;
+    double gp = cv.gp;
+    bool gp_valid = cv.gp_valid != 0, pk1_scaled = cv.pk1_scaled != 0;
+    sv.n_eval = cv.n_eval;
+
+    enum { ST_START_ITER = 1, ST_START_LS, ST_LS_PRE, ST_LS_EVAL };
+    int stage = ST_LS_EVAL;
+    CT_DECL;
+    for (;;) {
+        if (stage == ST_START_ITER) {
+            itNum++;
+            resetB = (itNum == 1) ? 1 : 0;
+            stage = ST_START_LS;
+        }
+        if (stage == ST_START_LS) {
+            if (resetB) {
+#pragma unroll
+                for (int s = 0; s < PPL; ++s) pk[s] = -gk[s];
+                gp_valid = false;
+            }
+            if (!gp_valid) gp = pdot<PPL>(gk, pk);
+            gp_valid = false;
+            if (itNum > 1 && resetB != 2) {
+                const double gp1 = pk1_scaled ? pdot<PPL>(gk1, pk1) : dfp;
+                const double ci = cubic_interp6(gp1, alpha, fk - fk1, gp, minAlpha, 1.0);
+                alpha = uniform_f64(__builtin_fmin(1.0, 1.01 * ci));
+            } else {
+                alpha = a.opt.init_alpha;
+            }
+            dfp = gp;
+            c1dfp = uniform_f64(c1 * dfp); c2dfp = uniform_f64(c2 * dfp);
+            alpha0 = minAlpha; prevF = fk; prevDFp = dfp;
+            nits = 0; lsRestarts = 0; zoom = 0; zit = 0;
+            stage = ST_LS_PRE;
+        }
+        bool ls_fail = false;
+        if (stage == ST_LS_PRE) {
+            if (!zoom) {
+                if (nits >= maxLSIts) ls_fail = true;
+            } else {
+                zit++;
+                if (__builtin_fabs(alo - ahi) < min_range) {
+                    ls_fail = true;
+                } else if (zit % 5 == 0) {
+                    alpha = uniform_f64(0.5 * (alo + ahi));
+                } else {
+                    const double d1 = aloDFp + ahiDFp - 3.0 * (aloF - ahiF) / (alo - ahi);
+                    double d2 = __builtin_sqrt(d1 * d1 - aloDFp * ahiDFp);
+                    if (ahi < alo) d2 = -d2;
+                    alpha = ahi - (ahi - alo) * (ahiDFp + d2 - d1) / (ahiDFp - aloDFp + 2.0 * d2);
+                    const double lo = __builtin_fmin(alo, ahi), hi = __builtin_fmax(alo, ahi),
+                                 w = __builtin_fabs(alo - ahi);
+                    if (!finite_f64(alpha) || alpha < lo + 0.01 * w || alpha > hi - 0.01 * w)
+                        alpha = 0.5 * (alo + ahi);
+                    alpha = uniform_f64(alpha);
+                }
+            }
+            if (!ls_fail) stage = ST_LS_EVAL;
+        }
+        if (!ls_fail) {
+            // (stage == ST_LS_EVAL: the only evaluation site of a resumed fit)
+            if (sv.n_eval >= 64 * a.opt.max_iter + 1024) { ret = TSF_ST_EVAL_LIMIT; break; }
+#pragma unroll
+            for (int s = 0; s < PPL; ++s) xk1[s] = __builtin_fma(alpha, pk[s], xk[s]);
+            double f1;
+            CT_LAP(0);
+            const bool bad = coop_eval_owner<KP, GROWTH, MODE, PPL, NW, XIDX>(sp, sv, cl, rbR, rbU, rbV, xk1, f1, gk1);
+            CT_LAP(1);
+            f1 = uniform_f64(f1);
+            if (bad) {
+                if (!zoom) {
+                    if (lsRestarts >= maxLSRestarts) ls_fail = true;
+                    else { alpha = uniform_f64(0.5 * (alpha0 + alpha)); lsRestarts++; }
+                } else {
+                    alpha = uniform_f64(0.5 * (alpha + __builtin_fmin(alo, ahi)));
+                    if (__builtin_fabs(__builtin_fmin(alo, ahi) - alpha) < min_range) ls_fail = true;
+                }
+                if (!ls_fail) continue;            // re-evaluate at the shortened step
+            }
+            if (!ls_fail) {
+                const double newDFp = pdot<PPL>(gk1, pk);
+                bool ls_ok = false;
+                if (!zoom) {
+                    lsRestarts = 0;
+                    if (f1 > fk + alpha * c1dfp || (f1 >= prevF && nits > 0)) {
+                        zoom = 1; alo = alpha0; aloF = prevF; aloDFp = prevDFp;
+                        ahi = alpha; ahiF = f1; ahiDFp = newDFp;
+                    } else if (__builtin_fabs(newDFp) <= -c2dfp) {
+                        ls_ok = true;
+                    } else if (newDFp >= 0) {
+                        zoom = 1; alo = alpha; aloF = f1; aloDFp = newDFp;
+                        ahi = alpha0; ahiF = prevF; ahiDFp = prevDFp;
+                    } else {
+                        alpha0 = alpha; prevF = f1; prevDFp = newDFp;
+                        alpha = uniform_f64(alpha * 10.0);
+                        nits++;
+                    }
+                } else {
+                    if (f1 > (fk + alpha * c1dfp) || f1 >= aloF) {
+                        ahi = alpha; ahiF = f1; ahiDFp = newDFp;
+                    } else if (__builtin_fabs(newDFp) <= -c2dfp) {
+                        ls_ok = true;
+                    } else {
+                        if (newDFp * (ahi - alo) >= 0) { ahi = alo; ahiF = aloF; ahiDFp = aloDFp; }
+                        alo = alpha; aloF = f1; aloDFp = newDFp;
+                    }
+                }
+                if (!ls_ok) { stage = ST_LS_PRE; continue; }
+                fk1 = f1;
+                // ---- accepted step: k becomes the most recent iterate ----
+                { const double tf = fk; fk = fk1; fk1 = tf; }
+                double sk[PPL], yk[PPL];
+#pragma unroll
+                for (int s = 0; s < PPL; ++s) {
+                    const double tx = xk[s]; xk[s] = xk1[s]; xk1[s] = tx;
+                    const double tg = gk[s]; gk[s] = gk1[s]; gk1[s] = tg;
+                    const double tp = pk[s]; pk[s] = pk1[s]; pk1[s] = tp;
+                    sk[s] = xk[s] - xk1[s];
+                    yk[s] = gk[s] - gk1[s];
+                }
+                const double dots = bfly_sum4_lanes(pdot_part<PPL>(gk, gk), pdot_part<PPL>(sk, sk),
+                                                    pdot_part<PPL>(yk, sk), pdot_part<PPL>(yk, yk));
+                const double nrm = __builtin_sqrt(dots);
+                const double gradNorm = readlane_f64(nrm, 0), stepNorm = readlane_f64(nrm, 2);
+                double qnum = dpp_mov<0x07>(dots);          // quad_perm [3,1,0,0]: y.y, y.s, -, -
+                if ((lane & 3) >= 2) qnum = 1.0;
+                const double qden = dpp_mov<0x5D>(dots);    // quad_perm [1,3,1,1]: y.s, y.y, y.s, y.s
+                const double qv = qnum / qden;
+                if (resetB) {
+                    const double B0fact = readlane_f64(qv, 0);
+                    hist_len = 0; hist_head = 0;
+#pragma unroll
+                    for (int s = 0; s < PPL; ++s) pk1[s] = pk1[s] / B0fact;
+                    alpha = uniform_f64(alpha * B0fact);
+                    pk1_scaled = true;
+                } else {
+                    pk1_scaled = false;
+                }
+                gammak = readlane_f64(qv, 1);
+                const double rho_new = readlane_f64(qv, 2);
+                {
+                    int hs;
+                    if (hist_len < H) { hs = (hist_head + hist_len) % H; hist_len++; }
+                    else { hs = hist_head; hist_head = (hist_head + 1) % H; }
+                    if (lane == 0) lds.rho[hs] = rho_new;
+#pragma unroll
+                    for (int s = 0; s < PPL; ++s) {
+                        lds.Sb[(hs * PPL + s) * W + lane] = sk[s];
+                        lds.Yb[(hs * PPL + s) * W + lane] = yk[s];
+                    }
+                }
+                TSF_WAVE_SYNC();
+#pragma unroll
+                for (int s = 0; s < PPL; ++s) pk[s] = -gk[s];
+                for (int h = hist_len - 1; h >= 0; --h) {
+                    const int hs = (hist_head + h) % H;
+                    double si[PPL], yi[PPL];
+#pragma unroll
+                    for (int s = 0; s < PPL; ++s) {
+                        si[s] = lds.Sb[(hs * PPL + s) * W + lane];
+                        yi[s] = lds.Yb[(hs * PPL + s) * W + lane];
+                    }
+                    const double aa = lane63(lds.rho[hs] * pdot_l63<PPL>(si, pk));
+#pragma unroll
+                    for (int s = 0; s < PPL; ++s) pk[s] = __builtin_fma(-aa, yi[s], pk[s]);
+                    if (lane == 0) lds.alphas[h] = aa;
+                }
+                TSF_WAVE_SYNC();
+#pragma unroll
+                for (int s = 0; s < PPL; ++s) pk[s] = pk[s] * gammak;
+                for (int h = 0; h < hist_len; ++h) {
+                    const int hs = (hist_head + h) % H;
+                    double si[PPL], yi[PPL];
+#pragma unroll
+                    for (int s = 0; s < PPL; ++s) {
+                        si[s] = lds.Sb[(hs * PPL + s) * W + lane];
+                        yi[s] = lds.Yb[(hs * PPL + s) * W + lane];
+                    }
+                    const double cc = lane63(lds.alphas[h] - lds.rho[hs] * pdot_l63<PPL>(yi, pk));
+#pragma unroll
+                    for (int s = 0; s < PPL; ++s) pk[s] = __builtin_fma(cc, si[s], pk[s]);
+                }
+                TSF_WAVE_SYNC();
+                const double dF = __builtin_fabs(fk1 - fk);
+                const double fmaxv = __builtin_fmax(__builtin_fabs(fk1),
+                                                    __builtin_fmax(__builtin_fabs(fk), 1.0));
+                gp = pdot<PPL>(gk, pk);
+                gp_valid = true;
+                if (dF < a.opt.tol_obj) ret = TSF_ST_ABSF;
+                else if (dF < a.opt.tol_rel_obj_eps * fmaxv) ret = TSF_ST_RELF;
+                else if (gradNorm < a.opt.tol_grad) ret = TSF_ST_ABSGRAD;
+                else if (-gp / __builtin_fmax(__builtin_fabs(fk), 1.0) < a.opt.tol_rel_grad_eps) ret = TSF_ST_RELGRAD;
+                else if (stepNorm < a.opt.tol_param) ret = TSF_ST_ABSX;
+                else if (itNum >= a.opt.max_iter) ret = TSF_ST_MAXIT;
+                else ret = 0;
+                if (ret != 0) break;
+                stage = ST_START_ITER;
+                continue;
+            }
+        }
+        // line search failed
+        if (resetB) { ret = TSF_ST_LSFAIL; break; }
+        resetB = 2;
+        stage = ST_START_LS;
+    }
+    if (lane == 0) cl.cmd = COOP_EXIT;
+    __syncthreads();                                        // A of the helpers' last round
+    store_theta<PPL>(a, sv, n, xk, a.theta);
+    if (lane == 0) { a.status[n] = ret; a.n_iter[n] = itNum; a.n_eval[n] = sv.n_eval; a.fval[n] = fk; }
+    CT_LAP(0);
+    CT_FLUSH(a.grad_out, n);
+}
+
+// ---- the kernel: persistent workgroups over the checkpoint list ---------------------------------
+template <int KP, int GROWTH, int MODE, int PPL, int NW, bool XIDX>
+__global__ __launch_bounds__(NW * 64) void fit_coop_kernel(FitArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    CoopLds<KP, PPL> &cl = *reinterpret_cast<CoopLds<KP, PPL> *>(smem);
+    double *rbR = reinterpret_cast<double *>(smem + sizeof(CoopLds<KP, PPL>));
+    double *rbU = rbR + (size_t)a.NTmax * W, *rbV = rbU + (size_t)a.NTmax * W;
+    const int wid = (int)threadIdx.x >> 6;
+    int n_ckpt = a.coop_ctl[1];
+    if (n_ckpt > a.coop_max) n_ckpt = a.coop_max;
+    for (;;) {
+        // (queue fetch kept branch-free: see the compiler note in DESIGN.md section 5)
+        if (wid == 0) {
+            const int it = atomicAdd(&a.coop_ctl[2], lane_id() == 0 ? 1 : 0);
+            if (lane_id() == 0) cl.item = it;
+        }
+        __syncthreads();
+        const int item = cl.item;
+        __syncthreads();
+        if (item >= n_ckpt) break;
+        const int64_t n = a.coop_list[item];
+        SeriesView sv;
+        make_view<KP, PPL>(a, n, sv);
+        if (wid == 0) {
+            for (int i = lane_id(); i < TSF_MAX_P + W; i += W) cl.w.th[i] = 0.0;
+            TSF_WAVE_SYNC();
+            coop_owner<KP, GROWTH, MODE, PPL, NW, XIDX>(a, sv, n, a.coop_slots + (size_t)item * a.coop_stride, cl, rbR, rbU, rbV);
+        } else {
+            coop_helper<KP, GROWTH, MODE, PPL, NW, XIDX>(a.sp, sv, cl, rbR, rbU, rbV, wid);
+        }
+    }
+}
+
+}  // namespace tsf

@@ -502,7 +502,56 @@ struct FitArgs {
     // (the one-wave kernel as the fallback of the matrix-core kernel, decided on the device)
     const int *run_flag;
     int run_if;
+    // cooperative tail (tsf_coop_kernels.h): where coop_ctl is set, a fit that is still running when
+    // the launch has started its last block (coop_after < 0) or that has used coop_after evaluations
+    // writes its optimiser state to a checkpoint slot and returns; fit_coop_kernel finishes it with a
+    // whole workgroup.  ctl[0] blocks started, ctl[1] slots taken, ctl[2] queue head of the tail.
+    int *coop_ctl;
+    int32_t *coop_list;                 // [coop_max] series of each slot
+    double *coop_slots;                 // [coop_max][coop_stride]
+    int coop_max, coop_stride, coop_after, coop_blocks;
 };
+
+// ---- checkpoint of a suspended fit (written by fit_kernel, read by fit_coop_kernel) -----------
+// slot layout (doubles): [0, COOP_VARS_D) CoopVars; [COOP_VARS_D, +MAXH) rho; then the vectors
+// x, g, p of the current iterate (0..2; 3..5 unused) and the L-BFGS history S (6..), Y (6+MAXH..),
+// each [PPL][64]
+constexpr int COOP_MAX_NT = 64;         // longest series the cooperative tail takes: 64 steps per chunk (4096 rows)
+constexpr int COOP_VARS_D = 32;
+constexpr int COOP_NVEC = 6 + 2 * MAXH;
+
+struct CoopVars {
+    double fk, fk1, alpha, gammak, dfp, c1dfp, c2dfp, alpha0, prevF, prevDFp;
+    double alo, aloF, aloDFp, ahi, ahiF, ahiDFp, gp;
+    int32_t itNum, resetB, hist_len, hist_head, nits, lsRestarts, zoom, zit, gp_valid, pk1_scaled,
+        n_eval, pad_;
+};
+static_assert(sizeof(CoopVars) <= COOP_VARS_D * sizeof(double), "CoopVars outgrew its slot header");
+
+__host__ __device__ constexpr int coop_slot_doubles(int PPL) { return COOP_VARS_D + MAXH + COOP_NVEC * PPL * W; }
+
+template <int PPL>
+__device__ __forceinline__ void coop_put_vec(double *slot, int idx, const double (&v)[PPL])
+{
+#pragma unroll
+    for (int s = 0; s < PPL; ++s) slot[COOP_VARS_D + MAXH + (idx * PPL + s) * W + lane_id()] = v[s];
+}
+template <int PPL>
+__device__ __forceinline__ void coop_get_vec(const double *slot, int idx, double (&v)[PPL])
+{
+#pragma unroll
+    for (int s = 0; s < PPL; ++s) v[s] = slot[COOP_VARS_D + MAXH + (idx * PPL + s) * W + lane_id()];
+}
+
+// suspend now?  coop_after >= 0: once that many evaluations are spent (tests, latency mode);
+// otherwise in the tail of the launch: every block has been started, whatever still runs is a
+// straggler (looked at every fourth evaluation)
+__device__ __forceinline__ bool coop_should_suspend(const FitArgs &a, int n_eval)
+{
+    if (a.coop_after >= 0) return n_eval >= a.coop_after;
+    if ((n_eval & 3) != 0) return false;
+    return __hip_atomic_load(&a.coop_ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (int)a.N;
+}
 
 template <int KP, int PPL>
 __device__ __forceinline__ void make_view(const FitArgs &a, int64_t n, SeriesView &sv)
@@ -603,6 +652,9 @@ __global__ __launch_bounds__(64, TSF_FIT_WPS) void fit_kernel(FitArgs a)
     if (n >= a.N) return;
     if (a.run_flag && (*a.run_flag != 0) != (a.run_if != 0)) return;
     const int lane = threadIdx.x;
+    if (a.coop_ctl) atomicAdd(&a.coop_ctl[0], lane == 0 ? 1 : 0);      // (branch-free: see coop_should_suspend)
+    bool coop_try = a.coop_ctl != nullptr;
+    int coop_ticket = -1;
     const DevSpec *sp = a.sp;
     SeriesView sv;
     make_view<KP, PPL>(a, n, sv);
@@ -706,6 +758,14 @@ __global__ __launch_bounds__(64, TSF_FIT_WPS) void fit_kernel(FitArgs a)
             if (stage == ST_LS_EVAL) {
                 // guard against a line search that never settles (oracle cn_lbfgs eval_limit)
                 if (sv.n_eval >= 64 * a.opt.max_iter + 1024) { ret = TSF_ST_EVAL_LIMIT; break; }
+                if (coop_try && coop_should_suspend(a, sv.n_eval)) {
+                    // hand this fit to the cooperative tail (the ticket fetch is branch-free: every
+                    // lane adds, lane 0 adds 1); the state is written after the loop
+                    coop_ticket = __builtin_amdgcn_readfirstlane(atomicAdd(&a.coop_ctl[1], lane == 0 ? 1 : 0));
+                    if (coop_ticket < a.coop_max) break;
+                    coop_ticket = -1;
+                    coop_try = false;           // no slot left: this fit stays where it is
+                }
 #pragma unroll
                 for (int s = 0; s < PPL; ++s) xk1[s] = __builtin_fma(alpha, pk[s], xk[s]);
             }
@@ -858,6 +918,33 @@ __global__ __launch_bounds__(64, TSF_FIT_WPS) void fit_kernel(FitArgs a)
         if (resetB) { ret = TSF_ST_LSFAIL; break; }
         resetB = 2;
         stage = ST_START_LS;
+    }
+    if (coop_ticket >= 0) {
+        // suspended: the whole optimiser state goes to the slot; fit_coop_kernel resumes at this
+        // line-search evaluation
+        double *slot = a.coop_slots + (size_t)coop_ticket * a.coop_stride;
+        if (lane == 0) {
+            CoopVars cv;
+            cv.fk = fk; cv.fk1 = fk1; cv.alpha = alpha; cv.gammak = gammak; cv.dfp = dfp;
+            cv.c1dfp = c1dfp; cv.c2dfp = c2dfp; cv.alpha0 = alpha0; cv.prevF = prevF; cv.prevDFp = prevDFp;
+            cv.alo = alo; cv.aloF = aloF; cv.aloDFp = aloDFp; cv.ahi = ahi; cv.ahiF = ahiF; cv.ahiDFp = ahiDFp;
+            cv.gp = gp; cv.itNum = itNum; cv.resetB = resetB; cv.hist_len = hist_len; cv.hist_head = hist_head;
+            cv.nits = nits; cv.lsRestarts = lsRestarts; cv.zoom = zoom; cv.zit = zit;
+            cv.gp_valid = gp_valid ? 1 : 0; cv.pk1_scaled = pk1_scaled ? 1 : 0; cv.n_eval = sv.n_eval; cv.pad_ = 0;
+            *reinterpret_cast<CoopVars *>(slot) = cv;
+            a.coop_list[coop_ticket] = (int32_t)n;
+        }
+        if (lane < MAXH) slot[COOP_VARS_D + lane] = lds.rho[lane];
+        coop_put_vec<PPL>(slot, 0, xk); coop_put_vec<PPL>(slot, 1, gk); coop_put_vec<PPL>(slot, 2, pk);
+        // (x, g, p of the previous iterate are dead at a line-search evaluation: the evaluation and the
+        // acceptance that follows overwrite all three before anything reads them)
+        for (int h = 0; h < H; ++h) {
+            double hs_[PPL], hy_[PPL];
+#pragma unroll
+            for (int s = 0; s < PPL; ++s) { hs_[s] = lds.Sb[(h * PPL + s) * W + lane]; hy_[s] = lds.Yb[(h * PPL + s) * W + lane]; }
+            coop_put_vec<PPL>(slot, 6 + h, hs_); coop_put_vec<PPL>(slot, 6 + MAXH + h, hy_);
+        }
+        return;
     }
     store_theta<PPL>(a, sv, n, xk, a.theta);
     if (lane == 0) { a.status[n] = ret; a.n_iter[n] = itNum; a.n_eval[n] = sv.n_eval; a.fval[n] = fk; }

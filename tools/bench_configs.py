@@ -24,14 +24,17 @@ H = 90
 
 def build(name):
     """-> (description, spec, ds, y, floor, cap, extra, extra_future, bytes_per_series)"""
-    if name.endswith(('_mfma', '_wave')) and not name.startswith(('cap', 'long')):
-        # the same configuration with the residual kernel forced (residual_kernel = MFMA / WAVE)
+    if name.endswith(('_mfma', '_wave', '_coop')) and not name.startswith(('cap', 'long')):
+        # the same configuration with the residual kernel forced (residual_kernel = MFMA / WAVE / COOP;
+        # the default AUTO is the one-wave kernel with the cooperative tail)
         from time_series_spark_amd import _lib
         out = list(build(name[:-5]))
         d = out[1].to_dict()
-        d['lbfgs'] = dict(d['lbfgs'], residual_kernel=_lib.RK_MFMA if name.endswith('_mfma') else _lib.RK_WAVE)
+        rk = {'_mfma': _lib.RK_MFMA, '_wave': _lib.RK_WAVE, '_coop': _lib.RK_COOP}[name[-5:]]
+        d['lbfgs'] = dict(d['lbfgs'], residual_kernel=rk)
         out[1] = fc.ModelSpec.from_dict(d)
-        out[0] += ' [matrix-core residual kernel]' if name.endswith('_mfma') else ' [one-wave residual kernel]'
+        out[0] += {'_mfma': ' [matrix-core residual kernel]', '_wave': ' [one-wave residual kernel, no cooperative tail]',
+                   '_coop': ' [cooperative kernel from the first evaluation]'}[name[-5:]]
         return tuple(out)
     if name in ('cfg2', 'cfg2_resid', 'cfg2x4', 'cfg2x16'):
         # cfg2x4 / cfg2x16: the cfg2 model on 40 000 / 160 000 series (throughput, not the longest series)
