@@ -10,7 +10,7 @@
 //   wave 0, the OWNER, runs the same L-BFGS state machine as fit_kernel from the restored state;
 //   an evaluation is split over the waves in the order eval_fg fixes (canonical arithmetic,
 //   tsf_common.h) -- same operations, same operand order, same bits:
-//     A  rows: step q of the 64 chunks (lane = chunk) -> wave 1 + q mod (NW-1): X.beta chain, trend,
+//     A  rows: step q of the 64 chunks (lane = chunk) -> wave 1 + q mod (NW-2): X.beta chain, trend,
 //        r, r g, v of the row into LDS;
 //     B  design column j -> wave 1 + j mod (NW-2): the chunk-partial fma chain over the steps (last
 //        row first) and the 32,16,1,2,4,8 butterfly over the chunks; wave NW-1: the trend sums with
@@ -23,29 +23,44 @@
 
 namespace tsf {
 
+constexpr int COOP_NTB = 16;    // steps per chunk the register-resident loops hold (series of at most 1024 rows)
+
 // ---- LDS of a cooperative workgroup -----------------------------------------------------------
 template <int KP, int PPL>
 struct CoopLds {
     WaveLds<KP, PPL> w;         // the owner's tables: theta, segment tables, time-axis sums, history
     int cmd, item;
-    long long pad_;
+    long long *dbg;             // (dev timing builds) per-series cycle counters, 16 per series
+    // trend wave, NT <= COOP_NTB: where changepoint j's snapshot of the running trend sums is taken
+    // (step and chunk of the first row at or after the changepoint), and the running sums of an
+    // evaluation after every step
+    int snap_q[NTAB], snap_l[NTAB];
+    double run1[COOP_NTB * W], run2[COOP_NTB * W];
 };
 enum { COOP_EVAL = 1, COOP_EXIT = 2 };
 #ifndef COOP_NW
-#define COOP_NW 16              // waves per cooperative workgroup (one workgroup per CU)
+#define COOP_NW 8               // waves per cooperative workgroup (one workgroup per CU, 256 VGPRs per wave)
 #endif
 
+// LDS of the resident rows' first XL values: [step][XL][64]
+__host__ __device__ constexpr size_t coop_xl_bytes(int KP, int NTmax) { return (KP == 28 && NTmax <= 12) ? sizeof(double) * 12 * 14 * W : 0; }
+// row buffers r, r g, v: [rows][64] each, rows = max(NTmax, COOP_NTB) (coop_rb_rows)
+__host__ __device__ constexpr int coop_rb_rows(int NTmax) { return NTmax > 16 ? NTmax : 16; }
 template <int KP, int PPL>
 __host__ __device__ constexpr size_t coop_lds_bytes(int NTmax)
 {
-    return sizeof(CoopLds<KP, PPL>) + sizeof(double) * 3 * (size_t)NTmax * W;
+    return sizeof(CoopLds<KP, PPL>) + sizeof(double) * 3 * (size_t)coop_rb_rows(NTmax) * W + coop_xl_bytes(KP, NTmax);
 }
 
 #ifdef TSF_COOP_TIMING      // dev only: owner-wave cycles per phase, summed per series
 #define CT_DECL long long ct_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long ct_t0 = __builtin_readcyclecounter(), ct_start = ct_t0
 #define CT_LAP(k) do { const long long t_ = __builtin_readcyclecounter(); ct_acc[k] += t_ - ct_t0; ct_t0 = t_; } while (0)
-#define CT_FLUSH(dst, n) do { if ((dst) && lane_id() == 0) { ct_acc[7] = __builtin_readcyclecounter() - ct_start; for (int k_ = 0; k_ < 8; ++k_) ((long long *)(dst))[(size_t)(n) * 8 + k_] = ct_acc[k_]; } } while (0)
+#define CT_FLUSH(dst, n) do { if ((dst) && lane_id() == 0) { ct_acc[7] = __builtin_readcyclecounter() - ct_start; for (int k_ = 0; k_ < 8; ++k_) ((long long *)(dst))[(size_t)(n) * 16 + k_] = ct_acc[k_]; } } while (0)
+#define CT_ARGS , long long (&ct_acc)[8], long long &ct_t0
+#define CT_PASS , ct_acc, ct_t0
 #else
+#define CT_ARGS
+#define CT_PASS
 #define CT_DECL do { } while (0)
 #define CT_LAP(k) do { } while (0)
 #define CT_FLUSH(dst, n) do { } while (0)
@@ -191,27 +206,320 @@ __device__ __forceinline__ double coop_sse(const SeriesView &sv, const double *r
     return bfly_sum(sse);
 }
 
-// ---- the helpers' loop -------------------------------------------------------------------------
+// ---- the helpers' loops ------------------------------------------------------------------------
+// Workgroup barrier that waits for this wave's LDS traffic only: global loads issued before it (the
+// design values of the next phase) stay in flight across it.  __syncthreads() would drain them
+// (its release fence is s_waitcnt vmcnt(0)).  Everything the waves exchange goes through LDS.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+
+// generic loops (any NT <= COOP_MAX_NT): every load inside its phase
 template <int KP, int GROWTH, int MODE, int PPL, int NW, bool XIDX>
 __device__ __forceinline__ void coop_helper(const DevSpec *__restrict__ sp, const SeriesView &sv,
                                             CoopLds<KP, PPL> &cl, double *rbR, double *rbU, double *rbV, int wid)
 {
     for (;;) {
-        __syncthreads();                                    // A: the owner has published theta / ks / mc / cmd
+        lds_barrier();                                      // A: the owner has published theta / ks / mc / cmd
         if (cl.cmd == COOP_EXIT) break;
-        coop_rows<KP, GROWTH, MODE, PPL, XIDX>(sp, sv, cl.w, rbR, rbU, rbV, wid - 1, NW - 1);
-        __syncthreads();                                    // B: rows complete
+        if (wid < NW - 1) coop_rows<KP, GROWTH, MODE, PPL, XIDX>(sp, sv, cl.w, rbR, rbU, rbV, wid - 1, NW - 2);
+        lds_barrier();                                      // B: rows complete
         if (wid == NW - 1) coop_trend(sv, cl.w, rbV);
         else coop_columns<KP, MODE, XIDX>(sp, sv, cl.w, rbR, rbU, wid - 1, NW - 2);
-        __syncthreads();                                    // C: sums complete
+        lds_barrier();                                      // C: sums complete
     }
+}
+
+// ---- helpers for series of at most NTB <= COOP_NTB steps per chunk ------------------------------
+// Roles: waves 1 .. NW-2 take the rows (row q -> wave 1 + q mod (NW-2), RPW rows of a wave side by
+// side: independent chains); TREND = wave NW-1 runs the trend sums.  Design columns:
+//   RES (resident): the design values a wave needs -- its rows for phase A, its columns x all steps
+//     for phase B -- are loaded ONCE per series and stay in registers (8 waves x 256 registers hold the
+//     panel's design matrix twice: 2 x 152 KB for 730 x 26; a CU's L1 fills at 64 B per cycle, so
+//     streaming both copies from L2 costs ~5 k cycles per evaluation); column j -> wave 1 + j mod (NW-1),
+//     the trend wave takes a share after its chain.  An evaluation touches LDS only.
+//   otherwise (wider models / longer series): the rows of phase A are requested before barrier A (they
+//     arrive while the owner runs the optimiser), the columns of phase B CB at a time, the first batch
+//     inside phase A; column j -> wave 1 + j mod (NW-2).
+// Straight-line code: requests that have no row / column / step behind them are clamped to row 0 /
+// column 0 / step 0 and their results dropped or multiplied by the zero rows [NT, COOP_NTB) of the row
+// buffers (cleared once per series by the caller).
+template <int KP, int NW, int NTB>
+struct CoopShape {
+    static constexpr int RPW = 2;                               // rows of a wave held at a time
+    static constexpr int XB = KP <= 32 ? KP : 32;               // design values of a row held at a time
+    static constexpr int NXB = KP / XB;                         // KP = 8, 16, 28: 1;  64: 2
+    static constexpr int CPW_RES = (KP + NW - 2) / (NW - 1);    // columns per wave, resident mode
+    // resident mode, 28 columns x 12 steps: the first XL design values of every row live in LDS instead
+    // of registers (with all of 2 rows x 28 + 4 columns x 12 values in registers the row waves spill
+    // ~30 of them, and every reload is a dependent scratch round trip inside the row chain: 7.4 k
+    // instead of ~2 k cycles per phase A)
+    static constexpr int XL = (KP == 28 && NTB == 12) ? 14 : 0;
+    static constexpr bool RES = NXB == 1 && RPW * (XB - XL) + CPW_RES * NTB <= 76;
+    static constexpr int NCW = RES ? NW - 1 : NW - 2;           // waves that take columns
+    static constexpr int CPW = (KP + NCW - 1) / NCW;
+    static constexpr int CB = RES ? CPW : 3;                    // columns held at a time
+    static constexpr int NCB = (CPW + CB - 1) / CB;
+};
+template <int KP, int GROWTH, int MODE, int PPL, int NW, bool XIDX, int NTB, bool TREND>
+__device__ __forceinline__ void coop_helper_pf(const DevSpec *__restrict__ sp, const SeriesView &sv,
+                                               CoopLds<KP, PPL> &cl, double *rbR, double *rbU, double *rbV, double *xl, int wid)
+{
+#ifdef TSF_COOP_TIMING
+    long long ht_a = 0, ht_b = 0, ht_t = 0;     // busy cycles of this wave in phase A / phase B
+#define HT_START() ht_t = __builtin_readcyclecounter()
+#define HT_STOP(acc) acc += __builtin_readcyclecounter() - ht_t
+#else
+#define HT_START() do { } while (0)
+#define HT_STOP(acc) do { } while (0)
+#endif
+    using SH = CoopShape<KP, NW, NTB>;
+    constexpr int NRW = NW - 2, RPW = SH::RPW, XB = SH::XB, NXB = SH::NXB, CB = SH::CB, NCB = SH::NCB, NCW = SH::NCW;
+    constexpr bool RES = SH::RES;
+    constexpr int XL = RES ? SH::XL : 0;                // design values of a row kept in LDS (xl)
+    constexpr bool ROWS = !TREND, COLS = RES || !TREND;
+    const int lane = lane_id();
+    const int NT = sv.NT, S = sv.S, K = sp->K;
+    const int Ka = (MODE == 0) ? K : (MODE == 1 ? 0 : sp->Ka);
+    auto &w = cl.w;
+    // per-series constants of the wave's rows
+    bool row[RPW], valid[RPW];
+    int idx[RPW], cq[RPW], qrow[RPW];
+    double tq[RPW], yq[RPW];
+    const double *xg[RPW];          // XIDX: the lane's gathered design row
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int q = (wid - 1) + i * NRW;
+        row[i] = ROWS && q < NT;                        // this wave has such a row (wave-uniform)
+        valid[i] = row[i] && q < sv.cnt;                // ... and it exists in this lane's chunk
+        qrow[i] = row[i] ? q : 0;
+        idx[i] = qrow[i] * W + lane;
+        cq[i] = (int)((unsigned)sv.cw[idx[i]] & 0xffu);
+        tq[i] = sv.tw[idx[i]]; yq[i] = sv.yw[idx[i]];
+        xg[i] = XIDX ? sv.Xu + (size_t)(valid[i] ? sv.uw[idx[i]] : 0) * KP : nullptr;
+    }
+    // the trend wave's segment indices and times of its 64 chunks, all steps
+    unsigned cwq[TREND ? NTB : 1];
+    double twq[TREND ? NTB : 1];
+    if constexpr (TREND) {
+        // once per series: the times of the wave's rows (0 where a chunk has no such row: fma(0, 0, s) = s)
+        // and, per changepoint, the (step, chunk) of the row whose running sums eval_fg snapshots
+        // (`for j in [cprev, c): tp[j] = running sums` at the row where the segment index passes j)
+        if (lane < NTAB) { cl.snap_q[lane] = 0; cl.snap_l[lane] = 0; }
+        wave_sync();
+#pragma unroll
+        for (int q = 0; q < NTB; ++q) {
+            const int qi = q < NT ? q : 0;
+            const bool ok = q < NT && q < sv.cnt;
+            cwq[q] = (unsigned)sv.cw[qi * W + lane];
+            const double tv = sv.tw[qi * W + lane];
+            twq[q] = ok ? tv : 0.0;
+            if (ok) {
+                const int c = (int)(cwq[q] & 0xffu), cprev = (int)(cwq[q] >> 8);
+                for (int j = cprev; j < c; ++j) { cl.snap_q[j] = q; cl.snap_l[j] = lane; }
+            }
+        }
+        wave_sync();
+    }
+    // Addresses: a wave-uniform base (scalar registers) plus the lane's offset.  In the streaming mode
+    // `z` is an opaque zero that keeps the compiler from hoisting ~50 loop-invariant 64-bit addresses
+    // into vector registers for the whole series (the base is recomputed with scalar adds instead).
+    auto load_row = [&](int i, int h, int z, double (&x)[XB]) {
+        if (XIDX) {
+#pragma unroll
+            for (int j = 0; j < XB; j += 2) {
+                const double2 v2 = reinterpret_cast<const double2 *>(xg[i])[(h * XB + j) >> 1];
+                x[j] = v2.x; x[j + 1 < XB ? j + 1 : j] = v2.y;
+            }
+        } else {
+            const double *base = sv.Xw + ((size_t)(qrow[i] + z) * KP + h * XB) * W;
+#pragma unroll
+            for (int j = 0; j < XB; ++j) x[j] = base[j * W + lane];
+        }
+    };
+    // column values of batch b: xc[u][q] = X[q][j_u][chunk]
+    auto load_cols = [&](int b, int z, double (&xc)[CB][NTB]) {
+#pragma unroll
+        for (int u = 0; u < CB; ++u) {
+            int j = (wid - 1) + (b * CB + u) * NCW + z;
+            j = j < K ? j : 0;
+#pragma unroll
+            for (int q = 0; q < NTB; ++q) {
+                const int qc = q < NT ? q : 0;
+                if (XIDX) xc[u][q] = (qc < sv.cnt) ? sv.Xu[(size_t)sv.uw[qc * W + lane] * KP + j] : 0.0;
+                else xc[u][q] = (sv.Xw + ((size_t)qc * KP + j) * W)[lane];
+            }
+        }
+    };
+
+    double x[ROWS ? RPW : 1][XB];
+    double xc[COLS ? CB : 1][NTB];
+    if constexpr (RES) {
+        if constexpr (ROWS) {
+#pragma unroll
+            for (int i = 0; i < RPW; ++i) {
+                load_row(i, 0, 0, x[i]);
+                if constexpr (XL > 0) {
+                    if (row[i]) {
+#pragma unroll
+                        for (int j = 0; j < XL; ++j) xl[(qrow[i] * XL + j) * W + lane] = x[i][j];
+                    }
+                }
+            }
+        }
+        load_cols(0, 0, xc);
+    }
+    for (;;) {
+        int z = 0;
+        if constexpr (!RES) {
+            asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+            if constexpr (ROWS) {
+#pragma unroll
+                for (int i = 0; i < RPW; ++i) load_row(i, 0, z, x[i]);
+            }
+        }
+        lds_barrier();                                      // A
+        if (cl.cmd == COOP_EXIT) break;
+        HT_START();
+        if constexpr (ROWS) {
+            double xa[RPW], xm[RPW];
+#pragma unroll
+            for (int i = 0; i < RPW; ++i) { xa[i] = 0.0; xm[i] = 0.0; }
+#pragma unroll
+            for (int h = 0; h < NXB; ++h) {
+                if (h > 0) {
+#pragma unroll
+                    for (int i = 0; i < RPW; ++i) load_row(i, h, z, x[i]);
+                }
+#pragma unroll
+                for (int j = 0; j < XB; ++j) {
+                    const int jj = h * XB + j;
+                    const double bj = w.th[3 + S + jj];     // zero beyond the model's parameters
+#pragma unroll
+                    for (int i = 0; i < RPW; ++i) {
+                        // (resident mode: the first XL values of the row come back from LDS)
+                        const double xv = (j < XL) ? xl[(qrow[i] * XL + j) * W + lane] : x[i][j];
+                        if (MODE == 0) xa[i] = __builtin_fma(xv, bj, xa[i]);
+                        else if (MODE == 1) xm[i] = __builtin_fma(xv, bj, xm[i]);
+                        else { if (jj < Ka) xa[i] = __builtin_fma(xv, bj, xa[i]); else xm[i] = __builtin_fma(xv, bj, xm[i]); }
+                    }
+                    // (keeps the coefficient reads next to their use: hoisted to the top of the chain, the
+                    // 28 of them hold 56 registers beside the resident design values)
+                    if ((j & 3) == 3) {
+#pragma unroll
+                        for (int i = 0; i < RPW; ++i) asm volatile("" : "+v"(xa[i]), "+v"(xm[i]) :: "memory");
+                    }
+                }
+            }
+            if constexpr (!RES) {
+                // The column requests go out here: after the row values are consumed (the empty asm pins
+                // the finished chains at this point -- otherwise the compiler sinks them below the requests
+                // and both sets of design values hold registers together, the rest spills) and ahead of
+                // the trend arithmetic that hides their latency.
+#pragma unroll
+                for (int i = 0; i < RPW; ++i) asm volatile("" : "+v"(xa[i]), "+v"(xm[i]));
+                load_cols(0, z, xc);
+            }
+#pragma unroll
+            for (int i = 0; i < RPW; ++i) {
+                const double ksc = w.ks[cq[i]], mcc = w.mc[cq[i]];
+                double gtr, qv = 0.0;
+                if (GROWTH == 0) {
+                    gtr = __builtin_fma(ksc, tq[i], mcc);
+                } else {
+                    const double z2 = ksc * (tq[i] - mcc);
+                    const double e = dm_exp_sel(-z2);
+                    const double sg = 1.0 / (1.0 + e);
+                    gtr = sv.cap * sg;
+                    qv = gtr * (1.0 - sg);
+                }
+                const double opm = 1.0 + xm[i];
+                const double mu = __builtin_fma(gtr, opm, xa[i]);
+                double r = yq[i] - mu;
+                double rg = r * gtr;
+                double v = r * opm;
+                if (GROWTH == 1) v = v * qv;
+                // rows past the end of a chunk: zeros (fma(x, 0, acc) leaves the chains of phase B unchanged)
+                r = valid[i] ? r : 0.0; rg = valid[i] ? rg : 0.0; v = valid[i] ? v : 0.0;
+                if (row[i]) { rbR[idx[i]] = r; rbU[idx[i]] = rg; rbV[idx[i]] = v; }
+            }
+            // NT beyond RPW rows per wave: the remaining rows the plain way
+            coop_rows<KP, GROWTH, MODE, PPL, XIDX>(sp, sv, w, rbR, rbU, rbV, (wid - 1) + RPW * NRW, NRW);
+        }
+        HT_STOP(ht_a);
+        lds_barrier();                                      // B
+        HT_START();
+        if constexpr (TREND) {
+            // running trend sums of every chunk, last row first (rows a chunk does not have carry
+            // v = 0 and t = 0: the sums pass through unchanged), kept per step; the snapshots at the
+            // changepoint rows are then one gather
+            double rt1 = 0.0, rt2 = 0.0;
+#pragma unroll
+            for (int q = NTB - 1; q >= 0; --q) {
+                const double v = rbV[q * W + lane];         // (zero rows beyond NT)
+                rt1 = __builtin_fma(v, twq[q], rt1);
+                rt2 = rt2 + v;
+                cl.run1[q * W + lane] = rt1; cl.run2[q * W + lane] = rt2;
+            }
+            const double s1 = suffix_scan(rt1), s2v = suffix_scan(rt2);
+            w.tot1[lane] = s1; w.tot2[lane] = s2v;
+            if (lane == 0) { w.tot1[W] = 0.0; w.tot2[W] = 0.0; }
+            wave_sync();
+            if (lane < S) {
+                const int at = cl.snap_q[lane] * W + cl.snap_l[lane];
+                w.tp1[lane] = cl.run1[at]; w.tp2[lane] = cl.run2[at];
+            }
+        }
+        if constexpr (COLS) {
+#pragma unroll
+            for (int b = 0; b < NCB; ++b) {
+                if (!RES && b > 0) load_cols(b, z, xc);
+                double acc[CB];
+#pragma unroll
+                for (int u = 0; u < CB; ++u) acc[u] = 0.0;
+#pragma unroll
+                for (int q = NTB - 1; q >= 0; --q) {
+                    // (steps in [NT, NTB): zero rows of the buffers, fma(x, 0, acc) = acc)
+                    const double r0 = (MODE == 1) ? 0.0 : rbR[q * W + lane];
+                    const double r1 = (MODE == 0) ? 0.0 : rbU[q * W + lane];
+#pragma unroll
+                    for (int u = 0; u < CB; ++u) {
+                        const int j = (wid - 1) + (b * CB + u) * NCW;
+                        const double ru = (MODE == 0) ? r0 : (MODE == 1 ? r1 : (j < Ka ? r0 : r1));
+                        acc[u] = __builtin_fma(xc[u][q], ru, acc[u]);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < CB; ++u) {
+                    const int j = (wid - 1) + (b * CB + u) * NCW;
+                    const double sacc = chunk_sum_1(acc[u]);
+                    if (j < K && lane == 0) w.accR[j] = sacc;
+                }
+            }
+        }
+        HT_STOP(ht_b);
+        lds_barrier();                                      // C
+    }
+#ifdef TSF_COOP_TIMING
+    if (cl.dbg && lane == 0 && (wid == 1 || wid == NW - 1)) {
+        cl.dbg[wid == 1 ? 8 : 10] = ht_a; cl.dbg[wid == 1 ? 9 : 11] = ht_b;
+    }
+#endif
+}
+
+template <int KP, int GROWTH, int MODE, int PPL, int NW, bool XIDX, int NTB>
+__device__ __forceinline__ void coop_helper_ntb(const DevSpec *__restrict__ sp, const SeriesView &sv,
+                                                CoopLds<KP, PPL> &cl, double *rbR, double *rbU, double *rbV, int wid)
+{
+    double *xl = rbV + (size_t)COOP_NTB * W;            // (present when coop_xl_bytes() > 0: NTmax <= 12 < COOP_NTB rows of row buffers)
+    if (wid == NW - 1) coop_helper_pf<KP, GROWTH, MODE, PPL, NW, XIDX, NTB, true>(sp, sv, cl, rbR, rbU, rbV, xl, wid);
+    else coop_helper_pf<KP, GROWTH, MODE, PPL, NW, XIDX, NTB, false>(sp, sv, cl, rbR, rbU, rbV, xl, wid);
 }
 
 // ---- one evaluation, the owner's side ---------------------------------------------------------
 template <int KP, int GROWTH, int MODE, int PPL, int NW, bool XIDX>
 __device__ __forceinline__ bool coop_eval_owner(const DevSpec *__restrict__ sp, SeriesView &sv,
                                                 CoopLds<KP, PPL> &cl, double *rbR, double *rbU, double *rbV,
-                                                const double (&th)[PPL], double &f_out, double (&g)[PPL])
+                                                const double (&th)[PPL], double &f_out, double (&g)[PPL] CT_ARGS)
 {
     const int lane = lane_id();
     sv.n_eval++;
@@ -219,14 +527,19 @@ __device__ __forceinline__ bool coop_eval_owner(const DevSpec *__restrict__ sp, 
     for (int s = 0; s < PPL; ++s) cl.w.th[lane + s * W] = th[s];
     segment_tables<GROWTH, PPL>(sv, cl.w, th);
     if (lane == 0) cl.cmd = COOP_EVAL;
-    __syncthreads();                                        // A
+    CT_LAP(1);
+    lds_barrier();                                          // A
     const double ls = theta_at<PPL>(th, 2);
     const double sigma = dm_exp_sel(ls);
     const double inv_s2 = 1.0 / (sigma * sigma);
-    __syncthreads();                                        // B
+    lds_barrier();                                          // B
+    CT_LAP(2);
     const double sse_t = coop_sse(sv, rbR);
-    __syncthreads();                                        // C
-    return eval_tail<GROWTH, PPL>(sp, sv, cl.w, cl.w, th, sigma, inv_s2, sse_t, f_out, g);
+    lds_barrier();                                          // C
+    CT_LAP(3);
+    const bool bad_ = eval_tail<GROWTH, PPL>(sp, sv, cl.w, cl.w, th, sigma, inv_s2, sse_t, f_out, g);
+    CT_LAP(4);
+    return bad_;
 }
 
 // ---- the owner: fit_kernel's L-BFGS loop, resumed at a line-search evaluation -----------------
@@ -330,8 +643,7 @@ __device__ __forceinline__ void coop_owner(const FitArgs &a, SeriesView &sv, int
             for (int s = 0; s < PPL; ++s) xk1[s] = __builtin_fma(alpha, pk[s], xk[s]);
             double f1;
             CT_LAP(0);
-            const bool bad = coop_eval_owner<KP, GROWTH, MODE, PPL, NW, XIDX>(sp, sv, cl, rbR, rbU, rbV, xk1, f1, gk1);
-            CT_LAP(1);
+            const bool bad = coop_eval_owner<KP, GROWTH, MODE, PPL, NW, XIDX>(sp, sv, cl, rbR, rbU, rbV, xk1, f1, gk1 CT_PASS);
             f1 = uniform_f64(f1);
             if (bad) {
                 if (!zoom) {
@@ -470,7 +782,7 @@ __device__ __forceinline__ void coop_owner(const FitArgs &a, SeriesView &sv, int
         stage = ST_START_LS;
     }
     if (lane == 0) cl.cmd = COOP_EXIT;
-    __syncthreads();                                        // A of the helpers' last round
+    lds_barrier();                                          // A of the helpers' last round
     store_theta<PPL>(a, sv, n, xk, a.theta);
     if (lane == 0) { a.status[n] = ret; a.n_iter[n] = itNum; a.n_eval[n] = sv.n_eval; a.fval[n] = fk; }
     CT_LAP(0);
@@ -484,8 +796,8 @@ __global__ __launch_bounds__(NW * 64) void fit_coop_kernel(FitArgs a)
     extern __shared__ __align__(16) unsigned char smem[];
     CoopLds<KP, PPL> &cl = *reinterpret_cast<CoopLds<KP, PPL> *>(smem);
     double *rbR = reinterpret_cast<double *>(smem + sizeof(CoopLds<KP, PPL>));
-    double *rbU = rbR + (size_t)a.NTmax * W, *rbV = rbU + (size_t)a.NTmax * W;
-    const int wid = (int)threadIdx.x >> 6;
+    double *rbU = rbR + (size_t)coop_rb_rows(a.NTmax) * W, *rbV = rbU + (size_t)coop_rb_rows(a.NTmax) * W;
+    const int wid = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);     // wave-uniform: addresses built from it stay scalar
     int n_ckpt = a.coop_ctl[1];
     if (n_ckpt > a.coop_max) n_ckpt = a.coop_max;
     for (;;) {
@@ -501,12 +813,23 @@ __global__ __launch_bounds__(NW * 64) void fit_coop_kernel(FitArgs a)
         const int64_t n = a.coop_list[item];
         SeriesView sv;
         make_view<KP, PPL>(a, n, sv);
+        // rows [NT, COOP_NTB) of the row buffers: zeros (the straight-line chains of coop_helper_pf)
+        if (sv.NT < COOP_NTB) {
+            for (int i = sv.NT * W + (int)threadIdx.x; i < COOP_NTB * W; i += NW * W) { rbR[i] = 0.0; rbU[i] = 0.0; rbV[i] = 0.0; }
+        }
+#ifdef TSF_COOP_TIMING
+        if (threadIdx.x == 0) cl.dbg = a.grad_out ? (long long *)a.grad_out + (size_t)n * 16 : nullptr;
+#endif
         if (wid == 0) {
             for (int i = lane_id(); i < TSF_MAX_P + W; i += W) cl.w.th[i] = 0.0;
             TSF_WAVE_SYNC();
             coop_owner<KP, GROWTH, MODE, PPL, NW, XIDX>(a, sv, n, a.coop_slots + (size_t)item * a.coop_stride, cl, rbR, rbU, rbV);
-        } else {
+        } else if (sv.NT > COOP_NTB) {
             coop_helper<KP, GROWTH, MODE, PPL, NW, XIDX>(a.sp, sv, cl, rbR, rbU, rbV, wid);
+        } else if (a.NTmax > 12) {      // (the call's longest series decides: the LDS of the 12-step variant is sized by it)
+            coop_helper_ntb<KP, GROWTH, MODE, PPL, NW, XIDX, COOP_NTB>(a.sp, sv, cl, rbR, rbU, rbV, wid);
+        } else {
+            coop_helper_ntb<KP, GROWTH, MODE, PPL, NW, XIDX, 12>(a.sp, sv, cl, rbR, rbU, rbV, wid);
         }
     }
 }
