@@ -139,6 +139,38 @@ def parity_context(f, spec, ds, y, fut, yhat_quad, n=256):
     return out
 
 
+def simulate_strong_scaling(n_eval, fit_ms, n_cu, waves_per_cu=12):
+    """What `bench.py --gpus G` (ONE panel split i mod G) should show, from THIS run's per-series
+    evaluation counts: every GPU is a queue of n_cu x waves_per_cu wave slots that takes its series in
+    index order, a series holds its slot for n_eval x tau, and tau is calibrated so that G = 1
+    reproduces the measured fit-path kernel time.  A model (one evaluation time for busy and idle
+    phases), labelled as such: a first real multi-GPU run has something to be compared with."""
+    import heapq
+    n_eval = np.asarray(n_eval, dtype=np.float64)
+    slots = int(n_cu) * waves_per_cu
+
+    def makespan(ev):
+        if len(ev) <= slots:
+            return float(ev.max())
+        h = [0.0] * slots
+        heapq.heapify(h)
+        end = 0.0
+        for e in ev:
+            t = heapq.heappop(h) + e
+            end = max(end, t)
+            heapq.heappush(h, t)
+        return end
+    base = makespan(n_eval)
+    tau_ms = fit_ms / base
+    out = {'model': 'greedy queue over %d wave slots per GPU, tau = %.3f us per evaluation (calibrated on G = 1)' % (slots, 1e3 * tau_ms),
+           'label': 'simulated', 'gpus': {}}
+    for g in (1, 2, 4, 8):
+        ms = max(makespan(n_eval[r::g]) for r in range(g)) * tau_ms
+        out['gpus'][str(g)] = {'fit_kernel_ms': ms, 'series_per_s_kernel_only': len(n_eval) / (ms * 1e-3)}
+    out['longest_series_ms'] = float(n_eval.max()) * tau_ms
+    return out
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/pmc_latest.json, written by tools/pmc_summary.py from separate FETCH_SIZE and
@@ -182,66 +214,59 @@ def main():
     dev = torch.device('cuda', local)
 
     spec = cfg2_spec()
-    ds_np, y_np = synth.make_panel(N_SERIES, T_POINTS, 'linear', seed=751 + rank)
+    # N = 1: the BASELINE.json metric as stated -- one 10 000 x 730 panel on one GPU.
+    # N > 1: the SAME quantity ("series fitted/sec on a 10k x 730-pt panel at 1/2/4/8 MI355X"): ONE
+    # 10 000-series panel split over the ranks, series i on rank i mod N (strong scaling; no
+    # collective on the data path), is `value`; the weak-scaling run (every rank its own 10 000-series
+    # panel) is timed the same way afterwards and reported beside it.
+    ds_np, y_full = synth.make_panel(N_SERIES, T_POINTS, 'linear', seed=751)
+    y_np = np.ascontiguousarray(y_full[rank::world])
+    n_local = y_np.shape[0]
     fut_np = ds_np[-1] + synth.DAY_NS * np.arange(1, HORIZON + 1)
     ds = torch.from_numpy(ds_np).to(dev)
     y = torch.from_numpy(y_np).to(dev)
     fut = torch.from_numpy(fut_np).to(dev)
     f = DeviceForecaster(spec, local)
-    out = f.alloc_fit_output(N_SERIES)
-    yhat = torch.zeros((N_SERIES, HORIZON), dtype=torch.float64, device=dev)
-    yint = torch.zeros((N_SERIES, HORIZON), dtype=torch.int32, device=dev)
 
-    def step():
-        f.fit_aligned(ds, y, out)
-        f.predict(out, fut, yhat, yint)
+    def timed_leg(yy):
+        """W warm-up + K timed steps (fit + 90-step forecast of the panel `yy`, resident in HBM),
+        bracketed by barrier + synchronize on both sides, MAX over ranks."""
+        n = yy.shape[0]
+        o = f.alloc_fit_output(n)
+        yh = torch.zeros((n, HORIZON), dtype=torch.float64, device=dev)
+        yi = torch.zeros((n, HORIZON), dtype=torch.int32, device=dev)
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    f.set_profiling(True)
-    parallel.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    parallel.barrier()
-    dt = time.perf_counter() - t0
-    dt = parallel.max_over_ranks(dt, dev if world > 1 else None)
-    kernel_ms = f.profile_read()
-    f.set_profiling(False)
+        def step():
+            f.fit_aligned(ds, yy, o)
+            f.predict(o, fut, yh, yi)
 
-    # strong scaling: ONE N_SERIES panel (rank 0's) split over the ranks, series i on rank i mod world
-    strong = None
-    if world > 1:
-        ds0, y0 = synth.make_panel(N_SERIES, T_POINTS, 'linear', seed=751)
-        ys = torch.from_numpy(np.ascontiguousarray(y0[rank::world])).to(dev)
-        ns = ys.shape[0]
-        outs = f.alloc_fit_output(ns)
-        yhs = torch.zeros((ns, HORIZON), dtype=torch.float64, device=dev)
-        yis = torch.zeros((ns, HORIZON), dtype=torch.int32, device=dev)
-
-        def sstep():
-            f.fit_aligned(ds, ys, outs)
-            f.predict(outs, fut, yhs, yis)
-
-        for _ in range(max(args.warmup, 1)):
-            sstep()
+        for _ in range(args.warmup):
+            step()
         torch.cuda.synchronize()
+        f.set_profiling(True)
         parallel.barrier()
         torch.cuda.synchronize()
-        t1 = time.perf_counter()
+        t0 = time.perf_counter()
         for _ in range(args.steps):
-            sstep()
+            step()
         torch.cuda.synchronize()
         parallel.barrier()
-        dts = parallel.max_over_ranks(time.perf_counter() - t1, dev)
-        strong = {'value': N_SERIES * args.steps / dts, 'unit': 'series/s', 'ms_per_step': 1e3 * dts / args.steps,
-                  'series_total': N_SERIES, 'series_per_gpu': int(ns), 'scaling': 'strong',
-                  'note': 'one %d-series panel split over %d GPUs (series i on rank i mod %d); a launch is '
-                          'bounded below by its longest series, so strong scaling of a 10k panel saturates '
-                          'early (DESIGN.md section 7)' % (N_SERIES, world, world)}
+        dt_ = time.perf_counter() - t0
+        dt_ = parallel.max_over_ranks(dt_, dev if world > 1 else None)
+        kms = f.profile_read()
+        f.set_profiling(False)
+        return dt_, kms, o, yh
+
+    dt, kernel_ms, out, yhat = timed_leg(y)
+
+    weak = None
+    if world > 1:
+        _, yw_np = synth.make_panel(N_SERIES, T_POINTS, 'linear', seed=751 + rank)
+        dtw, kmsw, _, _ = timed_leg(torch.from_numpy(yw_np).to(dev))
+        weak = {'value': world * N_SERIES * args.steps / dtw, 'unit': 'series/s', 'ms_per_step': 1e3 * dtw / args.steps,
+                'series_per_gpu': N_SERIES, 'series_total': world * N_SERIES, 'scaling': 'weak',
+                'fit_kernel_ms_rank0': float(np.mean(kmsw)) if kmsw else None,
+                'note': 'every rank fits its own %d-series panel (per-GPU work fixed)' % N_SERIES}
 
     if rank != 0:
         return
@@ -268,7 +293,7 @@ def main():
     P = 3 + spec.n_changepoints + spec.K
     bytes_per_series = T_POINTS * 8 + P * 8 + HORIZON * 8
     fit_ms = float(np.mean(kernel_ms)) if kernel_ms else float('nan')
-    achieved = bytes_per_series * N_SERIES / (fit_ms * 1e-3) / 1e9
+    achieved = bytes_per_series * n_local / (fit_ms * 1e-3) / 1e9
     quad = spec.lbfgs.get('eval_form', 0) != 1      # cfg2 is linear + additive + aligned
     kernel = 'fit_quad_kernel' if quad else 'fit_kernel'
     traffic, traffic_src = pmc_traffic(kernel)
@@ -282,15 +307,18 @@ def main():
         flops_per_eval = 4 * T_POINTS * spec.K + 20 * T_POINTS + 6 * spec.n_changepoints
     tflops = float(n_eval.sum()) * flops_per_eval / (fit_ms * 1e-3) / 1e12
     res = {
-        'metric': 'series_fitted_per_sec', 'value': world * N_SERIES * args.steps / dt,
+        'metric': 'series_fitted_per_sec', 'value': N_SERIES * args.steps / dt,
         'unit': 'series/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+        'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,
+        'scaling': 'weak' if world == 1 else 'strong',
         'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-        'config': {'workload': 'cfg2: %d series x %d daily points per GPU, linear trend + 25 '
+        'config': {'workload': 'cfg2: ONE panel of %d series x %d daily points%s, linear trend + 25 '
                                'changepoints, weekly(3)+yearly(10) additive Fourier, MAP L-BFGS '
                                '(Stan default tolerances) + %d-step forecast'
-                               % (N_SERIES, T_POINTS, HORIZON),
-                   'series_per_gpu': N_SERIES, 'points': T_POINTS, 'horizon': HORIZON,
+                               % (N_SERIES, T_POINTS,
+                                  '' if world == 1 else ' split over %d GPUs (series i on rank i mod %d, no collective)' % (world, world),
+                                  HORIZON),
+                   'series_total': N_SERIES, 'series_per_gpu': n_local, 'points': T_POINTS, 'horizon': HORIZON,
                    'K': spec.K, 'S': spec.n_changepoints, 'P': P,
                    'eval_form': 'quadratic (Gram) form, re-centred' if quad else 'residual form',
                    'parallelism': 'shard-by-id x%d' % world},
@@ -298,7 +326,7 @@ def main():
                      'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS,
                      'peak_measured_device_copy': copy_gbps,
                      'traffic': traffic, 'traffic_source': traffic_src,
-                     'algorithmic_bytes_per_launch': bytes_per_series * N_SERIES,
+                     'algorithmic_bytes_per_launch': bytes_per_series * n_local,
                      'kernel_ms_avg': fit_ms, 'launches_timed': len(kernel_ms),
                      'note': 'HBM sees each series once in and once out; the fit itself is a '
                              'vector-issue- and latency-bound fp64 L-BFGS loop on registers/LDS '
@@ -316,8 +344,13 @@ def main():
                       'status_counts': {str(int(k)): int(v) for k, v in
                                         zip(*np.unique(status, return_counts=True))}},
     }
-    if strong is not None:
-        res['strong_scaling'] = strong
+    if weak is not None:
+        res['weak_scaling'] = weak
+    if world == 1:
+        try:
+            res['strong_scaling_simulated'] = simulate_strong_scaling(n_eval, fit_ms, torch.cuda.get_device_properties(local).multi_processor_count)
+        except Exception as e:
+            res['strong_scaling_simulated'] = {'error': str(e)}
     # host-pointer entry point (what a DataFrame caller uses): the panel crosses PCIe, device
     # buffers are allocated per call; never part of `value`, reported beside it
     if world == 1 and not args.timed_only:

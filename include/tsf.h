@@ -296,6 +296,10 @@ void tsf_pack_free(tsf_pack *p);
  *   quantity    integer (the reference's schema) or decimal; an empty field is a null and
  *               comes out as NaN (the packer drops it as fbprophet drops y.isnull() rows)
  *   rows come out in file order, files in the order given.
+ *   A trailing '?' in layout ("dtq?") = Spark's default CSV mode PERMISSIVE: a line that does not
+ *   match the schema (a field that does not convert, too few fields) is not an error but a row of
+ *   nulls -- emitted here with a NaN quantity, which the packer drops like any null-y row;
+ *   tsf_csv_malformed counts them.  Without it the first such line fails the read (FAILFAST).
  * Returns 0; TSF_CSV_E_OPEN / TSF_CSV_E_PARSE with *err_file (index into paths) and *err_line
  * (1-based) set; -1 bad arguments, -2 out of memory, -3 other failure. */
 enum { TSF_CSV_E_OPEN = -10, TSF_CSV_E_PARSE = -11 };
@@ -304,6 +308,7 @@ int tsf_csv_read(int32_t n_files, const char *const *paths, const int64_t *serie
                  const char *layout, int32_t n_threads, tsf_csv **out, int64_t *n_rows,
                  int32_t *err_file, int64_t *err_line);
 int tsf_csv_fetch(tsf_csv *t, int64_t *series_id, int64_t *dim_id, int64_t *ds, double *y);
+int64_t tsf_csv_malformed(const tsf_csv *t);     /* rows replaced by nulls in permissive mode */
 void tsf_csv_free(tsf_csv *t);
 
 /* ---- forecast sink (host side) -------------------------------------------------------------

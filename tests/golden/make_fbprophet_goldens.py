@@ -46,6 +46,8 @@ def fit_predict(Prophet, df, fut, growth, mode, yearly, weekly, daily, holidays=
                 weekly_seasonality=weekly, daily_seasonality=daily, holidays=holidays)
     m.fit(df)
     fc = m.predict(fut)
+    tcc = getattr(m, 'train_component_cols', None)      # fbprophet 0.5: a DataFrame indexed by design column
+    cols = [str(c) for c in tcc.index] if isinstance(tcc, pd.DataFrame) else []
     return {'k': float(m.params['k'][0]), 'm': float(m.params['m'][0]),
             'sigma_obs': float(m.params['sigma_obs'][0]),
             'delta': np.asarray(m.params['delta'][0], dtype=np.float64),
@@ -53,7 +55,7 @@ def fit_predict(Prophet, df, fut, growth, mode, yearly, weekly, daily, holidays=
             'y_scale': float(m.y_scale), 'start_ns': int(pd.Timestamp(m.start).value),
             't_scale_ns': int(pd.Timedelta(m.t_scale).value),
             'changepoints_t': np.asarray(m.changepoints_t, dtype=np.float64),
-            'columns': np.array(list(m.train_component_cols.index if hasattr(m.train_component_cols, 'index') else []), dtype=str),
+            'columns': np.array(cols, dtype=str),
             'yhat': fc['yhat'].values.astype(np.float64), 'trend': fc['trend'].values.astype(np.float64)}
 
 

@@ -1,0 +1,105 @@
+"""GPU tests against the LITERAL restatement (oracle/fbprophet_restated.py: method-by-method numpy
+statement of fbprophet 0.5 and of prophet.stan's log-posterior with the dense changepoint matrix A),
+not against the canonical C oracle that shares the kernels' operation order.  What passes here does
+not pass through oracle/prophet_canon.c at all: the HIP log-posterior and gradient, the HIP
+predict, and the end point of the HIP fit judged by scipy's L-BFGS-B on the literal function.
+Parity is vs the restated oracle, NOT real fbprophet (unpinned, see oracle/ headers)."""
+import numpy as np
+import pandas as pd
+import pytest
+
+from tests import helpers
+from tests.test_oracle import _literal
+
+pytestmark = pytest.mark.gpu
+ULP = 2.220446049250313e-16
+
+
+@pytest.fixture(scope='module')
+def fc(built):
+    from time_series_spark_amd import _lib, forecaster
+    if _lib.load().tsf_device_count() < 1:
+        pytest.fail('no GPU visible')
+    return forecaster
+
+
+@pytest.mark.parametrize('case', list(helpers.CASES))
+def test_hip_log_posterior_and_gradient_against_the_literal_stan_model(fc, case):
+    """tsf_eval (eval_kernel: the residual-form evaluation every fit kernel shares) == the dense-A
+    numpy prophet.stan at random points around fbprophet's initial values: f to 1e-12, the gradient
+    to 1e-11 (relative to 1 + |g|), for every series of the case."""
+    from oracle.fbprophet_restated import stan_neg_log_prob_grad
+    spec, ds, y, floor, cap, extra, fut, exf = helpers.make_case(case)
+    N = y.shape[0]
+    rng = np.random.default_rng(17)
+    dats, th = [], np.zeros((N, spec.theta_stride))
+    for n in range(N):
+        m, dat, th0, _ = _literal(case, n)
+        assert th0.size == spec.theta_stride          # S = n_changepoints on these cases: same layout
+        dats.append(dat)
+        th[n] = th0 + rng.normal(0, 0.02, th0.size)
+    f, g = fc.eval_aligned(spec, ds, y, th, floor=floor, cap=cap, extra=extra)
+    for n in range(N):
+        fl, gl = stan_neg_log_prob_grad(dats[n], th[n])
+        assert abs(f[n] - fl) <= 1e-12 * abs(fl), (case, n)
+        assert np.max(np.abs(g[n] - gl) / (1 + np.abs(gl))) <= 1e-11, (case, n)
+
+
+@pytest.mark.parametrize('case', ['cfg2_linear_additive', 'ref_logistic_multiplicative',
+                                  'linear_multiplicative_365', 'logistic_additive_400', 'cfg4_holidays'])
+def test_hip_fit_and_predict_against_the_literal_prophet(fc, case):
+    """The parameters the HIP fit returns, put into the literal Prophet restatement (its own
+    setup_dataframe / make_all_seasonality_features / piecewise_* / predict), give the HIP forecast
+    to a few ulp; and the literal log-posterior at those parameters is the objective the kernel
+    reported."""
+    from oracle.fbprophet_restated import stan_neg_log_prob_grad
+    m, dat, th0, (spec, ds, y, floor, cap, extra, fut, exf) = _literal(case)
+    r = fc.fit_aligned(spec, ds, y[:1], floor=floor[:1], cap=cap[:1], extra=extra)
+    assert r.status[0] > 0
+    yhat = fc.predict(spec, r.theta, r.y_scale, r.grid, fut, floor=floor[:1], cap=cap[:1], extra_future=exf)[0]
+    f_lit, _ = stan_neg_log_prob_grad(dat, r.theta[0])
+    assert abs(f_lit - r.fval[0]) <= 1e-9 * abs(f_lit)
+    df = pd.DataFrame({'ds': pd.to_datetime(ds), 'y': y[0]})
+    if spec.growth == 'logistic':
+        df['floor'], df['cap'] = floor[0], cap[0]
+    m2 = type(m)(growth=spec.growth, seasonality_mode=spec.seasonality_mode,
+                 yearly_seasonality=m.yearly_seasonality, weekly_seasonality=True, daily_seasonality=False,
+                 holidays=m.holidays)
+    m2.fit(df, optimizer=lambda dat_, th0_, **kw: (r.theta[0].copy(), {'status': int(r.status[0])}))
+    assert abs(m2.y_scale - r.y_scale[0]) <= 4 * ULP * m2.y_scale
+    fdf = pd.DataFrame({'ds': pd.to_datetime(fut)})
+    if spec.growth == 'logistic':
+        fdf['floor'], fdf['cap'] = floor[0], cap[0]
+    lit = m2.predict(fdf)['yhat'].values
+    assert np.max(np.abs(yhat - lit) / np.abs(lit)) <= 16 * ULP
+
+
+@pytest.mark.parametrize('case', ['cfg2_linear_additive', 'ref_logistic_multiplicative', 'short_90',
+                                  'logistic_additive_400', 'cfg4_holidays', 'short_90@newton'])
+def test_hip_map_estimate_against_an_independent_optimiser(fc, case):
+    """scipy's L-BFGS-B (own line search, own stopping rule, tight tolerance) on the LITERAL numpy
+    log-posterior from fbprophet's initial values, against the end point of the HIP fit (Stan's
+    L-BFGS, or Stan's Newton for the 90-row case): the objective within a small gap of scipy's
+    minimum and the in-sample curves within a fraction of the fitted noise level.  Same bounds as the
+    CPU twin of this test (tests/test_oracle.py), measured there."""
+    from scipy.optimize import minimize
+    from oracle.fbprophet_restated import stan_neg_log_prob_grad, stan_trend, unpack_theta
+    from time_series_spark_amd import _lib
+    newton = case.endswith('@newton')
+    m, dat, th0, (spec, ds, y, floor, cap, extra, fut, exf) = _literal(case.split('@')[0])
+    if newton:
+        spec = type(spec).from_dict(dict(spec.to_dict(), lbfgs=dict(spec.lbfgs, algorithm=_lib.ALGO_NEWTON)))
+    r = fc.fit_aligned(spec, ds, y[:1], floor=floor[:1], cap=cap[:1], extra=extra)
+    assert r.status[0] > 0
+    res = minimize(lambda th: stan_neg_log_prob_grad(dat, th), th0, jac=True, method='L-BFGS-B',
+                   options=dict(maxiter=50000, maxfun=200000, ftol=1e-15, gtol=1e-7, maxcor=20))
+    f_hip, _ = stan_neg_log_prob_grad(dat, r.theta[0])
+    gap = f_hip - res.fun
+    assert -0.5 <= gap <= 0.5, (case, gap)
+
+    def fitted(th):
+        k, mm, ls, delta, beta = unpack_theta(th, dat['S'], dat['K'])
+        X = dat['X']
+        return stan_trend(dat, k, mm, delta) * (1 + X @ (beta * dat['s_m'])) + X @ (beta * dat['s_a'])
+    a, b = fitted(r.theta[0]), fitted(res.x)
+    assert np.sqrt(np.mean((a - b) ** 2)) <= 0.05 * np.exp(res.x[2]), case

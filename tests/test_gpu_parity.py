@@ -603,6 +603,19 @@ def test_odd_shapes_against_oracle(env):
     check(fc.ModelSpec(growth='linear', seasonalities=[helpers.WEEKLY]), ds, yc)
 
 
+def _sample_with_stragglers(r, bad, rng, n_random, n_special=6):
+    """Series to bit-check against the oracle: a random sample over ALL series (no filter on how long
+    they ran), the series with the most evaluations, and every series that ended at the iteration cap,
+    in a failed line search or at the evaluation guard (at most n_special of each kind) -- the
+    stragglers whose trajectories are the longest chains of dependent roundings."""
+    pick = list(rng.choice(r.N, n_random, replace=False))
+    pick.append(int(np.argmax(r.n_eval)))
+    for code in (40, -1, -3):
+        pick += list(np.flatnonzero(r.status == code)[:n_special])
+    return np.array(sorted(set(int(i) for i in pick)))
+
+
+
 def test_full_size_panel_properties(env):
     """BASELINE config 2 at full size (10 000 x 730): size-independent properties --
     every series terminates normally, forecasts finite, doubling y doubles the forecast
@@ -689,14 +702,21 @@ def test_full_size_cfg4_logistic_holidays(env):
     assert np.isin(r.status[~bad], [10, 20, 21, 30, 31, 40]).all()
     yh = fc.predict(spec, r.theta, r.y_scale, r.grid, fut, floor=floor, cap=cap, extra_future=exf)
     assert np.isfinite(yh[~bad]).all()
-    sub = np.random.default_rng(4).choice(np.flatnonzero(~bad & (r.n_eval < 3000)), 6, replace=False)
+    # no filter on the trajectory length: the longest series (tens of thousands of evaluations, finished
+    # by the cooperative kernel) and every MAXIT / LSFAIL / EVAL_LIMIT series are checked too
+    sub = _sample_with_stragglers(r, bad, np.random.default_rng(4), 5, n_special=3)
+    assert r.n_eval[sub].max() == r.n_eval.max()
     csp = helpers.oracle_spec(spec)
     for n in sub:
         o = cl.fit(csp, ds, y[n], floor[n], cap[n], extra)
-        yo, _ = cl.predict(csp, o, fut, floor[n], cap[n], exf)
-        assert (r.n_iter[n], r.n_eval[n], r.status[n]) == (o['n_iter'], o['n_eval'], o['status'])
-        assert np.max(np.abs(yh[n] - yo) / np.abs(yo)) <= REL_TOL
-        assert np.array_equal(yh[n], yo) and n_bit_diff(r.fval[n], o['f']) == 0
+        assert (r.n_iter[n], r.n_eval[n], r.status[n]) == (o['n_iter'], o['n_eval'], o['status']), n
+        assert n_bit_diff(r.fval[n], o['f']) == 0, n
+        S = o['info'].S
+        assert n_bit_diff(r.theta[n][:3 + S], o['theta'][:3 + S]) == 0 and n_bit_diff(r.theta[n][3 + spec.n_changepoints:], o['theta'][3 + S:]) == 0
+        if r.status[n] > 0:
+            yo, _ = cl.predict(csp, o, fut, floor[n], cap[n], exf)
+            assert np.max(np.abs(yh[n] - yo) / np.abs(yo)) <= REL_TOL
+            assert np.array_equal(yh[n], yo)
 
 
 @pytest.mark.parametrize('kernel', ['auto', 'mfma'])
@@ -717,14 +737,46 @@ def test_full_size_reference_model_on_both_residual_kernels(env, kernel):
     bad = r.status <= 0
     assert bad.sum() <= 4 and np.isin(r.status[bad], [-1, -3]).all() and (r.n_iter >= 1).all()
     fut = ds[-1] + helpers.DAY_NS * np.arange(1, H + 1)
-    sub = np.random.default_rng(7).choice(np.flatnonzero(~bad & (r.n_eval < 2500)), 8, replace=False)
+    sub = _sample_with_stragglers(r, bad, np.random.default_rng(7), 7, n_special=3)     # stragglers included
+    assert r.n_eval[sub].max() == r.n_eval.max()
     yh = fc.predict(spec, r.theta[sub], r.y_scale[sub], r.grid, fut, floor=floor[sub], cap=cap[sub])
     csp = helpers.oracle_spec(spec)
     for i, n in enumerate(sub):
         o = cl.fit(csp, ds, y[n], floor[n], cap[n])
-        yo, _ = cl.predict(csp, o, fut, floor[n], cap[n])
-        assert (r.n_iter[n], r.n_eval[n], r.status[n]) == (o['n_iter'], o['n_eval'], o['status'])
-        assert np.array_equal(yh[i], yo) and n_bit_diff(r.fval[n], o['f']) == 0
+        assert (r.n_iter[n], r.n_eval[n], r.status[n]) == (o['n_iter'], o['n_eval'], o['status']), n
+        assert n_bit_diff(r.fval[n], o['f']) == 0 and n_bit_diff(r.theta[n], o['theta']) == 0, n
+        if r.status[n] > 0:
+            yo, _ = cl.predict(csp, o, fut, floor[n], cap[n])
+            assert np.array_equal(yh[i], yo)
+
+
+def test_full_size_cfg5_under_fbprophets_own_optimiser_rule(env):
+    """BASELINE config 5 as fbprophet would run it: 90 rows < 100 -> Stan's Newton
+    (algorithm = AUTO applies `'Newton' if T < 100 else 'LBFGS'`), 100 000 fp32 series.  Every series
+    ends converged (or, rarely, at the iteration cap); a random sample plus the series with the most
+    evaluations are bit-identical to the oracle's Newton, forecasts included."""
+    fc, cl = env
+    from time_series_spark_amd import _lib, synth
+    N, T, H = 100000, 90, 90
+    ds, y = synth.make_panel(N, T, 'linear', seed=751, dtype=np.float32)
+    spec = fc.ModelSpec(growth='linear', seasonalities=fc.ModelSpec.auto_seasonalities(ds), algorithm=_lib.ALGO_AUTO)
+    assert spec.K == 6
+    r = fc.fit_aligned(spec, ds, y)
+    assert np.isin(r.status, [_lib.ST_NEWTON_CONVERGED, _lib.ST_MAXIT, _lib.ST_NEWTON_FAIL]).all()
+    assert (r.status == _lib.ST_NEWTON_CONVERGED).mean() >= 0.999
+    fut = ds[-1] + helpers.DAY_NS * np.arange(1, H + 1)
+    rng = np.random.default_rng(12)
+    sub = np.array(sorted(set(list(rng.choice(N, 8, replace=False)) + [int(np.argsort(r.n_eval)[-1])])))
+    yh = fc.predict(spec, r.theta[sub], r.y_scale[sub], r.grid, fut)
+    csp = helpers.oracle_spec(spec)
+    for i, n in enumerate(sub):
+        if r.n_eval[n] > 400000:        # (the oracle needs ~10 us per evaluation: keep the test bounded)
+            continue
+        o = cl.fit_newton(csp, ds, y[n].astype(np.float64))
+        assert (r.n_iter[n], r.n_eval[n], r.status[n]) == (o['n_iter'], o['n_eval'], o['status']), n
+        assert n_bit_diff(r.fval[n], o['f']) == 0 and n_bit_diff(r.theta[n], o['theta']) == 0, n
+        yo, _ = cl.predict(csp, o, fut)
+        assert np.array_equal(yh[i], yo)
 
 
 def test_upstream_known_answer_vectors_through_predict_kernel(env):

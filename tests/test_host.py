@@ -626,3 +626,131 @@ def test_regressor_standardisation_rule():
         mu, sd = features.standardize_regressor(vals)
         assert np.allclose(out['x'].values, (vals - mu) / sd, rtol=0, atol=1e-15)
         assert (mu, sd) == (m.extra_regressors['x']['mu'], m.extra_regressors['x']['std'])
+
+
+# ---- the grouped-map pandas_udf wiring against a stub pyspark ------------------------------------
+
+def _stub_pyspark(monkeypatch):
+    """A stand-in for the three pyspark names the reference imports for its UDFs
+    (prophet_modeler.py:8-9, prophet_scorer.py:8-9): type classes that remember their name,
+    StructType / StructField, and a pandas_udf(schema, functionType) decorator factory that records
+    what it was given.  No JVM, no Spark -- it pins names, types, order and the function type."""
+    import sys
+    import types as pytypes
+    calls = []
+
+    class _T(object):
+        def __init__(self):
+            self.name = type(self).__name__
+
+        def __eq__(self, other):
+            return type(self) is type(other)
+
+    tnames = ['BinaryType', 'FloatType', 'IntegerType', 'TimestampType', 'DoubleType', 'LongType', 'StringType']
+    tmod = pytypes.ModuleType('pyspark.sql.types')
+    for nm in tnames:
+        setattr(tmod, nm, type(nm, (_T,), {}))
+
+    class StructField(object):
+        def __init__(self, name, dataType, nullable=True):
+            self.name, self.dataType, self.nullable = name, dataType, nullable
+
+    class StructType(object):
+        def __init__(self, fields):
+            self.fields = list(fields)
+    tmod.StructField, tmod.StructType = StructField, StructType
+
+    class PandasUDFType(object):
+        SCALAR, GROUPED_MAP, GROUPED_AGG = 200, 201, 202
+
+    def pandas_udf(schema, functionType):
+        def deco(fn):
+            calls.append((schema, functionType, fn))
+
+            def wrapped(pdf):
+                return fn(pdf)
+            wrapped.returnType, wrapped.evalType, wrapped.func = schema, functionType, fn
+            return wrapped
+        return deco
+    fmod = pytypes.ModuleType('pyspark.sql.functions')
+    fmod.pandas_udf, fmod.PandasUDFType = pandas_udf, PandasUDFType
+    smod = pytypes.ModuleType('pyspark.sql')
+    smod.functions, smod.types = fmod, tmod
+    pmod = pytypes.ModuleType('pyspark')
+    pmod.sql = smod
+    for name, mod in (('pyspark', pmod), ('pyspark.sql', smod), ('pyspark.sql.functions', fmod), ('pyspark.sql.types', tmod)):
+        monkeypatch.setitem(sys.modules, name, mod)
+    return calls, PandasUDFType
+
+
+def _reference_schema(path, func):
+    """[(field, SparkType)] of the output_schema literal inside `func` of a reference job file, read
+    from the checkout when it is there (None on the GPU box)."""
+    import re
+    if not os.path.exists(path):
+        return None
+    src = open(path).read()
+    body = src[src.index('def %s(' % func):]
+    body = body[body.index('output_schema = StructType(['):]
+    body = body[:body.index('])')]
+    return re.findall(r"StructField\('(\w+)',\s*(\w+)\(\)", body)
+
+
+def test_as_pandas_udf_registers_the_references_two_schemas(monkeypatch):
+    """as_pandas_udf (jobs/prophet_modeler.py) must hand pyspark exactly what the reference's two
+    decorators do (prophet_modeler.py:32-41, prophet_scorer.py:27-35): GROUPED_MAP, and the output
+    schemas field for field -- names, Spark types, order, nullable.  pyspark is not installed here, so
+    the wiring runs against a stub that records the call; where the reference checkout is present the
+    expected schemas are read from its source instead of from this test."""
+    from time_series_spark_amd.jobs import prophet_modeler as pm, prophet_scorer as ps
+    calls, PandasUDFType = _stub_pyspark(monkeypatch)
+    want_model = [('series_id', 'IntegerType'), ('dim_id', 'IntegerType'), ('floor', 'FloatType'),
+                  ('cap', 'FloatType'), ('model', 'BinaryType')]                         # prophet_modeler.py:32-38
+    want_fc = [('series_id', 'IntegerType'), ('dim_id', 'IntegerType'), ('ds', 'TimestampType'),
+               ('yhat', 'IntegerType')]                                                  # prophet_scorer.py:27-32
+    ref_m = _reference_schema('/root/reference/src/jobs/prophet_modeler.py', 'model_time_series')
+    ref_f = _reference_schema('/root/reference/src/jobs/prophet_scorer.py', 'forecast_time_series')
+    if ref_m is not None:
+        assert ref_m == want_model and ref_f == want_fc
+    fn_m = lambda pdf: pdf      # noqa: E731
+    udf_m = pm.as_pandas_udf(fn_m)
+    udf_f = pm.as_pandas_udf(fn_m, columns=ps.FORECAST_COLUMNS)
+    assert len(calls) == 2
+    for (schema, ftype, fn), want in zip(calls, (want_model, want_fc)):
+        assert ftype == PandasUDFType.GROUPED_MAP and fn is fn_m
+        assert [(f.name, f.dataType.name) for f in schema.fields] == want
+        assert all(f.nullable is True for f in schema.fields)
+    # the wrapped object still is the `pdf -> pdf` function
+    df = pd.DataFrame({'a': [1]})
+    assert udf_m(df) is df and udf_f(df) is df
+    # and the frames the two job functions return carry exactly those columns, in that order, with
+    # dtypes Arrow converts to the declared Spark types without a cast error
+    assert pm.MODEL_OUTPUT_COLUMNS == [c for c, _ in want_model]
+    assert ps.FORECAST_COLUMNS == [c for c, _ in want_fc]
+
+
+def test_native_csv_reader_permissive_mode(tmp_path):
+    """spark.read.csv(schema=MODEL_INPUT_SCHEMA) runs in Spark's default mode PERMISSIVE
+    (prophet_modeler.py:109-114): a line that does not convert is a row of nulls, not an error.  The
+    native reader offers that as layout '...?' / mode='PERMISSIVE': the row comes out with a NaN
+    quantity (so the packer drops it exactly as fbprophet drops a null y), the good rows are
+    untouched, the count is reported; FAILFAST (default) still names file and line."""
+    root = tmp_path / 'in' / 'series_id=7'
+    root.mkdir(parents=True)
+    lines = ['1,2019-01-01 00:00:00,10', '1,not-a-date,11', '1,2019-01-03 00:00:00,twelve',
+             '1,2019-01-04 00:00:00', 'x,2019-01-05 00:00:00,14', '1,2019-01-06 00:00:00,15', '1,2019-01-07 00:00:00,']
+    (root / 'part-0.csv').write_text('\n'.join(lines) + '\n')
+    f = [str(root / 'part-0.csv')]
+    with pytest.raises(ValueError, match=r'part-0.csv line 2 '):
+        pm.read_model_input(f, str(tmp_path / 'in'))
+    stats = {}
+    sid, did, ds_ns, y = pm.read_model_input(f, str(tmp_path / 'in'), mode='PERMISSIVE', stats=stats)
+    assert stats == {'malformed': 4} and len(y) == 7 and (sid == 7).all()
+    good = [0, 5]
+    assert list(y[good]) == [10.0, 15.0] and np.isnan(np.delete(y, good)).all()      # (the last line: an empty quantity is a plain null)
+    assert list(ds_ns[good].astype('datetime64[ns]').astype(str)) == ['2019-01-01T00:00:00.000000000', '2019-01-06T00:00:00.000000000']
+    # through the packer: only the rows fbprophet would keep
+    p = pk.pack_rows(sid, did, ds_ns, y, key_dtypes=(np.int32, np.int32))
+    assert p.N == 1 and list(p.y) == [10.0, 15.0]
+    with pytest.raises(ValueError, match='mode must be'):
+        pm.read_model_input(f, str(tmp_path / 'in'), mode='DROPMALFORMED')

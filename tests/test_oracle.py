@@ -473,17 +473,11 @@ def test_no_changepoints_is_fitted_on_fbprophets_dummy_changepoint(growth):
     assert abs(th_lit[3]) > 100 * np.max(np.abs(o['theta'] - folded))
 
 
-def test_real_fbprophet_goldens_if_present():
-    """tests/golden/make_fbprophet_goldens.py run where fbprophet==0.5 exists writes
-    fbprophet_goldens.npz; when that file is present the oracle is compared with REAL fbprophet:
-    the deterministic pieces (scaling, changepoints, parameter count) exactly or to rounding, the
-    forecasts within what Stan's L-BFGS itself reproduces (a 1-ulp change of
-    one input moves them by a median 6e-4), reported as a distribution."""
-    import os
-    path = os.path.join(helpers.GOLDEN, 'fbprophet_goldens.npz')
-    if not os.path.exists(path):
-        pytest.skip('no fbprophet_goldens.npz: fbprophet==0.5 cannot be installed here (parity unpinned); '
-                    'generate it with tests/golden/make_fbprophet_goldens.py')
+def _check_fbprophet_goldens(path):
+    """The consumer of tests/golden/make_fbprophet_goldens.py's output: the deterministic pieces
+    (scaling, changepoints, parameter count) exactly or to rounding, the forecasts within what
+    Stan's L-BFGS itself reproduces (a 1-ulp change of one input moves them by
+    a median 6e-4), reported as a distribution."""
     g = np.load(path)
     errs = []
     for case in helpers.CASES:
@@ -499,9 +493,60 @@ def test_real_fbprophet_goldens_if_present():
             yo, _ = cl.predict(csp, o, fut, floor[n], cap[n], exf)
             errs.append(np.median(np.abs(yo - g[key + 'yhat']) / np.abs(g[key + 'yhat'])))
     errs = np.array(errs)
-    print('oracle vs real fbprophet %s: per-series median forecast rel err: median %.3g p90 %.3g max %.3g'
+    print('oracle vs %s: per-series median forecast rel err: median %.3g p90 %.3g max %.3g'
           % (g['fbprophet_version'], np.median(errs), np.quantile(errs, 0.9), errs.max()))
     assert np.median(errs) <= 5e-3 and np.quantile(errs, 0.9) <= 5e-2
+    return g
+
+
+def test_real_fbprophet_goldens_if_present():
+    """tests/golden/make_fbprophet_goldens.py run where fbprophet==0.5 exists writes
+    fbprophet_goldens.npz; when that file is present the oracle is compared with REAL fbprophet."""
+    import os
+    path = os.path.join(helpers.GOLDEN, 'fbprophet_goldens.npz')
+    if not os.path.exists(path):
+        pytest.skip('no fbprophet_goldens.npz: fbprophet==0.5 cannot be installed here (parity unpinned); '
+                    'generate it with tests/golden/make_fbprophet_goldens.py')
+    _check_fbprophet_goldens(path)
+
+
+def test_fbprophet_golden_generator_and_its_consumer_run_end_to_end_on_a_shim(tmp_path, monkeypatch):
+    """fbprophet cannot be installed here, so the one-command pin (make_fbprophet_goldens.py ->
+    fbprophet_goldens.npz -> test_real_fbprophet_goldens_if_present) had never executed.  Here it runs
+    from its first line to its last against a stand-in `fbprophet` module whose Prophet is the literal
+    restatement (same constructor arguments, fit / predict / make_future_dataframe, params layout,
+    y_scale / start / t_scale / changepoints_t attributes -- everything the script touches), including
+    the reference's own fixture when the checkout is present, and the consumer digests the file.  What
+    this pins: the script and the consumer work; what it cannot pin: fbprophet's numbers."""
+    import importlib.util
+    import os
+    import sys
+    import types
+    from oracle.fbprophet_restated import ProphetOracle
+    shim = types.ModuleType('fbprophet')
+    shim.Prophet = ProphetOracle
+    shim.__version__ = '0.5-shim(oracle.fbprophet_restated)'
+    monkeypatch.setitem(sys.modules, 'fbprophet', shim)
+    spec_ = importlib.util.spec_from_file_location('make_fbprophet_goldens',
+                                                   os.path.join(helpers.GOLDEN, 'make_fbprophet_goldens.py'))
+    gen = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(gen)
+    out = str(tmp_path / 'fbprophet_goldens.npz')
+    argv = ['make_fbprophet_goldens.py', '--out', out]
+    if os.path.exists('/root/reference/tests/fixtures/model-input/series_id=751/sample-model-input.csv'):
+        argv += ['--reference', '/root/reference']
+    monkeypatch.setattr(sys, 'argv', argv)
+    gen.main()
+    g = _check_fbprophet_goldens(out)
+    assert str(g['fbprophet_version']).startswith('0.5-shim')
+    if '--reference' in argv:
+        # the reference's fixture under its own settings (prophet_modeler.py:65, prophet_scorer_test.py:38-39):
+        # 40 forecasts per dim_id, daily + weekly seasonality picked by the auto rules (15-minute data, 9 days)
+        dims = sorted({k.split('/')[1] for k in g.files if k.startswith('fixture_751/')})
+        assert len(dims) == 2                   # the fixture's two dim_ids (prophet_modeler_test.py:65-68)
+        for dim in dims:
+            assert g['fixture_751/%s/yhat' % dim].shape == (40,) and np.isfinite(g['fixture_751/%s/yhat' % dim]).all()
+            assert list(g['fixture_751/%s/seasonalities' % dim]) == ['weekly', 'daily']
 
 
 @pytest.mark.parametrize('case', ['cfg2_linear_additive', 'ref_logistic_multiplicative'])

@@ -81,7 +81,7 @@ EXPORTS = ['tsf_create', 'tsf_destroy', 'tsf_last_error', 'tsf_device_count', 't
            'tsf_predict', 'tsf_predict_dev', 'tsf_predict_intervals', 'tsf_predict_intervals_dev', 'tsf_eval', 'tsf_design', 'tsf_selftest_math',
            'tsf_set_profiling', 'tsf_profile_read', 'tsf_last_fit_kernel_ms',
            'tsf_pack_rows', 'tsf_pack_fetch', 'tsf_pack_free',
-           'tsf_csv_read', 'tsf_csv_fetch', 'tsf_csv_free', 'tsf_csv_write_forecasts']
+           'tsf_csv_read', 'tsf_csv_fetch', 'tsf_csv_malformed', 'tsf_csv_free', 'tsf_csv_write_forecasts']
 
 CSV_E_OPEN, CSV_E_PARSE = -10, -11          # TSF_CSV_E_* (include/tsf.h)
 
@@ -143,6 +143,8 @@ def load():
                                ctypes.POINTER(vp), ctypes.POINTER(i64), ctypes.POINTER(i32),
                                ctypes.POINTER(i64)]
     L.tsf_csv_fetch.argtypes = [vp, vp, vp, vp, vp]
+    L.tsf_csv_malformed.argtypes = [vp]
+    L.tsf_csv_malformed.restype = ctypes.c_int64
     L.tsf_csv_free.argtypes = [vp]
     L.tsf_csv_free.restype = None
     L.tsf_csv_write_forecasts.argtypes = [ctypes.c_char_p, ctypes.c_char_p, i64, vp, vp, vp, vp, i32]

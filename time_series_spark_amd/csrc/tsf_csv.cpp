@@ -32,6 +32,7 @@ struct FileCols {
     std::vector<double> y;
     int err = 0;            // TSF_CSV_* code
     int64_t err_line = 0;   // 1-based
+    int64_t malformed = 0;  // permissive mode: rows that did not match the schema (emitted as all-null rows)
 };
 
 // days from 1970-01-01 of a proleptic Gregorian date (valid for all int years)
@@ -150,7 +151,7 @@ bool parse_quantity(const char *a, const char *b, double *out) {
 // layout: one letter per column of the file: s series_id, d dim_id, t start_time, q quantity,
 // x ignored.  Parses the lines of [p, end) (whole lines); line numbers in errors are relative to p.
 void parse_range(const char *p, const char *end, const char *layout, int ncol, int64_t sid_const,
-                 FileCols &out) {
+                 bool permissive, FileCols &out) {
     size_t guess = (size_t)(end - p) / 24 + 1;
     out.did.reserve(guess);
     out.ds.reserve(guess);
@@ -188,9 +189,17 @@ void parse_range(const char *p, const char *end, const char *layout, int ncol, i
             fa = fb + 1;
         }
         if (!ok || col != ncol) {
-            out.err = TSF_CSV_E_PARSE;
-            out.err_line = line;
-            return;
+            if (!permissive) {
+                out.err = TSF_CSV_E_PARSE;
+                out.err_line = line;
+                return;
+            }
+            // Spark 2.4 PERMISSIVE: a record that does not convert becomes a row of nulls; here the
+            // null quantity (NaN) is what matters downstream -- the packer drops the row as fbprophet
+            // drops rows with a null y (the partition's series_id stays: it comes from the path)
+            out.malformed++;
+            sid = sid_const; did = 0; ds = 0;
+            q = std::numeric_limits<double>::quiet_NaN();
         }
         out.sid.push_back(sid);
         out.did.push_back(did);
@@ -266,6 +275,9 @@ int tsf_csv_read(int32_t n_files, const char *const *paths, const int64_t *serie
     if (!out || n_files < 0 || (n_files > 0 && !paths) || !layout) return -1;
     *out = nullptr;
     int ncol = (int)std::strlen(layout);
+    // a trailing '?' = permissive mode (spark.read.csv's default mode=PERMISSIVE)
+    const bool permissive = ncol > 0 && layout[ncol - 1] == '?';
+    if (permissive) --ncol;
     bool has_s = false, has_d = false, has_t = false, has_q = false;
     for (int i = 0; i < ncol; ++i) {
         char c = layout[i];
@@ -322,7 +334,7 @@ int tsf_csv_read(int32_t n_files, const char *const *paths, const int64_t *serie
             const Segment &sg = segs[(size_t)k];
             const char *base = bufs[(size_t)sg.file].data();
             parse_range(base + sg.begin, base + sg.end, layout, ncol,
-                        series_id ? series_id[sg.file] : 0, t->files[(size_t)k]);
+                        series_id ? series_id[sg.file] : 0, permissive, t->files[(size_t)k]);
         });
         if (oom.load()) {
             delete t;
@@ -359,6 +371,13 @@ int tsf_csv_read(int32_t n_files, const char *const *paths, const int64_t *serie
     *out = t;
     if (n_rows) *n_rows = t->n_rows;
     return 0;
+}
+
+int64_t tsf_csv_malformed(const tsf_csv *t) {
+    if (!t) return -1;
+    int64_t n = 0;
+    for (const FileCols &fc : t->files) n += fc.malformed;
+    return n;
 }
 
 int tsf_csv_fetch(tsf_csv *t, int64_t *series_id, int64_t *dim_id, int64_t *ds, double *y) {

@@ -303,9 +303,12 @@ def find_model_input(root):
     return [f for _, f in found], [v for v, _ in found]
 
 
-def read_model_input(files, root, n_threads=0, part_sid=None):
+def read_model_input(files, root, n_threads=0, part_sid=None, mode='FAILFAST', stats=None):
     """Parse model-input CSV files into (series_id, dim_id, ds_ns, y) arrays (int64, int64,
-    int64 ns, float64 with NaN for nulls).  A `series_id=<v>` directory between `root` and the
+    int64 ns, float64 with NaN for nulls).  mode: 'FAILFAST' (a line that does not match the schema
+    raises, naming file and line) or 'PERMISSIVE' (spark.read.csv's default at prophet_modeler.py:109:
+    such a line becomes a row of nulls, which the fit drops like any null-y row; stats['malformed']
+    counts them).  A `series_id=<v>` directory between `root` and the
     file supplies series_id for that file (Spark's partition discovery); the file then holds
     the remaining MODEL_INPUT_SCHEMA columns in order.  part_sid: the partition values if the
     caller knows them already (find_model_input)."""
@@ -325,9 +328,12 @@ def read_model_input(files, root, n_threads=0, part_sid=None):
                 v = int(seg.split('=', 1)[1])
         part_sid.append(v)
     out = []
+    if mode not in ('FAILFAST', 'PERMISSIVE'):
+        raise ValueError("mode must be 'FAILFAST' or 'PERMISSIVE'")
+    q = b'?' if mode == 'PERMISSIVE' else b''
     # files under a partition directory hold 3 columns, the others all 4
-    for layout, pick in ((b'dtq', [i for i, v in enumerate(part_sid) if v is not None]),
-                         (b'sdtq', [i for i, v in enumerate(part_sid) if v is None])):
+    for layout, pick in ((b'dtq' + q, [i for i, v in enumerate(part_sid) if v is not None]),
+                         (b'sdtq' + q, [i for i, v in enumerate(part_sid) if v is None])):
         if not pick:
             continue
         paths = (ctypes.c_char_p * len(pick))(*[os.fsencode(files[i]) for i in pick])
@@ -344,6 +350,8 @@ def read_model_input(files, root, n_threads=0, part_sid=None):
         if rc != 0:
             raise _lib.TsfError('tsf_csv_read failed (%d)' % rc)
         try:
+            if stats is not None:
+                stats['malformed'] = stats.get('malformed', 0) + int(L.tsf_csv_malformed(h))
             n = n_rows.value
             cols = (np.empty(n, np.int64), np.empty(n, np.int64), np.empty(n, np.int64), np.empty(n))
             rc = L.tsf_csv_fetch(h, *[c.ctypes.data for c in cols])
@@ -387,7 +395,15 @@ class ProphetModeler:
         """The same rows as read_input_dataframe, as (series_id, dim_id, ds_ns, y) arrays."""
         root = self.config['io']['input']
         files, part = find_model_input(root)
-        return read_model_input(files, root, part_sid=part)
+        # io.input_mode: 'FAILFAST' (default here: a malformed line raises with file and line) or
+        # 'PERMISSIVE' (what spark.read.csv does by default, prophet_modeler.py:109: the line becomes a
+        # row of nulls and the fit drops it)
+        mode = str(self.config['io'].get('input_mode', 'FAILFAST')).upper()
+        stats = {}
+        cols = read_model_input(files, root, part_sid=part, mode=mode, stats=stats)
+        if stats.get('malformed'):
+            self.logger.warning('%d malformed model-input rows read as nulls (PERMISSIVE)', stats['malformed'])
+        return cols
 
     def persist_models(self, model_df):
         """Parquet, mode='overwrite' (:123-125)."""
