@@ -30,6 +30,8 @@ struct tsf_ctx {
     void *ws;
     size_t ws_bytes;
     DevSpec *d_spec;
+    double *fut_tab;        // design table of a shared future grid (predict): [K][H]
+    size_t fut_tab_bytes;
     int n_cu;               // compute units of the device (persistent kernels: one workgroup each)
     int profiling;
     hipEvent_t ev0[TSF_PROFILE_RING], ev1[TSF_PROFILE_RING];
@@ -68,11 +70,22 @@ extern "C" int tsf_create(int device_id, tsf_ctx **out)
     if (hipSetDevice(device_id) != hipSuccess) return -2;
     tsf_ctx *c = new tsf_ctx();
     c->device = device_id; c->ws = nullptr; c->ws_bytes = 0; c->d_spec = nullptr;
+    c->fut_tab = nullptr; c->fut_tab_bytes = 0;
     c->profiling = 0; c->ev_created = 0; c->ev_count = 0;
     if (hipMalloc((void **)&c->d_spec, sizeof(DevSpec)) != hipSuccess) { delete c; return -2; }
     {
         hipDeviceProp_t prop;
         c->n_cu = (hipGetDeviceProperties(&prop, device_id) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
+    {
+        // stream-ordered scratch (tsf_predict_intervals_dev): keep freed blocks in the device's pool
+        // instead of handing them back to the driver at every synchronisation
+        hipMemPool_t pool;
+        if (hipDeviceGetDefaultMemPool(&pool, device_id) == hipSuccess) {
+            uint64_t keep = (uint64_t)2 << 30;
+            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+        }
+        (void)hipGetLastError();
     }
     *out = c;
     return 0;
@@ -87,6 +100,7 @@ extern "C" void tsf_destroy(tsf_ctx *ctx)
     pool_trim(ctx->device);
     if (ctx->ws) hipFree(ctx->ws);
     if (ctx->d_spec) hipFree(ctx->d_spec);
+    if (ctx->fut_tab) hipFree(ctx->fut_tab);
     if (ctx->ev_created)
         for (int i = 0; i < TSF_PROFILE_RING; ++i) { hipEventDestroy(ctx->ev0[i]); hipEventDestroy(ctx->ev1[i]); }
     delete ctx;
@@ -739,6 +753,43 @@ extern "C" int tsf_eval(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int32_t T
 
 // ---- predict ----------------------------------------------------------------------------------
 
+// predict_kernel on the series [n0, n0 + n) of the caller's arrays.  A shared future grid gets its
+// design table built first (once per call: tab_ready), in the context's own buffer.
+static int launch_predict(tsf_ctx *ctx, const DevSpec &hs, PredictArgs a, int64_t n0, int64_t n, bool *tab_ready,
+                          hipStream_t st)
+{
+    if (a.shared_future) {
+        const size_t need = sizeof(double) * (size_t)(hs.K > 0 ? hs.K : 1) * a.H;
+        if (ctx->fut_tab_bytes < need) {
+            // (grows only: a buffer an earlier call on another stream may still read is never freed here
+            // without the device being idle -- hipFree synchronises)
+            if (ctx->fut_tab) { HIP_TRY(ctx, hipFree(ctx->fut_tab)); ctx->fut_tab = nullptr; ctx->fut_tab_bytes = 0; }
+            HIP_TRY(ctx, hipMalloc((void **)&ctx->fut_tab, need));
+            ctx->fut_tab_bytes = need;
+        }
+        if (!*tab_ready && hs.n_pairs > 0) {
+            const int work = a.H * hs.n_pairs;
+            hipLaunchKernelGGL(future_design_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st,
+                               ctx->d_spec, a.H, a.ds_future, ctx->fut_tab);
+            HIP_TRY(ctx, hipGetLastError());
+        }
+        *tab_ready = true;
+        a.Xf = ctx->fut_tab;
+    }
+    const int64_t g = a.n_grids == 1 ? 0 : n0;
+    a.N = n;
+    a.theta += (size_t)n0 * a.theta_stride; a.y_scale += n0; a.grid += g;
+    if (!a.shared_future) a.ds_future += (size_t)n0 * a.H;
+    if (a.floor_) a.floor_ += n0;
+    if (a.cap) a.cap += n0;
+    if (a.extra_future && !a.shared_future) a.extra_future += (size_t)n0 * hs.n_extra * a.H;
+    a.yhat += (size_t)n0 * a.H;
+    if (a.yhat_int) a.yhat_int += (size_t)n0 * a.H;
+    hipLaunchKernelGGL(predict_kernel, dim3((unsigned)((n + PREDICT_WAVES - 1) / PREDICT_WAVES)), dim3(PREDICT_WAVES * 64), 0, st, a);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
 extern "C" int tsf_predict_dev(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int32_t H,
                                const double *theta, const double *y_scale,
                                const tsf_grid_info *grid, int32_t n_grids, const int64_t *ds_future,
@@ -765,10 +816,8 @@ extern "C" int tsf_predict_dev(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, in
     a.n_grids = n_grids; a.shared_future = shared_future; a.theta = theta; a.y_scale = y_scale;
     a.grid = grid; a.ds_future = ds_future; a.floor_ = floor_; a.cap = cap;
     a.extra_future = extra_future; a.yhat = yhat; a.yhat_int = yhat_int;
-    const int64_t total = N * (int64_t)H;
-    hipLaunchKernelGGL(predict_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
-    HIP_TRY(ctx, hipGetLastError());
-    return 0;
+    bool tab_ready = false;
+    return launch_predict(ctx, hs, a, 0, N, &tab_ready, st);
 }
 
 extern "C" int tsf_predict(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int32_t H,
@@ -829,7 +878,7 @@ extern "C" int tsf_predict_intervals_dev(tsf_ctx *ctx, const tsf_spec *spec, int
     if (!ctx) return -1;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (N <= 0 || H <= 0) return fail(ctx, "N and H must be > 0");
-    if (!theta || !y_scale || !grid || !ds_future || !yhat || !yhat_lower || !yhat_upper) return fail(ctx, "NULL input");
+    if (!spec || !theta || !y_scale || !grid || !ds_future || !yhat || !yhat_lower || !yhat_upper) return fail(ctx, "NULL input");
     if (n_grids != 1 && n_grids != N) return fail(ctx, "n_grids must be 1 or N");
     if (n_samples < 2 || n_samples > 4096) return fail(ctx, "n_samples must be in [2, 4096]");
     if (!(interval_width > 0.0 && interval_width < 1.0)) return fail(ctx, "interval_width must be in (0, 1)");
@@ -841,45 +890,71 @@ extern "C" int tsf_predict_intervals_dev(tsf_ctx *ctx, const tsf_spec *spec, int
     if (hs.growth == TSF_GROWTH_LOGISTIC && !cap) return fail(ctx, "logistic growth needs cap");
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_spec, &hs, sizeof(hs), hipMemcpyHostToDevice, st));
-    // per-row pieces: the point forecast kernel, with its optional outputs
-    DevBuf d_t, d_xa, d_opm, d_samp;
-    const size_t nh = (size_t)N * H;
-    HIP_TRY(ctx, d_t.alloc(8 * nh)); HIP_TRY(ctx, d_xa.alloc(8 * nh)); HIP_TRY(ctx, d_opm.alloc(8 * nh));
+    // Series are processed in chunks sized so that ALL scratch of a chunk -- the per-row pieces of the
+    // point forecast (t, additive term, 1 + multiplicative term) and the samples -- stays within
+    // 512 MB.  The scratch is stream-ordered (hipMallocAsync / hipFreeAsync on the caller's stream):
+    // nothing here waits for the device, as the `_dev` contract (include/tsf.h) promises.
+    const size_t per_series = (size_t)H * 8 * (3 + (size_t)n_samples);
+    int64_t chunk = (int64_t)(((size_t)512 << 20) / per_series);
+    if (chunk < 1) chunk = 1;
+    if (chunk > N) chunk = N;
+    double *d_t = nullptr, *d_xa = nullptr, *d_opm = nullptr, *d_samp = nullptr;
+    const size_t nh = (size_t)chunk * H;
+    auto release = [&]() {
+        if (d_t) (void)hipFreeAsync(d_t, st);
+        if (d_xa) (void)hipFreeAsync(d_xa, st);
+        if (d_opm) (void)hipFreeAsync(d_opm, st);
+        if (d_samp) (void)hipFreeAsync(d_samp, st);
+    };
+#define HIP_TRY_REL(expr)                                                                     \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            ctx->err = std::string(#expr) + ": " + hipGetErrorString(e_);                     \
+            release();                                                                        \
+            return -2;                                                                        \
+        }                                                                                     \
+    } while (0)
+    HIP_TRY_REL(hipMallocAsync((void **)&d_t, 8 * nh, st));
+    HIP_TRY_REL(hipMallocAsync((void **)&d_xa, 8 * nh, st));
+    HIP_TRY_REL(hipMallocAsync((void **)&d_opm, 8 * nh, st));
+    HIP_TRY_REL(hipMallocAsync((void **)&d_samp, 8 * nh * n_samples, st));
     PredictArgs p;
     memset(&p, 0, sizeof(p));
     p.sp = ctx->d_spec; p.N = N; p.H = H; p.theta_stride = tsf_theta_stride(spec);
     p.n_grids = n_grids; p.shared_future = shared_future; p.theta = theta; p.y_scale = y_scale;
     p.grid = grid; p.ds_future = ds_future; p.floor_ = floor_; p.cap = cap;
     p.extra_future = extra_future; p.yhat = yhat; p.yhat_int = nullptr;
-    p.t_out = d_t.as<double>(); p.xa_out = d_xa.as<double>(); p.opm_out = d_opm.as<double>();
-    hipLaunchKernelGGL(predict_kernel, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, st, p);
-    HIP_TRY(ctx, hipGetLastError());
-    // samples in chunks of series (at most 512 MB at a time)
-    int64_t chunk = (int64_t)(((size_t)512 << 20) / ((size_t)H * n_samples * 8));
-    if (chunk < 1) chunk = 1;
-    if (chunk > N) chunk = N;
-    HIP_TRY(ctx, d_samp.alloc(8 * (size_t)chunk * H * n_samples));
+    p.t_out = d_t; p.xa_out = d_xa; p.opm_out = d_opm;
     int NSP = 2;
     while (NSP < n_samples) NSP <<= 1;
     IntervalArgs a;
     memset(&a, 0, sizeof(a));
     a.sp = ctx->d_spec; a.H = H; a.theta_stride = tsf_theta_stride(spec); a.n_grids = n_grids; a.NS = n_samples;
     a.theta = theta; a.y_scale = y_scale; a.grid = grid; a.floor_ = floor_; a.cap = cap;
-    a.t = d_t.as<double>(); a.xa = d_xa.as<double>(); a.opm = d_opm.as<double>();
     a.series_key = series_key; a.seed = seed;
     a.lo_frac = (1.0 - interval_width) / 2.0; a.hi_frac = (1.0 + interval_width) / 2.0;
-    a.samples = d_samp.as<double>(); a.lower = yhat_lower; a.upper = yhat_upper;
+    a.samples = d_samp; a.lower = yhat_lower; a.upper = yhat_upper;
+    bool tab_ready = false;
     for (int64_t n0 = 0; n0 < N; n0 += chunk) {
-        a.n0 = n0; a.n_chunk = (N - n0 < chunk) ? N - n0 : chunk;
+        const int64_t nc = (N - n0 < chunk) ? N - n0 : chunk;
+        // the point forecast of the chunk and its per-row pieces (chunk-local scratch: rows of
+        // series n0 + i at [i][H])
+        {
+            const int prc = launch_predict(ctx, hs, p, n0, nc, &tab_ready, st);
+            if (prc) { release(); return prc; }
+        }
+        a.n0 = n0; a.n_chunk = nc;
+        a.t = d_t - (size_t)n0 * H; a.xa = d_xa - (size_t)n0 * H; a.opm = d_opm - (size_t)n0 * H;
         hipLaunchKernelGGL(interval_sample_kernel, dim3((unsigned)a.n_chunk, (unsigned)((n_samples + 255) / 256)),
                            dim3(256), 0, st, a);
-        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY_REL(hipGetLastError());
         hipLaunchKernelGGL(interval_percentile_kernel, dim3((unsigned)(a.n_chunk * H)), dim3(256),
                            sizeof(double) * NSP, st, a, NSP);
-        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY_REL(hipGetLastError());
     }
-    // the scratch buffers go back to the pool when this returns: wait for the kernels that use them
-    HIP_TRY(ctx, hipStreamSynchronize(st));
+    release();      // stream-ordered: the blocks go back to the pool when the kernels above are done
+#undef HIP_TRY_REL
     return 0;
 }
 

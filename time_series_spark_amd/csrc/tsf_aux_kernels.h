@@ -217,8 +217,20 @@ __global__ __launch_bounds__(64) void setup_series_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
-// predict: one thread per (series, horizon step)
+// predict: one wavefront per series, lanes over the horizon
 // ---------------------------------------------------------------------------------------
+// (Prophet.predict as the reference calls it, /root/reference/src/jobs/prophet_scorer.py:64-84.)
+// Round 2 ran one thread per (series, step) with the design row in a per-thread array indexed
+// through the column permutation: the array went to scratch (390 MB of traffic for 10.8 MB of
+// output) and every thread recomputed the same 13 sincos of a future grid all series share.  Now:
+//   * a shared future grid gets ONE design table Xf[column][step] (future_design_kernel, H x K values,
+//     L2-resident), read coalesced over the steps;
+//   * per-series future grids compute their Fourier terms in place, column by column in the order of
+//     the chain (no array);
+//   * the trend's changepoint recurrence (a division per step for logistic growth) runs once per
+//     series, not once per (series, step): the wave walks it and parks (ks, mc) per segment in LDS;
+//   * the coefficients of a series are wave-uniform.
+// Same operations in the same order per forecast as before: bit-identical to oracle cn_predict.
 
 struct PredictArgs {
     const DevSpec *sp;
@@ -233,74 +245,122 @@ struct PredictArgs {
     // optional per-row pieces for the interval kernels (tsf_interval_kernels.h): scaled time,
     // additive term * y_scale, 1 + multiplicative term
     double *t_out, *xa_out, *opm_out;
+    const double *Xf;           // shared future grid: [K][H] design values in ORIGINAL column order
 };
 
-__global__ void predict_kernel(PredictArgs a)
+// Fourier columns of a shared future grid, original column order: Xf[col][h]
+__global__ void future_design_kernel(const DevSpec *sp, int H, const int64_t *ds_future, double *Xf)
 {
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= a.N * (int64_t)a.H) return;
-    const int64_t n = gid / a.H;
-    const int h = (int)(gid - n * a.H);
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= H * sp->n_pairs) return;
+    const int pr = i / H, h = i - pr * H;
+    const double tdays = (1e-9 * (double)ds_future[h]) / 86400.0;
+    const double arg = (sp->pair_mult[pr] * 3.141592653589793 * tdays) / sp->pair_period[pr];
+    double sv, cv;
+    dm_sincos(arg, sv, cv);
+    Xf[(size_t)sp->pair_col[pr] * H + h] = sv;
+    Xf[(size_t)(sp->pair_col[pr] + 1) * H + h] = cv;
+}
+
+constexpr int PREDICT_WAVES = 4;        // series per workgroup
+
+__global__ __launch_bounds__(PREDICT_WAVES * 64) void predict_kernel(PredictArgs a)
+{
+    __shared__ double seg_ks[PREDICT_WAVES][TSF_MAX_S + 4], seg_mc[PREDICT_WAVES][TSF_MAX_S + 4];
+    const int wid = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
+    const int64_t n = (int64_t)blockIdx.x * PREDICT_WAVES + wid;
+    if (n >= a.N) return;
     const DevSpec *sp = a.sp;
     const tsf_grid_info &gi = a.grid[a.n_grids == 1 ? 0 : n];
-    const int S = gi.S, K = sp->K, Ka = sp->Ka, n_cp = sp->n_cp;
+    const int S = gi.S, K = sp->K, Ka = sp->Ka, n_cp = sp->n_cp, H = a.H;
     const double *th = a.theta + (size_t)n * a.theta_stride;
     const double *delta = th + 3, *beta = th + 3 + n_cp;
     const double ys = a.y_scale[n];
     const double fl = (sp->growth == TSF_GROWTH_LOGISTIC && a.floor_) ? a.floor_[n] : 0.0;
     const double fl_clamp = a.floor_ ? a.floor_[n] : 0.0;
-    const int64_t dsv = a.ds_future[a.shared_future ? h : n * (int64_t)a.H + h];
-    const double t = (double)(dsv - gi.start_ns) / (double)gi.t_scale_ns;
-    double ks = th[0], mc = th[1];
-    int c = 0;
-    while (c < S && t >= gi.t_change[c]) {
-        const double dj = delta[c], tcj = gi.t_change[c];
-        const double ksn = ks + dj;
-        if (sp->growth == TSF_GROWTH_LINEAR) {
-            mc = mc + ((-tcj) * dj);
-        } else {
-            const double gamma = (tcj - mc) * (1.0 - ks / ksn);
-            mc = mc + gamma;
+    const double capsc = (sp->growth == TSF_GROWTH_LOGISTIC) ? (a.cap[n] - fl) / ys : 0.0;
+    // slope / offset of every trend segment: the sequential recurrence, once per series
+    {
+        double ks = th[0], mc = th[1];
+        if (lane == 0) { seg_ks[wid][0] = ks; seg_mc[wid][0] = mc; }
+        for (int c = 0; c < S; ++c) {
+            const double dj = delta[c], tcj = gi.t_change[c];
+            const double ksn = ks + dj;
+            if (sp->growth == TSF_GROWTH_LINEAR) {
+                mc = mc + ((-tcj) * dj);
+            } else {
+                const double gamma = (tcj - mc) * (1.0 - ks / ksn);
+                mc = mc + gamma;
+            }
+            ks = ksn;
+            if (lane == 0) { seg_ks[wid][c + 1] = ks; seg_mc[wid][c + 1] = mc; }
         }
-        ks = ksn;
-        ++c;
     }
-    // design row in original column order
-    double row[TSF_MAX_K];
-    const double tdays = (1e-9 * (double)dsv) / 86400.0;
-    for (int pr = 0; pr < sp->n_pairs; ++pr) {
-        const double arg = (sp->pair_mult[pr] * 3.141592653589793 * tdays) / sp->pair_period[pr];
-        dm_sincos(arg, row[sp->pair_col[pr]], row[sp->pair_col[pr] + 1]);
-    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int nf = K - sp->n_extra;
-    for (int e = 0; e < sp->n_extra; ++e) {
-        const size_t off = a.shared_future ? (size_t)e * a.H + h
-                                           : ((size_t)n * sp->n_extra + e) * a.H + h;
-        row[nf + e] = a.extra_future[off];
-    }
-    double xa = 0.0, xm = 0.0;
-    for (int j = 0; j < Ka; ++j) xa = __builtin_fma(row[sp->perm[j]], beta[sp->perm[j]], xa);
-    for (int j = Ka; j < K; ++j) xm = __builtin_fma(row[sp->perm[j]], beta[sp->perm[j]], xm);
-    double gtr;
-    if (sp->growth == TSF_GROWTH_LINEAR) {
-        gtr = __builtin_fma(ks, t, mc);
-    } else {
-        const double capsc = (a.cap[n] - fl) / ys;
-        const double z = ks * (t - mc);
-        gtr = capsc * (1.0 / (1.0 + dm_exp(-z)));
-    }
-    const double trend = gtr * ys + fl;
-    const double yh = trend * (1.0 + xm) + xa * ys;
-    a.yhat[gid] = yh;
-    if (a.t_out) { a.t_out[gid] = t; a.xa_out[gid] = xa * ys; a.opm_out[gid] = 1.0 + xm; }
-    if (a.yhat_int) {
-        // prophet_scorer.py:73 astype(int) truncates toward zero; :76-84 clamp to floor
-        double tr = __builtin_trunc(yh);
-        if (!(tr >= -2147483648.0)) tr = -2147483648.0;
-        if (tr > 2147483647.0) tr = 2147483647.0;
-        int32_t iv = (int32_t)tr;
-        if ((double)iv < fl_clamp) iv = (int32_t)fl_clamp;
-        a.yhat_int[gid] = iv;
+    for (int h = lane; h < H; h += 64) {
+        const int64_t gid = n * (int64_t)H + h;
+        const int64_t dsv = a.ds_future[a.shared_future ? h : gid];
+        const double t = (double)(dsv - gi.start_ns) / (double)gi.t_scale_ns;
+        int c = 0;
+        while (c < S && t >= gi.t_change[c]) ++c;
+        const double ks = seg_ks[wid][c], mc = seg_mc[wid][c];
+        // X.beta in the order of the chain: additive columns in original order, then the
+        // multiplicative ones (internal column j = original column perm[j])
+        double xa = 0.0, xm = 0.0;
+        if (a.Xf) {
+            for (int j = 0; j < K; ++j) {
+                const int col = sp->perm[j];
+                const double xv = (col < nf) ? a.Xf[(size_t)col * H + h]
+                                             : a.extra_future[a.shared_future ? (size_t)(col - nf) * H + h
+                                                                              : ((size_t)n * sp->n_extra + (col - nf)) * H + h];
+                if (j < Ka) xa = __builtin_fma(xv, beta[col], xa);
+                else xm = __builtin_fma(xv, beta[col], xm);
+            }
+        } else {
+            const double tdays = (1e-9 * (double)dsv) / 86400.0;
+            for (int pass = 0; pass < 2; ++pass) {
+                double acc = 0.0;
+                for (int pr = 0; pr < sp->n_pairs; ++pr) {
+                    const int col = sp->pair_col[pr];
+                    if ((sp->inv_perm[col] < Ka) != (pass == 0)) continue;
+                    const double arg = (sp->pair_mult[pr] * 3.141592653589793 * tdays) / sp->pair_period[pr];
+                    double sv, cv;
+                    dm_sincos(arg, sv, cv);
+                    acc = __builtin_fma(sv, beta[col], acc);
+                    acc = __builtin_fma(cv, beta[col + 1], acc);
+                }
+                for (int e = 0; e < sp->n_extra; ++e) {
+                    const int col = nf + e;
+                    if ((sp->inv_perm[col] < Ka) != (pass == 0)) continue;
+                    const size_t off = a.shared_future ? (size_t)e * H + h : ((size_t)n * sp->n_extra + e) * H + h;
+                    acc = __builtin_fma(a.extra_future[off], beta[col], acc);
+                }
+                if (pass == 0) xa = acc; else xm = acc;
+            }
+        }
+        double gtr;
+        if (sp->growth == TSF_GROWTH_LINEAR) {
+            gtr = __builtin_fma(ks, t, mc);
+        } else {
+            const double z = ks * (t - mc);
+            gtr = capsc * (1.0 / (1.0 + dm_exp(-z)));
+        }
+        const double trend = gtr * ys + fl;
+        const double yh = trend * (1.0 + xm) + xa * ys;
+        a.yhat[gid] = yh;
+        if (a.t_out) { a.t_out[gid] = t; a.xa_out[gid] = xa * ys; a.opm_out[gid] = 1.0 + xm; }
+        if (a.yhat_int) {
+            // prophet_scorer.py:73 astype(int) truncates toward zero; :76-84 clamp to floor
+            double tr = __builtin_trunc(yh);
+            if (!(tr >= -2147483648.0)) tr = -2147483648.0;
+            if (tr > 2147483647.0) tr = 2147483647.0;
+            int32_t iv = (int32_t)tr;
+            if ((double)iv < fl_clamp) iv = (int32_t)fl_clamp;
+            a.yhat_int[gid] = iv;
+        }
     }
 }
 

@@ -36,6 +36,10 @@ def init_process_group(backend=None):
     rank, world, local = env_rank_world()
     if world > 1 and not dist.is_initialized():
         if backend is None:
+            # TSF_DIST_BACKEND=gloo: several ranks on ONE GPU (RCCL refuses two ranks per device) --
+            # how the multi-rank path of bench.py is exercised on a 1-GPU box
+            backend = os.environ.get('TSF_DIST_BACKEND') or None
+        if backend is None:
             import torch
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -56,6 +60,8 @@ def max_over_ranks(value, device=None):
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         return float(value)
+    if dist.get_backend() == 'gloo':
+        device = 'cpu'
     t = torch.tensor([float(value)], dtype=torch.float64, device=device or 'cpu')
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
@@ -66,6 +72,8 @@ def sum_over_ranks(value, device=None):
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         return float(value)
+    if dist.get_backend() == 'gloo':
+        device = 'cpu'
     t = torch.tensor([float(value)], dtype=torch.float64, device=device or 'cpu')
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
