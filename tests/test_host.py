@@ -754,3 +754,18 @@ def test_native_csv_reader_permissive_mode(tmp_path):
     assert p.N == 1 and list(p.y) == [10.0, 15.0]
     with pytest.raises(ValueError, match='mode must be'):
         pm.read_model_input(f, str(tmp_path / 'in'), mode='DROPMALFORMED')
+
+
+def test_holiday_windows_and_names_follow_fbprophet():
+    """fbprophet's make_holiday_features parses lower_window and upper_window in one try (either one
+    unusable -> both 0) and refuses names that contain the column-name separator or are reserved."""
+    from time_series_spark_amd import features
+    h = features.normalize_holidays([{'holiday': 'a', 'ds': ['2019-01-01'], 'lower_window': float('nan'), 'upper_window': 2},
+                                     {'holiday': 'b', 'ds': ['2019-02-01'], 'lower_window': -1, 'upper_window': 1}])
+    assert (h[0]['lower_window'], h[0]['upper_window']) == (0, 0) and (h[1]['lower_window'], h[1]['upper_window']) == (-1, 1)
+    names, _, _ = features.holiday_columns(h)
+    assert names == ['a_delim_+0', 'b_delim_+0', 'b_delim_+1', 'b_delim_-1']
+    with pytest.raises(ValueError, match='_delim_'):
+        features.normalize_holidays([{'holiday': 'x_delim_y', 'ds': ['2019-01-01']}])
+    with pytest.raises(ValueError, match='reserved'):
+        features.normalize_holidays([{'holiday': 'weekly', 'ds': ['2019-01-01']}])

@@ -258,9 +258,23 @@ static WsLayout ws_layout(int64_t N, int64_t n_grids, int NTmax, int KP, int qua
     return l;
 }
 
-static int ensure_ws(tsf_ctx *ctx, size_t bytes)
+static int ensure_ws(tsf_ctx *ctx, size_t bytes, int64_t N = 0, int NTmax = 0, int ragged = 0)
 {
     if (ctx->ws_bytes >= bytes) return 0;
+    {
+        // a ragged panel pads EVERY series' tables to the longest series of the call: say so instead of
+        // failing inside hipMalloc
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && bytes > free_b + ctx->ws_bytes) {
+            char msg[384];
+            snprintf(msg, sizeof(msg), "workspace of %.1f GB does not fit the device (%.1f GB free): %lld series, the longest has "
+                     "%d rows%s", bytes / 1e9, (free_b + ctx->ws_bytes) / 1e9, (long long)N, NTmax * W,
+                     ragged ? " and every series of a ragged call is padded to it -- split the call by series length" : "");
+            ctx->err = msg;
+            return -2;
+        }
+        (void)hipGetLastError();
+    }
     if (ctx->ws) { HIP_TRY(ctx, hipFree(ctx->ws)); ctx->ws = nullptr; ctx->ws_bytes = 0; }
     HIP_TRY(ctx, hipMalloc(&ctx->ws, bytes));
     ctx->ws_bytes = bytes;
@@ -404,7 +418,7 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     const int coop_stride = coop ? coop_slot_doubles(hs.KP == 64 ? 2 : 1) : 0;
     const WsLayout l = ws_layout(N, n_grids, NTmax, hs.KP, qp.P4, qp.slots, (quad || newton_quad) && !aligned, lat_U, &mp,
                                  coop_slots, coop_stride);
-    rc = ensure_ws(ctx, l.total);
+    rc = ensure_ws(ctx, l.total, N, NTmax, !aligned);
     if (rc) return rc;
     char *ws = (char *)ctx->ws;
     GridTab *gtab = (GridTab *)(ws + l.gtab);
@@ -461,6 +475,8 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
         qa.counter = (int *)(ws + l.counter); qa.P4 = qp.P4;
         HIP_TRY(ctx, hipMemsetAsync(qa.counter, 0, sizeof(int), st));
         lrc = launch_newton_quad(hs.KP, qp, qa, (double *)(ws + l.Mg), fit_P(hs.n_cp, hs.K) | 1, ctx->n_cu, st);
+        // (-1: this shape does not fit the quadratic-form Newton kernel's LDS -- the residual-form kernel has no such limit)
+        if (lrc == -1) lrc = pick_newton_launch(hs.growth, mode)(hs.KP, a, fit_P(hs.n_cp, hs.K) | 1, st);
     } else if (newton) {
         lrc = pick_newton_launch(hs.growth, mode)(hs.KP, a, fit_P(hs.n_cp, hs.K) | 1, st);
     } else if (quad) {

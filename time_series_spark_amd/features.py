@@ -27,6 +27,15 @@ def _day_number(ds_ns):
     return np.floor_divide(np.asarray(ds_ns, dtype=np.int64), DAY_NS)
 
 
+RESERVED_NAMES = frozenset([
+    'trend', 'additive_terms', 'daily', 'weekly', 'yearly', 'holidays', 'zeros', 'extra_regressors_additive',
+    'yhat', 'extra_regressors_multiplicative', 'multiplicative_terms',
+    'ds', 'y', 'cap', 'floor', 'y_scaled', 'cap_scaled']) | frozenset(
+        n + s for n in ('trend', 'additive_terms', 'daily', 'weekly', 'yearly', 'holidays', 'zeros',
+                        'extra_regressors_additive', 'yhat', 'extra_regressors_multiplicative', 'multiplicative_terms')
+        for s in ('_lower', '_upper'))
+
+
 def normalize_holidays(holidays, default_prior_scale=10.0):
     """holidays: fbprophet-style DataFrame [holiday, ds, lower_window?, upper_window?, prior_scale?]
     or a list of dicts with the same keys ('ds' one date or a list of dates: what a YAML config can
@@ -57,17 +66,23 @@ def normalize_holidays(holidays, default_prior_scale=10.0):
         else:
             days = [int(v) for v in _day_number(pd.DatetimeIndex(pd.to_datetime(list(r['ds']))).asi8)]
 
-        def window(v):
-            try:
-                return int(v)
-            except (TypeError, ValueError):
-                return 0
-        lw, uw = window(r['lower_window']), window(r['upper_window'])
+        # fbprophet's make_holiday_features parses both windows inside ONE try: if either is missing /
+        # NaN / not a number, both are 0
+        try:
+            lw, uw = int(r['lower_window']), int(r['upper_window'])
+        except (TypeError, ValueError):
+            lw, uw = 0, 0
         ps = r['prior_scale']
         ps = default_prior_scale if ps is None or (isinstance(ps, float) and np.isnan(ps)) else float(ps)
         if ps <= 0:
             raise ValueError('Prior scale must be > 0')
         name = str(r['holiday'])
+        # fbprophet's validate_column_name: the separator of the generated column names and the names
+        # of its own components are not allowed as holiday names
+        if '_delim_' in name:
+            raise ValueError('Name cannot contain "_delim_"')
+        if name in RESERVED_NAMES:
+            raise ValueError('Name "{}" is reserved.'.format(name))
         if name in scales and scales[name] != ps:
             raise ValueError('Holiday {} does not have consistent prior scale specification.'.format(name))
         scales[name] = ps

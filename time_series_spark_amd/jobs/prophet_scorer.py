@@ -64,7 +64,11 @@ def forecast_panel(config):
                 ex = np.zeros((len(idx), len(spec.extra), periods))
                 if spec.holidays:
                     names, _scales, days = features.holiday_columns(features.normalize_holidays(spec.holidays))
-                    assert [e['name'] for e in spec.extra[:len(names)]] == names
+                    if [e['name'] for e in spec.extra[:len(names)]] != names:
+                        # (not an assert: it is the only guard between a blob whose `holidays` and
+                        # `extra` disagree and holiday indicators multiplied into the wrong coefficients)
+                        raise ValueError('model blob: the holiday columns rebuilt from `holidays` do not match '
+                                         'the leading entries of `extra`')
                     ex[:, :len(names), :] = np.moveaxis(features.holiday_matrix(fut, days), 0, 1)
             yhat, yint = fc.predict(spec, theta, rec['y_scale'], grid, fut, floor=floor, cap=cap,
                                     extra_future=ex, want_int=True,      # :70-84
