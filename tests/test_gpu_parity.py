@@ -508,6 +508,42 @@ def test_newton_kernel_matches_oracle(env):
                        ds[:60], y[:, :60], extra=np.zeros((12, 60)))
 
 
+def test_newton_for_the_references_widest_default_model(env):
+    """Prophet(growth='logistic', seasonality_mode='multiplicative') (prophet_modeler.py:65) on
+    sub-daily data spanning two years gets yearly + weekly + daily seasonality: K = 34, P = 62 -- one
+    parameter per lane still, the design row streamed (newton_kernel<64>).  Round 2 stopped Newton at
+    K = 28, so fbprophet's retry-with-Newton after an L-BFGS RuntimeError became "series dropped" for
+    exactly this model.  Bit-identical to the oracle's Newton on short 15-minute series; the job layer
+    routes short series of this model to it."""
+    from time_series_spark_amd import _lib, synth
+    from time_series_spark_amd.jobs import prophet_modeler as pm
+    fc, cl = env
+    T, N = 96, 2                           # one day of 15-minute rows (< 100: fbprophet picks Newton)
+    ds = np.datetime64('2019-03-01T00:00:00', 'ns').astype(np.int64) + 900 * 10 ** 9 * np.arange(T)
+    _, y = synth.make_panel(N, T, 'logistic', seed=31)
+    seas = [helpers.YEARLY, helpers.WEEKLY, helpers.DAILY]
+    spec = fc.ModelSpec(growth='logistic', seasonality_mode='multiplicative', seasonalities=seas,
+                        algorithm=_lib.ALGO_AUTO)
+    assert spec.K == 34 and spec.theta_stride == 62
+    floor, cap = np.zeros(N), y.max(axis=1) * 1.1
+    r = fc.fit_aligned(spec, ds, y, floor=floor, cap=cap)
+    csp = helpers.oracle_spec(spec)
+    for n in range(N):
+        o = cl.fit_newton(csp, ds, y[n], floor[n], cap[n])
+        S = o['info'].S
+        assert (r.status[n], r.n_iter[n], r.n_eval[n]) == (o['status'], o['n_iter'], o['n_eval']), n
+        assert n_bit_diff(r.theta[n][:3 + S], o['theta'][:3 + S]) == 0 and n_bit_diff(r.fval[n], o['f']) == 0
+        assert n_bit_diff(r.theta[n][3 + spec.n_changepoints:], o['theta'][3 + S:]) == 0
+    assert (r.status == _lib.ST_NEWTON_CONVERGED).all()
+    # a linear / additive model of the same width: quadratic-form Newton stops at 28 columns, the
+    # residual-form kernel takes it (eval_form says so to the oracle: the form is part of the arithmetic)
+    spec_l = fc.ModelSpec(growth='linear', seasonalities=seas, algorithm=_lib.ALGO_NEWTON, eval_form=_lib.EVAL_RESIDUAL)
+    rl = fc.fit_aligned(spec_l, ds, y[:1])
+    ol = cl.fit_newton(helpers.oracle_spec(spec_l), ds, y[0])
+    assert (rl.status[0], rl.n_iter[0], rl.n_eval[0]) == (ol['status'], ol['n_iter'], ol['n_eval'])
+    assert n_bit_diff(rl.fval[0], ol['f']) == 0
+
+
 def test_batched_job_is_independent_of_how_series_are_grouped(env):
     """model_panel groups series that share a timestamp vector (aligned kernel path) and fits the
     rest through the ragged entry point; each series' model must be byte-identical to the one

@@ -351,7 +351,7 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     const bool newton = theta_in == nullptr &&
                         (spec->algorithm == TSF_ALGO_NEWTON ||
                          (spec->algorithm == TSF_ALGO_AUTO && Tm < TSF_NEWTON_BELOW_T));
-    if (newton && (fit_P(hs.n_cp, hs.K) > W || mode == 2 || hs.KP > 28))
+    if (newton && (fit_P(hs.n_cp, hs.K) > W || mode == 2))
         return fail(ctx, "Newton needs 3 + n_changepoints + K <= 64 and all columns of one mode");
     const bool quad_ok = hs.growth == TSF_GROWTH_LINEAR && mode == 0 && hs.history == QH &&
                          theta_in == nullptr && !newton;
@@ -360,7 +360,7 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     const bool quad = quad_ok && spec->eval_form != TSF_EVAL_RESIDUAL;
     // Newton on the same models: residual form at the accepted points, quadratic form for the
     // finite-difference and halving evaluations (tsf_newton_quad.h); aligned panels
-    const bool newton_quad = newton && hs.growth == TSF_GROWTH_LINEAR && mode == 0 &&
+    const bool newton_quad = newton && hs.growth == TSF_GROWTH_LINEAR && mode == 0 && hs.KP <= 28 &&
                              spec->eval_form != TSF_EVAL_RESIDUAL && NTmax <= 16;
     QuadPlan qp;
     memset(&qp, 0, sizeof(qp));

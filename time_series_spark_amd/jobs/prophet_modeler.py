@@ -141,7 +141,7 @@ def fit_packed(panel, floor, cap, kw, devices=None):
         # more after an L-BFGS RuntimeError (UPSTREAM-RECALL forecaster.py fit).  The
         # Newton kernel holds one parameter per lane: wider models stay on L-BFGS.
         modes = {s_.get('mode', mode) for s_ in seas} | ({mode} if hol_extra else set())
-        newton_ok = 3 + lbfgs.n_changepoints + lbfgs.K <= 64 and lbfgs.K <= 28 and len(modes) <= 1
+        newton_ok = 3 + lbfgs.n_changepoints + lbfgs.K <= 64 and len(modes) <= 1
         if algo == 'newton' and not newton_ok:
             raise ValueError('algorithm newton needs 3 + n_changepoints + K <= 64 and one seasonality mode')
         short = panel.lengths[members] < NEWTON_BELOW_T
