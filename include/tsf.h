@@ -122,8 +122,9 @@ typedef struct {
      * cores (aligned panels, one parameter per lane, <= 28 changepoints); TSF_RK_AUTO = WAVE with
      * the cooperative tail: the series still running when the launch has handed out its last series
      * are suspended and finished by one WORKGROUP each (16 waves sharing every evaluation; series of
-     * at most 4096 rows); TSF_RK_COOP = every series goes to a workgroup after its first evaluation
-     * (lowest latency for panels smaller than the GPU). */
+     * at most 4096 rows) -- and models with more than 64 parameters (two per lane) run on workgroups from
+     * their first evaluation, the workgroup kernel being the faster one for them; TSF_RK_COOP = every
+     * series on a workgroup from its first evaluation (lowest latency for panels smaller than the GPU). */
     int32_t residual_kernel;                /* TSF_RK_AUTO */
     /* test / tuning hook of the cooperative tail: >= 0 suspends a fit once it has used that many
      * evaluations instead of at the tail of the launch; -1 = the default rule.  Results do not depend

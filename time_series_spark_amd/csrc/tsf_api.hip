@@ -519,7 +519,12 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
             a.coop_list = (int32_t *)(ws + l.clist);
             a.coop_slots = (double *)(ws + l.cslots);
             a.coop_max = coop_slots; a.coop_stride = coop_stride;
-            a.coop_after = spec->residual_kernel == TSF_RK_COOP ? 0 : spec->coop_after;
+            // TSF_RK_COOP: the cooperative kernel runs every fit from its first evaluation (no one-wave
+            // phase, no checkpoints).  AUTO does the same for the models whose one-wave kernel holds two
+            // parameters per lane (KP = 64): that kernel needs > 256 registers (one wave per SIMD) and
+            // measures 9.6 M evaluations/s on 50 000 x 730 with 56 columns, the workgroup kernel 11.4+ M.
+            a.coop_after = spec->residual_kernel == TSF_RK_COOP ? COOP_DIRECT : spec->coop_after;
+            if (spec->residual_kernel == TSF_RK_AUTO && spec->coop_after < 0 && hs.KP == 64) a.coop_after = COOP_DIRECT;
             a.coop_blocks = ctx->n_cu;
             HIP_TRY(ctx, hipMemsetAsync(a.coop_ctl, 0, 4 * sizeof(int), st));
         }

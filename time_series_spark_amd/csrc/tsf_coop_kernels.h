@@ -351,8 +351,9 @@ __device__ __forceinline__ void coop_helper_pf(const DevSpec *__restrict__ sp, c
         }
     };
 
-    double x[ROWS ? RPW : 1][XB];
+    double x[(ROWS && NXB == 1) ? RPW : 1][XB];
     double xc[COLS ? CB : 1][NTB];
+    double xc2[(COLS && !RES && NCB > 1) ? CB : 1][NTB];       // streaming mode: the next batch of columns
     if constexpr (RES) {
         if constexpr (ROWS) {
 #pragma unroll
@@ -368,14 +369,32 @@ __device__ __forceinline__ void coop_helper_pf(const DevSpec *__restrict__ sp, c
         }
         load_cols(0, 0, xc);
     }
+    // one half (XB values) of a row's X.beta chain
+    auto chain_half = [&](int i, int h, const double (&xv_)[XB], double &xa_, double &xm_) {
+#pragma unroll
+        for (int j = 0; j < XB; ++j) {
+            const int jj = h * XB + j;
+            const double bj = w.th[3 + S + jj];             // zero beyond the model's parameters
+            // (resident mode: the first XL values of the row come back from LDS)
+            const double xv = (j < XL) ? xl[(qrow[i] * XL + j) * W + lane] : xv_[j];
+            if (MODE == 0) xa_ = __builtin_fma(xv, bj, xa_);
+            else if (MODE == 1) xm_ = __builtin_fma(xv, bj, xm_);
+            else { if (jj < Ka) xa_ = __builtin_fma(xv, bj, xa_); else xm_ = __builtin_fma(xv, bj, xm_); }
+            // (keeps the coefficient reads next to their use: hoisted to the top of the chain, the 28 /
+            // 32 of them hold 56 / 64 registers beside the design values)
+            if ((j & 3) == 3) asm volatile("" : "+v"(xa_), "+v"(xm_) :: "memory");
+        }
+    };
+    double xw[(ROWS && NXB == 2) ? 3 : 1][XB];          // KP = 64: rotating half-row buffers
     for (;;) {
         int z = 0;
         if constexpr (!RES) {
             asm volatile("s_mov_b32 %0, 0" : "=s"(z));
-            if constexpr (ROWS) {
+            if constexpr (ROWS && NXB == 1) {
 #pragma unroll
                 for (int i = 0; i < RPW; ++i) load_row(i, 0, z, x[i]);
             }
+            if constexpr (ROWS && NXB == 2) { load_row(0, 0, z, xw[0]); load_row(0, 1, z, xw[1]); }
         }
         lds_barrier();                                      // A
         if (cl.cmd == COOP_EXIT) break;
@@ -384,31 +403,21 @@ __device__ __forceinline__ void coop_helper_pf(const DevSpec *__restrict__ sp, c
             double xa[RPW], xm[RPW];
 #pragma unroll
             for (int i = 0; i < RPW; ++i) { xa[i] = 0.0; xm[i] = 0.0; }
+            if constexpr (NXB == 1) {
 #pragma unroll
-            for (int h = 0; h < NXB; ++h) {
-                if (h > 0) {
-#pragma unroll
-                    for (int i = 0; i < RPW; ++i) load_row(i, h, z, x[i]);
-                }
-#pragma unroll
-                for (int j = 0; j < XB; ++j) {
-                    const int jj = h * XB + j;
-                    const double bj = w.th[3 + S + jj];     // zero beyond the model's parameters
-#pragma unroll
-                    for (int i = 0; i < RPW; ++i) {
-                        // (resident mode: the first XL values of the row come back from LDS)
-                        const double xv = (j < XL) ? xl[(qrow[i] * XL + j) * W + lane] : x[i][j];
-                        if (MODE == 0) xa[i] = __builtin_fma(xv, bj, xa[i]);
-                        else if (MODE == 1) xm[i] = __builtin_fma(xv, bj, xm[i]);
-                        else { if (jj < Ka) xa[i] = __builtin_fma(xv, bj, xa[i]); else xm[i] = __builtin_fma(xv, bj, xm[i]); }
-                    }
-                    // (keeps the coefficient reads next to their use: hoisted to the top of the chain, the
-                    // 28 of them hold 56 registers beside the resident design values)
-                    if ((j & 3) == 3) {
-#pragma unroll
-                        for (int i = 0; i < RPW; ++i) asm volatile("" : "+v"(xa[i]), "+v"(xm[i]) :: "memory");
-                    }
-                }
+                for (int i = 0; i < RPW; ++i) chain_half(i, 0, x[i], xa[i], xm[i]);
+            } else {
+                // two rows x two halves of 32 values: the request of a half goes out while an earlier half
+                // is being consumed (three buffers of 64 registers; the pins order request / chain / request)
+                static_assert(NXB == 1 || RPW == 2, "the half-row rotation is written for two rows");
+                load_row(1, 0, z, xw[2]);
+                chain_half(0, 0, xw[0], xa[0], xm[0]);
+                asm volatile("" : "+v"(xa[0]), "+v"(xm[0]) :: "memory");
+                load_row(1, 1, z, xw[0]);
+                chain_half(0, 1, xw[1], xa[0], xm[0]);
+                asm volatile("" : "+v"(xa[0]), "+v"(xm[0]) :: "memory");
+                chain_half(1, 0, xw[2], xa[1], xm[1]);
+                chain_half(1, 1, xw[0], xa[1], xm[1]);
             }
             if constexpr (!RES) {
                 // The column requests go out here: after the row values are consumed (the empty asm pins
@@ -470,9 +479,7 @@ __device__ __forceinline__ void coop_helper_pf(const DevSpec *__restrict__ sp, c
             }
         }
         if constexpr (COLS) {
-#pragma unroll
-            for (int b = 0; b < NCB; ++b) {
-                if (!RES && b > 0) load_cols(b, z, xc);
+            auto col_batch = [&](int b, const double (&xcb)[CB][NTB]) {
                 double acc[CB];
 #pragma unroll
                 for (int u = 0; u < CB; ++u) acc[u] = 0.0;
@@ -485,7 +492,7 @@ __device__ __forceinline__ void coop_helper_pf(const DevSpec *__restrict__ sp, c
                     for (int u = 0; u < CB; ++u) {
                         const int j = (wid - 1) + (b * CB + u) * NCW;
                         const double ru = (MODE == 0) ? r0 : (MODE == 1 ? r1 : (j < Ka ? r0 : r1));
-                        acc[u] = __builtin_fma(xc[u][q], ru, acc[u]);
+                        acc[u] = __builtin_fma(xcb[u][q], ru, acc[u]);
                     }
                 }
 #pragma unroll
@@ -493,6 +500,16 @@ __device__ __forceinline__ void coop_helper_pf(const DevSpec *__restrict__ sp, c
                     const int j = (wid - 1) + (b * CB + u) * NCW;
                     const double sacc = chunk_sum_1(acc[u]);
                     if (j < K && lane == 0) w.accR[j] = sacc;
+                }
+            };
+            if constexpr (RES || NCB == 1) {
+                col_batch(0, xc);
+            } else {
+                // streaming: the request of batch b + 1 goes out before batch b is consumed (two buffers)
+#pragma unroll
+                for (int b = 0; b < NCB; ++b) {
+                    if (b + 1 < NCB) { if ((b & 1) == 0) load_cols(b + 1, z, xc2); else load_cols(b + 1, z, xc); }
+                    if ((b & 1) == 0) col_batch(b, xc); else col_batch(b, xc2);
                 }
             }
         }
@@ -553,21 +570,52 @@ __device__ __forceinline__ void coop_owner(const FitArgs &a, SeriesView &sv, int
     const int lane = lane_id();
     const DevSpec *sp = a.sp;
     auto &lds = cl.w;
-    const CoopVars cv = *reinterpret_cast<const CoopVars *>(slot);
-
+    // slot == nullptr: the whole fit runs here (fit_coop_kernel in direct mode: no one-wave phase, no
+    // checkpoint) from fbprophet's initial values, as fit_kernel starts it
+    const bool scratch = slot == nullptr;
+    CoopVars cv;
     double xk[PPL], gk[PPL], pk[PPL], xk1[PPL], gk1[PPL], pk1[PPL];
-    coop_get_vec<PPL>(slot, 0, xk); coop_get_vec<PPL>(slot, 1, gk); coop_get_vec<PPL>(slot, 2, pk);
-#pragma unroll
-    for (int s = 0; s < PPL; ++s) { xk1[s] = 0.0; gk1[s] = 0.0; pk1[s] = 0.0; }     // dead at a line-search evaluation
     const int H = a.opt.history > MAXH ? MAXH : a.opt.history;
-    for (int h = 0; h < H; ++h) {
-        double sv_[PPL], yv_[PPL];
-        coop_get_vec<PPL>(slot, 6 + h, sv_); coop_get_vec<PPL>(slot, 6 + MAXH + h, yv_);
+    if (scratch) {
+        const SeriesTab st = a.stab[n];
+        if (lane == 0) {
+            a.y_scale[n] = st.y_scale;
+            if (!a.aligned || n == 0) a.grid_out[a.aligned ? 0 : n] = a.gtab[a.aligned ? 0 : n].info;
+        }
 #pragma unroll
-        for (int s = 0; s < PPL; ++s) { lds.Sb[(h * PPL + s) * W + lane] = sv_[s]; lds.Yb[(h * PPL + s) * W + lane] = yv_[s]; }
+        for (int s = 0; s < PPL; ++s) {
+            const int p = lane + s * W;
+            xk[s] = (p == 0) ? st.k0 : (p == 1 ? st.m0 : 0.0);
+            gk[s] = 0.0; pk[s] = 0.0; xk1[s] = xk[s]; gk1[s] = 0.0; pk1[s] = 0.0;
+        }
+        if (st.status0 != 0) {
+            // fbprophet raises (too few rows / cap <= floor) or skips optimisation (constant y)
+            if (st.status0 == TSF_ST_CONSTANT) {
+#pragma unroll
+                for (int s = 0; s < PPL; ++s) if (lane + s * W == 2) xk[s] = -20.72326583694641;
+            }
+            if (lane == 0) cl.cmd = COOP_EXIT;
+            lds_barrier();
+            store_theta<PPL>(a, sv, n, xk, a.theta);
+            if (lane == 0) { a.status[n] = st.status0; a.n_iter[n] = 0; a.n_eval[n] = 0; a.fval[n] = 0.0; }
+            return;
+        }
+        memset(&cv, 0, sizeof(cv));
+        cv.alpha = a.opt.init_alpha; cv.gammak = 1.0;
+    } else {
+        cv = *reinterpret_cast<const CoopVars *>(slot);
+        coop_get_vec<PPL>(slot, 0, xk); coop_get_vec<PPL>(slot, 1, gk); coop_get_vec<PPL>(slot, 2, pk);
+#pragma unroll
+        for (int s = 0; s < PPL; ++s) { xk1[s] = 0.0; gk1[s] = 0.0; pk1[s] = 0.0; }     // dead at a line-search evaluation
+        for (int h = 0; h < H; ++h) {
+            double sv_[PPL], yv_[PPL];
+            coop_get_vec<PPL>(slot, 6 + h, sv_); coop_get_vec<PPL>(slot, 6 + MAXH + h, yv_);
+#pragma unroll
+            for (int s = 0; s < PPL; ++s) { lds.Sb[(h * PPL + s) * W + lane] = sv_[s]; lds.Yb[(h * PPL + s) * W + lane] = yv_[s]; }
+        }
+        if (lane < MAXH) lds.rho[lane] = slot[COOP_VARS_D + lane];
+        TSF_WAVE_SYNC();
     }
-    if (lane < MAXH) lds.rho[lane] = slot[COOP_VARS_D + lane];
-    TSF_WAVE_SYNC();
 
     const double c1 = 1e-4, c2 = 0.9, minAlpha = 1e-12, min_range = 1e-16;
     const int maxLSIts = 20, maxLSRestarts = 10;
@@ -582,8 +630,8 @@ __device__ __forceinline__ void coop_owner(const FitArgs &a, SeriesView &sv, int
     bool gp_valid = cv.gp_valid != 0, pk1_scaled = cv.pk1_scaled != 0;
     sv.n_eval = cv.n_eval;
 
-    enum { ST_START_ITER = 1, ST_START_LS, ST_LS_PRE, ST_LS_EVAL };
-    int stage = ST_LS_EVAL;
+    enum { ST_INIT = 0, ST_START_ITER, ST_START_LS, ST_LS_PRE, ST_LS_EVAL };
+    int stage = scratch ? ST_INIT : ST_LS_EVAL;
     CT_DECL;
     for (;;) {
         if (stage == ST_START_ITER) {
@@ -637,14 +685,23 @@ __device__ __forceinline__ void coop_owner(const FitArgs &a, SeriesView &sv, int
             if (!ls_fail) stage = ST_LS_EVAL;
         }
         if (!ls_fail) {
-            // (stage == ST_LS_EVAL: the only evaluation site of a resumed fit)
-            if (sv.n_eval >= 64 * a.opt.max_iter + 1024) { ret = TSF_ST_EVAL_LIMIT; break; }
+            if (stage == ST_LS_EVAL) {
+                if (sv.n_eval >= 64 * a.opt.max_iter + 1024) { ret = TSF_ST_EVAL_LIMIT; break; }
 #pragma unroll
-            for (int s = 0; s < PPL; ++s) xk1[s] = __builtin_fma(alpha, pk[s], xk[s]);
+                for (int s = 0; s < PPL; ++s) xk1[s] = __builtin_fma(alpha, pk[s], xk[s]);
+            }
             double f1;
             CT_LAP(0);
             const bool bad = coop_eval_owner<KP, GROWTH, MODE, PPL, NW, XIDX>(sp, sv, cl, rbR, rbU, rbV, xk1, f1, gk1 CT_PASS);
             f1 = uniform_f64(f1);
+            if (stage == ST_INIT) {         // (direct mode only) the initial point
+                if (bad) { ret = TSF_ST_INIT_NONFINITE; fk = f1; break; }
+                fk = f1;
+#pragma unroll
+                for (int s = 0; s < PPL; ++s) { gk[s] = gk1[s]; pk[s] = -gk[s]; gk1[s] = 0.0; xk1[s] = 0.0; }
+                stage = ST_START_ITER;
+                continue;
+            }
             if (bad) {
                 if (!zoom) {
                     if (lsRestarts >= maxLSRestarts) ls_fail = true;
@@ -798,8 +855,11 @@ __global__ __launch_bounds__(NW * 64) void fit_coop_kernel(FitArgs a)
     double *rbR = reinterpret_cast<double *>(smem + sizeof(CoopLds<KP, PPL>));
     double *rbU = rbR + (size_t)coop_rb_rows(a.NTmax) * W, *rbV = rbU + (size_t)coop_rb_rows(a.NTmax) * W;
     const int wid = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);     // wave-uniform: addresses built from it stay scalar
-    int n_ckpt = a.coop_ctl[1];
-    if (n_ckpt > a.coop_max) n_ckpt = a.coop_max;
+    // direct mode: every series of the call, fitted here from its initial values; otherwise the fits
+    // fit_kernel suspended
+    const bool direct = a.coop_after == COOP_DIRECT;
+    int n_ckpt = direct ? (int)a.N : a.coop_ctl[1];
+    if (!direct && n_ckpt > a.coop_max) n_ckpt = a.coop_max;
     for (;;) {
         // (queue fetch kept branch-free: see the compiler note in DESIGN.md section 5)
         if (wid == 0) {
@@ -810,7 +870,7 @@ __global__ __launch_bounds__(NW * 64) void fit_coop_kernel(FitArgs a)
         const int item = cl.item;
         __syncthreads();
         if (item >= n_ckpt) break;
-        const int64_t n = a.coop_list[item];
+        const int64_t n = direct ? item : a.coop_list[item];
         SeriesView sv;
         make_view<KP, PPL>(a, n, sv);
         // rows [NT, COOP_NTB) of the row buffers: zeros (the straight-line chains of coop_helper_pf)
@@ -823,7 +883,8 @@ __global__ __launch_bounds__(NW * 64) void fit_coop_kernel(FitArgs a)
         if (wid == 0) {
             for (int i = lane_id(); i < TSF_MAX_P + W; i += W) cl.w.th[i] = 0.0;
             TSF_WAVE_SYNC();
-            coop_owner<KP, GROWTH, MODE, PPL, NW, XIDX>(a, sv, n, a.coop_slots + (size_t)item * a.coop_stride, cl, rbR, rbU, rbV);
+            coop_owner<KP, GROWTH, MODE, PPL, NW, XIDX>(a, sv, n, direct ? nullptr : a.coop_slots + (size_t)item * a.coop_stride,
+                                                        cl, rbR, rbU, rbV);
         } else if (sv.NT > COOP_NTB) {
             coop_helper<KP, GROWTH, MODE, PPL, NW, XIDX>(a.sp, sv, cl, rbR, rbU, rbV, wid);
         } else if (a.NTmax > 12) {      // (the call's longest series decides: the LDS of the 12-step variant is sized by it)

@@ -517,6 +517,7 @@ struct FitArgs {
 // x, g, p of the current iterate (0..2; 3..5 unused) and the L-BFGS history S (6..), Y (6+MAXH..),
 // each [PPL][64]
 constexpr int COOP_MAX_NT = 64;         // longest series the cooperative tail takes: 64 steps per chunk (4096 rows)
+constexpr int COOP_DIRECT = -2;          // FitArgs::coop_after: no one-wave phase, fit_coop_kernel fits every series from scratch
 constexpr int COOP_VARS_D = 32;
 constexpr int COOP_NVEC = 6 + 2 * MAXH;
 
