@@ -36,6 +36,10 @@ struct CoopLds {
     // evaluation after every step
     int snap_q[NTAB], snap_l[NTAB];
     double run1[COOP_NTB * W], run2[COOP_NTB * W];
+    // hand-overs inside an evaluation: 1 / sigma^2 (owner -> trend wave), the trend part of the gradient
+    // without its prior terms (trend wave -> owner: [0] d/dk, [1] d/dm, [3 + j] d/d delta_j)
+    double inv_s2;
+    double gtr[W];
 };
 enum { COOP_EVAL = 1, COOP_EXIT = 2 };
 #ifndef COOP_NW
@@ -206,6 +210,152 @@ __device__ __forceinline__ double coop_sse(const SeriesView &sv, const double *r
     return bfly_sum(sse);
 }
 
+// ---- pieces of an evaluation that moved off the owner ---------------------------------------------
+// Segment tables ks[c], mc[c] (segment_tables of tsf_fit_kernels.h: the sequential recurrences over
+// the changepoints) from the owner's LDS copy of theta, by ONE lane of the trend wave: operands come
+// from LDS instead of v_readlane and every step stores its value, so a step is its dependent adds /
+// multiplies and nothing else (the lane-parallel form costs ~10 vector instructions per step: the
+// owner spent 4.4 k cycles here per evaluation).  Same operations, same operands, same order.
+// Scratch: w.d1, w.d2 (free until the tail).
+template <int GROWTH, class L>
+__device__ __forceinline__ void coop_segment_tables(const SeriesView &sv, L &w)
+{
+    const int lane = lane_id();
+    const int S = sv.S;
+    // The chains run in blocks of 8 steps: the 8 operands of a block are read together (one LDS
+    // latency per block instead of one per step -- a rolled loop waits for every read), then the 8
+    // dependent steps and their stores.  Steps past S (the last block) work on whatever follows the
+    // deltas in LDS and write entries ks / mc [S+1 .. ] that nothing reads.
+    if (GROWTH == 0) {
+        // the product of step j, lane-parallel: (-t_change[j]) * delta[j]
+        w.d1[lane] = (lane < S) ? (-sv.tc_l) * w.th[3 + lane] : 0.0;
+        wave_sync();
+        if (lane == 0) {
+            double ksv = w.th[0], mcv = w.th[1];
+            w.ks[0] = ksv; w.mc[0] = mcv;
+            for (int j0 = 0; j0 < S; j0 += 8) {
+                double dj[8], pj[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { dj[u] = w.th[3 + j0 + u]; pj[u] = w.d1[j0 + u]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    ksv = ksv + dj[u];
+                    mcv = mcv + pj[u];
+                    w.ks[j0 + u + 1] = ksv; w.mc[j0 + u + 1] = mcv;
+                }
+            }
+        }
+    } else {
+        if (lane == 0) {
+            double ksv = w.th[0];
+            w.ks[0] = ksv;
+            for (int j0 = 0; j0 < S; j0 += 8) {
+                double dj[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) dj[u] = w.th[3 + j0 + u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { ksv = ksv + dj[u]; w.ks[j0 + u + 1] = ksv; }
+            }
+        }
+        wave_sync();
+        // gamma_j = (t_change[j] - mc[j]) * (1 - ks[j] / ks[j+1]): the S quotients are one lane-parallel
+        // division (lane j), the chain reads them back
+        w.d1[lane] = (lane < S) ? 1.0 - w.ks[lane] / w.ks[lane + 1] : 0.0;
+        w.d2[lane] = sv.tc_l;
+        wave_sync();
+        if (lane == 0) {
+            double mcv = w.th[1];
+            w.mc[0] = mcv;
+            for (int j0 = 0; j0 < S; j0 += 8) {
+                double om[8], tc[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { om[u] = w.d1[j0 + u]; tc[u] = w.d2[j0 + u]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const double gamma = (tc[u] - mcv) * om[u];
+                    mcv = mcv + gamma;
+                    w.mc[j0 + u + 1] = mcv;
+                }
+            }
+        }
+    }
+    wave_sync();
+}
+
+// The trend part of the gradient (eval_tail's GROWTH block and its delta / k / m entries, WITHOUT the
+// prior terms) from the time-axis sums the trend wave has just produced: cl.gtr.  Runs on the trend
+// wave while the other waves finish their columns.  Scratch: w.d1, w.d2, w.rb, w.ab.
+template <int GROWTH, int KP, int PPL>
+__device__ __forceinline__ void coop_tail_trend(const SeriesView &sv, CoopLds<KP, PPL> &cl)
+{
+    const int lane = lane_id();
+    const int S = sv.S;
+    auto &lds = cl.w;
+    const double nis = -cl.inv_s2;
+    const double TA = lds.tot1[0], TB = lds.tot2[0];
+    double gk, gm, gd = 0.0;
+    if (GROWTH == 1) {
+        // per-segment sums from suffix sums, then reverse sweep through the gamma recurrence
+        {
+            const int c = lane;
+            if (c <= S) {
+                const int Ljm = (c > 0) ? sv.Ljm1_l : 0, Ljc = (c < S) ? sv.Lj_l : 0;
+                const double hiA = (c == 0) ? TA : lds.tp1[c - 1] + lds.tot1[Ljm + 1];
+                const double hiB = (c == 0) ? TB : lds.tp2[c - 1] + lds.tot2[Ljm + 1];
+                const double loA = (c == S) ? 0.0 : lds.tp1[c] + lds.tot1[Ljc + 1];
+                const double loB = (c == S) ? 0.0 : lds.tp2[c] + lds.tot2[Ljc + 1];
+                const double A = hiA - loA, B = hiB - loB;
+                lds.d1[c] = A - lds.mc[c] * B;
+                lds.d2[c] = -(lds.ks[c] * B);
+            }
+        }
+        wave_sync();
+        {
+            const int cl_ = lane <= S ? lane : S;
+            const double ratio_l = (lane < S) ? lds.ks[cl_] / lds.ks[cl_ + 1] : 0.0;
+            const double tmc_l = (lane < S) ? sv.tc_l - lds.mc[cl_] : 0.0;
+            const double d2_l = lds.d2[cl_];
+            double abar = readlane_f64(d2_l, S);
+            double rb_l = 0.0;
+            TSF_UNROLL4_DOWN(c, S - 1, 0, {
+                const double rbc = abar * readlane_f64(tmc_l, c);
+                if (lane == c) rb_l = rbc;
+                abar = readlane_f64(d2_l, c) + abar * readlane_f64(ratio_l, c);
+            });
+            if (lane < S) lds.rb[lane] = rb_l;
+            gm = nis * abar;
+        }
+        wave_sync();
+        {
+            const int c = lane;
+            if (c <= S) {
+                double d = lds.d1[c];
+                if (c < S) d = d + lds.rb[c] * (-1.0 / lds.ks[c + 1]);
+                if (c >= 1) d = d + lds.rb[c - 1] * ((lds.ks[c - 1] / lds.ks[c]) / lds.ks[c]);
+                lds.ab[c] = d;
+            }
+        }
+        wave_sync();
+        const double ab_l = lds.ab[lane <= S ? lane : S];
+        double sK = 0.0;
+        TSF_UNROLL4_DOWN(c, S, 1, {
+            sK = sK + readlane_f64(ab_l, c);
+            if (lane == 3 + (c - 1)) gd = nis * sK;
+        });
+        gk = nis * (sK + readlane_f64(ab_l, 0));
+    } else {
+        gk = nis * TA;
+        gm = nis * TB;
+        if (lane >= 3 && lane < 3 + S) {
+            const int j = lane - 3, Lj = sv.Ljp_l[0];
+            const double SA = lds.tp1[j] + lds.tot1[Lj + 1];
+            const double SB = lds.tp2[j] + lds.tot2[Lj + 1];
+            gd = nis * (SA - sv.tcp_l[0] * SB);
+        }
+    }
+    cl.gtr[lane] = (lane == 0) ? gk : (lane == 1 ? gm : gd);
+}
+
 // ---- the helpers' loops ------------------------------------------------------------------------
 // Workgroup barrier that waits for this wave's LDS traffic only: global loads issued before it (the
 // design values of the next phase) stay in flight across it.  __syncthreads() would drain them
@@ -219,11 +369,13 @@ __device__ __forceinline__ void coop_helper(const DevSpec *__restrict__ sp, cons
                                             CoopLds<KP, PPL> &cl, double *rbR, double *rbU, double *rbV, int wid)
 {
     for (;;) {
-        lds_barrier();                                      // A: the owner has published theta / ks / mc / cmd
+        lds_barrier();                                      // A: the owner has published theta / cmd
         if (cl.cmd == COOP_EXIT) break;
+        if (wid == NW - 1) coop_segment_tables<GROWTH>(sv, cl.w);
+        lds_barrier();                                      // A2: segment tables, 1 / sigma^2
         if (wid < NW - 1) coop_rows<KP, GROWTH, MODE, PPL, XIDX>(sp, sv, cl.w, rbR, rbU, rbV, wid - 1, NW - 2);
         lds_barrier();                                      // B: rows complete
-        if (wid == NW - 1) coop_trend(sv, cl.w, rbV);
+        if (wid == NW - 1) { coop_trend(sv, cl.w, rbV); wave_sync(); coop_tail_trend<GROWTH>(sv, cl); }
         else coop_columns<KP, MODE, XIDX>(sp, sv, cl.w, rbR, rbU, wid - 1, NW - 2);
         lds_barrier();                                      // C: sums complete
     }
@@ -235,8 +387,9 @@ __device__ __forceinline__ void coop_helper(const DevSpec *__restrict__ sp, cons
 //   RES (resident): the design values a wave needs -- its rows for phase A, its columns x all steps
 //     for phase B -- are loaded ONCE per series and stay in registers (8 waves x 256 registers hold the
 //     panel's design matrix twice: 2 x 152 KB for 730 x 26; a CU's L1 fills at 64 B per cycle, so
-//     streaming both copies from L2 costs ~5 k cycles per evaluation); column j -> wave 1 + j mod (NW-1),
-//     the trend wave takes a share after its chain.  An evaluation touches LDS only.
+//     streaming both copies from L2 costs ~5 k cycles per evaluation); column j -> wave j mod (NW-1): the
+//     OWNER (wave 0, idle while the sums are formed) takes a share, the trend wave none (it forms the trend
+//     part of the gradient meanwhile).  An evaluation touches LDS only.
 //   otherwise (wider models / longer series): the rows of phase A are requested before barrier A (they
 //     arrive while the owner runs the optimiser), the columns of phase B CB at a time, the first batch
 //     inside phase A; column j -> wave 1 + j mod (NW-2).
@@ -248,7 +401,7 @@ struct CoopShape {
     static constexpr int RPW = 2;                               // rows of a wave held at a time
     static constexpr int XB = KP <= 32 ? KP : 32;               // design values of a row held at a time
     static constexpr int NXB = KP / XB;                         // KP = 8, 16, 28: 1;  64: 2
-    static constexpr int CPW_RES = (KP + NW - 2) / (NW - 1);    // columns per wave, resident mode
+    static constexpr int CPW_RES = (KP + NW - 2) / (NW - 1);    // columns per wave, resident mode (owner + row waves)
     // resident mode, 28 columns x 12 steps: the first XL design values of every row live in LDS instead
     // of registers (with all of 2 rows x 28 + 4 columns x 12 values in registers the row waves spill
     // ~30 of them, and every reload is a dependent scratch round trip inside the row chain: 7.4 k
@@ -276,7 +429,8 @@ __device__ __forceinline__ void coop_helper_pf(const DevSpec *__restrict__ sp, c
     constexpr int NRW = NW - 2, RPW = SH::RPW, XB = SH::XB, NXB = SH::NXB, CB = SH::CB, NCB = SH::NCB, NCW = SH::NCW;
     constexpr bool RES = SH::RES;
     constexpr int XL = RES ? SH::XL : 0;                // design values of a row kept in LDS (xl)
-    constexpr bool ROWS = !TREND, COLS = RES || !TREND;
+    constexpr bool ROWS = !TREND, COLS = !TREND;
+    const int cw0 = RES ? wid : wid - 1;                // first column of this wave (resident mode: wave 0 = the owner has one too)
     const int lane = lane_id();
     const int NT = sv.NT, S = sv.S, K = sp->K;
     const int Ka = (MODE == 0) ? K : (MODE == 1 ? 0 : sp->Ka);
@@ -340,7 +494,7 @@ __device__ __forceinline__ void coop_helper_pf(const DevSpec *__restrict__ sp, c
     auto load_cols = [&](int b, int z, double (&xc)[CB][NTB]) {
 #pragma unroll
         for (int u = 0; u < CB; ++u) {
-            int j = (wid - 1) + (b * CB + u) * NCW + z;
+            int j = cw0 + (b * CB + u) * NCW + z;
             j = j < K ? j : 0;
 #pragma unroll
             for (int q = 0; q < NTB; ++q) {
@@ -354,7 +508,7 @@ __device__ __forceinline__ void coop_helper_pf(const DevSpec *__restrict__ sp, c
     double x[(ROWS && NXB == 1) ? RPW : 1][XB];
     double xc[COLS ? CB : 1][NTB];
     double xc2[(COLS && !RES && NCB > 1) ? CB : 1][NTB];       // streaming mode: the next batch of columns
-    if constexpr (RES) {
+    if constexpr (RES && COLS) {
         if constexpr (ROWS) {
 #pragma unroll
             for (int i = 0; i < RPW; ++i) {
@@ -399,6 +553,7 @@ __device__ __forceinline__ void coop_helper_pf(const DevSpec *__restrict__ sp, c
         lds_barrier();                                      // A
         if (cl.cmd == COOP_EXIT) break;
         HT_START();
+        if constexpr (TREND) { coop_segment_tables<GROWTH>(sv, w); lds_barrier(); }    // A2 (trend wave)
         if constexpr (ROWS) {
             double xa[RPW], xm[RPW];
 #pragma unroll
@@ -428,6 +583,7 @@ __device__ __forceinline__ void coop_helper_pf(const DevSpec *__restrict__ sp, c
                 for (int i = 0; i < RPW; ++i) asm volatile("" : "+v"(xa[i]), "+v"(xm[i]));
                 load_cols(0, z, xc);
             }
+            lds_barrier();                                  // A2: the trend wave's segment tables are in LDS
 #pragma unroll
             for (int i = 0; i < RPW; ++i) {
                 const double ksc = w.ks[cq[i]], mcc = w.mc[cq[i]];
@@ -477,6 +633,8 @@ __device__ __forceinline__ void coop_helper_pf(const DevSpec *__restrict__ sp, c
                 const int at = cl.snap_q[lane] * W + cl.snap_l[lane];
                 w.tp1[lane] = cl.run1[at]; w.tp2[lane] = cl.run2[at];
             }
+            wave_sync();
+            coop_tail_trend<GROWTH>(sv, cl);
         }
         if constexpr (COLS) {
             auto col_batch = [&](int b, const double (&xcb)[CB][NTB]) {
@@ -490,14 +648,14 @@ __device__ __forceinline__ void coop_helper_pf(const DevSpec *__restrict__ sp, c
                     const double r1 = (MODE == 0) ? 0.0 : rbU[q * W + lane];
 #pragma unroll
                     for (int u = 0; u < CB; ++u) {
-                        const int j = (wid - 1) + (b * CB + u) * NCW;
+                        const int j = cw0 + (b * CB + u) * NCW;
                         const double ru = (MODE == 0) ? r0 : (MODE == 1 ? r1 : (j < Ka ? r0 : r1));
                         acc[u] = __builtin_fma(xcb[u][q], ru, acc[u]);
                     }
                 }
 #pragma unroll
                 for (int u = 0; u < CB; ++u) {
-                    const int j = (wid - 1) + (b * CB + u) * NCW;
+                    const int j = cw0 + (b * CB + u) * NCW;
                     const double sacc = chunk_sum_1(acc[u]);
                     if (j < K && lane == 0) w.accR[j] = sacc;
                 }
@@ -532,29 +690,125 @@ __device__ __forceinline__ void coop_helper_ntb(const DevSpec *__restrict__ sp, 
     else coop_helper_pf<KP, GROWTH, MODE, PPL, NW, XIDX, NTB, false>(sp, sv, cl, rbR, rbU, rbV, xl, wid);
 }
 
-// ---- one evaluation, the owner's side ---------------------------------------------------------
+// ---- one evaluation, the owner's side ----------------------------------------------------------
+// columns the owner holds in resident mode (column j of wave-slot 0: j = 0, NW-1, 2 (NW-1), ...)
+template <int KP, int NW>
+struct CoopOwnerCols {
+    static constexpr bool ANY = CoopShape<KP, NW, 12>::RES || CoopShape<KP, NW, COOP_NTB>::RES;
+    static constexpr int OC = ANY ? CoopShape<KP, NW, 12>::CPW_RES : 1;
+    static constexpr int ONT = CoopShape<KP, NW, COOP_NTB>::RES ? COOP_NTB : 12;     // steps the owner's columns span
+};
+
 template <int KP, int GROWTH, int MODE, int PPL, int NW, bool XIDX>
 __device__ __forceinline__ bool coop_eval_owner(const DevSpec *__restrict__ sp, SeriesView &sv,
                                                 CoopLds<KP, PPL> &cl, double *rbR, double *rbU, double *rbV,
-                                                const double (&th)[PPL], double &f_out, double (&g)[PPL] CT_ARGS)
+                                                const double (&th)[PPL], double &f_out, double (&g)[PPL],
+                                                bool res CT_ARGS)
 {
+    constexpr int OC = CoopOwnerCols<KP, NW>::OC, ONT = CoopOwnerCols<KP, NW>::ONT;
     const int lane = lane_id();
+    const int S = sv.S, T = sv.T, K = sp->K;
+    const int Ka = (MODE == 0) ? K : (MODE == 1 ? 0 : sp->Ka);
+    auto &lds = cl.w;
     sv.n_eval++;
 #pragma unroll
-    for (int s = 0; s < PPL; ++s) cl.w.th[lane + s * W] = th[s];
-    segment_tables<GROWTH, PPL>(sv, cl.w, th);
+    for (int s = 0; s < PPL; ++s) lds.th[lane + s * W] = th[s];
     if (lane == 0) cl.cmd = COOP_EVAL;
     CT_LAP(1);
-    lds_barrier();                                          // A
-    const double ls = theta_at<PPL>(th, 2);
+    lds_barrier();                                          // A: theta is out
+    // while the trend wave walks the changepoint recurrences and the row waves their X.beta chains:
+    // sigma terms and the two prior sums (eval_tail's first block)
+    const double k = theta_at<PPL>(th, 0), m = theta_at<PPL>(th, 1), ls = theta_at<PPL>(th, 2);
     const double sigma = dm_exp_sel(ls);
     const double inv_s2 = 1.0 / (sigma * sigma);
-    lds_barrier();                                          // B
+    if (lane == 0) cl.inv_s2 = inv_s2;
+    double pa = 0.0, pb = 0.0;
+#pragma unroll
+    for (int s = 0; s < PPL; ++s) {
+        const int p = lane + s * W;
+        if (p >= 3 && p < 3 + S) pa = pa + __builtin_fabs(th[s]);
+        if (p >= 3 + S && p < sv.P) { const double qq = th[s] / sv.prior_l[s]; pb = __builtin_fma(qq, qq, pb); }
+    }
+    const double sabs = bfly_sum(pa), sb = bfly_sum(pb);
+    const double s2 = sigma * sigma;
+    double f = ((0.5 * k) * k) / 25.0 + ((0.5 * m) * m) / 25.0;
+    f = f + sabs / sv.tau;
+    f = f + 2.0 * s2;
+    f = f + 0.5 * sb;
+    f = f + (double)T * ls;
+    // the owner's share of the design columns (resident mode of the helpers: column 0, NW-1, ...): it
+    // waits out the phases anyway, so it requests them here, every evaluation (they arrive during phase
+    // A), instead of holding ~100 registers across the whole optimiser loop
+    double xo[OC][ONT];
+#pragma unroll
+    for (int u = 0; u < OC; ++u) {
+        int j = u * (NW - 1);
+        j = j < K ? j : 0;
+#pragma unroll
+        for (int q = 0; q < ONT; ++q) {
+            const int qc = q < sv.NT ? q : 0;
+            double xv = 0.0;
+            if (res) {
+                if (XIDX) xv = (qc < sv.cnt) ? sv.Xu[(size_t)sv.uw[qc * W + lane] * KP + j] : 0.0;
+                else xv = (sv.Xw + ((size_t)qc * KP + j) * W)[lane];
+            }
+            xo[u][q] = xv;
+        }
+    }
+    lds_barrier();                                          // A2
+    lds_barrier();                                          // B: rows complete
     CT_LAP(2);
     const double sse_t = coop_sse(sv, rbR);
-    lds_barrier();                                          // C
+    if (res) {
+        // the owner's share of the design columns (resident mode), as in coop_helper_pf
+        double acc[OC];
+#pragma unroll
+        for (int u = 0; u < OC; ++u) acc[u] = 0.0;
+#pragma unroll
+        for (int q = ONT - 1; q >= 0; --q) {
+            const double r0 = (MODE == 1) ? 0.0 : rbR[q * W + lane];
+            const double r1 = (MODE == 0) ? 0.0 : rbU[q * W + lane];
+#pragma unroll
+            for (int u = 0; u < OC; ++u) {
+                const int j = u * (NW - 1);
+                const double ru = (MODE == 0) ? r0 : (MODE == 1 ? r1 : (j < Ka ? r0 : r1));
+                acc[u] = __builtin_fma(xo[u][q], ru, acc[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < OC; ++u) {
+            const int j = u * (NW - 1);
+            const double sacc = chunk_sum_1(acc[u]);
+            if (j < K && lane == 0) lds.accR[j] = sacc;
+        }
+    }
+    lds_barrier();                                          // C: all sums, and the trend part of the gradient
     CT_LAP(3);
-    const bool bad_ = eval_tail<GROWTH, PPL>(sp, sv, cl.w, cl.w, th, sigma, inv_s2, sse_t, f_out, g);
+    // the rest of eval_tail: f, and the gradient from cl.gtr (k, m, delta: trend wave) and accR (beta)
+    f = f + (0.5 * sse_t) * inv_s2;
+    const double nis = -inv_s2;
+    bool bad = !finite_f64(f);
+#pragma unroll
+    for (int s = 0; s < PPL; ++s) {
+        const int p = lane + s * W;
+        double gv = 0.0;
+        if (p == 0) gv = cl.gtr[0] + k / 25.0;
+        else if (p == 1) gv = cl.gtr[1] + m / 25.0;
+        else if (p == 2) gv = ((double)T - sse_t * inv_s2) + 4.0 * s2;
+        else if (p < 3 + S) {
+            const double dj = th[s];
+            const double sgn = (double)((dj > 0.0) - (dj < 0.0));
+            gv = cl.gtr[p] + sgn / sv.tau;
+        } else if (p < sv.P) {
+            const int j = p - 3 - S;
+            const double pr = sv.prior_l[s];
+            gv = nis * lds.accR[j] + th[s] / (pr * pr);
+        }
+        g[s] = gv;
+        bad = bad || !finite_f64(gv);
+    }
+    f_out = f;
+    const bool bad_ = __any(bad);
     CT_LAP(4);
     return bad_;
 }
@@ -630,6 +884,9 @@ __device__ __forceinline__ void coop_owner(const FitArgs &a, SeriesView &sv, int
     bool gp_valid = cv.gp_valid != 0, pk1_scaled = cv.pk1_scaled != 0;
     sv.n_eval = cv.n_eval;
 
+    // resident mode (as the helpers decide it, fit_coop_kernel): the owner then has a share of the columns
+    const bool res = sv.NT <= COOP_NTB && (a.NTmax > 12 ? CoopShape<KP, NW, COOP_NTB>::RES : CoopShape<KP, NW, 12>::RES);
+
     enum { ST_INIT = 0, ST_START_ITER, ST_START_LS, ST_LS_PRE, ST_LS_EVAL };
     int stage = scratch ? ST_INIT : ST_LS_EVAL;
     CT_DECL;
@@ -692,7 +949,7 @@ __device__ __forceinline__ void coop_owner(const FitArgs &a, SeriesView &sv, int
             }
             double f1;
             CT_LAP(0);
-            const bool bad = coop_eval_owner<KP, GROWTH, MODE, PPL, NW, XIDX>(sp, sv, cl, rbR, rbU, rbV, xk1, f1, gk1 CT_PASS);
+            const bool bad = coop_eval_owner<KP, GROWTH, MODE, PPL, NW, XIDX>(sp, sv, cl, rbR, rbU, rbV, xk1, f1, gk1, res CT_PASS);
             f1 = uniform_f64(f1);
             if (stage == ST_INIT) {         // (direct mode only) the initial point
                 if (bad) { ret = TSF_ST_INIT_NONFINITE; fk = f1; break; }
