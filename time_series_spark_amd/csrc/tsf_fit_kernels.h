@@ -505,7 +505,8 @@ struct FitArgs {
     // cooperative tail (tsf_coop_kernels.h): where coop_ctl is set, a fit that is still running when
     // the launch has started its last block (coop_after < 0) or that has used coop_after evaluations
     // writes its optimiser state to a checkpoint slot and returns; fit_coop_kernel finishes it with a
-    // whole workgroup.  ctl[0] blocks started, ctl[1] slots taken, ctl[2] queue head of the tail.
+    // whole workgroup.  ctl[0] blocks started, ctl[1] slots taken, ctl[2] queue head of the tail,
+    // ctl[3] blocks finished or suspended.
     int *coop_ctl;
     int32_t *coop_list;                 // [coop_max] series of each slot
     double *coop_slots;                 // [coop_max][coop_stride]
@@ -544,14 +545,20 @@ __device__ __forceinline__ void coop_get_vec(const double *slot, int idx, double
     for (int s = 0; s < PPL; ++s) v[s] = slot[COOP_VARS_D + MAXH + (idx * PPL + s) * W + lane_id()];
 }
 
-// suspend now?  coop_after >= 0: once that many evaluations are spent (tests, latency mode);
-// otherwise in the tail of the launch: every block has been started, whatever still runs is a
-// straggler (looked at every fourth evaluation)
+// suspend now?  coop_after >= 0: once that many evaluations are spent (tests, latency mode).
+// Otherwise in the tail of the launch: every block has been started AND no more fits are still running
+// than there are compute units (looked at every fourth evaluation).  While more are running the
+// one-wave kernel has the higher aggregate rate (R waves at one evaluation per ~16 us each against
+// n_cu workgroups at one per ~8.4 us); from there on every remaining fit gets a workgroup of its own
+// at once, which halves its time per evaluation.  ctl[0] blocks started, ctl[3] blocks finished or suspended.
 __device__ __forceinline__ bool coop_should_suspend(const FitArgs &a, int n_eval)
 {
     if (a.coop_after >= 0) return n_eval >= a.coop_after;
     if ((n_eval & 3) != 0) return false;
-    return __hip_atomic_load(&a.coop_ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (int)a.N;
+    const int started = __hip_atomic_load(&a.coop_ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (started < (int)a.N) return false;
+    const int done = __hip_atomic_load(&a.coop_ctl[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return started - done <= a.coop_blocks;
 }
 
 template <int KP, int PPL>
@@ -682,6 +689,7 @@ __global__ __launch_bounds__(64, TSF_FIT_WPS) void fit_kernel(FitArgs a)
         }
         store_theta<PPL>(a, sv, n, xk, a.theta);
         if (lane == 0) { a.status[n] = st.status0; a.n_iter[n] = 0; a.n_eval[n] = 0; a.fval[n] = 0.0; }
+        if (a.coop_ctl) atomicAdd(&a.coop_ctl[3], lane == 0 ? 1 : 0);
         return;
     }
 
@@ -920,6 +928,7 @@ __global__ __launch_bounds__(64, TSF_FIT_WPS) void fit_kernel(FitArgs a)
         resetB = 2;
         stage = ST_START_LS;
     }
+    if (a.coop_ctl) atomicAdd(&a.coop_ctl[3], lane == 0 ? 1 : 0);       // finished or suspended
     if (coop_ticket >= 0) {
         // suspended: the whole optimiser state goes to the slot; fit_coop_kernel resumes at this
         // line-search evaluation
