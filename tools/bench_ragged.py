@@ -19,7 +19,9 @@ for growth, mode in (('linear', 'additive'), ('logistic', 'multiplicative')):
     off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     dsr = np.concatenate([ds[:c] for c in lens])
     yr = np.concatenate([y[i][:c] for i, c in enumerate(lens)])
-    spec = fc.ModelSpec(growth=growth, seasonality_mode=mode,
+    # RK=wave: the one-wave residual kernel without the cooperative tail (for A/B runs)
+    rk = {'wave': _lib.RK_WAVE, 'coop': _lib.RK_COOP}.get(os.environ.get('RK', ''), _lib.RK_AUTO)
+    spec = fc.ModelSpec(growth=growth, seasonality_mode=mode, residual_kernel=rk,
                         seasonalities=[{'name': 'yearly', 'period': 365.25, 'fourier_order': 10},
                                        {'name': 'weekly', 'period': 7, 'fourier_order': 3}])
     cap = np.array([y[i][:c].max() * 1.1 for i, c in enumerate(lens)])
@@ -32,7 +34,7 @@ for growth, mode in (('linear', 'additive'), ('logistic', 'multiplicative')):
         r = fc.fit_ragged(spec, off, dsr, yr, floor=np.zeros(N), cap=cap)
         ctx.check(L.tsf_last_fit_kernel_ms(ctx.handle, ctypes.byref(ms)))
         out.append(float(ms.value))
-    print(json.dumps({'panel': 'ragged 10000 series, 640..730 rows', 'growth': growth, 'mode': mode,
+    print(json.dumps({'panel': 'ragged 10000 series, 640..730 rows', 'growth': growth, 'mode': mode, 'residual_kernel': os.environ.get('RK', 'auto'),
                       'fit_kernel_ms': out, 'series_per_s_kernel': N / (min(out) * 1e-3),
                       'mean_evals': float(r.n_eval.mean()),
                       'status_ok': int((r.status > 0).sum())}), flush=True)
