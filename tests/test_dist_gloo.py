@@ -50,3 +50,58 @@ def test_two_rank_sharding_and_gather():
         assert r[3] == 2.0                       # max over ranks of (1 + rank)
         assert r[4] == n_items
         assert np.array_equal(r[5][:, 0], np.arange(n_items)) and np.array_equal(r[5][:, 1], 2.0 * np.arange(n_items))
+
+
+def _fit_worker(rank, world, port, q):
+    """One rank of the sharded fit as bench.py --gpus N and forecaster.fit_aligned(devices=...) lay it out:
+    series i belongs to rank i mod world; every rank fits its share (here with the CPU oracle standing in
+    for the device -- the product has no CPU path), no collective touches the data, the results are gathered
+    and put back in series order."""
+    os.environ.update({'RANK': str(rank), 'WORLD_SIZE': str(world), 'LOCAL_RANK': str(rank),
+                       'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port)})
+    import torch.distributed as dist
+    from oracle import canon_lib as cl
+    from time_series_spark_amd import parallel, synth
+    from tests import helpers
+    r, w, _ = parallel.init_process_group(backend='gloo')
+    spec = helpers.make_case('short_90')[0]
+    ds, y = synth.make_panel(7, 90, 'linear', seed=5)
+    csp = helpers.oracle_spec(spec)
+    mine = np.arange(r, len(y), w)
+    rows = []
+    for n in mine:
+        o = cl.fit(csp, ds, y[n])
+        rows.append(np.concatenate([[n, o['n_eval'], o['f']], o['theta']]))
+    parallel.barrier()
+    allrows = parallel.gather_rows(np.array(rows))
+    q.put((r, allrows))
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_fit_equals_the_single_process_fit():
+    from oracle import canon_lib as cl
+    from time_series_spark_amd import synth
+    from tests import helpers
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fit_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    spec = helpers.make_case('short_90')[0]
+    ds, y = synth.make_panel(7, 90, 'linear', seed=5)
+    csp = helpers.oracle_spec(spec)
+    for _r, rows in res:                      # every rank holds the gathered result
+        assert rows.shape[0] == len(y)
+        # gathered in rank order = [0, 2, 4, 6, 1, 3, 5]: the series index travels with the row
+        assert list(rows[:, 0].astype(int)) == [0, 2, 4, 6, 1, 3, 5]
+        back = rows[np.argsort(rows[:, 0])]
+        for n in range(len(y)):
+            o = cl.fit(csp, ds, y[n])
+            assert back[n, 1] == o['n_eval'] and back[n, 2] == o['f']
+            assert np.array_equal(back[n, 3:], o['theta'])
