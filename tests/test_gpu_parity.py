@@ -228,6 +228,28 @@ def test_cooperative_tail_other_shapes(env):
         r_w = fc.fit_ragged(fc.ModelSpec(residual_kernel=_lib.RK_WAVE, **spec_kw), offs, dsr, yr, **fit_kw)
         for o in (dict(residual_kernel=_lib.RK_COOP), dict(coop_after=25)):
             same(fc.fit_ragged(fc.ModelSpec(**dict(spec_kw, **o)), offs, dsr, yr, **fit_kw), r_w, ('ragged', jitter, o))
+    # direct mode (every series on a workgroup from its initial values) with series that never reach the
+    # optimiser: constant y (fbprophet skips the fit), cap <= floor (fbprophet raises), too few rows
+    ds, y = synth.make_panel(5, 200, 'linear', seed=9)
+    y[1] = 7.0
+    lin = dict(growth='linear', seasonality_mode='multiplicative', seasonalities=[helpers.WEEKLY])
+    same(fc.fit_aligned(fc.ModelSpec(residual_kernel=_lib.RK_COOP, **lin), ds, y),
+         fc.fit_aligned(fc.ModelSpec(residual_kernel=_lib.RK_WAVE, **lin), ds, y), 'constant')
+    assert fc.fit_aligned(fc.ModelSpec(residual_kernel=_lib.RK_COOP, **lin), ds, y).status[1] == _lib.ST_CONSTANT
+    ds, y = synth.make_panel(4, 200, 'logistic', seed=10)
+    capb = y.max(axis=1) * 1.1
+    capb[2] = -1.0
+    lg = dict(growth='logistic', seasonality_mode='multiplicative', seasonalities=[helpers.WEEKLY])
+    r_c = fc.fit_aligned(fc.ModelSpec(residual_kernel=_lib.RK_COOP, **lg), ds, y, floor=np.zeros(4), cap=capb)
+    same(r_c, fc.fit_aligned(fc.ModelSpec(residual_kernel=_lib.RK_WAVE, **lg), ds, y, floor=np.zeros(4), cap=capb), 'cap')
+    assert r_c.status[2] == _lib.ST_CAP
+    offs = np.array([0, 200, 201, 401], dtype=np.int64)             # a one-row series in a ragged call
+    dsr = np.concatenate([ds, ds[:1], ds])
+    yr = np.concatenate([y[0], y[1][:1], y[3]])
+    fit_kw = dict(floor=np.zeros(3), cap=np.array([capb[0], capb[1], capb[3]]))
+    r_c = fc.fit_ragged(fc.ModelSpec(residual_kernel=_lib.RK_COOP, **lg), offs, dsr, yr, **fit_kw)
+    same(r_c, fc.fit_ragged(fc.ModelSpec(residual_kernel=_lib.RK_WAVE, **lg), offs, dsr, yr, **fit_kw), 'too few')
+    assert r_c.status[1] == _lib.ST_TOO_FEW
     # series longer than the cooperative kernel stages in LDS stay on the one-wave kernel (AUTO), and
     # asking for COOP there is an error
     ds, y = synth.make_panel(2, 4200, 'linear', seed=5)

@@ -842,18 +842,7 @@ __device__ __forceinline__ void coop_owner(const FitArgs &a, SeriesView &sv, int
             xk[s] = (p == 0) ? st.k0 : (p == 1 ? st.m0 : 0.0);
             gk[s] = 0.0; pk[s] = 0.0; xk1[s] = xk[s]; gk1[s] = 0.0; pk1[s] = 0.0;
         }
-        if (st.status0 != 0) {
-            // fbprophet raises (too few rows / cap <= floor) or skips optimisation (constant y)
-            if (st.status0 == TSF_ST_CONSTANT) {
-#pragma unroll
-                for (int s = 0; s < PPL; ++s) if (lane + s * W == 2) xk[s] = -20.72326583694641;
-            }
-            if (lane == 0) cl.cmd = COOP_EXIT;
-            lds_barrier();
-            store_theta<PPL>(a, sv, n, xk, a.theta);
-            if (lane == 0) { a.status[n] = st.status0; a.n_iter[n] = 0; a.n_eval[n] = 0; a.fval[n] = 0.0; }
-            return;
-        }
+        // (series that never reach the optimiser are reported by fit_coop_kernel itself: coop_report_unfitted)
         memset(&cv, 0, sizeof(cv));
         cv.alpha = a.opt.init_alpha; cv.gammak = 1.0;
     } else {
@@ -1103,6 +1092,27 @@ __device__ __forceinline__ void coop_owner(const FitArgs &a, SeriesView &sv, int
     CT_FLUSH(a.grad_out, n);
 }
 
+// direct mode: a series whose setup status says "no fit" (as fit_kernel reports it)
+template <int KP, int PPL>
+__device__ __forceinline__ void coop_report_unfitted(const FitArgs &a, const SeriesView &sv, int64_t n)
+{
+    const int lane = lane_id();
+    const SeriesTab st = a.stab[n];
+    if (lane == 0) {
+        a.y_scale[n] = st.y_scale;
+        if (!a.aligned || n == 0) a.grid_out[a.aligned ? 0 : n] = a.gtab[a.aligned ? 0 : n].info;
+    }
+    double xk[PPL];
+#pragma unroll
+    for (int s = 0; s < PPL; ++s) {
+        const int p = lane + s * W;
+        xk[s] = (p == 0) ? st.k0 : (p == 1 ? st.m0 : 0.0);
+        if (st.status0 == TSF_ST_CONSTANT && p == 2) xk[s] = -20.72326583694641;
+    }
+    store_theta<PPL>(a, sv, n, xk, a.theta);
+    if (lane == 0) { a.status[n] = st.status0; a.n_iter[n] = 0; a.n_eval[n] = 0; a.fval[n] = 0.0; }
+}
+
 // ---- the kernel: persistent workgroups over the checkpoint list ---------------------------------
 template <int KP, int GROWTH, int MODE, int PPL, int NW, bool XIDX>
 __global__ __launch_bounds__(NW * 64) void fit_coop_kernel(FitArgs a)
@@ -1130,6 +1140,12 @@ __global__ __launch_bounds__(NW * 64) void fit_coop_kernel(FitArgs a)
         const int64_t n = direct ? item : a.coop_list[item];
         SeriesView sv;
         make_view<KP, PPL>(a, n, sv);
+        if (direct && a.stab[n].status0 != 0) {
+            // never reaches the optimiser (fbprophet raises: too few rows / cap <= floor; or skips the fit:
+            // constant y): the owner reports it, nobody touches the series' tables (they may not exist)
+            if (wid == 0) coop_report_unfitted<KP, PPL>(a, sv, n);
+            continue;
+        }
         // rows [NT, COOP_NTB) of the row buffers: zeros (the straight-line chains of coop_helper_pf)
         if (sv.NT < COOP_NTB) {
             for (int i = sv.NT * W + (int)threadIdx.x; i < COOP_NTB * W; i += NW * W) { rbR[i] = 0.0; rbU[i] = 0.0; rbV[i] = 0.0; }
