@@ -194,6 +194,27 @@ def pmc_traffic(kernel):
         return None, 'unavailable: %s' % e
 
 
+def pmc_valu(kernel, kernel_ms, total_evals, n_cu):
+    """The bound that actually binds this kernel (not HBM): vector-instruction issue.  From the
+    same committed PMC passes (SQ_INSTS_VALU per launch): wave-instructions per evaluation, and the
+    fraction of the launch's issue slots they fill -- one fp64 wave-instruction occupies a SIMD for 4
+    cycles (16 lanes per cycle), 4 SIMDs per CU, at the MI355X peak engine clock of 2.4 GHz
+    (MI355X_MICROARCH.md), over the kernel time THIS run measured.  None when the profile is stale."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_latest.json')
+    try:
+        with open(path) as fh:
+            d = json.load(fh)
+        if d.get('kernel_sources_sha16') != kernel_sources_digest() or d.get('series_per_launch') != N_SERIES:
+            return None
+        insts = d['kernels'][kernel]['SQ_INSTS_VALU']
+        slots = n_cu * 4 * (kernel_ms * 1e-3 * 2.4e9) / 4.0
+        return {'valu_wave_insts_per_launch': insts, 'valu_wave_insts_per_evaluation': insts / float(total_evals),
+                'valu_issue_frac': insts / slots,
+                'note': 'SQ_INSTS_VALU of the committed rocprofv3 pass / (SIMDs x kernel cycles / 4 cycles per fp64 wave-instruction at 2.4 GHz)'}
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -344,6 +365,10 @@ def main():
                       'status_counts': {str(int(k)): int(v) for k, v in
                                         zip(*np.unique(status, return_counts=True))}},
     }
+    if world == 1:
+        v = pmc_valu(kernel, fit_ms, int(n_eval.sum()), torch.cuda.get_device_properties(local).multi_processor_count)
+        if v is not None:
+            res['roofline'].update(v)
     if weak is not None:
         res['weak_scaling'] = weak
     if world == 1:

@@ -27,14 +27,16 @@ for f in sorted(glob.glob(os.path.join(out, 'prof_*', '**', '*counter_collection
     per = defaultdict(lambda: defaultdict(float))
     with open(f) as fh:
         for row in csv.DictReader(fh):
-            if row['Counter_Name'] in ('FETCH_SIZE', 'WRITE_SIZE'):
+            if row['Counter_Name'] in ('FETCH_SIZE', 'WRITE_SIZE', 'SQ_INSTS_VALU', 'SQ_ACTIVE_INST_VALU',
+                                       'SQ_BUSY_CYCLES', 'SQ_WAVE_CYCLES', 'SQ_WAIT_INST_ANY'):
                 k = row['Kernel_Name'].split('(')[0]
                 for short in ('fit_quad_kernel', 'fit_kernel'):
                     if short in k and 'gram' not in k:
                         per[(short, row['Counter_Name'])][row['Dispatch_Id']] += float(row['Counter_Value'])
                         break
     for (k, c), d in per.items():
-        want.setdefault(k, {})[c + '_KiB'] = sum(d.values()) / len(d)
+        # HBM counters are in KiB; the SQ counters are plain counts (summed over the shader engines)
+        want.setdefault(k, {})[c + ('_KiB' if c in ('FETCH_SIZE', 'WRITE_SIZE') else '')] = sum(d.values()) / len(d)
 if want:
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
