@@ -307,7 +307,10 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
     const int S = sv.S, NT = sv.NT, T = sv.T;
     const int Ka = (MODE == 0) ? KP : (MODE == 1 ? 0 : sp->Ka);
     // design row + coefficients held in registers / SGPRs where they fit
-    constexpr bool HOLD = KP <= 32;
+#ifndef TSF_FIT_HOLD_MAX
+#define TSF_FIT_HOLD_MAX 32     // (dev: -DTSF_FIT_HOLD_MAX=0 streams every design row twice instead of holding it)
+#endif
+    constexpr bool HOLD = KP <= TSF_FIT_HOLD_MAX;
     sv.n_eval++;
     const double k = theta_at<PPL>(th, 0), m = theta_at<PPL>(th, 1), ls = theta_at<PPL>(th, 2);
     const double sigma = dm_exp_sel(ls);
