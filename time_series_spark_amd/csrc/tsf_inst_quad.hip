@@ -27,6 +27,45 @@ static int launch_quad_ragged_lds(const QuadPlan &qp, const QuadArgs &qa, hipStr
     return (int)hipGetLastError();
 }
 
+// ragged panel, Z^T Z of the running series in the wave's registers (QM_RAGGED_REG): 8 waves per
+// workgroup (two per SIMD, 256 registers each), history ring and residual staging in LDS; -2 when the
+// staging does not fit (long series)
+template <int KP, int PQ>
+static int launch_quad_ragged_reg(const QuadPlan &qp, const QuadArgs &qa, hipStream_t st)
+{
+    constexpr int NWR = 8;
+    if (qp.P4 != PQ) return -2;
+    const size_t lds = (quad_lanec_bytes<1>() + sizeof(QuadLds<KP, 1>) + quad_hist_bytes<1>(true) +
+                        sizeof(double) * (size_t)qa.f.NTmax * W) * NWR;
+    if (lds > 160 * 1024) return -2;
+    if (sizeof(double) * (size_t)qa.f.NTmax * W < sizeof(GramX)) return -2;   // the Gram build borrows the staging rows
+    hipFuncSetAttribute((const void *)fit_quad_kernel<KP, 1, NWR, QM_RAGGED_REG, PQ, true, true>,
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    int64_t blocks = qp.n_cu;       // one workgroup per CU
+    const int64_t need = (qa.f.N + NWR - 1) / NWR;
+    if (blocks > need) blocks = need;
+#ifdef TSF_QUAD_TIMING      // dev build: per-phase cycle counts (s_memtime), mean per series
+    {
+        QuadArgs qb = qa;
+        const size_t nb = sizeof(long long) * 8 * (size_t)qa.f.N;
+        hipMalloc((void **)&qb.dbg, nb);
+        hipMemsetAsync(qb.dbg, 0, nb, st);
+        hipLaunchKernelGGL((fit_quad_kernel<KP, 1, NWR, QM_RAGGED_REG, PQ, true, true>), dim3((unsigned)blocks), dim3(NWR * 64), lds, st, qb);
+        hipStreamSynchronize(st);
+        std::vector<long long> h(8 * (size_t)qa.f.N);
+        hipMemcpy(h.data(), qb.dbg, nb, hipMemcpyDeviceToHost);
+        double sum[8] = {0};
+        for (int64_t i = 0; i < qa.f.N; ++i) for (int k = 0; k < 8; ++k) sum[k] += (double)h[i * 8 + k];
+        fprintf(stderr, "[quad-timing ragged-reg] N %lld mean cycles/series: misc %.0f post %.0f ls %.0f resid %.0f eval %.0f gram-build %.0f | total %.0f\n",
+                (long long)qa.f.N, sum[0] / qa.f.N, sum[1] / qa.f.N, sum[2] / qa.f.N, sum[3] / qa.f.N, sum[4] / qa.f.N, sum[5] / qa.f.N, sum[7] / qa.f.N);
+        hipFree(qb.dbg);
+        return (int)hipGetLastError();
+    }
+#endif
+    hipLaunchKernelGGL((fit_quad_kernel<KP, 1, NWR, QM_RAGGED_REG, PQ, true, true>), dim3((unsigned)blocks), dim3(NWR * 64), lds, st, qa);
+    return (int)hipGetLastError();
+}
+
 // aligned panels share one M (in LDS when it fits: the one-slot kernels); ragged panels build one
 // per series
 template <int KP, int PPL, int PQ>
@@ -34,7 +73,9 @@ static int launch_quad_one(const QuadPlan &qp, const QuadArgs &qa, double *Mg, h
 {
     if (!qa.f.aligned) {
         if constexpr (PPL == 1 && PQ > 0) {
-            const int rc = launch_quad_ragged_lds<KP, PQ>(qp, qa, st);
+            int rc = launch_quad_ragged_reg<KP, PQ>(qp, qa, st);
+            if (rc != -2) return rc;
+            rc = launch_quad_ragged_lds<KP, PQ>(qp, qa, st);
             if (rc != -2) return rc;
         }
         return launch_quad_mm<KP, PPL, QM_RAGGED, PQ>(qp, qa, Mg, st);

@@ -106,7 +106,7 @@ __device__ __forceinline__ void newton_one_quad(const QuadArgs &qa, NewtonQuadLd
                 wave_sync();
             }
         } else {
-            bad = gram_eval_q<PPL, 0>(sv, lk, Mp, qa.P4, x, lds.ref, lds.cvec, s0, fx, gx, q2, nullptr);
+            { const double no_mreg[1] = {0.0}; bad = gram_eval_q<PPL, 0>(sv, lk, Mp, qa.P4, x, lds.ref, lds.cvec, s0, fx, gx, q2, nullptr, no_mreg); }
         }
         bool finish_iter = false, moved = false;
         if (stage == S_INIT) {

@@ -330,12 +330,16 @@ __device__ __forceinline__ bool resid_eval_q(const SeriesView &sv, QuadLds<KP, P
 // prior-sum chains of assemble_q underneath the LDS reads and the four fma chains.
 // MRS: doubles between consecutive rows of Ml (64, or PQ for the compact per-wave copies of ragged
 // panels: lanes >= MRS then read finite entries of the next row, which only ever meet D = 0)
-template <int PPL, int PQ, int MRS = W, int MB_ = 16>
+// MREG: row p of M (= column p: M is symmetric) in PQ registers of lane p instead of LDS / global
+// memory -- the per-series Z^T Z of a ragged panel: 25 KB of LDS per wave allowed 4 waves per CU, 112
+// registers per lane allow 8, and the mat-vec loses its 56 LDS reads of M.  Same operands, same order.
+template <int PPL, int PQ, int MRS = W, int MB_ = 16, bool MREG = false>
 __device__ __forceinline__ bool gram_eval_q(const SeriesView &sv, const LaneConst<PPL> &lk,
                                             const double *Ml, int P4, const double (&th)[PPL],
                                             const double *ref_l, const double *cvec_l,
                                             double s0, double &f_out, double (&g)[PPL],
-                                            double &q2_out, double *dl)
+                                            double &q2_out, double *dl,
+                                            const double (&mreg)[(MREG && PQ > 0) ? PQ : 1])
 {
     double ref[PPL], cvec[PPL];
 #pragma unroll
@@ -362,7 +366,7 @@ __device__ __forceinline__ bool gram_eval_q(const SeriesView &sv, const LaneCons
         for (int q0 = 0; q0 < PQ; q0 += MB) {
             double m[MB];
 #pragma unroll
-            for (int u = 0; u < MB; ++u) if (q0 + u < PQ) m[u] = mp[(q0 + u) * MRS];
+            for (int u = 0; u < MB; ++u) if (q0 + u < PQ) m[u] = MREG ? mreg[(MREG && q0 + u < PQ) ? q0 + u : 0] : mp[(q0 + u) * MRS];
             double dq[MB];              // D_q for the whole wave: one broadcast LDS read each
 #pragma unroll
             for (int u = 0; u < MB; ++u) if (q0 + u < PQ) dq[u] = dl[q0 + u];
@@ -467,6 +471,90 @@ __device__ __forceinline__ void gram_column(const SeriesView &sv, QuadLds<KP, PP
     ztr_pass<KP, PPL>(sv, wl, rb, gen, sse, ztr);
 }
 
+// Two columns of M in ONE pass over the rows (ragged panels: every wave builds the Z^T Z of its own
+// series, and with the matrix in registers the build was HALF of a fit: 54 passes, each streaming the
+// whole design matrix and staging its weights).  The weights of both columns are generated per row from
+// the row's own values (no staging), every design value of the row is loaded once and feeds both
+// columns' 28 accumulators.  Entry by entry the chains are those of ztr_pass / column_group: same
+// operands, same order, same bits.  gx: the second column's trend tables.
+struct GramX { double tp1[NTAB], tp2[NTAB], tot1[W + 1], tot2[W + 1], accR[32]; };
+
+template <int KP>
+__device__ __forceinline__ void gram_columns2(const SeriesView &sv, QuadLds<KP, 1> &wl, GramX &gx,
+                                              int qa_, int qb_, double &za, double &zb)
+{
+    const int lane = lane_id();
+    const int S = sv.S;
+    auto zval = [&](int qq, int st, int c, double ti) -> double {
+        if (qq == 0) return ti;
+        if (qq == 1) return 1.0;
+        if (qq < 3 + S) return (c > qq - 3) ? ti - sv.t_change[qq - 3] : 0.0;
+        return sv.Xw[((size_t)st * KP + (qq - 3 - S)) * W + lane];
+    };
+    double acca[KP], accb[KP];
+#pragma unroll
+    for (int j = 0; j < KP; ++j) { acca[j] = 0.0; accb[j] = 0.0; }
+    double rt1a = 0.0, rt2a = 0.0, rt1b = 0.0, rt2b = 0.0;
+#pragma unroll 1
+    for (int q = sv.NT - 1; q >= 0; --q) {
+        const bool valid = q < sv.cnt;
+        const int idx = q * W + lane;
+        const unsigned cwv = valid ? (unsigned)sv.cw[idx] : 0u;
+        const int c = (int)(cwv & 0xffu), cprev = (int)(cwv >> 8);
+        const double ti = valid ? sv.tw[idx] : 0.0;
+        const double *xp = sv.Xw + (size_t)q * KP * W + lane;
+        double x[KP];
+#pragma unroll
+        for (int j = 0; j < KP; ++j) x[j] = xp[j * W];
+        double ra = zval(qa_, q, c, ti), rb_ = zval(qb_, q, c, ti);
+        if (!valid) { ra = 0.0; rb_ = 0.0; }
+        rt1a = __builtin_fma(ra, ti, rt1a); rt2a = rt2a + ra;
+        rt1b = __builtin_fma(rb_, ti, rt1b); rt2b = rt2b + rb_;
+        for (int j = cprev; j < c; ++j) { wl.tp1[j] = rt1a; wl.tp2[j] = rt2a; gx.tp1[j] = rt1b; gx.tp2[j] = rt2b; }
+#pragma unroll
+        for (int j = 0; j < KP; ++j) { acca[j] = __builtin_fma(x[j], ra, acca[j]); accb[j] = __builtin_fma(x[j], rb_, accb[j]); }
+    }
+    {
+        const double s1 = suffix_scan(rt1a), s2v = suffix_scan(rt2a);
+        wl.tot1[lane] = s1; wl.tot2[lane] = s2v;
+        const double s1b = suffix_scan(rt1b), s2b = suffix_scan(rt2b);
+        gx.tot1[lane] = s1b; gx.tot2[lane] = s2b;
+        if (lane == 0) { wl.tot1[W] = 0.0; wl.tot2[W] = 0.0; gx.tot1[W] = 0.0; gx.tot2[W] = 0.0; }
+    }
+    constexpr int G8 = (KP / 8) * 8;
+#pragma unroll
+    for (int g0 = 0; g0 < G8; g0 += 8) {
+        double ta[8], tb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { ta[u] = acca[g0 + u]; tb[u] = accb[g0 + u]; }
+        column_sums_g<8>(ta, wl.accR + g0);
+        column_sums_g<8>(tb, gx.accR + g0);
+    }
+    if (KP % 8 != 0) {
+        double ta[4], tb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { ta[u] = acca[(G8 + u) < KP ? G8 + u : 0]; tb[u] = accb[(G8 + u) < KP ? G8 + u : 0]; }
+        column_sums_g<4>(ta, wl.accR + G8);
+        column_sums_g<4>(tb, gx.accR + G8);
+    }
+    wave_sync();
+    {
+        const int p = lane;
+        double va = 0.0, vb = 0.0;
+        if (p == 0) { va = wl.tot1[0]; vb = gx.tot1[0]; }
+        else if (p == 1) { va = wl.tot2[0]; vb = gx.tot2[0]; }
+        else if (p >= 3 && p < 3 + S) {
+            const int j = p - 3, Lj = sv.Ljp_l[0];
+            va = (wl.tp1[j] + wl.tot1[Lj + 1]) - sv.tcp_l[0] * (wl.tp2[j] + wl.tot2[Lj + 1]);
+            vb = (gx.tp1[j] + gx.tot1[Lj + 1]) - sv.tcp_l[0] * (gx.tp2[j] + gx.tot2[Lj + 1]);
+        } else if (p >= 3 + S && p < sv.P) {
+            va = wl.accR[p - 3 - S]; vb = gx.accR[p - 3 - S];
+        }
+        za = va; zb = vb;
+    }
+    wave_sync();
+}
+
 template <int KP, int PPL>
 __global__ __launch_bounds__(64) void gram_build_kernel(QuadArgs qa, double *Mout)
 {
@@ -504,10 +592,10 @@ __global__ __launch_bounds__(64) void gram_build_kernel(QuadArgs qa, double *Mou
 // HLDS: the L-BFGS history lives in the wave's LDS ring `hist` ([2][QH][PPL][64]: s then y, slot of
 // age h = (h0 + h) mod QH) instead of 4 QH PPL registers per lane -- what lets a third wave per
 // SIMD fit the register file (tsf_inst_quad.hip); same values, same operation order.
-template <int KP, int PPL, int PQ, bool RAGGED, int MRS = W, bool HLDS = false, int MBATCH = 16>
+template <int KP, int PPL, int PQ, bool RAGGED, int MRS = W, bool HLDS = false, int MBATCH = 16, bool MREG = false>
 __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL> &wl, double *rb,
                                           const double *Mp, double *Mown, int64_t n, double *lanec,
-                                          double *hist = nullptr)
+                                          double *hist = nullptr, GramX *gx = nullptr)
 {
     const FitArgs &a = qa.f;
     const DevSpec *sp = a.sp;
@@ -541,10 +629,31 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
     }
     LaneConst<PPL> lk;
     lane_consts<PPL>(sp, sv, lanec, lk);
+    QT_DECL;
     if (RAGGED) {
         // ragged panel: this series has its own grid, hence its own M = Z^T Z.  The wave builds
         // it column by column into its slot of global memory; lane p writes and later reads only
         // entries of its own row p, so no fence is needed.
+        if constexpr (MREG && PPL == 1) {
+            // two columns per pass (gram_columns2); rows 2 and >= P of M are zero
+            int qprev = -1;
+#pragma unroll 1
+            for (int q = 0; q < P4; ++q) {
+                const bool real = q != 2 && q < sv.P;
+                if (!real) { Mown[(size_t)q * W + lane] = 0.0; continue; }
+                if (qprev < 0) { qprev = q; continue; }
+                double za, zb;
+                gram_columns2<KP>(sv, wl, *gx, qprev, q, za, zb);
+                Mown[(size_t)qprev * W + lane] = za;
+                Mown[(size_t)q * W + lane] = zb;
+                qprev = -1;
+            }
+            if (qprev >= 0) {           // an odd column left over
+                double za, zb;
+                gram_columns2<KP>(sv, wl, *gx, qprev, qprev, za, zb);
+                Mown[(size_t)qprev * W + lane] = za;
+            }
+        } else {
 #pragma unroll 1
         for (int q = 0; q < P4; ++q) {
             double col[PPL];
@@ -558,7 +667,19 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
                 Mown[(size_t)q * MRS + lane] = col[0];
             }
         }
+        }
         Mp = Mown;
+        QT_LAP(5);
+    }
+    // MREG: the matrix just built goes from its global slot into registers (lane p: row p; the lane
+    // reads back what it wrote itself)
+    double mreg[(MREG && PQ > 0) ? PQ : 1];
+    if constexpr (MREG && PQ > 0) {
+        static_assert(!MREG || (RAGGED && MRS == W && PPL == 1), "register M: ragged one-slot kernels");
+#pragma unroll
+        for (int q = 0; q < PQ; ++q) mreg[q] = Mown[(size_t)q * W + lane];
+    } else {
+        mreg[0] = 0.0;
     }
 
     double s0 = 0.0, q2 = 0.0;
@@ -586,7 +707,6 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
     double gp = 0.0;
     bool gp_valid = false, pk1_scaled = false;
 
-    QT_DECL;
     const int eval_limit = 64 * a.opt.max_iter + 1024;      // guard, see cn_lbfgs (oracle)
     // Residual-form evaluation at xk (cn_resid_q): the initial point, and a re-centring of the
     // quadratic form at an accepted iterate.  When it is finite it becomes the reference point.
@@ -812,7 +932,7 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
                 for (int s = 0; s < PPL; ++s) { xk1[s] = __builtin_fma(alpha, pk[s], xk[s]); xe[s] = xk1[s]; }
                 sv.n_eval++;
                 QT_LAP(2);
-                const bool bad = gram_eval_q<PPL, PQ, MRS, MBATCH>(sv, lk, Mp, P4, xe, wl.ref, wl.cvec, s0, fe, ge, q2, wl.th);
+                const bool bad = gram_eval_q<PPL, PQ, MRS, MBATCH, MREG>(sv, lk, Mp, P4, xe, wl.ref, wl.cvec, s0, fe, ge, q2, wl.th, mreg);
                 QT_LAP(4);
 #pragma unroll
                 for (int s = 0; s < PPL; ++s) gk1[s] = ge[s];
@@ -885,7 +1005,8 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
 // 3 ragged panel, one M per resident wave in LDS (fewer waves per workgroup: an evaluation reads all
 // of M, and eight private 28 KB matrices per CU do not fit the 32 KB L1: from global memory the
 // ragged fit ran at the L2's pace, 5x the aligned time)
-enum { QM_LDS = 0, QM_GLOBAL = 1, QM_RAGGED = 2, QM_RAGGED_LDS = 3 };
+// 4 ragged panel, M of the running series in the wave's registers (built in its global slot first)
+enum { QM_LDS = 0, QM_GLOBAL = 1, QM_RAGGED = 2, QM_RAGGED_LDS = 3, QM_RAGGED_REG = 4 };
 
 template <int PPL>
 constexpr size_t quad_hist_bytes(bool hlds) { return hlds ? sizeof(double) * 2 * QH * PPL * W : 0; }
@@ -902,7 +1023,7 @@ __global__ __launch_bounds__(NW * 64, quad_waves_per_simd(quad_three_waves(MMODE
     //      [history ring x NW (HLDS)] [r staging x NW (RLDS)] [per-wave compact M (QM_RAGGED_LDS)]
     double *Ml = reinterpret_cast<double *>(smem);
     const size_t m_bytes = MLDS ? sizeof(double) * (size_t)P4 * PPL * W : 0;
-    constexpr bool RAGGED_K = MMODE == QM_RAGGED || MMODE == QM_RAGGED_LDS;
+    constexpr bool RAGGED_K = MMODE == QM_RAGGED || MMODE == QM_RAGGED_LDS || MMODE == QM_RAGGED_REG;
     constexpr size_t LCB = quad_lanec_bytes<PPL>();
     double *lanec = reinterpret_cast<double *>(smem + m_bytes + (RAGGED_K ? LCB * wid : 0));
     const size_t off_wl = m_bytes + LCB * (RAGGED_K ? NW : 1);
@@ -917,7 +1038,9 @@ __global__ __launch_bounds__(NW * 64, quad_waves_per_simd(quad_three_waves(MMODE
     double *hist = HLDS ? reinterpret_cast<double *>(smem + off_hist + HB * wid) : nullptr;
     const size_t off_rb = off_hist + HB * NW;
     const size_t rb_bytes = RLDS ? sizeof(double) * (size_t)NW * a.NTmax * W : 0;
-    double *Mown = (MMODE == QM_RAGGED) ? qa.Mslot + ((size_t)blockIdx.x * NW + wid) * (size_t)P4 * PPL * W
+    // QM_RAGGED_REG: the second column's tables of the two-columns-per-pass Gram build live in the wave's
+    // staging rows (idle during that build; the launcher checks that they are large enough)
+    double *Mown = (MMODE == QM_RAGGED || MMODE == QM_RAGGED_REG) ? qa.Mslot + ((size_t)blockIdx.x * NW + wid) * (size_t)P4 * PPL * W
                  : (MMODE == QM_RAGGED_LDS) ? reinterpret_cast<double *>(smem + off_rb + rb_bytes) +
                                                (size_t)wid * (PQ * PQ + W)
                                             : nullptr;
@@ -930,6 +1053,7 @@ __global__ __launch_bounds__(NW * 64, quad_waves_per_simd(quad_three_waves(MMODE
     // for NW x NTmax x 64 doubles, else in the global scratch (long series)
     double *rb = RLDS ? reinterpret_cast<double *>(smem + off_rb) + (size_t)wid * a.NTmax * W
                       : qa.rbuf + ((size_t)blockIdx.x * NW + wid) * a.NTmax * W;
+    GramX *gx = (MMODE == QM_RAGGED_REG && RLDS) ? reinterpret_cast<GramX *>(rb) : nullptr;
     for (int i = lane; i < PPL * W + W; i += W) wl.th[i] = 0.0;
     wave_sync();
 
@@ -942,8 +1066,8 @@ __global__ __launch_bounds__(NW * 64, quad_waves_per_simd(quad_three_waves(MMODE
         n32 = __builtin_amdgcn_readfirstlane(n32);
         const int64_t n = n32;
         if (n >= a.N) break;
-        fit_one_quad<KP, PPL, PQ, MMODE == QM_RAGGED || MMODE == QM_RAGGED_LDS, MRS, HLDS,
-                     (quad_three_waves(MMODE, PPL, HLDS) ? 8 : 16)>(qa, wl, rb, Mp, Mown, n, lanec, hist);
+        fit_one_quad<KP, PPL, PQ, RAGGED_K, MRS, HLDS,
+                     ((quad_three_waves(MMODE, PPL, HLDS) || MMODE == QM_RAGGED_REG) ? 8 : 16), MMODE == QM_RAGGED_REG>(qa, wl, rb, Mp, Mown, n, lanec, hist, gx);
     }
 }
 

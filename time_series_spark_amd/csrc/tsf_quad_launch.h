@@ -38,12 +38,12 @@ static int launch_quad_rl(const QuadPlan &qp, const QuadArgs &qa, double *Mg, hi
     int64_t blocks = qp.n_cu;                       // persistent: LDS admits one workgroup per CU
     if (blocks > (qa.f.N + NW - 1) / NW) blocks = (qa.f.N + NW - 1) / NW;
     if (blocks < 1) blocks = 1;
-    if (MMODE != QM_RAGGED) {       // aligned panel: one M for the whole call
+    if (MMODE != QM_RAGGED && MMODE != QM_RAGGED_REG) {       // aligned panel: one M for the whole call
         hipLaunchKernelGGL((gram_build_kernel<KP, PPL>), dim3((unsigned)qp.P4), dim3(64), 0, st, qa, Mg);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
     }
-    const size_t lds = (MLDS ? sizeof(double) * (size_t)qp.P4 * PPL * W : 0) + quad_lanec_bytes<PPL>() * (MMODE == QM_RAGGED ? NW : 1) +
+    const size_t lds = (MLDS ? sizeof(double) * (size_t)qp.P4 * PPL * W : 0) + quad_lanec_bytes<PPL>() * ((MMODE == QM_RAGGED || MMODE == QM_RAGGED_REG) ? NW : 1) +
                        (sizeof(QuadLds<KP, PPL>) + quad_hist_bytes<PPL>(HL)) * NW +
                        (RLDS ? sizeof(double) * (size_t)NW * qa.f.NTmax * W : 0);
     // per launch: the attribute is per device, and a process may drive several GPUs
@@ -78,7 +78,7 @@ static int launch_quad_mm(const QuadPlan &qp, const QuadArgs &qa, double *Mg, hi
 {
     constexpr int NW = QuadShape<PPL, MMODE>::NW;
     constexpr bool HL = QuadShape<PPL, MMODE>::HL;
-    const size_t base = (MMODE == QM_LDS ? sizeof(double) * (size_t)qp.P4 * PPL * W : 0) + quad_lanec_bytes<PPL>() * (MMODE == QM_RAGGED ? NW : 1) +
+    const size_t base = (MMODE == QM_LDS ? sizeof(double) * (size_t)qp.P4 * PPL * W : 0) + quad_lanec_bytes<PPL>() * ((MMODE == QM_RAGGED || MMODE == QM_RAGGED_REG) ? NW : 1) +
                         (sizeof(QuadLds<KP, PPL>) + quad_hist_bytes<PPL>(HL)) * NW;
     const size_t rbytes = sizeof(double) * (size_t)NW * qa.f.NTmax * W;
     if (base + rbytes <= 160 * 1024) return launch_quad_rl<KP, PPL, MMODE, PQ, true>(qp, qa, Mg, st);
