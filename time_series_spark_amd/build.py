@@ -34,6 +34,7 @@ def _newest_header():
 
 # per-file flags (the reason is at the top of the file named)
 EXTRA = {'tsf_inst_quad3.hip': ['-mllvm', '-disable-machine-licm'],
+         'tsf_inst_quad4.hip': ['-mllvm', '-disable-machine-licm'],
          'tsf_inst_quad.hip': ['-mllvm', '-disable-machine-licm']}
 
 

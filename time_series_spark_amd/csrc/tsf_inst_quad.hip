@@ -80,7 +80,14 @@ static int launch_quad_one(const QuadPlan &qp, const QuadArgs &qa, double *Mg, h
         }
         return launch_quad_mm<KP, PPL, QM_RAGGED, PQ>(qp, qa, Mg, st);
     }
-    if constexpr (PPL == 1) return launch_quad_aligned1(KP, qp, qa, Mg, st);   // tsf_inst_quad3.hip
+    if constexpr (PPL == 1) {
+        static const bool use_reg = getenv("TSF_QUAD_REG") != nullptr;
+        if (use_reg) {
+            const int rc = launch_quad_aligned_reg(KP, qp, qa, Mg, st);      // tsf_inst_quad4.hip
+            if (rc != -2) return rc;
+        }
+        return launch_quad_aligned1(KP, qp, qa, Mg, st);   // tsf_inst_quad3.hip
+    }
     else return launch_quad_mm<KP, PPL, QM_GLOBAL, PQ>(qp, qa, Mg, st);
 }
 
@@ -122,6 +129,24 @@ static int launch_newton_quad_rg(const QuadPlan &qp, const QuadArgs &qa, double 
     int64_t blocks = (int64_t)per_cu * n_cu;
     if (blocks > qp.slots) blocks = qp.slots;         // one Z^T Z slot per resident block (ragged)
     if (blocks > qa.f.N) blocks = qa.f.N;
+#ifdef TSF_QUAD_TIMING      // dev build: per-phase cycle counts (s_memtime), mean per series
+    {
+        QuadArgs qb = qa;
+        const size_t nb = sizeof(long long) * 8 * (size_t)qa.f.N;
+        hipMalloc((void **)&qb.dbg, nb);
+        hipMemsetAsync(qb.dbg, 0, nb, st);
+        hipLaunchKernelGGL((newton_quad_kernel<KP, RAGGED>), dim3((unsigned)blocks), dim3(64), lds, st, qb, PM);
+        hipStreamSynchronize(st);
+        std::vector<long long> h(8 * (size_t)qa.f.N);
+        hipMemcpy(h.data(), qb.dbg, nb, hipMemcpyDeviceToHost);
+        double sum[8] = {0};
+        for (int64_t i = 0; i < qa.f.N; ++i) for (int k = 0; k < 8; ++k) sum[k] += (double)h[i * 8 + k];
+        fprintf(stderr, "[newton-timing] N %lld waves/CU %d mean cycles/series: resid %.0f fd %.0f symm %.0f eig %.0f proj %.0f halving %.0f rest %.0f | total %.0f\n",
+                (long long)qa.f.N, per_cu, sum[0] / qa.f.N, sum[1] / qa.f.N, sum[2] / qa.f.N, sum[3] / qa.f.N, sum[4] / qa.f.N, sum[5] / qa.f.N, sum[6] / qa.f.N, sum[7] / qa.f.N);
+        hipFree(qb.dbg);
+        return (int)hipGetLastError();
+    }
+#endif
     hipLaunchKernelGGL((newton_quad_kernel<KP, RAGGED>), dim3((unsigned)blocks), dim3(64), lds, st, qa, PM);
     return (int)hipGetLastError();
 }

@@ -12,6 +12,7 @@ int quad_waves_per_block(int PPL);
 // gram_build_kernel + fit_quad_kernel (tsf_inst_quad.hip)
 int launch_quad(int KP, const QuadPlan &qp, const QuadArgs &qa, double *Mg, hipStream_t st);
 int launch_quad_aligned1(int KP, const QuadPlan &qp, const QuadArgs &qa, double *Mg, hipStream_t st);
+int launch_quad_aligned_reg(int KP, const QuadPlan &qp, const QuadArgs &qa, double *Mg, hipStream_t st);   // -2: no such variant
 // gram_build_kernel + newton_quad_kernel (Stan's Newton, quadratic-form evaluations; tsf_inst_quad.hip)
 int launch_newton_quad(int KP, const QuadPlan &qp, const QuadArgs &qa, double *Mg, int PM, int n_cu, hipStream_t st);
 int launch_g0m0(int KP, const FitArgs &a, int eval_only, hipStream_t st);

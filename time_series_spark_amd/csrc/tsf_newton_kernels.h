@@ -43,8 +43,16 @@ __device__ __forceinline__ double ql_pythag(double a, double b)
     return absb * __builtin_sqrt(1.0 + r * r);
 }
 
-__device__ __forceinline__ double ql_lds(int n, int PM, double *Am, double *Vm, QlScratch &sc)
+#ifdef TSF_QUAD_TIMING
+#define QL_LAP(k) do { if (qlt) { const long long t_ = __builtin_readcyclecounter(); qlt[k] += t_ - qlt0; qlt0 = t_; } } while (0)
+#else
+#define QL_LAP(k) do { } while (0)
+#endif
+__device__ __forceinline__ double ql_lds(int n, int PM, double *Am, double *Vm, QlScratch &sc, long long *qlt = nullptr)
 {
+#ifdef TSF_QUAD_TIMING
+    long long qlt0 = __builtin_readcyclecounter();
+#endif
     const int lane = lane_id();
     sc.e[lane] = 0.0; sc.hh[lane] = 0.0;
     TSF_WAVE_SYNC();
@@ -66,19 +74,50 @@ __device__ __forceinline__ double ql_lds(int n, int PM, double *Am, double *Vm, 
         if (lane == l) Am[i * PM + l] = ul;
         TSF_WAVE_SYNC();
         double a = 0.0;                                     // p = A u / H, lane = row j
-        if (lane <= l)
-            for (int k = 0; k <= l; ++k) a = __builtin_fma(Am[lane * PM + k], Am[i * PM + k], a);
+        // (the k loops of this routine read LDS in batches of 8 / 4 ahead of the fma chain: rolled,
+        // every step of the chain waited for its own two LDS reads -- same operands, same order)
+        if (lane <= l) {
+            const double *rowp = Am + lane * PM, *up = Am + i * PM;
+            int k = 0;
+            for (; k + 8 <= l + 1; k += 8) {
+                double rv[8], uv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { rv[u] = rowp[k + u]; uv[u] = up[k + u]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a = __builtin_fma(rv[u], uv[u], a);
+            }
+            if (k + 4 <= l + 1) {
+                double rv[4], uv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { rv[u] = rowp[k + u]; uv[u] = up[k + u]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a = __builtin_fma(rv[u], uv[u], a);
+                k += 4;
+            }
+            for (; k <= l; ++k) a = __builtin_fma(rowp[k], up[k], a);
+        }
         const double pj = a / H;
         const double K = bfly_sum((lane <= l) ? uj * pj : 0.0) / (2.0 * H);
         const double qj = pj - K * uj;
         sc.q[lane] = qj;
         TSF_WAVE_SYNC();
-        if (lane <= l)                                      // A <- A - u q^T - q u^T
-            for (int k = 0; k <= l; ++k)
-                Am[lane * PM + k] = __builtin_fma(-qj, Am[i * PM + k], __builtin_fma(-uj, sc.q[k], Am[lane * PM + k]));
+        if (lane <= l) {                                    // A <- A - u q^T - q u^T
+            double *rowp = Am + lane * PM;
+            const double *up = Am + i * PM;
+            int k = 0;
+            for (; k + 4 <= l + 1; k += 4) {
+                double rv[4], uv[4], qv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { rv[u] = rowp[k + u]; uv[u] = up[k + u]; qv[u] = sc.q[k + u]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) rowp[k + u] = __builtin_fma(-qj, uv[u], __builtin_fma(-uj, qv[u], rv[u]));
+            }
+            for (; k <= l; ++k) rowp[k] = __builtin_fma(-qj, up[k], __builtin_fma(-uj, sc.q[k], rowp[k]));
+        }
         if (lane == 0) { sc.e[i] = beta; sc.hh[i] = H; }
         TSF_WAVE_SYNC();
     }
+    QL_LAP(0);
     if (lane == 0 && n > 1) sc.e[1] = Am[1 * PM + 0];
     if (lane < n) sc.d[lane] = Am[lane * PM + lane];
     TSF_WAVE_SYNC();
@@ -96,9 +135,27 @@ __device__ __forceinline__ double ql_lds(int n, int PM, double *Am, double *Vm, 
         const int l = i - 1;
         if (Hi != 0.0 && lane <= l) {
             double w = 0.0;
-            for (int k = 0; k <= l; ++k) w = __builtin_fma(Am[i * PM + k], Vm[k * PM + lane], w);
+            const double *up = Am + i * PM;
+            double *colp = Vm + lane;
+            int k = 0;
+            for (; k + 8 <= l + 1; k += 8) {
+                double uv[8], vv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { uv[u] = up[k + u]; vv[u] = colp[(k + u) * PM]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) w = __builtin_fma(uv[u], vv[u], w);
+            }
+            for (; k <= l; ++k) w = __builtin_fma(up[k], colp[k * PM], w);
             w = w / Hi;
-            for (int r = 0; r <= l; ++r) Vm[r * PM + lane] = __builtin_fma(-Am[i * PM + r], w, Vm[r * PM + lane]);
+            int r = 0;
+            for (; r + 4 <= l + 1; r += 4) {
+                double uv[4], vv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { uv[u] = up[r + u]; vv[u] = colp[(r + u) * PM]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) colp[(r + u) * PM] = __builtin_fma(-uv[u], w, vv[u]);
+            }
+            for (; r <= l; ++r) colp[r * PM] = __builtin_fma(-up[r], w, colp[r * PM]);
         }
         TSF_WAVE_SYNC();
         if (lane <= i) { Vm[i * PM + lane] = (lane == i) ? 1.0 : 0.0; Vm[lane * PM + i] = (lane == i) ? 1.0 : 0.0; }
@@ -111,6 +168,7 @@ __device__ __forceinline__ double ql_lds(int n, int PM, double *Am, double *Vm, 
     // n dependent LDS reads, and no LDS hand-off is left inside the chain (a lane only touches its
     // own row of V).  Same operations on the same operands as the oracle's sequential loops.
     TSF_WAVE_SYNC();
+    QL_LAP(1);
     double dv = (lane < n) ? sc.d[lane] : 0.0;
     double ev = (lane + 1 < n) ? sc.e[lane + 1] : 0.0;      // e shifted down by one, e[n-1] = 0
     for (int l = 0; l < n; ++l) {
@@ -129,8 +187,17 @@ __device__ __forceinline__ double ql_lds(int n, int PM, double *Am, double *Vm, 
             double s = 1.0, c = 1.0, p = 0.0;
             int i = m - 1;
             bool underflow = false;
+            // V: rotation i mixes columns i and i + 1 (lane = row).  Column i + 1 is the column i of
+            // the previous rotation: carried in a register (vcar) and stored once it is final; column
+            // i is read one rotation ahead (its address does not depend on the chain), so the chain
+            // never waits for LDS.
+            double *vrow = Vm + lane * PM;
+            double vcar = (lane < n) ? vrow[m] : 0.0;
+            double v0n = (lane < n) ? vrow[m - 1] : 0.0;
             for (; i >= l; --i) {
                 const double ei = readlane_f64(ev, i), di = readlane_f64(dv, i), di1 = readlane_f64(dv, i + 1);
+                const double v0 = v0n;
+                if (i > l && lane < n) v0n = vrow[i - 1];
                 double f = s * ei;
                 const double b = c * ei;
                 r = __builtin_sqrt(__builtin_fma(f, f, g * g));
@@ -148,18 +215,18 @@ __device__ __forceinline__ double ql_lds(int n, int PM, double *Am, double *Vm, 
                 if (lane == i + 1) dv = g + p;
                 g = c * r - b;
                 if (lane < n) {
-                    f = Vm[lane * PM + i + 1];
-                    const double v0 = Vm[lane * PM + i];
-                    Vm[lane * PM + i + 1] = __builtin_fma(s, v0, c * f);
-                    Vm[lane * PM + i] = __builtin_fma(c, v0, -(s * f));
+                    vrow[i + 1] = __builtin_fma(s, v0, c * vcar);
+                    vcar = __builtin_fma(c, v0, -(s * vcar));
                 }
             }
+            if (lane < n) vrow[i + 1] = vcar;       // i = l - 1 after a full sweep, or the rotation that underflowed
             if (underflow) continue;
             if (lane == l) { dv = dv - p; ev = g; }
             if (lane == m) ev = 0.0;
         }
     }
     TSF_WAVE_SYNC();
+    QL_LAP(2);
     return (lane < n) ? dv : 0.0;
 }
 

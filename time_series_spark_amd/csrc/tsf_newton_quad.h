@@ -87,6 +87,7 @@ __device__ __forceinline__ void newton_one_quad(const QuadArgs &qa, NewtonQuadLd
     }
     const int P = sv.P;
     const double epsilon = 1e-3, half_epsilon = 0.5 * epsilon;
+    QT_DECL;        // -DTSF_QUAD_TIMING: 0 residual passes, 1 finite differences, 2 A + A^T, 3 eigen-solver, 4 projection + step, 5 halving evaluations, 6 the rest
 
     enum { S_INIT = 0, S_F0, S_HALVE };
     int stage = S_INIT, ret = TSF_ST_MAXIT, it = 0, mI = 0, d = 0, pi = 0;
@@ -94,6 +95,7 @@ __device__ __forceinline__ void newton_one_quad(const QuadArgs &qa, NewtonQuadLd
     for (;;) {
         bool bad;
         sv.n_eval++;
+        QT_LAP(6);
         if (stage == S_INIT || stage == S_F0) {
             double sse_e, ztr_e[PPL];
             wl.th[W + lane] = 0.0;      // theta of a pass is zero beyond P (the region held the matrix)
@@ -105,8 +107,10 @@ __device__ __forceinline__ void newton_one_quad(const QuadArgs &qa, NewtonQuadLd
                 s0 = sse_e;
                 wave_sync();
             }
+            QT_LAP(6);
         } else {
             { const double no_mreg[1] = {0.0}; bad = gram_eval_q<PPL, 0>(sv, lk, Mp, qa.P4, x, lds.ref, lds.cvec, s0, fx, gx, q2, nullptr, no_mreg); }
+            QT_LAP(5);
         }
         bool finish_iter = false, moved = false;
         if (stage == S_INIT) {
@@ -137,8 +141,10 @@ __device__ __forceinline__ void newton_one_quad(const QuadArgs &qa, NewtonQuadLd
                 const double s2_0 = sigma0 * sigma0;
                 const double inv_s2_0 = 1.0 / s2_0;
                 bool fd_bad = false;
+                double mnext = Mp[lane];                    // column d + 1 of Z^T Z is fetched (L2) while d is worked on
                 for (d = 0; d < P; ++d) {
-                    const double mcol = (d == 2) ? 0.0 : Mp[(size_t)d * W + lane];
+                    const double mcol = (d == 2) ? 0.0 : mnext;
+                    if (d + 1 < P) mnext = Mp[(size_t)(d + 1) * W + lane];
                     const double cvd = readlane_f64(cvl, d);
                     double accd = 0.0;
 #pragma unroll
@@ -173,6 +179,7 @@ __device__ __forceinline__ void newton_one_quad(const QuadArgs &qa, NewtonQuadLd
             }
             // ---- H = A + A^T (in place; lane b owns the pairs (a, b), a < b, and its diagonal)
             wave_sync();
+            QT_LAP(6);
             for (int r = 0; r < P; ++r) {
                 double u = 0.0, v = 0.0;
                 const bool mine = lane < P && r <= lane;
@@ -182,7 +189,15 @@ __device__ __forceinline__ void newton_one_quad(const QuadArgs &qa, NewtonQuadLd
                 wave_sync();
             }
             // ---- make_negative_definite_and_solve
+            QT_LAP(6);
+#ifdef TSF_QUAD_TIMING      // temporary: the eigen-solver's three parts in slots 0..2 (0 Householder, 1 Q, 2 QL)
+            long long qlt[3] = {0, 0, 0};
+            const double lam = ql_lds(P, PM, Am, Vm, lds.ql, qlt);
+            qt_acc[0] += qlt[0]; qt_acc[1] += qlt[1]; qt_acc[2] += qlt[2];
+            qt_t0 = __builtin_readcyclecounter();
+#else
             const double lam = ql_lds(P, PM, Am, Vm, lds.ql);
+#endif
             double pa = 0.0;
             for (int i = 0; i < P; ++i) {
                 const double gi = -readlane_f64(g[0], i);
@@ -197,6 +212,7 @@ __device__ __forceinline__ void newton_one_quad(const QuadArgs &qa, NewtonQuadLd
                 sa = __builtin_fma(vij, pj, sa);
             }
             step[0] = (lane < P) ? sa : 0.0;
+            QT_LAP(4);
             x[0] = th[0];
             size = 2.0; f1 = -1e100;
             stage = S_HALVE;
@@ -223,6 +239,8 @@ __device__ __forceinline__ void newton_one_quad(const QuadArgs &qa, NewtonQuadLd
     }
     store_theta<PPL>(a, sv, n, th, a.theta);
     if (lane == 0) { a.status[n] = ret; a.n_iter[n] = it; a.n_eval[n] = sv.n_eval; a.fval[n] = -lp; }
+    QT_LAP(6);
+    QT_FLUSH();
 }
 
 // persistent one-wave workgroups pulling series from a queue (the longest series needs ~7x the

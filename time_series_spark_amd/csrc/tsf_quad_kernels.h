@@ -675,9 +675,10 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
     // reads back what it wrote itself)
     double mreg[(MREG && PQ > 0) ? PQ : 1];
     if constexpr (MREG && PQ > 0) {
-        static_assert(!MREG || (RAGGED && MRS == W && PPL == 1), "register M: ragged one-slot kernels");
+        static_assert(!MREG || (MRS == W && PPL == 1), "register M: one-slot kernels");
+        const double *Msrc = RAGGED ? Mown : Mp;        // aligned panels: the call's one matrix
 #pragma unroll
-        for (int q = 0; q < PQ; ++q) mreg[q] = Mown[(size_t)q * W + lane];
+        for (int q = 0; q < PQ; ++q) mreg[q] = Msrc[(size_t)q * W + lane];
     } else {
         mreg[0] = 0.0;
     }
@@ -1006,7 +1007,7 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
 // of M, and eight private 28 KB matrices per CU do not fit the 32 KB L1: from global memory the
 // ragged fit ran at the L2's pace, 5x the aligned time)
 // 4 ragged panel, M of the running series in the wave's registers (built in its global slot first)
-enum { QM_LDS = 0, QM_GLOBAL = 1, QM_RAGGED = 2, QM_RAGGED_LDS = 3, QM_RAGGED_REG = 4 };
+enum { QM_LDS = 0, QM_GLOBAL = 1, QM_RAGGED = 2, QM_RAGGED_LDS = 3, QM_RAGGED_REG = 4, QM_GLOBAL_REG = 5 };
 
 template <int PPL>
 constexpr size_t quad_hist_bytes(bool hlds) { return hlds ? sizeof(double) * 2 * QH * PPL * W : 0; }
@@ -1067,7 +1068,8 @@ __global__ __launch_bounds__(NW * 64, quad_waves_per_simd(quad_three_waves(MMODE
         const int64_t n = n32;
         if (n >= a.N) break;
         fit_one_quad<KP, PPL, PQ, RAGGED_K, MRS, HLDS,
-                     ((quad_three_waves(MMODE, PPL, HLDS) || MMODE == QM_RAGGED_REG) ? 8 : 16), MMODE == QM_RAGGED_REG>(qa, wl, rb, Mp, Mown, n, lanec, hist, gx);
+                     ((quad_three_waves(MMODE, PPL, HLDS) || MMODE == QM_RAGGED_REG || MMODE == QM_GLOBAL_REG) ? 8 : 16),
+                     MMODE == QM_RAGGED_REG || MMODE == QM_GLOBAL_REG>(qa, wl, rb, Mp, Mown, n, lanec, hist, gx);
     }
 }
 
