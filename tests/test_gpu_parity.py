@@ -837,6 +837,38 @@ def test_full_size_cfg5_under_fbprophets_own_optimiser_rule(env):
         assert np.array_equal(yh[i], yo)
 
 
+def test_newton_several_series_per_wave_equals_one_series_per_wave(env):
+    """The Newton kernel for aligned linear/additive panels keeps several series per wave and runs their
+    QL rotation chains side by side, lane = series (tsf_newton_batch.h); calls with few series take the
+    one-series-per-wave kernel (tsf_newton_quad.h).  Same series, both routes -- and the route a slot
+    takes when its rotation list overflows (forced here with a 50-entry list) -- must give the same
+    bits, and those of the oracle."""
+    import os
+    fc, cl = env
+    from time_series_spark_amd import _lib, synth
+    N, T = 12000, 90
+    ds, y = synth.make_panel(N, T, 'linear', seed=99)
+    spec = fc.ModelSpec(growth='linear', seasonalities=fc.ModelSpec.auto_seasonalities(ds), algorithm=_lib.ALGO_NEWTON)
+    big = fc.fit_aligned(spec, ds, y)                    # >= 2 series per resident wave: slots
+    os.environ['TSF_NEWTON_LCAP'] = '50'
+    try:
+        over = fc.fit_aligned(spec, ds, y)               # every decomposition overflows its list
+    finally:
+        del os.environ['TSF_NEWTON_LCAP']
+    sub = np.arange(0, N, 37)[:300]
+    small = fc.fit_aligned(spec, ds, y[sub])             # one series per wave
+    for name in ('theta', 'fval', 'n_iter', 'n_eval', 'status'):
+        assert np.array_equal(getattr(big, name), getattr(over, name), equal_nan=True), name
+        assert np.array_equal(getattr(big, name)[sub], getattr(small, name), equal_nan=True), name
+    csp = helpers.oracle_spec(spec)
+    for n in (0, 5, int(np.argsort(big.n_eval)[-1])):
+        if big.n_eval[n] > 200000:
+            continue
+        o = cl.fit_newton(csp, ds, y[n])
+        assert (big.n_iter[n], big.n_eval[n], big.status[n]) == (o['n_iter'], o['n_eval'], o['status']), n
+        assert n_bit_diff(big.fval[n], o['f']) == 0 and n_bit_diff(big.theta[n], o['theta']) == 0, n
+
+
 def test_upstream_known_answer_vectors_through_predict_kernel(env):
     """fbprophet's own piecewise_linear / piecewise_logistic known-answer vectors
     (tests/golden/upstream_recall.json) through tsf_predict: scaled time = days, y_scale 1,

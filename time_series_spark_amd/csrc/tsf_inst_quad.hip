@@ -3,6 +3,7 @@
 // reason is at the top of that file: hoisted fp64 literals end up in scratch).
 #include "tsf_quad_launch.h"
 #include "tsf_newton_quad.h"
+#include "tsf_newton_batch.h"
 
 namespace tsf {
 
@@ -151,9 +152,75 @@ static int launch_newton_quad_rg(const QuadPlan &qp, const QuadArgs &qa, double 
     return (int)hipGetLastError();
 }
 
+// Aligned panels with enough series: several series per wave, the QL chains of a wave's slots run side by
+// side with lane = slot (tsf_newton_batch.h).  Slot records are stream-ordered scratch.  -2: not used.
+template <int KP>
+static int launch_newton_batch(const QuadPlan &qp, const QuadArgs &qa, double *Mg, int PM, int n_cu, hipStream_t st)
+{
+    static const bool off = getenv("TSF_NEWTON_BATCH") != nullptr && atoi(getenv("TSF_NEWTON_BATCH")) == 0;
+    if (off) return -2;
+    const size_t lds = newton_batch_lds_bytes<KP>(PM, qa.f.NTmax);
+    if (lds > 160 * 1024) return -2;
+    hipFuncSetAttribute((const void *)newton_batch_kernel<KP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    int per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, newton_batch_kernel<KP>, 64, lds) != hipSuccess || per_cu < 1)
+        per_cu = 1;
+    int64_t blocks = (int64_t)per_cu * n_cu;
+    if (qa.f.N < 2 * blocks) return -2;          // fewer than two series per wave: nothing to put side by side
+    NewtonBatchArgs nb;
+    nb.NS = (int)((qa.f.N + blocks - 1) / blocks);
+    if (nb.NS > NB_MAX_SLOTS) nb.NS = NB_MAX_SLOTS;
+    const int P = PM & ~1;      // PM = P | 1
+    nb.LCAP = nb_lcap(P > 0 ? P : 1);
+    if (const char *e = getenv("TSF_NEWTON_LCAP")) {       // tests: a list too short for any decomposition -> the in-wave chain
+        const int v = atoi(e);
+        if (v >= 1 && v < nb.LCAP) nb.LCAP = v;
+    }
+    nb.rec_stride = (nb_rec_doubles(PM, nb.LCAP) + 1) & ~1LL;
+    const size_t per_slot = sizeof(double) * (size_t)nb.rec_stride + sizeof(int) * (size_t)nb.LCAP;
+    while (nb.NS > 2 && per_slot * (size_t)blocks * nb.NS > ((size_t)6 << 30)) --nb.NS;      // at most 6 GB of records
+    const size_t rec_bytes = sizeof(double) * (size_t)nb.rec_stride * blocks * nb.NS;
+    const size_t idx_bytes = sizeof(int) * (size_t)nb.LCAP * blocks * nb.NS;
+    void *buf = nullptr;
+    if (hipMallocAsync(&buf, rec_bytes + idx_bytes, st) != hipSuccess) { (void)hipGetLastError(); return -2; }
+    nb.rec = (double *)buf;
+    nb.rot_idx = (int *)((char *)buf + rec_bytes);
+    hipLaunchKernelGGL((gram_build_kernel<KP, 1>), dim3((unsigned)qp.P4), dim3(64), 0, st, qa, Mg);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { hipFreeAsync(buf, st); return (int)e; }
+#ifdef TSF_QUAD_TIMING
+    {
+        QuadArgs qb = qa;
+        const size_t nbytes = sizeof(long long) * 9 * (size_t)blocks;
+        hipMalloc((void **)&qb.dbg, nbytes);
+        hipMemsetAsync(qb.dbg, 0, nbytes, st);
+        hipLaunchKernelGGL((newton_batch_kernel<KP>), dim3((unsigned)blocks), dim3(64), lds, st, qb, PM, nb);
+        hipStreamSynchronize(st);
+        std::vector<long long> h(9 * (size_t)blocks);
+        hipMemcpy(h.data(), qb.dbg, nbytes, hipMemcpyDeviceToHost);
+        double sum[9] = {0};
+        for (int64_t i = 0; i < blocks; ++i) for (int k = 0; k < 9; ++k) sum[k] += (double)h[i * 9 + k];
+        const double N = (double)qa.f.N;
+        fprintf(stderr, "[newton-batch-timing] N %lld waves/CU %d slots %d mean cycles/series: symm+tridiag+Q %.0f chain %.0f apply %.0f proj %.0f halving %.0f resid %.0f fd %.0f store %.0f | total %.0f\n",
+                (long long)qa.f.N, per_cu, nb.NS, sum[0] / N, sum[1] / N, sum[2] / N, sum[3] / N, sum[4] / N, sum[5] / N, sum[6] / N, sum[7] / N, sum[8] / N);
+        hipFree(qb.dbg);
+        hipFreeAsync(buf, st);
+        return (int)hipGetLastError();
+    }
+#endif
+    hipLaunchKernelGGL((newton_batch_kernel<KP>), dim3((unsigned)blocks), dim3(64), lds, st, qa, PM, nb);
+    e = hipGetLastError();
+    hipFreeAsync(buf, st);
+    return (int)e;
+}
+
 template <int KP>
 static int launch_newton_quad_one(const QuadPlan &qp, const QuadArgs &qa, double *Mg, int PM, int n_cu, hipStream_t st)
 {
+    if (qa.f.aligned) {
+        const int rc = launch_newton_batch<KP>(qp, qa, Mg, PM, n_cu, st);
+        if (rc != -2) return rc;
+    }
     if (qa.f.aligned) return launch_newton_quad_rg<KP, false>(qp, qa, Mg, PM, n_cu, st);
     return launch_newton_quad_rg<KP, true>(qp, qa, Mg, PM, n_cu, st);
 }

@@ -48,7 +48,8 @@ __device__ __forceinline__ double ql_pythag(double a, double b)
 #else
 #define QL_LAP(k) do { } while (0)
 #endif
-__device__ __forceinline__ double ql_lds(int n, int PM, double *Am, double *Vm, QlScratch &sc, long long *qlt = nullptr)
+// part 1: Householder tridiagonalisation + Q in place; leaves d in sc.d, e in sc.e (e[i] couples i-1 and i)
+__device__ __forceinline__ void ql_tridiag_q(int n, int PM, double *Am, double *Vm, QlScratch &sc, long long *qlt = nullptr)
 {
 #ifdef TSF_QUAD_TIMING
     long long qlt0 = __builtin_readcyclecounter();
@@ -161,6 +162,15 @@ __device__ __forceinline__ double ql_lds(int n, int PM, double *Am, double *Vm, 
         if (lane <= i) { Vm[i * PM + lane] = (lane == i) ? 1.0 : 0.0; Vm[lane * PM + i] = (lane == i) ? 1.0 : 0.0; }
         TSF_WAVE_SYNC();
     }
+}
+
+// part 2: implicit QL on (sc.d, sc.e), rotations applied to the columns of V
+__device__ __forceinline__ double ql_chain(int n, int PM, double *Vm, QlScratch &sc, long long *qlt = nullptr)
+{
+    const int lane = lane_id();
+#ifdef TSF_QUAD_TIMING
+    long long qlt0 = __builtin_readcyclecounter();
+#endif
     // ---- implicit QL on (d, e); rotations applied to the columns of V, lane = row k.
     // d and e live in REGISTERS here, entry j in lane j (n <= 64): the scalar rotation chain reads
     // them with v_readlane instead of waiting for an LDS round trip in every step, the search for
@@ -228,6 +238,12 @@ __device__ __forceinline__ double ql_lds(int n, int PM, double *Am, double *Vm, 
     TSF_WAVE_SYNC();
     QL_LAP(2);
     return (lane < n) ? dv : 0.0;
+}
+
+__device__ __forceinline__ double ql_lds(int n, int PM, double *Am, double *Vm, QlScratch &sc, long long *qlt = nullptr)
+{
+    ql_tridiag_q(n, PM, Am, Vm, sc, qlt);
+    return ql_chain(n, PM, Vm, sc, qlt);
 }
 
 // LDS of one Newton wave: the evaluation tables of eval_fg (no L-BFGS history), the QL scratch,

@@ -339,7 +339,8 @@ __device__ __forceinline__ bool gram_eval_q(const SeriesView &sv, const LaneCons
                                             const double *ref_l, const double *cvec_l,
                                             double s0, double &f_out, double (&g)[PPL],
                                             double &q2_out, double *dl,
-                                            const double (&mreg)[(MREG && PQ > 0) ? PQ : 1])
+                                            const double (&mreg)[(MREG && PQ > 0) ? PQ : 1],
+                                            int mstride = W)     // generic path (PQ == 0), PPL == 1: doubles between rows of Ml
 {
     double ref[PPL], cvec[PPL];
 #pragma unroll
@@ -386,7 +387,7 @@ __device__ __forceinline__ bool gram_eval_q(const SeriesView &sv, const LaneCons
 #pragma unroll
         for (int u = 0; u < 8; ++u)
 #pragma unroll
-            for (int s = 0; s < PPL; ++s) m[u][s] = mp[((q + u) * PPL + s) * W];
+            for (int s = 0; s < PPL; ++s) m[u][s] = mp[((q + u) * PPL + s) * (PPL == 1 ? mstride : W)];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const double Dq = readlane_f64(D[0], q + u);
@@ -400,7 +401,7 @@ __device__ __forceinline__ bool gram_eval_q(const SeriesView &sv, const LaneCons
             const double Dq = readlane_f64(D[0], q + u);
 #pragma unroll
             for (int s = 0; s < PPL; ++s)
-                a[s][u] = __builtin_fma(mp[((q + u) * PPL + s) * W], Dq, a[s][u]);
+                a[s][u] = __builtin_fma(mp[((q + u) * PPL + s) * (PPL == 1 ? mstride : W)], Dq, a[s][u]);
         }
     }
     if (PPL == 2) {
