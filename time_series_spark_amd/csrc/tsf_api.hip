@@ -30,6 +30,8 @@ struct tsf_ctx {
     void *ws;
     size_t ws_bytes;
     DevSpec *d_spec;
+    void *nb_ws;            // slot records of the several-series-per-wave Newton kernel (grown on demand)
+    size_t nb_ws_bytes;
     double *fut_tab;        // design table of a shared future grid (predict): [K][H]
     size_t fut_tab_bytes;
     int n_cu;               // compute units of the device (persistent kernels: one workgroup each)
@@ -71,6 +73,7 @@ extern "C" int tsf_create(int device_id, tsf_ctx **out)
     tsf_ctx *c = new tsf_ctx();
     c->device = device_id; c->ws = nullptr; c->ws_bytes = 0; c->d_spec = nullptr;
     c->fut_tab = nullptr; c->fut_tab_bytes = 0;
+    c->nb_ws = nullptr; c->nb_ws_bytes = 0;
     c->profiling = 0; c->ev_created = 0; c->ev_count = 0;
     if (hipMalloc((void **)&c->d_spec, sizeof(DevSpec)) != hipSuccess) { delete c; return -2; }
     {
@@ -101,6 +104,7 @@ extern "C" void tsf_destroy(tsf_ctx *ctx)
     if (ctx->ws) hipFree(ctx->ws);
     if (ctx->d_spec) hipFree(ctx->d_spec);
     if (ctx->fut_tab) hipFree(ctx->fut_tab);
+    if (ctx->nb_ws) hipFree(ctx->nb_ws);
     if (ctx->ev_created)
         for (int i = 0; i < TSF_PROFILE_RING; ++i) { hipEventDestroy(ctx->ev0[i]); hipEventDestroy(ctx->ev1[i]); }
     delete ctx;
@@ -473,6 +477,15 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
         qa.f = a; qa.Mg = (const double *)(ws + l.Mg); qa.Mslot = (double *)(ws + l.Mslot);
         qa.rbuf = (double *)(ws + l.rbuf);
         qa.counter = (int *)(ws + l.counter); qa.P4 = qp.P4;
+        if (aligned) {
+            const size_t need = newton_batch_scratch_bytes(hs.KP, fit_P(hs.n_cp, hs.K) | 1, N, NTmax, ctx->n_cu);
+            if (need > ctx->nb_ws_bytes) {
+                if (ctx->nb_ws) { HIP_TRY(ctx, hipFree(ctx->nb_ws)); ctx->nb_ws = nullptr; ctx->nb_ws_bytes = 0; }
+                if (hipMalloc(&ctx->nb_ws, need) == hipSuccess) ctx->nb_ws_bytes = need;
+                else { ctx->nb_ws = nullptr; (void)hipGetLastError(); }       // no room: the one-series-per-wave kernel
+            }
+            qa.nb_buf = ctx->nb_ws; qa.nb_bytes = ctx->nb_ws_bytes;
+        }
         HIP_TRY(ctx, hipMemsetAsync(qa.counter, 0, sizeof(int), st));
         lrc = launch_newton_quad(hs.KP, qp, qa, (double *)(ws + l.Mg), fit_P(hs.n_cp, hs.K) | 1, ctx->n_cu, st);
         // (-1: this shape does not fit the quadratic-form Newton kernel's LDS -- the residual-form kernel has no such limit)
@@ -485,7 +498,7 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
         qa.rbuf = (double *)(ws + l.rbuf);
         qa.counter = (int *)(ws + l.counter); qa.P4 = qp.P4;
         qa.recenter_every = spec->recenter_every; qa.recenter_ratio = spec->recenter_ratio;
-        qa.dbg = nullptr;
+        qa.dbg = nullptr; qa.nb_buf = nullptr; qa.nb_bytes = 0;
         HIP_TRY(ctx, hipMemsetAsync(qa.counter, 0, sizeof(int), st));
         lrc = launch_quad(hs.KP, qp, qa, (double *)(ws + l.Mg), st);
     } else if (mp.on) {

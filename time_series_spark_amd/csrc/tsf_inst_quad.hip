@@ -153,41 +153,76 @@ static int launch_newton_quad_rg(const QuadPlan &qp, const QuadArgs &qa, double 
 }
 
 // Aligned panels with enough series: several series per wave, the QL chains of a wave's slots run side by
-// side with lane = slot (tsf_newton_batch.h).  Slot records are stream-ordered scratch.  -2: not used.
+// side with lane = slot (tsf_newton_batch.h).  Shape of such a launch: waves, slots per wave, list capacity,
+// bytes of slot records (the caller provides them: QuadArgs::nb_buf).  false: this call does not take that kernel.
 template <int KP>
-static int launch_newton_batch(const QuadPlan &qp, const QuadArgs &qa, double *Mg, int PM, int n_cu, hipStream_t st)
+static bool newton_batch_shape(int PM, int64_t N, int NTmax, int n_cu, NewtonBatchArgs &nb, int64_t &blocks, size_t &lds,
+                               int &per_cu, size_t &rec_bytes, size_t &idx_bytes)
 {
     static const bool off = getenv("TSF_NEWTON_BATCH") != nullptr && atoi(getenv("TSF_NEWTON_BATCH")) == 0;
-    if (off) return -2;
-    const size_t lds = newton_batch_lds_bytes<KP>(PM, qa.f.NTmax);
-    if (lds > 160 * 1024) return -2;
+    if (off) return false;
+    lds = newton_batch_lds_bytes<KP>(PM, NTmax);
+    if (lds > 160 * 1024) return false;
     hipFuncSetAttribute((const void *)newton_batch_kernel<KP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    int per_cu = 1;
+    per_cu = 1;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, newton_batch_kernel<KP>, 64, lds) != hipSuccess || per_cu < 1)
         per_cu = 1;
-    int64_t blocks = (int64_t)per_cu * n_cu;
-    if (qa.f.N < 2 * blocks) return -2;          // fewer than two series per wave: nothing to put side by side
-    NewtonBatchArgs nb;
-    nb.NS = (int)((qa.f.N + blocks - 1) / blocks);
+    blocks = (int64_t)per_cu * n_cu;
+    if (N < 2 * blocks) return false;            // fewer than two series per wave: nothing to put side by side
+    nb.NS = (int)((N + blocks - 1) / blocks);
     if (nb.NS > NB_MAX_SLOTS) nb.NS = NB_MAX_SLOTS;
+    nb.flags = getenv("TSF_NEWTON_FLAGS") ? atoi(getenv("TSF_NEWTON_FLAGS")) : 0;
+    if (const char *e = getenv("TSF_NEWTON_NS")) { const int v = atoi(e); if (v >= 1 && v <= NB_MAX_SLOTS) nb.NS = v; }   // dev
     const int P = PM & ~1;      // PM = P | 1
     nb.LCAP = nb_lcap(P > 0 ? P : 1);
     if (const char *e = getenv("TSF_NEWTON_LCAP")) {       // tests: a list too short for any decomposition -> the in-wave chain
         const int v = atoi(e);
-        if (v >= 1 && v < nb.LCAP) nb.LCAP = v;
+        if (v >= 2 && v < nb.LCAP) nb.LCAP = v & ~1;
     }
     nb.rec_stride = (nb_rec_doubles(PM, nb.LCAP) + 1) & ~1LL;
     const size_t per_slot = sizeof(double) * (size_t)nb.rec_stride + sizeof(int) * (size_t)nb.LCAP;
     while (nb.NS > 2 && per_slot * (size_t)blocks * nb.NS > ((size_t)6 << 30)) --nb.NS;      // at most 6 GB of records
-    const size_t rec_bytes = sizeof(double) * (size_t)nb.rec_stride * blocks * nb.NS;
-    const size_t idx_bytes = sizeof(int) * (size_t)nb.LCAP * blocks * nb.NS;
-    void *buf = nullptr;
-    if (hipMallocAsync(&buf, rec_bytes + idx_bytes, st) != hipSuccess) { (void)hipGetLastError(); return -2; }
+    rec_bytes = sizeof(double) * (size_t)nb.rec_stride * blocks * nb.NS;
+    idx_bytes = sizeof(int) * (size_t)nb.LCAP * blocks * nb.NS;
+    return true;
+}
+
+size_t newton_batch_scratch_bytes(int KP, int PM, int64_t N, int NTmax, int n_cu)
+{
+    NewtonBatchArgs nb;
+    int64_t blocks = 0;
+    size_t lds = 0, rb = 0, ib = 0;
+    int per_cu = 0;
+    bool ok = false;
+    switch (KP) {
+    case 8: ok = newton_batch_shape<8>(PM, N, NTmax, n_cu, nb, blocks, lds, per_cu, rb, ib); break;
+    case 16: ok = newton_batch_shape<16>(PM, N, NTmax, n_cu, nb, blocks, lds, per_cu, rb, ib); break;
+    case 28: ok = newton_batch_shape<28>(PM, N, NTmax, n_cu, nb, blocks, lds, per_cu, rb, ib); break;
+    default: break;
+    }
+    return ok ? rb + ib : 0;
+}
+
+// -2: not used (the one-series-per-wave kernel takes the call)
+template <int KP>
+static int launch_newton_batch(const QuadPlan &qp, const QuadArgs &qa, double *Mg, int PM, int n_cu, hipStream_t st)
+{
+    NewtonBatchArgs nb;
+    int64_t blocks = 0;
+    size_t lds = 0, rec_bytes = 0, idx_bytes = 0;
+    int per_cu = 0;
+    if (!newton_batch_shape<KP>(PM, qa.f.N, qa.f.NTmax, n_cu, nb, blocks, lds, per_cu, rec_bytes, idx_bytes)) return -2;
+    // The records come from the caller's cached workspace, NOT from hipMallocAsync: with stream-ordered
+    // scratch of this size (gigabytes, above the pool's release threshold) fits went wrong intermittently
+    // after a large call on this ROCm (tools/dev/nb_debug.py; plain hipMalloc: never)
+    if (!qa.nb_buf || qa.nb_bytes < rec_bytes + idx_bytes) return -2;
+    void *buf = qa.nb_buf;
     nb.rec = (double *)buf;
     nb.rot_idx = (int *)((char *)buf + rec_bytes);
+    if (const char *e = getenv("TSF_NEWTON_FILL")) hipMemsetAsync(buf, atoi(e), rec_bytes + idx_bytes, st);   // dev: 255 = NaN everywhere
     hipLaunchKernelGGL((gram_build_kernel<KP, 1>), dim3((unsigned)qp.P4), dim3(64), 0, st, qa, Mg);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { hipFreeAsync(buf, st); return (int)e; }
+    if (e != hipSuccess) return (int)e;
 #ifdef TSF_QUAD_TIMING
     {
         QuadArgs qb = qa;
@@ -204,14 +239,11 @@ static int launch_newton_batch(const QuadPlan &qp, const QuadArgs &qa, double *M
         fprintf(stderr, "[newton-batch-timing] N %lld waves/CU %d slots %d mean cycles/series: symm+tridiag+Q %.0f chain %.0f apply %.0f proj %.0f halving %.0f resid %.0f fd %.0f store %.0f | total %.0f\n",
                 (long long)qa.f.N, per_cu, nb.NS, sum[0] / N, sum[1] / N, sum[2] / N, sum[3] / N, sum[4] / N, sum[5] / N, sum[6] / N, sum[7] / N, sum[8] / N);
         hipFree(qb.dbg);
-        hipFreeAsync(buf, st);
         return (int)hipGetLastError();
     }
 #endif
     hipLaunchKernelGGL((newton_batch_kernel<KP>), dim3((unsigned)blocks), dim3(64), lds, st, qa, PM, nb);
-    e = hipGetLastError();
-    hipFreeAsync(buf, st);
-    return (int)e;
+    return (int)hipGetLastError();
 }
 
 template <int KP>

@@ -15,6 +15,8 @@ int launch_quad_aligned1(int KP, const QuadPlan &qp, const QuadArgs &qa, double 
 int launch_quad_aligned_reg(int KP, const QuadPlan &qp, const QuadArgs &qa, double *Mg, hipStream_t st);   // -2: no such variant
 // gram_build_kernel + newton_quad_kernel (Stan's Newton, quadratic-form evaluations; tsf_inst_quad.hip)
 int launch_newton_quad(int KP, const QuadPlan &qp, const QuadArgs &qa, double *Mg, int PM, int n_cu, hipStream_t st);
+// bytes of slot records the several-series-per-wave Newton kernel needs for this call (QuadArgs::nb_buf); 0: not that kernel
+size_t newton_batch_scratch_bytes(int KP, int PM, int64_t N, int NTmax, int n_cu);
 int launch_g0m0(int KP, const FitArgs &a, int eval_only, hipStream_t st);
 int launch_g0m1(int KP, const FitArgs &a, int eval_only, hipStream_t st);
 int launch_g0m2(int KP, const FitArgs &a, int eval_only, hipStream_t st);

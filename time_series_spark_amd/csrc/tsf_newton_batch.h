@@ -31,22 +31,24 @@
 namespace tsf {
 
 #define NB_MAX_SLOTS 16
+#define NB_LONG_IT 256          // iterations after which a series counts as long (the mean is ~130)
 enum { NB_EMPTY = 0, NB_NEED_A = 1, NB_WAIT_CHAIN = 2, NB_HAVE_EIG = 3 };
 // slot record, in doubles
-enum { NB_LP = 0, NB_LASTLP, NB_F0, NB_S0, NB_IT, NB_MI, NB_NEVAL, NB_CNT, NB_SERIES, NB_OVER, NB_FRESH,
+enum { NB_LP = 0, NB_LASTLP, NB_F0, NB_S0, NB_IT, NB_MI, NB_NEVAL, NB_CNT, NB_SERIES, NB_OVER, NB_NSW,
        NB_TH = 16, NB_G = NB_TH + W, NB_REF = NB_G + W, NB_CVEC = NB_REF + W, NB_D = NB_CVEC + W,
        NB_E = NB_D + W, NB_LAM = NB_E + W, NB_V = NB_LAM + W };
 
 struct NewtonBatchArgs {
     double *rec;            // [blocks * NS][rec_stride]
-    int *rot_idx;           // [blocks * NS][LCAP]: column i of each recorded rotation
+    int *rot_idx;           // [blocks * NS][LCAP]: sweep headers (first column, rotations recorded), two ints per sweep
     long long rec_stride;   // doubles per slot record: NB_V + PM * PM + 2 * LCAP
     int NS, LCAP;
+    int flags;              // dev switches: 1 no hold, 2 Z^T Z of the halving trials from global memory
 };
 
 __host__ __device__ constexpr long long nb_rec_doubles(int PM, int LCAP)
 {
-    return (long long)NB_V + (long long)PM * PM + 2LL * LCAP;
+    return (((long long)NB_V + (long long)PM * PM + 1) & ~1LL) + 2LL * LCAP;        // (the list starts 16-byte aligned)
 }
 __host__ __device__ constexpr int nb_lcap(int P) { return 2 * P * P + 256; }
 
@@ -75,12 +77,12 @@ constexpr size_t newton_batch_lds_bytes(int PM, int NTmax)
 // eigenvalues need different numbers of sweeps do not wait for each other at every l; per lane the
 // sequence of operations is the same.
 __device__ __forceinline__ void ql_chain_slots(int n, double *dl, double *el, double *cs, int *ri, int LCAP,
-                                               int &cnt_out, bool &over_out)
+                                               int &cnt_out, int &nsw_out, bool &over_out)
 {
     const int lane = lane_id();
     double *d = dl + lane, *e = el + lane;
     constexpr int ST = NB_MAX_SLOTS;
-    int cnt = 0;
+    int cnt = 0, nsw = 0;
     bool over = false;
     int l = 0, guard = 0;
     while (l < n) {
@@ -108,6 +110,7 @@ __device__ __forceinline__ void ql_chain_slots(int n, double *dl, double *el, do
         // e[i - 1], d[i - 1] of the next rotation are read while this one computes
         double di1 = d[m * ST];
         double ei = e[i * ST], di = d[i * ST];
+        const int cnt0 = cnt;
         for (; i >= l; --i) {
             double ein = 0.0, din = 0.0;
             if (i > l) { ein = e[(i - 1) * ST]; din = d[(i - 1) * ST]; }
@@ -127,7 +130,7 @@ __device__ __forceinline__ void ql_chain_slots(int n, double *dl, double *el, do
             p = s * r;
             d[(i + 1) * ST] = g + p;
             g = c * r - b;
-            if (cnt < LCAP) { cs[2 * cnt] = c; cs[2 * cnt + 1] = s; ri[cnt] = i; }
+            if (cnt < LCAP) { cs[2 * cnt] = c; cs[2 * cnt + 1] = s; }
             else over = true;
             ++cnt;
             di1 = di; di = din; ei = ein;
@@ -137,79 +140,95 @@ __device__ __forceinline__ void ql_chain_slots(int n, double *dl, double *el, do
             e[l * ST] = g;
             e[m * ST] = 0.0;
         }
+        // the sweep's header: its first column (rotation k of the sweep mixes columns m-1-k and m-k) and
+        // how many rotations it recorded (an underflow ends a sweep early)
+        if (2 * nsw + 1 < LCAP) { ri[2 * nsw] = m - 1; ri[2 * nsw + 1] = cnt - cnt0; }
+        else over = true;
+        ++nsw;
         if (++guard == 60) { ++l; guard = 0; }
     }
     cnt_out = cnt;
+    nsw_out = nsw;
     over_out = over;
 }
 
-// recorded rotations applied to the columns of V (lane = row): what ql_chain does inside its sweeps --
-// within a sweep (consecutive columns, descending) the shared column is carried in a register; a new
-// sweep stores the carried column first.  The list is fetched 64 rotations at a time, one per lane
-// (coalesced), staged in LDS (stc, sts, sti: 64 entries each) and read back as broadcasts; the next 64
-// are in flight while these are applied.
-__device__ __forceinline__ void apply_rotations(int n, int PM, double *Vm, const double *cs, const int *ri, int cnt,
-                                                double *stc, double *sts, int *sti)
+// recorded rotations applied to the columns of V (lane = row): what ql_chain does inside its sweeps.
+// Within a sweep the columns descend one by one: the shared column is carried in a register and the
+// next four are read together ahead of the dependent chain.  Rotations (c, s pairs) and sweep headers are
+// fetched 64 at a time, one per lane (coalesced), staged in LDS (st_cs: 128 doubles, st_h: 128 ints) and
+// read back as broadcasts; the next 64 are in flight while these are applied.
+__device__ __forceinline__ void apply_sweeps(int n, int PM, double *Vm, const double *cs, const int *hdr, int cnt, int nsw,
+                                             double *st_cs, int *st_h)
 {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    typedef int i2 __attribute__((ext_vector_type(2)));
     const int lane = lane_id();
-    double *vrow = Vm + (lane < n ? lane : 0) * PM;
     const bool act = lane < n;
-    int prev = -2;
+    double *vrow = Vm + (act ? lane : 0) * PM;
+    const d2 *cs2 = reinterpret_cast<const d2 *>(cs);
+    const i2 *h2 = reinterpret_cast<const i2 *>(hdr);
+    d2 pc = {0.0, 0.0};
+    i2 ph = {0, 0};
+    if (lane < cnt) pc = cs2[lane];
+    if (lane < nsw) ph = h2[lane];
+    wave_sync();
+    reinterpret_cast<d2 *>(st_cs)[lane] = pc;
+    reinterpret_cast<i2 *>(st_h)[lane] = ph;
+    wave_sync();
+    int rb = 0, hb = 0;
+    if (W + lane < cnt) pc = cs2[W + lane];
+    if (W + lane < nsw) ph = h2[W + lane];
+    int r = 0, prevcol = -1;
     double vcar = 0.0;
-    double nc = 0.0, ns = 0.0;
-    int ni = 0;
-    if (lane < cnt) { nc = cs[2 * lane]; ns = cs[2 * lane + 1]; ni = ri[lane]; }
-    for (int base = 0; base < cnt; base += W) {
-        wave_sync();
-        stc[lane] = nc; sts[lane] = ns; sti[lane] = ni;
-        wave_sync();
-        if (base + W + lane < cnt) { nc = cs[2 * (base + W + lane)]; ns = cs[2 * (base + W + lane) + 1]; ni = ri[base + W + lane]; }
-        const int nb_ = (cnt - base < W) ? cnt - base : W;
-        if (act) {
-            int u = 0;
-            for (; u + 4 <= nb_; u += 4) {
-                double c4[4], s4[4];
-                int i4[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { c4[k] = stc[u + k]; s4[k] = sts[u + k]; i4[k] = sti[u + k]; }
-                const int i0 = i4[0];
-                if (i4[1] == i0 - 1 && i4[2] == i0 - 2 && i4[3] == i0 - 3) {
-                    // four rotations of one sweep: their columns i0-3 .. i0 have not been written in this
-                    // sweep yet, so they are read together, ahead of the dependent chain through vcar
-                    if (i0 != prev - 1) { if (prev >= 0) vrow[prev] = vcar; vcar = vrow[i0 + 1]; }
+    for (int sw = 0; sw < nsw; ++sw) {
+        if (sw >= hb + W) {
+            wave_sync();
+            reinterpret_cast<i2 *>(st_h)[lane] = ph;
+            wave_sync();
+            hb += W;
+            if (hb + W + lane < nsw) ph = h2[hb + W + lane];
+        }
+        const int i0 = __builtin_amdgcn_readfirstlane(st_h[2 * (sw - hb)]);
+        const int len = __builtin_amdgcn_readfirstlane(st_h[2 * (sw - hb) + 1]);
+        if (act) { if (prevcol >= 0) vrow[prevcol] = vcar; vcar = vrow[i0 + 1]; }
+        int k = 0;
+        while (k < len) {
+            if (r >= rb + W) {
+                wave_sync();
+                reinterpret_cast<d2 *>(st_cs)[lane] = pc;
+                wave_sync();
+                rb += W;
+                if (rb + W + lane < cnt) pc = cs2[rb + W + lane];
+            }
+            int chunk = len - k;
+            if (chunk > rb + W - r) chunk = rb + W - r;
+            if (act) {
+                const d2 *pcs = reinterpret_cast<const d2 *>(st_cs) + (r - rb);
+                double *col = vrow + (i0 - k);          // col[-u]: column of rotation k + u
+                int u = 0;
+                for (; u + 4 <= chunk; u += 4) {
                     double v4[4];
+                    d2 q4[4];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) v4[k] = vrow[i0 - k];
+                    for (int j = 0; j < 4; ++j) { v4[j] = col[-(u + j)]; q4[j] = pcs[u + j]; }
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        vrow[i0 - k + 1] = __builtin_fma(s4[k], v4[k], c4[k] * vcar);
-                        vcar = __builtin_fma(c4[k], v4[k], -(s4[k] * vcar));
-                    }
-                    prev = i0 - 3;
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int i = i4[k];
-                        if (i != prev - 1) { if (prev >= 0) vrow[prev] = vcar; vcar = vrow[i + 1]; }
-                        const double v0 = vrow[i];
-                        vrow[i + 1] = __builtin_fma(s4[k], v0, c4[k] * vcar);
-                        vcar = __builtin_fma(c4[k], v0, -(s4[k] * vcar));
-                        prev = i;
+                    for (int j = 0; j < 4; ++j) {
+                        col[-(u + j) + 1] = __builtin_fma(q4[j].y, v4[j], q4[j].x * vcar);
+                        vcar = __builtin_fma(q4[j].x, v4[j], -(q4[j].y * vcar));
                     }
                 }
+                for (; u < chunk; ++u) {
+                    const double v0 = col[-u];
+                    const d2 q = pcs[u];
+                    col[-u + 1] = __builtin_fma(q.y, v0, q.x * vcar);
+                    vcar = __builtin_fma(q.x, v0, -(q.y * vcar));
+                }
             }
-            for (; u < nb_; ++u) {
-                const int i = sti[u];
-                const double c = stc[u], s = sts[u];
-                if (i != prev - 1) { if (prev >= 0) vrow[prev] = vcar; vcar = vrow[i + 1]; }
-                const double v0 = vrow[i];
-                vrow[i + 1] = __builtin_fma(s, v0, c * vcar);
-                vcar = __builtin_fma(c, v0, -(s * vcar));
-                prev = i;
-            }
+            k += chunk; r += chunk;
         }
+        prevcol = i0 - len + 1;
     }
-    if (act && prev >= 0) vrow[prev] = vcar;
+    if (act && prevcol >= 0) vrow[prevcol] = vcar;
     wave_sync();
 }
 
@@ -244,13 +263,18 @@ __global__ __launch_bounds__(64, (KP <= 16 ? TSF_NEWTON_QUAD_WPS : 1)) void newt
     long long nbt0 = __builtin_readcyclecounter();
     const long long nbt_start = nbt0;
 #endif
-    bool queue_empty = false;
+    // A wave that holds a series far beyond the usual iteration count stops taking new series until its
+    // slots have drained: with NS series in flight a slot advances one iteration per NS slot-phases, and
+    // the longest series of a call (20 x the mean) would otherwise crawl for as long as the queue lasts
+    // and then keep the whole launch waiting.  Other waves take the queue meanwhile.
+    bool queue_empty = false, hold = false;
     for (;;) {
-        int n_wait = 0;
+        int n_wait = 0, n_busy = 0;
+        bool any_long = false;
         for (int s = 0; s < NS; ++s) {
             double *rec = nb.rec + ((size_t)blockIdx.x * NS + s) * nb.rec_stride;
             int *ridx = nb.rot_idx + ((size_t)blockIdx.x * NS + s) * nb.LCAP;
-            double *rcs = rec + NB_V + (size_t)PM * PM;
+            double *rcs = rec + (((size_t)NB_V + (size_t)PM * PM + 1) & ~(size_t)1);
             int stage = stage_l[s];
             // the slot's series, if it has one
             int64_t n = 0;
@@ -297,7 +321,7 @@ __global__ __launch_bounds__(64, (KP <= 16 ? TSF_NEWTON_QUAD_WPS : 1)) void newt
                     wave_sync();
                     lam = ql_chain(P, PM, Vm, lds.ql);
                 } else {
-                    apply_rotations(P, PM, Vm, rcs, ridx, cnt, lds.ql.d, lds.ql.e, reinterpret_cast<int *>(lds.ql.hh));
+                    apply_sweeps(P, PM, Vm, rcs, ridx, cnt, (int)rec[NB_NSW], lds.ql.d, reinterpret_cast<int *>(lds.ql.hh));
                     lam = rec[NB_LAM + lane];
                     wave_sync();
                 }
@@ -328,8 +352,12 @@ __global__ __launch_bounds__(64, (KP <= 16 ? TSF_NEWTON_QUAD_WPS : 1)) void newt
 #pragma unroll
                         for (int u = 0; u < 8; ++u) if (q0 + u < P && lane < PM) Am[(q0 + u) * PM + lane] = mrow[u];
                     }
-                    // rows P .. P4-1 of Z^T Z are zero: the generic mat-vec walks P4 rows
-                    for (int idx = P * PM + lane; idx < PM * PM; idx += W) Am[idx] = 0.0;
+                    // rows >= P of Z^T Z are zero, and the mat-vec walks whole groups of four rows with 64
+                    // lanes each: everything from row P to the end of the region is zeroed (the matrix's
+                    // last row, the rounding pad, stale scratch of a residual pass -- uninitialised LDS
+                    // may hold a NaN, and NaN x 0 is not 0); what follows the region is ref / cvec /
+                    // lanec, finite by construction
+                    for (int idx = P * PM + lane; idx < (int)(shared_bytes / sizeof(double)); idx += W) Am[idx] = 0.0;
                 }
                 wave_sync();
                 // Stan's `while (f1 < f0)` step-halving loop
@@ -344,7 +372,8 @@ __global__ __launch_bounds__(64, (KP <= 16 ? TSF_NEWTON_QUAD_WPS : 1)) void newt
                     x[0] = th[0] - size * stepv;
                     sv.n_eval++;
                     const double no_mreg[1] = {0.0};
-                    const bool bad = gram_eval_q<PPL, 0>(sv, lk, Am, P4h, x, lds.ref, lds.cvec, s0, fx, gx, q2, nullptr, no_mreg, PM);
+                    const bool bad = (nb.flags & 2) ? gram_eval_q<PPL, 0>(sv, lk, Mp, qa.P4, x, lds.ref, lds.cvec, s0, fx, gx, q2, nullptr, no_mreg)
+                                                    : gram_eval_q<PPL, 0>(sv, lk, Am, P4h, x, lds.ref, lds.cvec, s0, fx, gx, q2, nullptr, no_mreg, PM);
                     f1 = bad ? -1e100 : -fx;
                 }
                 NBT_LAP(4);
@@ -363,7 +392,7 @@ __global__ __launch_bounds__(64, (KP <= 16 ? TSF_NEWTON_QUAD_WPS : 1)) void newt
             }
             for (;;) {
             // ---------------- an empty slot takes the next series of the queue ----------------
-            while (stage == NB_EMPTY && !queue_empty) {
+            while (stage == NB_EMPTY && !queue_empty && !hold) {
                 int n32 = atomicAdd(qa.counter, lane == 0 ? 1 : 0);     // every lane takes part (see fit_quad_kernel)
                 n32 = __builtin_amdgcn_readfirstlane(n32);
                 if (n32 >= a.N) { queue_empty = true; break; }
@@ -498,9 +527,16 @@ __global__ __launch_bounds__(64, (KP <= 16 ? TSF_NEWTON_QUAD_WPS : 1)) void newt
             }
             }
             if (lane == 0) stage_l[s] = stage;
+            if (stage != NB_EMPTY) { ++n_busy; if (it >= NB_LONG_IT) any_long = true; }
             wave_sync();
         }
-        if (n_wait == 0) break;
+        if (any_long && !(nb.flags & 1)) hold = true;
+        if (n_busy == 0) {
+            if (queue_empty || !hold) break;    // (not holding: the slots found the queue empty)
+            hold = false;                       // drained: take series again
+            continue;
+        }
+        if (n_wait == 0) break;                 // (unreachable: a busy slot waits for its chain)
         // ---------------- the QL chains of every waiting slot, lane = slot ----------------
         __threadfence();        // the records written above are read below by other lanes
         const int P = 3 + a.gtab[0].S_fit + sp->K;      // one grid: every series of the panel has the same P
@@ -512,10 +548,11 @@ __global__ __launch_bounds__(64, (KP <= 16 ? TSF_NEWTON_QUAD_WPS : 1)) void newt
                     chd[j * NB_MAX_SLOTS + lane] = rec[NB_D + j];
                     che[j * NB_MAX_SLOTS + lane] = (j + 1 < P) ? rec[NB_E + j + 1] : 0.0;
                 }
-                int cnt = 0;
+                int cnt = 0, nsw = 0;
                 bool over = false;
-                ql_chain_slots(P, chd, che, rec + NB_V + (size_t)PM * PM,
-                               nb.rot_idx + ((size_t)blockIdx.x * NS + lane) * nb.LCAP, nb.LCAP, cnt, over);
+                ql_chain_slots(P, chd, che, rec + (((size_t)NB_V + (size_t)PM * PM + 1) & ~(size_t)1),
+                               nb.rot_idx + ((size_t)blockIdx.x * NS + lane) * nb.LCAP, nb.LCAP, cnt, nsw, over);
+                rec[NB_NSW] = (double)(over ? 0 : nsw);
                 for (int j = 0; j < P; ++j) rec[NB_LAM + j] = chd[j * NB_MAX_SLOTS + lane];
                 for (int j = P; j < W; ++j) rec[NB_LAM + j] = 0.0;
                 rec[NB_CNT] = (double)(over ? 0 : cnt);

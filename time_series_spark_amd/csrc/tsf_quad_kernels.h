@@ -51,6 +51,8 @@ struct QuadArgs {
     int recenter_every;
     double recenter_ratio;
     long long *dbg;                     // -DTSF_QUAD_TIMING builds only: [N][8] cycles per phase
+    void *nb_buf;                       // slot records of newton_batch_kernel (tsf_newton_batch.h), or null
+    size_t nb_bytes;
 };
 
 template <int KP, int PPL>
