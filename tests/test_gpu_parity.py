@@ -849,12 +849,14 @@ def test_newton_several_series_per_wave_equals_one_series_per_wave(env):
     N, T = 12000, 90
     ds, y = synth.make_panel(N, T, 'linear', seed=99)
     spec = fc.ModelSpec(growth='linear', seasonalities=fc.ModelSpec.auto_seasonalities(ds), algorithm=_lib.ALGO_NEWTON)
-    big = fc.fit_aligned(spec, ds, y)                    # >= 2 series per resident wave: slots
-    os.environ['TSF_NEWTON_LCAP'] = '50'
+    os.environ['TSF_NEWTON_BATCH'] = '2'                 # slots from two series per resident wave on (default: twelve)
     try:
+        big = fc.fit_aligned(spec, ds, y)
+        os.environ['TSF_NEWTON_LCAP'] = '50'
         over = fc.fit_aligned(spec, ds, y)               # every decomposition overflows its list
     finally:
-        del os.environ['TSF_NEWTON_LCAP']
+        os.environ.pop('TSF_NEWTON_LCAP', None)
+        del os.environ['TSF_NEWTON_BATCH']
     sub = np.arange(0, N, 37)[:300]
     small = fc.fit_aligned(spec, ds, y[sub])             # one series per wave
     for name in ('theta', 'fval', 'n_iter', 'n_eval', 'status'):

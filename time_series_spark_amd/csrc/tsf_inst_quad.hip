@@ -159,8 +159,13 @@ template <int KP>
 static bool newton_batch_shape(int PM, int64_t N, int NTmax, int n_cu, NewtonBatchArgs &nb, int64_t &blocks, size_t &lds,
                                int &per_cu, size_t &rec_bytes, size_t &idx_bytes)
 {
-    static const bool off = getenv("TSF_NEWTON_BATCH") != nullptr && atoi(getenv("TSF_NEWTON_BATCH")) == 0;
-    if (off) return false;
+    // TSF_NEWTON_BATCH: 0 never, 2 whenever there are two series per wave (tests); default: from twelve series per
+    // resident wave on -- measured on MI355X (profiles/r03_newton): 20 000 x 90 0.72 s here against 0.64 s on the
+    // one-series-per-wave kernel (few rounds, and the longest series advances one iteration per round of NS
+    // slots), 100 000: 3.16 against 3.69 s, 1 000 000: 15.1 against 26.0 s
+    const char *mode_env = getenv("TSF_NEWTON_BATCH");
+    const int mode = mode_env ? atoi(mode_env) : 1;
+    if (mode == 0) return false;
     lds = newton_batch_lds_bytes<KP>(PM, NTmax);
     if (lds > 160 * 1024) return false;
     hipFuncSetAttribute((const void *)newton_batch_kernel<KP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -168,7 +173,7 @@ static bool newton_batch_shape(int PM, int64_t N, int NTmax, int n_cu, NewtonBat
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, newton_batch_kernel<KP>, 64, lds) != hipSuccess || per_cu < 1)
         per_cu = 1;
     blocks = (int64_t)per_cu * n_cu;
-    if (N < 2 * blocks) return false;            // fewer than two series per wave: nothing to put side by side
+    if (N < (mode == 2 ? 2 : 12) * blocks) return false;
     nb.NS = (int)((N + blocks - 1) / blocks);
     if (nb.NS > NB_MAX_SLOTS) nb.NS = NB_MAX_SLOTS;
     nb.flags = getenv("TSF_NEWTON_FLAGS") ? atoi(getenv("TSF_NEWTON_FLAGS")) : 0;

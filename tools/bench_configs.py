@@ -111,16 +111,16 @@ def build(name):
         return ('50000 x 730 logistic + floor, multiplicative, 25 changepoints, 10 holidays x window [-1,+1]',
                 spec, ds, y, np.zeros(N), y.max(axis=1) * 1.1, extra, exf,
                 T * 8 + (3 + 25 + spec.K) * 8 + H * 8 + 8)
-    if name in ('cfg5', 'cfg5_newton'):
+    if name in ('cfg5', 'cfg5_newton', 'cfg5_newton_1m'):
         # cfg5_newton: the optimiser fbprophet itself picks for T = 90 (100x the work per series:
         # 100 000 series instead of 1 000 000 so that the run stays short)
-        N, T = (1000000 if name == 'cfg5' else 100000), 90
+        N, T = (100000 if name == 'cfg5_newton' else 1000000), 90      # cfg5_newton_1m: BASELINE's own size
         ds, y = synth.make_panel(N, T, 'linear', seed=751, dtype=np.float32)
         seas = fc.ModelSpec.auto_seasonalities(ds)
-        if name == 'cfg5_newton':
+        if name != 'cfg5':
             from time_series_spark_amd import _lib
             spec = fc.ModelSpec(growth='linear', seasonalities=seas, algorithm=_lib.ALGO_NEWTON)
-            return ('100000 x 90 fp32 y, linear additive, weekly only, Stan Newton (fbprophet\'s choice for T<100)',
+            return ('%d x 90 fp32 y, linear additive, weekly only, Stan Newton (fbprophet\'s choice for T<100)' % N,
                     spec, ds, y, None, None, None, None, T * 4 + (3 + 25 + spec.K) * 4 + H * 4)
         spec = fc.ModelSpec(growth='linear', seasonalities=seas)
         return ('1000000 x 90 fp32 y, linear additive, weekly only (L-BFGS; fbprophet would use Newton for T<100)',
