@@ -371,6 +371,35 @@ def main():
             res['roofline'].update(v)
     if weak is not None:
         res['weak_scaling'] = weak
+    if world == 1 and not args.timed_only:
+        # The strong-scaled run, rank by rank, on THIS GPU: `--gpus G` gives rank r the series r, r + G, ... of
+        # the one panel and there is no collective on the data path, so a G-GPU step lasts as long as its slowest
+        # rank -- and each rank's share can be timed here, one after the other (same step: fit + forecast).
+        # Not a multi-GPU measurement (no second device, no launch skew between processes), labelled so.
+        try:
+            rr = {}
+            for G in (2, 4, 8):
+                per_rank = []
+                for r in range(G):
+                    ys = torch.from_numpy(np.ascontiguousarray(y_full[r::G])).to(dev)
+                    o_ = f.alloc_fit_output(ys.shape[0])
+                    yh_ = torch.zeros((ys.shape[0], HORIZON), dtype=torch.float64, device=dev)
+                    yi_ = torch.zeros((ys.shape[0], HORIZON), dtype=torch.int32, device=dev)
+                    f.fit_aligned(ds, ys, o_); f.predict(o_, fut, yh_, yi_)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(3):
+                        f.fit_aligned(ds, ys, o_); f.predict(o_, fut, yh_, yi_)
+                    torch.cuda.synchronize()
+                    per_rank.append(1e3 * (time.perf_counter() - t0) / 3)
+                rr[str(G)] = {'ms_per_step_slowest_rank': max(per_rank), 'ms_per_step_ranks': [round(v, 3) for v in per_rank],
+                              'series_per_s': N_SERIES / (1e-3 * max(per_rank))}
+            res['strong_scaling_rank_by_rank_on_one_gpu'] = {
+                'label': 'each rank\'s share of the ONE %d-series panel timed on this GPU, one after the other; a G-GPU '
+                         'step = its slowest rank (no collective on the data path); not a multi-GPU measurement' % N_SERIES,
+                'gpus': rr}
+        except Exception as e:
+            res['strong_scaling_rank_by_rank_on_one_gpu'] = {'error': str(e)}
     if world == 1:
         try:
             res['strong_scaling_simulated'] = simulate_strong_scaling(n_eval, fit_ms, torch.cuda.get_device_properties(local).multi_processor_count)

@@ -837,6 +837,37 @@ def test_full_size_cfg5_under_fbprophets_own_optimiser_rule(env):
         assert np.array_equal(yh[i], yo)
 
 
+def test_quadratic_form_kernels_for_small_and_large_panels_give_the_same_bits(env):
+    """Aligned panels with P <= 64 have two quadratic-form kernels: Z^T Z in LDS at 12 waves per CU (large
+    panels: throughput) and Z^T Z in registers at 8 waves per CU (small panels: the launch is its longest
+    series, and the lone wave is faster).  The library picks by the number of series; both routes must give
+    the same bits, and those of the oracle."""
+    import os
+    fc, cl = env
+    from time_series_spark_amd import synth
+    N, T = 3000, 730
+    ds, y = synth.make_panel(N, T, 'linear', seed=31)
+    spec = fc.ModelSpec(growth='linear', seasonalities=fc.ModelSpec.auto_seasonalities(ds))
+    res = {}
+    for mode in ('0', '1', None):
+        if mode is None:
+            os.environ.pop('TSF_QUAD_REG', None)
+        else:
+            os.environ['TSF_QUAD_REG'] = mode
+        try:
+            res[mode] = fc.fit_aligned(spec, ds, y)
+        finally:
+            os.environ.pop('TSF_QUAD_REG', None)
+    for name in ('theta', 'fval', 'n_iter', 'n_eval', 'status'):
+        assert np.array_equal(getattr(res['0'], name), getattr(res['1'], name), equal_nan=True), name
+        assert np.array_equal(getattr(res['0'], name), getattr(res[None], name), equal_nan=True), name
+    csp = helpers.oracle_spec(spec)
+    for n in (0, int(np.argsort(res['1'].n_eval)[-1])):
+        o = cl.fit(csp, ds, y[n])
+        assert (res['1'].n_iter[n], res['1'].n_eval[n], res['1'].status[n]) == (o['n_iter'], o['n_eval'], o['status']), n
+        assert n_bit_diff(res['1'].theta[n], o['theta']) == 0 and n_bit_diff(res['1'].fval[n], o['f']) == 0, n
+
+
 def test_newton_several_series_per_wave_equals_one_series_per_wave(env):
     """The Newton kernel for aligned linear/additive panels keeps several series per wave and runs their
     QL rotation chains side by side, lane = series (tsf_newton_batch.h); calls with few series take the

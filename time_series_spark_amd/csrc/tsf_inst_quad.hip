@@ -82,9 +82,17 @@ static int launch_quad_one(const QuadPlan &qp, const QuadArgs &qa, double *Mg, h
         return launch_quad_mm<KP, PPL, QM_RAGGED, PQ>(qp, qa, Mg, st);
     }
     if constexpr (PPL == 1) {
-        static const bool use_reg = getenv("TSF_QUAD_REG") != nullptr;
+        // Two kernels for aligned panels with P <= 64.  Z^T Z in LDS, 12 waves per CU (tsf_inst_quad3.hip): the
+        // higher throughput.  Z^T Z in registers, 8 waves per CU (tsf_inst_quad4.hip): the faster lone wave (3.7
+        // against 4.5 M cycles per cfg2 series) and no staging traffic.  A launch with few series per wave slot is
+        // bound by its longest series, not by throughput -- measured (cfg2 model, ms per fit + forecast, LDS /
+        // registers): 1 250 series 3.99 / 3.31, 2 500: 4.74 / 4.55, 5 000: 6.79 / 6.66, 10 000: 9.36 / 9.85 -- so up
+        // to three series per slot of the register kernel it takes the call.  This is also what a rank of a
+        // strong-scaled 10 000-series panel sees (1 250 series on each of 8 GPUs).  TSF_QUAD_REG = 0 / 1 forces.
+        const char *e = getenv("TSF_QUAD_REG");
+        const bool use_reg = e ? atoi(e) != 0 : qa.f.N <= (int64_t)3 * 8 * qp.n_cu;
         if (use_reg) {
-            const int rc = launch_quad_aligned_reg(KP, qp, qa, Mg, st);      // tsf_inst_quad4.hip
+            const int rc = launch_quad_aligned_reg(KP, qp, qa, Mg, st);      // tsf_inst_quad4.hip (-2: no such variant)
             if (rc != -2) return rc;
         }
         return launch_quad_aligned1(KP, qp, qa, Mg, st);   // tsf_inst_quad3.hip
