@@ -868,6 +868,59 @@ def test_quadratic_form_kernels_for_small_and_large_panels_give_the_same_bits(en
         assert n_bit_diff(res['1'].theta[n], o['theta']) == 0 and n_bit_diff(res['1'].fval[n], o['f']) == 0, n
 
 
+def test_quadratic_form_kernel_routes_for_large_aligned_panels_give_the_same_bits(env):
+    """Aligned panels with P <= 64 and more than a few series per wave slot have three routes since round 3:
+    * 16 waves per CU (four per SIMD, <= 128 registers), the trend tables of a residual pass borrowed from a small
+      pool of shared LDS copies (tsf_quad_kernels.h QuadPool) -- what panels of >= 8 series per wave slot take;
+    * 12 waves per CU with the weights of a residual pass in the registers of the lane that produces and consumes
+      them (ztr_pass NTR) -- the default below that;
+    * 12 waves per CU with those weights staged through global memory (round 2's kernel; TSF_QUAD_RREG=0).
+    Same series through all of them, the pool also with ONE copy for sixteen waves (every pass of a workgroup
+    waits for the others: the lock under contention): identical bits, and those of the oracle incl. the longest
+    fit.  A short-series panel (T = 90: the staging rows ride in the pool slot) likewise."""
+    import os
+    fc, cl = env
+    from time_series_spark_amd import synth
+    N, T = 7000, 730                        # > 3 series per slot of the register-M kernel: the LDS kernels take the call
+    ds, y = synth.make_panel(N, T, 'linear', seed=77)
+    spec = fc.ModelSpec(growth='linear', seasonalities=fc.ModelSpec.auto_seasonalities(ds))
+    res = {}
+    legs = (('w4', {'TSF_QUAD_W4': '16'}), ('w4_one_copy', {'TSF_QUAD_W4': '1'}), ('w3_reg', {}),
+            ('w3_glob', {'TSF_QUAD_RREG': '0'}))
+    os.environ['TSF_QUAD_REG'] = '0'
+    try:
+        for tag, envs in legs:
+            os.environ.update(envs)
+            try:
+                res[tag] = fc.fit_aligned(spec, ds, y)
+            finally:
+                for k in envs:
+                    os.environ.pop(k, None)
+    finally:
+        os.environ.pop('TSF_QUAD_REG', None)
+    for tag, _ in legs[1:]:
+        for name in ('theta', 'fval', 'n_iter', 'n_eval', 'status'):
+            assert np.array_equal(getattr(res['w4'], name), getattr(res[tag], name), equal_nan=True), (tag, name)
+    csp = helpers.oracle_spec(spec)
+    r = res['w4']
+    for n in (0, 1, N - 1, int(np.argsort(r.n_eval)[-1])):
+        o = cl.fit(csp, ds, y[n])
+        assert (r.n_iter[n], r.n_eval[n], r.status[n]) == (o['n_iter'], o['n_eval'], o['status']), n
+        assert n_bit_diff(r.theta[n], o['theta']) == 0 and n_bit_diff(r.fval[n], o['f']) == 0, n
+    ds, y = synth.make_panel(4000, 90, 'linear', seed=78)
+    spec = fc.ModelSpec(growth='linear', seasonalities=fc.ModelSpec.auto_seasonalities(ds))
+    os.environ['TSF_QUAD_REG'] = '0'
+    try:
+        w3 = fc.fit_aligned(spec, ds, y)
+        os.environ['TSF_QUAD_W4'] = '16'
+        w4 = fc.fit_aligned(spec, ds, y)
+    finally:
+        os.environ.pop('TSF_QUAD_W4', None)
+        os.environ.pop('TSF_QUAD_REG', None)
+    for name in ('theta', 'fval', 'n_iter', 'n_eval', 'status'):
+        assert np.array_equal(getattr(w3, name), getattr(w4, name), equal_nan=True), name
+
+
 def test_newton_several_series_per_wave_equals_one_series_per_wave(env):
     """The Newton kernel for aligned linear/additive panels keeps several series per wave and runs their
     QL rotation chains side by side, lane = series (tsf_newton_batch.h); calls with few series take the

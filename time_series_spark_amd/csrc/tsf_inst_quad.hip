@@ -8,7 +8,8 @@
 namespace tsf {
 
 // the most waves per workgroup any variant for this PPL launches (workspace slots: tsf_api.hip quad_plan)
-int quad_waves_per_block(int PPL) { return PPL == 2 ? TSF_QUAD_NW2 : (TSF_QUAD_NW3 > TSF_QUAD_NW ? TSF_QUAD_NW3 : TSF_QUAD_NW); }
+int quad_waves_per_block(int PPL) { return PPL == 2 ? TSF_QUAD_NW2 : TSF_QUAD_NW4; }
+static_assert(TSF_QUAD_NW4 >= TSF_QUAD_NW3 && TSF_QUAD_NW4 >= TSF_QUAD_NW, "workspace slots are sized for the widest workgroup");
 
 // ragged panel, Z^T Z of every resident wave in LDS: NWR waves per workgroup (tsf_quad_kernels.h
 // QM_RAGGED_LDS); -2 when it does not fit (the caller falls back to M in global memory)
@@ -24,7 +25,7 @@ static int launch_quad_ragged_lds(const QuadPlan &qp, const QuadArgs &qa, hipStr
     int64_t blocks = qp.n_cu;       // one workgroup per CU
     const int64_t need = (qa.f.N + NWR - 1) / NWR;
     if (blocks > need) blocks = need;
-    hipLaunchKernelGGL((fit_quad_kernel<KP, 1, NWR, QM_RAGGED_LDS, PQ, true>), dim3((unsigned)blocks), dim3(NWR * 64), lds, st, qa);
+    hipLaunchKernelGGL((fit_quad_kernel<KP, 1, NWR, QM_RAGGED_LDS, PQ, true>), dim3((unsigned)blocks), dim3(NWR * 64), lds, st, qa, 0, 0);
     return (int)hipGetLastError();
 }
 
@@ -51,7 +52,7 @@ static int launch_quad_ragged_reg(const QuadPlan &qp, const QuadArgs &qa, hipStr
         const size_t nb = sizeof(long long) * 8 * (size_t)qa.f.N;
         hipMalloc((void **)&qb.dbg, nb);
         hipMemsetAsync(qb.dbg, 0, nb, st);
-        hipLaunchKernelGGL((fit_quad_kernel<KP, 1, NWR, QM_RAGGED_REG, PQ, true, true>), dim3((unsigned)blocks), dim3(NWR * 64), lds, st, qb);
+        hipLaunchKernelGGL((fit_quad_kernel<KP, 1, NWR, QM_RAGGED_REG, PQ, true, true>), dim3((unsigned)blocks), dim3(NWR * 64), lds, st, qb, 0, 0);
         hipStreamSynchronize(st);
         std::vector<long long> h(8 * (size_t)qa.f.N);
         hipMemcpy(h.data(), qb.dbg, nb, hipMemcpyDeviceToHost);
@@ -63,7 +64,7 @@ static int launch_quad_ragged_reg(const QuadPlan &qp, const QuadArgs &qa, hipStr
         return (int)hipGetLastError();
     }
 #endif
-    hipLaunchKernelGGL((fit_quad_kernel<KP, 1, NWR, QM_RAGGED_REG, PQ, true, true>), dim3((unsigned)blocks), dim3(NWR * 64), lds, st, qa);
+    hipLaunchKernelGGL((fit_quad_kernel<KP, 1, NWR, QM_RAGGED_REG, PQ, true, true>), dim3((unsigned)blocks), dim3(NWR * 64), lds, st, qa, 0, 0);
     return (int)hipGetLastError();
 }
 

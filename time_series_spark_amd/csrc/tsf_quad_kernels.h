@@ -37,7 +37,7 @@ constexpr int QH = 5;                   // L-BFGS history of the register-reside
 // shared-M one-slot kernel (<= 168 VGPRs, 12 waves per CU), else 2.  Every variant with LDS to spare
 // keeps its L-BFGS history in an LDS ring (HLDS); the ragged variant with a private Z^T Z per wave in
 // LDS has none left and keeps it in registers
-constexpr int quad_waves_per_simd(bool w3) { return w3 ? 3 : 2; }
+constexpr int quad_waves_per_simd(bool w3, int nw = 0) { return nw == 16 ? 4 : (w3 ? 3 : 2); }
 // the kernel variant that is: shared M in LDS, one parameter per lane, L-BFGS history in LDS
 constexpr bool quad_three_waves(int mmode, int ppl, bool hlds) { return hlds && mmode == 0 && ppl == 1; }
 
@@ -72,6 +72,46 @@ struct QuadLds {
 template <int PPL>
 constexpr size_t quad_lanec_bytes() { return sizeof(double) * 3 * PPL * W; }
 
+// The trend tables of a residual pass as a POOL of the workgroup (RPOOL kernels: 16 waves per CU).  A
+// residual pass -- the initial point and the re-centrings, ~6 of a series' ~450 evaluations, a tenth of its
+// time -- needs the tables of QuadLds (ks, mc, tp1/2, tot1/2, accR, th: 4.3 KB); an evaluation of the
+// quadratic form needs none of them.  Sixteen private copies do not fit next to M, the history rings and the
+// per-wave vectors, so NS < NW copies are shared: a wave takes one for the duration of a pass.  Per wave stay
+// D / ref / c (QuadWave, 1.5 KB) and the history ring (5 KB).
+// The lock is one LDS word per slot.  Every lane issues the compare-and-swap (wave-uniform control flow:
+// a lane-0-only retry loop is the pattern the comment in fit_quad_kernel warns about); exactly one lane of
+// one wave sees the word go 0 -> 1.  LDS operations of a CU execute in issue order, so the acquire / release
+// fences below only have to hold the compiler (and the s_waitcnt it derives from them) in place.
+template <int PPL>
+struct QuadWave { double dl[PPL * W], ref[PPL * W], cvec[PPL * W]; };
+
+struct QuadPool {
+    int *locks;                         // [ns] in LDS, 0 = free
+    unsigned char *slots;               // [ns] x slot_bytes in LDS: one QuadLds each, + NTmax x 64 staging rows where they fit
+    int ns, first;                      // first: where this wave starts looking (spreads the waves)
+    unsigned slot_bytes;
+};
+constexpr size_t QUAD_POOL_LOCK_BYTES = 64;
+
+__device__ __forceinline__ int pool_acquire(const QuadPool &pl)
+{
+    int i = pl.first;
+    for (;;) {
+        const int old = atomicCAS(pl.locks + i, 0, 1);
+        if (__any(old == 0)) break;
+        i = (i + 1 == pl.ns) ? 0 : i + 1;
+        if (i == pl.first) __builtin_amdgcn_s_sleep(8);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return __builtin_amdgcn_readfirstlane(i);
+}
+
+__device__ __forceinline__ void pool_release(const QuadPool &pl, int i)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __hip_atomic_store(pl.locks + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 
 // G-column slice of the register transpose network of column_sums (tsf_fit_kernels.h)
 template <int G>
@@ -101,9 +141,11 @@ __device__ __forceinline__ void column_sums_g(double (&acc)[G], double *accR)
     }
 }
 
-template <int KP, int G>
+// NTR > 0: the weights of the pass are in the register array rr[NTR] (sv.NT <= NTR, checked by the launcher)
+// instead of the staging rows rb
+template <int KP, int G, int NTR = 0>
 __device__ __forceinline__ void column_group(const SeriesView &sv, const double *rb, int g0,
-                                             double *accR)
+                                             double *accR, const double (&rr)[NTR > 0 ? NTR : 1])
 {
     const int lane = lane_id();
     double acc[G];
@@ -113,7 +155,7 @@ __device__ __forceinline__ void column_group(const SeriesView &sv, const double 
     // ztr_pass) and X = 0 (zero-filled padding), and fma(0, 0, acc) leaves acc unchanged
 #pragma unroll 4
     for (int q = sv.NT - 1; q >= 0; --q) {
-        const double r = rb[q * W + lane];
+        const double r = NTR > 0 ? rr[NTR > 0 ? q : 0] : rb[q * W + lane];
         const double *xp = sv.Xw + ((size_t)q * KP + g0) * W + lane;
         double x[G];
 #pragma unroll
@@ -128,13 +170,23 @@ __device__ __forceinline__ void column_group(const SeriesView &sv, const double 
 // row lane*NT+q comes from gen(q, idx, c, ti) (called for valid rows only, q descending); it is
 // parked in rb[q*64+lane] for the per-column passes (0 for rows past the end of the series).
 // ztr[s]: entry p = lane + 64 s.
-template <int KP, int PPL, class RGen>
+// NTR > 0 (sv.NT <= NTR): the weights stay in NTR registers of the lane that made them -- row lane*NT+q is
+// produced and consumed by the same lane, so the staging rows are nothing but spill space: 12 doubles per
+// lane for cfg2, which the 168-register budget of the 12-waves-per-CU kernel has room for (138 used).  Round 2
+// staged them through global memory (the LDS is full at 12 waves): 7 x the algorithmic HBM bytes.  The array is
+// indexed by the wave-uniform step q (s_set_gpr_idx / v_movrel, no scratch).
+template <int KP, int PPL, int NTR = 0, class RGen>
 __device__ __forceinline__ void ztr_pass(const SeriesView &sv, QuadLds<KP, PPL> &wl, double *rb,
                                          RGen gen, double &sse_out, double (&ztr)[PPL])
 {
     const int lane = lane_id();
     const int S = sv.S;
     double sse = 0.0, rt1 = 0.0, rt2 = 0.0;
+    double rr[NTR > 0 ? NTR : 1];
+    if (NTR > 0) {
+#pragma unroll
+        for (int q = 0; q < (NTR > 0 ? NTR : 1); ++q) rr[q] = 0.0;
+    }
 #pragma unroll 1
     for (int q = sv.NT - 1; q >= 0; --q) {
         const bool valid = q < sv.cnt;
@@ -144,7 +196,7 @@ __device__ __forceinline__ void ztr_pass(const SeriesView &sv, QuadLds<KP, PPL> 
         const double ti = valid ? sv.tw[idx] : 0.0;
         double r = gen(q, idx, c, ti);
         if (!valid) r = 0.0;
-        rb[idx] = r;
+        if (NTR > 0) rr[NTR > 0 ? q : 0] = r; else rb[idx] = r;
         sse = __builtin_fma(r, r, sse);
         rt1 = __builtin_fma(r, ti, rt1);
         rt2 = rt2 + r;
@@ -156,8 +208,8 @@ __device__ __forceinline__ void ztr_pass(const SeriesView &sv, QuadLds<KP, PPL> 
     if (lane == 0) { wl.tot1[W] = 0.0; wl.tot2[W] = 0.0; }
     constexpr int G8 = (KP / 8) * 8;
 #pragma unroll 1
-    for (int g0 = 0; g0 < G8; g0 += 8) column_group<KP, 8>(sv, rb, g0, wl.accR);
-    if (KP % 8 != 0) column_group<KP, 4>(sv, rb, G8, wl.accR);
+    for (int g0 = 0; g0 < G8; g0 += 8) column_group<KP, 8, NTR>(sv, rb, g0, wl.accR, rr);
+    if (KP % 8 != 0) column_group<KP, 4, NTR>(sv, rb, G8, wl.accR, rr);
     wave_sync();
 #pragma unroll
     for (int s = 0; s < PPL; ++s) {
@@ -286,7 +338,7 @@ __device__ __forceinline__ bool assemble_q(const SeriesView &sv, const LaneConst
 }
 
 // residual-form evaluation (cn_resid_q): r -> rb, then Z^T r, then assemble_q
-template <int KP, int PPL>
+template <int KP, int PPL, int NTR = 0>
 __device__ __forceinline__ bool resid_eval_q(const SeriesView &sv, QuadLds<KP, PPL> &wl,
                                              const LaneConst<PPL> &lk, double *rb,
                                              const double (&th)[PPL], double &f_out,
@@ -322,7 +374,7 @@ __device__ __forceinline__ bool resid_eval_q(const SeriesView &sv, QuadLds<KP, P
         const double gtr = __builtin_fma(wl.ks[c], ti, wl.mc[c]);
         return yi - (gtr + xa);
     };
-    ztr_pass<KP, PPL>(sv, wl, rb, gen, sse_out, ztr);
+    ztr_pass<KP, PPL, NTR>(sv, wl, rb, gen, sse_out, ztr);
     return assemble_q<PPL>(sv, lk, th, sse_out, ztr, f_out, g);
 }
 
@@ -595,11 +647,19 @@ __global__ __launch_bounds__(64) void gram_build_kernel(QuadArgs qa, double *Mou
 // HLDS: the L-BFGS history lives in the wave's LDS ring `hist` ([2][QH][PPL][64]: s then y, slot of
 // age h = (h0 + h) mod QH) instead of 4 QH PPL registers per lane -- what lets a third wave per
 // SIMD fit the register file (tsf_inst_quad.hip); same values, same operation order.
-template <int KP, int PPL, int PQ, bool RAGGED, int MRS = W, bool HLDS = false, int MBATCH = 16, bool MREG = false>
-__device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL> &wl, double *rb,
+// NTR > 0: the weights of a residual pass in NTR registers (ztr_pass), rb unused.
+// POOL: wlp is null; a residual pass borrows a QuadLds of `pool` and the vectors that live across
+// evaluations (D, ref, c) sit in the wave's QuadWave `qw`.
+template <int KP, int PPL, int PQ, bool RAGGED, int MRS = W, bool HLDS = false, int MBATCH = 16, bool MREG = false, int NTR = 0, bool POOL = false>
+__device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL> *wlp, double *rb,
                                           const double *Mp, double *Mown, int64_t n, double *lanec,
-                                          double *hist = nullptr, GramX *gx = nullptr)
+                                          double *hist = nullptr, GramX *gx = nullptr,
+                                          QuadWave<PPL> *qw = nullptr, const QuadPool *pool = nullptr)
 {
+    static_assert(!POOL || (!RAGGED && PQ > 0 && PPL == 1), "pooled trend tables: the shared-M one-slot kernel");
+    double *const dl_w = POOL ? qw->dl : wlp->th;
+    double *const ref_w = POOL ? qw->ref : wlp->ref;
+    double *const cvec_w = POOL ? qw->cvec : wlp->cvec;
     const FitArgs &a = qa.f;
     const DevSpec *sp = a.sp;
     const int lane = lane_id();
@@ -646,14 +706,14 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
                 if (!real) { Mown[(size_t)q * W + lane] = 0.0; continue; }
                 if (qprev < 0) { qprev = q; continue; }
                 double za, zb;
-                gram_columns2<KP>(sv, wl, *gx, qprev, q, za, zb);
+                gram_columns2<KP>(sv, *wlp, *gx, qprev, q, za, zb);
                 Mown[(size_t)qprev * W + lane] = za;
                 Mown[(size_t)q * W + lane] = zb;
                 qprev = -1;
             }
             if (qprev >= 0) {           // an odd column left over
                 double za, zb;
-                gram_columns2<KP>(sv, wl, *gx, qprev, qprev, za, zb);
+                gram_columns2<KP>(sv, *wlp, *gx, qprev, qprev, za, zb);
                 Mown[(size_t)qprev * W + lane] = za;
             }
         } else {
@@ -662,7 +722,7 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
             double col[PPL];
 #pragma unroll
             for (int s = 0; s < PPL; ++s) col[s] = 0.0;
-            if (q != 2 && q < sv.P) gram_column<KP, PPL>(sv, wl, rb, q, col);
+            if (q != 2 && q < sv.P) gram_column<KP, PPL>(sv, *wlp, rb, q, col);
             if (MRS == W) {
 #pragma unroll
                 for (int s = 0; s < PPL; ++s) Mown[((size_t)q * PPL + s) * W + lane] = col[s];
@@ -720,14 +780,24 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
         for (int s = 0; s < PPL; ++s) xe[s] = xk[s];
         sv.n_eval++;
         QT_LAP(2);
-        const bool bad = resid_eval_q<KP, PPL>(sv, wl, lk, rb, xe, fe, ge, sse_e, ztr_e);
+        bool bad;
+        if constexpr (POOL) {
+            const int slot = pool_acquire(*pool);
+            unsigned char *sl = pool->slots + (size_t)slot * pool->slot_bytes;
+            // short series: the slot also holds the staging rows (slot_bytes says so); else the global scratch
+            double *rbs = pool->slot_bytes > sizeof(QuadLds<KP, PPL>) ? reinterpret_cast<double *>(sl + sizeof(QuadLds<KP, PPL>)) : rb;
+            bad = resid_eval_q<KP, PPL, NTR>(sv, *reinterpret_cast<QuadLds<KP, PPL> *>(sl), lk, rbs, xe, fe, ge, sse_e, ztr_e);
+            pool_release(*pool, slot);
+        } else {
+            bad = resid_eval_q<KP, PPL, NTR>(sv, *wlp, lk, rb, xe, fe, ge, sse_e, ztr_e);
+        }
         QT_LAP(3);
         if (!bad) {
 #pragma unroll
             for (int s = 0; s < PPL; ++s) {
                 const int p = lane + s * W;
-                wl.ref[p] = (p == 2) ? 0.0 : xe[s];
-                wl.cvec[p] = ztr_e[s];
+                ref_w[p] = (p == 2) ? 0.0 : xe[s];
+                cvec_w[p] = ztr_e[s];
                 gk[s] = ge[s];
             }
             s0 = sse_e; since_rc = 0; fk = UQ(fe);
@@ -936,7 +1006,7 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
                 for (int s = 0; s < PPL; ++s) { xk1[s] = __builtin_fma(alpha, pk[s], xk[s]); xe[s] = xk1[s]; }
                 sv.n_eval++;
                 QT_LAP(2);
-                const bool bad = gram_eval_q<PPL, PQ, MRS, MBATCH, MREG>(sv, lk, Mp, P4, xe, wl.ref, wl.cvec, s0, fe, ge, q2, wl.th, mreg);
+                const bool bad = gram_eval_q<PPL, PQ, MRS, MBATCH, MREG>(sv, lk, Mp, P4, xe, ref_w, cvec_w, s0, fe, ge, q2, dl_w, mreg);
                 QT_LAP(4);
 #pragma unroll
                 for (int s = 0; s < PPL; ++s) gk1[s] = ge[s];
@@ -1015,9 +1085,13 @@ enum { QM_LDS = 0, QM_GLOBAL = 1, QM_RAGGED = 2, QM_RAGGED_LDS = 3, QM_RAGGED_RE
 template <int PPL>
 constexpr size_t quad_hist_bytes(bool hlds) { return hlds ? sizeof(double) * 2 * QH * PPL * W : 0; }
 
-template <int KP, int PPL, int NW, int MMODE, int PQ, bool RLDS, bool HLDS = false>
-__global__ __launch_bounds__(NW * 64, quad_waves_per_simd(quad_three_waves(MMODE, PPL, HLDS))) void fit_quad_kernel(QuadArgs qa)
+// NTR > 0: residual-pass weights in NTR registers per lane (NTmax <= NTR, RLDS false: no staging at all)
+// RPOOL (NW = 16, four waves per SIMD at <= 128 registers): trend tables from a pool of pool_slots QuadLds
+template <int KP, int PPL, int NW, int MMODE, int PQ, bool RLDS, bool HLDS = false, int NTR = 0, bool RPOOL = false>
+__global__ __launch_bounds__(NW * 64, quad_waves_per_simd(quad_three_waves(MMODE, PPL, HLDS), NW)) void fit_quad_kernel(QuadArgs qa, int pool_slots, int pool_slot_bytes)
 {
+    static_assert(NTR == 0 || (!RLDS && MMODE == QM_LDS), "register-resident weights: the shared-M kernel without LDS staging");
+    static_assert(!RPOOL || (MMODE == QM_LDS && !RLDS && PPL == 1 && PQ > 0 && HLDS), "pooled trend tables: the shared-M one-slot kernel");
     extern __shared__ __align__(16) unsigned char smem[];
     const FitArgs &a = qa.f;
     const int lane = lane_id(), wid = (int)threadIdx.x >> 6;
@@ -1025,22 +1099,39 @@ __global__ __launch_bounds__(NW * 64, quad_waves_per_simd(quad_three_waves(MMODE
     constexpr bool MLDS = MMODE == QM_LDS;
     // LDS: [M (aligned, P <= 64)] [lane constants: one (aligned) or NW (ragged)] [QuadLds x NW]
     //      [history ring x NW (HLDS)] [r staging x NW (RLDS)] [per-wave compact M (QM_RAGGED_LDS)]
+    // RPOOL: [M] [lane constants] [QuadWave x NW] [history ring x NW] [locks] [QuadLds x pool_slots]
     double *Ml = reinterpret_cast<double *>(smem);
     const size_t m_bytes = MLDS ? sizeof(double) * (size_t)P4 * PPL * W : 0;
     constexpr bool RAGGED_K = MMODE == QM_RAGGED || MMODE == QM_RAGGED_LDS || MMODE == QM_RAGGED_REG;
     constexpr size_t LCB = quad_lanec_bytes<PPL>();
     double *lanec = reinterpret_cast<double *>(smem + m_bytes + (RAGGED_K ? LCB * wid : 0));
     const size_t off_wl = m_bytes + LCB * (RAGGED_K ? NW : 1);
-    QuadLds<KP, PPL> &wl = *reinterpret_cast<QuadLds<KP, PPL> *>(smem + off_wl + sizeof(QuadLds<KP, PPL>) * wid);
+    constexpr size_t WLB = RPOOL ? sizeof(QuadWave<PPL>) : sizeof(QuadLds<KP, PPL>);
+    QuadLds<KP, PPL> *wlp = RPOOL ? nullptr : reinterpret_cast<QuadLds<KP, PPL> *>(smem + off_wl + WLB * wid);
+    QuadWave<PPL> *qw = RPOOL ? reinterpret_cast<QuadWave<PPL> *>(smem + off_wl + WLB * wid) : nullptr;
+    constexpr size_t HB = quad_hist_bytes<PPL>(HLDS);
+    const size_t off_hist = off_wl + WLB * NW;
+    double *hist = HLDS ? reinterpret_cast<double *>(smem + off_hist + HB * wid) : nullptr;
+    const size_t off_rb = off_hist + HB * NW;
+    QuadPool pool;
+    pool.locks = reinterpret_cast<int *>(smem + off_rb);
+    pool.slots = smem + off_rb + QUAD_POOL_LOCK_BYTES;
+    pool.ns = pool_slots;
+    pool.first = __builtin_amdgcn_readfirstlane(wid % (pool_slots > 0 ? pool_slots : 1));
+    pool.slot_bytes = (unsigned)pool_slot_bytes;
+    if (RPOOL) {
+        // locks free; theta rows of every slot zero beyond P (resid_eval_q writes the first PPL x 64 only)
+        for (int i = threadIdx.x; i < (int)(QUAD_POOL_LOCK_BYTES / sizeof(int)); i += NW * 64) pool.locks[i] = 0;
+        for (int i = threadIdx.x; i < pool_slots * (PPL * W + W); i += NW * 64) {
+            const int sl = i / (PPL * W + W), k = i - sl * (PPL * W + W);
+            reinterpret_cast<QuadLds<KP, PPL> *>(pool.slots + (size_t)sl * pool.slot_bytes)->th[k] = 0.0;
+        }
+    }
     if (MLDS) {
         for (int i = threadIdx.x; i < P4 * PPL * W; i += NW * 64) Ml[i] = qa.Mg[i];
         __syncthreads();
     }
     const double *Mp = MLDS ? Ml : qa.Mg;
-    constexpr size_t HB = quad_hist_bytes<PPL>(HLDS);
-    const size_t off_hist = off_wl + sizeof(QuadLds<KP, PPL>) * NW;
-    double *hist = HLDS ? reinterpret_cast<double *>(smem + off_hist + HB * wid) : nullptr;
-    const size_t off_rb = off_hist + HB * NW;
     const size_t rb_bytes = RLDS ? sizeof(double) * (size_t)NW * a.NTmax * W : 0;
     // QM_RAGGED_REG: the second column's tables of the two-columns-per-pass Gram build live in the wave's
     // staging rows (idle during that build; the launcher checks that they are large enough)
@@ -1054,11 +1145,15 @@ __global__ __launch_bounds__(NW * 64, quad_waves_per_simd(quad_three_waves(MMODE
         wave_sync();
     }
     // residual staging r[q][lane] of the running residual pass: in LDS when the launch found room
-    // for NW x NTmax x 64 doubles, else in the global scratch (long series)
+    // for NW x NTmax x 64 doubles, in registers (NTR), else in the global scratch (long series)
     double *rb = RLDS ? reinterpret_cast<double *>(smem + off_rb) + (size_t)wid * a.NTmax * W
                       : qa.rbuf + ((size_t)blockIdx.x * NW + wid) * a.NTmax * W;
     GramX *gx = (MMODE == QM_RAGGED_REG && RLDS) ? reinterpret_cast<GramX *>(rb) : nullptr;
-    for (int i = lane; i < PPL * W + W; i += W) wl.th[i] = 0.0;
+    if (RPOOL) {
+        for (int i = lane; i < PPL * W; i += W) qw->dl[i] = 0.0;
+    } else {
+        for (int i = lane; i < PPL * W + W; i += W) wlp->th[i] = 0.0;
+    }
     wave_sync();
 
     for (;;) {
@@ -1072,7 +1167,7 @@ __global__ __launch_bounds__(NW * 64, quad_waves_per_simd(quad_three_waves(MMODE
         if (n >= a.N) break;
         fit_one_quad<KP, PPL, PQ, RAGGED_K, MRS, HLDS,
                      ((quad_three_waves(MMODE, PPL, HLDS) || MMODE == QM_RAGGED_REG || MMODE == QM_GLOBAL_REG) ? 8 : 16),
-                     MMODE == QM_RAGGED_REG || MMODE == QM_GLOBAL_REG>(qa, wl, rb, Mp, Mown, n, lanec, hist, gx);
+                     MMODE == QM_RAGGED_REG || MMODE == QM_GLOBAL_REG, NTR, RPOOL>(qa, wlp, rb, Mp, Mown, n, lanec, hist, gx, qw, &pool);
     }
 }
 
