@@ -141,8 +141,8 @@ __device__ __forceinline__ void column_sums_g(double (&acc)[G], double *accR)
     }
 }
 
-// NTR > 0: the weights of the pass are in the register array rr[NTR] (sv.NT <= NTR, checked by the launcher)
-// instead of the staging rows rb
+// NTR > 0: the weights of steps q < NTR are in the register array rr[NTR], those of later steps (series of more
+// than 64 NTR rows) in the staging rows rb
 template <int KP, int G, int NTR = 0>
 __device__ __forceinline__ void column_group(const SeriesView &sv, const double *rb, int g0,
                                              double *accR, const double (&rr)[NTR > 0 ? NTR : 1])
@@ -153,15 +153,25 @@ __device__ __forceinline__ void column_group(const SeriesView &sv, const double 
     for (int j = 0; j < G; ++j) acc[j] = 0.0;
     // branch-free over the NT steps: rows past the end of the series hold r = 0 (written by
     // ztr_pass) and X = 0 (zero-filled padding), and fma(0, 0, acc) leaves acc unchanged
-#pragma unroll 4
-    for (int q = sv.NT - 1; q >= 0; --q) {
-        const double r = NTR > 0 ? rr[NTR > 0 ? q : 0] : rb[q * W + lane];
+    auto step = [&](int q, double r) {
         const double *xp = sv.Xw + ((size_t)q * KP + g0) * W + lane;
         double x[G];
 #pragma unroll
         for (int j = 0; j < G; ++j) x[j] = xp[j * W];
 #pragma unroll
         for (int j = 0; j < G; ++j) acc[j] = __builtin_fma(x[j], r, acc[j]);
+    };
+    if (NTR > 0) {
+        // (two loops, q descending throughout: a select between the register array and memory inside ONE
+        // loop sends the array to scratch)
+#pragma unroll 2
+        for (int q = sv.NT - 1; q >= NTR; --q) step(q, rb[q * W + lane]);
+        const int q1 = sv.NT < NTR ? sv.NT : NTR;
+#pragma unroll 4
+        for (int q = q1 - 1; q >= 0; --q) step(q, rr[NTR > 0 ? q : 0]);
+    } else {
+#pragma unroll 4
+        for (int q = sv.NT - 1; q >= 0; --q) step(q, rb[q * W + lane]);
     }
     column_sums_g<G>(acc, accR + g0);
 }
@@ -170,7 +180,8 @@ __device__ __forceinline__ void column_group(const SeriesView &sv, const double 
 // row lane*NT+q comes from gen(q, idx, c, ti) (called for valid rows only, q descending); it is
 // parked in rb[q*64+lane] for the per-column passes (0 for rows past the end of the series).
 // ztr[s]: entry p = lane + 64 s.
-// NTR > 0 (sv.NT <= NTR): the weights stay in NTR registers of the lane that made them -- row lane*NT+q is
+// NTR > 0: the weights of the first NTR steps stay in NTR registers of the lane that made them (later steps, if any:
+// staging rows) -- row lane*NT+q is
 // produced and consumed by the same lane, so the staging rows are nothing but spill space: 12 doubles per
 // lane for cfg2, which the 168-register budget of the 12-waves-per-CU kernel has room for (138 used).  Round 2
 // staged them through global memory (the LDS is full at 12 waves): 7 x the algorithmic HBM bytes.  The array is
@@ -187,8 +198,7 @@ __device__ __forceinline__ void ztr_pass(const SeriesView &sv, QuadLds<KP, PPL> 
 #pragma unroll
         for (int q = 0; q < (NTR > 0 ? NTR : 1); ++q) rr[q] = 0.0;
     }
-#pragma unroll 1
-    for (int q = sv.NT - 1; q >= 0; --q) {
+    auto row_step = [&](int q) -> double {
         const bool valid = q < sv.cnt;
         const int idx = q * W + lane;
         const unsigned cwv = valid ? (unsigned)sv.cw[idx] : 0u;
@@ -196,11 +206,21 @@ __device__ __forceinline__ void ztr_pass(const SeriesView &sv, QuadLds<KP, PPL> 
         const double ti = valid ? sv.tw[idx] : 0.0;
         double r = gen(q, idx, c, ti);
         if (!valid) r = 0.0;
-        if (NTR > 0) rr[NTR > 0 ? q : 0] = r; else rb[idx] = r;
         sse = __builtin_fma(r, r, sse);
         rt1 = __builtin_fma(r, ti, rt1);
         rt2 = rt2 + r;
         for (int j = cprev; j < c; ++j) { wl.tp1[j] = rt1; wl.tp2[j] = rt2; }
+        return r;
+    };
+    if (NTR > 0) {
+#pragma unroll 1
+        for (int q = sv.NT - 1; q >= NTR; --q) rb[q * W + lane] = row_step(q);
+        const int q1 = sv.NT < NTR ? sv.NT : NTR;
+#pragma unroll 1
+        for (int q = q1 - 1; q >= 0; --q) rr[NTR > 0 ? q : 0] = row_step(q);
+    } else {
+#pragma unroll 1
+        for (int q = sv.NT - 1; q >= 0; --q) rb[q * W + lane] = row_step(q);
     }
     sse_out = bfly_sum(sse);
     const double s1 = suffix_scan(rt1), s2v = suffix_scan(rt2);
@@ -1085,7 +1105,7 @@ enum { QM_LDS = 0, QM_GLOBAL = 1, QM_RAGGED = 2, QM_RAGGED_LDS = 3, QM_RAGGED_RE
 template <int PPL>
 constexpr size_t quad_hist_bytes(bool hlds) { return hlds ? sizeof(double) * 2 * QH * PPL * W : 0; }
 
-// NTR > 0: residual-pass weights in NTR registers per lane (NTmax <= NTR, RLDS false: no staging at all)
+// NTR > 0: residual-pass weights of the first NTR steps in registers (RLDS false; steps beyond: global scratch)
 // RPOOL (NW = 16, four waves per SIMD at <= 128 registers): trend tables from a pool of pool_slots QuadLds
 template <int KP, int PPL, int NW, int MMODE, int PQ, bool RLDS, bool HLDS = false, int NTR = 0, bool RPOOL = false>
 __global__ __launch_bounds__(NW * 64, quad_waves_per_simd(quad_three_waves(MMODE, PPL, HLDS), NW)) void fit_quad_kernel(QuadArgs qa, int pool_slots, int pool_slot_bytes)

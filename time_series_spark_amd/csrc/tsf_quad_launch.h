@@ -134,12 +134,12 @@ static int launch_quad_mm(const QuadPlan &qp, const QuadArgs &qa, double *Mg, hi
                         (sizeof(QuadLds<KP, PPL>) + quad_hist_bytes<PPL>(HL)) * NW;
     const size_t rbytes = sizeof(double) * (size_t)NW * qa.f.NTmax * W;
     if (base + rbytes <= 160 * 1024) return launch_quad_rl<KP, PPL, MMODE, PQ, true>(qp, qa, Mg, st);
-    // no room in LDS (the 12-waves-per-CU kernel on series of >= ~600 rows): the weights of a pass stay in
-    // registers when the series have at most TSF_QUAD_NTR steps per lane (cfg2: 12), else they are staged
-    // through the global scratch.  TSF_QUAD_RREG=0: always the global scratch (round 2's route; tests).
+    // no room in LDS (the 12-waves-per-CU kernel on series of >= ~600 rows): the weights of the first
+    // TSF_QUAD_NTR steps of a pass stay in registers (cfg2: all 12), those of later steps go through the
+    // global scratch (cfg3, 1 095 rows: 6 of 18).  TSF_QUAD_RREG=0: all of them (round 2's route; tests).
     if constexpr (MMODE == QM_LDS && PPL == 1 && PQ > 0) {
         const char *e = getenv("TSF_QUAD_RREG");
-        if (qa.f.NTmax <= TSF_QUAD_NTR && !(e && atoi(e) == 0))
+        if (!(e && atoi(e) == 0))
             return launch_quad_rl<KP, PPL, MMODE, PQ, false, TSF_QUAD_NTR>(qp, qa, Mg, st);
     }
     return launch_quad_rl<KP, PPL, MMODE, PQ, false>(qp, qa, Mg, st);
