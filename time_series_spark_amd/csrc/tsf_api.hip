@@ -8,6 +8,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -678,6 +679,11 @@ static int fit_host(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, 
     if (max_T > TSF_MAX_T) return fail(ctx, "series too long (TSF_MAX_T rows per series)");
     const int64_t n_ds = aligned ? T : total;
     const int64_t n_grids = aligned ? 1 : N;
+    // TSF_HOST_TIMING=1 (dev): wall-clock of the phases of this entry point on stderr
+    static const bool host_timing = getenv("TSF_HOST_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_start = host_timing ? now() : 0.0;
+    double t_h2d = 0.0, t_fit = 0.0;
     DevBuf d_ds, d_y, d_off, d_floor, d_cap, d_extra, d_theta, d_ys, d_f, d_st, d_it, d_ev, d_grid, d_thin, d_grad;
     HIP_TRY(ctx, d_ds.alloc(8 * n_ds));
     HIP_TRY(ctx, d_y.alloc(ysize(y_dtype) * total));
@@ -728,6 +734,7 @@ static int fit_host(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, 
             if (U <= (uint64_t)1 << 18) { lat_base = lo; lat_step = (int64_t)g; lat_U = (int64_t)U; }
         }
     }
+    if (host_timing) t_h2d = now();
     int rc = run_fit(ctx, spec, N, aligned, T, d_off.as<int64_t>(), total, max_T, d_ds.as<int64_t>(),
                      d_y.p, y_dtype, floor_ ? d_floor.as<double>() : nullptr,
                      cap ? d_cap.as<double>() : nullptr,
@@ -736,6 +743,7 @@ static int fit_host(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, 
                      theta_in ? d_grad.as<double>() : nullptr, nullptr, lat_base, lat_step, lat_U);
     if (rc) return rc;
     HIP_TRY(ctx, hipDeviceSynchronize());
+    if (host_timing) t_fit = now();
     if (theta_in) {
         HIP_TRY(ctx, hipMemcpy(f_out, d_f.p, 8 * N, hipMemcpyDeviceToHost));
         HIP_TRY(ctx, hipMemcpy(grad_out, d_grad.p, 8 * (size_t)N * stride, hipMemcpyDeviceToHost));
@@ -748,6 +756,9 @@ static int fit_host(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, 
     HIP_TRY(ctx, hipMemcpy(out->n_iter, d_it.p, 4 * N, hipMemcpyDeviceToHost));
     HIP_TRY(ctx, hipMemcpy(out->n_eval, d_ev.p, 4 * N, hipMemcpyDeviceToHost));
     HIP_TRY(ctx, hipMemcpy(out->grid, d_grid.p, sizeof(tsf_grid_info) * n_grids, hipMemcpyDeviceToHost));
+    if (host_timing)
+        fprintf(stderr, "[host-timing] N %lld: alloc + H2D + clears %.3f ms, fit (launch .. device idle) %.3f ms, D2H %.3f ms\n",
+                (long long)N, t_h2d - t_start, t_fit - t_h2d, now() - t_fit);
     return 0;
 }
 

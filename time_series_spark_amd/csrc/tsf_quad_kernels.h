@@ -407,7 +407,10 @@ __device__ __forceinline__ bool resid_eval_q(const SeriesView &sv, QuadLds<KP, P
 // MREG: row p of M (= column p: M is symmetric) in PQ registers of lane p instead of LDS / global
 // memory -- the per-series Z^T Z of a ragged panel: 25 KB of LDS per wave allowed 4 waves per CU, 112
 // registers per lane allow 8, and the mat-vec loses its 56 LDS reads of M.  Same operands, same order.
-template <int PPL, int PQ, int MRS = W, int MB_ = 16, bool MREG = false>
+#ifndef TSF_QUAD_MPIPE
+#define TSF_QUAD_MPIPE 1
+#endif
+template <int PPL, int PQ, int MRS = W, int MB_ = 16, bool MREG = false, bool MPIPE = (TSF_QUAD_MPIPE != 0)>
 __device__ __forceinline__ bool gram_eval_q(const SeriesView &sv, const LaneConst<PPL> &lk,
                                             const double *Ml, int P4, const double (&th)[PPL],
                                             const double *ref_l, const double *cvec_l,
@@ -437,6 +440,29 @@ __device__ __forceinline__ bool gram_eval_q(const SeriesView &sv, const LaneCons
         // batches of MB rows (16, or 8 in the three-waves-per-SIMD kernel): MB LDS reads in flight, then their fmas; the scheduling barrier
         // keeps the compiler from hoisting every read of M to the top (register pressure)
         constexpr int MB = MB_;
+        if constexpr (!MREG && MPIPE) {
+            // Software-pipelined: the reads of batch b + 1 are issued BEFORE the fmas of batch b, so only the first
+            // batch pays the LDS latency (one batch at a time cost ~230 cycles each, seven of them per evaluation:
+            // 1.0 k of the 2.6 k cycles of an evaluation; with M in registers the whole evaluation takes 1.7 k).
+            // Same operands, same chains (q & 3), same order.
+            constexpr int NB = (PQ + MB - 1) / MB;
+            double m[2][MB], dq[2][MB];
+#pragma unroll
+            for (int u = 0; u < MB; ++u) if (u < PQ) { m[0][u] = mp[u * MRS]; dq[0][u] = dl[u]; }
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int q1 = (b + 1) * MB;
+#pragma unroll
+                for (int u = 0; u < MB; ++u) if (b + 1 < NB && q1 + u < PQ) { m[(b + 1) & 1][u] = mp[(q1 + u) * MRS]; dq[(b + 1) & 1][u] = dl[q1 + u]; }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < MB; ++u) {
+                    const int q = b * MB + u;
+                    if (q < PQ) a[0][q & 3] = __builtin_fma(m[b & 1][u], dq[b & 1][u], a[0][q & 3]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
 #pragma unroll
         for (int q0 = 0; q0 < PQ; q0 += MB) {
             double m[MB];
@@ -450,6 +476,7 @@ __device__ __forceinline__ bool gram_eval_q(const SeriesView &sv, const LaneCons
                 if (q0 + u < PQ) a[0][(q0 + u) & 3] = __builtin_fma(m[u], dq[u], a[0][(q0 + u) & 3]);
             }
             __builtin_amdgcn_sched_barrier(0);
+        }
         }
     } else {
     const int q_lo = P4 < W ? P4 : W;
@@ -670,7 +697,8 @@ __global__ __launch_bounds__(64) void gram_build_kernel(QuadArgs qa, double *Mou
 // NTR > 0: the weights of a residual pass in NTR registers (ztr_pass), rb unused.
 // POOL: wlp is null; a residual pass borrows a QuadLds of `pool` and the vectors that live across
 // evaluations (D, ref, c) sit in the wave's QuadWave `qw`.
-template <int KP, int PPL, int PQ, bool RAGGED, int MRS = W, bool HLDS = false, int MBATCH = 16, bool MREG = false, int NTR = 0, bool POOL = false>
+template <int KP, int PPL, int PQ, bool RAGGED, int MRS = W, bool HLDS = false, int MBATCH = 16, bool MREG = false, int NTR = 0, bool POOL = false,
+          bool MPIPE = (TSF_QUAD_MPIPE != 0) && !POOL>     // (the 128-register kernel has no room for a second batch in flight)
 __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL> *wlp, double *rb,
                                           const double *Mp, double *Mown, int64_t n, double *lanec,
                                           double *hist = nullptr, GramX *gx = nullptr,
@@ -931,6 +959,7 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
             }
             }
             double alphas[QH];
+            QT_LAP(1);
 #pragma unroll
             for (int s = 0; s < PPL; ++s) pk[s] = -gk[s];
 #pragma unroll
@@ -952,6 +981,7 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
                     for (int s = 0; s < PPL; ++s) pk[s] = __builtin_fma(cc, Sh[h][s], pk[s]);
                 }
             }
+            QT_LAP(6);                  // the two-loop recursion
             const double dF = __builtin_fabs(fk1 - fk);
             const double fmaxv = __builtin_fmax(__builtin_fabs(fk1),
                                                 __builtin_fmax(__builtin_fabs(fk), 1.0));
@@ -1026,7 +1056,7 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
                 for (int s = 0; s < PPL; ++s) { xk1[s] = __builtin_fma(alpha, pk[s], xk[s]); xe[s] = xk1[s]; }
                 sv.n_eval++;
                 QT_LAP(2);
-                const bool bad = gram_eval_q<PPL, PQ, MRS, MBATCH, MREG>(sv, lk, Mp, P4, xe, ref_w, cvec_w, s0, fe, ge, q2, dl_w, mreg);
+                const bool bad = gram_eval_q<PPL, PQ, MRS, MBATCH, MREG, MPIPE>(sv, lk, Mp, P4, xe, ref_w, cvec_w, s0, fe, ge, q2, dl_w, mreg);
                 QT_LAP(4);
 #pragma unroll
                 for (int s = 0; s < PPL; ++s) gk1[s] = ge[s];
