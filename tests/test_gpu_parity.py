@@ -921,6 +921,39 @@ def test_quadratic_form_kernel_routes_for_large_aligned_panels_give_the_same_bit
         assert np.array_equal(getattr(w3, name), getattr(w4, name), equal_nan=True), name
 
 
+def test_cost_hints_change_the_order_of_the_launch_and_nothing_else(env):
+    """tsf_set_cost_hints: the work queue hands out the series in order of decreasing expected cost (a caller that
+    re-fits a panel regularly passes the evaluation counts of the previous fit).  Every series is fitted by itself,
+    so the results must not move by a bit -- with the true counts, with random hints, with hints for another panel
+    size (ignored), on the quadratic-form kernel (queue) and on the residual-form kernel (one block per series)."""
+    fc, cl = env
+    from time_series_spark_amd import synth
+    rng = np.random.default_rng(5)
+    for growth, N, T in (('linear', 7000, 730), ('logistic', 600, 365)):
+        ds, y = synth.make_panel(N, T, growth, seed=79)
+        kw = {} if growth == 'linear' else {'floor': np.zeros(N), 'cap': y.max(axis=1) * 1.1}
+        spec = fc.ModelSpec(growth=growth, seasonalities=fc.ModelSpec.auto_seasonalities(ds),
+                            **({} if growth == 'linear' else {'seasonality_mode': 'multiplicative'}))
+        base = fc.fit_aligned(spec, ds, y, **kw)
+        legs = {'true': base.n_eval, 'random': rng.integers(0, 1000, N), 'constant': np.zeros(N, np.int32),
+                'other_size': np.arange(N - 1)}
+        for tag, hints in legs.items():
+            if tag == 'other_size':
+                ctx = fc.get_context()
+                hh = np.ascontiguousarray(hints, dtype=np.int32)
+                ctx.check(_lib_handle().tsf_set_cost_hints(ctx.handle, hh.ctypes.data, hh.shape[0]))
+                r = fc.fit_aligned(spec, ds, y, **kw)
+            else:
+                r = fc.fit_aligned(spec, ds, y, cost_hints=hints, **kw)
+            for name in ('theta', 'fval', 'n_iter', 'n_eval', 'status', 'y_scale'):
+                assert np.array_equal(getattr(base, name), getattr(r, name), equal_nan=True), (growth, tag, name)
+
+
+def _lib_handle():
+    from time_series_spark_amd import _lib
+    return _lib.load()
+
+
 def test_newton_several_series_per_wave_equals_one_series_per_wave(env):
     """The Newton kernel for aligned linear/additive panels keeps several series per wave and runs their
     QL rotation chains side by side, lane = series (tsf_newton_batch.h); calls with few series take the

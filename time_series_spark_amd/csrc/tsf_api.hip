@@ -8,6 +8,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <algorithm>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -35,6 +36,10 @@ struct tsf_ctx {
     size_t nb_ws_bytes;
     double *fut_tab;        // design table of a shared future grid (predict): [K][H]
     size_t fut_tab_bytes;
+    int32_t *order_dev[2];  // tsf_set_cost_hints: series in order of decreasing expected cost (two buffers, used in
+    size_t order_cap[2];    // turn: a fit that is still running on its stream keeps reading the one it was given)
+    int order_next;
+    int64_t order_n;        // series count the pending hints are for (0: none pending)
     int n_cu;               // compute units of the device (persistent kernels: one workgroup each)
     int profiling;
     hipEvent_t ev0[TSF_PROFILE_RING], ev1[TSF_PROFILE_RING];
@@ -75,6 +80,7 @@ extern "C" int tsf_create(int device_id, tsf_ctx **out)
     c->device = device_id; c->ws = nullptr; c->ws_bytes = 0; c->d_spec = nullptr;
     c->fut_tab = nullptr; c->fut_tab_bytes = 0;
     c->nb_ws = nullptr; c->nb_ws_bytes = 0;
+    c->order_dev[0] = c->order_dev[1] = nullptr; c->order_cap[0] = c->order_cap[1] = 0; c->order_next = 0; c->order_n = 0;
     c->profiling = 0; c->ev_created = 0; c->ev_count = 0;
     if (hipMalloc((void **)&c->d_spec, sizeof(DevSpec)) != hipSuccess) { delete c; return -2; }
     {
@@ -106,6 +112,7 @@ extern "C" void tsf_destroy(tsf_ctx *ctx)
     if (ctx->d_spec) hipFree(ctx->d_spec);
     if (ctx->fut_tab) hipFree(ctx->fut_tab);
     if (ctx->nb_ws) hipFree(ctx->nb_ws);
+    for (int b = 0; b < 2; ++b) if (ctx->order_dev[b]) hipFree(ctx->order_dev[b]);
     if (ctx->ev_created)
         for (int i = 0; i < TSF_PROFILE_RING; ++i) { hipEventDestroy(ctx->ev0[i]); hipEventDestroy(ctx->ev1[i]); }
     delete ctx;
@@ -469,6 +476,9 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     a.n_iter = out->n_iter; a.n_eval = out->n_eval; a.grid_out = out->grid;
     a.theta_in = theta_in; a.grad_out = grad_out;
     a.uw = (const int32_t *)(ws + l.uw); a.Xu = (const double *)(ws + l.Xu); a.xidx = lat_U > 0 ? 1 : 0;
+    // scheduling hints of tsf_set_cost_hints: for this call if they were given for this many series; used once
+    if (ctx->order_n == N && !theta_in) a.order = ctx->order_dev[ctx->order_next ^ 1];
+    ctx->order_n = 0;
     const int slot = (int)(ctx->ev_count % TSF_PROFILE_RING);
     if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev0[slot], st));
     int lrc;
@@ -1123,6 +1133,29 @@ extern "C" int tsf_selftest_math(tsf_ctx *ctx, int32_t op, int64_t n, const doub
 }
 
 // ---- measurement hooks --------------------------------------------------------------------------
+
+extern "C" int tsf_set_cost_hints(tsf_ctx *ctx, const int32_t *cost, int64_t n)
+{
+    if (!ctx) return -1;
+    ctx->order_n = 0;
+    if (!cost || n <= 0) return 0;
+    if (n > (int64_t)INT32_MAX) return fail(ctx, "tsf_set_cost_hints: too many series");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::vector<int32_t> order((size_t)n);
+    for (int64_t i = 0; i < n; ++i) order[(size_t)i] = (int32_t)i;
+    std::stable_sort(order.begin(), order.end(), [cost](int32_t x, int32_t y) { return cost[x] > cost[y]; });
+    const int b = ctx->order_next;
+    const size_t need = sizeof(int32_t) * (size_t)n;
+    if (ctx->order_cap[b] < need) {
+        if (ctx->order_dev[b]) { HIP_TRY(ctx, hipFree(ctx->order_dev[b])); ctx->order_dev[b] = nullptr; ctx->order_cap[b] = 0; }
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->order_dev[b], need));
+        ctx->order_cap[b] = need;
+    }
+    HIP_TRY(ctx, hipMemcpy(ctx->order_dev[b], order.data(), need, hipMemcpyHostToDevice));
+    ctx->order_next = b ^ 1;
+    ctx->order_n = n;
+    return 0;
+}
 
 extern "C" int tsf_set_profiling(tsf_ctx *ctx, int32_t enable)
 {

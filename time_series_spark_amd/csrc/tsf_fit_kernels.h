@@ -514,6 +514,8 @@ struct FitArgs {
     int32_t *coop_list;                 // [coop_max] series of each slot
     double *coop_slots;                 // [coop_max][coop_stride]
     int coop_max, coop_stride, coop_after, coop_blocks;
+    // scheduling hint (tsf_set_cost_hints): the q-th series the launch starts is order[q]; null = q
+    const int32_t *order;
 };
 
 // ---- checkpoint of a suspended fit (written by fit_kernel, read by fit_coop_kernel) -----------
@@ -637,8 +639,8 @@ __global__ __launch_bounds__(64) void eval_kernel(FitArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     WaveLds<KP, PPL> &lds = *reinterpret_cast<WaveLds<KP, PPL> *>(smem);
-    const int64_t n = blockIdx.x;
-    if (n >= a.N) return;
+    if ((int64_t)blockIdx.x >= a.N) return;
+    const int64_t n = a.order ? (int64_t)a.order[blockIdx.x] : (int64_t)blockIdx.x;
     SeriesView sv;
     make_view<KP, PPL>(a, n, sv);
     for (int i = threadIdx.x; i < TSF_MAX_P + W; i += W) lds.th[i] = 0.0;
@@ -659,8 +661,8 @@ __global__ __launch_bounds__(64, TSF_FIT_WPS) void fit_kernel(FitArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     WaveLds<KP, PPL> &lds = *reinterpret_cast<WaveLds<KP, PPL> *>(smem);
-    const int64_t n = blockIdx.x;
-    if (n >= a.N) return;
+    if ((int64_t)blockIdx.x >= a.N) return;
+    const int64_t n = a.order ? (int64_t)a.order[blockIdx.x] : (int64_t)blockIdx.x;
     if (a.run_flag && (*a.run_flag != 0) != (a.run_if != 0)) return;
     const int lane = threadIdx.x;
     if (a.coop_ctl) atomicAdd(&a.coop_ctl[0], lane == 0 ? 1 : 0);      // (branch-free: see coop_should_suspend)

@@ -1213,8 +1213,8 @@ __global__ __launch_bounds__(NW * 64, quad_waves_per_simd(quad_three_waves(MMODE
         // the readfirstlane below) without lane 0: an endless loop on the hardware.
         int n32 = atomicAdd(qa.counter, lane == 0 ? 1 : 0);
         n32 = __builtin_amdgcn_readfirstlane(n32);
-        const int64_t n = n32;
-        if (n >= a.N) break;
+        if (n32 >= a.N) break;
+        const int64_t n = a.order ? (int64_t)a.order[n32] : (int64_t)n32;   // (cost hints: longest fits first)
         fit_one_quad<KP, PPL, PQ, RAGGED_K, MRS, HLDS,
                      ((quad_three_waves(MMODE, PPL, HLDS) || MMODE == QM_RAGGED_REG || MMODE == QM_GLOBAL_REG) ? 8 : 16),
                      MMODE == QM_RAGGED_REG || MMODE == QM_GLOBAL_REG, NTR, RPOOL>(qa, wlp, rb, Mp, Mown, n, lanec, hist, gx, qw, &pool);

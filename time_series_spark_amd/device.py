@@ -51,6 +51,18 @@ class DeviceForecaster(object):
     def _stream(self):
         return ctypes.c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)
 
+    def set_cost_hints(self, cost):
+        """Scheduling hint for the next fit call with len(cost) series (tsf_set_cost_hints): cost[i] = expected
+        relative cost of series i, e.g. n_eval of the previous fit of the same panel.  None clears."""
+        import numpy as np
+        if cost is None:
+            self.ctx.check(self.L.tsf_set_cost_hints(self.ctx.handle, None, 0))
+            return
+        if hasattr(cost, 'detach'):
+            cost = cost.detach().cpu().numpy()
+        c = np.ascontiguousarray(cost, dtype=np.int32)
+        self.ctx.check(self.L.tsf_set_cost_hints(self.ctx.handle, c.ctypes.data, c.shape[0]))
+
     def set_profiling(self, on=True):
         self.ctx.check(self.L.tsf_set_profiling(self.ctx.handle, int(on)))
 

@@ -280,10 +280,15 @@ def _alloc_out(N, stride, n_grids):
     return out, (theta, y_scale, fval, status, n_iter, n_eval, grid)
 
 
-def fit_aligned(spec, ds_ns, y, floor=None, cap=None, extra=None, ctx=None, devices=None):
+def fit_aligned(spec, ds_ns, y, floor=None, cap=None, extra=None, ctx=None, devices=None, cost_hints=None):
     """Fit N series observed on the same T timestamps.  y: [N][T] float64/float32/int32.
-    devices: see resolve_devices (several GPUs, one host thread each)."""
+    devices: see resolve_devices (several GPUs, one host thread each).
+    cost_hints: optional [N] expected relative cost per series (the `n_eval` of an earlier fit of the same series):
+    the launch starts its longest fits first (tsf_set_cost_hints); results do not depend on it."""
     devs = None if ctx is not None else resolve_devices(devices)
+    ch = None if cost_hints is None else np.ascontiguousarray(cost_hints, dtype=np.int32)
+    if ch is not None and ch.shape != (len(y),):
+        raise ValueError('cost_hints must be [N]')
     if devs and len(y) >= 2 * MIN_SERIES_PER_DEVICE:
         parts = min(len(devs), len(y) // MIN_SERIES_PER_DEVICE)
         fl = _opt_f64(floor, len(y), 'floor')
@@ -295,7 +300,8 @@ def fit_aligned(spec, ds_ns, y, floor=None, cap=None, extra=None, ctx=None, devi
         blocks = [(c, d) for d, c in enumerate(_contexts(devs[:parts]))]
         res = _run_blocks(lambda c, d: fit_aligned(
             spec, ds_ns, np.ascontiguousarray(y[d::parts]), None if fl is None else fl[d::parts],
-            None if cp is None else cp[d::parts], extra, ctx=c), blocks)
+            None if cp is None else cp[d::parts], extra, ctx=c,
+            cost_hints=None if ch is None else ch[d::parts]), blocks)
         return _merge_interleaved(spec, res, len(y), parts)
     ctx = ctx or get_context()
     L = _lib.load()
@@ -303,6 +309,8 @@ def fit_aligned(spec, ds_ns, y, floor=None, cap=None, extra=None, ctx=None, devi
     y = np.ascontiguousarray(y)
     if y.ndim != 2 or y.shape[1] != ds_ns.shape[0]:
         raise ValueError('y must be [N][T] with T == len(ds)')
+    if ch is not None:
+        ctx.check(L.tsf_set_cost_hints(ctx.handle, ch.ctypes.data, ch.shape[0]))
     N, T = y.shape
     cs = spec.to_c()
     floor = _opt_f64(floor, N, 'floor')
