@@ -122,6 +122,34 @@ __device__ __forceinline__ void column_sums(double (&acc)[KP], L &lds)
     }
 }
 
+// G-column slice of the register transpose network of column_sums (above)
+template <int G>
+__device__ __forceinline__ void column_sums_g(double (&acc)[G], double *accR)
+{
+    static_assert(G % 4 == 0, "column groups are multiples of 4");
+    const int lane = lane_id();
+    double c[G / 2];
+#pragma unroll
+    for (int i = 0; i < G / 2; ++i) {
+        double a = acc[2 * i], b = acc[2 * i + 1];
+        swap32(a, b);
+        c[i] = a + b;
+    }
+    double d[G / 4];
+#pragma unroll
+    for (int i = 0; i < G / 4; ++i) {
+        double a = c[2 * i], b = c[2 * i + 1];
+        swap16(a, b);
+        d[i] = row_bfly_sum(a + b);
+    }
+    if ((lane & 15) == 0) {
+        const int r = lane >> 4;
+        const int sub = (r == 0) ? 0 : (r == 1 ? 2 : (r == 2 ? 1 : 3));
+#pragma unroll
+        for (int i = 0; i < G / 4; ++i) accR[4 * i + sub] = d[i];
+    }
+}
+
 // Ascending / descending loop over a run-time range, body written out four times per trip: the
 // recurrences over the changepoints read lanes (v_readlane is convergent, so the compiler does not
 // unroll such loops by itself); unrolled, the lane reads of the next steps issue ahead of the chain
@@ -298,7 +326,12 @@ __device__ __forceinline__ bool eval_tail(const DevSpec *__restrict__ sp, const 
 // MODE: 0 all columns additive, 1 all multiplicative, 2 mixed (Ka additive first)
 // L: the wave's LDS carve-up (WaveLds, or NewtonLds: any struct with th, ks, mc, tp1, tp2, tot1,
 // tot2, d1, d2, rb, ab, accR)
-template <int KP, int GROWTH, int MODE, int PPL, bool XIDX = false, class L = WaveLds<KP, PPL>>
+// GNTR > 0 (wide models, KP > 32, series of <= 64 GNTR rows): the per-column sums in groups of 8 columns AFTER
+// the row pass, with the weights of the rows kept in GNTR registers per lane -- 8 accumulators live instead of KP.
+// With all 64 accumulators live the kernel needs 379 registers (one wave per SIMD, design values through AGPRs);
+// grouped it runs at two.  Column by column the fma chain (rows q descending) and the reduction network are those
+// of the ungrouped form: same bits.
+template <int KP, int GROWTH, int MODE, int PPL, bool XIDX = false, class L = WaveLds<KP, PPL>, int GNTR = 0>
 __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesView &sv,
                                         L &lds, const double (&th)[PPL],
                                         double &f_out, double (&g)[PPL] FT_ARGS)
@@ -329,9 +362,15 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
     FT_LAP(1);
 
     double sse = 0.0, rt1 = 0.0, rt2 = 0.0;
-    double acc[KP];
+    constexpr bool GROUPED = GNTR > 0 && !HOLD;
+    double acc[GROUPED ? 1 : KP];
 #pragma unroll
-    for (int j = 0; j < KP; ++j) acc[j] = 0.0;
+    for (int j = 0; j < (GROUPED ? 1 : KP); ++j) acc[j] = 0.0;
+    double wr[GROUPED ? GNTR : 1], wg[(GROUPED && MODE != 0) ? GNTR : 1];     // r and r * trend of the lane's rows
+#pragma unroll
+    for (int j = 0; j < (GROUPED ? GNTR : 1); ++j) wr[j] = 0.0;
+#pragma unroll
+    for (int j = 0; j < ((GROUPED && MODE != 0) ? GNTR : 1); ++j) wg[j] = 0.0;
     for (int q = NT - 1; q >= 0; --q) {
         if (q < sv.cnt) {
             const int idx = q * W + lane;
@@ -387,6 +426,10 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
             const double r = yi - mu;
             sse = __builtin_fma(r, r, sse);
             const double rg = r * gtr;
+            if constexpr (GROUPED) {
+                wr[GROUPED ? q : 0] = r;
+                if (MODE != 0) wg[(GROUPED && MODE != 0) ? q : 0] = rg;
+            } else {
             // batches of 8 columns: all of acc[] stays in registers, only 8 design values in flight
 #pragma unroll
             for (int j0 = 0; j0 < KP; j0 += 8) {
@@ -404,6 +447,7 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
                 }
                 if (!HOLD) __builtin_amdgcn_sched_barrier(0);
             }
+            }
             double v = r * opm;
             if (GROWTH == 1) v = v * qv;
             rt1 = __builtin_fma(v, ti, rt1);
@@ -417,7 +461,36 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
     const double s1 = suffix_scan(rt1), s2v = suffix_scan(rt2);
     lds.tot1[lane] = s1; lds.tot2[lane] = s2v;
     if (lane == 0) { lds.tot1[W] = 0.0; lds.tot2[W] = 0.0; }
-    column_sums<KP, PPL, L>(acc, lds);
+    if constexpr (GROUPED) {
+        static_assert(!GROUPED || (KP % 8 == 0 && !XIDX), "grouped column sums: aligned step-major design tiles, KP a multiple of 8");
+        // rows past the end of the series: weight 0 (initialised above, never written) against the zero-filled
+        // padding of the design tile: fma(0, 0, acc) leaves acc unchanged, as skipping the row does
+#pragma unroll 1
+        for (int j0 = 0; j0 < KP; j0 += 8) {
+            double ga[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) ga[u] = 0.0;
+#pragma unroll 2
+            for (int q = NT - 1; q >= 0; --q) {
+                const double *xp = sv.Xw + ((size_t)q * KP + j0) * W + lane;
+                double xv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) xv[u] = xp[u * W];
+                const double w_r = wr[GROUPED ? q : 0];
+                const double w_g = (MODE != 0) ? wg[(GROUPED && MODE != 0) ? q : 0] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int j = j0 + u;
+                    if (MODE == 0) ga[u] = __builtin_fma(xv[u], w_r, ga[u]);
+                    else if (MODE == 1) ga[u] = __builtin_fma(xv[u], w_g, ga[u]);
+                    else ga[u] = __builtin_fma(xv[u], (j < Ka) ? w_r : w_g, ga[u]);
+                }
+            }
+            column_sums_g<8>(ga, lds.accR + j0);
+        }
+    } else {
+        column_sums<KP, PPL, L>(acc, lds);
+    }
     TSF_WAVE_SYNC();
     FT_LAP(3);
     const bool bad_ = eval_tail<GROWTH, PPL>(sp, sv, lds, lds, th, sigma, inv_s2, sse_t, f_out, g);
@@ -656,8 +729,8 @@ __global__ __launch_bounds__(64) void eval_kernel(FitArgs a)
 #ifndef TSF_FIT_WPS
 #define TSF_FIT_WPS 1
 #endif
-template <int KP, int GROWTH, int MODE, int PPL, bool XIDX = false>
-__global__ __launch_bounds__(64, TSF_FIT_WPS) void fit_kernel(FitArgs a)
+template <int KP, int GROWTH, int MODE, int PPL, bool XIDX = false, int GNTR = 0>
+__global__ __launch_bounds__(64, GNTR > 0 ? 2 : TSF_FIT_WPS) void fit_kernel(FitArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     WaveLds<KP, PPL> &lds = *reinterpret_cast<WaveLds<KP, PPL> *>(smem);
@@ -785,7 +858,7 @@ __global__ __launch_bounds__(64, TSF_FIT_WPS) void fit_kernel(FitArgs a)
             }
             double f1;
             FT_LAP(0);
-            const bool bad = eval_fg<KP, GROWTH, MODE, PPL, XIDX>(sp, sv, lds, xk1, f1, gk1 FT_PASS);
+            const bool bad = eval_fg<KP, GROWTH, MODE, PPL, XIDX, WaveLds<KP, PPL>, GNTR>(sp, sv, lds, xk1, f1, gk1 FT_PASS);
             f1 = uniform_f64(f1);       // every lane holds the same bits: let the compiler know (scalar branches)
             if (stage == ST_INIT) {
                 if (bad) { ret = TSF_ST_INIT_NONFINITE; fk = f1; break; }

@@ -113,34 +113,6 @@ __device__ __forceinline__ void pool_release(const QuadPool &pl, int i)
 }
 
 
-// G-column slice of the register transpose network of column_sums (tsf_fit_kernels.h)
-template <int G>
-__device__ __forceinline__ void column_sums_g(double (&acc)[G], double *accR)
-{
-    static_assert(G % 4 == 0, "column groups are multiples of 4");
-    const int lane = lane_id();
-    double c[G / 2];
-#pragma unroll
-    for (int i = 0; i < G / 2; ++i) {
-        double a = acc[2 * i], b = acc[2 * i + 1];
-        swap32(a, b);
-        c[i] = a + b;
-    }
-    double d[G / 4];
-#pragma unroll
-    for (int i = 0; i < G / 4; ++i) {
-        double a = c[2 * i], b = c[2 * i + 1];
-        swap16(a, b);
-        d[i] = row_bfly_sum(a + b);
-    }
-    if ((lane & 15) == 0) {
-        const int r = lane >> 4;
-        const int sub = (r == 0) ? 0 : (r == 1 ? 2 : (r == 2 ? 1 : 3));
-#pragma unroll
-        for (int i = 0; i < G / 4; ++i) accR[4 * i + sub] = d[i];
-    }
-}
-
 // NTR > 0: the weights of steps q < NTR are in the register array rr[NTR], those of later steps (series of more
 // than 64 NTR rows) in the staging rows rb
 template <int KP, int G, int NTR = 0>
