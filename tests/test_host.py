@@ -553,6 +553,66 @@ def test_job_layer_follows_fbprophets_optimiser_rule(monkeypatch):
         pm.model_panel(cfg)(df)
 
 
+def test_a_rerun_schedules_its_launches_from_the_previous_runs_models(monkeypatch, tmp_path):
+    """ProphetModeler.model overwrites io.models -- with model.schedule_from_previous_models after reading what the
+    previous run left there: every model blob carries its iteration count, and the next run hands those counts to the
+    library as scheduling hints
+    (tsf_set_cost_hints: longest fits first).  GPU calls replaced by recorders; that hints never change a result is
+    tests/test_gpu_parity.py::test_cost_hints_change_the_order_of_the_launch_and_nothing_else."""
+    seen = []
+
+    def fake_aligned(spec, ds_ns, y, floor=None, cap=None, extra=None, ctx=None, devices=None, cost_hints=None):
+        seen.append(None if cost_hints is None else np.asarray(cost_hints).copy())
+        N = len(y)
+        g = np.zeros(1, dtype=_lib.GRID_DTYPE)
+        g['S'] = 3
+        n_iter = (100 + 10 * np.arange(N)).astype(np.int32)          # series i "took" 100 + 10 i iterations
+        return fc.FitResult(spec, np.zeros((N, spec.theta_stride)), np.ones(N), np.zeros(N),
+                            np.full(N, 31, np.int32), n_iter, 2 * n_iter, g)
+
+    monkeypatch.setattr(fc, 'fit_aligned', fake_aligned)
+    root = tmp_path / 'in'
+    day = np.datetime64('2020-01-01', 'ns') + np.arange(120).astype('timedelta64[D]')
+    for sid in (3, 1, 2):
+        d = root / ('series_id=%d' % sid)
+        d.mkdir(parents=True)
+        with open(d / 'part-00000.csv', 'w') as fh:
+            for i, t in enumerate(day):
+                fh.write('7,%s,%d\n' % (str(t)[:10], 5 + (i * sid) % 9))
+    cfg = {'io': {'input': str(root), 'models': str(tmp_path / 'models')},
+           'model': {'floor': 0, 'cap_multiplier': 1.1, 'schedule_from_previous_models': True,
+                     'prophet': {'growth': 'linear', 'seasonality_mode': 'additive', 'algorithm': 'lbfgs'}}}
+    first = pm.ProphetModeler.model(None, cfg)
+    assert len(first) == 3 and seen == [None]                        # nothing to learn from yet
+    prev = pm.previous_run_cost(cfg['io']['models'])
+    assert sorted(prev['cost']) == [100, 110, 120]
+    seen.clear()
+    # second run: one series gone, one new
+    import shutil
+    shutil.rmtree(root / 'series_id=2')
+    d = root / 'series_id=9'
+    d.mkdir()
+    with open(d / 'part-00000.csv', 'w') as fh:
+        for i, t in enumerate(day):
+            fh.write('7,%s,%d\n' % (str(t)[:10], 3 + i % 4))
+    second = pm.ProphetModeler.model(None, cfg)
+    assert len(second) == 3 and len(seen) == 1
+    order = list(second['series_id'])
+    want = {int(r.series_id): int(r.cost) for r in prev.itertuples()}
+    med = int(np.median(prev['cost']))
+    assert list(seen[0]) == [want.get(s, med) for s in order]        # known series: their count; the new one: the median
+    seen.clear()
+    cfg['model']['schedule_from_previous_models'] = False
+    pm.ProphetModeler.model(None, cfg)
+    assert seen == [None]
+    # a foreign file where the models should be must not fail the run
+    cfg['model']['schedule_from_previous_models'] = True
+    with open(os.path.join(cfg['io']['models'], 'part-00000.parquet'), 'wb') as fh:
+        fh.write(b'not parquet')
+    seen.clear()
+    assert len(pm.ProphetModeler.model(None, cfg)) == 3 and seen == [None]
+
+
 def test_native_csv_reader_cuts_big_files_into_segments(tmp_path):
     """One 10 MB file is parsed by several threads (cut at line ends); same rows, same order,
     and a parse error deep inside still reports its line number in the file."""

@@ -1137,7 +1137,7 @@ __global__ __launch_bounds__(NW * 64) void fit_coop_kernel(FitArgs a)
         const int item = cl.item;
         __syncthreads();
         if (item >= n_ckpt) break;
-        const int64_t n = direct ? item : a.coop_list[item];
+        const int64_t n = direct ? (a.order ? (int64_t)a.order[item] : (int64_t)item) : (int64_t)a.coop_list[item];      // (cost hints: tsf_set_cost_hints)
         SeriesView sv;
         make_view<KP, PPL>(a, n, sv);
         if (direct && a.stab[n].status0 != 0) {

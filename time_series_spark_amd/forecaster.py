@@ -328,10 +328,14 @@ def fit_aligned(spec, ds_ns, y, floor=None, cap=None, extra=None, ctx=None, devi
     return FitResult(spec, *arrs)
 
 
-def fit_ragged(spec, offsets, ds_ns, y, floor=None, cap=None, extra=None, ctx=None, devices=None):
+def fit_ragged(spec, offsets, ds_ns, y, floor=None, cap=None, extra=None, ctx=None, devices=None, cost_hints=None):
     """Fit N series of different lengths / timestamps; series n owns rows
-    offsets[n]:offsets[n+1] of ds_ns / y (each slice sorted by ds, NaN rows removed)."""
+    offsets[n]:offsets[n+1] of ds_ns / y (each slice sorted by ds, NaN rows removed).
+    cost_hints: as in fit_aligned."""
     devs = None if ctx is not None else resolve_devices(devices)
+    ch = None if cost_hints is None else np.ascontiguousarray(cost_hints, dtype=np.int32)
+    if ch is not None and ch.shape != (len(offsets) - 1,):
+        raise ValueError('cost_hints must be [N]')
     if devs and len(offsets) - 1 >= 2 * MIN_SERIES_PER_DEVICE:
         offsets = np.ascontiguousarray(offsets, dtype=np.int64)
         N = len(offsets) - 1
@@ -347,7 +351,8 @@ def fit_ragged(spec, offsets, ds_ns, y, floor=None, cap=None, extra=None, ctx=No
             r0, r1 = int(offsets[a]), int(offsets[b])
             return fit_ragged(spec, offsets[a:b + 1] - r0, ds_ns[r0:r1], y[r0:r1],
                               None if fl is None else fl[a:b], None if cp is None else cp[a:b],
-                              None if ex is None else ex[:, r0:r1], ctx=c)
+                              None if ex is None else ex[:, r0:r1], ctx=c,
+                              cost_hints=None if ch is None else ch[a:b])
         return _merge_fits(spec, _run_blocks(one, blocks), shared_grid=False)
     ctx = ctx or get_context()
     L = _lib.load()
@@ -366,6 +371,8 @@ def fit_ragged(spec, offsets, ds_ns, y, floor=None, cap=None, extra=None, ctx=No
         if ex.shape != (len(spec.extra), y.shape[0]):
             raise ValueError('extra must be [n_extra][total_rows]')
     out, arrs = _alloc_out(N, spec.theta_stride, N)
+    if ch is not None:
+        ctx.check(L.tsf_set_cost_hints(ctx.handle, ch.ctypes.data, ch.shape[0]))
     rc = L.tsf_fit_ragged(ctx.handle, ctypes.byref(cs), N, offsets.ctypes.data, ds_ns.ctypes.data,
                           y.ctypes.data, _lib.y_dtype_code(y), _lib._ptr(floor), _lib._ptr(cap),
                           _lib._ptr(ex), ctypes.byref(out))

@@ -42,15 +42,48 @@ def _prophet_kwargs(config):
     return kw
 
 
+def _hint_kw(h):
+    """cost_hints only where there are any (the keyword stays out of calls without them)"""
+    return {} if h is None else {'cost_hints': h}
+
+
+def previous_run_cost(models):
+    """Expected cost per (series_id, dim_id) from the models of an earlier run: the iteration count stored in every
+    model blob.  models: a frame with series_id, dim_id, model columns, or the path of a model parquet directory
+    (what persist_models wrote).  Returns a frame series_id, dim_id, cost -- or None when there is nothing usable.
+    A launch ends with its longest fits; nothing cheap about a series predicts them except its previous fit."""
+    try:
+        if isinstance(models, str):
+            if not os.path.isdir(models):
+                return None
+            parts = sorted(f for f in os.listdir(models) if f.endswith('.parquet'))
+            if not parts:
+                return None
+            models = pd.concat([pd.read_parquet(os.path.join(models, f)) for f in parts], ignore_index=True)
+        if models is None or len(models) == 0:
+            return None
+        cost = np.zeros(len(models), dtype=np.int64)
+        for _sd, pos, rec in pk.load_models(list(models['model'])):
+            cost[np.asarray(pos)] = rec['n_iter']
+        return pd.DataFrame({'series_id': models['series_id'].to_numpy().astype(np.int64),
+                             'dim_id': models['dim_id'].to_numpy().astype(np.int64), 'cost': cost})
+    except Exception as e:                  # hints are an optimisation: a stale or foreign file must not fail the run
+        print(f"previous models not usable as scheduling hints: {e}")
+        return None
+
+
 def _empty_models():
     return pd.DataFrame(columns=MODEL_OUTPUT_COLUMNS)
 
 
-def fit_packed(panel, floor, cap, kw, devices=None):
+def fit_packed(panel, floor, cap, kw, devices=None, cost=None):
     """Fit every series of a PackedPanel.  Series are bucketed by the seasonality set
     fbprophet's 'auto' rules give their own history (each Prophet object decides alone), one
-    kernel launch per bucket.  Returns per-series (blob | None, status)."""
+    kernel launch per bucket.  Returns per-series (blob | None, status).
+    cost: optional [N] expected relative cost per series (the iteration counts of the previous run's models):
+    scheduling hints for the launches (tsf_set_cost_hints); results do not depend on them."""
     N = panel.N
+    hint = (lambda mem: None) if cost is None else (lambda mem: np.asarray(cost)[mem])
     span, min_dt, _ = pk.per_series_stats(panel)
     growth = kw.get('growth', 'linear')
     mode = kw.get('seasonality_mode', 'additive')
@@ -103,7 +136,7 @@ def fit_packed(panel, floor, cap, kw, devices=None):
             calls.append((gm, fc.fit_aligned(
                 spec, panel.ds_ns[a0:a0 + T], y2d,
                 floor=None if floor is None else np.asarray(floor)[gm],
-                cap=None if cap is None else np.asarray(cap)[gm], extra=ex, devices=devices)))
+                cap=None if cap is None else np.asarray(cap)[gm], extra=ex, devices=devices, **_hint_kw(hint(gm)))))
         if len(rest):
             lens = panel.lengths[rest]
             off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
@@ -115,7 +148,7 @@ def fit_packed(panel, floor, cap, kw, devices=None):
             calls.append((rest, fc.fit_ragged(
                 spec, off, panel.ds_ns[idx], panel.y[idx],
                 floor=None if floor is None else np.asarray(floor)[rest],
-                cap=None if cap is None else np.asarray(cap)[rest], extra=ex, devices=devices)))
+                cap=None if cap is None else np.asarray(cap)[rest], extra=ex, devices=devices, **_hint_kw(hint(rest)))))
         for mem, res in calls:
             st = np.asarray(res.status)
             status[mem] = st
@@ -177,7 +210,7 @@ def _spec_opts(kw):
     return out
 
 
-def _model_packed(config, panel, n_rows, execution_time):
+def _model_packed(config, panel, n_rows, execution_time, previous=None):
     floor = config['model']['floor']                                   # :56-57
     ymax = pk.per_series_stats(panel)[2]
     cap = ymax * config['model']['cap_multiplier']                     # :59-60
@@ -191,7 +224,20 @@ def _model_packed(config, panel, n_rows, execution_time):
         raise ValueError('cap must be greater than floor (which defaults to 0).')
     # config['devices'] (not in the reference): GPUs to spread the series over, e.g. [0, 1, 2, 3]
     # or 'all'; default: TSF_DEVICES, else one GPU
-    blobs, status = fit_packed(panel, floors, cap, kw, devices=config.get('devices'))
+    cost = None
+    if previous is not None and len(previous):
+        # series this run shares with the previous one get its iteration count, new series the median
+        # (one sorted 64-bit key per (series_id, dim_id): a pandas merge of the two key frames costs more than the
+        # hints save on a 10 000-series run)
+        def key64(sid, did):
+            return (np.asarray(sid).astype(np.int64) << 32) | (np.asarray(did).astype(np.int64) & 0xffffffff)
+        pkey = key64(previous['series_id'].to_numpy(), previous['dim_id'].to_numpy())
+        o = np.argsort(pkey, kind='stable')
+        pkey, pcost = pkey[o], previous['cost'].to_numpy()[o]
+        k = key64(panel.keys['series_id'].to_numpy(), panel.keys['dim_id'].to_numpy())
+        at = np.minimum(np.searchsorted(pkey, k), len(pkey) - 1)
+        cost = np.where(pkey[at] == k, pcost[at], int(np.median(pcost))).astype(np.int32)
+    blobs, status = fit_packed(panel, floors, cap, kw, devices=config.get('devices'), cost=cost)
     sids = panel.keys['series_id'].to_numpy()
     dids = panel.keys['dim_id'].to_numpy()
     ok = np.fromiter((b is not None for b in blobs), dtype=bool, count=panel.N)
@@ -221,9 +267,10 @@ def model_panel(config):
     return model_panel_fn
 
 
-def model_arrays(config):
+def model_arrays(config, previous=None):
     """model_panel for columns that never were a DataFrame (what read_model_input returns):
-    series_id, dim_id int64; ds_ns int64 ns; y float64 with NaN for nulls."""
+    series_id, dim_id int64; ds_ns int64 ns; y float64 with NaN for nulls.
+    previous: previous_run_cost(...) of an earlier run, or None."""
 
     def model_arrays_fn(sid, did, ds_ns, y):
         execution_time = time.time()
@@ -232,7 +279,7 @@ def model_arrays(config):
         if np.isinf(y).any():
             raise ValueError('Found infinity in column y.')
         panel = pk.pack_rows(sid, did, ds_ns, y, key_dtypes=(np.int32, np.int32))
-        return _model_packed(config, panel, len(y), execution_time)
+        return _model_packed(config, panel, len(y), execution_time, previous=previous)
 
     return model_arrays_fn
 
@@ -422,8 +469,17 @@ class ProphetModeler:
         """Create the trained time series models (:127-143).  spark_session is accepted for
         signature compatibility and may be None."""
         scorer = ProphetModeler(config)
+        # A re-run overwrites io.models (:123-125).  With config['model']['schedule_from_previous_models'] (not in the
+        # reference; default false) it first reads what the previous run left there: its models carry their iteration
+        # counts, the one cheap predictor of how long each fit takes, and the launches of this run start their longest
+        # fits first.  Results do not depend on it.  It pays where the fit dominates the run (the reference's model on
+        # 100 000 series: 1.00 -> 0.84 s of fit for ~0.2 s of reading the old models); on a 10 000-series run the
+        # 19 ms it takes to read them are more than the launch gains (tools/e2e_bench.py).
+        previous = None
+        if (config.get('model') or {}).get('schedule_from_previous_models', False):
+            previous = previous_run_cost(config['io']['models'])
         # the columns go from the reader to the packer as arrays; read_input_dataframe gives the
         # same rows as a frame for callers that want one
-        model_df = model_arrays(scorer.config)(*scorer.read_input_columns())
+        model_df = model_arrays(scorer.config, previous=previous)(*scorer.read_input_columns())
         scorer.persist_models(model_df)
         return model_df

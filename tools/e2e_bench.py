@@ -38,6 +38,7 @@ def main():
     ap.add_argument('--n', type=int, default=10000)
     ap.add_argument('--t', type=int, default=730)
     ap.add_argument('--kind', default='cfg2', choices=['cfg2', 'reference'])
+    ap.add_argument('--no-hints', action='store_true', help='do not schedule the second pass from the first pass\'s models')
     ap.add_argument('--fake-gpu', action='store_true', help='stand-ins for the GPU calls (host cost only)')
     ap.add_argument('--keep', action='store_true')
     a = ap.parse_args()
@@ -71,8 +72,12 @@ def main():
     try:
         for rep in ('warm-up ', ''):              # first pass pays library load + HIP init
             mo = pm.ProphetModeler(mcfg)
+            # what ProphetModeler.model does: the previous run's models (none in the first pass) give this run its
+            # scheduling hints before they are overwritten
+            prev = stage(rep + 'previous_run_cost (scheduling hints)', pm.previous_run_cost, mcfg['io']['models']) \
+                if not a.no_hints else None
             cols = stage(rep + 'read_input_columns', mo.read_input_columns)
-            models = stage(rep + 'model_arrays (pack + fit + blobs)', lambda c: pm.model_arrays(mcfg)(*c), cols)
+            models = stage(rep + 'model_arrays (pack + fit + blobs)', lambda c: pm.model_arrays(mcfg, previous=prev)(*c), cols)
             stage(rep + 'persist_models', mo.persist_models, models)
             sc = ps.ProphetScorer(scfg)
             mdf = stage(rep + 'read_model_dataframe', sc.read_model_dataframe)
