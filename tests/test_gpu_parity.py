@@ -581,14 +581,18 @@ def test_batched_job_is_independent_of_how_series_are_grouped(env):
     rows += [(9, 7, np.datetime64(int(t) + 3600 * 10 ** 9, 'ns'), int(v)) for t, v in zip(ds[:300], y[0][:300])]
     df = pd.DataFrame(rows, columns=['series_id', 'dim_id', 'ds', 'y'])
     config = {'model': {'floor': 0, 'cap_multiplier': 1.1}}
-    both = pm.model_panel(config)(df.copy())
-    assert len(both) == 6
     udf = pm.model_time_series(config)
-    for (sid, did), grp in df.groupby(['series_id', 'dim_id']):
-        one = udf(grp.copy())
-        row = both[(both['series_id'] == sid) & (both['dim_id'] == did)]
-        assert bytes(one['model'].iloc[0]) == bytes(row['model'].iloc[0]), sid
-        assert one['cap'].iloc[0] == row['cap'].iloc[0]
+    singles = {(sid, did): udf(grp.copy()) for (sid, did), grp in df.groupby(['series_id', 'dim_id'])}
+    # groups of any size through the aligned entry point (min_aligned_group 2: three launches + one ragged call), and
+    # the default policy (groups of fewer than 4 096 series join the ragged call: one launch)
+    for prophet in ({'min_aligned_group': 2}, {}):
+        cfg = {'model': dict(config['model'], prophet=dict({'growth': 'logistic', 'seasonality_mode': 'multiplicative'}, **prophet))}
+        both = pm.model_panel(cfg)(df.copy())
+        assert len(both) == 6
+        for (sid, did), one in singles.items():
+            row = both[(both['series_id'] == sid) & (both['dim_id'] == did)]
+            assert bytes(one['model'].iloc[0]) == bytes(row['model'].iloc[0]), (sid, prophet)
+            assert one['cap'].iloc[0] == row['cap'].iloc[0]
 
 
 def test_odd_shapes_against_oracle(env):
