@@ -535,7 +535,8 @@ def test_job_layer_follows_fbprophets_optimiser_rule(monkeypatch):
     for sid, T in enumerate([150, 150, 150, 60, 60, 99]):
         rows += [(sid, 1, d, 5 + (i * (sid + 1)) % 7) for i, d in enumerate(day[:T])]
     df = pd.DataFrame(rows, columns=['series_id', 'dim_id', 'ds', 'y'])
-    cfg = {'model': {'floor': 0, 'cap_multiplier': 1.1, 'prophet': {'growth': 'linear', 'seasonality_mode': 'additive'}}}
+    cfg = {'model': {'floor': 0, 'cap_multiplier': 1.1, 'prophet': {'growth': 'linear', 'seasonality_mode': 'additive',
+                                                                     'min_aligned_group': 2}}}     # (default 4 096: see below)
     out = pm.model_panel(cfg)(df)
     assert len(out) == 6                                     # the failed L-BFGS series came back through Newton
     assert calls == [('aligned', _lib.ALGO_LBFGS, (3, 150)),       # T >= 100 together
@@ -544,6 +545,14 @@ def test_job_layer_follows_fbprophets_optimiser_rule(monkeypatch):
                      ('ragged', _lib.ALGO_NEWTON, (99,))]
     (sd, pos, rec), = pk.load_models(list(out['model']))     # one spec for all: no optimiser in it
     assert 'algorithm' not in sd['lbfgs'] and list(rec['status']) == [60, 31, 31, 60, 60, 60]
+    # default grouping policy: a group of series sharing their timestamps is a launch of its own only from 4 096 series
+    # on (or when it is the whole bucket): the two 60-row series join the ragged call of the 99-row one
+    calls.clear()
+    del cfg['model']['prophet']['min_aligned_group']
+    assert len(pm.model_panel(cfg)(df)) == 6
+    assert calls == [('aligned', _lib.ALGO_LBFGS, (3, 150)), ('ragged', _lib.ALGO_NEWTON, (150,)),
+                     ('ragged', _lib.ALGO_NEWTON, (60, 60, 99))]
+    cfg['model']['prophet']['min_aligned_group'] = 2
     calls.clear()
     cfg['model']['prophet']['algorithm'] = 'lbfgs'
     out = pm.model_panel(cfg)(df)
