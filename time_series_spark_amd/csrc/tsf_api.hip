@@ -40,6 +40,8 @@ struct tsf_ctx {
     size_t order_cap[2];    // turn: a fit that is still running on its stream keeps reading the one it was given)
     int order_next;
     int64_t order_n;        // series count the pending hints are for (0: none pending)
+    hipEvent_t order_ev[2]; // recorded behind the launch that reads order_dev[b]: the buffer is rewritten only after it
+    int order_busy[2];
     int n_cu;               // compute units of the device (persistent kernels: one workgroup each)
     int profiling;
     hipEvent_t ev0[TSF_PROFILE_RING], ev1[TSF_PROFILE_RING];
@@ -81,6 +83,7 @@ extern "C" int tsf_create(int device_id, tsf_ctx **out)
     c->fut_tab = nullptr; c->fut_tab_bytes = 0;
     c->nb_ws = nullptr; c->nb_ws_bytes = 0;
     c->order_dev[0] = c->order_dev[1] = nullptr; c->order_cap[0] = c->order_cap[1] = 0; c->order_next = 0; c->order_n = 0;
+    c->order_ev[0] = c->order_ev[1] = nullptr; c->order_busy[0] = c->order_busy[1] = 0;
     c->profiling = 0; c->ev_created = 0; c->ev_count = 0;
     if (hipMalloc((void **)&c->d_spec, sizeof(DevSpec)) != hipSuccess) { delete c; return -2; }
     {
@@ -112,7 +115,7 @@ extern "C" void tsf_destroy(tsf_ctx *ctx)
     if (ctx->d_spec) hipFree(ctx->d_spec);
     if (ctx->fut_tab) hipFree(ctx->fut_tab);
     if (ctx->nb_ws) hipFree(ctx->nb_ws);
-    for (int b = 0; b < 2; ++b) if (ctx->order_dev[b]) hipFree(ctx->order_dev[b]);
+    for (int b = 0; b < 2; ++b) { if (ctx->order_dev[b]) hipFree(ctx->order_dev[b]); if (ctx->order_ev[b]) hipEventDestroy(ctx->order_ev[b]); }
     if (ctx->ev_created)
         for (int i = 0; i < TSF_PROFILE_RING; ++i) { hipEventDestroy(ctx->ev0[i]); hipEventDestroy(ctx->ev1[i]); }
     delete ctx;
@@ -477,7 +480,8 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     a.theta_in = theta_in; a.grad_out = grad_out;
     a.uw = (const int32_t *)(ws + l.uw); a.Xu = (const double *)(ws + l.Xu); a.xidx = lat_U > 0 ? 1 : 0;
     // scheduling hints of tsf_set_cost_hints: for this call if they were given for this many series; used once
-    if (ctx->order_n == N && !theta_in) a.order = ctx->order_dev[ctx->order_next ^ 1];
+    const int order_buf = (ctx->order_n == N && !theta_in) ? (ctx->order_next ^ 1) : -1;
+    if (order_buf >= 0) a.order = ctx->order_dev[order_buf];
     ctx->order_n = 0;
     const int slot = (int)(ctx->ev_count % TSF_PROFILE_RING);
     if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev0[slot], st));
@@ -561,6 +565,11 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
         lrc = pick_launch(hs.growth, mode)(hs.KP, a, theta_in != nullptr, st);
     }
     if (ctx->profiling) { HIP_TRY(ctx, hipEventRecord(ctx->ev1[slot], st)); ctx->ev_count++; }
+    if (order_buf >= 0) {       // the launch above reads the hint buffer: tsf_set_cost_hints waits for this before rewriting it
+        if (!ctx->order_ev[order_buf]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->order_ev[order_buf], hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventRecord(ctx->order_ev[order_buf], st));
+        ctx->order_busy[order_buf] = 1;
+    }
     if (lrc != 0) {
         ctx->err = std::string("kernel launch failed: ") + (lrc > 0 ? hipGetErrorString((hipError_t)lrc) : "no kernel for this shape");
         return -2;
@@ -1151,6 +1160,10 @@ extern "C" int tsf_set_cost_hints(tsf_ctx *ctx, const int32_t *cost, int64_t n)
     for (int64_t i = 0; i < n; ++i) order[(size_t)i] = (int32_t)i;
     std::stable_sort(order.begin(), order.end(), [cost](int32_t x, int32_t y) { return cost[x] > cost[y]; });
     const int b = ctx->order_next;
+    if (ctx->order_busy[b]) {   // a fit two calls back may still be reading this buffer on its stream
+        HIP_TRY(ctx, hipEventSynchronize(ctx->order_ev[b]));
+        ctx->order_busy[b] = 0;
+    }
     const size_t need = sizeof(int32_t) * (size_t)n;
     if (ctx->order_cap[b] < need) {
         if (ctx->order_dev[b]) { HIP_TRY(ctx, hipFree(ctx->order_dev[b])); ctx->order_dev[b] = nullptr; ctx->order_cap[b] = 0; }
