@@ -5,6 +5,7 @@
  * out: N*stride theta, then N*H yhat, then N (status, n_iter, n_eval as doubles). */
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "tsf.h"
 
@@ -49,6 +50,19 @@ int main(int argc, char **argv)
     out.grid = &grid;
     int rc = tsf_fit_aligned(ctx, &spec, N, T, ds, y, TSF_Y_F64, NULL, NULL, NULL, &out);
     if (rc != 0) { fprintf(stderr, "fit rc=%d: %s\n", rc, tsf_last_error(ctx)); return 4; }
+    /* the same fit again with the evaluation counts of the first one as scheduling hints (tsf_set_cost_hints):
+     * the launch starts its longest fits first, and not a bit of the result may change */
+    {
+        double *theta0 = malloc((size_t)(N * stride) * sizeof(double));
+        int32_t *hints = malloc((size_t)N * sizeof(int32_t));
+        memcpy(theta0, out.theta, (size_t)(N * stride) * sizeof(double));
+        memcpy(hints, out.n_eval, (size_t)N * sizeof(int32_t));
+        if (tsf_set_cost_hints(ctx, hints, N) != 0) { fprintf(stderr, "hints: %s\n", tsf_last_error(ctx)); return 7; }
+        rc = tsf_fit_aligned(ctx, &spec, N, T, ds, y, TSF_Y_F64, NULL, NULL, NULL, &out);
+        if (rc != 0) { fprintf(stderr, "hinted fit rc=%d: %s\n", rc, tsf_last_error(ctx)); return 8; }
+        if (memcmp(theta0, out.theta, (size_t)(N * stride) * sizeof(double)) != 0) { fprintf(stderr, "hints changed a result\n"); return 9; }
+        free(theta0); free(hints);
+    }
     double *yhat = calloc((size_t)(N * H), sizeof(double));
     rc = tsf_predict(ctx, &spec, N, H, out.theta, out.y_scale, &grid, 1, fut, 1, NULL, NULL, NULL, yhat, NULL);
     if (rc != 0) { fprintf(stderr, "predict rc=%d: %s\n", rc, tsf_last_error(ctx)); return 5; }

@@ -933,6 +933,16 @@ def test_cost_hints_change_the_order_of_the_launch_and_nothing_else(env):
     fc, cl = env
     from time_series_spark_amd import synth
     rng = np.random.default_rng(5)
+    # ragged entry point (quadratic form: the queue of the ragged kernel)
+    ds, y = synth.make_panel(900, 400, 'linear', seed=80)
+    lens = 330 + (np.arange(900) * 13) % 71
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    dsr = np.concatenate([ds[:c] for c in lens]); yr = np.concatenate([y[i][:c] for i, c in enumerate(lens)])
+    spec = fc.ModelSpec(growth='linear', seasonalities=fc.ModelSpec.auto_seasonalities(ds))
+    base = fc.fit_ragged(spec, off, dsr, yr)
+    hinted = fc.fit_ragged(spec, off, dsr, yr, cost_hints=base.n_eval)
+    for name in ('theta', 'fval', 'n_iter', 'n_eval', 'status', 'y_scale'):
+        assert np.array_equal(getattr(base, name), getattr(hinted, name), equal_nan=True), ('ragged', name)
     for growth, N, T in (('linear', 7000, 730), ('logistic', 600, 365)):
         ds, y = synth.make_panel(N, T, growth, seed=79)
         kw = {} if growth == 'linear' else {'floor': np.zeros(N), 'cap': y.max(axis=1) * 1.1}
