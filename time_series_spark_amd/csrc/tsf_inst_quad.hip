@@ -98,7 +98,17 @@ static int launch_quad_one(const QuadPlan &qp, const QuadArgs &qa, double *Mg, h
         }
         return launch_quad_aligned1(KP, qp, qa, Mg, st);   // tsf_inst_quad3.hip
     }
-    else return launch_quad_mm<KP, PPL, QM_GLOBAL, PQ>(qp, qa, Mg, st);
+    else {
+        // Two parameters per lane (64 < P <= 128).  Z^T Z is [P4][2][64] doubles: up to P4 = 88 it fits in LDS beside
+        // the state of the kernel's four waves (cfg2 + 30 holiday columns, P4 = 84: 86 KB + 4 x 17 KB), and an
+        // evaluation then reads its 86 KB from LDS instead of L2.  TSF_QUAD_M2_LDS=0: from L2 as before.
+        const char *e = getenv("TSF_QUAD_M2_LDS");
+        constexpr int NW = QuadShape<PPL, QM_LDS>::NW;
+        const size_t lds = sizeof(double) * (size_t)qp.P4 * PPL * W + quad_lanec_bytes<PPL>() +
+                           (sizeof(QuadLds<KP, PPL>) + quad_hist_bytes<PPL>(true)) * NW;
+        if (lds <= 160 * 1024 && !(e && atoi(e) == 0)) return launch_quad_mm<KP, PPL, QM_LDS, PQ>(qp, qa, Mg, st);
+        return launch_quad_mm<KP, PPL, QM_GLOBAL, PQ>(qp, qa, Mg, st);
+    }
 }
 
 int launch_quad(int KP, const QuadPlan &qp, const QuadArgs &qa, double *Mg, hipStream_t st)
