@@ -8,7 +8,7 @@
 namespace tsf {
 
 // the most waves per workgroup any variant for this PPL launches (workspace slots: tsf_api.hip quad_plan)
-int quad_waves_per_block(int PPL) { return PPL == 2 ? TSF_QUAD_NW2 : TSF_QUAD_NW4; }
+int quad_waves_per_block(int PPL) { return PPL == 2 ? (TSF_QUAD_NW2G > TSF_QUAD_NW2 ? TSF_QUAD_NW2G : TSF_QUAD_NW2) : TSF_QUAD_NW4; }
 static_assert(TSF_QUAD_NW4 >= TSF_QUAD_NW3 && TSF_QUAD_NW4 >= TSF_QUAD_NW, "workspace slots are sized for the widest workgroup");
 
 // ragged panel, Z^T Z of every resident wave in LDS: NWR waves per workgroup (tsf_quad_kernels.h

@@ -33,6 +33,9 @@
 #ifndef TSF_QUAD_W4_DEFAULT
 #define TSF_QUAD_W4_DEFAULT -1      // -1: the 16-wave kernel wherever it fits; 0: never
 #endif
+#ifndef TSF_QUAD_NW2G
+#define TSF_QUAD_NW2G 8     // two-slot kernel, Z^T Z read from L2
+#endif
 #ifndef TSF_QUAD_NW2
 #define TSF_QUAD_NW2 4      // two-slot kernel (P > 64): twice the per-wave LDS
 #endif
@@ -44,7 +47,8 @@ namespace tsf {
 template <int PPL, int MMODE>
 struct QuadShape {
     static constexpr bool HL = true;        // L-BFGS history in LDS (these variants have the room)
-    static constexpr int NW = (PPL == 2) ? TSF_QUAD_NW2 : (quad_three_waves(MMODE, PPL, HL) ? TSF_QUAD_NW3 : TSF_QUAD_NW);
+    // (two-slot kernel with Z^T Z in L2: no matrix in LDS, room for eight waves -- two per SIMD at 215 registers)
+    static constexpr int NW = (PPL == 2) ? (MMODE == QM_GLOBAL ? TSF_QUAD_NW2G : TSF_QUAD_NW2) : (quad_three_waves(MMODE, PPL, HL) ? TSF_QUAD_NW3 : TSF_QUAD_NW);
 };
 
 // RPOOL: the 16-waves-per-CU kernel (four per SIMD) with pool_slots shared copies of the trend tables
