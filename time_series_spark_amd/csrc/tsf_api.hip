@@ -552,12 +552,13 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
             // parameters per lane (KP = 64): that kernel needs > 256 registers (one wave per SIMD) and
             // measures 9.6 M evaluations/s on 50 000 x 730 with 56 columns, the workgroup kernel 11.4+ M.
             a.coop_after = spec->residual_kernel == TSF_RK_COOP ? COOP_DIRECT : spec->coop_after;
-            // (Round 3 also gave the one-wave kernel of these models grouped column sums -- eval_fg GNTR: 187 instead of
-            // 379 registers, two waves per SIMD -- which makes it 1.45 x faster, 13.9 M evaluations/s on cfg4, and still
-            // slower than the workgroup kernel's 15.4 M: both read the 374 KB design matrix twice per evaluation through
-            // L1, 10 TB/s of it.  TSF_FIT_GROUPED=1 takes that route for series of <= 768 rows.)
+            // Round 3: on series of <= 768 rows the one-wave kernel of these models takes its per-column sums in groups
+            // of 8 (eval_fg GNTR: 187 instead of 379 registers, two waves per SIMD) and allocates only the history pairs
+            // it uses (wave_lds_bytes: eight blocks per CU instead of six): 17.0 M evaluations/s on cfg4 against the
+            // workgroup kernel's 15.4 M (2.27 against 2.50 s) -- so AUTO runs it, with the workgroup kernel for the tail
+            // as for the narrower models.  TSF_FIT_GROUPED=0: every series on the workgroup kernel, as before.
             const char *eg = getenv("TSF_FIT_GROUPED");
-            const bool grouped = NTmax <= 12 && eg && atoi(eg) != 0 && lat_U == 0;
+            const bool grouped = NTmax <= 12 && !(eg && atoi(eg) == 0) && lat_U == 0;
             if (spec->residual_kernel == TSF_RK_AUTO && spec->coop_after < 0 && hs.KP == 64 && !grouped) a.coop_after = COOP_DIRECT;
             a.coop_blocks = ctx->n_cu;
             HIP_TRY(ctx, hipMemsetAsync(a.coop_ctl, 0, 4 * sizeof(int), st));

@@ -854,7 +854,7 @@ __device__ __forceinline__ void coop_owner(const FitArgs &a, SeriesView &sv, int
             double sv_[PPL], yv_[PPL];
             coop_get_vec<PPL>(slot, 6 + h, sv_); coop_get_vec<PPL>(slot, 6 + MAXH + h, yv_);
 #pragma unroll
-            for (int s = 0; s < PPL; ++s) { lds.Sb[(h * PPL + s) * W + lane] = sv_[s]; lds.Yb[(h * PPL + s) * W + lane] = yv_[s]; }
+            for (int s = 0; s < PPL; ++s) { lds.SY[((2 * h) * PPL + s) * W + lane] = sv_[s]; lds.SY[((2 * h + 1) * PPL + s) * W + lane] = yv_[s]; }
         }
         if (lane < MAXH) lds.rho[lane] = slot[COOP_VARS_D + lane];
         TSF_WAVE_SYNC();
@@ -1026,8 +1026,8 @@ __device__ __forceinline__ void coop_owner(const FitArgs &a, SeriesView &sv, int
                     if (lane == 0) lds.rho[hs] = rho_new;
 #pragma unroll
                     for (int s = 0; s < PPL; ++s) {
-                        lds.Sb[(hs * PPL + s) * W + lane] = sk[s];
-                        lds.Yb[(hs * PPL + s) * W + lane] = yk[s];
+                        lds.SY[((2 * hs) * PPL + s) * W + lane] = sk[s];
+                        lds.SY[((2 * hs + 1) * PPL + s) * W + lane] = yk[s];
                     }
                 }
                 TSF_WAVE_SYNC();
@@ -1038,8 +1038,8 @@ __device__ __forceinline__ void coop_owner(const FitArgs &a, SeriesView &sv, int
                     double si[PPL], yi[PPL];
 #pragma unroll
                     for (int s = 0; s < PPL; ++s) {
-                        si[s] = lds.Sb[(hs * PPL + s) * W + lane];
-                        yi[s] = lds.Yb[(hs * PPL + s) * W + lane];
+                        si[s] = lds.SY[((2 * hs) * PPL + s) * W + lane];
+                        yi[s] = lds.SY[((2 * hs + 1) * PPL + s) * W + lane];
                     }
                     const double aa = lane63(lds.rho[hs] * pdot_l63<PPL>(si, pk));
 #pragma unroll
@@ -1054,8 +1054,8 @@ __device__ __forceinline__ void coop_owner(const FitArgs &a, SeriesView &sv, int
                     double si[PPL], yi[PPL];
 #pragma unroll
                     for (int s = 0; s < PPL; ++s) {
-                        si[s] = lds.Sb[(hs * PPL + s) * W + lane];
-                        yi[s] = lds.Yb[(hs * PPL + s) * W + lane];
+                        si[s] = lds.SY[((2 * hs) * PPL + s) * W + lane];
+                        yi[s] = lds.SY[((2 * hs + 1) * PPL + s) * W + lane];
                     }
                     const double cc = lane63(lds.alphas[h] - lds.rho[hs] * pdot_l63<PPL>(yi, pk));
 #pragma unroll

@@ -1,6 +1,7 @@
 // tsf_fit_kernels.h -- the fit / eval kernel templates (see tsf_common.h for the execution
 // model and the canonical-arithmetic contract).  Instantiated by tsf_inst_g*m*.hip.
 #pragma once
+#include <cstddef>
 #include "tsf_common.h"
 
 namespace tsf {
@@ -60,8 +61,18 @@ struct WaveLds {
     double d1[NTAB + 1], d2[NTAB + 1], rb[NTAB + 1], ab[NTAB + 1];
     double rho[MAXH], alphas[MAXH];
     double accR[KP];                   // per-column sums X^T r
-    double Sb[MAXH * PPL * W], Yb[MAXH * PPL * W];
+    // L-BFGS history, LAST and interleaved -- pair h: s at [(2h) PPL + slot][64], y at [(2h + 1) PPL + slot][64] -- so that a
+    // launch allocates only the `history` pairs it uses (wave_lds_bytes): with all MAXH = 8 pairs a two-slot block took
+    // 23.7 KB, six blocks per CU; with Stan's five pairs 17.7 KB, eight
+    double SY[2 * MAXH * PPL * W];
 };
+template <int KP, int PPL>
+inline size_t wave_lds_bytes(int history)
+{
+    const int H = history > MAXH ? MAXH : (history < 1 ? 1 : history);
+    using WL = WaveLds<KP, PPL>;
+    return offsetof(WL, SY) + sizeof(double) * 2 * (size_t)H * PPL * W;
+}
 
 // LDS hand-off inside one wave (see wave_sync in tsf_common.h); never a workgroup barrier, so
 // the same code runs in one-wave and in multi-wave workgroups
@@ -948,8 +959,8 @@ __global__ __launch_bounds__(64, GNTR > 0 ? 2 : TSF_FIT_WPS) void fit_kernel(Fit
                     if (lane == 0) lds.rho[slot] = rho_new;
 #pragma unroll
                     for (int s = 0; s < PPL; ++s) {
-                        lds.Sb[(slot * PPL + s) * W + lane] = sk[s];
-                        lds.Yb[(slot * PPL + s) * W + lane] = yk[s];
+                        lds.SY[((2 * slot) * PPL + s) * W + lane] = sk[s];
+                        lds.SY[((2 * slot + 1) * PPL + s) * W + lane] = yk[s];
                     }
                 }
                 TSF_WAVE_SYNC();
@@ -960,8 +971,8 @@ __global__ __launch_bounds__(64, GNTR > 0 ? 2 : TSF_FIT_WPS) void fit_kernel(Fit
                     double si[PPL], yi[PPL];
 #pragma unroll
                     for (int s = 0; s < PPL; ++s) {
-                        si[s] = lds.Sb[(slot * PPL + s) * W + lane];
-                        yi[s] = lds.Yb[(slot * PPL + s) * W + lane];
+                        si[s] = lds.SY[((2 * slot) * PPL + s) * W + lane];
+                        yi[s] = lds.SY[((2 * slot + 1) * PPL + s) * W + lane];
                     }
                     const double aa = lane63(lds.rho[slot] * pdot_l63<PPL>(si, pk));
 #pragma unroll
@@ -976,8 +987,8 @@ __global__ __launch_bounds__(64, GNTR > 0 ? 2 : TSF_FIT_WPS) void fit_kernel(Fit
                     double si[PPL], yi[PPL];
 #pragma unroll
                     for (int s = 0; s < PPL; ++s) {
-                        si[s] = lds.Sb[(slot * PPL + s) * W + lane];
-                        yi[s] = lds.Yb[(slot * PPL + s) * W + lane];
+                        si[s] = lds.SY[((2 * slot) * PPL + s) * W + lane];
+                        yi[s] = lds.SY[((2 * slot + 1) * PPL + s) * W + lane];
                     }
                     const double cc = lane63(lds.alphas[h] - lds.rho[slot] * pdot_l63<PPL>(yi, pk));
 #pragma unroll
@@ -1029,7 +1040,7 @@ __global__ __launch_bounds__(64, GNTR > 0 ? 2 : TSF_FIT_WPS) void fit_kernel(Fit
         for (int h = 0; h < H; ++h) {
             double hs_[PPL], hy_[PPL];
 #pragma unroll
-            for (int s = 0; s < PPL; ++s) { hs_[s] = lds.Sb[(h * PPL + s) * W + lane]; hy_[s] = lds.Yb[(h * PPL + s) * W + lane]; }
+            for (int s = 0; s < PPL; ++s) { hs_[s] = lds.SY[((2 * h) * PPL + s) * W + lane]; hy_[s] = lds.SY[((2 * h + 1) * PPL + s) * W + lane]; }
             coop_put_vec<PPL>(slot, 6 + h, hs_); coop_put_vec<PPL>(slot, 6 + MAXH + h, hy_);
         }
         return;
