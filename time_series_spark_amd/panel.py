@@ -151,22 +151,34 @@ def rows_2d(arr, off, members, T):
     return arr[off[members][:, None] + np.arange(T, dtype=np.int64)[None, :]]
 
 
-def group_by_grid(panel, members, min_group=2):
+def group_by_grid(panel, members, min_group=2, keep_single=False):
     """Partition `members` (series indices of a PackedPanel) by identical timestamp vector.
     Returns (groups, rest): groups = list of index arrays (each >= min_group series sharing one
     grid, to be fitted through the aligned entry point: one set of design tables, shared through
     L2 / LDS by every series of the group), rest = the series whose grid nobody shares.
+    keep_single: members that ALL share one grid form a group whatever their number (>= 2).
     Results do not depend on the grouping (the evaluation form is a property of the model and the
     aligned / ragged kernels are bit-identical); only the speed does."""
     members = np.asarray(members, dtype=np.int64)
     if len(members) == 0:
         return [], members
-    if panel.aligned and len(members) == panel.N and len(members) >= min_group:
+    if panel.aligned and len(members) == panel.N and len(members) >= (2 if keep_single else min_group):
         return [np.sort(members)], np.zeros(0, dtype=np.int64)
     off = panel.offsets
     lens = panel.lengths[members]
     if (panel.lengths <= 0).any():           # empty series present: treat everything as ragged
         return [], members
+    # cheap necessary condition first: series that share a grid share its length, first and last timestamp.  When no
+    # such class is large enough there is nothing to hash (the signature below reads every row of the panel)
+    first = panel.ds_ns[off[:-1][members]]
+    last = panel.ds_ns[off[1:][members] - 1]
+    o3 = np.lexsort((last, first, lens))
+    k3 = np.stack([lens[o3], first[o3], last[o3]], axis=1)
+    cut = np.flatnonzero((k3[1:] != k3[:-1]).any(axis=1)) + 1
+    sizes = np.diff(np.concatenate([[0], cut, [len(members)]]))
+    need = 2 if (keep_single and len(sizes) == 1) else min_group
+    if sizes.max() < need:
+        return [], np.sort(members)
     # 64-bit signature of every grid: length and a position-weighted wrap-around sum of ds
     pos = np.arange(len(panel.ds_ns), dtype=np.uint64) - np.repeat(off[:-1].astype(np.uint64), panel.lengths)
     w = (pos * np.uint64(0x9E3779B97F4A7C15) + np.uint64(0xD1B54A32D192ED03))
@@ -176,8 +188,11 @@ def group_by_grid(panel, members, min_group=2):
     ms, ls, ss = members[order], lens[order], sig[order]
     brk = np.flatnonzero((ls[1:] != ls[:-1]) | (ss[1:] != ss[:-1])) + 1
     groups, rest = [], []
-    for chunk in np.split(ms, brk):
-        if len(chunk) < min_group:
+    chunks = np.split(ms, brk)
+    if keep_single and len(chunks) == 1:
+        min_group = 2
+    for chunk in chunks:
+        if len(chunk) < min_group:              # (before the row-by-row comparison: small groups cost nothing)
             rest.extend(chunk.tolist())
             continue
         T = int(panel.lengths[chunk[0]])
