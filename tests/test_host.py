@@ -262,6 +262,21 @@ def test_group_by_grid_partitions_by_identical_timestamps():
     assert groups == [] and rest.tolist() == [0, 2, 4]
     groups, rest = pk.group_by_grid(p, np.arange(p.N), min_group=3)
     assert [g.tolist() for g in groups] == [[0, 1, 3]] and rest.tolist() == [2, 4, 5, 6]
+    # the job layer's policy: groups from min_group series on -- nothing is hashed or compared when no class of equal
+    # (length, first, last) is that large -- but members that ALL share one grid stay a group whatever their number
+    groups, rest = pk.group_by_grid(p, np.arange(p.N), min_group=4096, keep_single=True)
+    assert groups == [] and rest.tolist() == list(range(p.N))
+    groups, rest = pk.group_by_grid(p, np.array([0, 1, 3]), min_group=4096, keep_single=True)
+    assert [g.tolist() for g in groups] == [[0, 1, 3]] and rest.tolist() == []
+    groups, rest = pk.group_by_grid(p, np.array([0, 1, 3]), min_group=4096)
+    assert groups == [] and rest.tolist() == [0, 1, 3]
+    # same length, first and last timestamp, different interior: the cheap classes match, the rows do not
+    g2 = ds.to_series().reset_index(drop=True)
+    g2[5] = g2[5] + pd.Timedelta(hours=3)
+    rows2 = [(0, 0, t, 1.0) for t in ds] + [(1, 0, t, 2.0) for t in g2]
+    p2 = pk.pack_long_frame(pd.DataFrame(rows2, columns=['series_id', 'dim_id', 'ds', 'y']))
+    groups, rest = pk.group_by_grid(p2, np.arange(2), keep_single=True)
+    assert groups == [] and rest.tolist() == [0, 1]
 
 
 @pytest.mark.parametrize('case', ['shuffled', 'grouped_unsorted', 'packed', 'nan_rows', 'single_rows',
