@@ -92,13 +92,14 @@ def build(name):
         spec = fc.ModelSpec(growth='logistic', seasonality_mode='multiplicative', seasonalities=seas)
         return ('100 x 365, reference settings (logistic, floor 0, cap 1.1 max y, multiplicative, auto seasonalities)',
                 spec, ds, y, np.zeros(N), y.max(axis=1) * 1.1, None, None, T * 8 + (3 + 25 + spec.K) * 8 + H * 8)
-    if name == 'cfg3':
-        N, T = 12500, 1095       # one GPU's share of 100 000 series over 8 GPUs
+    if name in ('cfg3', 'cfg3_full'):
+        # cfg3: one GPU's share of 100 000 series over 8 GPUs; cfg3_full: BASELINE's whole panel on one GPU (876 MB of y)
+        N, T = (12500 if name == 'cfg3' else 100000), 1095
         ds, y = synth.make_panel(N, T, 'linear', seed=751)
         seas = fc.ModelSpec.auto_seasonalities(ds)
         spec = fc.ModelSpec(growth='linear', seasonalities=seas)
-        return ('12500 x 1095 (1/8 of cfg3) linear additive, yearly on by auto', spec, ds, y, None, None,
-                None, None, T * 8 + (3 + 25 + spec.K) * 8 + H * 8)
+        return ('%d x 1095 (%s cfg3) linear additive, yearly on by auto' % (N, '1/8 of' if name == 'cfg3' else 'all of'),
+                spec, ds, y, None, None, None, None, T * 8 + (3 + 25 + spec.K) * 8 + H * 8)
     if name == 'cfg4':
         N, T = 50000, 730
         ds = synth.daily_grid(T)
