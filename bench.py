@@ -11,10 +11,15 @@ of that fit + predict over the whole panel with the panel already resident in HB
   (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
 Multi-GPU: series are sharded by id, one rank per GPU, no data-path collective;
-torch.distributed (RCCL) only brackets the timed regions.  `value` is WEAK scaling (every rank
-fits its own 10 000-series panel); for N > 1 the same line also carries `strong_scaling`: the
-BASELINE metric's "10k x 730 panel at 1/2/4/8 GPUs" read literally -- ONE 10 000-series panel
-split over the ranks (series i on rank i mod N), timed the same way.  Rank 0 prints one JSON line.
+torch.distributed (RCCL) only brackets the timed regions and gathers the evaluation counts.
+`value` is the BASELINE metric read literally for every N: ONE 10 000-series panel, split over the
+ranks for N > 1 (series i on rank i mod N: parallel.shard_indices) -- STRONG scaling.  A launch cannot
+end before its longest fit, so this panel stops scaling early (`strong_scaling_expectation` states the
+ceiling next to the measurement).  Beside it, timed the same way:
+  * `weak_scaling` (N > 1): every rank its own 10 000-series panel;
+  * `cfg3_sharded` (every N): BASELINE config 3 -- 100 000 series x 1 095 points as 8 blocks of 12 500,
+    block b on rank b mod N -- the configuration that has enough work per GPU to scale.
+Rank 0 prints one JSON line.
 """
 import argparse
 import json
@@ -93,6 +98,25 @@ def cpu_baseline(spec, ds, y, fut, budget_s=12.0, yhat_gpu=None):
             'mean_evals': float(np.mean(evals))}
 
 
+def cpu_baseline_python(budget_series=4096, timeout_s=240):
+    """A CPU baseline SHAPED like the reference's path (Spark local[*]: one Python worker per core, one
+    series per UDF call; /root/reference/tests/unit/prophet_modeler_test.py:20): oracle/py_baseline.py --
+    per series a pandas frame -> the literal ProphetOracle(...).fit -> make_future_dataframe -> predict, under
+    multiprocessing.Pool(os.cpu_count()), on a bounded sample (>= 512 series) of the same panel.  Its own
+    process (subprocess: nothing forks the process that holds the HIP context).  Labelled "restated python --
+    not fbprophet+Stan": real fbprophet + Stan's autodiff + pystan's marshalling would be slower still."""
+    import subprocess
+    cores = os.cpu_count() or 1
+    series = int(min(N_SERIES, max(512, min(budget_series, 16 * cores))))
+    cmd = [sys.executable, '-m', 'oracle.py_baseline', '--series', str(series), '--procs', str(cores),
+           '--points', str(T_POINTS), '--horizon', str(HORIZON), '--total', str(N_SERIES)]
+    env = dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1')
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout_s)
+    if out.returncode != 0:
+        raise RuntimeError('oracle.py_baseline failed: %s' % out.stderr[-400:])
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
 def kernel_sources_digest():
     """sha256 (first 16 hex digits) over the HIP sources + the C-ABI header, in name order."""
     import glob
@@ -137,6 +161,17 @@ def parity_context(f, spec, ds, y, fut, yhat_quad, n=256):
         rel = (torch.abs(yh - yhat_quad[:n]) / torch.abs(yhat_quad[:n])).median(dim=1).values.cpu().numpy()
         out[key] = {'median': float(np.median(rel)), 'p90': float(np.quantile(rel, 0.9)), 'series': int(n)}
     return out
+
+
+def quad_waves_per_cu(n_series, n_cu):
+    """Wave slots per CU of the route an aligned linear/additive panel of n_series takes (tsf_quad_launch.h /
+    tsf_inst_quad.hip): the register-M kernel (8) up to 3 series per its wave slot, the 16-wave pooled kernel
+    from 8 series per its wave slot on, else the 12-wave kernel."""
+    if n_series <= 3 * 8 * n_cu:
+        return 8
+    if n_series >= 8 * 16 * n_cu:
+        return 16
+    return 12
 
 
 def simulate_strong_scaling(n_eval, fit_ms, n_cu, waves_per_cu=12):
@@ -221,6 +256,7 @@ def main():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-cfg3', action='store_true', help='skip the cfg3_sharded leg (100 000 x 1 095 over the ranks)')
     ap.add_argument('--timed-only', action='store_true',
                     help='only warm-up + the K timed steps (for rocprofv3 runs: every dispatch of the fit '
                          'kernel is then a full-panel launch, so per-kernel means are per launch)')
@@ -241,15 +277,16 @@ def main():
     # collective on the data path), is `value`; the weak-scaling run (every rank its own 10 000-series
     # panel) is timed the same way afterwards and reported beside it.
     ds_np, y_full = synth.make_panel(N_SERIES, T_POINTS, 'linear', seed=751)
-    y_np = np.ascontiguousarray(y_full[rank::world])
+    y_np = np.ascontiguousarray(y_full[parallel.shard_indices(N_SERIES, rank, world)])
     n_local = y_np.shape[0]
     fut_np = ds_np[-1] + synth.DAY_NS * np.arange(1, HORIZON + 1)
     ds = torch.from_numpy(ds_np).to(dev)
     y = torch.from_numpy(y_np).to(dev)
     fut = torch.from_numpy(fut_np).to(dev)
     f = DeviceForecaster(spec, local)
+    n_cu = torch.cuda.get_device_properties(local).multi_processor_count
 
-    def timed_leg(yy):
+    def timed_leg(yy, f=f, ds=ds, fut=fut):
         """W warm-up + K timed steps (fit + 90-step forecast of the panel `yy`, resident in HBM),
         bracketed by barrier + synchronize on both sides, MAX over ranks."""
         n = yy.shape[0]
@@ -289,6 +326,42 @@ def main():
                 'fit_kernel_ms_rank0': float(np.mean(kmsw)) if kmsw else None,
                 'note': 'every rank fits its own %d-series panel (per-GPU work fixed)' % N_SERIES}
 
+    # BASELINE config 3 (100 000 x 1 095, "sharded across 8 MI355X"): the configuration with enough work per
+    # GPU to scale -- 8 blocks of 12 500 series (block b = make_panel(12 500, 1 095, seed 3000 + b)), block b on
+    # rank b mod N, no collective; same step (fit + 90-step forecast), same bracketing, MAX over ranks
+    cfg3 = None
+    if not args.timed_only and not args.no_cfg3 and 8 % world == 0:
+        try:
+            C3_BLOCKS, C3_N, C3_T = 8, int(os.environ.get('BENCH_C3_BLOCK', '12500')), 1095
+            mine = [b for b in range(C3_BLOCKS) if b % world == rank]
+            ds3_np = synth.daily_grid(C3_T)
+            y3 = torch.empty((len(mine) * C3_N, C3_T), dtype=torch.float64, device=dev)
+            for k, b in enumerate(mine):
+                y3[k * C3_N:(k + 1) * C3_N] = torch.from_numpy(synth.make_panel(C3_N, C3_T, 'linear', seed=3000 + b)[1]).to(dev)
+            spec3 = fc.ModelSpec(growth='linear', seasonalities=fc.ModelSpec.auto_seasonalities(ds3_np))
+            f3 = DeviceForecaster(spec3, local)
+            ds3 = torch.from_numpy(ds3_np).to(dev)
+            fut3 = torch.from_numpy(ds3_np[-1] + synth.DAY_NS * np.arange(1, HORIZON + 1)).to(dev)
+            dt3, kms3, o3, _ = timed_leg(y3, f3, ds3, fut3)
+            ev3 = o3.n_eval.cpu().numpy().astype(np.float64)
+            # per-rank summary rows gathered on every rank: [series, total evaluations, longest fit, fit-path kernel ms]
+            rows3 = parallel.gather_rows(np.array([[len(ev3), ev3.sum(), ev3.max(), float(np.mean(kms3)) if kms3 else np.nan]]), None, dev)
+            total3 = C3_BLOCKS * C3_N
+            cfg3 = {'value': total3 * args.steps / dt3, 'unit': 'series/s', 'ms_per_step': 1e3 * dt3 / args.steps,
+                    'scaling': 'strong', 'series_total': total3, 'series_per_gpu': len(mine) * C3_N, 'points': C3_T,
+                    'K': spec3.K, 'P': 3 + spec3.n_changepoints + spec3.K,
+                    'workload': 'BASELINE config 3: %d series x %d daily points (8 blocks of %d, block b on rank b mod %d), '
+                                'linear trend + 25 changepoints, weekly(3)+yearly(10) additive (fbprophet auto rule: span 1 094 d), '
+                                'MAP L-BFGS + %d-step forecast' % (total3, C3_T, C3_N, world, HORIZON),
+                    'fit_kernel_ms_per_rank': [float(v) for v in rows3[:, 3]],
+                    'evaluations_total': float(rows3[:, 1].sum()), 'evaluations_longest_fit': float(rows3[:, 2].max()),
+                    'waves_per_cu': quad_waves_per_cu(len(mine) * C3_N, n_cu)}
+            del y3, f3, o3
+        except Exception as e:
+            cfg3 = {'error': str(e)}
+
+    # the evaluation counts of the whole cfg2 panel on every rank, in series order (rank r holds the series i mod world == r)
+    n_eval_all = parallel.gather_rows(out.n_eval.cpu().numpy().astype(np.float64).reshape(-1, 1), N_SERIES, dev)[:, 0]
     if rank != 0:
         return
     # measured HBM ceiling on this device beside the 8 TB/s spec figure: device-to-device copy of
@@ -352,8 +425,8 @@ def main():
                      'note': 'HBM sees each series once in and once out; the fit itself is a '
                              'vector-issue- and latency-bound fp64 L-BFGS loop on registers/LDS '
                              '(SURVEY 8d, DESIGN.md section 5), so the HBM fraction is small by '
-                             'construction; at 12 waves per CU the r staging of the residual passes '
-                             'goes through the global scratch, which is most of the measured traffic; '
+                             'construction; the weights of a residual pass stay in registers (round 3), '
+                             'so the measured traffic is ~1.2 x the algorithmic bytes; '
                              'evaluation rate and fp64 figure alongside',
                      'evaluations_per_s': float(n_eval.sum()) / (fit_ms * 1e-3),
                      'flops_per_evaluation_algorithmic': flops_per_eval,
@@ -366,11 +439,69 @@ def main():
                                         zip(*np.unique(status, return_counts=True))}},
     }
     if world == 1:
-        v = pmc_valu(kernel, fit_ms, int(n_eval.sum()), torch.cuda.get_device_properties(local).multi_processor_count)
+        v = pmc_valu(kernel, fit_ms, int(n_eval.sum()), n_cu)
         if v is not None:
             res['roofline'].update(v)
     if weak is not None:
         res['weak_scaling'] = weak
+    if cfg3 is not None:
+        res['cfg3_sharded'] = cfg3
+    # What the strong-scaled legs SHOULD show, stated next to what they do show: a launch cannot end before
+    # its longest fit, and a rank's queue cannot drain faster than its wave slots allow.  tau = time per
+    # evaluation of one wave, calibrated on THIS run (rank 0's fit-path kernel time / the queue model's
+    # makespan for rank 0's own share); the model then gives every N.  `ceiling` = N -> infinity.
+    try:
+        wpc = quad_waves_per_cu(n_local, n_cu)
+        sim = simulate_strong_scaling(n_eval_all[parallel.shard_indices(N_SERIES, 0, world)], fit_ms, n_cu, wpc)
+        tau_ms = sim['longest_series_ms'] / float(n_eval.max())
+        exp = {'label': 'simulated (queue model, one evaluation time), NOT measured', 'tau_us_per_evaluation': 1e3 * tau_ms,
+               'cfg2': {'longest_fit_evaluations': float(n_eval_all.max()),
+                        'ceiling_ms_fit_kernel': float(n_eval_all.max()) * tau_ms,
+                        'ceiling_series_per_s_kernel_only': N_SERIES / (float(n_eval_all.max()) * tau_ms * 1e-3),
+                        'gpus': {}}}
+        for G in (1, 2, 4, 8):
+            # per-G route: the kernel a share of N_SERIES / G takes has its own number of wave slots
+            import heapq
+            w_g = quad_waves_per_cu((N_SERIES + G - 1) // G, n_cu)
+            worst = 0.0
+            for r in range(G):
+                ev = n_eval_all[parallel.shard_indices(N_SERIES, r, G)]
+                slots = n_cu * w_g
+                if len(ev) <= slots:
+                    worst = max(worst, float(ev.max()))
+                else:
+                    h = [0.0] * slots
+                    for e in ev:
+                        heapq.heappush(h, heapq.heappop(h) + e)
+                    worst = max(worst, max(h))
+            exp['cfg2']['gpus'][str(G)] = {'fit_kernel_ms': worst * tau_ms, 'speedup_vs_1': None}
+        base = exp['cfg2']['gpus']['1']['fit_kernel_ms']
+        for G in exp['cfg2']['gpus']:
+            exp['cfg2']['gpus'][G]['speedup_vs_1'] = base / exp['cfg2']['gpus'][G]['fit_kernel_ms']
+        if cfg3 is not None and 'error' not in cfg3:
+            # cfg3: enough series per GPU that the queue, not the longest fit, sets the time: work / slots, with the
+            # longest fit as the floor
+            ev_tot, ev_max = cfg3['evaluations_total'], cfg3['evaluations_longest_fit']
+            tau3 = None
+            k0 = cfg3['fit_kernel_ms_per_rank'][0]
+            slots0 = n_cu * cfg3['waves_per_cu']
+            if k0 == k0:
+                tau3 = k0 / max(ev_tot / world / slots0, ev_max)
+            exp['cfg3'] = {'tau_us_per_evaluation': None if tau3 is None else 1e3 * tau3,
+                           'longest_fit_evaluations': ev_max, 'gpus': {}}
+            if tau3 is not None:
+                for G in (1, 2, 4, 8):
+                    w_g = quad_waves_per_cu(cfg3['series_total'] // G, n_cu)
+                    # a fourth wave per SIMD slows every wave by ~23 %: tau scales with the route
+                    rel = {8: 0.82, 12: 1.0, 16: 1.23}[w_g] / {8: 0.82, 12: 1.0, 16: 1.23}[cfg3['waves_per_cu']]
+                    ms = max(ev_tot / G / (n_cu * w_g), ev_max) * tau3 * rel
+                    exp['cfg3']['gpus'][str(G)] = {'fit_kernel_ms': ms}
+                b3 = exp['cfg3']['gpus']['1']['fit_kernel_ms']
+                for G in exp['cfg3']['gpus']:
+                    exp['cfg3']['gpus'][G]['speedup_vs_1'] = b3 / exp['cfg3']['gpus'][G]['fit_kernel_ms']
+        res['strong_scaling_expectation'] = exp
+    except Exception as e:
+        res['strong_scaling_expectation'] = {'error': str(e)}
     if world == 1 and not args.timed_only:
         # The strong-scaled run, rank by rank, on THIS GPU: `--gpus G` gives rank r the series r, r + G, ... of
         # the one panel and there is no collective on the data path, so a G-GPU step lasts as long as its slowest
@@ -381,7 +512,7 @@ def main():
             for G in (2, 4, 8):
                 per_rank = []
                 for r in range(G):
-                    ys = torch.from_numpy(np.ascontiguousarray(y_full[r::G])).to(dev)
+                    ys = torch.from_numpy(np.ascontiguousarray(y_full[parallel.shard_indices(N_SERIES, r, G)])).to(dev)
                     o_ = f.alloc_fit_output(ys.shape[0])
                     yh_ = torch.zeros((ys.shape[0], HORIZON), dtype=torch.float64, device=dev)
                     yi_ = torch.zeros((ys.shape[0], HORIZON), dtype=torch.int32, device=dev)
@@ -402,7 +533,7 @@ def main():
             res['strong_scaling_rank_by_rank_on_one_gpu'] = {'error': str(e)}
     if world == 1:
         try:
-            res['strong_scaling_simulated'] = simulate_strong_scaling(n_eval, fit_ms, torch.cuda.get_device_properties(local).multi_processor_count)
+            res['strong_scaling_simulated'] = simulate_strong_scaling(n_eval, fit_ms, n_cu)
         except Exception as e:
             res['strong_scaling_simulated'] = {'error': str(e)}
     # the same panel re-fitted with the evaluation counts of the previous fit as scheduling hints
@@ -469,6 +600,12 @@ def main():
         except Exception as e:
             res['cpu_baseline'] = {'value': None, 'unit': 'series/s', 'cores': os.cpu_count(),
                                    'kind': 'port', 'sample': 'failed: %s' % e}
+    if world == 1 and not args.no_cpu_baseline and not args.timed_only:
+        try:
+            res['cpu_baseline_python'] = cpu_baseline_python()
+        except Exception as e:
+            res['cpu_baseline_python'] = {'value': None, 'unit': 'series/s', 'cores': os.cpu_count(), 'kind': 'port',
+                                          'sample': 'failed: %s' % e}
     print(json.dumps(res))
 
 

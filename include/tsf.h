@@ -239,6 +239,16 @@ int tsf_predict_intervals_dev(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int
 int tsf_eval(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int32_t T, const int64_t *ds,
              const void *y, int32_t y_dtype, const double *floor, const double *cap,
              const double *extra, const double *theta, double *f_out, double *grad_out);
+/* tsf_eval_quadratic: the QUADRATIC evaluation form (eval_form; what fit_quad_kernel evaluates at every
+ * trial point of its line searches) at theta [N][stride], built around the reference point
+ * theta_ref [N][stride]: s0 = |y - Z ref|^2 and c = Z^T (y - Z ref) from one residual-form pass at
+ * theta_ref, M = Z^T Z once per call, then f and the gradient from (s0, c, M, theta - theta_ref).  Aligned
+ * panel, linear growth, additive columns only, 3 + n_changepoints + K <= 64 (else an error).  The
+ * per-evaluation check of the headline kernel's arithmetic against the literal model
+ * (tests/test_gpu_literal.py); reference-side counterpart: none (Stan evaluates in residual form). */
+int tsf_eval_quadratic(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int32_t T, const int64_t *ds,
+                       const void *y, int32_t y_dtype, const double *extra, const double *theta_ref,
+                       const double *theta, double *f_out, double *grad_out);
 int tsf_design(tsf_ctx *ctx, const tsf_spec *spec, int32_t T, const int64_t *ds,
                const double *extra, double *X_out, double *t_out, tsf_grid_info *grid_out);
 /* IEEE self test of the device arithmetic the canonical order relies on: fills out[n] with

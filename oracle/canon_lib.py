@@ -189,6 +189,24 @@ def eval_at(sp, ds_ns, y, theta, floor=0.0, cap=0.0, extra=None):
     return f.value, g[:len(theta)].copy(), rc
 
 
+def eval_quadratic_at(sp, ds_ns, y, theta_ref, theta, extra=None):
+    """Quadratic-form evaluation (cn_eval_gram) at theta around the reference point theta_ref
+    (cn_eval_quadratic_at): returns (f, gradient, rc)."""
+    ds_ns, y = _i64(ds_ns), _f64(y)
+    T = len(ds_ns)
+    g = np.zeros(128)
+    f = ctypes.c_double(0.0)
+    ekeep, eptr = _extra_ptr(sp, extra, T)
+    th, thr = np.zeros(128), np.zeros(128)
+    th[:len(theta)] = theta
+    thr[:len(theta_ref)] = theta_ref
+    L = lib()
+    L.cn_eval_quadratic_at.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.POINTER(ctypes.c_double), ctypes.c_void_p]
+    rc = L.cn_eval_quadratic_at(ctypes.byref(sp), T, ds_ns.ctypes.data, y.ctypes.data, eptr, thr.ctypes.data,
+                                th.ctypes.data, ctypes.byref(f), g.ctypes.data)
+    return f.value, g[:len(theta)].copy(), rc
+
+
 def fit(sp, ds_ns, y, floor=0.0, cap=0.0, extra=None):
     """Returns dict(theta, t_change, info, status, n_iter, n_eval, f)."""
     ds_ns, y = _i64(ds_ns), _f64(y)

@@ -1284,6 +1284,29 @@ int cn_eval_at(const cn_spec *sp, int T, const int64_t *ds, const double *y, dou
     return rc;
 }
 
+/* Quadratic-form evaluation (cn_eval_gram) at theta around the reference point theta_ref: a residual-form
+ * pass at theta_ref (cn_resid_q) makes it the reference, then ONE evaluation of the quadratic form -- what
+ * every trial point of a line search costs under eval_mode 1.  Counterpart of the product's
+ * tsf_eval_quadratic (tests compare bits).  Returns 0, 1 (non-finite) or < 0 (model not linear/additive). */
+int cn_eval_quadratic_at(const cn_spec *sp, int T, const int64_t *ds, const double *y, const double *extra,
+                         const double *theta_ref, const double *theta, double *f_out, double *g_out)
+{
+    int err;
+    cn_series *se = cn_prepare(sp, T, ds, y, 0.0, 0.0, extra, &err);
+    if (!se) return err;
+    if (!(sp->growth == 0 && se->Ka == se->K)) { free_series(se); return -100; }
+    se->gram = 1; cn_build_gram(se);
+    double thr[CN_MAX_P], th[CN_MAX_P], g[CN_MAX_P], fr;
+    to_internal(se, theta_ref, thr);
+    to_internal(se, theta, th);
+    int rc = cn_resid_q(se, thr, &fr, g);
+    cn_set_ref(se, thr);
+    rc |= cn_eval_gram(se, th, f_out, g);
+    to_original(se, g, g_out, 0);
+    free_series(se);
+    return rc;
+}
+
 /* Full fit.  theta_out: [3+S+K] original order; tchange_out: [S]. */
 int cn_fit(const cn_spec *sp, int T, const int64_t *ds, const double *y, double floor_,
            double cap, const double *extra, double *theta_out, double *tchange_out,

@@ -1,5 +1,5 @@
-"""World-size-2 CPU test of the multi-GPU plumbing (gloo): contiguous shard-by-id partition,
-max-over-ranks step time, gather of per-rank results in series order.  The data path itself has
+"""World-size-2 CPU test of the multi-GPU plumbing (gloo): the i mod world shard-by-id partition,
+max-over-ranks step time, gather of per-rank results back into series order.  The data path itself has
 no collective (series are independent), so there is nothing else to exercise."""
 import os
 import socket
@@ -22,14 +22,14 @@ def _worker(rank, world, port, n_items, q):
     import torch.distributed as dist
     from time_series_spark_amd import parallel
     r, w, _ = parallel.init_process_group(backend='gloo')
-    lo, hi = parallel.shard_bounds(n_items, r, w)
+    mine = parallel.shard_indices(n_items, r, w)
     # stand-in for the per-rank fit: row i -> [i, 2i]
-    local = np.stack([np.arange(lo, hi, dtype=np.float64), 2.0 * np.arange(lo, hi)], axis=1)
+    local = np.stack([mine.astype(np.float64), 2.0 * mine], axis=1)
     parallel.barrier()
     t = parallel.max_over_ranks(1.0 + r)
-    tot = parallel.sum_over_ranks(hi - lo)
-    allrows = parallel.gather_rows(local)
-    q.put((r, lo, hi, t, tot, allrows))
+    tot = parallel.sum_over_ranks(len(mine))
+    allrows = parallel.gather_rows(local, n_items)
+    q.put((r, list(mine), t, tot, allrows))
     dist.destroy_process_group()
 
 
@@ -45,11 +45,11 @@ def test_two_rank_sharding_and_gather():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    assert [(r[1], r[2]) for r in res] == [(0, 6), (6, 11)]
+    assert [r[1] for r in res] == [[0, 2, 4, 6, 8, 10], [1, 3, 5, 7, 9]]
     for r in res:
-        assert r[3] == 2.0                       # max over ranks of (1 + rank)
-        assert r[4] == n_items
-        assert np.array_equal(r[5][:, 0], np.arange(n_items)) and np.array_equal(r[5][:, 1], 2.0 * np.arange(n_items))
+        assert r[2] == 2.0                       # max over ranks of (1 + rank)
+        assert r[3] == n_items
+        assert np.array_equal(r[4][:, 0], np.arange(n_items)) and np.array_equal(r[4][:, 1], 2.0 * np.arange(n_items))
 
 
 def _fit_worker(rank, world, port, q):
@@ -67,13 +67,13 @@ def _fit_worker(rank, world, port, q):
     spec = helpers.make_case('short_90')[0]
     ds, y = synth.make_panel(7, 90, 'linear', seed=5)
     csp = helpers.oracle_spec(spec)
-    mine = np.arange(r, len(y), w)
+    mine = parallel.shard_indices(len(y), r, w)
     rows = []
     for n in mine:
         o = cl.fit(csp, ds, y[n])
         rows.append(np.concatenate([[n, o['n_eval'], o['f']], o['theta']]))
     parallel.barrier()
-    allrows = parallel.gather_rows(np.array(rows))
+    allrows = parallel.gather_rows(np.array(rows), len(y))
     q.put((r, allrows))
     dist.destroy_process_group()
 
@@ -98,9 +98,9 @@ def test_two_rank_sharded_fit_equals_the_single_process_fit():
     csp = helpers.oracle_spec(spec)
     for _r, rows in res:                      # every rank holds the gathered result
         assert rows.shape[0] == len(y)
-        # gathered in rank order = [0, 2, 4, 6, 1, 3, 5]: the series index travels with the row
-        assert list(rows[:, 0].astype(int)) == [0, 2, 4, 6, 1, 3, 5]
-        back = rows[np.argsort(rows[:, 0])]
+        # gather_rows puts the rows back in series order (rank r holds the series i with i mod world == r)
+        assert list(rows[:, 0].astype(int)) == list(range(len(y)))
+        back = rows
         for n in range(len(y)):
             o = cl.fit(csp, ds, y[n])
             assert back[n, 1] == o['n_eval'] and back[n, 2] == o['f']

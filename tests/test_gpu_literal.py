@@ -45,6 +45,55 @@ def test_hip_log_posterior_and_gradient_against_the_literal_stan_model(fc, case)
         assert np.max(np.abs(g[n] - gl) / (1 + np.abs(gl))) <= 1e-11, (case, n)
 
 
+@pytest.mark.parametrize('case', ['cfg2_linear_additive', 'short_90', 'cfg3_linear_1095', 'long_linear_1400',
+                                  'kp16_linear_400'])
+def test_hip_quadratic_form_evaluation_against_the_literal_stan_model(fc, case):
+    """tsf_eval_quadratic (eval_quad_kernel: a residual pass at a reference point, then ONE gram_eval_q -- the
+    template instance fit_quad_kernel runs at every trial point of its line searches, Z^T Z in LDS, pipelined
+    reads) == the dense-A numpy prophet.stan at the same theta: f to 1e-11, the gradient to 1e-11 (relative to
+    1 + |g|).  The arithmetic of the headline kernel, per evaluation, against a model that does not pass through
+    oracle/prophet_canon.c -- and, beside it, bit for bit against the oracle's cn_eval_quadratic_at."""
+    from oracle import canon_lib as cl
+    from oracle.fbprophet_restated import stan_neg_log_prob_grad
+    from tests.test_oracle import quad_eval_points
+    spec, ds, y, floor, cap, extra, fut, exf = helpers.make_case(case)
+    csp = helpers.oracle_spec(spec)
+    N = y.shape[0]
+    rng = np.random.default_rng(23)
+    dats, refs, pts = [], np.zeros((N, spec.theta_stride)), np.zeros((2, N, spec.theta_stride))
+    for n in range(N):
+        m, dat, th0, _ = _literal(case, n)
+        assert th0.size == spec.theta_stride
+        dats.append(dat)
+        refs[n], (pts[0, n], pts[1, n]) = quad_eval_points(case, n, th0, rng)
+    for k in range(2):
+        f, g = fc.eval_quadratic(spec, ds, y, refs, pts[k])
+        for n in range(N):
+            fl, gl = stan_neg_log_prob_grad(dats[n], pts[k, n])
+            assert abs(f[n] - fl) <= 1e-11 * abs(fl), (case, k, n)
+            assert np.max(np.abs(g[n] - gl) / (1 + np.abs(gl))) <= 1e-11, (case, k, n)
+            fo, go, rc = cl.eval_quadratic_at(csp, ds, y[n], refs[n], pts[k, n])
+            assert rc == 0 and helpers.n_bit_diff(f[n], fo) == 0 and helpers.n_bit_diff(g[n], go) == 0, (case, k, n)
+    # a point far from the reference (what re-centring exists to prevent): still the oracle's bits
+    far = refs + rng.normal(0, 0.5, refs.shape)
+    f, g = fc.eval_quadratic(spec, ds, y, refs, far)
+    for n in range(N):
+        fo, go, rc = cl.eval_quadratic_at(csp, ds, y[n], refs[n], far[n])
+        assert helpers.n_bit_diff(f[n], fo) == 0 and helpers.n_bit_diff(g[n], go) == 0, (case, n)
+
+
+def test_quadratic_form_evaluation_refuses_other_models(fc):
+    from time_series_spark_amd import _lib
+    spec, ds, y, floor, cap, extra, fut, exf = helpers.make_case('ref_logistic_multiplicative')
+    th = np.zeros((y.shape[0], spec.theta_stride))
+    with pytest.raises(_lib.TsfError):
+        fc.eval_quadratic(spec, ds, y, th, th)
+    spec, ds, y, floor, cap, extra, fut, exf = helpers.make_case('linear_additive_holidays')     # P = 84
+    th = np.zeros((y.shape[0], spec.theta_stride))
+    with pytest.raises(_lib.TsfError):
+        fc.eval_quadratic(spec, ds, y, th, th, extra=extra)
+
+
 @pytest.mark.parametrize('case', ['cfg2_linear_additive', 'ref_logistic_multiplicative',
                                   'linear_multiplicative_365', 'logistic_additive_400', 'cfg4_holidays'])
 def test_hip_fit_and_predict_against_the_literal_prophet(fc, case):

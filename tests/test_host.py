@@ -219,16 +219,17 @@ def test_input_discovery_follows_spark_rules(tmp_path):
         pm.find_model_input(str(root))
 
 
-def test_shard_bounds_partition():
+def test_shard_indices_partition():
+    """series i on rank i mod world: the shards of all ranks partition the panel, sizes differ by at most one,
+    shard_rank inverts it."""
     for n, w in [(10, 3), (10000, 8), (7, 8), (100000, 8), (1, 1)]:
-        cuts = [parallel.shard_bounds(n, r, w) for r in range(w)]
-        assert cuts[0][0] == 0 and cuts[-1][1] == n
-        assert all(cuts[i][1] == cuts[i + 1][0] for i in range(w - 1))
-        sizes = [b - a for a, b in cuts]
+        shards = [parallel.shard_indices(n, r, w) for r in range(w)]
+        allidx = np.concatenate(shards)
+        assert len(allidx) == n and np.array_equal(np.sort(allidx), np.arange(n))
+        sizes = [len(x) for x in shards]
         assert max(sizes) - min(sizes) <= 1
         for i in range(0, n, max(1, n // 17)):
-            r = parallel.shard_of(i, n, w)
-            assert cuts[r][0] <= i < cuts[r][1]
+            assert i in shards[parallel.shard_rank(i, w)]
 
 
 def test_spec_validation_messages():

@@ -200,6 +200,45 @@ def test_quadratic_form_matches_residual_form_on_every_evaluation():
             assert r['n_resid'] * 4 <= r['n_eval'] + 40
 
 
+QUAD_EVAL_CASES = ['cfg2_linear_additive', 'short_90', 'cfg3_linear_1095', 'long_linear_1400', 'kp16_linear_400']
+
+
+def quad_eval_points(case, n, th0, rng):
+    """Reference points and evaluation points of the per-evaluation quadratic-form checks (CPU twin here, GPU in
+    tests/test_gpu_literal.py): the reference point is fbprophet's initial point moved by N(0, 0.02) per
+    parameter -- an iterate of a fit, not the start --, the evaluation points lie 1e-3 and 0.02 away per parameter
+    (a line-search trial; an iterate ~100 iterations after the last re-centring)."""
+    ref = th0 + rng.normal(0, 0.02, th0.size)
+    return ref, [ref + rng.normal(0, sc, th0.size) for sc in (1e-3, 0.02)]
+
+
+@pytest.mark.parametrize('case', QUAD_EVAL_CASES)
+def test_quadratic_form_single_evaluation_against_the_literal_stan_model(case):
+    """ONE evaluation of the quadratic form (s0, c, M built at a reference point; cn_eval_quadratic_at) against
+    the dense-A numpy prophet.stan at the same theta: f to 1e-11 relative, the gradient to 1e-11 relative to
+    1 + |g| -- the arithmetic every line-search trial of a linear/additive fit runs, checked evaluation by
+    evaluation and not only at fit end points."""
+    from oracle.fbprophet_restated import stan_neg_log_prob_grad
+    rng = np.random.default_rng(23)
+    spec = helpers.make_case(case)[0]
+    csp = helpers.oracle_spec(spec)
+    assert csp.eval_mode == 1
+    for n in range(3):
+        m, dat, th0, (spec, ds, y, floor, cap, extra, fut, exf) = _literal(case, n)
+        ref, pts = quad_eval_points(case, n, th0, rng)
+        for th in pts:
+            f, g, rc = cl.eval_quadratic_at(csp, ds, y[n], ref, th)
+            assert rc == 0
+            fl, gl = stan_neg_log_prob_grad(dat, th)
+            assert abs(f - fl) <= 1e-11 * abs(fl), (case, n, f, fl)
+            assert np.max(np.abs(g - gl) / (1 + np.abs(gl))) <= 1e-11, (case, n)
+    # not a linear/additive model: refused
+    spec = helpers.make_case('ref_logistic_multiplicative')[0]
+    spec_, ds, y, floor, cap, extra, fut, exf = helpers.make_case('ref_logistic_multiplicative')
+    th = np.zeros(spec.theta_stride)
+    assert cl.eval_quadratic_at(helpers.oracle_spec(spec), ds, y[0], th, th)[2] < 0
+
+
 def test_quadratic_and_residual_forms_reach_equivalent_optima():
     """The two evaluation forms follow different floating-point trajectories (the optimiser
     stops on Stan's loose relative tolerances, far from the exact MAP, so ANY rounding change

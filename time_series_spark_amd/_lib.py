@@ -78,7 +78,7 @@ class TsfFitOut(ctypes.Structure):
 EXPORTS = ['tsf_create', 'tsf_destroy', 'tsf_last_error', 'tsf_device_count', 'tsf_spec_default',
            'tsf_spec_size', 'tsf_grid_info_size', 'tsf_spec_K', 'tsf_theta_stride',
            'tsf_fit_aligned', 'tsf_fit_aligned_dev', 'tsf_fit_ragged', 'tsf_fit_ragged_dev',
-           'tsf_predict', 'tsf_predict_dev', 'tsf_predict_intervals', 'tsf_predict_intervals_dev', 'tsf_eval', 'tsf_design', 'tsf_selftest_math',
+           'tsf_predict', 'tsf_predict_dev', 'tsf_predict_intervals', 'tsf_predict_intervals_dev', 'tsf_eval', 'tsf_eval_quadratic', 'tsf_design', 'tsf_selftest_math',
            'tsf_set_cost_hints', 'tsf_set_profiling', 'tsf_profile_read', 'tsf_last_fit_kernel_ms',
            'tsf_pack_rows', 'tsf_pack_fetch', 'tsf_pack_free',
            'tsf_csv_read', 'tsf_csv_fetch', 'tsf_csv_malformed', 'tsf_csv_free', 'tsf_csv_write_forecasts']
@@ -129,6 +129,7 @@ def load():
                                         u64, vp, vp, vp]
     L.tsf_predict_intervals_dev.argtypes = L.tsf_predict_intervals.argtypes + [vp]
     L.tsf_eval.argtypes = [vp, psp, i64, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp]
+    L.tsf_eval_quadratic.argtypes = [vp, psp, i64, i32, vp, vp, i32, vp, vp, vp, vp, vp]
     L.tsf_design.argtypes = [vp, psp, i32, vp, vp, vp, vp, vp]
     L.tsf_selftest_math.argtypes = [vp, i32, i64, vp, vp, vp]
     L.tsf_set_cost_hints.argtypes = [vp, vp, i64]

@@ -342,7 +342,7 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
                    const void *y, int32_t y_dtype, const double *floor_, const double *cap,
                    const double *extra, tsf_fit_out *out, const double *theta_in,
                    double *grad_out, hipStream_t st, int64_t lat_base = 0, int64_t lat_step = 0,
-                   int64_t lat_U = 0)
+                   int64_t lat_U = 0, const double *theta_ref = nullptr)
 {
     if (!ctx) return -1;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -377,9 +377,13 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     // finite-difference and halving evaluations (tsf_newton_quad.h); aligned panels
     const bool newton_quad = newton && hs.growth == TSF_GROWTH_LINEAR && mode == 0 && hs.KP <= 28 &&
                              spec->eval_form != TSF_EVAL_RESIDUAL && NTmax <= 16;
+    // tsf_eval_quadratic: one quadratic-form evaluation at theta_in around the reference point theta_ref
+    const bool quad_eval = theta_in != nullptr && theta_ref != nullptr;
+    if (quad_eval && !(aligned && hs.growth == TSF_GROWTH_LINEAR && mode == 0 && hs.KP != 64))
+        return fail(ctx, "the quadratic form needs an aligned panel, linear growth, additive columns only and 3 + n_changepoints + K <= 64");
     QuadPlan qp;
     memset(&qp, 0, sizeof(qp));
-    if (quad || newton_quad) {
+    if (quad || newton_quad || quad_eval) {
         rc = quad_plan(ctx, hs, N, &qp);
         if (rc) return rc;
         if (newton_quad) {          // one-wave workgroups, up to 16 per CU: that many Z^T Z slots (ragged)
@@ -507,6 +511,12 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
         if (lrc == -1) lrc = pick_newton_launch(hs.growth, mode)(hs.KP, a, fit_P(hs.n_cp, hs.K) | 1, st);
     } else if (newton) {
         lrc = pick_newton_launch(hs.growth, mode)(hs.KP, a, fit_P(hs.n_cp, hs.K) | 1, st);
+    } else if (quad_eval) {
+        QuadArgs qa;
+        memset(&qa, 0, sizeof(qa));
+        qa.f = a; qa.Mg = (const double *)(ws + l.Mg); qa.rbuf = (double *)(ws + l.rbuf);
+        qa.counter = (int *)(ws + l.counter); qa.P4 = qp.P4;
+        lrc = launch_eval_quad(hs.KP, qp, qa, (double *)(ws + l.Mg), theta_ref, st);
     } else if (quad) {
         QuadArgs qa;
         qa.f = a; qa.Mg = (const double *)(ws + l.Mg); qa.Mslot = (double *)(ws + l.Mslot);
@@ -679,7 +689,8 @@ size_t ysize(int dt) { return dt == TSF_Y_F64 ? 8 : 4; }
 static int fit_host(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, int32_t T,
                     const int64_t *offsets, const int64_t *ds, const void *y, int32_t y_dtype,
                     const double *floor_, const double *cap, const double *extra,
-                    tsf_fit_out *out, const double *theta_in, double *f_out, double *grad_out)
+                    tsf_fit_out *out, const double *theta_in, double *f_out, double *grad_out,
+                    const double *theta_ref = nullptr)
 {
     if (!ctx) return -1;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -710,7 +721,7 @@ static int fit_host(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, 
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_start = host_timing ? now() : 0.0;
     double t_h2d = 0.0, t_fit = 0.0;
-    DevBuf d_ds, d_y, d_off, d_floor, d_cap, d_extra, d_theta, d_ys, d_f, d_st, d_it, d_ev, d_grid, d_thin, d_grad;
+    DevBuf d_ds, d_y, d_off, d_floor, d_cap, d_extra, d_theta, d_ys, d_f, d_st, d_it, d_ev, d_grid, d_thin, d_grad, d_thref;
     HIP_TRY(ctx, d_ds.alloc(8 * n_ds));
     HIP_TRY(ctx, d_y.alloc(ysize(y_dtype) * total));
     HIP_TRY(ctx, hipMemcpy(d_ds.p, ds, 8 * n_ds, hipMemcpyHostToDevice));
@@ -742,6 +753,10 @@ static int fit_host(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, 
         HIP_TRY(ctx, d_thin.alloc(8 * (size_t)N * stride));
         HIP_TRY(ctx, hipMemcpy(d_thin.p, theta_in, 8 * (size_t)N * stride, hipMemcpyHostToDevice));
         HIP_TRY(ctx, d_grad.alloc(8 * (size_t)N * stride));
+        if (theta_ref) {
+            HIP_TRY(ctx, d_thref.alloc(8 * (size_t)N * stride));
+            HIP_TRY(ctx, hipMemcpy(d_thref.p, theta_ref, 8 * (size_t)N * stride, hipMemcpyHostToDevice));
+        }
     }
     // ragged panel: do all timestamps lie on one lattice base + u*step (the usual case: one
     // sampling grid, different start dates / lengths)?  Then the design rows are computed once
@@ -766,7 +781,8 @@ static int fit_host(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, 
                      cap ? d_cap.as<double>() : nullptr,
                      spec->n_extra > 0 ? d_extra.as<double>() : nullptr, &dout,
                      theta_in ? d_thin.as<double>() : nullptr,
-                     theta_in ? d_grad.as<double>() : nullptr, nullptr, lat_base, lat_step, lat_U);
+                     theta_in ? d_grad.as<double>() : nullptr, nullptr, lat_base, lat_step, lat_U,
+                     (theta_in && theta_ref) ? d_thref.as<double>() : nullptr);
     if (rc) return rc;
     HIP_TRY(ctx, hipDeviceSynchronize());
     if (host_timing) t_fit = now();
@@ -820,6 +836,18 @@ extern "C" int tsf_eval(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int32_t T
     memset(&dummy, 0, sizeof(dummy));
     return fit_host(ctx, spec, N, 1, T, nullptr, ds, y, y_dtype, floor_, cap, extra, &dummy, theta,
                     f_out, grad_out);
+}
+
+extern "C" int tsf_eval_quadratic(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int32_t T, const int64_t *ds,
+                                  const void *y, int32_t y_dtype, const double *extra, const double *theta_ref,
+                                  const double *theta, double *f_out, double *grad_out)
+{
+    if (!ctx) return -1;
+    if (!ds || !y || !theta || !theta_ref || !f_out || !grad_out) return fail(ctx, "NULL input");
+    tsf_fit_out dummy;
+    memset(&dummy, 0, sizeof(dummy));
+    return fit_host(ctx, spec, N, 1, T, nullptr, ds, y, y_dtype, nullptr, nullptr, extra, &dummy, theta,
+                    f_out, grad_out, theta_ref);
 }
 
 // ---- predict ----------------------------------------------------------------------------------

@@ -24,4 +24,35 @@ int launch_quad_aligned1(int KP, const QuadPlan &qp, const QuadArgs &qa, double 
     }
 }
 
+// tsf_eval_quadratic: gram_build_kernel + eval_quad_kernel (one wave per workgroup, at most qp.slots of them:
+// the staging rows of long series are per workgroup)
+template <int KP, int PQ>
+static int launch_eval_quad_one(const QuadPlan &qp, const QuadArgs &qa, double *Mg, const double *theta_ref, hipStream_t st)
+{
+    hipLaunchKernelGGL((gram_build_kernel<KP, 1>), dim3((unsigned)qp.P4), dim3(64), 0, st, qa, Mg);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    const size_t lds = sizeof(double) * (size_t)PQ * W + quad_lanec_bytes<1>() + sizeof(QuadLds<KP, 1>);
+    hipFuncSetAttribute((const void *)eval_quad_kernel<KP, PQ, TSF_QUAD_NTR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    int64_t blocks = qa.f.N < qp.slots ? qa.f.N : qp.slots;
+    hipLaunchKernelGGL((eval_quad_kernel<KP, PQ, TSF_QUAD_NTR>), dim3((unsigned)blocks), dim3(64), lds, st, qa, theta_ref);
+    return (int)hipGetLastError();
+}
+
+int launch_eval_quad(int KP, const QuadPlan &qp, const QuadArgs &qa, double *Mg, const double *theta_ref, hipStream_t st)
+{
+    switch (KP * 100 + qp.P4) {
+    case 840: return launch_eval_quad_one<8, 40>(qp, qa, Mg, theta_ref, st);
+    case 856: return launch_eval_quad_one<8, 56>(qp, qa, Mg, theta_ref, st);
+    case 864: return launch_eval_quad_one<8, 64>(qp, qa, Mg, theta_ref, st);
+    case 1640: return launch_eval_quad_one<16, 40>(qp, qa, Mg, theta_ref, st);
+    case 1656: return launch_eval_quad_one<16, 56>(qp, qa, Mg, theta_ref, st);
+    case 1664: return launch_eval_quad_one<16, 64>(qp, qa, Mg, theta_ref, st);
+    case 2840: return launch_eval_quad_one<28, 40>(qp, qa, Mg, theta_ref, st);
+    case 2856: return launch_eval_quad_one<28, 56>(qp, qa, Mg, theta_ref, st);
+    case 2864: return launch_eval_quad_one<28, 64>(qp, qa, Mg, theta_ref, st);
+    default: return -1;
+    }
+}
+
 }  // namespace tsf

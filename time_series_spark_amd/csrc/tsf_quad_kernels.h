@@ -1194,4 +1194,48 @@ __global__ __launch_bounds__(NW * 64, quad_waves_per_simd(quad_three_waves(MMODE
 }
 
 
+// ---------------------------------------------------------------------------------------
+// eval-only kernel of the QUADRATIC form (parity tests: tsf_eval_quadratic): one residual pass at
+// theta_ref makes it the reference point (s0, c = Z^T r_ref; M = Z^T Z from gram_build_kernel, copied
+// to LDS as the fit kernel does), then ONE gram_eval_q at theta -- the template instance the 12-wave
+// fit kernel calls for every trial point of its line searches (MB = 8, pipelined reads of M), so what
+// a test sees here is the arithmetic of the headline kernel, per evaluation.
+// One wave per workgroup; series n = blockIdx.x, + gridDim.x, ... (the staging rows of steps beyond
+// NTR are per workgroup: qa.rbuf).
+// ---------------------------------------------------------------------------------------
+template <int KP, int PQ, int NTR>
+__global__ __launch_bounds__(64) void eval_quad_kernel(QuadArgs qa, const double *theta_ref)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const FitArgs &a = qa.f;
+    const int lane = lane_id();
+    double *Ml = reinterpret_cast<double *>(smem);
+    const size_t m_bytes = sizeof(double) * (size_t)PQ * W;
+    double *lanec = reinterpret_cast<double *>(smem + m_bytes);
+    QuadLds<KP, 1> &wl = *reinterpret_cast<QuadLds<KP, 1> *>(smem + m_bytes + quad_lanec_bytes<1>());
+    for (int i = lane; i < PQ * W; i += W) Ml[i] = qa.Mg[i];
+    for (int i = lane; i < 2 * W; i += W) wl.th[i] = 0.0;
+    wave_sync();
+    double *rb = qa.rbuf + (size_t)blockIdx.x * a.NTmax * W;
+    for (int64_t n = blockIdx.x; n < a.N; n += gridDim.x) {
+        SeriesView sv;
+        make_view_q<KP, 1>(a, n, sv);
+        LaneConst<1> lk;
+        lane_consts<1>(a.sp, sv, lanec, lk);
+        double xr[1], gr[1], fr, s0, ztr[1];
+        load_theta<1>(a, sv, n, theta_ref, xr);
+        const bool bad_ref = resid_eval_q<KP, 1, NTR>(sv, wl, lk, rb, xr, fr, gr, s0, ztr);
+        wl.ref[lane] = (lane == 2) ? 0.0 : xr[0];
+        wl.cvec[lane] = ztr[0];
+        wave_sync();
+        double th[1], g[1], f, q2;
+        load_theta<1>(a, sv, n, a.theta_in, th);
+        const double mreg[1] = {0.0};
+        const bool bad = gram_eval_q<1, PQ, W, 8, false, true>(sv, lk, Ml, qa.P4, th, wl.ref, wl.cvec, s0, f, g, q2, wl.th, mreg);
+        store_theta<1, false>(a, sv, n, g, a.grad_out);
+        if (lane == 0) { a.fval[n] = f; a.status[n] = (bad || bad_ref) ? 1 : 0; }
+        wave_sync();
+    }
+}
+
 }  // namespace tsf

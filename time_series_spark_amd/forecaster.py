@@ -11,7 +11,7 @@ import os
 
 import numpy as np
 
-from . import _lib
+from . import _lib, parallel
 
 DAY_NS = 86400 * 10 ** 9
 
@@ -253,7 +253,7 @@ def _merge_interleaved(spec, parts_res, N, parts):
         first = getattr(parts_res[0], k)
         out = np.zeros((N,) + first.shape[1:], dtype=first.dtype)
         for d, p in enumerate(parts_res):
-            out[d::parts] = getattr(p, k)
+            out[parallel.shard_indices(N, d, parts)] = getattr(p, k)
         return out
     return FitResult(spec, put('theta'), put('y_scale'), put('fval'), put('status'), put('n_iter'),
                      put('n_eval'), parts_res[0].grid)
@@ -295,13 +295,14 @@ def fit_aligned(spec, ds_ns, y, floor=None, cap=None, extra=None, ctx=None, devi
         cp = _opt_f64(cap, len(y), 'cap')
         # series i goes to device i mod parts (evaluation counts vary 3-40x per series and
         # neighbours in a panel tend to be alike; interleaving evens the devices out where contiguous
-        # blocks would not)
+        # blocks would not); parallel.shard_indices is the one statement of that layout (bench.py --gpus N
+        # deals its ranks the same way)
         y = np.asarray(y)
-        blocks = [(c, d) for d, c in enumerate(_contexts(devs[:parts]))]
-        res = _run_blocks(lambda c, d: fit_aligned(
-            spec, ds_ns, np.ascontiguousarray(y[d::parts]), None if fl is None else fl[d::parts],
-            None if cp is None else cp[d::parts], extra, ctx=c,
-            cost_hints=None if ch is None else ch[d::parts]), blocks)
+        blocks = [(c, parallel.shard_indices(len(y), d, parts)) for d, c in enumerate(_contexts(devs[:parts]))]
+        res = _run_blocks(lambda c, idx: fit_aligned(
+            spec, ds_ns, np.ascontiguousarray(y[idx]), None if fl is None else fl[idx],
+            None if cp is None else cp[idx], extra, ctx=c,
+            cost_hints=None if ch is None else ch[idx]), blocks)
         return _merge_interleaved(spec, res, len(y), parts)
     ctx = ctx or get_context()
     L = _lib.load()
@@ -494,6 +495,30 @@ def eval_aligned(spec, ds_ns, y, theta, floor=None, cap=None, extra=None, ctx=No
     rc = L.tsf_eval(ctx.handle, ctypes.byref(cs), N, T, ds_ns.ctypes.data, y.ctypes.data,
                     _lib.y_dtype_code(y), _lib._ptr(floor), _lib._ptr(cap), _lib._ptr(ex),
                     theta.ctypes.data, f.ctypes.data, g.ctypes.data)
+    ctx.check(rc)
+    return f, g
+
+
+def eval_quadratic(spec, ds_ns, y, theta_ref, theta, extra=None, ctx=None):
+    """-log posterior and gradient at theta [N][stride] in the QUADRATIC evaluation form built around the
+    reference point theta_ref [N][stride] (include/tsf.h tsf_eval_quadratic): what fit_quad_kernel
+    evaluates at the trial points of its line searches."""
+    ctx = ctx or get_context()
+    L = _lib.load()
+    ds_ns = np.ascontiguousarray(ds_ns, dtype=np.int64)
+    y = np.ascontiguousarray(y)
+    N, T = y.shape
+    theta = np.ascontiguousarray(theta, dtype=np.float64)
+    theta_ref = np.ascontiguousarray(theta_ref, dtype=np.float64)
+    if theta.shape != (N, spec.theta_stride) or theta_ref.shape != theta.shape:
+        raise ValueError('theta and theta_ref must be [N][theta_stride]')
+    cs = spec.to_c()
+    ex = np.ascontiguousarray(extra, dtype=np.float64) if spec.extra else None
+    f = np.zeros(N)
+    g = np.zeros_like(theta)
+    rc = L.tsf_eval_quadratic(ctx.handle, ctypes.byref(cs), N, T, ds_ns.ctypes.data, y.ctypes.data,
+                              _lib.y_dtype_code(y), _lib._ptr(ex), theta_ref.ctypes.data, theta.ctypes.data,
+                              f.ctypes.data, g.ctypes.data)
     ctx.check(rc)
     return f, g
 

@@ -1,8 +1,9 @@
 """Multi-GPU layout: series are sharded by id across ranks, one process per GPU, NO data-path
 collective (each (series_id, dim_id) model is independent -- the reference gets the same
 independence from Spark's hash partitioning, /root/reference/src/jobs/prophet_modeler.py:139-141).
-torch.distributed is used only for the start/stop barrier, the max-over-ranks step time and the
-gather of per-rank counts/results (backend "nccl" = RCCL on GPUs, "gloo" in CPU tests)."""
+Series i lives on rank i mod world (shard_indices).  torch.distributed is used only for the start/stop
+barrier, the max-over-ranks step time and the gather of per-rank counts / results back into series order
+(backend "nccl" = RCCL on GPUs, "gloo" in CPU tests)."""
 import os
 
 import numpy as np
@@ -13,22 +14,17 @@ def env_rank_world():
         int(os.environ.get('LOCAL_RANK', '0'))
 
 
-def shard_bounds(n_items, rank, world):
-    """Contiguous block partition [lo, hi) of n_items series over `world` ranks (sizes differ by
-    at most one).  Contiguous keeps each rank's panel a dense [N_r][T] slab."""
-    base, rem = divmod(int(n_items), int(world))
-    lo = rank * base + min(rank, rem)
-    hi = lo + base + (1 if rank < rem else 0)
-    return lo, hi
+def shard_indices(n_items, rank, world):
+    """The series of rank `rank`: i with i mod world == rank (what bench.py --gpus N and
+    forecaster.fit_aligned(devices=...) deal out).  Interleaved, not contiguous: evaluation counts vary
+    3-40 x per series and neighbours of a panel tend to be alike, so i mod world evens the ranks out
+    (SURVEY 8e); the price is that a rank's panel is a strided gather of the caller's, made once."""
+    return np.arange(int(rank), int(n_items), int(world), dtype=np.int64)
 
 
-def shard_of(series_index, n_items, world):
-    """Inverse of shard_bounds: which rank owns series_index."""
-    base, rem = divmod(int(n_items), int(world))
-    cut = rem * (base + 1)
-    if series_index < cut:
-        return series_index // (base + 1)
-    return rem + (series_index - cut) // max(base, 1)
+def shard_rank(series_index, world):
+    """Inverse of shard_indices: the rank that owns series_index."""
+    return int(series_index) % int(world)
 
 
 def init_process_group(backend=None):
@@ -79,14 +75,17 @@ def sum_over_ranks(value, device=None):
     return float(t.item())
 
 
-def gather_rows(local_rows, device=None):
-    """Concatenate per-rank [n_r][C] float64 arrays on every rank, in rank order (results of a
-    sharded fit; rank order == series order because shards are contiguous)."""
+def gather_rows(local_rows, n_items=None, device=None):
+    """Rows of a sharded result ([n_r][C] float64 per rank, rank r holding the series
+    shard_indices(n_items, r, world) in that order) gathered on every rank and put back in SERIES order.
+    n_items None: plain concatenation in rank order (per-rank summaries)."""
     import torch
     import torch.distributed as dist
     local_rows = np.ascontiguousarray(local_rows, dtype=np.float64)
     if not (dist.is_available() and dist.is_initialized()):
         return local_rows
+    if dist.get_backend() == 'gloo':
+        device = 'cpu'
     world = dist.get_world_size()
     dev = device or 'cpu'
     n = torch.tensor([local_rows.shape[0]], dtype=torch.int64, device=dev)
@@ -99,4 +98,13 @@ def gather_rows(local_rows, device=None):
     pad[:local_rows.shape[0]] = torch.from_numpy(local_rows).to(dev)
     bufs = [torch.zeros_like(pad) for _ in range(world)]
     dist.all_gather(bufs, pad)
-    return np.concatenate([b[:c].cpu().numpy() for b, c in zip(bufs, counts)], axis=0)
+    parts = [b[:c].cpu().numpy() for b, c in zip(bufs, counts)]
+    if n_items is None:
+        return np.concatenate(parts, axis=0)
+    out = np.zeros((int(n_items), C))
+    for r, part in enumerate(parts):
+        idx = shard_indices(n_items, r, world)
+        if len(idx) != part.shape[0]:
+            raise ValueError('rank %d holds %d rows, its shard has %d series' % (r, part.shape[0], len(idx)))
+        out[idx] = part
+    return out
