@@ -121,7 +121,7 @@ typedef struct {
      * wavefront per series; TSF_RK_MFMA 16 series per workgroup evaluated together on the matrix
      * cores (aligned panels, one parameter per lane, <= 28 changepoints); TSF_RK_AUTO = WAVE with
      * the cooperative tail: the series still running when the launch has handed out its last series
-     * are suspended and finished by one WORKGROUP each (16 waves sharing every evaluation; series of
+     * are suspended and finished by one WORKGROUP each (8 waves sharing every evaluation; series of
      * at most 4096 rows) -- and models with more than 64 parameters (two per lane) run on workgroups from
      * their first evaluation, the workgroup kernel being the faster one for them; TSF_RK_COOP = every
      * series on a workgroup from its first evaluation (lowest latency for panels smaller than the GPU). */
@@ -263,7 +263,7 @@ int tsf_selftest_math(tsf_ctx *ctx, int32_t op, int64_t n, const double *a, cons
  * series: a job that re-fits its panel regularly (the reference's modeler is such a job) can hand
  * the evaluation counts of the previous run (tsf_fit_out.n_eval) to the next one.
  * tsf_set_cost_hints: cost[i] = expected relative cost of series i of the NEXT fit call on this
- * context that has exactly n series (any fit entry point).  The work queue of that call hands the
+ * context (any fit entry point): consumed by it if it has exactly n series, discarded otherwise.  The work queue of that call hands the
  * series out in order of decreasing cost (ties: by index).  Results do not depend on the order
  * (every series is fitted by itself); only the launch time does: the BASELINE cfg2 panel with the
  * counts of its own previous fit takes 7.1-7.6 ms instead of 9.4.
@@ -322,9 +322,11 @@ void tsf_pack_free(tsf_pack *p);
  *               comes out as NaN (the packer drops it as fbprophet drops y.isnull() rows)
  *   rows come out in file order, files in the order given.
  *   A trailing '?' in layout ("dtq?") = Spark's default CSV mode PERMISSIVE: a line that does not
- *   match the schema (a field that does not convert, too few fields) is not an error but a row of
- *   nulls -- emitted here with a NaN quantity, which the packer drops like any null-y row;
- *   tsf_csv_malformed counts them.  Without it the first such line fails the read (FAILFAST).
+ *   match the schema (a field that does not convert, too few fields) is not an error.  Spark 2.4 turns
+ *   it into a row of nulls (every column, dim_id included); a null y is dropped by the fit, and a null
+ *   key cannot be expressed in the int64 columns here, so the record is DROPPED by the reader and
+ *   counted (tsf_csv_malformed) -- never emitted under a made-up key.  Without the '?' the first such
+ *   line fails the read (FAILFAST).
  * Returns 0; TSF_CSV_E_OPEN / TSF_CSV_E_PARSE with *err_file (index into paths) and *err_line
  * (1-based) set; -1 bad arguments, -2 out of memory, -3 other failure. */
 enum { TSF_CSV_E_OPEN = -10, TSF_CSV_E_PARSE = -11 };
@@ -333,7 +335,7 @@ int tsf_csv_read(int32_t n_files, const char *const *paths, const int64_t *serie
                  const char *layout, int32_t n_threads, tsf_csv **out, int64_t *n_rows,
                  int32_t *err_file, int64_t *err_line);
 int tsf_csv_fetch(tsf_csv *t, int64_t *series_id, int64_t *dim_id, int64_t *ds, double *y);
-int64_t tsf_csv_malformed(const tsf_csv *t);     /* rows replaced by nulls in permissive mode */
+int64_t tsf_csv_malformed(const tsf_csv *t);     /* records dropped in permissive mode */
 void tsf_csv_free(tsf_csv *t);
 
 /* ---- forecast sink (host side) -------------------------------------------------------------

@@ -198,7 +198,8 @@ def test_read_input_dataframe_hive_layout(tmp_path):
 def test_input_discovery_follows_spark_rules(tmp_path):
     """spark.read.csv(path) reads every non-hidden file under the path (prophet_modeler.py:102-116):
     part files without an extension count, `_SUCCESS` / `.crc` files and `_temporary` directories do
-    not; a compressed part raises instead of being skipped silently."""
+    not; .gz / .deflate parts are inflated by the reader (as Spark's Hadoop codecs do transparently), a part in
+    another codec raises instead of being skipped silently, a corrupt stream raises naming the file."""
     root = tmp_path / 'in'
     for sid in (7, 12):
         d = root / ('series_id=%d' % sid)
@@ -214,7 +215,23 @@ def test_input_discovery_follows_spark_rules(tmp_path):
     assert part == [7, 7, 12, 12]
     sid, did, ds, y = pm.read_model_input(files, str(root), part_sid=part)
     assert sorted(set(sid.tolist())) == [7, 12] and len(y) == 6 and y.sum() == 36
-    (root / 'series_id=7' / 'part-00002.csv.gz').write_bytes(b'\x1f\x8b')
+    import gzip
+    import zlib
+    more = '1,2020-01-04 00:00:00,8\n1,2020-01-05 00:00:00,\n1,2020-01-06 00:00:00,9\n'
+    (root / 'series_id=7' / 'part-00002.csv.gz').write_bytes(gzip.compress(more[:24].encode()) + gzip.compress(more[24:].encode()))   # two members
+    (root / 'series_id=12' / 'part-00002.deflate').write_bytes(zlib.compress(b'2,2020-01-04 00:00:00,100\n'))
+    big = ''.join('3,2021-%02d-%02d 00:00:00,%d\n' % (1 + i // 28, 1 + i % 28, i) for i in range(300)) * 200   # > one output guess
+    (root / 'series_id=12' / 'part-00003.gz').write_bytes(gzip.compress(big.encode()))
+    files, part = pm.find_model_input(str(root))
+    assert len(files) == 7
+    sid, did, ds, y = pm.read_model_input(files, str(root), part_sid=part)
+    assert len(y) == 6 + 3 + 1 + 60000 and np.nansum(y[sid == 7]) == 18 + 17 and np.isnan(y).sum() == 1
+    assert np.nansum(y[(sid == 12) & (did == 2)]) == 100 and np.nansum(y[did == 3]) == 200 * sum(range(300))
+    (root / 'series_id=7' / 'part-00004.csv.gz').write_bytes(gzip.compress(more.encode())[:-9])     # truncated
+    with pytest.raises(OSError, match='corrupt or truncated compressed stream in .*part-00004.csv.gz'):
+        pm.read_model_input(*pm.find_model_input(str(root))[:1], str(root))
+    os.remove(root / 'series_id=7' / 'part-00004.csv.gz')
+    (root / 'series_id=7' / 'part-00005.csv.bz2').write_bytes(b'BZh9')
     with pytest.raises(ValueError, match='compressed input file'):
         pm.find_model_input(str(root))
 
@@ -816,10 +833,11 @@ def test_as_pandas_udf_registers_the_references_two_schemas(monkeypatch):
 
 def test_native_csv_reader_permissive_mode(tmp_path):
     """spark.read.csv(schema=MODEL_INPUT_SCHEMA) runs in Spark's default mode PERMISSIVE
-    (prophet_modeler.py:109-114): a line that does not convert is a row of nulls, not an error.  The
-    native reader offers that as layout '...?' / mode='PERMISSIVE': the row comes out with a NaN
-    quantity (so the packer drops it exactly as fbprophet drops a null y), the good rows are
-    untouched, the count is reported; FAILFAST (default) still names file and line."""
+    (prophet_modeler.py:109-114): a line that does not convert is a row of nulls (EVERY column, dim_id
+    included), not an error.  The native reader offers that as layout '...?' / mode='PERMISSIVE': the record
+    is dropped and counted -- it must never come out under a made-up key (round-3 advice: it came out as
+    (series_id, dim_id = 0), which either joined series 0 or formed a one-row group whose fit raised) --,
+    the good rows are untouched; FAILFAST (default) still names file and line."""
     root = tmp_path / 'in' / 'series_id=7'
     root.mkdir(parents=True)
     lines = ['1,2019-01-01 00:00:00,10', '1,not-a-date,11', '1,2019-01-03 00:00:00,twelve',
@@ -830,13 +848,12 @@ def test_native_csv_reader_permissive_mode(tmp_path):
         pm.read_model_input(f, str(tmp_path / 'in'))
     stats = {}
     sid, did, ds_ns, y = pm.read_model_input(f, str(tmp_path / 'in'), mode='PERMISSIVE', stats=stats)
-    assert stats == {'malformed': 4} and len(y) == 7 and (sid == 7).all()
-    good = [0, 5]
-    assert list(y[good]) == [10.0, 15.0] and np.isnan(np.delete(y, good)).all()      # (the last line: an empty quantity is a plain null)
-    assert list(ds_ns[good].astype('datetime64[ns]').astype(str)) == ['2019-01-01T00:00:00.000000000', '2019-01-06T00:00:00.000000000']
-    # through the packer: only the rows fbprophet would keep
+    assert stats == {'malformed': 4} and len(y) == 3 and (sid == 7).all() and (did == 1).all()
+    assert list(y[:2]) == [10.0, 15.0] and np.isnan(y[2])      # (the last line: an empty quantity is a plain null, a valid record)
+    assert list(ds_ns[:2].astype('datetime64[ns]').astype(str)) == ['2019-01-01T00:00:00.000000000', '2019-01-06T00:00:00.000000000']
+    # through the packer: only the rows fbprophet would keep, and no key that is not in the file
     p = pk.pack_rows(sid, did, ds_ns, y, key_dtypes=(np.int32, np.int32))
-    assert p.N == 1 and list(p.y) == [10.0, 15.0]
+    assert p.N == 1 and list(p.y) == [10.0, 15.0] and len(p.dropped_keys) == 0
     with pytest.raises(ValueError, match='mode must be'):
         pm.read_model_input(f, str(tmp_path / 'in'), mode='DROPMALFORMED')
 

@@ -59,7 +59,7 @@ def build_lib(force=False, verbose=False):
             if verbose and did:
                 print('compiled', os.path.basename(obj))
     if changed or not os.path.exists(LIB):
-        cmd = [_hipcc(), '--offload-arch=' + ARCH, '-shared', '-fPIC', '-pthread', '-o', LIB] + [o for _, o in jobs]
+        cmd = [_hipcc(), '--offload-arch=' + ARCH, '-shared', '-fPIC', '-pthread', '-o', LIB] + [o for _, o in jobs] + ['-lz']
         subprocess.check_call(cmd)
         if verbose:
             print('linked', LIB)

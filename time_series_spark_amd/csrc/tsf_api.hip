@@ -36,6 +36,8 @@ struct tsf_ctx {
     size_t nb_ws_bytes;
     double *fut_tab;        // design table of a shared future grid (predict): [K][H]
     size_t fut_tab_bytes;
+    void *iv_ws;            // scratch of tsf_predict_intervals_dev (per-row pieces + samples of one chunk; grown on demand, <= ~0.5 GB)
+    size_t iv_ws_bytes;
     int32_t *order_dev[2];  // tsf_set_cost_hints: series in order of decreasing expected cost (two buffers, used in
     size_t order_cap[2];    // turn: a fit that is still running on its stream keeps reading the one it was given)
     int order_next;
@@ -82,6 +84,7 @@ extern "C" int tsf_create(int device_id, tsf_ctx **out)
     c->device = device_id; c->ws = nullptr; c->ws_bytes = 0; c->d_spec = nullptr;
     c->fut_tab = nullptr; c->fut_tab_bytes = 0;
     c->nb_ws = nullptr; c->nb_ws_bytes = 0;
+    c->iv_ws = nullptr; c->iv_ws_bytes = 0;
     c->order_dev[0] = c->order_dev[1] = nullptr; c->order_cap[0] = c->order_cap[1] = 0; c->order_next = 0; c->order_n = 0;
     c->order_ev[0] = c->order_ev[1] = nullptr; c->order_busy[0] = c->order_busy[1] = 0;
     c->profiling = 0; c->ev_created = 0; c->ev_count = 0;
@@ -90,16 +93,9 @@ extern "C" int tsf_create(int device_id, tsf_ctx **out)
         hipDeviceProp_t prop;
         c->n_cu = (hipGetDeviceProperties(&prop, device_id) == hipSuccess) ? prop.multiProcessorCount : 256;
     }
-    {
-        // stream-ordered scratch (tsf_predict_intervals_dev): keep freed blocks in the device's pool
-        // instead of handing them back to the driver at every synchronisation
-        hipMemPool_t pool;
-        if (hipDeviceGetDefaultMemPool(&pool, device_id) == hipSuccess) {
-            uint64_t keep = (uint64_t)2 << 30;
-            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
-        }
-        (void)hipGetLastError();
-    }
+    // (No hipMallocAsync anywhere in this library, and the device's default memory pool is left as the process
+    // set it: round 3 measured intermittently wrong Newton fits after gigabytes of stream-ordered scratch
+    // (DESIGN 5b), cause not found; every scratch buffer is a cached hipMalloc block of the context.)
     *out = c;
     return 0;
 }
@@ -115,6 +111,7 @@ extern "C" void tsf_destroy(tsf_ctx *ctx)
     if (ctx->d_spec) hipFree(ctx->d_spec);
     if (ctx->fut_tab) hipFree(ctx->fut_tab);
     if (ctx->nb_ws) hipFree(ctx->nb_ws);
+    if (ctx->iv_ws) hipFree(ctx->iv_ws);
     for (int b = 0; b < 2; ++b) { if (ctx->order_dev[b]) hipFree(ctx->order_dev[b]); if (ctx->order_ev[b]) hipEventDestroy(ctx->order_ev[b]); }
     if (ctx->ev_created)
         for (int i = 0; i < TSF_PROFILE_RING; ++i) { hipEventDestroy(ctx->ev0[i]); hipEventDestroy(ctx->ev1[i]); }
@@ -230,7 +227,17 @@ struct WsLayout {
 
 // checkpoint slots of the cooperative tail: one per fit that can be suspended at a time -- the blocks
 // resident when the launch runs dry (a few thousand), all series of a small call
-static int coop_slots_for(int64_t N) { return (int)(N < 8192 ? N : 8192); }
+constexpr size_t TSF_NB_KEEP = (size_t)1 << 30;
+
+// (after: FitArgs::coop_after.  COOP_DIRECT suspends nothing; the tail rule (< 0) suspends at most the fits
+// still running when no more of them are left than there are CUs -- 2 n_cu covers the waves racing past the
+// test; an explicit hand-over point (>= 0: tests, latency mode) can suspend every running fit)
+static int coop_slots_for(int64_t N, int after, int n_cu)
+{
+    if (after == COOP_DIRECT) return 0;
+    const int64_t cap = after >= 0 ? 8192 : 2 * (int64_t)n_cu;
+    return (int)(N < cap ? N : cap);
+}
 
 // launch plan of the matrix-core residual kernel
 struct MfmaPlan { int on, NG, KF, NCB, rr0, blocks; };
@@ -280,7 +287,13 @@ static int ensure_ws(tsf_ctx *ctx, size_t bytes, int64_t N = 0, int NTmax = 0, i
         // a ragged panel pads EVERY series' tables to the longest series of the call: say so instead of
         // failing inside hipMalloc
         size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && bytes > free_b + ctx->ws_bytes) {
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && bytes > free_b + ctx->ws_bytes && (ctx->nb_ws || ctx->iv_ws)) {
+            // the cached scratch of other entry points (Newton slot records: up to 6 GB; interval samples) gives way
+            if (ctx->nb_ws) { (void)hipFree(ctx->nb_ws); ctx->nb_ws = nullptr; ctx->nb_ws_bytes = 0; }
+            if (ctx->iv_ws) { (void)hipFree(ctx->iv_ws); ctx->iv_ws = nullptr; ctx->iv_ws_bytes = 0; }
+            (void)hipMemGetInfo(&free_b, &total_b);
+        }
+        if (free_b + total_b > 0 && bytes > free_b + ctx->ws_bytes) {
             char msg[384];
             snprintf(msg, sizeof(msg), "workspace of %.1f GB does not fit the device (%.1f GB free): %lld series, the longest has "
                      "%d rows%s", bytes / 1e9, (free_b + ctx->ws_bytes) / 1e9, (long long)N, NTmax * W,
@@ -381,6 +394,12 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     const bool quad_eval = theta_in != nullptr && theta_ref != nullptr;
     if (quad_eval && !(aligned && hs.growth == TSF_GROWTH_LINEAR && mode == 0 && hs.KP != 64))
         return fail(ctx, "the quadratic form needs an aligned panel, linear growth, additive columns only and 3 + n_changepoints + K <= 64");
+    // the slot records of the several-series-per-wave Newton kernel are cached between Newton calls, but at most
+    // TSF_NB_KEEP bytes of them outlive a call that does not use them
+    if (!(newton_quad && aligned) && ctx->nb_ws_bytes > TSF_NB_KEEP) {
+        HIP_TRY(ctx, hipFree(ctx->nb_ws));
+        ctx->nb_ws = nullptr; ctx->nb_ws_bytes = 0;
+    }
     QuadPlan qp;
     memset(&qp, 0, sizeof(qp));
     if (quad || newton_quad || quad_eval) {
@@ -433,7 +452,23 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     if (spec->residual_kernel == TSF_RK_COOP && !coop_ok && theta_in == nullptr)
         return fail(ctx, "residual_kernel COOP needs a residual-form L-BFGS fit of series of at most 4096 rows");
     const bool coop = coop_ok && spec->residual_kernel != TSF_RK_WAVE;
-    const int coop_slots = coop ? coop_slots_for(N) : 0;
+    // where fits are handed over (FitArgs::coop_after).  TSF_RK_COOP: the cooperative kernel runs every fit from
+    // its first evaluation (no one-wave phase, no checkpoints).  AUTO does the same for the models whose one-wave
+    // kernel holds two parameters per lane (KP = 64) on series too long for the grouped column sums: that kernel
+    // needs > 256 registers (one wave per SIMD) and measures 9.6 M evaluations/s on 50 000 x 730 with 56 columns,
+    // the workgroup kernel 11.4+ M.
+    // Round 3: on series of <= 768 rows the one-wave kernel of these models takes its per-column sums in groups
+    // of 8 (eval_fg GNTR: 187 instead of 379 registers, two waves per SIMD) and allocates only the history pairs
+    // it uses (wave_lds_bytes: eight blocks per CU instead of six): 17.0 M evaluations/s on cfg4 against the
+    // workgroup kernel's 15.4 M (2.27 against 2.50 s) -- so AUTO runs it, with the workgroup kernel for the tail
+    // as for the narrower models.  TSF_FIT_GROUPED=0: every series on the workgroup kernel, as before.
+    int coop_after = spec->residual_kernel == TSF_RK_COOP ? COOP_DIRECT : spec->coop_after;
+    if (coop) {
+        const char *eg = getenv("TSF_FIT_GROUPED");
+        const bool grouped = NTmax <= 12 && !(eg && atoi(eg) == 0) && lat_U == 0;
+        if (spec->residual_kernel == TSF_RK_AUTO && spec->coop_after < 0 && hs.KP == 64 && !grouped) coop_after = COOP_DIRECT;
+    }
+    const int coop_slots = coop ? coop_slots_for(N, coop_after, ctx->n_cu) : 0;
     const int coop_stride = coop ? coop_slot_doubles(hs.KP == 64 ? 2 : 1) : 0;
     const WsLayout l = ws_layout(N, n_grids, NTmax, hs.KP, qp.P4, qp.slots, (quad || newton_quad) && !aligned, lat_U, &mp,
                                  coop_slots, coop_stride);
@@ -557,19 +592,7 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
             a.coop_list = (int32_t *)(ws + l.clist);
             a.coop_slots = (double *)(ws + l.cslots);
             a.coop_max = coop_slots; a.coop_stride = coop_stride;
-            // TSF_RK_COOP: the cooperative kernel runs every fit from its first evaluation (no one-wave
-            // phase, no checkpoints).  AUTO does the same for the models whose one-wave kernel holds two
-            // parameters per lane (KP = 64): that kernel needs > 256 registers (one wave per SIMD) and
-            // measures 9.6 M evaluations/s on 50 000 x 730 with 56 columns, the workgroup kernel 11.4+ M.
-            a.coop_after = spec->residual_kernel == TSF_RK_COOP ? COOP_DIRECT : spec->coop_after;
-            // Round 3: on series of <= 768 rows the one-wave kernel of these models takes its per-column sums in groups
-            // of 8 (eval_fg GNTR: 187 instead of 379 registers, two waves per SIMD) and allocates only the history pairs
-            // it uses (wave_lds_bytes: eight blocks per CU instead of six): 17.0 M evaluations/s on cfg4 against the
-            // workgroup kernel's 15.4 M (2.27 against 2.50 s) -- so AUTO runs it, with the workgroup kernel for the tail
-            // as for the narrower models.  TSF_FIT_GROUPED=0: every series on the workgroup kernel, as before.
-            const char *eg = getenv("TSF_FIT_GROUPED");
-            const bool grouped = NTmax <= 12 && !(eg && atoi(eg) == 0) && lat_U == 0;
-            if (spec->residual_kernel == TSF_RK_AUTO && spec->coop_after < 0 && hs.KP == 64 && !grouped) a.coop_after = COOP_DIRECT;
+            a.coop_after = coop_after;
             a.coop_blocks = ctx->n_cu;
             HIP_TRY(ctx, hipMemsetAsync(a.coop_ctl, 0, 4 * sizeof(int), st));
         }
@@ -686,11 +709,11 @@ struct DevBuf {
 size_t ysize(int dt) { return dt == TSF_Y_F64 ? 8 : 4; }
 }  // namespace
 
-static int fit_host(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, int32_t T,
-                    const int64_t *offsets, const int64_t *ds, const void *y, int32_t y_dtype,
-                    const double *floor_, const double *cap, const double *extra,
-                    tsf_fit_out *out, const double *theta_in, double *f_out, double *grad_out,
-                    const double *theta_ref = nullptr)
+static int fit_host_one(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, int32_t T,
+                        const int64_t *offsets, const int64_t *ds, const void *y, int32_t y_dtype,
+                        const double *floor_, const double *cap, const double *extra,
+                        tsf_fit_out *out, const double *theta_in, double *f_out, double *grad_out,
+                        const double *theta_ref = nullptr)
 {
     if (!ctx) return -1;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -801,6 +824,101 @@ static int fit_host(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, 
     if (host_timing)
         fprintf(stderr, "[host-timing] N %lld: alloc + H2D + clears %.3f ms, fit (launch .. device idle) %.3f ms, D2H %.3f ms\n",
                 (long long)N, t_h2d - t_start, t_fit - t_h2d, now() - t_fit);
+    return 0;
+}
+
+
+// Ragged panels by length.  The device tables of a ragged call are laid out [series][NTmax] (NTmax = steps of
+// the LONGEST series of the call: every other series' rows are padding), so one 100 000-row series among
+// 10 000 series of 700 rows would ask for ~224 GB.  When the padding is more than half of the layout (and the
+// layout is not small anyway) the host entry point therefore cuts the call into length classes -- the longest
+// series and every series at least half as long, then the same again for the rest: at most ~11 classes, each
+// padded by < 2 x -- and runs one fit call per class on the gathered rows: workspace proportional to the rows
+// that exist.  Every series is fitted by itself, so the results do not depend on the grouping (GPU test:
+// bit-identical to the single call).  Scheduling hints (tsf_set_cost_hints) are for whole calls and are not
+// applied to the classes.  tsf_fit_ragged_dev (device pointers: the lengths are not on the host) leaves
+// this to its caller.
+static int fit_host(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, int32_t T,
+                    const int64_t *offsets, const int64_t *ds, const void *y, int32_t y_dtype,
+                    const double *floor_, const double *cap, const double *extra,
+                    tsf_fit_out *out, const double *theta_in, double *f_out, double *grad_out,
+                    const double *theta_ref = nullptr)
+{
+    if (!ctx) return -1;
+    if (aligned || theta_in || !offsets || !spec || N < 2 || y_dtype < TSF_Y_F64 || y_dtype > TSF_Y_I32)
+        return fit_host_one(ctx, spec, N, aligned, T, offsets, ds, y, y_dtype, floor_, cap, extra, out, theta_in,
+                            f_out, grad_out, theta_ref);
+    int64_t sum_nt = 0, nt_max = 0;
+    for (int64_t n = 0; n < N; ++n) {
+        const int64_t len = offsets[n + 1] - offsets[n];
+        if (len < 0 || len > (int64_t)TSF_MAX_T)
+            return fit_host_one(ctx, spec, N, aligned, T, offsets, ds, y, y_dtype, floor_, cap, extra, out,
+                                theta_in, f_out, grad_out, theta_ref);      // (reports the error)
+        const int64_t nt = (len + W - 1) / W;
+        sum_nt += nt;
+        if (nt > nt_max) nt_max = nt;
+    }
+    static const char *e_split = getenv("TSF_RAGGED_SPLIT");        // 0: never, 1: whenever the padding rule says so (tests)
+    const int force = e_split ? atoi(e_split) : -1;
+    const double padded = (double)N * (double)nt_max;
+    const bool small = padded * 512.0 * (3 + tsf_spec_K(spec)) < 256e6;
+    if (force == 0 || padded <= 2.0 * (double)sum_nt || (small && force != 1))
+        return fit_host_one(ctx, spec, N, aligned, T, offsets, ds, y, y_dtype, floor_, cap, extra, out, theta_in,
+                            f_out, grad_out, theta_ref);
+    std::vector<int64_t> order((size_t)N);
+    for (int64_t n = 0; n < N; ++n) order[(size_t)n] = n;
+    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {
+        return offsets[a + 1] - offsets[a] > offsets[b + 1] - offsets[b];
+    });
+    const int stride = tsf_theta_stride(spec);
+    const size_t ys = (y_dtype == TSF_Y_F64) ? 8 : 4;
+    const int64_t total = offsets[N] - offsets[0];
+    for (int64_t b0 = 0; b0 < N;) {
+        const int64_t top = (offsets[order[(size_t)b0] + 1] - offsets[order[(size_t)b0]] + W - 1) / W;
+        int64_t b1 = b0;
+        while (b1 < N && 2 * ((offsets[order[(size_t)b1] + 1] - offsets[order[(size_t)b1]] + W - 1) / W) >= top) ++b1;
+        const int64_t nb = b1 - b0;
+        // the class in the caller's order (stable: neighbours stay neighbours)
+        std::vector<int64_t> idx(order.begin() + b0, order.begin() + b1);
+        std::sort(idx.begin(), idx.end());
+        std::vector<int64_t> off((size_t)nb + 1, 0);
+        for (int64_t i = 0; i < nb; ++i) off[(size_t)i + 1] = off[(size_t)i] + (offsets[idx[(size_t)i] + 1] - offsets[idx[(size_t)i]]);
+        const int64_t rows = off[(size_t)nb];
+        std::vector<int64_t> dsb((size_t)rows);
+        std::vector<char> yb((size_t)rows * ys);
+        std::vector<double> flb, cpb, exb;
+        if (floor_) flb.resize((size_t)nb);
+        if (cap) cpb.resize((size_t)nb);
+        if (spec->n_extra > 0 && extra) exb.resize((size_t)spec->n_extra * (size_t)rows);
+        for (int64_t i = 0; i < nb; ++i) {
+            const int64_t n = idx[(size_t)i], r0 = offsets[n], len = offsets[n + 1] - r0;
+            if (len > 0) {
+                memcpy(dsb.data() + off[(size_t)i], ds + r0, (size_t)len * 8);
+                memcpy(yb.data() + (size_t)off[(size_t)i] * ys, (const char *)y + (size_t)r0 * ys, (size_t)len * ys);
+                for (int e = 0; e < spec->n_extra && !exb.empty(); ++e)
+                    memcpy(exb.data() + (size_t)e * rows + off[(size_t)i], extra + (size_t)e * total + r0, (size_t)len * 8);
+            }
+            if (floor_) flb[(size_t)i] = floor_[n];
+            if (cap) cpb[(size_t)i] = cap[n];
+        }
+        std::vector<double> th((size_t)nb * stride), ysc((size_t)nb), fv((size_t)nb);
+        std::vector<int32_t> st((size_t)nb), it((size_t)nb), ev((size_t)nb);
+        std::vector<tsf_grid_info> gr((size_t)nb);
+        tsf_fit_out ob;
+        ob.theta = th.data(); ob.y_scale = ysc.data(); ob.fval = fv.data(); ob.status = st.data();
+        ob.n_iter = it.data(); ob.n_eval = ev.data(); ob.grid = gr.data();
+        const int rc = fit_host_one(ctx, spec, nb, 0, 0, off.data(), dsb.data(), yb.data(), y_dtype,
+                                    floor_ ? flb.data() : nullptr, cap ? cpb.data() : nullptr,
+                                    exb.empty() ? (spec->n_extra > 0 ? extra : nullptr) : exb.data(), &ob, nullptr, nullptr, nullptr);
+        if (rc) return rc;
+        for (int64_t i = 0; i < nb; ++i) {
+            const int64_t n = idx[(size_t)i];
+            memcpy(out->theta + (size_t)n * stride, th.data() + (size_t)i * stride, sizeof(double) * stride);
+            out->y_scale[n] = ysc[(size_t)i]; out->fval[n] = fv[(size_t)i]; out->status[n] = st[(size_t)i];
+            out->n_iter[n] = it[(size_t)i]; out->n_eval[n] = ev[(size_t)i]; out->grid[n] = gr[(size_t)i];
+        }
+        b0 = b1;
+    }
     return 0;
 }
 
@@ -991,20 +1109,26 @@ extern "C" int tsf_predict_intervals_dev(tsf_ctx *ctx, const tsf_spec *spec, int
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_spec, &hs, sizeof(hs), hipMemcpyHostToDevice, st));
     // Series are processed in chunks sized so that ALL scratch of a chunk -- the per-row pieces of the
     // point forecast (t, additive term, 1 + multiplicative term) and the samples -- stays within
-    // 512 MB.  The scratch is stream-ordered (hipMallocAsync / hipFreeAsync on the caller's stream):
-    // nothing here waits for the device, as the `_dev` contract (include/tsf.h) promises.
+    // 512 MB.  The scratch is ONE cached block of the context (like the fit workspace: grown on demand by a
+    // plain hipMalloc, which waits for the device only on the call that grows it); the chunks of a call and
+    // successive calls reuse it in stream order, so in the steady state nothing here waits for the device, as
+    // the `_dev` contract (include/tsf.h) promises.  (Round 3 used hipMallocAsync / hipFreeAsync here; see
+    // tsf_create.)  As with the workspace: one stream at a time per context.
     const size_t per_series = (size_t)H * 8 * (3 + (size_t)n_samples);
     int64_t chunk = (int64_t)(((size_t)512 << 20) / per_series);
     if (chunk < 1) chunk = 1;
     if (chunk > N) chunk = N;
-    double *d_t = nullptr, *d_xa = nullptr, *d_opm = nullptr, *d_samp = nullptr;
     const size_t nh = (size_t)chunk * H;
-    auto release = [&]() {
-        if (d_t) (void)hipFreeAsync(d_t, st);
-        if (d_xa) (void)hipFreeAsync(d_xa, st);
-        if (d_opm) (void)hipFreeAsync(d_opm, st);
-        if (d_samp) (void)hipFreeAsync(d_samp, st);
-    };
+    {
+        const size_t need = 8 * nh * (3 + (size_t)n_samples);
+        if (ctx->iv_ws_bytes < need) {
+            if (ctx->iv_ws) { HIP_TRY(ctx, hipFree(ctx->iv_ws)); ctx->iv_ws = nullptr; ctx->iv_ws_bytes = 0; }
+            HIP_TRY(ctx, hipMalloc(&ctx->iv_ws, need));
+            ctx->iv_ws_bytes = need;
+        }
+    }
+    double *d_t = (double *)ctx->iv_ws, *d_xa = d_t + nh, *d_opm = d_xa + nh, *d_samp = d_opm + nh;
+    auto release = [&]() {};
 #define HIP_TRY_REL(expr)                                                                     \
     do {                                                                                      \
         hipError_t e_ = (expr);                                                               \
@@ -1014,10 +1138,6 @@ extern "C" int tsf_predict_intervals_dev(tsf_ctx *ctx, const tsf_spec *spec, int
             return -2;                                                                        \
         }                                                                                     \
     } while (0)
-    HIP_TRY_REL(hipMallocAsync((void **)&d_t, 8 * nh, st));
-    HIP_TRY_REL(hipMallocAsync((void **)&d_xa, 8 * nh, st));
-    HIP_TRY_REL(hipMallocAsync((void **)&d_opm, 8 * nh, st));
-    HIP_TRY_REL(hipMallocAsync((void **)&d_samp, 8 * nh * n_samples, st));
     PredictArgs p;
     memset(&p, 0, sizeof(p));
     p.sp = ctx->d_spec; p.N = N; p.H = H; p.theta_stride = tsf_theta_stride(spec);
@@ -1052,7 +1172,6 @@ extern "C" int tsf_predict_intervals_dev(tsf_ctx *ctx, const tsf_spec *spec, int
                            sizeof(double) * NSP, st, a, NSP);
         HIP_TRY_REL(hipGetLastError());
     }
-    release();      // stream-ordered: the blocks go back to the pool when the kernels above are done
 #undef HIP_TRY_REL
     return 0;
 }

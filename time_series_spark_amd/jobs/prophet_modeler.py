@@ -328,7 +328,8 @@ def as_pandas_udf(fn, columns=MODEL_OUTPUT_COLUMNS):
     return pandas_udf(schema, PandasUDFType.GROUPED_MAP)(fn)
 
 
-_COMPRESSED = ('.gz', '.bz2', '.snappy', '.lz4', '.zst', '.deflate', '.xz')
+# codecs spark.read.csv would decompress and the native reader does not (.gz and .deflate it inflates itself: zlib)
+_COMPRESSED = ('.bz2', '.snappy', '.lz4', '.zst', '.xz')
 
 
 def find_model_input(root):
@@ -336,7 +337,8 @@ def find_model_input(root):
     (None if there is none), ordered by (series_id, path): partition directories in numeric
     order hand the packer a table that is already grouped.  As `spark.read.csv(path)` does, every
     non-hidden file counts (names starting with `_` or `.` -- `_SUCCESS`, `.part-0.crc` -- are
-    skipped); a compressed file raises (Spark would decompress it; this reader does not)."""
+    skipped).  `.gz` / `.deflate` parts are read (the native reader inflates them, as Spark's Hadoop codecs
+    do transparently); a file in another codec raises (Spark would decompress it; this reader does not)."""
     if os.path.isfile(root):
         return [root], [None]
     found = []
@@ -370,8 +372,8 @@ def read_model_input(files, root, n_threads=0, part_sid=None, mode='FAILFAST', s
     """Parse model-input CSV files into (series_id, dim_id, ds_ns, y) arrays (int64, int64,
     int64 ns, float64 with NaN for nulls).  mode: 'FAILFAST' (a line that does not match the schema
     raises, naming file and line) or 'PERMISSIVE' (spark.read.csv's default at prophet_modeler.py:109:
-    such a line becomes a row of nulls, which the fit drops like any null-y row; stats['malformed']
-    counts them).  A `series_id=<v>` directory between `root` and the
+    such a line becomes a row of nulls there -- dim_id included --, whose null y the fit would drop; the
+    reader drops the record itself, it never appears under a made-up key; stats['malformed'] counts them).  A `series_id=<v>` directory between `root` and the
     file supplies series_id for that file (Spark's partition discovery); the file then holds
     the remaining MODEL_INPUT_SCHEMA columns in order.  part_sid: the partition values if the
     caller knows them already (find_model_input)."""
@@ -406,7 +408,8 @@ def read_model_input(files, root, n_threads=0, part_sid=None, mode='FAILFAST', s
         rc = L.tsf_csv_read(len(pick), paths, sids.ctypes.data, layout, int(n_threads), ctypes.byref(h),
                             ctypes.byref(n_rows), ctypes.byref(ef), ctypes.byref(el))
         if rc == _lib.CSV_E_OPEN:
-            raise OSError('cannot read %s' % files[pick[ef.value]])
+            raise OSError(('corrupt or truncated compressed stream in %s' if el.value == -1 else 'cannot read %s')
+                          % files[pick[ef.value]])
         if rc == _lib.CSV_E_PARSE:
             raise ValueError('%s line %d does not match the model-input schema %s'
                              % (files[pick[ef.value]], el.value, layout.decode()))
@@ -460,12 +463,12 @@ class ProphetModeler:
         files, part = find_model_input(root)
         # io.input_mode: 'FAILFAST' (default here: a malformed line raises with file and line) or
         # 'PERMISSIVE' (what spark.read.csv does by default, prophet_modeler.py:109: the line becomes a
-        # row of nulls and the fit drops it)
+        # row of nulls there; here the reader drops the record and counts it)
         mode = str(self.config['io'].get('input_mode', 'FAILFAST')).upper()
         stats = {}
         cols = read_model_input(files, root, part_sid=part, mode=mode, stats=stats)
         if stats.get('malformed'):
-            self.logger.warning('%d malformed model-input rows read as nulls (PERMISSIVE)', stats['malformed'])
+            self.logger.warning('%d malformed model-input records dropped (PERMISSIVE)', stats['malformed'])
         return cols
 
     def persist_models(self, model_df):

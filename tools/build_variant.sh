@@ -13,6 +13,6 @@ mkdir -p "$out"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -Wno-unused-value -pthread "$@" \
     -c "$root/time_series_spark_amd/csrc/$base.hip" -o "$out/${base}_$tag.o"
 others=$(ls $obj/*.o | grep -v "/$base.o")
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -pthread -o "$out/libtsf_amd_$tag.so" $others "$out/${base}_$tag.o"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -pthread -o "$out/libtsf_amd_$tag.so" $others "$out/${base}_$tag.o" -lz
 rm -f "$out/${base}_$tag.o"
 echo "built $out/libtsf_amd_$tag.so"

@@ -9,7 +9,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 echo "== pytest -m gpu" | tee $OUT/summary.txt
 if [ -z "$SKIP_TESTS" ]; then
-timeout 900 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/summary.txt
+timeout 1500 python -m pytest tests -m gpu -x -q --durations=12 > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/summary.txt
 tail -5 $OUT/pytest_gpu.log | tee -a $OUT/summary.txt
 fi
 echo "== bench" | tee -a $OUT/summary.txt
