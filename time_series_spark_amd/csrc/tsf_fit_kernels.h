@@ -513,6 +513,24 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
 // Stan L-BFGS (BFGSMinimizer<LBFGSUpdate>::step, WolfeLineSearch, WolfLSZoom, CubicInterp)
 // ---------------------------------------------------------------------------------------
 
+// a / 3.0, correctly rounded, without the ~22-instruction IEEE division sequence: with y = RN(1/3),
+// q = RN(a y), r = a - 3 q (exact: one fma), RN(q + r y) IS RN(a / 3) (Markstein's correction step; the
+// divisor's significand is not all ones), wherever nothing over- or underflows -- so only for
+// 2^-900 <= |a| <= 2^1000, and the wave takes the true division if any lane holds anything else (zeros, NaN,
+// infinities included).  Checked against a / 3.0 on 4e8 operands (round-4 notes in DESIGN.md).
+__device__ __forceinline__ double div3_rn(double a)
+{
+    const double aa = __builtin_fabs(a);
+    const bool safe = aa >= 0x1p-900 && aa <= 0x1p1000;
+    if (__all(safe)) {
+        const double y = 0x1.5555555555555p-2;
+        const double q = a * y;
+        const double r = __builtin_fma(-3.0, q, a);
+        return __builtin_fma(r, y, q);
+    }
+    return a / 3.0;
+}
+
 // value a/b/c/d in lane 0/1/2/3 (other lanes: d)
 __device__ __forceinline__ double lanes4(double a, double b, double c, double d)
 {
@@ -539,7 +557,7 @@ __device__ __forceinline__ double cubic_interp6(double df0, double x1, double f1
     const double sr = lanes4(-(c2 + t_s), -(c2 - t_s), 0.0, 0.0) / c3;
     const double s1 = readlane_f64(sr, 0), s2 = readlane_f64(sr, 1);
     const double xs = lanes4(loX, hiX, s1, s2);
-    const double pv = xs * (xs * (xs * c3 / 3.0 + c2) / 2.0 + c1);
+    const double pv = xs * (xs * (div3_rn(xs * c3) + c2) / 2.0 + c1);
     double tmpF, minF, minX;
     minF = readlane_f64(pv, 0);
     minX = loX;

@@ -69,19 +69,29 @@ struct QuadLds {
 // cn_assemble_q lane constants (lc, sc, qc: [3][PPL][64] doubles).  They depend on the model and
 // on the number of changepoints only: one copy per workgroup on an aligned panel (every wave
 // writes the same bits), one per wave on a ragged one.
+// ... followed (fit_quad_kernel / eval_quad_kernel) by a table of QC_N wave-uniform constants, read with
+// broadcast LDS loads where the code needs them.  Round 4: the fp64 literals of exp (13 coefficients: two
+// v_mov_b32 each, 26 vector instructions per evaluation) and the optimiser's tolerances (kernel arguments the
+// compiler kept in scalar registers spilled into VGPR lanes: ~22 v_readlane per iteration to get six doubles
+// back) cost vector-issue slots, which is what this kernel is bound by; an LDS read of a uniform address costs
+// none.  Same values, same operations (the oracle is untouched).
+constexpr int QC_N = 32;
+enum { QC_LOG2E = 0, QC_LN2HI = 1, QC_LN2LO = 2, QC_EXP_P = 3 /* 11 coefficients */, QC_EXP_HI = 14, QC_EXP_LO = 15,
+       QC_TOL_OBJ = 16, QC_TOL_REL_OBJ = 17, QC_TOL_GRAD = 18, QC_TOL_REL_GRAD = 19, QC_TOL_PARAM = 20,
+       QC_INIT_ALPHA = 21, QC_RC_RATIO = 22,
+       QC_GRAD2_LO = 23, QC_GRAD2_HI = 24, QC_PARAM2_LO = 25, QC_PARAM2_HI = 26, QC_RELGRAD_LO = 27, QC_RELGRAD_HI = 28 };
 template <int PPL>
-constexpr size_t quad_lanec_bytes() { return sizeof(double) * 3 * PPL * W; }
+constexpr size_t quad_lanec_bytes() { return sizeof(double) * (3 * PPL * W + QC_N); }
 
-// The trend tables of a residual pass as a POOL of the workgroup (RPOOL kernels: 16 waves per CU).  A
-// residual pass -- the initial point and the re-centrings, ~6 of a series' ~450 evaluations, a tenth of its
-// time -- needs the tables of QuadLds (ks, mc, tp1/2, tot1/2, accR, th: 4.3 KB); an evaluation of the
-// quadratic form needs none of them.  Sixteen private copies do not fit next to M, the history rings and the
-// per-wave vectors, so NS < NW copies are shared: a wave takes one for the duration of a pass.  Per wave stay
-// D / ref / c (QuadWave, 1.5 KB) and the history ring (5 KB).
-// The lock is one LDS word per slot.  Every lane issues the compare-and-swap (wave-uniform control flow:
-// a lane-0-only retry loop is the pattern the comment in fit_quad_kernel warns about); exactly one lane of
-// one wave sees the word go 0 -> 1.  LDS operations of a CU execute in issue order, so the acquire / release
-// fences below only have to hold the compiler (and the s_waitcnt it derives from them) in place.
+// a wave-uniform constant from the LDS table.  volatile: the load stays where it is written -- hoisted out of the
+// optimiser's loops each constant would occupy a VGPR pair for the whole fit, which is what the table exists to
+// avoid.  (Tried instead: ordinary loads through a pointer re-derived once per iteration behind an empty asm
+// statement -- the 12-wave kernel then spilled 49 registers per lane to scratch; with volatile loads none.)
+// (The cast names the address space: a volatile access through a generic pointer is not rewritten to LDS by the
+// compiler's address-space inference and would become a flat load.)
+typedef const volatile __attribute__((address_space(3))) double *qc_lds_ptr;
+__device__ __forceinline__ double qc(const double *ct, int k) { return *((qc_lds_ptr)ct + k); }
+
 template <int PPL>
 struct QuadWave { double dl[PPL * W], ref[PPL * W], cvec[PPL * W]; };
 
@@ -227,13 +237,78 @@ template <int PPL>
 struct LaneConst {
     const double *lc, *sc, *qc;         // in LDS, entry p = lane + 64 s at [s * 64 + lane]
     double inv_tau;
+    const double *ct;                   // table of wave-uniform constants (QC_*), or null (Newton kernels)
 };
+
+// the math constants of the table (dm_exp_sel's, in its order)
+__device__ const double QC_MATH[16] = {
+    1.4426950408889634, 6.93147180369123816490e-01, 1.90821492927058770002e-10,
+    1.6059043836821613e-10, 2.08767569878681e-09, 2.505210838544172e-08, 2.755731922398589e-07,
+    2.7557319223985893e-06, 2.48015873015873e-05, 1.984126984126984e-04, 1.388888888888889e-03,
+    8.333333333333333e-03, 4.1666666666666664e-02, 1.6666666666666666e-01,
+    709.782712893384, -745.2};
+
+// fills the table behind the lane constants (lane k writes entry k); opt: the call's optimiser settings
+__device__ __forceinline__ void quad_const_table(double *ct, const LbfgsOpts &opt, double recenter_ratio)
+{
+    const int l = lane_id();
+    double v = 0.0;
+    if (l < 16) v = QC_MATH[l];
+    else if (l == QC_TOL_OBJ) v = opt.tol_obj;
+    else if (l == QC_TOL_REL_OBJ) v = opt.tol_rel_obj_eps;
+    else if (l == QC_TOL_GRAD) v = opt.tol_grad;
+    else if (l == QC_TOL_REL_GRAD) v = opt.tol_rel_grad_eps;
+    else if (l == QC_TOL_PARAM) v = opt.tol_param;
+    else if (l == QC_INIT_ALPHA) v = opt.init_alpha;
+    else if (l == QC_RC_RATIO) v = recenter_ratio;
+    // brackets of the termination tests that compare a NORM or a QUOTIENT with a tolerance (fit_one_quad): where the
+    // operand is clearly on one side the square root / the division is not taken.  (1 +- 4 eps) covers every
+    // rounding on the way; a tolerance whose square leaves the normal range, or that is not positive and finite,
+    // gets the bracket (0, inf) / (-inf, inf): every test then takes the exact path.
+    else if (l >= QC_GRAD2_LO && l <= QC_PARAM2_HI) {
+        const double tol = (l <= QC_GRAD2_HI) ? opt.tol_grad : opt.tol_param;
+        const double t2 = tol * tol;
+        const bool ok = tol > 0.0 && t2 >= 1e-290 && t2 <= 1e290;
+        const bool lo = (l == QC_GRAD2_LO || l == QC_PARAM2_LO);
+        v = ok ? t2 * (lo ? 1.0 - 8.881784197001252e-16 : 1.0 + 8.881784197001252e-16) : (lo ? 0.0 : __builtin_huge_val());
+    } else if (l == QC_RELGRAD_LO || l == QC_RELGRAD_HI) {
+        const double t = opt.tol_rel_grad_eps;
+        const bool ok = t >= 1e-290 && t <= 1e290;
+        v = (l == QC_RELGRAD_LO) ? (ok ? t * (1.0 - 8.881784197001252e-16) : -__builtin_huge_val())
+                                 : (ok ? t * (1.0 + 8.881784197001252e-16) : __builtin_huge_val());
+    }
+    if (l < QC_N) ct[l] = v;
+}
+
+// dm_exp_sel (tsf_detmath.h) with its constants read from the table: the same operations on the same values
+__device__ __forceinline__ double dm_exp_sel_tab(double x, const double *ct)
+{
+    const double n = __builtin_rint(x * qc(ct, QC_LOG2E));
+    double r = __builtin_fma(-n, qc(ct, QC_LN2HI), x);
+    r = __builtin_fma(-n, qc(ct, QC_LN2LO), r);
+    double p = qc(ct, QC_EXP_P);
+#pragma unroll
+    for (int k = 1; k < 11; ++k) p = __builtin_fma(p, r, qc(ct, QC_EXP_P + k));
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    const double hi = qc(ct, QC_EXP_HI), lo = qc(ct, QC_EXP_LO);
+    const bool in_range = (x <= hi) && (x >= lo);
+    const int ni = in_range ? (int)n : 0;
+    const int n1 = ni / 2, n2 = ni - n1;
+    double e = (p * dm_pow2i(n1)) * dm_pow2i(n2);
+    if (x > hi) e = __builtin_huge_val();
+    if (x < lo) e = 0.0;
+    if (x != x) e = x;
+    return e;
+}
 
 template <int PPL>
 __device__ __forceinline__ void lane_consts(const DevSpec *sp, const SeriesView &sv,
                                             double *dst, LaneConst<PPL> &k)
 {
     const double C25 = 1.0 / 25.0;
+    k.ct = nullptr;
     k.inv_tau = 1.0 / sv.tau;
     double *lcp = dst, *scp = dst + PPL * W, *qcp = dst + 2 * PPL * W;
     k.lc = lcp; k.sc = scp; k.qc = qcp;
@@ -262,14 +337,14 @@ struct AsmPre {
     double lc[PPL], sc[PPL];
 };
 
-template <int PPL>
+template <int PPL, bool CTAB = false>
 __device__ __forceinline__ void assemble_pre(const SeriesView &sv, const LaneConst<PPL> &lk,
                                              const double (&th)[PPL], AsmPre<PPL> &ap)
 {
     const int lane = lane_id();
     const double k = readlane_f64(th[0], 0), m = readlane_f64(th[0], 1), ls = readlane_f64(th[0], 2);
     const double C25 = 1.0 / 25.0;
-    const double sigma = dm_exp_sel(ls);
+    const double sigma = CTAB ? dm_exp_sel_tab(ls, lk.ct) : dm_exp_sel(ls);
     const double s2 = sigma * sigma;
     ap.inv_s2 = 1.0 / s2;
     ap.s2 = s2;
@@ -382,7 +457,14 @@ __device__ __forceinline__ bool resid_eval_q(const SeriesView &sv, QuadLds<KP, P
 #ifndef TSF_QUAD_MPIPE
 #define TSF_QUAD_MPIPE 1
 #endif
-template <int PPL, int PQ, int MRS = W, int MB_ = 16, bool MREG = false, bool MPIPE = (TSF_QUAD_MPIPE != 0)>
+// exp's fp64 literals from the LDS table (dm_exp_sel_tab) instead of two v_mov_b32 each.  Measured (round 4,
+// profiles/r04_quad/phase_cycles.txt): 26 vector instructions fewer per evaluation and 1 000 cycles MORE -- each
+// Horner step then waits for its own LDS round trip (the loads are volatile and stay at their use), and a wave of
+// this kernel is bound by its dependent chains, not by vector issue.  Off; the table keeps the tolerances.
+#ifndef TSF_QUAD_EXPTAB
+#define TSF_QUAD_EXPTAB 0
+#endif
+template <int PPL, int PQ, int MRS = W, int MB_ = 16, bool MREG = false, bool MPIPE = (TSF_QUAD_MPIPE != 0), bool CTAB = false>
 __device__ __forceinline__ bool gram_eval_q(const SeriesView &sv, const LaneConst<PPL> &lk,
                                             const double *Ml, int P4, const double (&th)[PPL],
                                             const double *ref_l, const double *cvec_l,
@@ -405,7 +487,7 @@ __device__ __forceinline__ bool gram_eval_q(const SeriesView &sv, const LaneCons
     }
     if (PQ > 0) { dl[lane] = D[0]; wave_sync(); }
     AsmPre<PPL> ap;
-    assemble_pre<PPL>(sv, lk, th, ap);
+    assemble_pre<PPL, CTAB>(sv, lk, th, ap);
     const double *mp = Ml + lane;
     if (PQ > 0) {
         static_assert(PQ == 0 || PPL == 1, "compile-time M rows only for P <= 64");
@@ -694,12 +776,12 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
         a.y_scale[n] = st.y_scale;
         if (!a.aligned || n == 0) a.grid_out[a.aligned ? 0 : n] = a.gtab[a.aligned ? 0 : n].info;
     }
-    double xk[PPL], gk[PPL], pk[PPL], xk1[PPL], gk1[PPL], pk1[PPL];
+    double xk[PPL], gk[PPL], pk[PPL], xk1[PPL], gk1[PPL];
 #pragma unroll
     for (int s = 0; s < PPL; ++s) {
         const int p = lane + s * W;
         xk[s] = (p == 0) ? st.k0 : (p == 1 ? st.m0 : 0.0);
-        gk[s] = 0.0; pk[s] = 0.0; xk1[s] = xk[s]; gk1[s] = 0.0; pk1[s] = 0.0;
+        gk[s] = 0.0; pk[s] = 0.0; xk1[s] = xk[s]; gk1[s] = 0.0;
     }
     if (st.status0 != 0) {
         if (st.status0 == TSF_ST_CONSTANT) {
@@ -711,7 +793,16 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
         return;
     }
     LaneConst<PPL> lk;
+    quad_const_table(lanec + 3 * PPL * W, a.opt, qa.recenter_ratio);
     lane_consts<PPL>(sp, sv, lanec, lk);
+    lk.ct = lanec + 3 * PPL * W;
+    // The table is READ by the aligned shared-M kernels only (12 and 16 waves per CU, register budgets 168 / 128: the
+    // tolerances as kernel arguments were SGPR pairs spilled into VGPR lanes there, ~22 v_readlane per iteration).
+    // The ragged and two-slot kernels run at 256 registers per lane with nothing to spare, and ANY read of the table
+    // inside their iteration loop made the register allocator spill 40 more values per lane to scratch (measured:
+    // tools/dev one-kernel compiles, ragged panels 15.3 -> 18 ms); they keep reading the kernel arguments.
+    constexpr bool CT = HLDS && !RAGGED && !MREG && PQ > 0 && PPL == 1;
+    const double *const ct = lk.ct;
     QT_DECL;
     if (RAGGED) {
         // ragged panel: this series has its own grid, hence its own M = Z^T Z.  The wave builds
@@ -779,6 +870,9 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
     }
     int h0 = 0;                          // HLDS: ring slot of the oldest pair
     double *const histS = hist, *const histY = hist + QH * PPL * W;
+    // HLDS: rho of the pair in ring slot s at histR[s] (round 4: as five scalars in age order they were five SGPR
+    // pairs live across the whole fit, shifted by select chains and spilled into VGPR lanes every iteration)
+    double *const histR = hist + 2 * QH * PPL * W;
 
     double fk = 0.0, fk1 = 0.0, alpha = a.opt.init_alpha, gammak = 1.0;
     int itNum = 0, ret = 0, resetB = 0, hist_len = 0, since_rc = 0;
@@ -790,6 +884,7 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
     // bits, so they are computed once and carried
     double gp = 0.0;
     bool gp_valid = false, pk1_scaled = false;
+    double gp1s = 0.0;                  // g_{k-1}.(p_{k-1} / B0fact) where the previous direction was rescaled (below)
 
     const int eval_limit = 64 * a.opt.max_iter + 1024;      // guard, see cn_lbfgs (oracle)
     // Residual-form evaluation at xk (cn_resid_q): the initial point, and a re-centring of the
@@ -854,8 +949,15 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
             // one lane each, operands moved into place inside the quad
             const double dots = bfly_sum4_lanes(pdot_part<PPL>(gk, gk), pdot_part<PPL>(sk, sk),
                                                 pdot_part<PPL>(yk, sk), pdot_part<PPL>(yk, yk));
-            const double nrm = __builtin_sqrt(dots);
-            const double gradNorm = readlane_f64(nrm, 0), stepNorm = readlane_f64(nrm, 2);
+            // |g| and |s| are only ever COMPARED with a tolerance: the squares decide wherever they are clearly on
+            // one side (quad_const_table: brackets of width 8 eps around tol^2), the square root is taken otherwise
+            // -- same outcome as `sqrt(x2) < tol` for every x2, NaN included
+            const double g2sum = readlane_f64(dots, 0), s2sum = readlane_f64(dots, 2);
+            auto norm_below = [&](double x2, int k_lo, int k_tol) -> bool {
+                if (x2 < qc(ct, k_lo)) return true;
+                if (x2 >= qc(ct, k_lo + 1)) return false;
+                return __builtin_sqrt(x2) < qc(ct, k_tol);
+            };
             double qnum = dpp_mov<0x07>(dots);          // quad_perm [3,1,0,0]: y.y, y.s, -, -
             if ((lane & 3) >= 2) qnum = 1.0;
             const double qden = dpp_mov<0x5D>(dots);    // quad_perm [1,3,1,1]: y.s, y.y, y.s, y.s
@@ -863,8 +965,14 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
             if (resetB) {
                 const double B0fact = readlane_f64(qv, 0);
                 hist_len = 0;
+                // Stan rescales the previous direction here and the next line search's first step is interpolated from
+                // g_{k-1}.p_{k-1} with the rescaled p_{k-1}: the only use of that vector, so the dot product is taken now
+                // (pk still holds the direction of the line search that just ended, gk1 the gradient it started from)
+                // and the vector itself is not kept -- two registers per lane and a swap per iteration less
+                double ps[PPL];
 #pragma unroll
-                for (int s = 0; s < PPL; ++s) pk1[s] = pk1[s] / B0fact;
+                for (int s = 0; s < PPL; ++s) ps[s] = pk[s] / B0fact;
+                gp1s = pdot<PPL>(gk1, ps);
                 alpha = UQ(alpha * B0fact);
                 pk1_scaled = true;
             } else {
@@ -878,20 +986,16 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
                 int slot;
                 if (hist_len < QH) {
                     slot = h0 + hist_len; if (slot >= QH) slot -= QH;
-#pragma unroll
-                    for (int h = 0; h < QH; ++h) if (h == hist_len) rh[h] = rho_new;
                     hist_len++;
                 } else {
                     slot = h0; h0 = (h0 + 1 == QH) ? 0 : h0 + 1;
-#pragma unroll
-                    for (int h = 0; h + 1 < QH; ++h) rh[h] = rh[h + 1];
-                    rh[QH - 1] = rho_new;
                 }
 #pragma unroll
                 for (int s = 0; s < PPL; ++s) {
                     histS[(slot * PPL + s) * W + lane] = sk[s];
                     histY[(slot * PPL + s) * W + lane] = yk[s];
                 }
+                histR[slot] = rho_new;          // (every lane: the same value to the same word)
                 wave_sync();
 #pragma unroll
                 for (int h = 0; h < QH; ++h) {
@@ -901,6 +1005,7 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
                         Sh[h][s] = histS[(sl * PPL + s) * W + lane];
                         Yh[h][s] = histY[(sl * PPL + s) * W + lane];
                     }
+                    rh[h] = histR[sl];          // (slots of age >= hist_len: stale or unset, never used)
                 }
             } else {
             if (hist_len < QH) {
@@ -937,6 +1042,11 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
 #pragma unroll
             for (int h = QH - 1; h >= 0; --h) {
                 if (h < hist_len) {
+                    // (alphas as the VECTORS whose lane 63 holds the value -- the second loop uses them in lane 63 only --
+                    // instead of five scalars saves 29 vector instructions per iteration (no SGPR pairs spilled into
+                    // VGPR lanes) and costs ten registers per lane across the recursion: the kernel then spills to
+                    // scratch, 114 instead of 80 MB of HBM traffic per cfg2 launch for 1.5 % of its time
+                    // (profiles/r04_quad/ab_alphas.txt).  Scalars stay: no scratch at all.)
                     const double aa = lane63(rh[h] * pdot_l63<PPL>(Sh[h], pk));
 #pragma unroll
                     for (int s = 0; s < PPL; ++s) pk[s] = __builtin_fma(-aa, Yh[h][s], pk[s]);
@@ -959,13 +1069,30 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
                                                 __builtin_fmax(__builtin_fabs(fk), 1.0));
             gp = pdot<PPL>(gk, pk);
             gp_valid = true;
-            if (dF < a.opt.tol_obj) ret = TSF_ST_ABSF;
-            else if (dF < a.opt.tol_rel_obj_eps * fmaxv) ret = TSF_ST_RELF;
-            else if (gradNorm < a.opt.tol_grad) ret = TSF_ST_ABSGRAD;
-            else if (-gp / __builtin_fmax(__builtin_fabs(fk), 1.0) < a.opt.tol_rel_grad_eps) ret = TSF_ST_RELGRAD;
-            else if (stepNorm < a.opt.tol_param) ret = TSF_ST_ABSX;
-            else if (itNum >= a.opt.max_iter) ret = TSF_ST_MAXIT;
-            else ret = 0;
+            // -g.p / max(|f|, 1) < tol_rel_grad: the same bracketing for the quotient (m >= 1)
+            auto relgrad_below = [&]() -> bool {
+                const double m = __builtin_fmax(__builtin_fabs(fk), 1.0), ngp = -gp;
+                if (ngp < qc(ct, QC_RELGRAD_LO) * m) return true;
+                if (ngp > qc(ct, QC_RELGRAD_HI) * m) return false;
+                return ngp / m < qc(ct, QC_TOL_REL_GRAD);
+            };
+            if constexpr (CT) {
+                if (dF < qc(ct, QC_TOL_OBJ)) ret = TSF_ST_ABSF;
+                else if (dF < qc(ct, QC_TOL_REL_OBJ) * fmaxv) ret = TSF_ST_RELF;
+                else if (norm_below(g2sum, QC_GRAD2_LO, QC_TOL_GRAD)) ret = TSF_ST_ABSGRAD;
+                else if (relgrad_below()) ret = TSF_ST_RELGRAD;
+                else if (norm_below(s2sum, QC_PARAM2_LO, QC_TOL_PARAM)) ret = TSF_ST_ABSX;
+                else if (itNum >= a.opt.max_iter) ret = TSF_ST_MAXIT;
+                else ret = 0;
+            } else {
+                if (dF < a.opt.tol_obj) ret = TSF_ST_ABSF;
+                else if (dF < a.opt.tol_rel_obj_eps * fmaxv) ret = TSF_ST_RELF;
+                else if (__builtin_sqrt(g2sum) < a.opt.tol_grad) ret = TSF_ST_ABSGRAD;
+                else if (-gp / __builtin_fmax(__builtin_fabs(fk), 1.0) < a.opt.tol_rel_grad_eps) ret = TSF_ST_RELGRAD;
+                else if (__builtin_sqrt(s2sum) < a.opt.tol_param) ret = TSF_ST_ABSX;
+                else if (itNum >= a.opt.max_iter) ret = TSF_ST_MAXIT;
+                else ret = 0;
+            }
 
             QT_LAP(1);
             if (ret != 0) break;
@@ -984,11 +1111,11 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
             if (itNum > 1 && resetB != 2) {
                 // g_{k-1}.p_{k-1} is the slope `dfp` of the previous line search unless p_{k-1}
                 // has been rescaled since
-                const double gp1 = pk1_scaled ? pdot<PPL>(gk1, pk1) : dfp;
+                const double gp1 = pk1_scaled ? gp1s : dfp;
                 const double ci = cubic_interp6(gp1, alpha, fk - fk1, gp, minAlpha, 1.0);
                 alpha = UQ(__builtin_fmin(1.0, 1.01 * ci));
             } else {
-                alpha = a.opt.init_alpha;
+                alpha = CT ? qc(ct, QC_INIT_ALPHA) : a.opt.init_alpha;
             }
             dfp = gp;
             c1dfp = UQ(c1 * dfp); c2dfp = UQ(c2 * dfp);
@@ -1028,7 +1155,7 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
                 for (int s = 0; s < PPL; ++s) { xk1[s] = __builtin_fma(alpha, pk[s], xk[s]); xe[s] = xk1[s]; }
                 sv.n_eval++;
                 QT_LAP(2);
-                const bool bad = gram_eval_q<PPL, PQ, MRS, MBATCH, MREG, MPIPE>(sv, lk, Mp, P4, xe, ref_w, cvec_w, s0, fe, ge, q2, dl_w, mreg);
+                const bool bad = gram_eval_q<PPL, PQ, MRS, MBATCH, MREG, MPIPE, (TSF_QUAD_EXPTAB != 0)>(sv, lk, Mp, P4, xe, ref_w, cvec_w, s0, fe, ge, q2, dl_w, mreg);
                 QT_LAP(4);
 #pragma unroll
                 for (int s = 0; s < PPL; ++s) gk1[s] = ge[s];
@@ -1046,6 +1173,7 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
                     continue;
                 }
                 const double newDFp = pdot<PPL>(gk1, pk);
+                QT_LAP(5);                  // (aligned panels: slot 5 = from the end of the evaluation to g.p of the trial point)
                 bool ls_ok = false;
                 if (!zoom) {
                     lsRestarts = 0;
@@ -1086,10 +1214,9 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
         for (int s = 0; s < PPL; ++s) {
             const double tx = xk[s]; xk[s] = xk1[s]; xk1[s] = tx;
             const double tg = gk[s]; gk[s] = gk1[s]; gk1[s] = tg;
-            const double tp = pk[s]; pk[s] = pk1[s]; pk1[s] = tp;
         }
         since_rc++;
-        do_resid = q2 > qa.recenter_ratio * s0 || since_rc >= qa.recenter_every;
+        do_resid = q2 > (CT ? qc(ct, QC_RC_RATIO) : qa.recenter_ratio) * s0 || since_rc >= qa.recenter_every;
     }
     store_theta<PPL>(a, sv, n, xk, a.theta);
     if (lane == 0) { a.status[n] = ret; a.n_iter[n] = itNum; a.n_eval[n] = sv.n_eval; a.fval[n] = fk; }
@@ -1104,8 +1231,9 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
 // 4 ragged panel, M of the running series in the wave's registers (built in its global slot first)
 enum { QM_LDS = 0, QM_GLOBAL = 1, QM_RAGGED = 2, QM_RAGGED_LDS = 3, QM_RAGGED_REG = 4, QM_GLOBAL_REG = 5 };
 
+// (S and Y of the QH pairs, then their rho = 1 / y.s by ring slot: 8 doubles)
 template <int PPL>
-constexpr size_t quad_hist_bytes(bool hlds) { return hlds ? sizeof(double) * 2 * QH * PPL * W : 0; }
+constexpr size_t quad_hist_bytes(bool hlds) { return hlds ? sizeof(double) * (2 * QH * PPL * W + 8) : 0; }
 
 // NTR > 0: residual-pass weights of the first NTR steps in registers (RLDS false; steps beyond: global scratch)
 // RPOOL (NW = 16, four waves per SIMD at <= 128 registers): trend tables from a pool of pool_slots QuadLds
@@ -1221,7 +1349,9 @@ __global__ __launch_bounds__(64) void eval_quad_kernel(QuadArgs qa, const double
         SeriesView sv;
         make_view_q<KP, 1>(a, n, sv);
         LaneConst<1> lk;
+        quad_const_table(lanec + 3 * W, a.opt, qa.recenter_ratio);
         lane_consts<1>(a.sp, sv, lanec, lk);
+        lk.ct = lanec + 3 * W;
         double xr[1], gr[1], fr, s0, ztr[1];
         load_theta<1>(a, sv, n, theta_ref, xr);
         const bool bad_ref = resid_eval_q<KP, 1, NTR>(sv, wl, lk, rb, xr, fr, gr, s0, ztr);
@@ -1231,7 +1361,7 @@ __global__ __launch_bounds__(64) void eval_quad_kernel(QuadArgs qa, const double
         double th[1], g[1], f, q2;
         load_theta<1>(a, sv, n, a.theta_in, th);
         const double mreg[1] = {0.0};
-        const bool bad = gram_eval_q<1, PQ, W, 8, false, true>(sv, lk, Ml, qa.P4, th, wl.ref, wl.cvec, s0, f, g, q2, wl.th, mreg);
+        const bool bad = gram_eval_q<1, PQ, W, 8, false, true, (TSF_QUAD_EXPTAB != 0)>(sv, lk, Ml, qa.P4, th, wl.ref, wl.cvec, s0, f, g, q2, wl.th, mreg);
         store_theta<1, false>(a, sv, n, g, a.grad_out);
         if (lane == 0) { a.fval[n] = f; a.status[n] = (bad || bad_ref) ? 1 : 0; }
         wave_sync();

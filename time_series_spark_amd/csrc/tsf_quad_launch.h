@@ -94,8 +94,8 @@ static int launch_quad_rl(const QuadPlan &qp, const QuadArgs &qa, double *Mg, hi
         double sum[8] = {0};
         long long mx = 0;
         for (int64_t i = 0; i < qa.f.N; ++i) { for (int k = 0; k < 8; ++k) sum[k] += (double)h[i * 8 + k]; if (h[i * 8 + 7] > mx) mx = h[i * 8 + 7]; }
-        fprintf(stderr, "[quad-timing] N %lld waves/CU %d pool %d mean cycles/series: misc %.0f post %.0f (+ two-loop %.0f) ls %.0f resid %.0f gram %.0f | total %.0f max %lld\n",
-                (long long)qa.f.N, NW, pool_slots, sum[0] / qa.f.N, sum[1] / qa.f.N, sum[6] / qa.f.N, sum[2] / qa.f.N, sum[3] / qa.f.N, sum[4] / qa.f.N, sum[7] / qa.f.N, mx);
+        fprintf(stderr, "[quad-timing] N %lld waves/CU %d pool %d mean cycles/series: misc %.0f post %.0f (+ two-loop %.0f) ls %.0f resid %.0f gram %.0f newDFp %.0f | total %.0f max %lld\n",
+                (long long)qa.f.N, NW, pool_slots, sum[0] / qa.f.N, sum[1] / qa.f.N, sum[6] / qa.f.N, sum[2] / qa.f.N, sum[3] / qa.f.N, sum[4] / qa.f.N, sum[5] / qa.f.N, sum[7] / qa.f.N, mx);
         hipFree(qb.dbg);
         return (int)hipGetLastError();
     }

@@ -52,7 +52,7 @@ def main():
         else:
             path = a
     blocks = []
-    cur = {'label': 'entry', 'start': 1, 'ins': [], 'succ': []}
+    cur = {'label': 'entry', 'start': 1, 'ins': [], 'succ': [], 'depth': 0, 'hdr': ''}
     for i, line in enumerate(open(path), 1):
         s = line.strip()
         m = re.match(r'^(\.LBB\d+_\d+):', s)
@@ -62,6 +62,11 @@ def main():
             cur['end'] = i - 1
             blocks.append(cur)
             cur = {'label': m.group(1), 'start': i, 'ins': [], 'succ': []}
+            d = re.search(r'Depth=(\d+)', s)
+            h = re.search(r'Header=(\w+)', s)
+            inner = re.search(r'Inner Loop Header', s)
+            cur['depth'] = int(d.group(1)) if d else 0
+            cur['hdr'] = h.group(1) if h else ('*' if inner or 'Loop Header' in s else '')
             continue
         op = s.split()[0]
         cur['ins'].append((op, s))
@@ -71,7 +76,8 @@ def main():
     blocks.append(cur)
     order = {b['label']: k for k, b in enumerate(blocks)}
     cats = ['f64', 'rdl', 'wrl', 'mov', 'dpp', 'cnd', 'cmp', 'vother', 'lds', 'vmem', 'smem', 'salu', 'wait', 'nop', 'br']
-    print('%-12s %11s %5s | %s | succ' % ('block', 'lines', 'valu', ' '.join('%4s' % c[:4] for c in cats)))
+    print('%-12s %11s %2s %-9s %5s | %s | succ' % ('block', 'lines', 'd', 'loop', 'valu', ' '.join('%4s' % c[:4] for c in cats)))
+    by_depth = {}
     tot = dict.fromkeys(cats, 0)
     for k, b in enumerate(blocks):
         cnt = dict.fromkeys(cats + ['other'], 0)
@@ -80,14 +86,23 @@ def main():
         valu = sum(cnt[c] for c in ('f64', 'rdl', 'wrl', 'mov', 'dpp', 'cnd', 'cmp', 'vother'))
         for c in cats:
             tot[c] += cnt[c]
+        bd = by_depth.setdefault((b['depth'], b['hdr']), dict.fromkeys(cats + ['valu', 'all'], 0))
+        bd['valu'] += valu
+        bd['all'] += len(b['ins'])
+        for c in cats:
+            bd[c] += cnt[c]
         if valu < min_valu:
             continue
         succ = []
         for t in b['succ']:
             succ.append(t + ('^' if t in order and order[t] <= k else ''))
-        print('%-12s %5d-%-5d %5d | %s | %s' % (b['label'], b['start'], b['end'], valu,
+        print('%-12s %5d-%-5d %2d %-9s %5d | %s | %s' % (b['label'], b['start'], b['end'], b['depth'], b['hdr'], valu,
                                                ' '.join('%4d' % cnt[c] for c in cats), ' '.join(succ)))
     print('total', tot)
+    print('by loop (depth, header): all instructions, valu, then the mix')
+    for k in sorted(by_depth):
+        v = by_depth[k]
+        print('  depth %d %-10s all %5d valu %5d | %s' % (k[0], k[1], v['all'], v['valu'], ' '.join('%s %d' % (c, v[c]) for c in cats if v[c])))
 
 
 if __name__ == '__main__':
