@@ -329,14 +329,38 @@ void tsf_pack_free(tsf_pack *p);
  *   line fails the read (FAILFAST).
  * Returns 0; TSF_CSV_E_OPEN / TSF_CSV_E_PARSE with *err_file (index into paths) and *err_line
  * (1-based) set; -1 bad arguments, -2 out of memory, -3 other failure. */
-enum { TSF_CSV_E_OPEN = -10, TSF_CSV_E_PARSE = -11 };
+enum { TSF_CSV_E_OPEN = -10, TSF_CSV_E_PARSE = -11, TSF_CSV_E_CODEC = -12 };
 typedef struct tsf_csv tsf_csv;
 int tsf_csv_read(int32_t n_files, const char *const *paths, const int64_t *series_id,
                  const char *layout, int32_t n_threads, tsf_csv **out, int64_t *n_rows,
                  int32_t *err_file, int64_t *err_line);
 int tsf_csv_fetch(tsf_csv *t, int64_t *series_id, int64_t *dim_id, int64_t *ds, double *y);
+/* The table's own columns ([n_rows] each, valid until tsf_csv_free): a caller that can adopt foreign memory
+ * (numpy can) saves the copy of tsf_csv_fetch. */
+int tsf_csv_columns(tsf_csv *t, const int64_t **series_id, const int64_t **dim_id, const int64_t **ds,
+                    const double **y);
 int64_t tsf_csv_malformed(const tsf_csv *t);     /* records dropped in permissive mode */
 void tsf_csv_free(tsf_csv *t);
+
+/* ---- input discovery (host side) -----------------------------------------------------------
+ * What spark.read.csv(path) lists under a directory (prophet_modeler.py:109-114): every regular file below
+ * `root` whose name, and every directory's name on the way, does not start with '_' or '.' (_SUCCESS, .crc,
+ * _temporary); a `series_id=<int>` directory supplies series_id for the files below it (Hive partition
+ * discovery).  A root that is a regular file is that file alone.  The files come out partitioned ones first,
+ * by partition value, then by path -- so that the reader's rows arrive grouped --: *n_partitioned of the
+ * *n_files.  tsf_csv_dir_paths / _series_id can be handed to tsf_csv_read as they are (layout "dtq" for the
+ * first n_partitioned, "sdtq" for the rest).
+ * Returns 0, or with the handle still valid (free it) TSF_CSV_E_OPEN (a directory could not be read),
+ * TSF_CSV_E_PARSE (a `series_id=` directory whose value is not an integer) or TSF_CSV_E_CODEC (a part in a
+ * codec the reader does not inflate: .bz2 .snappy .lz4 .zst .xz; .gz and .deflate are read) with the offending
+ * path in tsf_csv_dir_error_path; -1 bad arguments, -2 out of memory. */
+typedef struct tsf_csv_dir tsf_csv_dir;
+int tsf_csv_discover(const char *root, int32_t n_threads, tsf_csv_dir **out, int32_t *n_files,
+                     int32_t *n_partitioned);
+const char *const *tsf_csv_dir_paths(const tsf_csv_dir *d);
+const int64_t *tsf_csv_dir_series_id(const tsf_csv_dir *d);
+const char *tsf_csv_dir_error_path(const tsf_csv_dir *d);
+void tsf_csv_dir_free(tsf_csv_dir *d);
 
 /* ---- forecast sink (host side) -------------------------------------------------------------
  * ProphetScorer.convert_forecasts + write_forecasts in one pass

@@ -236,6 +236,80 @@ def test_input_discovery_follows_spark_rules(tmp_path):
         pm.find_model_input(str(root))
 
 
+def test_native_discovery_and_in_place_reader_match_the_python_walk(tmp_path):
+    """read_model_input_dir (tsf_csv_discover + tsf_csv_read on its path list, rows parsed straight into one block
+    that numpy adopts) against read_model_input(*find_model_input(root)): the same rows in the same order on a tree
+    with partition and plain directories, nested directories, hidden files, a symlinked directory, compressed
+    parts, blank lines (the block then has gaps to close) and, in PERMISSIVE mode, dropped records; the same
+    errors for a foreign codec, a non-integer partition value and a malformed line."""
+    import gzip
+    root = tmp_path / 'in'
+    rng = np.random.default_rng(5)
+
+    def lines(dim, n, start):
+        return ''.join('%d,2021-%02d-%02d 00:00:00,%d\n' % (dim, 1 + (start + i) // 28 % 12, 1 + (start + i) % 28, rng.integers(1, 99))
+                       for i in range(n))
+    for sid in (12, 7, 100, 3):
+        d = root / ('series_id=%d' % sid)
+        d.mkdir(parents=True)
+        (d / 'part-00000').write_text(lines(1, 40, sid))
+        (d / 'part-00001.csv').write_text(lines(2, 5, sid) + '\n\n' + lines(2, 3, sid + 9) + '   \n')      # blank lines
+        (d / '.part-00000.crc').write_text('x')
+        (d / '_SUCCESS').write_text('')
+    (root / 'series_id=7' / 'sub').mkdir()
+    (root / 'series_id=7' / 'sub' / 'part-00002.gz').write_bytes(gzip.compress(lines(3, 6, 2).encode()))
+    (root / '_temporary').mkdir()
+    (root / '_temporary' / 'part-00009').write_text('garbage')
+    (root / 'loose').mkdir()
+    (root / 'loose' / 'a.csv').write_text(''.join('55,' + l for l in lines(4, 4, 0).splitlines(True)))        # 4 columns
+    (tmp_path / 'elsewhere' / 'series_id=41').mkdir(parents=True)
+    (tmp_path / 'elsewhere' / 'series_id=41' / 'p.csv').write_text(lines(5, 7, 1))
+    os.symlink(tmp_path / 'elsewhere' / 'series_id=41', root / 'series_id=41')
+    files, part = pm.find_model_input(str(root))
+    want = pm.read_model_input(files, str(root), part_sid=part)
+    got = pm.read_model_input_dir(str(root))
+    assert len(got[3]) == 4 * 48 + 6 + 4 + 7
+    for a, b in zip(want, got):
+        assert a.dtype == b.dtype and np.array_equal(a, b, equal_nan=True)
+    assert list(np.unique(got[0])) == [3, 7, 12, 41, 55, 100] and list(got[0][:48]) == [3] * 48       # partition order
+    for nt in (1, 3):
+        for a, b in zip(got, pm.read_model_input_dir(str(root), n_threads=nt)):
+            assert np.array_equal(a, b, equal_nan=True)
+    # the arrays outlive every reference to the native table but their own
+    import gc
+    y = got[3]
+    del got, want
+    gc.collect()
+    assert y.sum() > 0
+    # a single file as root; an empty directory
+    one = pm.read_model_input_dir(str(root / 'loose' / 'a.csv'))
+    assert list(one[0]) == [55] * 4 and list(one[1]) == [4] * 4
+    (tmp_path / 'empty').mkdir()
+    assert len(pm.read_model_input_dir(str(tmp_path / 'empty'))[3]) == 0
+    # PERMISSIVE: dropped records leave gaps inside the block
+    (root / 'series_id=3' / 'part-00003.csv').write_text('1,2021-01-01 00:00:00,5\n1,bad,6\nx,2021-01-03 00:00:00,7\n1,2021-01-04 00:00:00,8\n')
+    with pytest.raises(ValueError, match=r'series_id=3/part-00003.csv line 2 '):
+        pm.read_model_input_dir(str(root))
+    stats = {}
+    got = pm.read_model_input_dir(str(root), mode='PERMISSIVE', stats=stats)
+    stats2 = {}
+    files, part = pm.find_model_input(str(root))
+    want = pm.read_model_input(files, str(root), part_sid=part, mode='PERMISSIVE', stats=stats2)
+    assert stats == stats2 == {'malformed': 2}
+    for a, b in zip(want, got):
+        assert np.array_equal(a, b, equal_nan=True)
+    assert got[3][got[0] == 3][-2:].tolist() == [5.0, 8.0]
+    os.remove(root / 'series_id=3' / 'part-00003.csv')
+    # errors
+    (root / 'series_id=12' / 'part-9.csv.zst').write_bytes(b'xx')
+    with pytest.raises(ValueError, match='compressed input file .*part-9.csv.zst'):
+        pm.read_model_input_dir(str(root))
+    os.remove(root / 'series_id=12' / 'part-9.csv.zst')
+    (root / 'series_id=abc').mkdir()
+    with pytest.raises(ValueError, match='series_id=abc'):
+        pm.read_model_input_dir(str(root))
+
+
 def test_shard_indices_partition():
     """series i on rank i mod world: the shards of all ranks partition the panel, sizes differ by at most one,
     shard_rank inverts it."""

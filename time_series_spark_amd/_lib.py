@@ -81,9 +81,10 @@ EXPORTS = ['tsf_create', 'tsf_destroy', 'tsf_last_error', 'tsf_device_count', 't
            'tsf_predict', 'tsf_predict_dev', 'tsf_predict_intervals', 'tsf_predict_intervals_dev', 'tsf_eval', 'tsf_eval_quadratic', 'tsf_design', 'tsf_selftest_math',
            'tsf_set_cost_hints', 'tsf_set_profiling', 'tsf_profile_read', 'tsf_last_fit_kernel_ms',
            'tsf_pack_rows', 'tsf_pack_fetch', 'tsf_pack_free',
-           'tsf_csv_read', 'tsf_csv_fetch', 'tsf_csv_malformed', 'tsf_csv_free', 'tsf_csv_write_forecasts']
+           'tsf_csv_read', 'tsf_csv_fetch', 'tsf_csv_columns', 'tsf_csv_malformed', 'tsf_csv_free', 'tsf_csv_write_forecasts',
+           'tsf_csv_discover', 'tsf_csv_dir_paths', 'tsf_csv_dir_series_id', 'tsf_csv_dir_error_path', 'tsf_csv_dir_free']
 
-CSV_E_OPEN, CSV_E_PARSE = -10, -11          # TSF_CSV_E_* (include/tsf.h)
+CSV_E_OPEN, CSV_E_PARSE, CSV_E_CODEC = -10, -11, -12          # TSF_CSV_E_* (include/tsf.h)
 
 _lib = None
 
@@ -141,10 +142,20 @@ def load():
     L.tsf_pack_fetch.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.tsf_pack_free.argtypes = [vp]
     L.tsf_pack_free.restype = None
-    L.tsf_csv_read.argtypes = [i32, ctypes.POINTER(ctypes.c_char_p), vp, ctypes.c_char_p, i32,
+    L.tsf_csv_read.argtypes = [i32, vp, vp, ctypes.c_char_p, i32,
                                ctypes.POINTER(vp), ctypes.POINTER(i64), ctypes.POINTER(i32),
                                ctypes.POINTER(i64)]
     L.tsf_csv_fetch.argtypes = [vp, vp, vp, vp, vp]
+    L.tsf_csv_columns.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp)]
+    L.tsf_csv_discover.argtypes = [ctypes.c_char_p, i32, ctypes.POINTER(vp), ctypes.POINTER(i32), ctypes.POINTER(i32)]
+    L.tsf_csv_dir_paths.argtypes = [vp]
+    L.tsf_csv_dir_paths.restype = vp
+    L.tsf_csv_dir_series_id.argtypes = [vp]
+    L.tsf_csv_dir_series_id.restype = vp
+    L.tsf_csv_dir_error_path.argtypes = [vp]
+    L.tsf_csv_dir_error_path.restype = ctypes.c_char_p
+    L.tsf_csv_dir_free.argtypes = [vp]
+    L.tsf_csv_dir_free.restype = None
     L.tsf_csv_malformed.argtypes = [vp]
     L.tsf_csv_malformed.restype = ctypes.c_int64
     L.tsf_csv_free.argtypes = [vp]

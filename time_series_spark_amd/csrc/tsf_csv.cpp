@@ -12,13 +12,17 @@
 // (a small file is one segment, a big one is cut at line ends every 4 MB); rows come out in
 // file order, files in the order given.  gzip / zlib compressed parts (.gz, .deflate) are inflated in
 // memory (zlib), as Spark's Hadoop codecs do transparently.
+#include <dirent.h>
+#include <errno.h>
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -34,12 +38,31 @@
 
 namespace {
 
-struct FileCols {
-    std::vector<int64_t> sid, did, ds;
-    std::vector<double> y;
+// One segment of input (a small file, or a piece of a big one cut at line ends) and where its rows go: straight
+// into the table's one block of columns at `first` (round 4: a vector per column and segment, then a copy into the
+// caller's arrays, touched every row's 32 bytes three times and every page of three allocations once -- the page
+// faults, not the parsing, were most of the 0.13 s this reader took on 10 000 part files).
+struct SegOut {
+    int64_t *sid = nullptr, *did = nullptr, *ds = nullptr;
+    double *y = nullptr;
+    int64_t first = 0;      // first row of the segment in the block
+    int64_t cap = 0;        // lines of the segment: an upper bound of its rows (blank / dropped lines write none)
+    int64_t n = 0;          // rows written
     int err = 0;            // TSF_CSV_* code
     int64_t err_line = 0;   // 1-based
     int64_t malformed = 0;  // permissive mode: records that did not match the schema (dropped, counted)
+};
+
+// file contents: one uninitialised allocation (a std::vector would zero 170 MB first)
+struct FileBuf {
+    char *p = nullptr;
+    size_t n = 0;
+    FileBuf() = default;
+    FileBuf(const FileBuf &) = delete;
+    FileBuf &operator=(const FileBuf &) = delete;
+    ~FileBuf() { std::free(p); }
+    bool alloc(size_t bytes) { std::free(p); p = (char *)std::malloc(bytes ? bytes : 1); n = p ? bytes : 0; return p != nullptr; }
+    void release() { std::free(p); p = nullptr; n = 0; }
 };
 
 // days from 1970-01-01 of a proleptic Gregorian date (valid for all int years)
@@ -158,13 +181,8 @@ bool parse_quantity(const char *a, const char *b, double *out) {
 // layout: one letter per column of the file: s series_id, d dim_id, t start_time, q quantity,
 // x ignored.  Parses the lines of [p, end) (whole lines); line numbers in errors are relative to p.
 void parse_range(const char *p, const char *end, const char *layout, int ncol, int64_t sid_const,
-                 bool permissive, FileCols &out) {
-    size_t guess = (size_t)(end - p) / 24 + 1;
-    out.did.reserve(guess);
-    out.ds.reserve(guess);
-    out.y.reserve(guess);
-    out.sid.reserve(guess);
-    int64_t line = 0;
+                 bool permissive, SegOut &out) {
+    int64_t line = 0, w = 0;
     while (p < end) {
         const char *eol = (const char *)std::memchr(p, '\n', (size_t)(end - p));
         if (!eol) eol = end;
@@ -210,25 +228,46 @@ void parse_range(const char *p, const char *end, const char *layout, int ncol, i
             p = eol + 1;
             continue;
         }
-        out.sid.push_back(sid);
-        out.did.push_back(did);
-        out.ds.push_back(ds);
-        out.y.push_back(q);
+        if (w >= out.cap) {         // (cannot happen: cap counts every line)
+            out.err = TSF_CSV_E_PARSE;
+            out.err_line = line;
+            return;
+        }
+        out.sid[w] = sid;
+        out.did[w] = did;
+        out.ds[w] = ds;
+        out.y[w] = q;
+        ++w;
         p = eol + 1;
     }
+    out.n = w;
+}
+
+// lines of [p, end): newline characters, plus one for an unterminated last line
+int64_t count_lines(const char *p, const char *end) {
+    int64_t n = 0;
+    const char *q = p;
+    while (q < end) {
+        const char *nl = (const char *)std::memchr(q, '\n', (size_t)(end - q));
+        if (!nl) break;
+        ++n;
+        q = nl + 1;
+    }
+    if (q < end) ++n;
+    return n;
 }
 
 // gzip members (.gz: what Hadoop's GzipCodec writes and spark.read.csv decompresses transparently,
 // prophet_modeler.py:109-114) and zlib streams (.deflate: DefaultCodec), recognised by their header bytes;
 // several concatenated members are one file.  false = corrupt or truncated stream.
-bool inflate_all(const std::vector<char> &in, std::vector<char> &out) {
+bool inflate_all(const FileBuf &in, std::vector<char> &out) {
     z_stream zs;
     std::memset(&zs, 0, sizeof(zs));
     if (inflateInit2(&zs, 15 + 32) != Z_OK) return false;       // + 32: gzip or zlib header, detected
     out.clear();
-    out.resize(in.size() * 6 + 4096);
-    zs.next_in = (Bytef *)in.data();
-    zs.avail_in = (uInt)in.size();
+    out.resize(in.n * 6 + 4096);
+    zs.next_in = (Bytef *)in.p;
+    zs.avail_in = (uInt)in.n;
     size_t have = 0;
     bool ok = true;
     for (;;) {
@@ -251,34 +290,35 @@ bool inflate_all(const std::vector<char> &in, std::vector<char> &out) {
     return ok;
 }
 
-bool is_deflated(const std::vector<char> &b) {
-    if (b.size() < 2) return false;
-    const unsigned char b0 = (unsigned char)b[0], b1 = (unsigned char)b[1];
+bool is_deflated(const FileBuf &b) {
+    if (b.n < 2) return false;
+    const unsigned char b0 = (unsigned char)b.p[0], b1 = (unsigned char)b.p[1];
     if (b0 == 0x1f && b1 == 0x8b) return true;                                  // gzip
     return (b0 & 0x0f) == 8 && (b0 >> 4) <= 7 && ((b0 << 8) | b1) % 31 == 0 && b0 == 0x78;    // zlib, 32 K window
 }
 
 // the whole file with one open / fstat / read / close (10 000 part files of a Hive-partitioned input are
 // 40 000 system calls instead of the 70 000 of fopen / fseek / ftell / fread / fclose)
-bool read_whole(const char *path, std::vector<char> &buf, bool *corrupt) {
+bool read_whole(const char *path, FileBuf &buf, bool *corrupt) {
     *corrupt = false;
     const int fd = ::open(path, O_RDONLY | O_CLOEXEC);
     if (fd < 0) return false;
     struct stat sb;
     if (::fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) { ::close(fd); return false; }
-    buf.resize((size_t)sb.st_size);
+    if (!buf.alloc((size_t)sb.st_size)) { ::close(fd); throw std::bad_alloc(); }
     size_t got = 0;
-    while (got < buf.size()) {
-        const ssize_t k = ::read(fd, buf.data() + got, buf.size() - got);
+    while (got < buf.n) {
+        const ssize_t k = ::read(fd, buf.p + got, buf.n - got);
         if (k <= 0) break;
         got += (size_t)k;
     }
     ::close(fd);
-    if (got != buf.size()) return false;
+    if (got != buf.n) return false;
     if (is_deflated(buf)) {
         std::vector<char> raw;
         if (!inflate_all(buf, raw)) { *corrupt = true; return false; }
-        buf.swap(raw);
+        if (!buf.alloc(raw.size())) throw std::bad_alloc();
+        std::memcpy(buf.p, raw.data(), raw.size());
     }
     return true;
 }
@@ -294,10 +334,13 @@ struct Segment {
 }  // namespace
 
 struct tsf_csv {
-    std::vector<FileCols> files;    // one entry per SEGMENT, in file order then byte order
-    std::vector<int64_t> first;     // row offset of each segment
-    int64_t n_rows = 0;
+    std::vector<SegOut> segs;       // one entry per SEGMENT, in file order then byte order
+    int64_t *sid = nullptr, *did = nullptr, *ds = nullptr;     // the table: one block, [cap] rows per column
+    double *y = nullptr;
+    void *block = nullptr;
+    int64_t n_rows = 0, malformed = 0;
     int n_threads = 1;
+    ~tsf_csv() { std::free(block); }
 };
 
 namespace {
@@ -357,8 +400,14 @@ int tsf_csv_read(int32_t n_files, const char *const *paths, const int64_t *serie
         if (hw < 1) hw = 1;
         t->n_threads = n_threads > 0 ? n_threads : (hw < 32 ? hw : 32);
         std::atomic<int> oom(0);
-        // ---- phase 1: the files into memory (parallel)
-        std::vector<std::vector<char>> bufs((size_t)n_files);
+        // TSF_CSV_TIMING=1 (dev): wall clock of the phases on stderr
+        static const bool timing = std::getenv("TSF_CSV_TIMING") != nullptr;
+        auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double t_0 = timing ? now() : 0.0;
+        double t_read = 0, t_count = 0, t_alloc = 0, t_parse = 0;
+        // ---- phase 1: the files into memory (parallel); every thread also counts the lines of its files
+        std::vector<FileBuf> bufs_store((size_t)n_files);
+        std::vector<FileBuf> &bufs = bufs_store;
         std::vector<char> opened((size_t)n_files, 0);
         run_workers(t->n_threads, n_files, oom, [&](int64_t i) {
             bool corrupt = false;
@@ -375,54 +424,103 @@ int tsf_csv_read(int32_t n_files, const char *const *paths, const int64_t *serie
                 delete t;
                 return TSF_CSV_E_OPEN;
             }
+        if (timing) t_read = now();
         // ---- segments: small files whole, big ones cut after a line end every SEGMENT_BYTES
         std::vector<Segment> segs;
         for (int32_t i = 0; i < n_files; ++i) {
-            const std::vector<char> &b = bufs[(size_t)i];
+            const FileBuf &b = bufs[(size_t)i];
             size_t at = 0;
-            while (b.size() - at > SEGMENT_BYTES + SEGMENT_BYTES / 2) {
-                const char *nl = (const char *)std::memchr(b.data() + at + SEGMENT_BYTES, '\n',
-                                                           b.size() - at - SEGMENT_BYTES);
+            while (b.n - at > SEGMENT_BYTES + SEGMENT_BYTES / 2) {
+                const char *nl = (const char *)std::memchr(b.p + at + SEGMENT_BYTES, '\n', b.n - at - SEGMENT_BYTES);
                 if (!nl) break;
-                size_t stop = (size_t)(nl - b.data()) + 1;
+                size_t stop = (size_t)(nl - b.p) + 1;
                 segs.push_back(Segment{i, at, stop});
                 at = stop;
             }
-            segs.push_back(Segment{i, at, b.size()});
+            segs.push_back(Segment{i, at, b.n});
         }
-        t->files.resize(segs.size());
-        // ---- phase 2: parse (parallel over segments)
+        t->segs.resize(segs.size());
+        // ---- lines per segment (an upper bound of its rows), then ONE block for the four columns
         run_workers(t->n_threads, (int64_t)segs.size(), oom, [&](int64_t k) {
             const Segment &sg = segs[(size_t)k];
-            const char *base = bufs[(size_t)sg.file].data();
+            const char *base = bufs[(size_t)sg.file].p;
+            t->segs[(size_t)k].cap = count_lines(base + sg.begin, base + sg.end);
+        });
+        if (timing) t_count = now();
+        int64_t cap = 0;
+        for (SegOut &so : t->segs) { so.first = cap; cap += so.cap; }
+        {
+            // one block for the table, on transparent huge pages where the system grants them: 234 MB of 4 KB pages
+            // are 57 000 page faults while the rows are written and 50 ms of unmapping when the table is freed
+            const size_t bytes = (size_t)(cap > 0 ? cap : 1) * 32, huge = (size_t)2 << 20;
+            if (bytes >= 4 * huge && posix_memalign(&t->block, huge, (bytes + huge - 1) / huge * huge) == 0)
+                (void)::madvise(t->block, (bytes + huge - 1) / huge * huge, MADV_HUGEPAGE);
+            else
+                t->block = std::malloc(bytes);
+        }
+        if (!t->block) { delete t; return -2; }
+        t->sid = (int64_t *)t->block; t->did = t->sid + cap; t->ds = t->did + cap; t->y = (double *)(t->ds + cap);
+        for (SegOut &so : t->segs) { so.sid = t->sid + so.first; so.did = t->did + so.first; so.ds = t->ds + so.first; so.y = t->y + so.first; }
+        if (timing) t_alloc = now();
+        // ---- phase 2: parse in place (parallel over segments)
+        run_workers(t->n_threads, (int64_t)segs.size(), oom, [&](int64_t k) {
+            const Segment &sg = segs[(size_t)k];
+            const char *base = bufs[(size_t)sg.file].p;
             parse_range(base + sg.begin, base + sg.end, layout, ncol,
-                        series_id ? series_id[sg.file] : 0, permissive, t->files[(size_t)k]);
+                        series_id ? series_id[sg.file] : 0, permissive, t->segs[(size_t)k]);
         });
         if (oom.load()) {
             delete t;
             return -2;
         }
-        t->first.resize(segs.size() + 1);
+        if (timing) {
+            t_parse = now();
+            std::fprintf(stderr, "[csv-timing] %d files, %d threads: read %.1f ms, segments + line count %.1f, block %.1f, parse %.1f\n",
+                         (int)n_files, t->n_threads, t_read - t_0, t_count - t_read, t_alloc - t_count, t_parse - t_alloc);
+        }
         int64_t pos = 0;
+        bool holes = false;
         for (size_t k = 0; k < segs.size(); ++k) {
-            const FileCols &fc = t->files[k];
-            if (fc.err) {
+            const SegOut &so = t->segs[k];
+            if (so.err) {
                 // line number inside the file = lines of the earlier segments + line in this one
                 const Segment &sg = segs[k];
-                const char *base = bufs[(size_t)sg.file].data();
+                const char *base = bufs[(size_t)sg.file].p;
                 int64_t before = 0;
                 for (const char *q = base; q < base + sg.begin; ++q) before += (*q == '\n');
                 if (err_file) *err_file = sg.file;
-                if (err_line) *err_line = before + fc.err_line;
-                int e = fc.err;
+                if (err_line) *err_line = before + so.err_line;
+                int e = so.err;
                 delete t;
                 return e;
             }
-            t->first[k] = pos;
-            pos += (int64_t)fc.ds.size();
+            holes = holes || so.first != pos;
+            pos += so.n;
+            t->malformed += so.malformed;
         }
-        t->first[segs.size()] = pos;
         t->n_rows = pos;
+        {
+            // the file buffers go back in parallel too: 10 000 frees are 20 ms on one thread, 4 ms on the pool
+            const double t_a = timing ? now() : 0.0;
+            run_workers(t->n_threads, n_files, oom, [&](int64_t i) { bufs[(size_t)i].release(); });
+            if (timing) std::fprintf(stderr, "[csv-timing] releasing the file buffers %.1f ms\n", now() - t_a);
+        }
+        if (holes) {
+            // blank or dropped lines left gaps between the segments' rows: close them (in order, so that a
+            // segment only ever moves down onto rows already moved), then the four columns themselves --
+            // did / ds / y start at multiples of cap, the caller's view is [n_rows] each
+            pos = 0;
+            for (SegOut &so : t->segs) {
+                if (so.first != pos && so.n > 0) {
+                    std::memmove(t->sid + pos, t->sid + so.first, (size_t)so.n * 8);
+                    std::memmove(t->did + pos, t->did + so.first, (size_t)so.n * 8);
+                    std::memmove(t->ds + pos, t->ds + so.first, (size_t)so.n * 8);
+                    std::memmove(t->y + pos, t->y + so.first, (size_t)so.n * 8);
+                }
+                so.first = pos;
+                pos += so.n;
+            }
+        }
     } catch (const std::bad_alloc &) {
         delete t;
         return -2;
@@ -435,43 +533,183 @@ int tsf_csv_read(int32_t n_files, const char *const *paths, const int64_t *serie
     return 0;
 }
 
-int64_t tsf_csv_malformed(const tsf_csv *t) {
+int64_t tsf_csv_malformed(const tsf_csv *t) { return t ? t->malformed : -1; }
+
+int tsf_csv_columns(tsf_csv *t, const int64_t **series_id, const int64_t **dim_id, const int64_t **ds, const double **y) {
     if (!t) return -1;
-    int64_t n = 0;
-    for (const FileCols &fc : t->files) n += fc.malformed;
-    return n;
+    if (series_id) *series_id = t->sid;
+    if (dim_id) *dim_id = t->did;
+    if (ds) *ds = t->ds;
+    if (y) *y = t->y;
+    return 0;
 }
 
 int tsf_csv_fetch(tsf_csv *t, int64_t *series_id, int64_t *dim_id, int64_t *ds, double *y) {
     if (!t) return -1;
-    const int32_t nf = (int32_t)t->files.size();
-    std::atomic<int32_t> next(0);
-    auto worker = [&]() {
-        for (;;) {
-            int32_t i = next.fetch_add(1);
-            if (i >= nf) break;
-            const FileCols &fc = t->files[(size_t)i];
-            size_t n = fc.ds.size();
-            int64_t at = t->first[(size_t)i];
-            if (!n) continue;
-            if (series_id) std::memcpy(series_id + at, fc.sid.data(), n * sizeof(int64_t));
-            if (dim_id) std::memcpy(dim_id + at, fc.did.data(), n * sizeof(int64_t));
-            if (ds) std::memcpy(ds + at, fc.ds.data(), n * sizeof(int64_t));
-            if (y) std::memcpy(y + at, fc.y.data(), n * sizeof(double));
-        }
-    };
-    if (t->n_threads <= 1 || nf < 2) {
-        worker();
-    } else {
-        std::vector<std::thread> th;
-        int k = t->n_threads < nf ? t->n_threads : nf;
-        for (int i = 0; i < k; ++i) th.emplace_back(worker);
-        for (auto &x : th) x.join();
-    }
+    // (chunks of 1 M rows per column copied by the pool)
+    const int64_t CH = (int64_t)1 << 20;
+    const int64_t nch = (t->n_rows + CH - 1) / CH;
+    std::atomic<int> oom(0);
+    run_workers(t->n_threads, nch * 4, oom, [&](int64_t j) {
+        const int64_t c = j / nch, at = (j % nch) * CH;
+        const size_t n = (size_t)((t->n_rows - at < CH) ? t->n_rows - at : CH) * 8;
+        if (c == 0 && series_id) std::memcpy(series_id + at, t->sid + at, n);
+        if (c == 1 && dim_id) std::memcpy(dim_id + at, t->did + at, n);
+        if (c == 2 && ds) std::memcpy(ds + at, t->ds + at, n);
+        if (c == 3 && y) std::memcpy(y + at, t->y + at, n);
+    });
     return 0;
 }
 
 void tsf_csv_free(tsf_csv *t) { delete t; }
+// ---- input discovery ---------------------------------------------------------------------------
+// What spark.read.csv(path) reads under a directory (prophet_modeler.py:109-114) and how it finds the partition
+// column: every regular file below `root` whose name -- and the name of every directory on the way -- does not
+// start with '_' or '.', a `series_id=<int>` directory supplying series_id for everything below it.  The Python
+// walk (jobs/prophet_modeler.find_model_input: os.scandir, one directory at a time) took 0.07 s of the 0.16 s
+// read stage on 10 000 partition directories; here the directories are read by the pool and Python never sees a
+// path unless something is wrong with one.
+struct tsf_csv_dir {
+    struct Item { std::string path; int64_t sid; bool has; };
+    std::vector<Item> items;
+    std::vector<const char *> paths;
+    std::vector<int64_t> sids;
+    int32_t n_part = 0;
+    int err = 0;
+    std::string err_path;
+};
+
+namespace {
+
+bool hidden_name(const char *n) { return n[0] == '_' || n[0] == '.'; }
+
+bool has_suffix(const std::string &s, const char *suf) {
+    const size_t n = std::strlen(suf);
+    return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+}
+
+// one directory: files appended to `out`, sub-directories to `dirs`
+void scan_dir(const std::string &d, int64_t sid, bool has, std::vector<tsf_csv_dir::Item> &out,
+              std::vector<tsf_csv_dir::Item> &dirs, int &err, std::string &err_path) {
+    DIR *h = ::opendir(d.c_str());
+    if (!h) { err = TSF_CSV_E_OPEN; err_path = d; return; }
+    while (struct dirent *e = ::readdir(h)) {
+        const char *nm = e->d_name;
+        if (hidden_name(nm)) continue;          // (covers "." and "..")
+        std::string p = d + "/" + nm;
+        unsigned char ty = e->d_type;
+        if (ty == DT_UNKNOWN || ty == DT_LNK) {
+            struct stat sb;
+            if (::stat(p.c_str(), &sb) != 0) continue;          // dangling link: Spark lists nothing for it
+            ty = S_ISDIR(sb.st_mode) ? DT_DIR : (S_ISREG(sb.st_mode) ? DT_REG : DT_UNKNOWN);
+        }
+        if (ty == DT_DIR) {
+            int64_t v = sid;
+            bool hv = has;
+            if (std::strncmp(nm, "series_id=", 10) == 0) {
+                char *end = nullptr;
+                errno = 0;
+                const long long q = std::strtoll(nm + 10, &end, 10);
+                if (end == nm + 10 || *end != '\0' || errno != 0) { err = TSF_CSV_E_PARSE; err_path = p; continue; }
+                v = q; hv = true;
+            }
+            dirs.push_back(tsf_csv_dir::Item{std::move(p), v, hv});
+        } else if (ty == DT_REG) {
+            for (const char *suf : {".bz2", ".snappy", ".lz4", ".zst", ".xz"})
+                if (has_suffix(p, suf)) { err = TSF_CSV_E_CODEC; err_path = p; }
+            out.push_back(tsf_csv_dir::Item{std::move(p), sid, has});
+        }
+    }
+    ::closedir(h);
+}
+
+}  // namespace
+
+int tsf_csv_discover(const char *root, int32_t n_threads, tsf_csv_dir **out, int32_t *n_files, int32_t *n_partitioned) {
+    if (!root || !out) return -1;
+    *out = nullptr;
+    tsf_csv_dir *d = nullptr;
+    static const bool timing = std::getenv("TSF_CSV_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_0 = timing ? now() : 0.0;
+    double t_walk = 0;
+    try {
+        d = new tsf_csv_dir();
+        struct stat sb;
+        if (::stat(root, &sb) == 0 && S_ISREG(sb.st_mode)) {
+            d->items.push_back(tsf_csv_dir::Item{root, 0, false});
+        } else if (::stat(root, &sb) == 0 && S_ISDIR(sb.st_mode)) {
+            int hw = (int)std::thread::hardware_concurrency();
+            if (hw < 1) hw = 1;
+            const int nt = n_threads > 0 ? n_threads : (hw < 32 ? hw : 32);
+            std::string r(root);
+            while (r.size() > 1 && r.back() == '/') r.pop_back();
+            // breadth first: the directories of one level are read by the pool, each thread into its own lists
+            std::vector<tsf_csv_dir::Item> level{tsf_csv_dir::Item{r, 0, false}};
+            while (!level.empty()) {
+                const int64_t n = (int64_t)level.size();
+                const int k = (int)std::min<int64_t>(nt, n);
+                std::vector<std::vector<tsf_csv_dir::Item>> files((size_t)k), dirs((size_t)k);
+                std::vector<int> errs((size_t)k, 0);
+                std::vector<std::string> eps((size_t)k);
+                std::atomic<int64_t> next(0);
+                auto work = [&](int w) {
+                    for (;;) {
+                        const int64_t i = next.fetch_add(1);
+                        if (i >= n) break;
+                        scan_dir(level[(size_t)i].path, level[(size_t)i].sid, level[(size_t)i].has, files[(size_t)w], dirs[(size_t)w],
+                                 errs[(size_t)w], eps[(size_t)w]);
+                    }
+                };
+                if (k <= 1) work(0);
+                else {
+                    std::vector<std::thread> th;
+                    for (int w = 0; w < k; ++w) th.emplace_back(work, w);
+                    for (auto &x : th) x.join();
+                }
+                level.clear();
+                for (int w = 0; w < k; ++w) {
+                    if (errs[(size_t)w] && !d->err) { d->err = errs[(size_t)w]; d->err_path = eps[(size_t)w]; }
+                    for (auto &it : files[(size_t)w]) d->items.push_back(std::move(it));
+                    for (auto &it : dirs[(size_t)w]) level.push_back(std::move(it));
+                }
+            }
+        }
+        if (timing) t_walk = now();
+        // (partitioned files first, by partition value, then by path: what the packer wants to see -- a table
+        // that already is grouped)
+        std::sort(d->items.begin(), d->items.end(), [](const tsf_csv_dir::Item &a, const tsf_csv_dir::Item &b) {
+            if (a.has != b.has) return a.has;
+            if (a.has && a.sid != b.sid) return a.sid < b.sid;
+            return a.path < b.path;
+        });
+        d->paths.reserve(d->items.size());
+        d->sids.reserve(d->items.size());
+        for (const auto &it : d->items) {
+            d->paths.push_back(it.path.c_str());
+            d->sids.push_back(it.sid);
+            d->n_part += it.has ? 1 : 0;
+        }
+    } catch (const std::bad_alloc &) {
+        delete d;
+        return -2;
+    } catch (...) {
+        delete d;
+        return -3;
+    }
+    if (timing) std::fprintf(stderr, "[csv-timing] discover: walk %.1f ms, sort + lists %.1f ms, %d files\n", t_walk - t_0, now() - t_walk, (int)d->items.size());
+    *out = d;
+    if (n_files) *n_files = (int32_t)d->items.size();
+    if (n_partitioned) *n_partitioned = d->n_part;
+    return d->err;
+}
+
+const char *const *tsf_csv_dir_paths(const tsf_csv_dir *d) { return d ? d->paths.data() : nullptr; }
+const int64_t *tsf_csv_dir_series_id(const tsf_csv_dir *d) { return d ? d->sids.data() : nullptr; }
+const char *tsf_csv_dir_error_path(const tsf_csv_dir *d) { return d ? d->err_path.c_str() : ""; }
+void tsf_csv_dir_free(tsf_csv_dir *d) { delete d; }
+
+
 
 // ---- forecast sink ----------------------------------------------------------------------------
 // ProphetScorer.convert_forecasts + write_forecasts (/root/reference/src/jobs/prophet_scorer.py:
@@ -535,77 +773,88 @@ int tsf_csv_write_forecasts(const char *path, const char *created_timestamp, int
         return -1;
     const size_t clen = std::strlen(created_timestamp);
     if (clen > 64) return -1;
-    FILE *f = std::fopen(path, "wb");
-    if (!f) return TSF_CSV_E_OPEN;
+    const int fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0644);
+    if (fd < 0) return TSF_CSV_E_OPEN;
     static const char header[] =
         "created_timestamp,series_id,dim_id,forecast_date,forecast_timestamp,forecast_quantity\n";
-    bool ok = std::fwrite(header, 1, sizeof(header) - 1, f) == sizeof(header) - 1;
+    const size_t hlen = sizeof(header) - 1;
     int hw = (int)std::thread::hardware_concurrency();
     if (hw < 1) hw = 1;
-    int nt = n_threads > 0 ? n_threads : (hw < 16 ? hw : 16);
+    const int nt = n_threads > 0 ? n_threads : (hw < 32 ? hw : 32);
     const size_t row_max = clen + 1 + 21 + 21 + 11 + 25 + 21 + 1;
-    const int64_t block = 1 << 16;                 // rows formatted per thread per turn
+    // Blocks of 16 384 rows are formatted by the pool into buffers of their own (uninitialised: round 3 zero-filled
+    // 16 buffers of 8.5 MB before the first row), their lengths prefix-summed, and every block then written at its
+    // offset by the thread that holds it (pwrite): 900 000 rows in 55 blocks instead of one turn of 14 threads and
+    // a serial fwrite of 60 MB.
+    const int64_t block = 1 << 14;
+    const int64_t nb = (n + block - 1) / block;
+    bool ok = true;
     try {
-        std::vector<std::vector<char>> bufs((size_t)nt);
-        std::vector<size_t> used((size_t)nt);
-        for (auto &b : bufs) b.resize((size_t)block * row_max);
-        for (int64_t base = 0; base < n && ok; base += block * nt) {
-            auto work = [&](int t) {
-                int64_t a = base + (int64_t)t * block, b = a + block < n ? a + block : n;
-                char *p = bufs[(size_t)t].data();
-                for (int64_t r = a; r < b; ++r) {
-                    std::memcpy(p, created_timestamp, clen);
-                    p += clen;
-                    *p++ = ',';
-                    p = put_int(p, series_id[r]);
-                    *p++ = ',';
-                    p = put_int(p, dim_id[r]);
-                    *p++ = ',';
-                    const int64_t v = ds[r];
-                    int64_t days = v / 86400000000000ll, rem = v % 86400000000000ll;
-                    if (rem < 0) {
-                        rem += 86400000000000ll;
-                        --days;
-                    }
-                    p = put_date(p, days);
-                    *p++ = ',';
-                    p = put_date(p, days);
-                    *p++ = 'T';
-                    const int64_t secs = rem / 1000000000ll;
-                    const unsigned ms = (unsigned)((rem % 1000000000ll) / 1000000ll);
-                    p = put2(p, (unsigned)(secs / 3600));
-                    *p++ = ':';
-                    p = put2(p, (unsigned)(secs / 60 % 60));
-                    *p++ = ':';
-                    p = put2(p, (unsigned)(secs % 60));
-                    *p++ = '.';
-                    *p++ = (char)('0' + ms / 100);
-                    p = put2(p, ms % 100);
-                    *p++ = 'Z';
-                    *p++ = ',';
-                    p = put_int(p, quantity[r]);
-                    *p++ = '\n';
+        std::vector<FileBuf> bufs((size_t)nb);
+        std::vector<size_t> used((size_t)nb, 0);
+        std::atomic<int> oom(0);
+        run_workers(nt, nb, oom, [&](int64_t k) {
+            const int64_t a = k * block, b = a + block < n ? a + block : n;
+            if (!bufs[(size_t)k].alloc((size_t)(b - a) * row_max)) throw std::bad_alloc();
+            char *p = bufs[(size_t)k].p;
+            for (int64_t r = a; r < b; ++r) {
+                std::memcpy(p, created_timestamp, clen);
+                p += clen;
+                *p++ = ',';
+                p = put_int(p, series_id[r]);
+                *p++ = ',';
+                p = put_int(p, dim_id[r]);
+                *p++ = ',';
+                const int64_t v = ds[r];
+                int64_t days = v / 86400000000000ll, rem = v % 86400000000000ll;
+                if (rem < 0) {
+                    rem += 86400000000000ll;
+                    --days;
                 }
-                used[(size_t)t] = a < b ? (size_t)(p - bufs[(size_t)t].data()) : 0;
-            };
-            int live = 0;
-            for (int t = 0; t < nt; ++t)
-                if (base + (int64_t)t * block < n) live = t + 1;
-            if (live <= 1) {
-                work(0);
-            } else {
-                std::vector<std::thread> th;
-                for (int t = 0; t < live; ++t) th.emplace_back(work, t);
-                for (auto &x : th) x.join();
+                p = put_date(p, days);
+                *p++ = ',';
+                p = put_date(p, days);
+                *p++ = 'T';
+                const int64_t secs = rem / 1000000000ll;
+                const unsigned ms = (unsigned)((rem % 1000000000ll) / 1000000ll);
+                p = put2(p, (unsigned)(secs / 3600));
+                *p++ = ':';
+                p = put2(p, (unsigned)(secs / 60 % 60));
+                *p++ = ':';
+                p = put2(p, (unsigned)(secs % 60));
+                *p++ = '.';
+                *p++ = (char)('0' + ms / 100);
+                p = put2(p, ms % 100);
+                *p++ = 'Z';
+                *p++ = ',';
+                p = put_int(p, quantity[r]);
+                *p++ = '\n';
             }
-            for (int t = 0; t < live && ok; ++t)
-                ok = std::fwrite(bufs[(size_t)t].data(), 1, used[(size_t)t], f) == used[(size_t)t];
-        }
+            used[(size_t)k] = (size_t)(p - bufs[(size_t)k].p);
+        });
+        if (oom.load()) { ::close(fd); return -2; }
+        std::vector<size_t> at((size_t)nb + 1, hlen);
+        for (int64_t k = 0; k < nb; ++k) at[(size_t)k + 1] = at[(size_t)k] + used[(size_t)k];
+        auto put = [&](const char *q, size_t len, size_t off) {
+            while (len > 0) {
+                const ssize_t w = ::pwrite(fd, q, len, (off_t)off);
+                if (w <= 0) return false;
+                q += w; len -= (size_t)w; off += (size_t)w;
+            }
+            return true;
+        };
+        std::atomic<int> bad(0);
+        if (!put(header, hlen, 0)) bad.store(1);
+        run_workers(nt, nb, oom, [&](int64_t k) {
+            if (!put(bufs[(size_t)k].p, used[(size_t)k], at[(size_t)k])) bad.store(1);
+            bufs[(size_t)k].release();
+        });
+        ok = bad.load() == 0 && oom.load() == 0;
     } catch (...) {
-        std::fclose(f);
+        ::close(fd);
         return -2;
     }
-    if (std::fclose(f) != 0) ok = false;
+    if (::close(fd) != 0) ok = false;
     return ok ? 0 : TSF_CSV_E_OPEN;
 }
 

@@ -368,17 +368,75 @@ def find_model_input(root):
     return [f for _, f in found], [v for v, _ in found]
 
 
+class _CsvTable:
+    """Owns one native table (tsf_csv handle); the numpy columns handed out view its memory and keep it alive
+    through their .base chain -- no copy of the 32 bytes per row into arrays of Python's own."""
+
+    def __init__(self, handle, n_rows):
+        self.handle, self.n_rows = handle, int(n_rows)
+
+    def __del__(self):
+        if self.handle:
+            _lib.load().tsf_csv_free(self.handle)
+            self.handle = None
+
+    def columns(self):
+        import ctypes
+        L = _lib.load()
+        ptrs = [ctypes.c_void_p() for _ in range(4)]
+        if L.tsf_csv_columns(self.handle, *[ctypes.byref(p) for p in ptrs]) != 0:
+            raise _lib.TsfError('tsf_csv_columns failed')
+        out = []
+        for p, dt in zip(ptrs, (np.int64, np.int64, np.int64, np.float64)):
+            if self.n_rows == 0:
+                out.append(np.zeros(0, dt))
+                continue
+            buf = (ctypes.c_char * (8 * self.n_rows)).from_address(p.value)
+            buf._owner = self                   # the ctypes view keeps the table; the array keeps the view
+            out.append(np.frombuffer(buf, dtype=dt))
+        return tuple(out)
+
+
+def _csv_read_call(n, paths_ptr, sids_ptr, layout, n_threads, name_of, stats):
+    """One tsf_csv_read; returns the four columns as views of the native table.  name_of(i): path of file i."""
+    import ctypes
+    L = _lib.load()
+    h, n_rows = ctypes.c_void_p(), ctypes.c_int64()
+    ef, el = ctypes.c_int32(-1), ctypes.c_int64(0)
+    rc = L.tsf_csv_read(n, paths_ptr, sids_ptr, layout, int(n_threads), ctypes.byref(h),
+                        ctypes.byref(n_rows), ctypes.byref(ef), ctypes.byref(el))
+    if rc == _lib.CSV_E_OPEN:
+        raise OSError(('corrupt or truncated compressed stream in %s' if el.value == -1 else 'cannot read %s')
+                      % name_of(ef.value))
+    if rc == _lib.CSV_E_PARSE:
+        raise ValueError('%s line %d does not match the model-input schema %s'
+                         % (name_of(ef.value), el.value, layout.decode()))
+    if rc != 0:
+        raise _lib.TsfError('tsf_csv_read failed (%d)' % rc)
+    tab = _CsvTable(h, n_rows.value)
+    if stats is not None:
+        stats['malformed'] = stats.get('malformed', 0) + int(L.tsf_csv_malformed(h))
+    return tab.columns()
+
+
+def _layouts(mode):
+    if mode not in ('FAILFAST', 'PERMISSIVE'):
+        raise ValueError("mode must be 'FAILFAST' or 'PERMISSIVE'")
+    q = b'?' if mode == 'PERMISSIVE' else b''
+    return b'dtq' + q, b'sdtq' + q          # files under a partition directory hold 3 columns, the others all 4
+
+
 def read_model_input(files, root, n_threads=0, part_sid=None, mode='FAILFAST', stats=None):
     """Parse model-input CSV files into (series_id, dim_id, ds_ns, y) arrays (int64, int64,
     int64 ns, float64 with NaN for nulls).  mode: 'FAILFAST' (a line that does not match the schema
     raises, naming file and line) or 'PERMISSIVE' (spark.read.csv's default at prophet_modeler.py:109:
     such a line becomes a row of nulls there -- dim_id included --, whose null y the fit would drop; the
-    reader drops the record itself, it never appears under a made-up key; stats['malformed'] counts them).  A `series_id=<v>` directory between `root` and the
+    reader drops the record itself, it never appears under a made-up key; stats['malformed'] counts them).
+    A `series_id=<v>` directory between `root` and the
     file supplies series_id for that file (Spark's partition discovery); the file then holds
     the remaining MODEL_INPUT_SCHEMA columns in order.  part_sid: the partition values if the
-    caller knows them already (find_model_input)."""
+    caller knows them already (find_model_input).  The arrays are read-only views of the native table."""
     import ctypes
-    L = _lib.load()
     if not files:
         z = np.zeros(0, np.int64)
         return z, z.copy(), z.copy(), np.zeros(0)
@@ -393,39 +451,54 @@ def read_model_input(files, root, n_threads=0, part_sid=None, mode='FAILFAST', s
                 v = int(seg.split('=', 1)[1])
         part_sid.append(v)
     out = []
-    if mode not in ('FAILFAST', 'PERMISSIVE'):
-        raise ValueError("mode must be 'FAILFAST' or 'PERMISSIVE'")
-    q = b'?' if mode == 'PERMISSIVE' else b''
-    # files under a partition directory hold 3 columns, the others all 4
-    for layout, pick in ((b'dtq' + q, [i for i, v in enumerate(part_sid) if v is not None]),
-                         (b'sdtq' + q, [i for i, v in enumerate(part_sid) if v is None])):
+    lay_part, lay_all = _layouts(mode)
+    for layout, pick in ((lay_part, [i for i, v in enumerate(part_sid) if v is not None]),
+                         (lay_all, [i for i, v in enumerate(part_sid) if v is None])):
         if not pick:
             continue
         paths = (ctypes.c_char_p * len(pick))(*[os.fsencode(files[i]) for i in pick])
         sids = np.array([part_sid[i] if part_sid[i] is not None else 0 for i in pick], dtype=np.int64)
-        h, n_rows = ctypes.c_void_p(), ctypes.c_int64()
-        ef, el = ctypes.c_int32(-1), ctypes.c_int64(0)
-        rc = L.tsf_csv_read(len(pick), paths, sids.ctypes.data, layout, int(n_threads), ctypes.byref(h),
-                            ctypes.byref(n_rows), ctypes.byref(ef), ctypes.byref(el))
-        if rc == _lib.CSV_E_OPEN:
-            raise OSError(('corrupt or truncated compressed stream in %s' if el.value == -1 else 'cannot read %s')
-                          % files[pick[ef.value]])
-        if rc == _lib.CSV_E_PARSE:
-            raise ValueError('%s line %d does not match the model-input schema %s'
-                             % (files[pick[ef.value]], el.value, layout.decode()))
+        out.append(_csv_read_call(len(pick), paths, sids.ctypes.data, layout, n_threads,
+                                  lambda i, pick=pick: files[pick[i]], stats))
+    if len(out) == 1:
+        return out[0]
+    return tuple(np.concatenate([o[k] for o in out]) for k in range(4))
+
+
+def read_model_input_dir(root, n_threads=0, mode='FAILFAST', stats=None):
+    """find_model_input + read_model_input in one go, natively: the directory walk (tsf_csv_discover: Spark's
+    file-listing and partition-discovery rules, the directories read by a pool of threads) hands its path list
+    straight to the reader, so no path becomes a Python object unless an error names it.  Same rows, same order,
+    same errors as read_model_input(*find_model_input(root))."""
+    import ctypes
+    L = _lib.load()
+    lay_part, lay_all = _layouts(mode)
+    d, n, n_part = ctypes.c_void_p(), ctypes.c_int32(), ctypes.c_int32()
+    rc = L.tsf_csv_discover(os.fsencode(root), int(n_threads), ctypes.byref(d), ctypes.byref(n), ctypes.byref(n_part))
+    try:
+        if rc in (_lib.CSV_E_OPEN, _lib.CSV_E_PARSE, _lib.CSV_E_CODEC):
+            bad = os.fsdecode(L.tsf_csv_dir_error_path(d))
+            if rc == _lib.CSV_E_CODEC:
+                raise ValueError('compressed input file %s: decompress it first (Spark reads it, '
+                                 'this reader does not)' % bad)
+            if rc == _lib.CSV_E_PARSE:
+                raise ValueError('partition directory %s: series_id is not an integer' % bad)
+            raise OSError('cannot list %s' % bad)
         if rc != 0:
-            raise _lib.TsfError('tsf_csv_read failed (%d)' % rc)
-        try:
-            if stats is not None:
-                stats['malformed'] = stats.get('malformed', 0) + int(L.tsf_csv_malformed(h))
-            n = n_rows.value
-            cols = (np.empty(n, np.int64), np.empty(n, np.int64), np.empty(n, np.int64), np.empty(n))
-            rc = L.tsf_csv_fetch(h, *[c.ctypes.data for c in cols])
-            if rc != 0:
-                raise _lib.TsfError('tsf_csv_fetch failed (%d)' % rc)
-        finally:
-            L.tsf_csv_free(h)
-        out.append(cols)
+            raise _lib.TsfError('tsf_csv_discover failed (%d)' % rc)
+        if n.value == 0:
+            z = np.zeros(0, np.int64)
+            return z, z.copy(), z.copy(), np.zeros(0)
+        paths, sids = L.tsf_csv_dir_paths(d), L.tsf_csv_dir_series_id(d)
+        pp = ctypes.cast(paths, ctypes.POINTER(ctypes.c_char_p))
+        out = []
+        for layout, lo, hi in ((lay_part, 0, n_part.value), (lay_all, n_part.value, n.value)):
+            if hi > lo:
+                out.append(_csv_read_call(hi - lo, paths + 8 * lo, sids + 8 * lo, layout, n_threads,
+                                          lambda i, lo=lo: os.fsdecode(pp[lo + i]), stats))
+    finally:
+        if d:
+            L.tsf_csv_dir_free(d)
     if len(out) == 1:
         return out[0]
     return tuple(np.concatenate([o[k] for o in out]) for k in range(4))
@@ -460,13 +533,12 @@ class ProphetModeler:
     def read_input_columns(self):
         """The same rows as read_input_dataframe, as (series_id, dim_id, ds_ns, y) arrays."""
         root = self.config['io']['input']
-        files, part = find_model_input(root)
         # io.input_mode: 'FAILFAST' (default here: a malformed line raises with file and line) or
         # 'PERMISSIVE' (what spark.read.csv does by default, prophet_modeler.py:109: the line becomes a
         # row of nulls there; here the reader drops the record and counts it)
         mode = str(self.config['io'].get('input_mode', 'FAILFAST')).upper()
         stats = {}
-        cols = read_model_input(files, root, part_sid=part, mode=mode, stats=stats)
+        cols = read_model_input_dir(root, mode=mode, stats=stats)
         if stats.get('malformed'):
             self.logger.warning('%d malformed model-input records dropped (PERMISSIVE)', stats['malformed'])
         return cols
