@@ -31,6 +31,9 @@ namespace tsf {
 // branches of the line search become scalar branches (no exec masking, no per-lane copies of the
 // optimiser state at every join) and the state lives in SGPRs instead of one VGPR pair per scalar.
 #define UQ(x) uniform_f64(x)
+#ifndef TSF_QUAD_EXPSC
+#define TSF_QUAD_EXPSC 0        // exp's literals as scalar operands of VOP3 instructions (dm_exp_sel_sc): see there
+#endif
 
 constexpr int QH = 5;                   // L-BFGS history of the register-resident path
 // waves per SIMD the kernels are compiled for (register budget 512 / this per lane): 3 for the
@@ -280,6 +283,64 @@ __device__ __forceinline__ void quad_const_table(double *ct, const LbfgsOpts &op
     if (l < QC_N) ct[l] = v;
 }
 
+// fp64 arithmetic with a LITERAL operand held in a scalar register pair.  A VOP3 instruction of gfx950 cannot encode
+// a 64-bit literal, and left to itself the compiler materialises each one in a VGPR pair (two v_mov_b32) to use the
+// two-address v_fmac form: 26 vector instructions per evaluation for exp's 13 coefficients, in a kernel whose large
+// launches are bound by vector issue (SQ_ACTIVE_INST_VALU 91 % at 16 waves per CU: profiles/r04_pmc_wide).  Written
+// as the VOP3 instruction itself, the constant is two s_mov_b32 on the scalar unit, which has the room (26 % busy).
+// Same instruction, same rounding: only the operand's register file differs.
+// MEASURED (round 4, static: tools/dev/isa_mix.sh) and NOT enabled: the asm statements pin the schedule of the
+// evaluation, the 12- and 16-wave kernels then spill ~49 registers per lane to scratch and issue MORE vector
+// instructions per evaluation (371 against 339 in the trial loop), not fewer.  Kept behind TSF_QUAD_EXPSC.
+__device__ __forceinline__ double fma_vvs(double a, double b, double c_scalar)
+{
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c_scalar));
+    return r;
+}
+__device__ __forceinline__ double fma_vsv(double a, double b_scalar, double c)
+{
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b_scalar), "v"(c));
+    return r;
+}
+__device__ __forceinline__ double mul_vs(double a, double b_scalar)
+{
+    double r;
+    asm("v_mul_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(b_scalar));
+    return r;
+}
+
+// dm_exp_sel (tsf_detmath.h) with its literals as scalar operands: the same operations on the same values
+__device__ __forceinline__ double dm_exp_sel_sc(double x)
+{
+    const double n = __builtin_rint(mul_vs(x, 1.4426950408889634));
+    double r = fma_vsv(-n, 6.93147180369123816490e-01, x);
+    r = fma_vsv(-n, 1.90821492927058770002e-10, r);
+    double p = 1.6059043836821613e-10;
+    p = fma_vvs(p, r, 2.08767569878681e-09);
+    p = fma_vvs(p, r, 2.505210838544172e-08);
+    p = fma_vvs(p, r, 2.755731922398589e-07);
+    p = fma_vvs(p, r, 2.7557319223985893e-06);
+    p = fma_vvs(p, r, 2.48015873015873e-05);
+    p = fma_vvs(p, r, 1.984126984126984e-04);
+    p = fma_vvs(p, r, 1.388888888888889e-03);
+    p = fma_vvs(p, r, 8.333333333333333e-03);
+    p = fma_vvs(p, r, 4.1666666666666664e-02);
+    p = fma_vvs(p, r, 1.6666666666666666e-01);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    const bool in_range = (x <= 709.782712893384) && (x >= -745.2);
+    const int ni = in_range ? (int)n : 0;
+    const int n1 = ni / 2, n2 = ni - n1;
+    double e = (p * dm_pow2i(n1)) * dm_pow2i(n2);
+    if (x > 709.782712893384) e = __builtin_huge_val();
+    if (x < -745.2) e = 0.0;
+    if (x != x) e = x;
+    return e;
+}
+
 // dm_exp_sel (tsf_detmath.h) with its constants read from the table: the same operations on the same values
 __device__ __forceinline__ double dm_exp_sel_tab(double x, const double *ct)
 {
@@ -344,7 +405,7 @@ __device__ __forceinline__ void assemble_pre(const SeriesView &sv, const LaneCon
     const int lane = lane_id();
     const double k = readlane_f64(th[0], 0), m = readlane_f64(th[0], 1), ls = readlane_f64(th[0], 2);
     const double C25 = 1.0 / 25.0;
-    const double sigma = CTAB ? dm_exp_sel_tab(ls, lk.ct) : dm_exp_sel(ls);
+    const double sigma = CTAB ? dm_exp_sel_tab(ls, lk.ct) : (TSF_QUAD_EXPSC ? dm_exp_sel_sc(ls) : dm_exp_sel(ls));
     const double s2 = sigma * sigma;
     ap.inv_s2 = 1.0 / s2;
     ap.s2 = s2;
