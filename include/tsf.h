@@ -63,7 +63,12 @@ enum { TSF_Y_F64 = 0, TSF_Y_F32 = 1, TSF_Y_I32 = 2 };
 enum { TSF_EVAL_AUTO = 0, TSF_EVAL_RESIDUAL = 1, TSF_EVAL_QUADRATIC = 2 };
 /* Which of Stan's optimisers runs the MAP fit.  fbprophet 0.5 chooses
  * `'Newton' if T < 100 else 'LBFGS'` (TSF_ALGO_AUTO: decided per CALL from the longest series of
- * the call -- callers split panels at 100 rows).  Default TSF_ALGO_LBFGS. */
+ * the call -- callers split panels at 100 rows).  Default TSF_ALGO_LBFGS.
+ * Newton kernels: one parameter per lane for models of up to 64 parameters (3 + n_changepoints + K) of one
+ * column mode -- quadratic-form evaluations, several series per wave, for linear / additive models of up to 28
+ * design columns --; two parameters per lane (round 4, one wave and ~140 KB of LDS per series: slow, meant for the
+ * handful of series fbprophet retries after a failed L-BFGS fit) up to TSF_MAX_P = 128 and for mixed additive /
+ * multiplicative columns.  Every model the library fits has one. */
 enum { TSF_ALGO_LBFGS = 0, TSF_ALGO_NEWTON = 1, TSF_ALGO_AUTO = 2 };
 enum { TSF_RK_AUTO = 0, TSF_RK_WAVE = 1, TSF_RK_MFMA = 2, TSF_RK_COOP = 3 };
 #define TSF_NEWTON_BELOW_T 100

@@ -939,7 +939,13 @@ done:
  *   proj[j]   = fma chain over i of V[i][j] * g[i];  proj[j] = -proj[j] / |lambda_j|;
  *   step[i]   = fma chain over j of V[i][j] * proj[j];  new[i] = th[i] - size * step[i]. */
 
-#define CN_NEWTON_MAX_P 64
+/* Newton up to 128 parameters (round 4: the two-parameters-per-lane kernel newton_kernel2, so that fbprophet's
+ * retry-with-Newton and its T < 100 rule exist for models of more than 64 parameters and for mixed additive /
+ * multiplicative columns too).  Sums over more than 64 entries follow the rule of dotc: entry j in slot j % 64, the
+ * j >= 64 term fma'd onto the j - 64 term, then the 64-slot butterfly.  The round-robin Jacobi cross-check keeps
+ * its 64 (CN_JACOBI_MAX_P). */
+#define CN_NEWTON_MAX_P 128
+#define CN_JACOBI_MAX_P 64
 enum { TERM_NEWTON_CONVERGED = 60, CN_NEWTON_FAIL = -4, CN_NEWTON_TOO_WIDE = -13 };
 
 /* Symmetric eigen-decomposition, parallel-order Jacobi.  Every round applies n/2 rotations on
@@ -950,9 +956,10 @@ enum { TERM_NEWTON_CONVERGED = 60, CN_NEWTON_FAIL = -4, CN_NEWTON_TOO_WIDE = -13
 static int cn_jacobi(int n, double *A, double *V, double *lam)
 {
     const int m = n + (n & 1);
-    double B[CN_NEWTON_MAX_P * CN_NEWTON_MAX_P], W[CN_NEWTON_MAX_P * CN_NEWTON_MAX_P];
-    double c[CN_NEWTON_MAX_P], kap[CN_NEWTON_MAX_P];
-    int par[CN_NEWTON_MAX_P];
+    double B[CN_JACOBI_MAX_P * CN_JACOBI_MAX_P], W[CN_JACOBI_MAX_P * CN_JACOBI_MAX_P];
+    double c[CN_JACOBI_MAX_P], kap[CN_JACOBI_MAX_P];
+    int par[CN_JACOBI_MAX_P];
+    if (n > CN_JACOBI_MAX_P) return -1;
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < n; ++j) V[i * n + j] = (i == j) ? 1.0 : 0.0;
     int sweep = 0;
@@ -1034,6 +1041,7 @@ static int cn_tridiag_ql(int n, double *A, double *V, double *lam)
     for (int i = n - 1; i >= 2; --i) {
         const int l = i - 1;
         for (int j = 0; j < CN_W; ++j) part[j] = (j < l) ? A[i * n + j] * A[i * n + j] : 0.0;
+        for (int j = CN_W; j < l; ++j) part[j - CN_W] = fma(A[i * n + j], A[i * n + j], part[j - CN_W]);
         const double sigma = bfly(part);
         const double alpha = A[i * n + l];
         if (sigma == 0.0) { e[i] = alpha; hh[i] = 0.0; continue; }
@@ -1048,6 +1056,7 @@ static int cn_tridiag_ql(int n, double *A, double *V, double *lam)
             pv[j] = a / H;
         }
         for (int j = 0; j < CN_W; ++j) part[j] = (j <= l) ? u[j] * pv[j] : 0.0;
+        for (int j = CN_W; j <= l; ++j) part[j - CN_W] = fma(u[j], pv[j], part[j - CN_W]);
         const double K = bfly(part) / (2.0 * H);
         for (int j = 0; j <= l; ++j) qv[j] = pv[j] - K * u[j];
         for (int j = 0; j <= l; ++j)                        /* A <- A - u q^T - q u^T */

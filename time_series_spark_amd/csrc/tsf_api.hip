@@ -379,8 +379,9 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     const bool newton = theta_in == nullptr &&
                         (spec->algorithm == TSF_ALGO_NEWTON ||
                          (spec->algorithm == TSF_ALGO_AUTO && Tm < TSF_NEWTON_BELOW_T));
-    if (newton && (fit_P(hs.n_cp, hs.K) > W || mode == 2))
-        return fail(ctx, "Newton needs 3 + n_changepoints + K <= 64 and all columns of one mode");
+    // (more than 64 parameters, or mixed additive / multiplicative columns: newton_kernel2, two parameters per lane)
+    if (newton && fit_P(hs.n_cp, hs.K) > 2 * W)
+        return fail(ctx, "Newton needs 3 + n_changepoints + K <= 128");
     const bool quad_ok = hs.growth == TSF_GROWTH_LINEAR && mode == 0 && hs.history == QH &&
                          theta_in == nullptr && !newton;
     if (spec->eval_form == TSF_EVAL_QUADRATIC && !quad_ok && theta_in == nullptr)

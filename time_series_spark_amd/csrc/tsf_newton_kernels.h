@@ -391,4 +391,373 @@ __global__ __launch_bounds__(64) void newton_kernel(FitArgs a, int PM)
     if (lane == 0) { a.status[n] = ret; a.n_iter[n] = it; a.n_eval[n] = sv.n_eval; a.fval[n] = -lp; }
 }
 
+
+// =========================================================================================
+// Two parameters per lane (64 < P <= 128, or mixed additive / multiplicative columns, whose
+// kernels hold two parameters per lane whatever P is): newton_kernel2.  Round 4: fbprophet
+// retries EVERY failed L-BFGS fit with Stan's Newton (and starts with it below 100 rows); without
+// this kernel such a series of a wide model was "dropped" where the reference would have fitted it.
+// It serves a handful of series per call, so it is written for correctness, not for speed: the
+// operations and their order are cn_tridiag_ql's / cn_newton's (oracle), entry p = lane + 64 s,
+// sums over more than 64 entries by dotc's rule (the p >= 64 term fma'd onto the p - 64 term, then
+// the butterfly), d and e of the QL iteration in LDS (every lane computes the scalar chain from
+// broadcast reads), the eigenvectors in place.  One wave per workgroup; the 129 x 129 matrix takes
+// 133 KB of LDS, so one workgroup per CU.
+// =========================================================================================
+struct QlScratch2 { double d[2 * W], e[2 * W], hh[2 * W], q[2 * W]; };
+
+__device__ __forceinline__ void ql2_tridiag_q(int n, int PM, double *Am, QlScratch2 &sc)
+{
+    const int lane = lane_id();
+#pragma unroll
+    for (int s = 0; s < 2; ++s) { sc.e[lane + s * W] = 0.0; sc.hh[lane + s * W] = 0.0; }
+    TSF_WAVE_SYNC();
+    for (int i = n - 1; i >= 2; --i) {
+        const int l = i - 1;
+        double xj[2], uj[2], pj[2], qj[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) xj[s] = (lane + s * W <= l) ? Am[i * PM + lane + s * W] : 0.0;
+        double part = (lane < l) ? xj[0] * xj[0] : 0.0;
+        if (lane + W < l) part = __builtin_fma(xj[1], xj[1], part);
+        const double sigma = bfly_sum(part);
+        const double alpha = Am[i * PM + l];
+        if (sigma == 0.0) {
+            if (lane == 0) { sc.e[i] = alpha; sc.hh[i] = 0.0; }
+            TSF_WAVE_SYNC();
+            continue;
+        }
+        const double mu = __builtin_sqrt(sigma + alpha * alpha);
+        const double beta = (alpha >= 0.0) ? -mu : mu;
+        const double ul = alpha - beta;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) uj[s] = (lane + s * W == l) ? ul : xj[s];
+        const double H = 0.5 * (sigma + ul * ul);
+        TSF_WAVE_SYNC();
+        if (lane == 0) Am[i * PM + l] = ul;
+        TSF_WAVE_SYNC();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {                          // p = A u / H, row j = lane + 64 s
+            const int j = lane + s * W;
+            double a = 0.0;
+            if (j <= l) {
+                const double *rowp = Am + j * PM, *up = Am + i * PM;
+                for (int k = 0; k <= l; ++k) a = __builtin_fma(rowp[k], up[k], a);
+            }
+            pj[s] = a / H;
+        }
+        part = (lane <= l) ? uj[0] * pj[0] : 0.0;
+        if (lane + W <= l) part = __builtin_fma(uj[1], pj[1], part);
+        const double K = bfly_sum(part) / (2.0 * H);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) { qj[s] = pj[s] - K * uj[s]; sc.q[lane + s * W] = qj[s]; }
+        TSF_WAVE_SYNC();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {                          // A <- A - u q^T - q u^T, row j
+            const int j = lane + s * W;
+            if (j <= l) {
+                double *rowp = Am + j * PM;
+                const double *up = Am + i * PM;
+                for (int k = 0; k <= l; ++k) rowp[k] = __builtin_fma(-qj[s], up[k], __builtin_fma(-uj[s], sc.q[k], rowp[k]));
+            }
+        }
+        if (lane == 0) { sc.e[i] = beta; sc.hh[i] = H; }
+        TSF_WAVE_SYNC();
+    }
+    if (lane == 0 && n > 1) sc.e[1] = Am[1 * PM + 0];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) if (lane + s * W < n) sc.d[lane + s * W] = Am[(lane + s * W) * PM + lane + s * W];
+    TSF_WAVE_SYNC();
+    // Q = H_{n-1} ... H_2 applied to the identity, in place (see ql_tridiag_q): lane + 64 s = column c
+    double *Vm = Am;
+    if (lane < 2 && n > 0) {
+        Vm[0 * PM + lane] = (lane == 0) ? 1.0 : 0.0;
+        if (n > 1) Vm[1 * PM + lane] = (lane == 1) ? 1.0 : 0.0;
+    }
+    TSF_WAVE_SYNC();
+    for (int i = 2; i < n; ++i) {
+        const double Hi = sc.hh[i];
+        const int l = i - 1;
+        if (Hi != 0.0) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int c = lane + s * W;
+                if (c <= l) {
+                    double w = 0.0;
+                    const double *up = Am + i * PM;
+                    double *colp = Vm + c;
+                    for (int k = 0; k <= l; ++k) w = __builtin_fma(up[k], colp[k * PM], w);
+                    w = w / Hi;
+                    for (int r = 0; r <= l; ++r) colp[r * PM] = __builtin_fma(-up[r], w, colp[r * PM]);
+                }
+            }
+        }
+        TSF_WAVE_SYNC();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int c = lane + s * W;
+            if (c <= i) { Vm[i * PM + c] = (c == i) ? 1.0 : 0.0; Vm[c * PM + i] = (c == i) ? 1.0 : 0.0; }
+        }
+        TSF_WAVE_SYNC();
+    }
+}
+
+// implicit QL on (sc.d, sc.e) in LDS, rotations applied to the columns of V (lane + 64 s = row); the
+// eigenvalue of entry lane + 64 s comes back in lam[s]
+__device__ __forceinline__ void ql2_chain(int n, int PM, double *Vm, QlScratch2 &sc, double (&lam)[2])
+{
+    const int lane = lane_id();
+    TSF_WAVE_SYNC();
+    {   // e shifted down by one, e[n-1] = 0
+        double ev[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) ev[s] = (lane + s * W + 1 < n) ? sc.e[lane + s * W + 1] : 0.0;
+        TSF_WAVE_SYNC();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) sc.e[lane + s * W] = ev[s];
+        TSF_WAVE_SYNC();
+    }
+    for (int l = 0; l < n; ++l) {
+        for (int guard = 0; guard < 60; ++guard) {
+            // m: first index in [l, n-2] whose off-diagonal element is negligible, else n-1
+            bool tiny[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int j = lane + s * W;
+                const bool in = j >= l && j < n - 1;
+                const double dj = in ? sc.d[j] : 0.0, dn = in ? sc.d[j + 1] : 0.0, ej = in ? sc.e[j] : 0.0;
+                const double dd = __builtin_fabs(dj) + __builtin_fabs(dn);
+                tiny[s] = in && (__builtin_fabs(ej) + dd == dd);
+            }
+            const unsigned long long m0 = __ballot(tiny[0]), m1 = __ballot(tiny[1]);
+            const int m = m0 ? (int)__builtin_ctzll(m0) : (m1 ? W + (int)__builtin_ctzll(m1) : n - 1);
+            if (m == l) break;
+            const double dl = sc.d[l], el = sc.e[l];
+            double g = (sc.d[l + 1] - dl) / (2.0 * el);
+            double r = ql_pythag(g, 1.0);
+            g = sc.d[m] - dl + el / (g + (g >= 0.0 ? __builtin_fabs(r) : -__builtin_fabs(r)));
+            double sn = 1.0, c = 1.0, p = 0.0;
+            int i = m - 1;
+            bool underflow = false;
+            for (; i >= l; --i) {
+                const double ei = sc.e[i], di = sc.d[i], di1 = sc.d[i + 1];
+                const double f = sn * ei;
+                const double b = c * ei;
+                r = __builtin_sqrt(__builtin_fma(f, f, g * g));
+                TSF_WAVE_SYNC();
+                if (lane == 0) sc.e[i + 1] = r;
+                if (r == 0.0) {
+                    if (lane == 0) { sc.d[i + 1] = di1 - p; sc.e[m] = 0.0; }
+                    TSF_WAVE_SYNC();
+                    underflow = true;
+                    break;
+                }
+                { const double ri = 1.0 / r; sn = f * ri; c = g * ri; }
+                g = di1 - p;
+                r = (di - g) * sn + 2.0 * c * b;
+                p = sn * r;
+                if (lane == 0) sc.d[i + 1] = g + p;
+                g = c * r - b;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const int k = lane + s * W;
+                    if (k < n) {
+                        double *vrow = Vm + k * PM;
+                        const double v1 = vrow[i + 1], v0 = vrow[i];
+                        vrow[i + 1] = __builtin_fma(sn, v0, c * v1);
+                        vrow[i] = __builtin_fma(c, v0, -(sn * v1));
+                    }
+                }
+                TSF_WAVE_SYNC();
+            }
+            if (underflow) continue;
+            if (lane == 0) { sc.d[l] = sc.d[l] - p; sc.e[l] = g; sc.e[m] = 0.0; }
+            TSF_WAVE_SYNC();
+        }
+    }
+    TSF_WAVE_SYNC();
+#pragma unroll
+    for (int s = 0; s < 2; ++s) lam[s] = (lane + s * W < n) ? sc.d[lane + s * W] : 0.0;
+}
+
+template <int KP>
+struct NewtonLds2 {
+    double th[TSF_MAX_P + W];
+    double ks[NTAB + 1], mc[NTAB + 1];
+    double tp1[NTAB], tp2[NTAB];
+    double tot1[W + 1], tot2[W + 1];
+    double d1[NTAB + 1], d2[NTAB + 1], rb[NTAB + 1], ab[NTAB + 1];
+    double accR[KP];
+    QlScratch2 ql;
+};
+
+template <int KP>
+constexpr size_t newton2_lds_bytes(int PM)
+{
+    return ((sizeof(NewtonLds2<KP>) + 15) & ~(size_t)15) + (size_t)PM * PM * sizeof(double);
+}
+
+// entry i (wave-uniform) of a two-slot vector as a scalar
+__device__ __forceinline__ double entry2(const double (&v)[2], int i)
+{
+    return (i < W) ? readlane_f64(v[0], i) : readlane_f64(v[1], i - W);
+}
+
+template <int KP, int GROWTH, int MODE>
+__global__ __launch_bounds__(64) void newton_kernel2(FitArgs a, int PM)
+{
+    constexpr int PPL = 2;
+    extern __shared__ __align__(16) unsigned char smem[];
+    NewtonLds2<KP> &lds = *reinterpret_cast<NewtonLds2<KP> *>(smem);
+    double *Am = reinterpret_cast<double *>(smem + ((sizeof(NewtonLds2<KP>) + 15) & ~(size_t)15));
+    double *Vm = Am;
+    const int lane = threadIdx.x;
+    const DevSpec *sp = a.sp;
+    for (int64_t n = blockIdx.x; n < a.N; n += gridDim.x) {
+    SeriesView sv;
+    make_view<KP, PPL>(a, n, sv);
+    for (int i = threadIdx.x; i < TSF_MAX_P + W; i += W) lds.th[i] = 0.0;
+    TSF_WAVE_SYNC();
+    const SeriesTab st = a.stab[n];
+    if (lane == 0) {
+        a.y_scale[n] = st.y_scale;
+        if (!a.aligned || n == 0) a.grid_out[a.aligned ? 0 : n] = a.gtab[a.aligned ? 0 : n].info;
+    }
+    double th[PPL], x[PPL], g[PPL], gx[PPL], step[PPL], acc[PPL];
+#pragma unroll
+    for (int s = 0; s < PPL; ++s) {
+        const int p = lane + s * W;
+        th[s] = (p == 0) ? st.k0 : (p == 1 ? st.m0 : 0.0);
+        x[s] = th[s]; g[s] = 0.0; gx[s] = 0.0; step[s] = 0.0; acc[s] = 0.0;
+    }
+    if (st.status0 != 0) {
+        if (st.status0 == TSF_ST_CONSTANT && lane == 2) th[0] = -20.72326583694641;
+        store_theta<PPL>(a, sv, n, th, a.theta);
+        if (lane == 0) { a.status[n] = st.status0; a.n_iter[n] = 0; a.n_eval[n] = 0; a.fval[n] = 0.0; }
+        continue;
+    }
+    const int P = sv.P;
+    const double epsilon = 1e-3, half_epsilon = 0.5 * epsilon;
+    enum { S_INIT = 0, S_F0, S_FD, S_HALVE };
+    int stage = S_INIT, ret = TSF_ST_MAXIT, it = 0, mI = 0, d = 0, pi = 0;
+    double lp = 0.0, lastlp = 0.0, f0 = 0.0, f1 = 0.0, size = 2.0, fx = 0.0;
+    for (;;) {
+        FT_DECL;
+        const bool bad = eval_fg<KP, GROWTH, MODE, PPL, false, NewtonLds2<KP>>(sp, sv, lds, x, fx, gx FT_PASS);
+        bool finish_iter = false, moved = false;
+        if (stage == S_INIT) {
+            if (bad) { ret = TSF_ST_INIT_NONFINITE; lp = -fx; break; }
+            lp = -fx;
+            stage = S_F0;
+#pragma unroll
+            for (int s = 0; s < PPL; ++s) x[s] = th[s];
+            continue;
+        }
+        if (stage == S_F0) {
+            if (bad) { ret = TSF_ST_NEWTON_FAIL; break; }
+            lastlp = lp;
+            f0 = -fx;
+            d = 0; pi = 0;
+#pragma unroll
+            for (int s = 0; s < PPL; ++s) { g[s] = gx[s]; acc[s] = 0.0; x[s] = (lane + s * W == 0) ? th[s] + (-2 * epsilon) : th[s]; }
+            stage = S_FD;
+            continue;
+        }
+        if (stage == S_FD) {
+            if (bad) { ret = TSF_ST_NEWTON_FAIL; break; }
+            const double coef = (pi == 0) ? 1.0 / 12.0 : (pi == 1 ? -2.0 / 3.0 : (pi == 2 ? 2.0 / 3.0 : -1.0 / 12.0));
+#pragma unroll
+            for (int s = 0; s < PPL; ++s) acc[s] = __builtin_fma(half_epsilon * coef, -gx[s], acc[s]);
+            if (++pi == 4) {
+#pragma unroll
+                for (int s = 0; s < PPL; ++s) { if (lane + s * W < P) Am[d * PM + lane + s * W] = acc[s]; acc[s] = 0.0; }
+                pi = 0; ++d;
+            }
+            if (d < P) {
+                const double pert = (pi == 0) ? -2 * epsilon : (pi == 1 ? -1 * epsilon : (pi == 2 ? epsilon : 2 * epsilon));
+#pragma unroll
+                for (int s = 0; s < PPL; ++s) x[s] = (lane + s * W == d) ? th[s] + pert : th[s];
+                continue;
+            }
+            // ---- H = A + A^T (in place; entry b owns the pairs (r, b), r <= b)
+            TSF_WAVE_SYNC();
+            for (int r = 0; r < P; ++r) {
+                double u[PPL], v[PPL];
+#pragma unroll
+                for (int s = 0; s < PPL; ++s) {
+                    const int b = lane + s * W;
+                    const bool mine = b < P && r <= b;
+                    u[s] = mine ? Am[r * PM + b] : 0.0; v[s] = mine ? Am[b * PM + r] : 0.0;
+                }
+                TSF_WAVE_SYNC();
+#pragma unroll
+                for (int s = 0; s < PPL; ++s) {
+                    const int b = lane + s * W;
+                    if (b < P && r <= b) { const double h = u[s] + v[s]; Am[r * PM + b] = h; Am[b * PM + r] = h; }
+                }
+                TSF_WAVE_SYNC();
+            }
+            // ---- make_negative_definite_and_solve
+            double lam[PPL], proj[PPL];
+            ql2_tridiag_q(P, PM, Am, lds.ql);
+            ql2_chain(P, PM, Vm, lds.ql, lam);
+#pragma unroll
+            for (int s = 0; s < PPL; ++s) {
+                const int c = lane + s * W;
+                double pa = 0.0;
+                for (int i = 0; i < P; ++i) {
+                    const double gi = -entry2(g, i);
+                    const double vij = (c < P) ? Vm[i * PM + c] : 0.0;
+                    pa = __builtin_fma(vij, gi, pa);
+                }
+                proj[s] = (c < P) ? -pa / __builtin_fabs(lam[s]) : 0.0;
+            }
+#pragma unroll
+            for (int s = 0; s < PPL; ++s) {
+                const int r = lane + s * W;
+                double sa = 0.0;
+                for (int j = 0; j < P; ++j) {
+                    const double pjv = entry2(proj, j);
+                    const double vij = (r < P) ? Vm[r * PM + j] : 0.0;
+                    sa = __builtin_fma(vij, pjv, sa);
+                }
+                step[s] = (r < P) ? sa : 0.0;
+                x[s] = th[s];
+            }
+            size = 2.0; f1 = -1e100;
+            stage = S_HALVE;
+        } else {   // S_HALVE: a trial point was evaluated
+            f1 = bad ? -1e100 : -fx;
+        }
+        // ---- Stan's `while (f1 < f0)` step-halving loop
+        if (f1 < f0) {
+            size *= 0.5;
+            if (size < 1e-50) { finish_iter = true; moved = false; }
+            else {
+#pragma unroll
+                for (int s = 0; s < PPL; ++s) x[s] = th[s] - size * step[s];
+                continue;
+            }
+        } else {
+            finish_iter = true; moved = true;
+        }
+        if (finish_iter) {
+            ++it;
+            if (moved) {
+#pragma unroll
+                for (int s = 0; s < PPL; ++s) th[s] = x[s];
+                lp = f1;
+            } else lp = f0;
+            if (mI > 0 && __builtin_fabs(lp - lastlp) < 1e-8) { ret = TSF_ST_NEWTON_CONVERGED; break; }
+            if (++mI >= a.opt.max_iter) { ret = TSF_ST_MAXIT; break; }
+            stage = S_F0;
+#pragma unroll
+            for (int s = 0; s < PPL; ++s) x[s] = th[s];
+        }
+    }
+    store_theta<PPL>(a, sv, n, th, a.theta);
+    if (lane == 0) { a.status[n] = ret; a.n_iter[n] = it; a.n_eval[n] = sv.n_eval; a.fval[n] = -lp; }
+    TSF_WAVE_SYNC();
+    }
+}
+
 }  // namespace tsf

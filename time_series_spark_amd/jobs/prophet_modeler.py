@@ -187,16 +187,16 @@ def fit_packed(panel, floor, cap, kw, devices=None, cost=None):
         newton = fc.ModelSpec(algorithm=_lib.ALGO_NEWTON, **model, **opts)
         sd = fc.ModelSpec(**model, **opts).to_dict()      # what predict needs: no optimiser choice
         # fbprophet 0.5: optimizing(algorithm='Newton' if T < 100 else 'LBFGS'), and Newton once
-        # more after an L-BFGS RuntimeError (UPSTREAM-RECALL forecaster.py fit).  The
-        # Newton kernel holds one parameter per lane: wider models stay on L-BFGS.
+        # more after an L-BFGS RuntimeError (UPSTREAM-RECALL forecaster.py fit).  Every model the
+        # library fits has a Newton kernel since round 4 (3 + n_changepoints + K <= 128 = TSF_MAX_P; one parameter
+        # per lane up to 64 parameters of one column mode, two per lane beyond that and for mixed modes --
+        # newton_kernel2, slow but there: a failed fit of a wide model is retried as the reference would, not dropped).
         modes = {s_.get('mode', mode) for s_ in seas} | ({mode} if hol_extra else set())
-        newton_ok = 3 + lbfgs.n_changepoints + lbfgs.K <= 64 and len(modes) <= 1
+        newton_ok = 3 + lbfgs.n_changepoints + lbfgs.K <= 128
         if algo == 'newton' and not newton_ok:
-            raise ValueError('algorithm newton needs 3 + n_changepoints + K <= 64 and one seasonality mode')
+            raise ValueError('algorithm newton needs 3 + n_changepoints + K <= 128')
         short = panel.lengths[members] < NEWTON_BELOW_T
         if algo == 'auto' and not newton_ok and short.any():
-            # fbprophet would run Stan's Newton here (and retry failed L-BFGS fits with it); the Newton
-            # kernel holds one parameter per lane, so these models stay on L-BFGS: said, not hidden
             print(f"Newton optimiser unavailable for this model (3 + n_changepoints + K = "
                   f"{3 + lbfgs.n_changepoints + lbfgs.K}, K = {lbfgs.K}, modes {sorted(modes)}): "
                   f"{int(short.sum())} series shorter than {NEWTON_BELOW_T} rows are fitted with L-BFGS")
