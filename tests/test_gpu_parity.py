@@ -468,6 +468,57 @@ def test_ragged_call_is_cut_into_length_classes(env):
         assert n_bit_diff(r.theta[n], o['theta']) == 0 and n_bit_diff(r.fval[n], o['f']) == 0, n
 
 
+def test_ragged_series_with_equal_timestamps_share_grid_tables(env):
+    """Series of a ragged call whose timestamp vectors are byte-identical share one set of grid tables (t, changepoint
+    counts, design matrix) and, on the quadratic form, one prebuilt Z^T Z (tsf_api.hip fit_host_one: hash + memcmp
+    classes; gram_grids_kernel).  Sharing changes where a table lives, not a bit of any result: default against
+    TSF_GRID_SHARE=0 (a grid per series) against TSF_GRAM_SHARE=0 (shared tables, every wave builds its own Z^T Z),
+    three models and Newton; a series with the same LENGTH but timestamps one day later is its own class; a sample
+    against the oracle."""
+    import os
+    fc, cl = env
+    from time_series_spark_amd import _lib, synth
+    rng = np.random.default_rng(43)
+    N = 90
+    kinds = rng.integers(0, 4, N)                       # four calendars ...
+    kinds[[7, 50]] = 4                                  # ... and two loners: length of calendar 0, shifted by a day
+    Tm = 760
+    dsm = synth.daily_grid(Tm + 1)
+    cal = {0: dsm[:730], 1: dsm[:365], 2: dsm[20:750], 3: dsm[:400][::2], 4: dsm[1:731]}
+    lens = np.array([len(cal[k]) for k in kinds])
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    dsr = np.concatenate([cal[k] for k in kinds])
+    for growth, mode, algo in (('linear', 'additive', None), ('logistic', 'multiplicative', None),
+                               ('linear', 'multiplicative', None), ('linear', 'additive', _lib.ALGO_NEWTON)):
+        _, ym = synth.make_panel(N, Tm, growth, seed=9)
+        yr = np.concatenate([ym[i][:c] for i, c in enumerate(lens)])
+        cap = np.array([ym[i][:c].max() * 1.1 for i, c in enumerate(lens)])
+        spec = fc.ModelSpec(growth=growth, seasonality_mode=mode, seasonalities=[helpers.YEARLY, helpers.WEEKLY])
+        if algo is not None:
+            spec = type(spec).from_dict(dict(spec.to_dict(), lbfgs=dict(spec.lbfgs, algorithm=algo)))
+        res = {}
+        for tag, envs in (('shared', {}), ('own_grids', {'TSF_GRID_SHARE': '0'}), ('own_gram', {'TSF_GRAM_SHARE': '0'})):
+            os.environ.update(envs)
+            try:
+                res[tag] = fc.fit_ragged(spec, off, dsr, yr, floor=np.zeros(N), cap=cap)
+            finally:
+                for k in envs:
+                    os.environ.pop(k, None)
+        for tag in ('own_grids', 'own_gram'):
+            for name in ('theta', 'fval', 'n_iter', 'n_eval', 'status', 'y_scale'):
+                assert np.array_equal(getattr(res['shared'], name), getattr(res[tag], name), equal_nan=True), (growth, mode, algo, tag, name)
+            assert res['shared'].grid.tobytes() == res[tag].grid.tobytes()
+        r = res['shared']
+        assert (r.status > 0).sum() >= N - 10
+        if algo is None:
+            csp = helpers.oracle_spec(spec)
+            for n in (0, 7, 8, 50, N - 1):
+                o = cl.fit(csp, dsr[off[n]:off[n + 1]], yr[off[n]:off[n + 1]], 0.0, cap[n])
+                assert (r.n_iter[n], r.n_eval[n], r.status[n]) == (o['n_iter'], o['n_eval'], o['status']), (growth, mode, n)
+                P = len(o['theta'])
+                assert n_bit_diff(r.theta[n][:P], o['theta']) == 0 and n_bit_diff(r.fval[n], o['f']) == 0, (growth, mode, n)
+
+
 def test_one_host_thread_per_device_gives_identical_bits(env, monkeypatch):
     """SURVEY 8e, in-process arrangement: a call cut into blocks of series, one tsf_ctx + host
     thread per device (here: three contexts on the one GPU the box has), equals the

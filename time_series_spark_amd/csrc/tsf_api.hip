@@ -14,6 +14,8 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
+#include <atomic>
 #include <vector>
 
 #include "tsf_aux_kernels.h"
@@ -246,7 +248,7 @@ static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 static WsLayout ws_layout(int64_t N, int64_t n_grids, int NTmax, int KP, int quad_P4 = 0,
                           int quad_slots = 0, int quad_ragged = 0, int64_t lat_U = 0,
-                          const MfmaPlan *mp = nullptr, int coop_slots = 0, int coop_stride = 0)
+                          const MfmaPlan *mp = nullptr, int coop_slots = 0, int coop_stride = 0, int64_t quad_pre = 0)
 {
     WsLayout l;
     size_t off = 0;
@@ -258,7 +260,8 @@ static WsLayout ws_layout(int64_t N, int64_t n_grids, int NTmax, int KP, int qua
     // instead of a design matrix per grid
     l.Xw = off; off = align_up(off + (lat_U > 0 ? 0 : sizeof(double) * (size_t)n_grids * NTmax * KP * W));
     l.yw = off; off = align_up(off + sizeof(double) * (size_t)N * NTmax * W);
-    l.Mg = off; off = align_up(off + sizeof(double) * (size_t)quad_P4 * 2 * W);
+    // one Gram matrix for an aligned panel; quad_pre of them for a ragged panel whose series share timestamp vectors
+    l.Mg = off; off = align_up(off + sizeof(double) * (size_t)quad_P4 * 2 * W * (size_t)(quad_pre > 0 ? quad_pre : 1));
     l.Mslot = off; off = align_up(off + (quad_ragged ? sizeof(double) * (size_t)quad_slots * quad_P4 * 2 * W : 0));
     l.rbuf = off; off = align_up(off + sizeof(double) * (size_t)quad_slots * NTmax * W);
     l.counter = off; off = align_up(off + 256);
@@ -355,7 +358,8 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
                    const void *y, int32_t y_dtype, const double *floor_, const double *cap,
                    const double *extra, tsf_fit_out *out, const double *theta_in,
                    double *grad_out, hipStream_t st, int64_t lat_base = 0, int64_t lat_step = 0,
-                   int64_t lat_U = 0, const double *theta_ref = nullptr)
+                   int64_t lat_U = 0, const double *theta_ref = nullptr,
+                   const int32_t *grid_of = nullptr, const int64_t *grid_rows = nullptr, int64_t n_distinct = 0)
 {
     if (!ctx) return -1;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -372,7 +376,10 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     if (Tm < 1) return fail(ctx, "no rows");
     if (Tm > TSF_MAX_T) return fail(ctx, "series too long (TSF_MAX_T rows per series)");
     const int NTmax = (Tm + W - 1) / W;
-    const int64_t n_grids = aligned ? 1 : N;
+    // ragged panel whose series share timestamp vectors (fit_host found n_distinct < N of them): one set of grid tables
+    // per distinct vector
+    if (aligned || !grid_of || !grid_rows || n_distinct <= 0 || n_distinct >= N) { grid_of = nullptr; grid_rows = nullptr; n_distinct = 0; }
+    const int64_t n_grids = aligned ? 1 : (grid_of ? n_distinct : N);
     // quadratic (Gram) form of the data term: see tsf_quad_kernels.h
     // Stan's Newton optimiser (tsf_newton_kernels.h): explicitly, or by fbprophet's rule on the
     // longest series of the call
@@ -471,8 +478,12 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     }
     const int coop_slots = coop ? coop_slots_for(N, coop_after, ctx->n_cu) : 0;
     const int coop_stride = coop ? coop_slot_doubles(hs.KP == 64 ? 2 : 1) : 0;
+    // ragged panel, quadratic form, series sharing timestamp vectors: Z^T Z once per distinct vector (gram_grids_kernel)
+    // instead of once per series inside the fit kernel -- when that at least halves the builds (TSF_GRAM_SHARE=0: never)
+    const char *egs = getenv("TSF_GRAM_SHARE");
+    const int64_t quad_pre = (quad && !aligned && grid_of && n_grids * 2 <= N && !(egs && atoi(egs) == 0)) ? n_grids : 0;
     const WsLayout l = ws_layout(N, n_grids, NTmax, hs.KP, qp.P4, qp.slots, (quad || newton_quad) && !aligned, lat_U, &mp,
-                                 coop_slots, coop_stride);
+                                 coop_slots, coop_stride, quad_pre);
     rc = ensure_ws(ctx, l.total, N, NTmax, !aligned);
     if (rc) return rc;
     char *ws = (char *)ctx->ws;
@@ -497,11 +508,11 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     hipLaunchKernelGGL(setup_grid_kernel, dim3((unsigned)n_grids), dim3(256), 0, st, ctx->d_spec,
                        (int)n_grids, aligned ? nullptr : offsets, T, ds, extra,
                        aligned ? (int64_t)T : total_rows, NTmax, gtab, tw, cw, Xw,
-                       (int32_t *)(ws + l.uw), lat_base, lat_U > 0 ? lat_step : (int64_t)0);
+                       (int32_t *)(ws + l.uw), lat_base, lat_U > 0 ? lat_step : (int64_t)0, grid_rows);
     HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(setup_series_kernel, dim3((unsigned)N), dim3(64), 0, st, ctx->d_spec, N,
                        aligned ? nullptr : offsets, T, ds, y, y_dtype, floor_, cap, NTmax, gtab,
-                       aligned, stab, yw);
+                       aligned, stab, yw, grid_of);
     HIP_TRY(ctx, hipGetLastError());
     FitArgs a;
     memset(&a, 0, sizeof(a));
@@ -519,6 +530,7 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     a.n_iter = out->n_iter; a.n_eval = out->n_eval; a.grid_out = out->grid;
     a.theta_in = theta_in; a.grad_out = grad_out;
     a.uw = (const int32_t *)(ws + l.uw); a.Xu = (const double *)(ws + l.Xu); a.xidx = lat_U > 0 ? 1 : 0;
+    a.grid_of = grid_of;
     // scheduling hints of tsf_set_cost_hints: for this call if they were given for this many series; used once
     const int order_buf = (ctx->order_n == N && !theta_in) ? (ctx->order_next ^ 1) : -1;
     if (order_buf >= 0) a.order = ctx->order_dev[order_buf];
@@ -560,6 +572,7 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
         qa.counter = (int *)(ws + l.counter); qa.P4 = qp.P4;
         qa.recenter_every = spec->recenter_every; qa.recenter_ratio = spec->recenter_ratio;
         qa.dbg = nullptr; qa.nb_buf = nullptr; qa.nb_bytes = 0;
+        qa.Mpre = quad_pre ? qa.Mg : nullptr; qa.n_pre = quad_pre;
         HIP_TRY(ctx, hipMemsetAsync(qa.counter, 0, sizeof(int), st));
         lrc = launch_quad(hs.KP, qp, qa, (double *)(ws + l.Mg), st);
     } else if (mp.on) {
@@ -799,6 +812,84 @@ static int fit_host_one(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int align
             if (U <= (uint64_t)1 << 18) { lat_base = lo; lat_step = (int64_t)g; lat_U = (int64_t)U; }
         }
     }
+    // ragged panel: which series SHARE a timestamp vector (the usual case: many series observed on a few calendars)?
+    // Their grid tables -- scaled time, changepoint segments, the design matrix: 172 KB for two years of daily data --
+    // are then built once per distinct vector and shared as on an aligned panel (FitArgs::grid_of), and the
+    // quadratic-form path builds Z^T Z once per vector instead of once per series.  Identical vectors only (hash of
+    // the bytes, then memcmp against the class's first member); models with explicit columns are left alone (their
+    // columns are per row, not per timestamp).  TSF_GRID_SHARE=0 turns it off (tests compare both).
+    DevBuf d_gof, d_grows;
+    int64_t n_distinct = 0;
+    {
+        const char *e_share = getenv("TSF_GRID_SHARE");
+        if (!aligned && !theta_in && spec->n_extra == 0 && N >= 2 && !(e_share && atoi(e_share) == 0)) {
+            struct Key { int64_t len; uint64_t h; int64_t n; };
+            std::vector<Key> keys((size_t)N);
+            {
+                int hw = (int)std::thread::hardware_concurrency();
+                const int nt = hw < 1 ? 1 : (hw > 16 ? 16 : hw);
+                std::atomic<int64_t> next(0);
+                auto work = [&]() {
+                    for (;;) {
+                        const int64_t b = next.fetch_add(256);
+                        if (b >= N) break;
+                        for (int64_t n = b; n < N && n < b + 256; ++n) {
+                            const int64_t len = offsets[n + 1] - offsets[n];
+                            const uint64_t *p = (const uint64_t *)(ds + offsets[n]);
+                            uint64_t h = 0x9e3779b97f4a7c15ull ^ (uint64_t)len;
+                            for (int64_t i = 0; i < len; ++i) { h ^= p[i]; h *= 0xff51afd7ed558ccdull; h ^= h >> 32; }
+                            keys[(size_t)n] = Key{len, h, n};
+                        }
+                    }
+                };
+                if (nt <= 1 || N < 1024) work();
+                else {
+                    std::vector<std::thread> th;
+                    for (int i = 0; i < nt; ++i) th.emplace_back(work);
+                    for (auto &x : th) x.join();
+                }
+            }
+            std::sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) {
+                return a.len != b.len ? a.len < b.len : (a.h != b.h ? a.h < b.h : a.n < b.n);
+            });
+            std::vector<int64_t> rep((size_t)N);            // first member of the class of series n
+            for (size_t i = 0; i < keys.size();) {
+                size_t j = i;
+                while (j < keys.size() && keys[j].len == keys[i].len && keys[j].h == keys[i].h) ++j;
+                // members of one (length, hash) run: classes by memcmp against the representatives found so far
+                std::vector<int64_t> reps;
+                for (size_t k = i; k < j; ++k) {
+                    const int64_t n = keys[k].n;
+                    int64_t r = -1;
+                    for (int64_t c : reps)
+                        if (memcmp(ds + offsets[c], ds + offsets[n], (size_t)keys[k].len * 8) == 0) { r = c; break; }
+                    if (r < 0) { reps.push_back(n); r = n; }
+                    rep[(size_t)n] = r;
+                }
+                i = j;
+            }
+            std::vector<int32_t> gof((size_t)N), id_of((size_t)N, -1);
+            std::vector<int64_t> grows;
+            for (int64_t n = 0; n < N; ++n) {
+                const int64_t r = rep[(size_t)n];
+                if (id_of[(size_t)r] < 0) {
+                    id_of[(size_t)r] = (int32_t)(grows.size() / 2);
+                    grows.push_back(offsets[r]);
+                    grows.push_back(offsets[r + 1] - offsets[r]);
+                }
+                gof[(size_t)n] = id_of[(size_t)r];
+            }
+            n_distinct = (int64_t)(grows.size() / 2);
+            if (n_distinct < N) {
+                HIP_TRY(ctx, d_gof.alloc(4 * (size_t)N));
+                HIP_TRY(ctx, d_grows.alloc(8 * grows.size()));
+                HIP_TRY(ctx, hipMemcpy(d_gof.p, gof.data(), 4 * (size_t)N, hipMemcpyHostToDevice));
+                HIP_TRY(ctx, hipMemcpy(d_grows.p, grows.data(), 8 * grows.size(), hipMemcpyHostToDevice));
+            } else {
+                n_distinct = 0;
+            }
+        }
+    }
     if (host_timing) t_h2d = now();
     int rc = run_fit(ctx, spec, N, aligned, T, d_off.as<int64_t>(), total, max_T, d_ds.as<int64_t>(),
                      d_y.p, y_dtype, floor_ ? d_floor.as<double>() : nullptr,
@@ -806,7 +897,8 @@ static int fit_host_one(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int align
                      spec->n_extra > 0 ? d_extra.as<double>() : nullptr, &dout,
                      theta_in ? d_thin.as<double>() : nullptr,
                      theta_in ? d_grad.as<double>() : nullptr, nullptr, lat_base, lat_step, lat_U,
-                     (theta_in && theta_ref) ? d_thref.as<double>() : nullptr);
+                     (theta_in && theta_ref) ? d_thref.as<double>() : nullptr,
+                     n_distinct > 0 ? d_gof.as<int32_t>() : nullptr, n_distinct > 0 ? d_grows.as<int64_t>() : nullptr, n_distinct);
     if (rc) return rc;
     HIP_TRY(ctx, hipDeviceSynchronize());
     if (host_timing) t_fit = now();

@@ -20,12 +20,15 @@ __global__ void setup_grid_kernel(const DevSpec *__restrict__ sp, int n_grids,
                                   int NTmax, GridTab *__restrict__ gtab,
                                   double *__restrict__ tw_all, uint16_t *__restrict__ cw_all,
                                   double *__restrict__ Xw_all, int32_t *__restrict__ uw_all,
-                                  int64_t lat_base, int64_t lat_step)
+                                  int64_t lat_base, int64_t lat_step,
+                                  const int64_t *__restrict__ grid_rows = nullptr)
 {
     const int g = blockIdx.x;
     if (g >= n_grids) return;
-    const int64_t row0 = offsets ? offsets[g] : 0;
-    const int T = offsets ? (int)(offsets[g + 1] - offsets[g]) : T_aligned;
+    // grid_rows (ragged panels whose series share timestamp vectors: FitArgs::grid_of): [n_grids][2] first row and
+    // row count of the vector of grid g; else the rows of series g
+    const int64_t row0 = grid_rows ? grid_rows[2 * g] : (offsets ? offsets[g] : 0);
+    const int T = grid_rows ? (int)grid_rows[2 * g + 1] : (offsets ? (int)(offsets[g + 1] - offsets[g]) : T_aligned);
     const int64_t *ds = ds_all + row0;
     GridTab &gt = gtab[g];
     double *tw = tw_all + (size_t)g * NTmax * W;
@@ -147,12 +150,12 @@ __global__ __launch_bounds__(64) void setup_series_kernel(
     const int64_t *__restrict__ ds_all, const void *__restrict__ y_all, int y_dtype,
     const double *__restrict__ floor_in, const double *__restrict__ cap_in, int NTmax,
     const GridTab *__restrict__ gtab, int aligned, SeriesTab *__restrict__ stab,
-    double *__restrict__ yw_all)
+    double *__restrict__ yw_all, const int32_t *__restrict__ grid_of = nullptr)
 {
     const int64_t n = blockIdx.x;
     if (n >= N) return;
     const int lane = threadIdx.x;
-    const GridTab &gt = gtab[aligned ? 0 : n];
+    const GridTab &gt = gtab[aligned ? 0 : (grid_of ? (int64_t)grid_of[n] : n)];
     const int T = gt.info.T, NT = gt.info.NT;
     const int64_t row0 = offsets ? offsets[n] : n * (int64_t)T_aligned;
     const int64_t *ds = ds_all + (offsets ? offsets[n] : 0);

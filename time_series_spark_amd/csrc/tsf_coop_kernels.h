@@ -834,7 +834,7 @@ __device__ __forceinline__ void coop_owner(const FitArgs &a, SeriesView &sv, int
         const SeriesTab st = a.stab[n];
         if (lane == 0) {
             a.y_scale[n] = st.y_scale;
-            if (!a.aligned || n == 0) a.grid_out[a.aligned ? 0 : n] = a.gtab[a.aligned ? 0 : n].info;
+            if (!a.aligned || n == 0) a.grid_out[a.aligned ? 0 : n] = a.gtab[grid_index(a, n)].info;
         }
 #pragma unroll
         for (int s = 0; s < PPL; ++s) {
@@ -1100,7 +1100,7 @@ __device__ __forceinline__ void coop_report_unfitted(const FitArgs &a, const Ser
     const SeriesTab st = a.stab[n];
     if (lane == 0) {
         a.y_scale[n] = st.y_scale;
-        if (!a.aligned || n == 0) a.grid_out[a.aligned ? 0 : n] = a.gtab[a.aligned ? 0 : n].info;
+        if (!a.aligned || n == 0) a.grid_out[a.aligned ? 0 : n] = a.gtab[grid_index(a, n)].info;
     }
     double xk[PPL];
 #pragma unroll

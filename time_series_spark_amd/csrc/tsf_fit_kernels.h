@@ -618,7 +618,17 @@ struct FitArgs {
     int coop_max, coop_stride, coop_after, coop_blocks;
     // scheduling hint (tsf_set_cost_hints): the q-th series the launch starts is order[q]; null = q
     const int32_t *order;
+    // ragged panels whose series SHARE timestamp vectors (round 4): grid_of[n] = the grid (timestamp vector with its
+    // derived tables: tw, cw, Xw, GridTab) of series n, grids numbered 0 .. G-1 in order of first appearance; null =
+    // one grid per series (grid n).  Found on the host by tsf_fit_ragged (identical vectors only, models without
+    // explicit columns); the tables of a grid are then built once and shared, as on an aligned panel.
+    const int32_t *grid_of;
 };
+
+__device__ __forceinline__ int64_t grid_index(const FitArgs &a, int64_t n)
+{
+    return a.aligned ? 0 : (a.grid_of ? (int64_t)a.grid_of[n] : n);
+}
 
 // ---- checkpoint of a suspended fit (written by fit_kernel, read by fit_coop_kernel) -----------
 // slot layout (doubles): [0, COOP_VARS_D) CoopVars; [COOP_VARS_D, +MAXH) rho; then the vectors
@@ -671,7 +681,7 @@ __device__ __forceinline__ bool coop_should_suspend(const FitArgs &a, int n_eval
 template <int KP, int PPL>
 __device__ __forceinline__ void make_view(const FitArgs &a, int64_t n, SeriesView &sv)
 {
-    const int g = a.aligned ? 0 : (int)n;
+    const int64_t g = grid_index(a, n);
     const GridTab &gt = a.gtab[g];
     sv.T = gt.info.T; sv.NT = gt.info.NT; sv.S = gt.S_fit; sv.S_out = gt.info.S;
     sv.P = 3 + sv.S + a.sp->K;
@@ -778,7 +788,7 @@ __global__ __launch_bounds__(64, GNTR > 0 ? 2 : TSF_FIT_WPS) void fit_kernel(Fit
     const SeriesTab st = a.stab[n];
     if (lane == 0) {
         a.y_scale[n] = st.y_scale;
-        if (!a.aligned || n == 0) a.grid_out[a.aligned ? 0 : n] = a.gtab[a.aligned ? 0 : n].info;
+        if (!a.aligned || n == 0) a.grid_out[a.aligned ? 0 : n] = a.gtab[grid_index(a, n)].info;
     }
 
     double xk[PPL], gk[PPL], pk[PPL], xk1[PPL], gk1[PPL], pk1[PPL];

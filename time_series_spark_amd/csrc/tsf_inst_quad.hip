@@ -11,6 +11,23 @@ namespace tsf {
 int quad_waves_per_block(int PPL) { return PPL == 2 ? (TSF_QUAD_NW2G > TSF_QUAD_NW2 ? TSF_QUAD_NW2G : TSF_QUAD_NW2) : TSF_QUAD_NW4; }
 static_assert(TSF_QUAD_NW4 >= TSF_QUAD_NW3 && TSF_QUAD_NW4 >= TSF_QUAD_NW, "workspace slots are sized for the widest workgroup");
 
+// ragged panel whose series share timestamp vectors (QuadArgs::Mpre): Z^T Z once per distinct vector, ahead of the
+// fit kernel, for the kernels that read it (M in registers, M in global memory)
+template <int KP, int PPL>
+static int prebuild_grams(const QuadPlan &qp, const QuadArgs &qa, hipStream_t st)
+{
+    if (!qa.Mpre) return 0;
+    const int64_t per = qp.slots / qp.P4 > 0 ? qp.slots / qp.P4 : 1;        // staging rows: one rbuf slot per (grid, column)
+    for (int64_t g0 = 0; g0 < qa.n_pre; g0 += per) {
+        const int64_t cnt = qa.n_pre - g0 < per ? qa.n_pre - g0 : per;
+        hipLaunchKernelGGL((gram_grids_kernel<KP, PPL>), dim3((unsigned)qp.P4, (unsigned)cnt), dim3(64), 0, st,
+                           qa, const_cast<double *>(qa.Mpre), g0);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+
 // ragged panel, Z^T Z of every resident wave in LDS: NWR waves per workgroup (tsf_quad_kernels.h
 // QM_RAGGED_LDS); -2 when it does not fit (the caller falls back to M in global memory)
 template <int KP, int PQ>
@@ -41,6 +58,7 @@ static int launch_quad_ragged_reg(const QuadPlan &qp, const QuadArgs &qa, hipStr
                         sizeof(double) * (size_t)qa.f.NTmax * W) * NWR;
     if (lds > 160 * 1024) return -2;
     if (sizeof(double) * (size_t)qa.f.NTmax * W < sizeof(GramX)) return -2;   // the Gram build borrows the staging rows
+    if (int e = prebuild_grams<KP, 1>(qp, qa, st)) return e;
     hipFuncSetAttribute((const void *)fit_quad_kernel<KP, 1, NWR, QM_RAGGED_REG, PQ, true, true>,
                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     int64_t blocks = qp.n_cu;       // one workgroup per CU
@@ -80,6 +98,7 @@ static int launch_quad_one(const QuadPlan &qp, const QuadArgs &qa, double *Mg, h
             rc = launch_quad_ragged_lds<KP, PQ>(qp, qa, st);
             if (rc != -2) return rc;
         }
+        if (int e = prebuild_grams<KP, PPL>(qp, qa, st)) return e;
         return launch_quad_mm<KP, PPL, QM_RAGGED, PQ>(qp, qa, Mg, st);
     }
     if constexpr (PPL == 1) {

@@ -401,7 +401,7 @@ __global__ __launch_bounds__(64, (KP <= 16 ? TSF_NEWTON_QUAD_WPS : 1)) void newt
                 const SeriesTab st = a.stab[n];
                 if (lane == 0) {
                     a.y_scale[n] = st.y_scale;
-                    if (!a.aligned || n == 0) a.grid_out[a.aligned ? 0 : n] = a.gtab[a.aligned ? 0 : n].info;
+                    if (!a.aligned || n == 0) a.grid_out[a.aligned ? 0 : n] = a.gtab[grid_index(a, n)].info;
                 }
                 th[0] = (lane == 0) ? st.k0 : (lane == 1 ? st.m0 : 0.0);
                 if (st.status0 != 0) {

@@ -284,7 +284,7 @@ __global__ __launch_bounds__(64) void newton_kernel(FitArgs a, int PM)
     const SeriesTab st = a.stab[n];
     if (lane == 0) {
         a.y_scale[n] = st.y_scale;
-        if (!a.aligned || n == 0) a.grid_out[a.aligned ? 0 : n] = a.gtab[a.aligned ? 0 : n].info;
+        if (!a.aligned || n == 0) a.grid_out[a.aligned ? 0 : n] = a.gtab[grid_index(a, n)].info;
     }
     double th[PPL], x[PPL], g[PPL], gx[PPL], step[PPL];
     th[0] = (lane == 0) ? st.k0 : (lane == 1 ? st.m0 : 0.0);
@@ -620,7 +620,7 @@ __global__ __launch_bounds__(64) void newton_kernel2(FitArgs a, int PM)
     const SeriesTab st = a.stab[n];
     if (lane == 0) {
         a.y_scale[n] = st.y_scale;
-        if (!a.aligned || n == 0) a.grid_out[a.aligned ? 0 : n] = a.gtab[a.aligned ? 0 : n].info;
+        if (!a.aligned || n == 0) a.grid_out[a.aligned ? 0 : n] = a.gtab[grid_index(a, n)].info;
     }
     double th[PPL], x[PPL], g[PPL], gx[PPL], step[PPL], acc[PPL];
 #pragma unroll

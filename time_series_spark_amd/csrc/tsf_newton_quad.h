@@ -62,7 +62,7 @@ __device__ __forceinline__ void newton_one_quad(const QuadArgs &qa, NewtonQuadLd
     const SeriesTab st = a.stab[n];
     if (lane == 0) {
         a.y_scale[n] = st.y_scale;
-        if (!a.aligned || n == 0) a.grid_out[a.aligned ? 0 : n] = a.gtab[a.aligned ? 0 : n].info;
+        if (!a.aligned || n == 0) a.grid_out[a.aligned ? 0 : n] = a.gtab[grid_index(a, n)].info;
     }
     double th[PPL], x[PPL], g[PPL], gx[PPL], step[PPL];
     th[0] = (lane == 0) ? st.k0 : (lane == 1 ? st.m0 : 0.0);

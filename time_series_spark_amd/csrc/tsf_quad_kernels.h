@@ -48,6 +48,8 @@ struct QuadArgs {
     FitArgs f;
     const double *Mg;                   // aligned: [P4][PPL][64] Gram matrix, column-major over q
     double *Mslot;                      // ragged: [slots][P4][PPL][64], one per resident wave
+    const double *Mpre;                 // ragged, shared grids: [n_pre][P4][PPL][64], one per distinct timestamp vector; or null
+    int64_t n_pre;
     double *rbuf;                       // [slots][NTmax][64] residual scratch
     int *counter;                       // work queue head (zeroed before the launch)
     int P4;                             // P rounded up to a multiple of 4
@@ -647,9 +649,8 @@ __device__ __forceinline__ bool gram_eval_q(const SeriesView &sv, const LaneCons
 
 // lane-id based variants of make_view / store_theta for multi-wave workgroups
 template <int KP, int PPL>
-__device__ __forceinline__ void make_view_q(const FitArgs &a, int64_t n, SeriesView &sv)
+__device__ __forceinline__ void make_view_grid(const FitArgs &a, int64_t g, int64_t n, SeriesView &sv)
 {
-    const int64_t g = a.aligned ? 0 : n;            // ragged panels: one grid per series
     const GridTab &gt = a.gtab[g];
     sv.T = gt.info.T; sv.NT = gt.info.NT; sv.S = gt.S_fit; sv.S_out = gt.info.S;
     sv.P = 3 + sv.S + a.sp->K;
@@ -666,6 +667,13 @@ __device__ __forceinline__ void make_view_q(const FitArgs &a, int64_t n, SeriesV
     sv.tau = a.sp->tau;
     sv.n_eval = 0;
     set_lane_tables<PPL>(a.sp, sv);
+}
+
+template <int KP, int PPL>
+__device__ __forceinline__ void make_view_q(const FitArgs &a, int64_t n, SeriesView &sv)
+{
+    // ragged panels: one grid per series, or per distinct timestamp vector
+    make_view_grid<KP, PPL>(a, grid_index(a, n), n, sv);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -792,6 +800,30 @@ __global__ __launch_bounds__(64) void gram_build_kernel(QuadArgs qa, double *Mou
     for (int s = 0; s < PPL; ++s) out[s * W + lane] = ztr[s];
 }
 
+// Ragged panel whose series share timestamp vectors (FitArgs::grid_of): Z^T Z of grids g0 .. g0 + gridDim.y - 1,
+// one workgroup per (column, grid), into Mpre[g][P4][PPL][64].  The same gram_column as above, so the same bits
+// the fit kernel's own build gives (tests: TSF_GRAM_SHARE=0 against the default).  gridDim.y * P4 <= slots of rbuf.
+template <int KP, int PPL>
+__global__ __launch_bounds__(64) void gram_grids_kernel(QuadArgs qa, double *Mpre, int64_t g0)
+{
+    __shared__ QuadLds<KP, PPL> wl;
+    const int q = blockIdx.x, lane = threadIdx.x;
+    const int64_t g = g0 + blockIdx.y;
+    SeriesView sv;
+    make_view_grid<KP, PPL>(qa.f, g, 0, sv);          // series 0's y is not read: the columns of Z depend on the grid alone
+    double *out = Mpre + ((size_t)g * qa.P4 + q) * PPL * W;
+    if (q == 2 || q >= sv.P) {
+#pragma unroll
+        for (int s = 0; s < PPL; ++s) out[s * W + lane] = 0.0;
+        return;
+    }
+    double *rb = qa.rbuf + ((size_t)blockIdx.y * qa.P4 + q) * qa.f.NTmax * W;
+    double ztr[PPL];
+    gram_column<KP, PPL>(sv, wl, rb, q, ztr);
+#pragma unroll
+    for (int s = 0; s < PPL; ++s) out[s * W + lane] = ztr[s];
+}
+
 // ---------------------------------------------------------------------------------------
 // the fit kernel
 // ---------------------------------------------------------------------------------------
@@ -835,7 +867,7 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
     const SeriesTab st = a.stab[n];
     if (lane == 0) {
         a.y_scale[n] = st.y_scale;
-        if (!a.aligned || n == 0) a.grid_out[a.aligned ? 0 : n] = a.gtab[a.aligned ? 0 : n].info;
+        if (!a.aligned || n == 0) a.grid_out[a.aligned ? 0 : n] = a.gtab[grid_index(a, n)].info;
     }
     double xk[PPL], gk[PPL], pk[PPL], xk1[PPL], gk1[PPL];
 #pragma unroll
@@ -865,7 +897,11 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
     constexpr bool CT = HLDS && !RAGGED && !MREG && PQ > 0 && PPL == 1;
     const double *const ct = lk.ct;
     QT_DECL;
-    if (RAGGED) {
+    if (RAGGED && MRS == W && qa.Mpre) {
+        // ragged panel whose series share timestamp vectors: gram_grids_kernel built the M of this series' grid
+        // (the M-in-LDS kernel, compact rows, keeps building its own: long series, where the build is the smaller part)
+        Mp = qa.Mpre + (size_t)grid_index(a, n) * P4 * PPL * W;
+    } else if (RAGGED) {
         // ragged panel: this series has its own grid, hence its own M = Z^T Z.  The wave builds
         // it column by column into its slot of global memory; lane p writes and later reads only
         // entries of its own row p, so no fence is needed.
@@ -911,7 +947,7 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
     double mreg[(MREG && PQ > 0) ? PQ : 1];
     if constexpr (MREG && PQ > 0) {
         static_assert(!MREG || (MRS == W && PPL == 1), "register M: one-slot kernels");
-        const double *Msrc = RAGGED ? Mown : Mp;        // aligned panels: the call's one matrix
+        const double *Msrc = Mp;                        // aligned panels: the call's one matrix; ragged: just built (Mown) or prebuilt
 #pragma unroll
         for (int q = 0; q < PQ; ++q) mreg[q] = Msrc[(size_t)q * W + lane];
     } else {

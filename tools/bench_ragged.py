@@ -1,6 +1,9 @@
 """Times the fit kernel on a RAGGED panel (every series carries its own timestamps and design
 tables): the cfg2 series with lengths 640..730, linear/additive (quadratic form, per-series
 Z^T Z built in-kernel) and the reference's logistic/multiplicative settings (residual form).
+The panel's 10 000 series share 91 distinct timestamp vectors (lengths 640..730 of one daily calendar), which since
+round 4 share grid tables and one prebuilt Z^T Z per vector: every (model) is timed that way ("grids": "shared", the
+default) and with TSF_GRID_SHARE=0 ("own": a grid per series, what a panel of unrelated calendars costs).
 Host entry point (PCIe copies outside the kernel time, which comes from the library's HIP events)."""
 import ctypes
 import json
@@ -28,13 +31,21 @@ for growth, mode in (('linear', 'additive'), ('logistic', 'multiplicative')):
     ctx = fc.get_context()
     L = _lib.load()
     ms = ctypes.c_float(0.0)
-    out = []
-    for rep in range(3):
-        ctx.check(L.tsf_set_profiling(ctx.handle, 1))
-        r = fc.fit_ragged(spec, off, dsr, yr, floor=np.zeros(N), cap=cap)
-        ctx.check(L.tsf_last_fit_kernel_ms(ctx.handle, ctypes.byref(ms)))
-        out.append(float(ms.value))
-    print(json.dumps({'panel': 'ragged 10000 series, 640..730 rows', 'growth': growth, 'mode': mode, 'residual_kernel': os.environ.get('RK', 'auto'),
-                      'fit_kernel_ms': out, 'series_per_s_kernel': N / (min(out) * 1e-3),
-                      'mean_evals': float(r.n_eval.mean()),
-                      'status_ok': int((r.status > 0).sum())}), flush=True)
+    for grids in ('shared', 'own'):
+        if grids == 'own':
+            os.environ['TSF_GRID_SHARE'] = '0'
+        out, wall = [], []
+        import time
+        for rep in range(3):
+            ctx.check(L.tsf_set_profiling(ctx.handle, 1))
+            t0 = time.perf_counter()
+            r = fc.fit_ragged(spec, off, dsr, yr, floor=np.zeros(N), cap=cap)
+            wall.append((time.perf_counter() - t0) * 1e3)
+            ctx.check(L.tsf_last_fit_kernel_ms(ctx.handle, ctypes.byref(ms)))
+            out.append(float(ms.value))
+        os.environ.pop('TSF_GRID_SHARE', None)
+        print(json.dumps({'panel': 'ragged 10000 series, 640..730 rows, 91 distinct timestamp vectors', 'grids': grids,
+                          'growth': growth, 'mode': mode, 'residual_kernel': os.environ.get('RK', 'auto'),
+                          'fit_kernel_ms': out, 'host_call_ms': wall, 'series_per_s_kernel': N / (min(out) * 1e-3),
+                          'mean_evals': float(r.n_eval.mean()),
+                          'status_ok': int((r.status > 0).sum())}), flush=True)
