@@ -1325,7 +1325,8 @@ def test_reference_contract_fit_and_forecast_udfs(env, tmp_path):
     assert modeler_driver.main(['x']) == 1                      # "arg1 must be the config YAML"
     assert modeler_driver.main(['x', str(tmp_path / 'm.yaml')]) == 0
     assert scorer_driver.main(['x', str(tmp_path / 's.yaml')]) == 0
-    conv = ps.ProphetScorer.score(None, sconfig)
+    assert ps.ProphetScorer.score(None, sconfig) is None        # writes; returns nothing (prophet_scorer.py:152-165)
+    conv = pd.concat([pd.read_csv(f) for f in glob.glob(str(tmp_path / 'forecasts' / '*.csv'))])
     assert len(conv) == 80 and np.array_equal(np.sort(conv['forecast_quantity'].values), np.sort(fdf['yhat'].values))
 
 

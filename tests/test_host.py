@@ -702,6 +702,16 @@ def test_a_rerun_schedules_its_launches_from_the_previous_runs_models(monkeypatc
     assert len(first) == 3 and seen == [None]                        # nothing to learn from yet
     prev = pm.previous_run_cost(cfg['io']['models'])
     assert sorted(prev['cost']) == [100, 110, 120]
+    # persist_models left the counts beside the parquet part (read in place of 10 000 blobs); without the
+    # sidecar, or with a part that is not the one it was written for, the blobs give the same frame
+    side = os.path.join(cfg['io']['models'], pm.COST_SIDECAR)
+    assert os.path.isfile(side)
+    assert list(pd.read_parquet(cfg['io']['models']).columns) == ['series_id', 'dim_id', 'floor', 'cap', 'model']
+    os.rename(side, side + '.away')
+    slow = pm.previous_run_cost(cfg['io']['models'])
+    os.rename(side + '.away', side)
+    for c in ('series_id', 'dim_id', 'cost'):
+        assert np.array_equal(prev[c].to_numpy(), slow[c].to_numpy())
     seen.clear()
     # second run: one series gone, one new
     import shutil

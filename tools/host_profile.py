@@ -27,14 +27,14 @@ def _grid(spec, ds_ns, n=1):
     return g
 
 
-def fake_fit_aligned(spec, ds_ns, y, floor=None, cap=None, extra=None, ctx=None, devices=None):
+def fake_fit_aligned(spec, ds_ns, y, floor=None, cap=None, extra=None, ctx=None, devices=None, cost_hints=None):
     N = y.shape[0]
     return fc.FitResult(spec, np.zeros((N, spec.theta_stride)), np.ones(N), np.zeros(N),
                         np.zeros(N, np.int32), np.ones(N, np.int32), np.ones(N, np.int32),
                         _grid(spec, ds_ns))
 
 
-def fake_fit_ragged(spec, offsets, ds_ns, y, floor=None, cap=None, extra=None, ctx=None, devices=None):
+def fake_fit_ragged(spec, offsets, ds_ns, y, floor=None, cap=None, extra=None, ctx=None, devices=None, cost_hints=None):
     N = len(offsets) - 1
     return fc.FitResult(spec, np.zeros((N, spec.theta_stride)), np.ones(N), np.zeros(N),
                         np.zeros(N, np.int32), np.ones(N, np.int32), np.ones(N, np.int32),
