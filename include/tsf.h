@@ -378,6 +378,10 @@ void tsf_csv_dir_free(tsf_csv_dir *d);
 int tsf_csv_write_forecasts(const char *path, const char *created_timestamp, int64_t n,
                             const int64_t *series_id, const int64_t *dim_id, const int64_t *ds,
                             const int64_t *quantity, int32_t n_threads);
+/* the same sink for int32 id / quantity columns (what the scorer's forecast frame holds: no widening copies) */
+int tsf_csv_write_forecasts_i32(const char *path, const char *created_timestamp, int64_t n,
+                                const int32_t *series_id, const int32_t *dim_id, const int64_t *ds,
+                                const int32_t *quantity, int32_t n_threads);
 
 #ifdef __cplusplus
 }

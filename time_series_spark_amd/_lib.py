@@ -81,7 +81,7 @@ EXPORTS = ['tsf_create', 'tsf_destroy', 'tsf_last_error', 'tsf_device_count', 't
            'tsf_predict', 'tsf_predict_dev', 'tsf_predict_intervals', 'tsf_predict_intervals_dev', 'tsf_eval', 'tsf_eval_quadratic', 'tsf_design', 'tsf_selftest_math',
            'tsf_set_cost_hints', 'tsf_set_profiling', 'tsf_profile_read', 'tsf_last_fit_kernel_ms',
            'tsf_pack_rows', 'tsf_pack_fetch', 'tsf_pack_free',
-           'tsf_csv_read', 'tsf_csv_fetch', 'tsf_csv_columns', 'tsf_csv_malformed', 'tsf_csv_free', 'tsf_csv_write_forecasts',
+           'tsf_csv_read', 'tsf_csv_fetch', 'tsf_csv_columns', 'tsf_csv_malformed', 'tsf_csv_free', 'tsf_csv_write_forecasts', 'tsf_csv_write_forecasts_i32',
            'tsf_csv_discover', 'tsf_csv_dir_paths', 'tsf_csv_dir_series_id', 'tsf_csv_dir_error_path', 'tsf_csv_dir_free']
 
 CSV_E_OPEN, CSV_E_PARSE, CSV_E_CODEC = -10, -11, -12          # TSF_CSV_E_* (include/tsf.h)
@@ -161,6 +161,7 @@ def load():
     L.tsf_csv_free.argtypes = [vp]
     L.tsf_csv_free.restype = None
     L.tsf_csv_write_forecasts.argtypes = [ctypes.c_char_p, ctypes.c_char_p, i64, vp, vp, vp, vp, i32]
+    L.tsf_csv_write_forecasts_i32.argtypes = [ctypes.c_char_p, ctypes.c_char_p, i64, vp, vp, vp, vp, i32]
     if L.tsf_spec_size() != ctypes.sizeof(TsfSpec):
         raise TsfError('tsf_spec layout mismatch between _lib.py and libtsf_amd.so')
     if L.tsf_grid_info_size() != ctypes.sizeof(TsfGridInfo) or GRID_DTYPE.itemsize != ctypes.sizeof(TsfGridInfo):

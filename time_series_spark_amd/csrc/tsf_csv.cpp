@@ -717,6 +717,8 @@ void tsf_csv_dir_free(tsf_csv_dir *d) { delete d; }
 //   created_timestamp,series_id,dim_id,forecast_date,forecast_timestamp,forecast_quantity
 // forecast_date = ds.date() as %Y-%m-%d (:107-108), forecast_timestamp in Spark 2.4's default
 // CSV timestampFormat yyyy-MM-dd'T'HH:mm:ss.SSSXXX with the wall time taken as UTC.
+}  // extern "C"
+
 namespace {
 
 inline void civil_from_days(int64_t z, int64_t *y, unsigned *m, unsigned *d) {
@@ -764,11 +766,11 @@ inline char *put_date(char *p, int64_t days) {
     return put2(p, d);
 }
 
-}  // namespace
-
-int tsf_csv_write_forecasts(const char *path, const char *created_timestamp, int64_t n,
-                            const int64_t *series_id, const int64_t *dim_id, const int64_t *ds,
-                            const int64_t *quantity, int32_t n_threads) {
+// the sink, for id / quantity columns of either width (the scorer's frame holds int32: prophet_scorer.py:73, :99-104)
+template <class I>
+int write_forecasts(const char *path, const char *created_timestamp, int64_t n,
+                    const I *series_id, const I *dim_id, const int64_t *ds,
+                    const I *quantity, int32_t n_threads) {
     if (!path || !created_timestamp || n < 0 || (n > 0 && (!series_id || !dim_id || !ds || !quantity)))
         return -1;
     const size_t clen = std::strlen(created_timestamp);
@@ -856,6 +858,22 @@ int tsf_csv_write_forecasts(const char *path, const char *created_timestamp, int
     }
     if (::close(fd) != 0) ok = false;
     return ok ? 0 : TSF_CSV_E_OPEN;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tsf_csv_write_forecasts(const char *path, const char *created_timestamp, int64_t n,
+                            const int64_t *series_id, const int64_t *dim_id, const int64_t *ds,
+                            const int64_t *quantity, int32_t n_threads) {
+    return write_forecasts<int64_t>(path, created_timestamp, n, series_id, dim_id, ds, quantity, n_threads);
+}
+
+int tsf_csv_write_forecasts_i32(const char *path, const char *created_timestamp, int64_t n,
+                                const int32_t *series_id, const int32_t *dim_id, const int64_t *ds,
+                                const int32_t *quantity, int32_t n_threads) {
+    return write_forecasts<int32_t>(path, created_timestamp, n, series_id, dim_id, ds, quantity, n_threads);
 }
 
 }  // extern "C"

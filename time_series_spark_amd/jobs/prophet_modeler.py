@@ -52,10 +52,12 @@ def _hint_kw(h):
     return {} if h is None else {'cost_hints': h}
 
 
-def previous_run_cost(models):
+def previous_run_cost(models, sidecar_only=False):
     """Expected cost per (series_id, dim_id) from the models of an earlier run: the iteration count stored in every
     model blob.  models: a frame with series_id, dim_id, model columns, or the path of a model parquet directory
-    (what persist_models wrote).  Returns a frame series_id, dim_id, cost -- or None when there is nothing usable.
+    (what persist_models wrote: the counts are then read from the file it leaves beside the parquet part, the blobs
+    only when that file is missing or stale -- and not at all with sidecar_only).  Returns a frame series_id, dim_id,
+    cost -- or None when there is nothing usable.
     A launch ends with its longest fits; nothing cheap about a series predicts them except its previous fit."""
     try:
         if isinstance(models, str):
@@ -65,7 +67,7 @@ def previous_run_cost(models):
             if not parts:
                 return None
             side = _read_cost_sidecar(models, parts)
-            if side is not None:
+            if side is not None or sidecar_only:
                 return side
             models = pd.concat([pd.read_parquet(os.path.join(models, f)) for f in parts], ignore_index=True)
         if models is None or len(models) == 0:
@@ -599,15 +601,17 @@ class ProphetModeler:
         """Create the trained time series models (:127-143).  spark_session is accepted for
         signature compatibility and may be None."""
         scorer = ProphetModeler(config)
-        # A re-run overwrites io.models (:123-125).  With config['model']['schedule_from_previous_models'] (not in the
-        # reference; default false) it first reads what the previous run left there: its models carry their iteration
-        # counts, the one cheap predictor of how long each fit takes, and the launches of this run start their longest
-        # fits first.  Results do not depend on it.  It pays where the fit dominates the run (the reference's model on
-        # 100 000 series: 1.00 -> 0.84 s of fit for ~0.2 s of reading the old models); on a 10 000-series run the
-        # 19 ms it takes to read them are more than the launch gains (tools/e2e_bench.py).
+        # A re-run overwrites io.models (:123-125).  Before it does, what the previous run left there gives this run
+        # its scheduling hints: the iteration count of every model, the one cheap predictor of how long each fit takes,
+        # so that the launches start their longest fits first (the reference's model on 100 000 series: 1.00 -> 0.84 s
+        # of fit; cfg2 on 10 000: 9.1 -> 7.3 ms).  Results do not depend on it.
+        # config['model']['schedule_from_previous_models'] (not in the reference): 'auto' (default) -- only when
+        # persist_models' own side file is there (_tsf_cost.npz, ~1 ms for 10 000 series); true -- else parse the model
+        # blobs (17 ms per 10 000: pays from ~100 000 series of the reference's model on); false -- never.
         previous = None
-        if (config.get('model') or {}).get('schedule_from_previous_models', False):
-            previous = previous_run_cost(config['io']['models'])
+        how = (config.get('model') or {}).get('schedule_from_previous_models', 'auto')
+        if how:
+            previous = previous_run_cost(config['io']['models'], sidecar_only=(how == 'auto'))
         # the columns go from the reader to the packer as arrays; read_input_dataframe gives the
         # same rows as a frame for callers that want one
         model_df = model_arrays(scorer.config, previous=previous)(*scorer.read_input_columns())

@@ -91,12 +91,15 @@ def forecast_panel(config):
             pieces.append((idx, fut, yint, iv))
         if not pieces:
             return _empty_forecasts()
+
+        def cat(parts):                     # one launch (the usual case): its array, not a copy of it
+            return parts[0] if len(parts) == 1 else np.concatenate(parts)
         res = pd.DataFrame({
-            'series_id': np.concatenate([np.repeat(sids[p[0]], periods) for p in pieces]).astype('int32'),
-            'dim_id': np.concatenate([np.repeat(dids[p[0]], periods) for p in pieces]).astype('int32'),
-            'ds': np.concatenate([p[1].reshape(-1) for p in pieces]).astype('datetime64[ns]'),
-            'yhat': np.concatenate([p[2].reshape(-1) for p in pieces]).astype('int32'),
-        }, columns=FORECAST_COLUMNS)
+            'series_id': cat([np.repeat(sids[p[0]].astype('int32'), periods) for p in pieces]),
+            'dim_id': cat([np.repeat(dids[p[0]].astype('int32'), periods) for p in pieces]),
+            'ds': cat([p[1].reshape(-1) for p in pieces]).view('datetime64[ns]'),
+            'yhat': cat([p[2].reshape(-1) for p in pieces]).astype('int32', copy=False),
+        }, columns=FORECAST_COLUMNS, copy=False)     # (copy=True stacks the three int32 columns into one block: a copy of 900 000 x 3)
         if pieces[0][3] is not None:
             res['yhat_lower'] = np.concatenate([p[3][0].reshape(-1) for p in pieces])
             res['yhat_upper'] = np.concatenate([p[3][1].reshape(-1) for p in pieces])
@@ -192,10 +195,15 @@ class ProphetScorer:
         if os.path.isdir(path):
             shutil.rmtree(path)
         os.makedirs(path, exist_ok=True)
-        cols = [np.ascontiguousarray(forecast_df[c].values, dtype=np.int64) for c in ('series_id', 'dim_id')]
-        cols.append(np.ascontiguousarray(forecast_df['ds'].values.astype('datetime64[ns]').astype(np.int64)))
-        cols.append(np.ascontiguousarray(forecast_df['yhat'].values, dtype=np.int64))
-        rc = _lib.load().tsf_csv_write_forecasts(
+        ids = [forecast_df[c].values for c in ('series_id', 'dim_id', 'yhat')]
+        narrow = all(v.dtype == np.int32 for v in ids)          # forecast_panel's frame: the columns go as they are
+        ids = [np.ascontiguousarray(v, dtype=np.int32 if narrow else np.int64) for v in ids]
+        ds = forecast_df['ds'].values
+        ds = np.ascontiguousarray(ds.view(np.int64) if ds.dtype == np.dtype('datetime64[ns]')
+                                  else ds.astype('datetime64[ns]').astype(np.int64))
+        cols = [ids[0], ids[1], ds, ids[2]]
+        L = _lib.load()
+        rc = (L.tsf_csv_write_forecasts_i32 if narrow else L.tsf_csv_write_forecasts)(
             os.fsencode(os.path.join(path, 'part-00000.csv')), created_timestamp.encode(),
             len(forecast_df.index), *[c.ctypes.data for c in cols], 0)
         if rc != 0:

@@ -302,6 +302,24 @@ def load_models(blobs):
     (spec_dict, positions, records) -- one entry per distinct (spec, record shape); positions
     index into `blobs`; records is a structured array (fields as in dump_models).  None
     entries are skipped."""
+    # the usual column -- every series of a run fitted with one spec: all blobs the same length with the same prefix --
+    # is one reshape of the joined bytes instead of a Python loop over the blobs
+    n = len(blobs)
+    if n > 1 and all(type(b) is bytes for b in blobs):
+        L = len(blobs[0])
+        if min(map(len, blobs)) == L == max(map(len, blobs)):
+            pre, body0 = _split(blobs[0])
+            pl = len(pre)
+            arr = np.frombuffer(b''.join(blobs), dtype=np.uint8).reshape(n, L)
+            if L - pl >= _REC_FIXED and (arr[:, :pl] == arr[0, :pl]).all():
+                nth, ntc = struct.unpack_from('<ii', body0, _REC_FIXED - 8)
+                dt = _rec_dtype(nth, ntc)
+                if dt.itemsize != L - pl:
+                    raise ValueError('model blob size does not match its header')
+                rec = np.ascontiguousarray(arr[:, pl:]).view(dt).reshape(n)
+                if (rec['n_theta'] != nth).any() or (rec['n_tchange'] != ntc).any():
+                    raise ValueError('inconsistent model blobs')
+                return [(json.loads(pre[12:].decode()), np.arange(n, dtype=np.int64), rec)]
     buckets = {}
     for i, blob in enumerate(blobs):
         if blob is None:
