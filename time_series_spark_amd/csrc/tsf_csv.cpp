@@ -31,6 +31,7 @@
 #include <limits>
 #include <new>
 #include <string>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -54,15 +55,73 @@ struct SegOut {
 };
 
 // file contents: one uninitialised allocation (a std::vector would zero 170 MB first)
+// Bump allocator of one reader thread: the bytes of the files it reads go side by side into 8 MB chunks on
+// transparent huge pages.  (One malloc per file -- 10 000 x 146 KB, each its own mmap above glibc's threshold -- was
+// 36 000 page faults and 20 000 map / unmap calls contending for the process's mmap lock: 15 ms in a bare process,
+// 39 ms inside the job, whose address space also holds the HIP runtime's mappings.)
+struct Arena {
+    static constexpr size_t CHUNK = (size_t)8 << 20, HUGE = (size_t)2 << 20;
+    std::vector<void *> chunks;
+    char *cur = nullptr;
+    size_t left = 0;
+    Arena() = default;
+    Arena(const Arena &) = delete;
+    Arena &operator=(const Arena &) = delete;
+    ~Arena() { for (void *c : chunks) std::free(c); }
+    // nullptr: too large for a chunk (the caller takes a block of its own), or out of memory
+    char *get(size_t bytes) {
+        bytes = (bytes + 63) & ~(size_t)63;
+        if (bytes > CHUNK / 4) return nullptr;
+        if (bytes > left) {
+            void *c = nullptr;
+            if (posix_memalign(&c, HUGE, CHUNK) != 0) return nullptr;
+            (void)::madvise(c, CHUNK, MADV_HUGEPAGE);
+            chunks.push_back(c);
+            cur = (char *)c; left = CHUNK;
+        }
+        char *r = cur;
+        cur += bytes; left -= bytes;
+        return r;
+    }
+};
+
+// Large blocks go back to the system on a thread of their own: unmapping 146 MB of file bytes took 20-50 ms of the
+// read stage and the 234 MB table 28 ms of whoever dropped it (measured on the GPU box, profiles/r04_host3/) -- time the
+// job spends better packing and fitting.  One reaper at a time: a new hand-over waits for the previous one, and the
+// last is joined at exit.  TSF_CSV_BG_FREE=0: free in place.
+class Reaper {
+    std::mutex mu;
+    std::thread th;
+public:
+    ~Reaper() { if (th.joinable()) th.join(); }
+    static bool enabled() {
+        static const bool on = !(std::getenv("TSF_CSV_BG_FREE") && std::atoi(std::getenv("TSF_CSV_BG_FREE")) == 0);
+        return on;
+    }
+    void give(std::vector<void *> &&blocks) {
+        if (blocks.empty()) return;
+        std::lock_guard<std::mutex> g(mu);
+        if (th.joinable()) th.join();
+        th = std::thread([b = std::move(blocks)]() { for (void *c : b) std::free(c); });
+    }
+};
+Reaper &reaper() { static Reaper r; return r; }
+
 struct FileBuf {
     char *p = nullptr;
     size_t n = 0;
+    bool borrowed = false;          // p belongs to an Arena
     FileBuf() = default;
     FileBuf(const FileBuf &) = delete;
     FileBuf &operator=(const FileBuf &) = delete;
-    ~FileBuf() { std::free(p); }
-    bool alloc(size_t bytes) { std::free(p); p = (char *)std::malloc(bytes ? bytes : 1); n = p ? bytes : 0; return p != nullptr; }
-    void release() { std::free(p); p = nullptr; n = 0; }
+    ~FileBuf() { if (!borrowed) std::free(p); }
+    bool alloc(size_t bytes, Arena *a = nullptr) {
+        release();
+        if (a && bytes > 0 && (p = a->get(bytes)) != nullptr) { borrowed = true; n = bytes; return true; }
+        p = (char *)std::malloc(bytes ? bytes : 1); n = p ? bytes : 0;
+        return p != nullptr;
+    }
+    void release() { if (!borrowed) std::free(p); p = nullptr; n = 0; borrowed = false; }
 };
 
 // days from 1970-01-01 of a proleptic Gregorian date (valid for all int years)
@@ -299,13 +358,13 @@ bool is_deflated(const FileBuf &b) {
 
 // the whole file with one open / fstat / read / close (10 000 part files of a Hive-partitioned input are
 // 40 000 system calls instead of the 70 000 of fopen / fseek / ftell / fread / fclose)
-bool read_whole(const char *path, FileBuf &buf, bool *corrupt) {
+bool read_whole(const char *path, FileBuf &buf, bool *corrupt, Arena *arena = nullptr) {
     *corrupt = false;
     const int fd = ::open(path, O_RDONLY | O_CLOEXEC);
     if (fd < 0) return false;
     struct stat sb;
     if (::fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) { ::close(fd); return false; }
-    if (!buf.alloc((size_t)sb.st_size)) { ::close(fd); throw std::bad_alloc(); }
+    if (!buf.alloc((size_t)sb.st_size, arena)) { ::close(fd); throw std::bad_alloc(); }
     size_t got = 0;
     while (got < buf.n) {
         const ssize_t k = ::read(fd, buf.p + got, buf.n - got);
@@ -345,28 +404,34 @@ struct tsf_csv {
 
 namespace {
 
+// item(i, w): item i on worker w (0 <= w < n_threads)
 template <class F>
-void run_workers(int n_threads, int64_t n_items, std::atomic<int> &oom, F item) {
+void run_workers_w(int n_threads, int64_t n_items, std::atomic<int> &oom, F item) {
     std::atomic<int64_t> next(0);
-    auto worker = [&]() {
+    auto worker = [&](int w) {
         for (;;) {
             int64_t i = next.fetch_add(1);
             if (i >= n_items) break;
             try {
-                item(i);
+                item(i, w);
             } catch (...) {
                 oom.store(1);
             }
         }
     };
     if (n_threads <= 1 || n_items < 2) {
-        worker();
+        worker(0);
         return;
     }
     std::vector<std::thread> th;
     int k = (int64_t)n_threads < n_items ? n_threads : (int)n_items;
-    for (int i = 0; i < k; ++i) th.emplace_back(worker);
+    for (int i = 0; i < k; ++i) th.emplace_back(worker, i);
     for (auto &x : th) x.join();
+}
+
+template <class F>
+void run_workers(int n_threads, int64_t n_items, std::atomic<int> &oom, F item) {
+    run_workers_w(n_threads, n_items, oom, [&](int64_t i, int) { item(i); });
 }
 
 }  // namespace
@@ -406,12 +471,13 @@ int tsf_csv_read(int32_t n_files, const char *const *paths, const int64_t *serie
         const double t_0 = timing ? now() : 0.0;
         double t_read = 0, t_count = 0, t_alloc = 0, t_parse = 0;
         // ---- phase 1: the files into memory (parallel); every thread also counts the lines of its files
+        std::vector<Arena> arenas((size_t)t->n_threads);       // declared before the buffers that borrow from them
         std::vector<FileBuf> bufs_store((size_t)n_files);
         std::vector<FileBuf> &bufs = bufs_store;
         std::vector<char> opened((size_t)n_files, 0);
-        run_workers(t->n_threads, n_files, oom, [&](int64_t i) {
+        run_workers_w(t->n_threads, n_files, oom, [&](int64_t i, int w) {
             bool corrupt = false;
-            opened[(size_t)i] = read_whole(paths[i], bufs[(size_t)i], &corrupt) ? 1 : (corrupt ? 2 : 0);
+            opened[(size_t)i] = read_whole(paths[i], bufs[(size_t)i], &corrupt, &arenas[(size_t)w]) ? 1 : (corrupt ? 2 : 0);
         });
         if (oom.load()) {
             delete t;
@@ -503,6 +569,16 @@ int tsf_csv_read(int32_t n_files, const char *const *paths, const int64_t *serie
             // the file buffers go back in parallel too: 10 000 frees are 20 ms on one thread, 4 ms on the pool
             const double t_a = timing ? now() : 0.0;
             run_workers(t->n_threads, n_files, oom, [&](int64_t i) { bufs[(size_t)i].release(); });
+            if (Reaper::enabled()) {
+                std::vector<void *> all;
+                for (Arena &a : arenas) { all.insert(all.end(), a.chunks.begin(), a.chunks.end()); a.chunks.clear(); }
+                reaper().give(std::move(all));
+            } else {
+                run_workers(t->n_threads, (int64_t)arenas.size(), oom, [&](int64_t i) {
+                    for (void *c : arenas[(size_t)i].chunks) std::free(c);
+                    arenas[(size_t)i].chunks.clear();
+                });
+            }
             if (timing) std::fprintf(stderr, "[csv-timing] releasing the file buffers %.1f ms\n", now() - t_a);
         }
         if (holes) {
@@ -561,7 +637,14 @@ int tsf_csv_fetch(tsf_csv *t, int64_t *series_id, int64_t *dim_id, int64_t *ds, 
     return 0;
 }
 
-void tsf_csv_free(tsf_csv *t) { delete t; }
+void tsf_csv_free(tsf_csv *t) {
+    if (t && t->block && Reaper::enabled()) {
+        std::vector<void *> b{t->block};
+        t->block = nullptr;
+        try { reaper().give(std::move(b)); } catch (...) { std::free(b.empty() ? nullptr : b[0]); }
+    }
+    delete t;
+}
 // ---- input discovery ---------------------------------------------------------------------------
 // What spark.read.csv(path) reads under a directory (prophet_modeler.py:109-114) and how it finds the partition
 // column: every regular file below `root` whose name -- and the name of every directory on the way -- does not
