@@ -82,7 +82,7 @@ EXPORTS = ['tsf_create', 'tsf_destroy', 'tsf_last_error', 'tsf_device_count', 't
            'tsf_set_cost_hints', 'tsf_set_profiling', 'tsf_profile_read', 'tsf_last_fit_kernel_ms',
            'tsf_pack_rows', 'tsf_pack_fetch', 'tsf_pack_free',
            'tsf_csv_read', 'tsf_csv_fetch', 'tsf_csv_columns', 'tsf_csv_malformed', 'tsf_csv_free', 'tsf_csv_write_forecasts', 'tsf_csv_write_forecasts_i32',
-           'tsf_csv_discover', 'tsf_csv_dir_paths', 'tsf_csv_dir_series_id', 'tsf_csv_dir_error_path', 'tsf_csv_dir_free']
+           'tsf_csv_discover', 'tsf_csv_discover_load', 'tsf_csv_read_loaded', 'tsf_csv_dir_paths', 'tsf_csv_dir_series_id', 'tsf_csv_dir_error_path', 'tsf_csv_dir_free']
 
 CSV_E_OPEN, CSV_E_PARSE, CSV_E_CODEC = -10, -11, -12          # TSF_CSV_E_* (include/tsf.h)
 
@@ -148,6 +148,9 @@ def load():
     L.tsf_csv_fetch.argtypes = [vp, vp, vp, vp, vp]
     L.tsf_csv_columns.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp)]
     L.tsf_csv_discover.argtypes = [ctypes.c_char_p, i32, ctypes.POINTER(vp), ctypes.POINTER(i32), ctypes.POINTER(i32)]
+    L.tsf_csv_discover_load.argtypes = L.tsf_csv_discover.argtypes
+    L.tsf_csv_read_loaded.argtypes = [vp, i32, i32, ctypes.c_char_p, i32, ctypes.POINTER(vp), ctypes.POINTER(i64),
+                                      ctypes.POINTER(i32), ctypes.POINTER(i64)]
     L.tsf_csv_dir_paths.argtypes = [vp]
     L.tsf_csv_dir_paths.restype = vp
     L.tsf_csv_dir_series_id.argtypes = [vp]

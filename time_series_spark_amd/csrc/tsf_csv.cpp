@@ -114,6 +114,11 @@ struct FileBuf {
     FileBuf() = default;
     FileBuf(const FileBuf &) = delete;
     FileBuf &operator=(const FileBuf &) = delete;
+    FileBuf(FileBuf &&o) noexcept : p(o.p), n(o.n), borrowed(o.borrowed) { o.p = nullptr; o.n = 0; o.borrowed = false; }
+    FileBuf &operator=(FileBuf &&o) noexcept {
+        if (this != &o) { release(); p = o.p; n = o.n; borrowed = o.borrowed; o.p = nullptr; o.n = 0; o.borrowed = false; }
+        return *this;
+    }
     ~FileBuf() { if (!borrowed) std::free(p); }
     bool alloc(size_t bytes, Arena *a = nullptr) {
         release();
@@ -436,12 +441,12 @@ void run_workers(int n_threads, int64_t n_items, std::atomic<int> &oom, F item) 
 
 }  // namespace
 
-extern "C" {
-
-int tsf_csv_read(int32_t n_files, const char *const *paths, const int64_t *series_id,
-                 const char *layout, int32_t n_threads, tsf_csv **out, int64_t *n_rows,
-                 int32_t *err_file, int64_t *err_line) {
-    if (!out || n_files < 0 || (n_files > 0 && !paths) || !layout) return -1;
+// tsf_csv_read and tsf_csv_read_loaded: `loaded` (or null) holds the bytes of the files already -- one entry per file,
+// `loaded_ok[i]` = 1 read, 2 corrupt compressed stream, 0 could not be read (tsf_csv_discover with preload)
+static int read_impl(int32_t n_files, const char *const *paths, const int64_t *series_id,
+              const char *layout, int32_t n_threads, tsf_csv **out, int64_t *n_rows,
+              int32_t *err_file, int64_t *err_line, FileBuf *loaded, const char *loaded_ok) {
+    if (!out || n_files < 0 || (n_files > 0 && !paths && !loaded) || !layout) return -1;
     *out = nullptr;
     int ncol = (int)std::strlen(layout);
     // a trailing '?' = permissive mode (spark.read.csv's default mode=PERMISSIVE)
@@ -475,10 +480,14 @@ int tsf_csv_read(int32_t n_files, const char *const *paths, const int64_t *serie
         std::vector<FileBuf> bufs_store((size_t)n_files);
         std::vector<FileBuf> &bufs = bufs_store;
         std::vector<char> opened((size_t)n_files, 0);
-        run_workers_w(t->n_threads, n_files, oom, [&](int64_t i, int w) {
-            bool corrupt = false;
-            opened[(size_t)i] = read_whole(paths[i], bufs[(size_t)i], &corrupt, &arenas[(size_t)w]) ? 1 : (corrupt ? 2 : 0);
-        });
+        if (loaded) {
+            for (int32_t i = 0; i < n_files; ++i) { bufs[(size_t)i] = std::move(loaded[i]); opened[(size_t)i] = loaded_ok[i]; }
+        } else {
+            run_workers_w(t->n_threads, n_files, oom, [&](int64_t i, int w) {
+                bool corrupt = false;
+                opened[(size_t)i] = read_whole(paths[i], bufs[(size_t)i], &corrupt, &arenas[(size_t)w]) ? 1 : (corrupt ? 2 : 0);
+            });
+        }
         if (oom.load()) {
             delete t;
             return -2;
@@ -609,6 +618,15 @@ int tsf_csv_read(int32_t n_files, const char *const *paths, const int64_t *serie
     return 0;
 }
 
+extern "C" {
+
+int tsf_csv_read(int32_t n_files, const char *const *paths, const int64_t *series_id,
+                 const char *layout, int32_t n_threads, tsf_csv **out, int64_t *n_rows,
+                 int32_t *err_file, int64_t *err_line) {
+    if (n_files > 0 && !paths) return -1;
+    return read_impl(n_files, paths, series_id, layout, n_threads, out, n_rows, err_file, err_line, nullptr, nullptr);
+}
+
 int64_t tsf_csv_malformed(const tsf_csv *t) { return t ? t->malformed : -1; }
 
 int tsf_csv_columns(tsf_csv *t, const int64_t **series_id, const int64_t **dim_id, const int64_t **ds, const double **y) {
@@ -653,8 +671,16 @@ void tsf_csv_free(tsf_csv *t) {
 // read stage on 10 000 partition directories; here the directories are read by the pool and Python never sees a
 // path unless something is wrong with one.
 struct tsf_csv_dir {
-    struct Item { std::string path; int64_t sid; bool has; };
+    struct Item { std::string path; int64_t sid; bool has; FileBuf buf; char ok = 0; };
     std::vector<Item> items;
+    std::vector<Arena> arenas;      // preload: the bytes of the files, read by the thread that listed their directory
+    bool preloaded = false;
+    ~tsf_csv_dir() {
+        if (!Reaper::enabled()) return;
+        std::vector<void *> all;
+        for (Arena &a : arenas) { all.insert(all.end(), a.chunks.begin(), a.chunks.end()); a.chunks.clear(); }
+        try { reaper().give(std::move(all)); } catch (...) { for (void *c : all) std::free(c); }
+    }
     std::vector<const char *> paths;
     std::vector<int64_t> sids;
     int32_t n_part = 0;
@@ -673,7 +699,7 @@ bool has_suffix(const std::string &s, const char *suf) {
 
 // one directory: files appended to `out`, sub-directories to `dirs`
 void scan_dir(const std::string &d, int64_t sid, bool has, std::vector<tsf_csv_dir::Item> &out,
-              std::vector<tsf_csv_dir::Item> &dirs, int &err, std::string &err_path) {
+              std::vector<tsf_csv_dir::Item> &dirs, int &err, std::string &err_path, Arena *arena) {
     DIR *h = ::opendir(d.c_str());
     if (!h) { err = TSF_CSV_E_OPEN; err_path = d; return; }
     while (struct dirent *e = ::readdir(h)) {
@@ -696,11 +722,17 @@ void scan_dir(const std::string &d, int64_t sid, bool has, std::vector<tsf_csv_d
                 if (end == nm + 10 || *end != '\0' || errno != 0) { err = TSF_CSV_E_PARSE; err_path = p; continue; }
                 v = q; hv = true;
             }
-            dirs.push_back(tsf_csv_dir::Item{std::move(p), v, hv});
+            dirs.push_back(tsf_csv_dir::Item{std::move(p), v, hv, FileBuf(), 0});
         } else if (ty == DT_REG) {
+            bool codec = false;
             for (const char *suf : {".bz2", ".snappy", ".lz4", ".zst", ".xz"})
-                if (has_suffix(p, suf)) { err = TSF_CSV_E_CODEC; err_path = p; }
-            out.push_back(tsf_csv_dir::Item{std::move(p), sid, has});
+                if (has_suffix(p, suf)) { err = TSF_CSV_E_CODEC; err_path = p; codec = true; }
+            tsf_csv_dir::Item it{std::move(p), sid, has, FileBuf(), 0};
+            if (arena && !codec) {      // preload: the listing thread reads the file while its directory entry is warm
+                bool corrupt = false;
+                it.ok = read_whole(it.path.c_str(), it.buf, &corrupt, arena) ? 1 : (corrupt ? 2 : 0);
+            }
+            out.push_back(std::move(it));
         }
     }
     ::closedir(h);
@@ -708,7 +740,8 @@ void scan_dir(const std::string &d, int64_t sid, bool has, std::vector<tsf_csv_d
 
 }  // namespace
 
-int tsf_csv_discover(const char *root, int32_t n_threads, tsf_csv_dir **out, int32_t *n_files, int32_t *n_partitioned) {
+static int discover_impl(const char *root, int32_t n_threads, tsf_csv_dir **out, int32_t *n_files, int32_t *n_partitioned,
+                         bool preload) {
     if (!root || !out) return -1;
     *out = nullptr;
     tsf_csv_dir *d = nullptr;
@@ -719,8 +752,14 @@ int tsf_csv_discover(const char *root, int32_t n_threads, tsf_csv_dir **out, int
     try {
         d = new tsf_csv_dir();
         struct stat sb;
+        d->preloaded = preload;
         if (::stat(root, &sb) == 0 && S_ISREG(sb.st_mode)) {
-            d->items.push_back(tsf_csv_dir::Item{root, 0, false});
+            tsf_csv_dir::Item it{root, 0, false, FileBuf(), 0};
+            if (preload) {
+                bool corrupt = false;
+                it.ok = read_whole(root, it.buf, &corrupt, nullptr) ? 1 : (corrupt ? 2 : 0);
+            }
+            d->items.push_back(std::move(it));
         } else if (::stat(root, &sb) == 0 && S_ISDIR(sb.st_mode)) {
             int hw = (int)std::thread::hardware_concurrency();
             if (hw < 1) hw = 1;
@@ -728,7 +767,9 @@ int tsf_csv_discover(const char *root, int32_t n_threads, tsf_csv_dir **out, int
             std::string r(root);
             while (r.size() > 1 && r.back() == '/') r.pop_back();
             // breadth first: the directories of one level are read by the pool, each thread into its own lists
-            std::vector<tsf_csv_dir::Item> level{tsf_csv_dir::Item{r, 0, false}};
+            std::vector<tsf_csv_dir::Item> level;
+            level.push_back(tsf_csv_dir::Item{r, 0, false, FileBuf(), 0});
+            if (preload) d->arenas = std::vector<Arena>((size_t)nt);
             while (!level.empty()) {
                 const int64_t n = (int64_t)level.size();
                 const int k = (int)std::min<int64_t>(nt, n);
@@ -741,7 +782,7 @@ int tsf_csv_discover(const char *root, int32_t n_threads, tsf_csv_dir **out, int
                         const int64_t i = next.fetch_add(1);
                         if (i >= n) break;
                         scan_dir(level[(size_t)i].path, level[(size_t)i].sid, level[(size_t)i].has, files[(size_t)w], dirs[(size_t)w],
-                                 errs[(size_t)w], eps[(size_t)w]);
+                                 errs[(size_t)w], eps[(size_t)w], preload ? &d->arenas[(size_t)w] : nullptr);
                     }
                 };
                 if (k <= 1) work(0);
@@ -785,6 +826,33 @@ int tsf_csv_discover(const char *root, int32_t n_threads, tsf_csv_dir **out, int
     if (n_files) *n_files = (int32_t)d->items.size();
     if (n_partitioned) *n_partitioned = d->n_part;
     return d->err;
+}
+
+int tsf_csv_discover(const char *root, int32_t n_threads, tsf_csv_dir **out, int32_t *n_files, int32_t *n_partitioned) {
+    return discover_impl(root, n_threads, out, n_files, n_partitioned, false);
+}
+
+int tsf_csv_discover_load(const char *root, int32_t n_threads, tsf_csv_dir **out, int32_t *n_files, int32_t *n_partitioned) {
+    return discover_impl(root, n_threads, out, n_files, n_partitioned, true);
+}
+
+int tsf_csv_read_loaded(tsf_csv_dir *d, int32_t first, int32_t count, const char *layout, int32_t n_threads,
+                        tsf_csv **out, int64_t *n_rows, int32_t *err_file, int64_t *err_line) {
+    if (!d || !d->preloaded || first < 0 || count < 0 || (size_t)first + (size_t)count > d->items.size()) return -1;
+    try {
+        std::vector<FileBuf> bufs((size_t)count);
+        std::vector<char> ok((size_t)count);
+        for (int32_t i = 0; i < count; ++i) {
+            bufs[(size_t)i] = std::move(d->items[(size_t)(first + i)].buf);
+            ok[(size_t)i] = d->items[(size_t)(first + i)].ok;
+            d->items[(size_t)(first + i)].ok = 0;          // a range is handed over once
+        }
+        const int rc = read_impl(count, d->paths.data() + first, d->sids.data() + first, layout, n_threads, out, n_rows,
+                                 err_file, err_line, bufs.data(), ok.data());
+        return rc;                                         // (err_file is relative to `first`)
+    } catch (const std::bad_alloc &) {
+        return -2;
+    }
 }
 
 const char *const *tsf_csv_dir_paths(const tsf_csv_dir *d) { return d ? d->paths.data() : nullptr; }

@@ -436,14 +436,19 @@ class _CsvTable:
         return tuple(out)
 
 
-def _csv_read_call(n, paths_ptr, sids_ptr, layout, n_threads, name_of, stats):
-    """One tsf_csv_read; returns the four columns as views of the native table.  name_of(i): path of file i."""
+def _csv_read_call(n, paths_ptr, sids_ptr, layout, n_threads, name_of, stats, loaded=None):
+    """One tsf_csv_read; returns the four columns as views of the native table.  name_of(i): path of file i.
+    loaded = (dir handle, first): the files were read during the walk (tsf_csv_discover_load)."""
     import ctypes
     L = _lib.load()
     h, n_rows = ctypes.c_void_p(), ctypes.c_int64()
     ef, el = ctypes.c_int32(-1), ctypes.c_int64(0)
-    rc = L.tsf_csv_read(n, paths_ptr, sids_ptr, layout, int(n_threads), ctypes.byref(h),
-                        ctypes.byref(n_rows), ctypes.byref(ef), ctypes.byref(el))
+    if loaded is not None:
+        rc = L.tsf_csv_read_loaded(loaded[0], int(loaded[1]), n, layout, int(n_threads), ctypes.byref(h),
+                                   ctypes.byref(n_rows), ctypes.byref(ef), ctypes.byref(el))
+    else:
+        rc = L.tsf_csv_read(n, paths_ptr, sids_ptr, layout, int(n_threads), ctypes.byref(h),
+                            ctypes.byref(n_rows), ctypes.byref(ef), ctypes.byref(el))
     if rc == _lib.CSV_E_OPEN:
         raise OSError(('corrupt or truncated compressed stream in %s' if el.value == -1 else 'cannot read %s')
                       % name_of(ef.value))
@@ -513,7 +518,8 @@ def read_model_input_dir(root, n_threads=0, mode='FAILFAST', stats=None):
     L = _lib.load()
     lay_part, lay_all = _layouts(mode)
     d, n, n_part = ctypes.c_void_p(), ctypes.c_int32(), ctypes.c_int32()
-    rc = L.tsf_csv_discover(os.fsencode(root), int(n_threads), ctypes.byref(d), ctypes.byref(n), ctypes.byref(n_part))
+    # (the thread that lists a directory reads its files at once: tsf_csv_discover_load)
+    rc = L.tsf_csv_discover_load(os.fsencode(root), int(n_threads), ctypes.byref(d), ctypes.byref(n), ctypes.byref(n_part))
     try:
         if rc in (_lib.CSV_E_OPEN, _lib.CSV_E_PARSE, _lib.CSV_E_CODEC):
             bad = os.fsdecode(L.tsf_csv_dir_error_path(d))
@@ -534,7 +540,7 @@ def read_model_input_dir(root, n_threads=0, mode='FAILFAST', stats=None):
         for layout, lo, hi in ((lay_part, 0, n_part.value), (lay_all, n_part.value, n.value)):
             if hi > lo:
                 out.append(_csv_read_call(hi - lo, paths + 8 * lo, sids + 8 * lo, layout, n_threads,
-                                          lambda i, lo=lo: os.fsdecode(pp[lo + i]), stats))
+                                          lambda i, lo=lo: os.fsdecode(pp[lo + i]), stats, loaded=(d, lo)))
     finally:
         if d:
             L.tsf_csv_dir_free(d)
