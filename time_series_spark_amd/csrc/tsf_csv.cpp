@@ -31,6 +31,7 @@
 #include <limits>
 #include <new>
 #include <string>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -86,26 +87,30 @@ struct Arena {
 };
 
 // Large blocks go back to the system on a thread of their own: unmapping 146 MB of file bytes took 20-50 ms of the
-// read stage and the 234 MB table 28 ms of whoever dropped it (measured on the GPU box, profiles/r04_host3/) -- time the
-// job spends better packing and fitting.  One reaper at a time: a new hand-over waits for the previous one, and the
-// last is joined at exit.  TSF_CSV_BG_FREE=0: free in place.
-class Reaper {
-    std::mutex mu;
-    std::thread th;
-public:
-    ~Reaper() { if (th.joinable()) th.join(); }
+// read stage and the 234 MB table 28 ms of whoever dropped it (measured on the GPU box, profiles/r04_host4/) -- time the
+// job spends better packing and fitting.  The thread is detached and touches nothing but its own list of blocks (no
+// object to outlive, nothing to join at exit or to inherit across a fork).  TSF_CSV_BG_FREE=0: free in place.
+struct Reaper {
     static bool enabled() {
         static const bool on = !(std::getenv("TSF_CSV_BG_FREE") && std::atoi(std::getenv("TSF_CSV_BG_FREE")) == 0);
         return on;
     }
-    void give(std::vector<void *> &&blocks) {
+    static void give(std::vector<void *> &&blocks) noexcept {
         if (blocks.empty()) return;
-        std::lock_guard<std::mutex> g(mu);
-        if (th.joinable()) th.join();
-        th = std::thread([b = std::move(blocks)]() { for (void *c : b) std::free(c); });
+        std::shared_ptr<std::vector<void *>> held;
+        try {
+            held = std::make_shared<std::vector<void *>>(std::move(blocks));
+        } catch (...) {                     // (blocks is untouched when make_shared throws)
+            for (void *c : blocks) std::free(c);
+            return;
+        }
+        try {
+            std::thread([held]() { for (void *c : *held) std::free(c); }).detach();
+        } catch (...) {                     // no thread to be had: in place
+            for (void *c : *held) std::free(c);
+        }
     }
 };
-Reaper &reaper() { static Reaper r; return r; }
 
 struct FileBuf {
     char *p = nullptr;
@@ -581,7 +586,7 @@ static int read_impl(int32_t n_files, const char *const *paths, const int64_t *s
             if (Reaper::enabled()) {
                 std::vector<void *> all;
                 for (Arena &a : arenas) { all.insert(all.end(), a.chunks.begin(), a.chunks.end()); a.chunks.clear(); }
-                reaper().give(std::move(all));
+                Reaper::give(std::move(all));
             } else {
                 run_workers(t->n_threads, (int64_t)arenas.size(), oom, [&](int64_t i) {
                     for (void *c : arenas[(size_t)i].chunks) std::free(c);
@@ -659,7 +664,7 @@ void tsf_csv_free(tsf_csv *t) {
     if (t && t->block && Reaper::enabled()) {
         std::vector<void *> b{t->block};
         t->block = nullptr;
-        try { reaper().give(std::move(b)); } catch (...) { std::free(b.empty() ? nullptr : b[0]); }
+        Reaper::give(std::move(b));
     }
     delete t;
 }
@@ -679,7 +684,7 @@ struct tsf_csv_dir {
         if (!Reaper::enabled()) return;
         std::vector<void *> all;
         for (Arena &a : arenas) { all.insert(all.end(), a.chunks.begin(), a.chunks.end()); a.chunks.clear(); }
-        try { reaper().give(std::move(all)); } catch (...) { for (void *c : all) std::free(c); }
+        Reaper::give(std::move(all));
     }
     std::vector<const char *> paths;
     std::vector<int64_t> sids;
