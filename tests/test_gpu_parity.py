@@ -519,6 +519,71 @@ def test_ragged_series_with_equal_timestamps_share_grid_tables(env):
                 assert n_bit_diff(r.theta[n][:P], o['theta']) == 0 and n_bit_diff(r.fval[n], o['f']) == 0, (growth, mode, n)
 
 
+def test_sparse_indicator_columns_equal_dense_columns(env):
+    """Models with more than 28 design columns whose columns from the 29th on are 0 / 1 indicators (holidays) run the
+    28-column kernel with those columns in sparse form (eval_fg<..., SPARSE>: the ones of a lane's rows as entry words,
+    the per-column sums folded in the reduction network's order from a few LDS slots) -- adding a zero is exact, so
+    not a bit may differ from the dense 64-column kernel (TSF_SPARSE_EXTRA=0) or from the oracle: BASELINE cfg4's
+    model (logistic, multiplicative), its additive twin in residual form, a ragged call, stragglers included; and
+    the cases the analysis kernel must REFUSE (a holiday value of 2, nine holidays inside one lane's rows, an
+    indicator column that is mostly ones) fall back to the dense kernel with the same bits as before."""
+    import os
+    fc, cl = env
+    from time_series_spark_amd import synth
+
+    def both(spec, call):
+        out = {}
+        for tag in ('sparse', 'dense'):
+            if tag == 'dense':
+                os.environ['TSF_SPARSE_EXTRA'] = '0'
+            try:
+                out[tag] = call()
+            finally:
+                os.environ.pop('TSF_SPARSE_EXTRA', None)
+        for name in ('theta', 'fval', 'n_iter', 'n_eval', 'status', 'y_scale'):
+            assert np.array_equal(getattr(out['sparse'], name), getattr(out['dense'], name), equal_nan=True), name
+        return out['sparse']
+
+    for case in ('cfg4_holidays', 'linear_additive_holidays@resid'):
+        spec, ds, y, floor, cap, extra, fut, exf = helpers.make_case(case, N=48, seed=5)
+        r = both(spec, lambda: fc.fit_aligned(spec, ds, y, floor=floor, cap=cap, extra=extra))
+        assert (r.status > 0).sum() >= 40
+        csp = helpers.oracle_spec(spec)
+        order = np.argsort(r.n_eval)
+        for n in list(order[-2:]) + [0, 17]:
+            o = cl.fit(csp, ds, y[n], floor[n], cap[n], extra)
+            assert (r.n_iter[n], r.n_eval[n], r.status[n]) == (o['n_iter'], o['n_eval'], o['status']), (case, n)
+            P = len(o['theta'])
+            assert n_bit_diff(r.theta[n][:P], o['theta']) == 0 and n_bit_diff(r.fval[n], o['f']) == 0, (case, n)
+        # ragged: truncated histories, explicit columns per row
+        T = len(ds)
+        cut = np.array([T - 13 * (i % 7) for i in range(len(y))])
+        off = np.concatenate([[0], np.cumsum(cut)]).astype(np.int64)
+        dsr = np.concatenate([ds[:c] for c in cut])
+        yr = np.concatenate([y[i][:c] for i, c in enumerate(cut)])
+        exr = np.concatenate([extra[:, :c] for c in cut], axis=1)
+        rr = both(spec, lambda: fc.fit_ragged(spec, off, dsr, yr, floor=floor, cap=cap, extra=exr))
+        for n in (0, 7):                 # full-length members of the ragged call = the aligned fit
+            assert np.array_equal(rr.theta[n], r.theta[n]) and rr.n_eval[n] == r.n_eval[n], (case, n)
+    # refused by the analysis kernel: same results through the dense kernel
+    spec, ds, y, floor, cap, extra, fut, exf = helpers.make_case('cfg4_holidays', N=6, seed=6)
+    csp = helpers.oracle_spec(spec)
+    for what in ('value 2', 'nine in one lane', 'dense column'):
+        ex = extra.copy()
+        if what == 'value 2':
+            ex[3, np.flatnonzero(ex[3])[0]] = 2.0
+        elif what == 'nine in one lane':
+            ex[:, :] = 0.0
+            for j in range(9):
+                ex[2 + j, 24 + j] = 1.0          # rows 24..32 lie in lane 2's twelve rows (T = 730: 12 rows per lane)
+        else:
+            ex[5, ::2] = 1.0
+        r = both(spec, lambda: fc.fit_aligned(spec, ds, y, floor=floor, cap=cap, extra=ex))
+        o = cl.fit(csp, ds, y[1], floor[1], cap[1], ex)
+        assert (r.n_iter[1], r.n_eval[1], r.status[1]) == (o['n_iter'], o['n_eval'], o['status']), what
+        assert n_bit_diff(r.theta[1][:len(o['theta'])], o['theta']) == 0, what
+
+
 def test_one_host_thread_per_device_gives_identical_bits(env, monkeypatch):
     """SURVEY 8e, in-process arrangement: a call cut into blocks of series, one tsf_ctx + host
     thread per device (here: three contexts on the one GPU the box has), equals the

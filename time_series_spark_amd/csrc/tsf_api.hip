@@ -221,7 +221,7 @@ static int build_devspec(tsf_ctx *ctx, const tsf_spec *s, DevSpec *d, int *mode_
 // ---- workspace ------------------------------------------------------------------------------
 
 struct WsLayout {
-    size_t gtab, stab, tw, cw, Xw, yw, Mg, Mslot, rbuf, counter, uw, Xu;
+    size_t gtab, stab, tw, cw, Xw, yw, Mg, Mslot, rbuf, counter, uw, Xu, spm, spp;
     size_t mXF, mXB, mXT, mtq, mcq, mcpof, myq, mhist;      // matrix-core path (tsf_mfma_kernels.h)
     size_t clist, cslots;                                   // cooperative tail (tsf_coop_kernels.h)
     size_t total;
@@ -248,7 +248,8 @@ static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 static WsLayout ws_layout(int64_t N, int64_t n_grids, int NTmax, int KP, int quad_P4 = 0,
                           int quad_slots = 0, int quad_ragged = 0, int64_t lat_U = 0,
-                          const MfmaPlan *mp = nullptr, int coop_slots = 0, int coop_stride = 0, int64_t quad_pre = 0)
+                          const MfmaPlan *mp = nullptr, int coop_slots = 0, int coop_stride = 0, int64_t quad_pre = 0,
+                          bool sparse = false)
 {
     WsLayout l;
     size_t off = 0;
@@ -265,6 +266,9 @@ static WsLayout ws_layout(int64_t N, int64_t n_grids, int NTmax, int KP, int qua
     l.Mslot = off; off = align_up(off + (quad_ragged ? sizeof(double) * (size_t)quad_slots * quad_P4 * 2 * W : 0));
     l.rbuf = off; off = align_up(off + sizeof(double) * (size_t)quad_slots * NTmax * W);
     l.counter = off; off = align_up(off + 256);
+    // sparse indicator columns (SP_* in tsf_fit_kernels.h): the lanes' entries and the columns' fold programs per grid
+    l.spm = off; off = align_up(off + (sparse ? sizeof(uint32_t) * (size_t)n_grids * SP_M * W : 0));
+    l.spp = off; off = align_up(off + (sparse ? sizeof(unsigned long long) * (size_t)n_grids * SP_MAXC : 0));
     l.uw = off; off = align_up(off + (lat_U > 0 ? sizeof(int32_t) * (size_t)n_grids * NTmax * W : 0));
     l.Xu = off; off = align_up(off + (lat_U > 0 ? sizeof(double) * (size_t)lat_U * KP : 0));
     const bool mf = mp && mp->on;
@@ -482,8 +486,15 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     // instead of once per series inside the fit kernel -- when that at least halves the builds (TSF_GRAM_SHARE=0: never)
     const char *egs = getenv("TSF_GRAM_SHARE");
     const int64_t quad_pre = (quad && !aligned && grid_of && n_grids * 2 <= N && !(egs && atoi(egs) == 0)) ? n_grids : 0;
+    // Wide models (64-column tables) whose columns from the 29th on are explicit columns -- holidays: 0 / 1 indicators,
+    // almost all 0 -- are tried on the sparse-column form of the 28-column kernel (eval_fg<..., SPARSE>, tsf_fit_kernels.h):
+    // sparse_extra_kernel decides on the device whether every grid qualifies, the dense kernel is launched behind it
+    // with the opposite guard.  TSF_SPARSE_EXTRA=0: never.
+    const char *esp = getenv("TSF_SPARSE_EXTRA");
+    const bool sparse_try = !quad && !newton && !mp.on && theta_in == nullptr && lat_U == 0 && hs.KP == 64 && mode != 2 &&
+                            hs.K > SP_DENSE && hs.K - hs.n_extra <= SP_DENSE && NTmax <= 12 && !(esp && atoi(esp) == 0);
     const WsLayout l = ws_layout(N, n_grids, NTmax, hs.KP, qp.P4, qp.slots, (quad || newton_quad) && !aligned, lat_U, &mp,
-                                 coop_slots, coop_stride, quad_pre);
+                                 coop_slots, coop_stride, quad_pre, sparse_try);
     rc = ensure_ws(ctx, l.total, N, NTmax, !aligned);
     if (rc) return rc;
     char *ws = (char *)ctx->ws;
@@ -510,6 +521,13 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
                        aligned ? (int64_t)T : total_rows, NTmax, gtab, tw, cw, Xw,
                        (int32_t *)(ws + l.uw), lat_base, lat_U > 0 ? lat_step : (int64_t)0, grid_rows);
     HIP_TRY(ctx, hipGetLastError());
+    if (sparse_try) {
+        int *sp_bad = (int *)(ws + l.counter) + 8;
+        HIP_TRY(ctx, hipMemsetAsync(sp_bad, 0, sizeof(int), st));
+        hipLaunchKernelGGL(sparse_extra_kernel, dim3((unsigned)n_grids), dim3(64), 0, st, ctx->d_spec, gtab, Xw, NTmax,
+                           (uint32_t *)(ws + l.spm), (unsigned long long *)(ws + l.spp), sp_bad);
+        HIP_TRY(ctx, hipGetLastError());
+    }
     hipLaunchKernelGGL(setup_series_kernel, dim3((unsigned)N), dim3(64), 0, st, ctx->d_spec, N,
                        aligned ? nullptr : offsets, T, ds, y, y_dtype, floor_, cap, NTmax, gtab,
                        aligned, stab, yw, grid_of);
@@ -531,6 +549,10 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     a.theta_in = theta_in; a.grad_out = grad_out;
     a.uw = (const int32_t *)(ws + l.uw); a.Xu = (const double *)(ws + l.Xu); a.xidx = lat_U > 0 ? 1 : 0;
     a.grid_of = grid_of;
+    if (sparse_try) {
+        a.sp_meta = (const uint32_t *)(ws + l.spm); a.sp_prog = (const unsigned long long *)(ws + l.spp);
+        a.sp_flag = (int *)(ws + l.counter) + 8;
+    }
     // scheduling hints of tsf_set_cost_hints: for this call if they were given for this many series; used once
     const int order_buf = (ctx->order_n == N && !theta_in) ? (ctx->order_next ^ 1) : -1;
     if (order_buf >= 0) a.order = ctx->order_dev[order_buf];

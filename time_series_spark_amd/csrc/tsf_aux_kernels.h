@@ -10,6 +10,97 @@ namespace tsf {
 // setup kernels
 // ---------------------------------------------------------------------------------------
 
+// Sparse indicator columns of a 64-column design table (SP_* in tsf_fit_kernels.h; included before this file by
+// tsf_api.hip).  One workgroup of 64 per grid, lane = chunk as in the fit kernels.  Writes the lanes' entry words
+// meta[grid][SP_M][64] and the columns' fold programs prog[grid][SP_MAXC]; sets *bad if the grid does not qualify.
+__global__ __launch_bounds__(64) void sparse_extra_kernel(const DevSpec *__restrict__ sp, const GridTab *__restrict__ gtab,
+                                                          const double *__restrict__ Xw_all, int NTmax,
+                                                          uint32_t *__restrict__ meta_all, unsigned long long *__restrict__ prog_all,
+                                                          int *__restrict__ bad)
+{
+    const int g = blockIdx.x, lane = threadIdx.x;
+    __shared__ unsigned long long mask[SP_MAXC];
+    const int Ks = sp->K - SP_DENSE;
+    const GridTab &gt = gtab[g];
+    const int NT = gt.info.NT, T = gt.info.T;
+    const double *X = Xw_all + (size_t)g * NTmax * 64 * W;
+    uint32_t *meta = meta_all + (size_t)g * SP_M * W;
+    unsigned long long *prog = prog_all + (size_t)g * SP_MAXC;
+    bool ok = Ks > 0 && Ks <= SP_MAXC && NT <= 16 && sp->KP == 64;
+    if (lane < SP_MAXC) mask[lane] = 0ull;
+    for (int e = 0; e < SP_M; ++e) meta[e * W + lane] = 0u;
+    __syncthreads();
+    int rows = T - lane * NT;
+    rows = rows < 0 ? 0 : (rows > NT ? NT : rows);
+    int ne = 0;
+    unsigned long long seen = 0ull;
+    // rows ascending, columns ascending inside a row: the ones of a row then stand in the order of its fma chain
+    for (int q = 0; q < rows && ok; ++q) {
+        for (int c = 0; c < Ks; ++c) {
+            const double v = X[((size_t)q * 64 + SP_DENSE + c) * W + lane];
+            if (v == 0.0) continue;
+            if (v != 1.0 || ((seen >> c) & 1ull) || ne == SP_M) { ok = false; break; }
+            seen |= 1ull << c;
+            meta[ne * W + lane] = (unsigned)q | ((unsigned)c << 4);
+            ++ne;
+            atomicOr(&mask[c], 1ull << lane);
+        }
+    }
+    ok = __syncthreads_and(ok ? 1 : 0) != 0;
+    if (ok && lane < Ks && __popcll(mask[lane]) > SP_E) ok = false;
+    ok = __syncthreads_and(ok ? 1 : 0) != 0;
+    if (!ok) {
+        if (lane == 0) atomicExch(bad, 1);
+        return;
+    }
+    // the slot of every entry: column * SP_E + rank of this lane among the column's lanes
+    for (int e = 0; e < ne; ++e) {
+        const unsigned m = meta[e * W + lane];
+        const int c = (int)((m >> 4) & 63u);
+        const int rank = __popcll(mask[c] & ((1ull << lane) - 1ull));
+        meta[e * W + lane] = m | ((unsigned)(c * SP_E + rank) << 10) | 0x80000000u;
+    }
+    // the fold program of column `lane`: the nodes are the column's lanes (slot = rank); the reduction network of
+    // column_sums pairs lanes that differ in bit 5, then 4, 0, 1, 2, 3 -- two nodes merge at the stage after which they
+    // agree on every bit not yet used
+    if (lane < SP_MAXC) {
+        unsigned long long pg = 0ull;
+        if (lane < Ks) {
+            const unsigned long long mk = mask[lane];
+            const int k = __popcll(mk);
+            int L[SP_E];
+            bool alive[SP_E];
+            {
+                unsigned long long r = mk;
+                for (int i = 0; i < SP_E; ++i) {
+                    alive[i] = i < k;
+                    L[i] = 0;
+                    if (i < k) { L[i] = __ffsll((long long)r) - 1; r &= r - 1ull; }
+                }
+            }
+            int nm = 0;
+            unsigned used = 0u;
+            const int order[6] = {5, 4, 0, 1, 2, 3};
+            for (int s = 0; s < 6; ++s) {
+                used |= 1u << order[s];
+                for (int i = 0; i < SP_E; ++i) {
+                    if (!alive[i]) continue;
+                    for (int j = i + 1; j < SP_E; ++j) {
+                        if (!alive[j]) continue;
+                        if (((unsigned)L[i] & ~used) == ((unsigned)L[j] & ~used)) {
+                            pg |= ((unsigned long long)i | ((unsigned long long)j << 3)) << (10 + 6 * nm);
+                            ++nm;
+                            alive[j] = false;
+                        }
+                    }
+                }
+            }
+            pg |= (unsigned long long)nm | (0ull << 3) | ((unsigned long long)k << 6);
+        }
+        prog[lane] = pg;
+    }
+}
+
 // One block per grid.  Derives scaled time, changepoints, segment indices and the design
 // matrix (fbprophet setup_dataframe / set_changepoints / make_all_seasonality_features).
 // Xw must be zero-filled by the caller (padding columns / rows).

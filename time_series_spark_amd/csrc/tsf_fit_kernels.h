@@ -12,6 +12,9 @@ namespace tsf {
 
 struct SeriesView {
     int T, NT, S, P, cnt;               // cnt: valid rows of this lane's chunk
+    unsigned sp_m[SP_M];                // (SPARSE kernels) this lane's ones
+    unsigned long long sp_prog;         // (SPARSE kernels) lane c: the fold program of sparse column c
+    double *sp_acc;                     // (SPARSE kernels) [SP_MAXC][SP_E] slots in LDS
     int S_out;                          // changepoints in the caller's layout (S = 1 > S_out = 0: dummy changepoint)
     const double *tw, *yw, *Xw;         // step-major tables
     const int32_t *uw;                  // (lattice panels) row -> row of the shared table Xu, step-major
@@ -67,7 +70,7 @@ struct WaveLds {
     double SY[2 * MAXH * PPL * W];
 };
 template <int KP, int PPL>
-inline size_t wave_lds_bytes(int history)
+__host__ __device__ inline size_t wave_lds_bytes(int history)
 {
     const int H = history > MAXH ? MAXH : (history < 1 ? 1 : history);
     using WL = WaveLds<KP, PPL>;
@@ -342,7 +345,7 @@ __device__ __forceinline__ bool eval_tail(const DevSpec *__restrict__ sp, const 
 // With all 64 accumulators live the kernel needs 379 registers (one wave per SIMD, design values through AGPRs);
 // grouped it runs at two.  Column by column the fma chain (rows q descending) and the reduction network are those
 // of the ungrouped form: same bits.
-template <int KP, int GROWTH, int MODE, int PPL, bool XIDX = false, class L = WaveLds<KP, PPL>, int GNTR = 0>
+template <int KP, int GROWTH, int MODE, int PPL, bool XIDX = false, class L = WaveLds<KP, PPL>, int GNTR = 0, bool SPARSE = false>
 __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesView &sv,
                                         L &lds, const double (&th)[PPL],
                                         double &f_out, double (&g)[PPL] FT_ARGS)
@@ -355,11 +358,13 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
 #define TSF_FIT_HOLD_MAX 32     // (dev: -DTSF_FIT_HOLD_MAX=0 streams every design row twice instead of holding it)
 #endif
     constexpr bool HOLD = KP <= TSF_FIT_HOLD_MAX;
+    static_assert(!SPARSE || (KP == SP_DENSE && HOLD && !XIDX && GNTR == 0 && MODE != 2), "sparse columns: the 28-column row in registers, one column mode");
+    constexpr int XCOLS = SPARSE ? 64 : KP;     // columns per row of the design table
     sv.n_eval++;
     const double k = theta_at<PPL>(th, 0), m = theta_at<PPL>(th, 1), ls = theta_at<PPL>(th, 2);
     const double sigma = dm_exp_sel(ls);
     const double inv_s2 = 1.0 / (sigma * sigma);
-    if (!HOLD) {
+    if (!HOLD || SPARSE) {
 #pragma unroll
         for (int s = 0; s < PPL; ++s) lds.th[lane + s * W] = th[s];
     }
@@ -390,7 +395,7 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
             const double ti = sv.tw[idx];
             const double yi = sv.yw[idx];
             constexpr int XS = XIDX ? 1 : W;      // stride between the columns of a design row
-            const double *xp = XIDX ? sv.Xu + (size_t)sv.uw[idx] * KP : sv.Xw + (size_t)q * KP * W + lane;
+            const double *xp = XIDX ? sv.Xu + (size_t)sv.uw[idx] * KP : sv.Xw + (size_t)q * XCOLS * W + lane;
             double x[HOLD ? KP : 1];
             double xa = 0.0, xm = 0.0;
             if (HOLD) {
@@ -419,6 +424,17 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
                     if (MODE == 0) xa = __builtin_fma(xv, bv, xa);
                     else if (MODE == 1) xm = __builtin_fma(xv, bv, xm);
                     else { if (j < Ka) xa = __builtin_fma(xv, bv, xa); else xm = __builtin_fma(xv, bv, xm); }
+                }
+            }
+            if constexpr (SPARSE) {
+                // the ones of this row, ascending column: fma(1, b, chain) = chain + b
+#pragma unroll
+                for (int e = 0; e < SP_M; ++e) {
+                    const unsigned m = sv.sp_m[e];
+                    if ((m >> 31) && (int)(m & 15u) == q) {
+                        const double bv = lds.th[3 + S + SP_DENSE + (int)((m >> 4) & 63u)];
+                        if (MODE == 0) xa = xa + bv; else xm = xm + bv;
+                    }
                 }
             }
             const double ksc = lds.ks[c], mcc = lds.mc[c];
@@ -458,6 +474,14 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
                 }
                 if (!HOLD) __builtin_amdgcn_sched_barrier(0);
             }
+            }
+            if constexpr (SPARSE) {
+                // fma(1, w, +0) = w: the lane's partial of that column (a column comes once per lane)
+#pragma unroll
+                for (int e = 0; e < SP_M; ++e) {
+                    const unsigned m = sv.sp_m[e];
+                    if ((m >> 31) && (int)(m & 15u) == q) sv.sp_acc[(m >> 10) & 511u] = (MODE == 0) ? r : rg;
+                }
             }
             double v = r * opm;
             if (GROWTH == 1) v = v * qv;
@@ -501,6 +525,21 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
         }
     } else {
         column_sums<KP, PPL, L>(acc, lds);
+    }
+    if constexpr (SPARSE) {
+        // the sparse columns' sums: lane c folds the slots of column c in the reduction network's order; a sum that
+        // met only zeros in the dense network has been added to +0 there (-0 + 0 = +0): the final + 0.0
+        TSF_WAVE_SYNC();
+        if (lane < sv.P - 3 - S - SP_DENSE) {
+            const unsigned long long pg = sv.sp_prog;
+            const int nm = (int)(pg & 7u), root = (int)((pg >> 3) & 7u), kl = (int)((pg >> 6) & 15u);
+            double *w = sv.sp_acc + lane * SP_E;
+            for (int i = 0; i < nm; ++i) {
+                const int d = (int)((pg >> (10 + 6 * i)) & 7u), r2 = (int)((pg >> (13 + 6 * i)) & 7u);
+                w[d] = w[d] + w[r2];
+            }
+            lds.accR[SP_DENSE + lane] = (kl > 0 ? w[root] : 0.0) + 0.0;
+        }
     }
     TSF_WAVE_SYNC();
     FT_LAP(3);
@@ -623,6 +662,12 @@ struct FitArgs {
     // one grid per series (grid n).  Found on the host by tsf_fit_ragged (identical vectors only, models without
     // explicit columns); the tables of a grid are then built once and shared, as on an aligned panel.
     const int32_t *grid_of;
+    // sparse indicator columns (SP_* above): per grid the lanes' ones [grid][SP_M][64] and the columns' fold programs
+    // [grid][SP_MAXC]; sp_flag: cleared by sparse_extra_kernel when a grid does not qualify (fit_kernel<..., SPARSE> is
+    // launched with run_flag = sp_flag, run_if = 1, the dense kernel behind it with run_if = 0)
+    const uint32_t *sp_meta;
+    const unsigned long long *sp_prog;
+    int *sp_flag;
 };
 
 __device__ __forceinline__ int64_t grid_index(const FitArgs &a, int64_t n)
@@ -768,11 +813,13 @@ __global__ __launch_bounds__(64) void eval_kernel(FitArgs a)
 #ifndef TSF_FIT_WPS
 #define TSF_FIT_WPS 1
 #endif
-template <int KP, int GROWTH, int MODE, int PPL, bool XIDX = false, int GNTR = 0>
-__global__ __launch_bounds__(64, GNTR > 0 ? 2 : TSF_FIT_WPS) void fit_kernel(FitArgs a)
+template <int KP, int GROWTH, int MODE, int PPL, bool XIDX = false, int GNTR = 0, bool SPARSE = false>
+__global__ __launch_bounds__(64, (GNTR > 0 || SPARSE) ? 2 : TSF_FIT_WPS) void fit_kernel(FitArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    WaveLds<KP, PPL> &lds = *reinterpret_cast<WaveLds<KP, PPL> *>(smem);
+    constexpr int KL = SPARSE ? 64 : KP;            // SPARSE: tables and LDS of the 64-column model, registers of the 28-column one
+    using WL = WaveLds<KL, PPL>;
+    WL &lds = *reinterpret_cast<WL *>(smem);
     if ((int64_t)blockIdx.x >= a.N) return;
     const int64_t n = a.order ? (int64_t)a.order[blockIdx.x] : (int64_t)blockIdx.x;
     if (a.run_flag && (*a.run_flag != 0) != (a.run_if != 0)) return;
@@ -782,7 +829,14 @@ __global__ __launch_bounds__(64, GNTR > 0 ? 2 : TSF_FIT_WPS) void fit_kernel(Fit
     int coop_ticket = -1;
     const DevSpec *sp = a.sp;
     SeriesView sv;
-    make_view<KP, PPL>(a, n, sv);
+    make_view<KL, PPL>(a, n, sv);
+    if constexpr (SPARSE) {
+        const int64_t g = grid_index(a, n);
+#pragma unroll
+        for (int e = 0; e < SP_M; ++e) sv.sp_m[e] = a.sp_meta[((size_t)g * SP_M + e) * W + lane];
+        sv.sp_prog = lane < SP_MAXC ? a.sp_prog[(size_t)g * SP_MAXC + lane] : 0ull;
+        sv.sp_acc = reinterpret_cast<double *>(smem + wave_lds_bytes<KL, PPL>(a.opt.history));
+    }
     for (int i = threadIdx.x; i < TSF_MAX_P + W; i += W) lds.th[i] = 0.0;
     TSF_WAVE_SYNC();
     const SeriesTab st = a.stab[n];
@@ -897,7 +951,7 @@ __global__ __launch_bounds__(64, GNTR > 0 ? 2 : TSF_FIT_WPS) void fit_kernel(Fit
             }
             double f1;
             FT_LAP(0);
-            const bool bad = eval_fg<KP, GROWTH, MODE, PPL, XIDX, WaveLds<KP, PPL>, GNTR>(sp, sv, lds, xk1, f1, gk1 FT_PASS);
+            const bool bad = eval_fg<KP, GROWTH, MODE, PPL, XIDX, WL, GNTR, SPARSE>(sp, sv, lds, xk1, f1, gk1 FT_PASS);
             f1 = uniform_f64(f1);       // every lane holds the same bits: let the compiler know (scalar branches)
             if (stage == ST_INIT) {
                 if (bad) { ret = TSF_ST_INIT_NONFINITE; fk = f1; break; }
