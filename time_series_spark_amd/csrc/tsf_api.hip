@@ -492,7 +492,7 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     // with the opposite guard.  TSF_SPARSE_EXTRA=0: never.
     const char *esp = getenv("TSF_SPARSE_EXTRA");
     const bool sparse_try = !quad && !newton && !mp.on && theta_in == nullptr && lat_U == 0 && hs.KP == 64 && mode != 2 &&
-                            hs.K > SP_DENSE && hs.K - hs.n_extra <= SP_DENSE && NTmax <= 12 && !(esp && atoi(esp) == 0);
+                            hs.K > SP_DENSE && hs.K <= SP_DENSE + SP_MAXC && hs.K - hs.n_extra <= SP_DENSE && NTmax <= 12 && !(esp && atoi(esp) == 0);
     const WsLayout l = ws_layout(N, n_grids, NTmax, hs.KP, qp.P4, qp.slots, (quad || newton_quad) && !aligned, lat_U, &mp,
                                  coop_slots, coop_stride, quad_pre, sparse_try);
     rc = ensure_ws(ctx, l.total, N, NTmax, !aligned);

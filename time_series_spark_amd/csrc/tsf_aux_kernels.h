@@ -26,22 +26,23 @@ __global__ __launch_bounds__(64) void sparse_extra_kernel(const DevSpec *__restr
     const double *X = Xw_all + (size_t)g * NTmax * 64 * W;
     uint32_t *meta = meta_all + (size_t)g * SP_M * W;
     unsigned long long *prog = prog_all + (size_t)g * SP_MAXC;
-    bool ok = Ks > 0 && Ks <= SP_MAXC && NT <= 16 && sp->KP == 64;
+    bool ok = Ks > 0 && Ks <= SP_MAXC && NT <= SP_MAX_NT && sp->KP == 64;
     if (lane < SP_MAXC) mask[lane] = 0ull;
-    for (int e = 0; e < SP_M; ++e) meta[e * W + lane] = 0u;
+    for (int e = 0; e < SP_M; ++e) meta[e * W + lane] = SP_END;
     __syncthreads();
     int rows = T - lane * NT;
     rows = rows < 0 ? 0 : (rows > NT ? NT : rows);
     int ne = 0;
     unsigned long long seen = 0ull;
-    // rows ascending, columns ascending inside a row: the ones of a row then stand in the order of its fma chain
-    for (int q = 0; q < rows && ok; ++q) {
+    // last row first (the order in which the fit kernel's row loop meets them), columns ascending inside a row: the
+    // ones of a row then stand in the order of its fma chain
+    for (int q = rows - 1; q >= 0 && ok; --q) {
         for (int c = 0; c < Ks; ++c) {
             const double v = X[((size_t)q * 64 + SP_DENSE + c) * W + lane];
             if (v == 0.0) continue;
             if (v != 1.0 || ((seen >> c) & 1ull) || ne == SP_M) { ok = false; break; }
             seen |= 1ull << c;
-            meta[ne * W + lane] = (unsigned)q | ((unsigned)c << 4);
+            meta[ne * W + lane] = (unsigned)q | ((unsigned)c << 7);
             ++ne;
             atomicOr(&mask[c], 1ull << lane);
         }
@@ -56,9 +57,9 @@ __global__ __launch_bounds__(64) void sparse_extra_kernel(const DevSpec *__restr
     // the slot of every entry: column * SP_E + rank of this lane among the column's lanes
     for (int e = 0; e < ne; ++e) {
         const unsigned m = meta[e * W + lane];
-        const int c = (int)((m >> 4) & 63u);
+        const int c = (int)((m >> 7) & 63u);
         const int rank = __popcll(mask[c] & ((1ull << lane) - 1ull));
-        meta[e * W + lane] = m | ((unsigned)(c * SP_E + rank) << 10) | 0x80000000u;
+        meta[e * W + lane] = m | ((unsigned)rank << 13);
     }
     // the fold program of column `lane`: the nodes are the column's lanes (slot = rank); the reduction network of
     // column_sums pairs lanes that differ in bit 5, then 4, 0, 1, 2, 3 -- two nodes merge at the stage after which they

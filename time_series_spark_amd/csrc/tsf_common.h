@@ -39,20 +39,28 @@ constexpr int NTAB = TSF_MAX_S + 4;     // per-changepoint tables
 // on BASELINE cfg4 -- streams 64-column rows twice per evaluation to multiply zeros.  Adding a zero is exact
 // (fma(0, b, a) = a for finite b; a + 0 = a), so the dense chains and the reduction network collapse onto the few
 // entries that exist WITHOUT changing a bit: the first SP_DENSE columns run as the 28-column kernel runs them (row and
-// accumulators in registers), each lane keeps the <= SP_M ones of its rows as (step, column, slot) words, a one adds
-// its coefficient to the row's chain after the dense columns (ascending column: the chain's order) and hands r g to a
-// slot of a small LDS array, and the lane that owns a column folds that column's <= SP_E slots in the order of the
-// reduction network (column_sums: lane bits 5, 4, 0, 1, 2, 3), a precomputed list of merges.  sparse_extra_kernel
-// (tsf_aux_kernels.h) builds the tables and clears FitArgs::sp_flag if a grid does not qualify (a value other than
-// 0 / 1, more than SP_M ones in a lane's rows, a column twice in one lane, more than SP_E lanes per column); the
-// dense kernel, launched behind with the opposite guard, then does the work.
+// accumulators in registers), the ones of a lane's rows stand in a short list (row step, column, slot) in LDS, last row
+// first, which the lane walks with a cursor as the row loop descends: a one adds its coefficient to the row's chain
+// after the dense columns (ascending column: the chain's order) and hands r g to a slot of a small LDS array, and the
+// lane that owns a column folds that column's <= SP_E slots in the order of the reduction network (column_sums: lane
+// bits 5, 4, 0, 1, 2, 3), a precomputed list of merges.  sparse_extra_kernel (tsf_aux_kernels.h) builds the tables and
+// sets FitArgs::sp_flag if a grid does not qualify (a value other than 0 / 1, more than SP_M ones in a lane's rows, a
+// column twice in one lane, more than SP_E lanes per column); the dense kernel, launched behind with the opposite
+// guard, then does the work.
 constexpr int SP_DENSE = 28;            // columns [0, SP_DENSE) dense, [SP_DENSE, K) sparse
-constexpr int SP_M = 8;                 // entries per lane
+constexpr int SP_M = 12;                // entries per lane
 constexpr int SP_E = 8;                 // lanes per column
-constexpr int SP_MAXC = 64 - SP_DENSE;  // sparse columns at most
-// entry word: bit 31 valid, bits 0-3 step q, bits 4-9 sparse column, bits 10-18 slot (column * SP_E + rank of the lane)
+constexpr int SP_MAXC = 32;            // sparse columns at most (their slots fit eval_tail's scratch)
+// entry word (16 bits): bits 0-6 row step q, bits 7-12 sparse column, bits 13-15 rank of the lane among the column's
+// lanes (slot = column * SP_E + rank); a lane's list ends with SP_END (SP_M + 1 words per lane).  The list lives in
+// SP_LDS_BYTES of LDS behind the wave's tables; the slots share the bytes of eval_tail's scratch (WaveLds::d1 .. ab),
+// which is written only after the fold has read them.
 // program word of a column: bits 0-2 number of merges, 3-5 slot that ends up holding the sum, 6-9 number of lanes,
 // then 6 bits per merge from bit 10: dst slot (3), src slot (3)
+constexpr unsigned SP_END = 0xffffu;
+constexpr int SP_MAX_NT = 127;          // row steps per lane at most (7 bits)
+constexpr size_t SP_LDS_BYTES = sizeof(unsigned short) * (SP_M + 1) * 64;
+static_assert(SP_MAXC * SP_E <= 4 * (NTAB + 1), "the sparse columns' slots overlay WaveLds::d1 .. ab");
 
 // Model description resident in device memory (built on the host by tsf_api).
 struct DevSpec {

@@ -12,9 +12,9 @@ namespace tsf {
 
 struct SeriesView {
     int T, NT, S, P, cnt;               // cnt: valid rows of this lane's chunk
-    unsigned sp_m[SP_M];                // (SPARSE kernels) this lane's ones
     unsigned long long sp_prog;         // (SPARSE kernels) lane c: the fold program of sparse column c
     double *sp_acc;                     // (SPARSE kernels) [SP_MAXC][SP_E] slots in LDS
+    const unsigned short *sp_list;      // (SPARSE kernels) [SP_M + 1][64] entry words of the lanes, last row first, in LDS
     int S_out;                          // changepoints in the caller's layout (S = 1 > S_out = 0: dummy changepoint)
     const double *tw, *yw, *Xw;         // step-major tables
     const int32_t *uw;                  // (lattice panels) row -> row of the shared table Xu, step-major
@@ -387,6 +387,9 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
     for (int j = 0; j < (GROUPED ? GNTR : 1); ++j) wr[j] = 0.0;
 #pragma unroll
     for (int j = 0; j < ((GROUPED && MODE != 0) ? GNTR : 1); ++j) wg[j] = 0.0;
+    unsigned sp_cur = SP_END;
+    int sp_i = 0;
+    if constexpr (SPARSE) sp_cur = sv.sp_list[lane];
     for (int q = NT - 1; q >= 0; --q) {
         if (q < sv.cnt) {
             const int idx = q * W + lane;
@@ -427,13 +430,16 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
                 }
             }
             if constexpr (SPARSE) {
-                // the ones of this row, ascending column: fma(1, b, chain) = chain + b
-#pragma unroll
-                for (int e = 0; e < SP_M; ++e) {
-                    const unsigned m = sv.sp_m[e];
-                    if ((m >> 31) && (int)(m & 15u) == q) {
-                        const double bv = lds.th[3 + S + SP_DENSE + (int)((m >> 4) & 63u)];
+                // the ones of this row, ascending column: fma(1, b, chain) = chain + b.  (sp_cur: the lane's next
+                // entry; it stays on the row's first one for the second walk below.)
+                unsigned c2 = sp_cur;
+                int i2 = sp_i;
+                while (__any(c2 != SP_END && (int)(c2 & 127u) == q)) {
+                    if (c2 != SP_END && (int)(c2 & 127u) == q) {
+                        const double bv = lds.th[3 + S + SP_DENSE + (int)((c2 >> 7) & 63u)];
                         if (MODE == 0) xa = xa + bv; else xm = xm + bv;
+                        ++i2;
+                        c2 = sv.sp_list[i2 * W + lane];
                     }
                 }
             }
@@ -477,10 +483,12 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
             }
             if constexpr (SPARSE) {
                 // fma(1, w, +0) = w: the lane's partial of that column (a column comes once per lane)
-#pragma unroll
-                for (int e = 0; e < SP_M; ++e) {
-                    const unsigned m = sv.sp_m[e];
-                    if ((m >> 31) && (int)(m & 15u) == q) sv.sp_acc[(m >> 10) & 511u] = (MODE == 0) ? r : rg;
+                while (__any(sp_cur != SP_END && (int)(sp_cur & 127u) == q)) {
+                    if (sp_cur != SP_END && (int)(sp_cur & 127u) == q) {
+                        sv.sp_acc[((sp_cur >> 7) & 63u) * SP_E + (sp_cur >> 13)] = (MODE == 0) ? r : rg;
+                        ++sp_i;
+                        sp_cur = sv.sp_list[sp_i * W + lane];
+                    }
                 }
             }
             double v = r * opm;
@@ -832,10 +840,12 @@ __global__ __launch_bounds__(64, (GNTR > 0 || SPARSE) ? 2 : TSF_FIT_WPS) void fi
     make_view<KL, PPL>(a, n, sv);
     if constexpr (SPARSE) {
         const int64_t g = grid_index(a, n);
-#pragma unroll
-        for (int e = 0; e < SP_M; ++e) sv.sp_m[e] = a.sp_meta[((size_t)g * SP_M + e) * W + lane];
         sv.sp_prog = lane < SP_MAXC ? a.sp_prog[(size_t)g * SP_MAXC + lane] : 0ull;
-        sv.sp_acc = reinterpret_cast<double *>(smem + wave_lds_bytes<KL, PPL>(a.opt.history));
+        sv.sp_acc = lds.d1;                  // [SP_MAXC][SP_E] over d1, d2, rb, ab (written by eval_tail after the fold)
+        unsigned short *lst = reinterpret_cast<unsigned short *>(smem + wave_lds_bytes<KL, PPL>(a.opt.history));
+        for (int e = 0; e < SP_M; ++e) lst[e * W + lane] = (unsigned short)a.sp_meta[((size_t)g * SP_M + e) * W + lane];
+        lst[SP_M * W + lane] = (unsigned short)SP_END;
+        sv.sp_list = lst;
     }
     for (int i = threadIdx.x; i < TSF_MAX_P + W; i += W) lds.th[i] = 0.0;
     TSF_WAVE_SYNC();
