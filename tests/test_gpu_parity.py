@@ -565,6 +565,20 @@ def test_sparse_indicator_columns_equal_dense_columns(env):
         rr = both(spec, lambda: fc.fit_ragged(spec, off, dsr, yr, floor=floor, cap=cap, extra=exr))
         for n in (0, 7):                 # full-length members of the ragged call = the aligned fit
             assert np.array_equal(rr.theta[n], r.theta[n]) and rr.n_eval[n] == r.n_eval[n], (case, n)
+    # longer series: the dense route is the workgroup kernel from the first evaluation (<= 4 096 rows) or the ungrouped
+    # one-wave kernel (longer); the sparse route the same one-wave kernel with the cooperative tail
+    for T_long, Nl in ((1095, 20), (4200, 4)):
+        dsl = synth.daily_grid(T_long)
+        exl, names = synth.holiday_matrix(dsl, 10)
+        _, yl = synth.make_panel(Nl, T_long, 'logistic', seed=8, holidays=exl)
+        specl = fc.ModelSpec(growth='logistic', seasonality_mode='multiplicative', seasonalities=[helpers.YEARLY, helpers.WEEKLY],
+                             extra=[{'name': n} for n in names], max_iter=400)
+        capl = yl.max(axis=1) * 1.1
+        r = both(specl, lambda: fc.fit_aligned(specl, dsl, yl, floor=np.zeros(Nl), cap=capl, extra=exl))
+        cspl = helpers.oracle_spec(specl)
+        o = cl.fit(cspl, dsl, yl[1], 0.0, capl[1], exl)
+        assert (r.n_iter[1], r.n_eval[1], r.status[1]) == (o['n_iter'], o['n_eval'], o['status']), T_long
+        assert n_bit_diff(r.theta[1][:len(o['theta'])], o['theta']) == 0 and n_bit_diff(r.fval[1], o['f']) == 0, T_long
     # refused by the analysis kernel: same results through the dense kernel
     spec, ds, y, floor, cap, extra, fut, exf = helpers.make_case('cfg4_holidays', N=6, seed=6)
     csp = helpers.oracle_spec(spec)

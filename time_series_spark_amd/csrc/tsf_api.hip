@@ -474,11 +474,22 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     // it uses (wave_lds_bytes: eight blocks per CU instead of six): 17.0 M evaluations/s on cfg4 against the
     // workgroup kernel's 15.4 M (2.27 against 2.50 s) -- so AUTO runs it, with the workgroup kernel for the tail
     // as for the narrower models.  TSF_FIT_GROUPED=0: every series on the workgroup kernel, as before.
+    // Wide models (64-column tables) whose columns from the 29th on are explicit columns -- holidays: 0 / 1 indicators,
+    // almost all 0 -- are tried on the sparse-column form of the 28-column kernel (eval_fg<..., SPARSE>, tsf_fit_kernels.h):
+    // sparse_extra_kernel decides on the device whether every grid qualifies, the dense route is launched behind it
+    // with the opposite guard (series of <= 768 rows: the grouped one-wave kernel; up to 4 096 rows: the workgroup
+    // kernel from the first evaluation; longer: the ungrouped one-wave kernel).  TSF_SPARSE_EXTRA=0: never.
+    const char *esp = getenv("TSF_SPARSE_EXTRA");
+    const bool sparse_try = !quad && !newton && !mp.on && theta_in == nullptr && lat_U == 0 && hs.KP == 64 && mode != 2 &&
+                            spec->residual_kernel == TSF_RK_AUTO && hs.K > SP_DENSE && hs.K <= SP_DENSE + SP_MAXC &&
+                            hs.K - hs.n_extra <= SP_DENSE && NTmax <= SP_MAX_NT && !(esp && atoi(esp) == 0);
     int coop_after = spec->residual_kernel == TSF_RK_COOP ? COOP_DIRECT : spec->coop_after;
     if (coop) {
         const char *eg = getenv("TSF_FIT_GROUPED");
         const bool grouped = NTmax <= 12 && !(eg && atoi(eg) == 0) && lat_U == 0;
-        if (spec->residual_kernel == TSF_RK_AUTO && spec->coop_after < 0 && hs.KP == 64 && !grouped) coop_after = COOP_DIRECT;
+        // (with sparse_try the slots of the tail exist either way: the dense route of longer series is then launched
+        // in direct mode by the launch function itself)
+        if (spec->residual_kernel == TSF_RK_AUTO && spec->coop_after < 0 && hs.KP == 64 && !grouped && !sparse_try) coop_after = COOP_DIRECT;
     }
     const int coop_slots = coop ? coop_slots_for(N, coop_after, ctx->n_cu) : 0;
     const int coop_stride = coop ? coop_slot_doubles(hs.KP == 64 ? 2 : 1) : 0;
@@ -486,13 +497,6 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     // instead of once per series inside the fit kernel -- when that at least halves the builds (TSF_GRAM_SHARE=0: never)
     const char *egs = getenv("TSF_GRAM_SHARE");
     const int64_t quad_pre = (quad && !aligned && grid_of && n_grids * 2 <= N && !(egs && atoi(egs) == 0)) ? n_grids : 0;
-    // Wide models (64-column tables) whose columns from the 29th on are explicit columns -- holidays: 0 / 1 indicators,
-    // almost all 0 -- are tried on the sparse-column form of the 28-column kernel (eval_fg<..., SPARSE>, tsf_fit_kernels.h):
-    // sparse_extra_kernel decides on the device whether every grid qualifies, the dense kernel is launched behind it
-    // with the opposite guard.  TSF_SPARSE_EXTRA=0: never.
-    const char *esp = getenv("TSF_SPARSE_EXTRA");
-    const bool sparse_try = !quad && !newton && !mp.on && theta_in == nullptr && lat_U == 0 && hs.KP == 64 && mode != 2 &&
-                            hs.K > SP_DENSE && hs.K <= SP_DENSE + SP_MAXC && hs.K - hs.n_extra <= SP_DENSE && NTmax <= 12 && !(esp && atoi(esp) == 0);
     const WsLayout l = ws_layout(N, n_grids, NTmax, hs.KP, qp.P4, qp.slots, (quad || newton_quad) && !aligned, lat_U, &mp,
                                  coop_slots, coop_stride, quad_pre, sparse_try);
     rc = ensure_ws(ctx, l.total, N, NTmax, !aligned);

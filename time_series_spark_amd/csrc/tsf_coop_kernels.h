@@ -1121,6 +1121,7 @@ __global__ __launch_bounds__(NW * 64) void fit_coop_kernel(FitArgs a)
     CoopLds<KP, PPL> &cl = *reinterpret_cast<CoopLds<KP, PPL> *>(smem);
     double *rbR = reinterpret_cast<double *>(smem + sizeof(CoopLds<KP, PPL>));
     double *rbU = rbR + (size_t)coop_rb_rows(a.NTmax) * W, *rbV = rbU + (size_t)coop_rb_rows(a.NTmax) * W;
+    if (a.run_flag && (*a.run_flag != 0) != (a.run_if != 0)) return;          // launch guard (FitArgs::run_flag), as in fit_kernel
     const int wid = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);     // wave-uniform: addresses built from it stay scalar
     // direct mode: every series of the call, fitted here from its initial values; otherwise the fits
     // fit_kernel suspended
