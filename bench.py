@@ -18,7 +18,10 @@ end before its longest fit, so this panel stops scaling early (`strong_scaling_e
 ceiling next to the measurement).  Beside it, timed the same way:
   * `weak_scaling` (N > 1): every rank its own 10 000-series panel;
   * `cfg3_sharded` (every N): BASELINE config 3 -- 100 000 series x 1 095 points as 8 blocks of 12 500,
-    block b on rank b mod N -- the configuration that has enough work per GPU to scale.
+    block b on rank b mod N -- the configuration that has enough work per GPU to scale;
+  * `other_baseline_configs` (N = 1, rank 0): BASELINE configs 1 and 4 and the reference's own model settings on
+    10 000 x 730 -- the residual-form kernels, one warm-up + one or two timed steps each (tools/bench_configs.py has
+    every configuration at full length).
 Rank 0 prints one JSON line.
 """
 import argparse
@@ -250,6 +253,67 @@ def pmc_valu(kernel, kernel_ms, total_evals, n_cu):
         return None
 
 
+def other_baseline_configs(dev, local):
+    """BASELINE configs 1 and 4 and the reference's own model settings (logistic growth, multiplicative seasonality:
+    prophet_modeler.py:56-65) on 10 000 x 730: the residual-form kernels, inputs resident in HBM, step = fit + 90-step
+    forecast as in the headline leg; fit-path kernel time from the library's HIP events."""
+    import torch
+    yearly = {'name': 'yearly', 'period': 365.25, 'fourier_order': 10}
+    weekly = {'name': 'weekly', 'period': 7, 'fourier_order': 3}
+    out = {}
+
+    def leg(name, desc, spec, ds_np, y_np, cap, extra, exf, steps):
+        N = y_np.shape[0]
+        fut_np = ds_np[-1] + synth.DAY_NS * np.arange(1, HORIZON + 1)
+        to = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+        ds, y, fut, fl, cp, ex, exfd = to(ds_np), to(y_np), to(fut_np), to(np.zeros(N)), to(cap), to(extra), to(exf)
+        f = DeviceForecaster(spec, local)
+        o = f.alloc_fit_output(N)
+        yh = torch.zeros((N, HORIZON), dtype=torch.float64, device=dev)
+
+        def step():
+            f.fit_aligned(ds, y, o, floor=fl, cap=cp, extra=ex)
+            f.predict(o, fut, yh, None, floor=fl, cap=cp, extra_future=exfd)
+
+        step()
+        torch.cuda.synchronize()
+        f.set_profiling(True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dt_ = (time.perf_counter() - t0) / steps
+        kms = f.profile_read()
+        f.set_profiling(False)
+        ne = o.n_eval.cpu().numpy().astype(np.int64)
+        st = o.status.cpu().numpy()
+        out[name] = {'workload': desc, 'series': N, 'series_per_s': N / dt_, 'ms_per_step': 1e3 * dt_,
+                     'fit_kernel_ms': float(np.mean(kms)) if kms else None, 'mean_evals': float(ne.mean()),
+                     'max_evals': int(ne.max()), 'fitted': int((st > 0).sum()),
+                     'finite_forecasts': bool(torch.isfinite(yh[o.status > 0]).all().item())}
+
+    ref = fc.ModelSpec(growth='logistic', seasonality_mode='multiplicative', seasonalities=[yearly, weekly])
+    ds1, y1 = synth.make_panel(100, 365, 'logistic', seed=751)
+    leg('cfg1', 'BASELINE config 1: 100 x 365, the reference settings (logistic, floor 0, cap 1.1 max y, multiplicative, '
+        'auto seasonalities)',
+        fc.ModelSpec(growth='logistic', seasonality_mode='multiplicative',
+                     seasonalities=fc.ModelSpec.auto_seasonalities(ds1, seasonality_mode='multiplicative')),
+        ds1, y1, y1.max(axis=1) * 1.1, None, None, 3)
+    dsr, yr = synth.make_panel(10000, T_POINTS, 'logistic', seed=751)
+    leg('reference_settings_10k', '10 000 x 730, the reference settings (logistic, multiplicative, yearly + weekly)',
+        ref, dsr, yr, yr.max(axis=1) * 1.1, None, None, 2)
+    ds4 = synth.daily_grid(T_POINTS)
+    fut4 = ds4[-1] + synth.DAY_NS * np.arange(1, HORIZON + 1)
+    allm, names = synth.holiday_matrix(np.concatenate([ds4, fut4]), 10)
+    ex4, exf4 = np.ascontiguousarray(allm[:, :T_POINTS]), np.ascontiguousarray(allm[:, T_POINTS:])
+    _, y4 = synth.make_panel(50000, T_POINTS, 'logistic', seed=751, holidays=ex4)
+    leg('cfg4', 'BASELINE config 4: 50 000 x 730, logistic + floor, multiplicative, 10 holidays x window [-1, +1] '
+        '(30 indicator columns, P = 84: the sparse-column kernel, DESIGN.md 5g)',
+        fc.ModelSpec(growth='logistic', seasonality_mode='multiplicative', seasonalities=[yearly, weekly],
+                     extra=[{'name': n} for n in names]), ds4, y4, y4.max(axis=1) * 1.1, ex4, exf4, 1)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -257,6 +321,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-cfg3', action='store_true', help='skip the cfg3_sharded leg (100 000 x 1 095 over the ranks)')
+    ap.add_argument('--no-other-configs', action='store_true', help='skip the other_baseline_configs leg (cfg1, cfg4, reference settings)')
     ap.add_argument('--timed-only', action='store_true',
                     help='only warm-up + the K timed steps (for rocprofv3 runs: every dispatch of the fit '
                          'kernel is then a full-panel launch, so per-kernel means are per launch)')
@@ -446,6 +511,8 @@ def main():
         res['weak_scaling'] = weak
     if cfg3 is not None:
         res['cfg3_sharded'] = cfg3
+    if world == 1 and not args.no_other_configs and not args.timed_only:
+        res['other_baseline_configs'] = other_baseline_configs(dev, local)
     # What the strong-scaled legs SHOULD show, stated next to what they do show: a launch cannot end before
     # its longest fit, and a rank's queue cannot drain faster than its wave slots allow.  tau = time per
     # evaluation of one wave, calibrated on THIS run (rank 0's fit-path kernel time / the queue model's

@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 timeout 900 python -m pytest tests -m gpu -x -q -k "$KEXPR" > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee $OUT/summary.txt
 tail -3 $OUT/pytest_gpu.log | tee -a $OUT/summary.txt
 for i in 1 2; do
-timeout 600 python bench.py --steps 5 --warmup 2 --no-cfg3 --no-cpu-baseline > $OUT/bench$i.json 2> $OUT/bench$i.err; echo "bench rc=$?" | tee -a $OUT/summary.txt
+timeout 600 python bench.py --steps 5 --warmup 2 --no-cfg3 --no-cpu-baseline --no-other-configs > $OUT/bench$i.json 2> $OUT/bench$i.err; echo "bench rc=$?" | tee -a $OUT/summary.txt
 python - <<PY | tee -a $OUT/summary.txt
 import json
 d=json.load(open('$OUT/bench$i.json'))
