@@ -363,7 +363,8 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
                    const double *extra, tsf_fit_out *out, const double *theta_in,
                    double *grad_out, hipStream_t st, int64_t lat_base = 0, int64_t lat_step = 0,
                    int64_t lat_U = 0, const double *theta_ref = nullptr,
-                   const int32_t *grid_of = nullptr, const int64_t *grid_rows = nullptr, int64_t n_distinct = 0)
+                   const int32_t *grid_of = nullptr, const int64_t *grid_rows = nullptr, int64_t n_distinct = 0,
+                   const int32_t *grid_order = nullptr)
 {
     if (!ctx) return -1;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -424,6 +425,15 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     }
     // shared lattice table: ragged panel, residual-form kernel, no explicit columns
     if (aligned || quad || newton || theta_in != nullptr || hs.n_extra > 0 || lat_step <= 0) lat_U = 0;
+    {
+        // Series that share timestamp vectors (grid_of) have step-major tables per DISTINCT vector: where those fit the
+        // caches (<= 64 MB of design tables) every wave reads them coalesced, as on an aligned panel, and the lattice
+        // table with its gathered rows (64 cache lines per load instruction) is the slower of the two.
+        // TSF_LATTICE=0: never the lattice table; =1: always where it applies.
+        const char *el = getenv("TSF_LATTICE");
+        const size_t tab = sizeof(double) * (size_t)n_grids * (size_t)NTmax * hs.KP * W;
+        if (el ? atoi(el) == 0 : (grid_of != nullptr && tab <= ((size_t)64 << 20))) lat_U = 0;
+    }
     // matrix-core residual kernel (tsf_mfma_kernels.h): aligned panel, L-BFGS, one parameter per lane
     // (KP <= 28 implies one column mode and P <= 64), at most MT_SP changepoints, and an upper bound
     // on the changepoint rows one chunk can hold (the exact count is checked on the device:
@@ -560,6 +570,7 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     // scheduling hints of tsf_set_cost_hints: for this call if they were given for this many series; used once
     const int order_buf = (ctx->order_n == N && !theta_in) ? (ctx->order_next ^ 1) : -1;
     if (order_buf >= 0) a.order = ctx->order_dev[order_buf];
+    else if (grid_order && !getenv("TSF_GRID_ORDER_OFF")) a.order = grid_order;       // series grouped by shared grid (fit_host_one)
     ctx->order_n = 0;
     const int slot = (int)(ctx->ev_count % TSF_PROFILE_RING);
     if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev0[slot], st));
@@ -844,7 +855,7 @@ static int fit_host_one(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int align
     // quadratic-form path builds Z^T Z once per vector instead of once per series.  Identical vectors only (hash of
     // the bytes, then memcmp against the class's first member); models with explicit columns are left alone (their
     // columns are per row, not per timestamp).  TSF_GRID_SHARE=0 turns it off (tests compare both).
-    DevBuf d_gof, d_grows;
+    DevBuf d_gof, d_grows, d_gord;
     int64_t n_distinct = 0;
     {
         const char *e_share = getenv("TSF_GRID_SHARE");
@@ -911,6 +922,25 @@ static int fit_host_one(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int align
                 HIP_TRY(ctx, d_grows.alloc(8 * grows.size()));
                 HIP_TRY(ctx, hipMemcpy(d_gof.p, gof.data(), 4 * (size_t)N, hipMemcpyHostToDevice));
                 HIP_TRY(ctx, hipMemcpy(d_grows.p, grows.data(), 8 * grows.size(), hipMemcpyHostToDevice));
+                // The order in which the launch starts the series: grouped by grid, and the grouped list cut into 8
+                // segments dealt out one position each in turn -- block b of a one-wave launch runs on XCD b % 8
+                // (observed, MI355X_MICROARCH: for speed only), so every XCD works its way through ITS segment and its
+                // 4 MB of L2 hold the two or three grids its resident blocks are on, instead of a share of all of them
+                // (10 000 series on 91 grids, the reference's model: 205 -> see profiles/r04_final3/ragged.txt).  Used
+                // when the caller gave no cost hints; results do not depend on the order.
+                std::vector<int32_t> byg((size_t)N), ord((size_t)N);
+                {
+                    std::vector<int64_t> start((size_t)n_distinct + 1, 0);
+                    for (int64_t n = 0; n < N; ++n) start[(size_t)gof[(size_t)n] + 1]++;
+                    for (int64_t g = 0; g < n_distinct; ++g) start[(size_t)g + 1] += start[(size_t)g];
+                    for (int64_t n = 0; n < N; ++n) byg[(size_t)start[(size_t)gof[(size_t)n]]++] = (int32_t)n;
+                    const int64_t seg = (N + 7) / 8;
+                    int64_t q = 0;
+                    for (int64_t i = 0; i < seg; ++i)
+                        for (int x = 0; x < 8; ++x) { const int64_t k = (int64_t)x * seg + i; if (k < N) ord[(size_t)q++] = byg[(size_t)k]; }
+                }
+                HIP_TRY(ctx, d_gord.alloc(4 * (size_t)N));
+                HIP_TRY(ctx, hipMemcpy(d_gord.p, ord.data(), 4 * (size_t)N, hipMemcpyHostToDevice));
             } else {
                 n_distinct = 0;
             }
@@ -924,7 +954,8 @@ static int fit_host_one(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int align
                      theta_in ? d_thin.as<double>() : nullptr,
                      theta_in ? d_grad.as<double>() : nullptr, nullptr, lat_base, lat_step, lat_U,
                      (theta_in && theta_ref) ? d_thref.as<double>() : nullptr,
-                     n_distinct > 0 ? d_gof.as<int32_t>() : nullptr, n_distinct > 0 ? d_grows.as<int64_t>() : nullptr, n_distinct);
+                     n_distinct > 0 ? d_gof.as<int32_t>() : nullptr, n_distinct > 0 ? d_grows.as<int64_t>() : nullptr, n_distinct,
+                     n_distinct > 0 ? d_gord.as<int32_t>() : nullptr);
     if (rc) return rc;
     HIP_TRY(ctx, hipDeviceSynchronize());
     if (host_timing) t_fit = now();
