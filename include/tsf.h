@@ -286,6 +286,10 @@ int tsf_set_cost_hints(tsf_ctx *ctx, const int32_t *cost, int64_t n);
 int tsf_set_profiling(tsf_ctx *ctx, int32_t enable);
 int tsf_profile_read(tsf_ctx *ctx, float *ms_out, int32_t max_n, int32_t *n_out);
 int tsf_last_fit_kernel_ms(tsf_ctx *ctx, float *ms_out);
+/* Which route the last fit call of this context took where the library decides on the device (tests, measurements):
+ * *sparse_columns = 1 if a wide model's indicator columns ran in sparse form (every grid qualified), 0 if the dense
+ * kernels ran or the call was not a candidate.  Waits for the device; valid until the next fit call. */
+int tsf_last_fit_route(tsf_ctx *ctx, int32_t *sparse_columns);
 
 /* ---- host-side panel packing (no device work, no tsf_ctx) ---------------------------------
  * Regroups a long table (one row per observation) into the contiguous per-series runs

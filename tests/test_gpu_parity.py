@@ -519,25 +519,35 @@ def test_ragged_series_with_equal_timestamps_share_grid_tables(env):
                 assert n_bit_diff(r.theta[n][:P], o['theta']) == 0 and n_bit_diff(r.fval[n], o['f']) == 0, (growth, mode, n)
 
 
+def _used_sparse_columns(fc):
+    import ctypes
+    from time_series_spark_amd import _lib
+    ctx = fc.get_context()
+    v = ctypes.c_int32(-1)
+    ctx.check(_lib.load().tsf_last_fit_route(ctx.handle, ctypes.byref(v)))
+    return v.value == 1
+
+
 def test_sparse_indicator_columns_equal_dense_columns(env):
     """Models with more than 28 design columns whose columns from the 29th on are 0 / 1 indicators (holidays) run the
     28-column kernel with those columns in sparse form (eval_fg<..., SPARSE>: the ones of a lane's rows as entry words,
     the per-column sums folded in the reduction network's order from a few LDS slots) -- adding a zero is exact, so
     not a bit may differ from the dense 64-column kernel (TSF_SPARSE_EXTRA=0) or from the oracle: BASELINE cfg4's
     model (logistic, multiplicative), its additive twin in residual form, a ragged call, stragglers included; and
-    the cases the analysis kernel must REFUSE (a holiday value of 2, nine holidays inside one lane's rows, an
+    the cases the analysis kernel must REFUSE (a holiday value of 2, thirteen ones inside one lane's rows, an
     indicator column that is mostly ones) fall back to the dense kernel with the same bits as before."""
     import os
     fc, cl = env
     from time_series_spark_amd import synth
 
-    def both(spec, call):
+    def both(spec, call, want_sparse=True):
         out = {}
         for tag in ('sparse', 'dense'):
             if tag == 'dense':
                 os.environ['TSF_SPARSE_EXTRA'] = '0'
             try:
                 out[tag] = call()
+                assert _used_sparse_columns(fc) == (tag == 'sparse' and want_sparse), (tag, want_sparse)
             finally:
                 os.environ.pop('TSF_SPARSE_EXTRA', None)
         for name in ('theta', 'fval', 'n_iter', 'n_eval', 'status', 'y_scale'):
@@ -570,6 +580,7 @@ def test_sparse_indicator_columns_equal_dense_columns(env):
     for T_long, Nl in ((1095, 20), (4200, 4)):
         dsl = synth.daily_grid(T_long)
         exl, names = synth.holiday_matrix(dsl, 10)
+        exl[:, 2600:] = 0.0                  # (at most eight occurrences per column: what the sparse form takes)
         _, yl = synth.make_panel(Nl, T_long, 'logistic', seed=8, holidays=exl)
         specl = fc.ModelSpec(growth='logistic', seasonality_mode='multiplicative', seasonalities=[helpers.YEARLY, helpers.WEEKLY],
                              extra=[{'name': n} for n in names], max_iter=400)
@@ -582,20 +593,74 @@ def test_sparse_indicator_columns_equal_dense_columns(env):
     # refused by the analysis kernel: same results through the dense kernel
     spec, ds, y, floor, cap, extra, fut, exf = helpers.make_case('cfg4_holidays', N=6, seed=6)
     csp = helpers.oracle_spec(spec)
-    for what in ('value 2', 'nine in one lane', 'dense column'):
+    for what in ('value 2', 'thirteen in one lane', 'dense column'):
         ex = extra.copy()
         if what == 'value 2':
             ex[3, np.flatnonzero(ex[3])[0]] = 2.0
-        elif what == 'nine in one lane':
+        elif what == 'thirteen in one lane':
             ex[:, :] = 0.0
-            for j in range(9):
-                ex[2 + j, 24 + j] = 1.0          # rows 24..32 lie in lane 2's twelve rows (T = 730: 12 rows per lane)
+            for j in range(13):
+                ex[2 + j, 24 + min(j, 11)] = 1.0     # rows 24..35 are lane 2's twelve rows (T = 730); two columns share the last
         else:
             ex[5, ::2] = 1.0
-        r = both(spec, lambda: fc.fit_aligned(spec, ds, y, floor=floor, cap=cap, extra=ex))
+        r = both(spec, lambda: fc.fit_aligned(spec, ds, y, floor=floor, cap=cap, extra=ex), want_sparse=False)
         o = cl.fit(csp, ds, y[1], floor[1], cap[1], ex)
         assert (r.n_iter[1], r.n_eval[1], r.status[1]) == (o['n_iter'], o['n_eval'], o['status']), what
         assert n_bit_diff(r.theta[1][:len(o['theta'])], o['theta']) == 0, what
+
+
+def test_randomised_sparse_indicator_layouts(env):
+    """A seeded sweep over indicator layouts for the sparse-column kernel: 200 .. 2 000 rows (4 .. 32 rows per lane),
+    seasonal blocks of 6 .. 26 columns (so that some indicator columns fall into the dense first 28), 4 .. 32 indicator
+    columns with 1 .. 9 ones each at random rows -- up to eight lanes per column and several ones per lane and per row,
+    sometimes more than the kernel takes (the analysis kernel must then refuse and the dense kernel run) --, both
+    growths, both column modes: sparse route = dense route (TSF_SPARSE_EXTRA=0) bit for bit, one series per case
+    against the oracle."""
+    import os
+    fc, cl = env
+    from time_series_spark_amd import synth
+    rng = np.random.default_rng(20260924)
+    n_sparse = 0
+    for trial in range(28):
+        growth = 'logistic' if trial % 2 == 0 else 'linear'
+        mode = 'multiplicative' if trial % 3 != 1 else 'additive'
+        T = int(rng.choice([200, 365, 730, 768, 769, 1095, 2000]))
+        seas = [{'name': 'weekly', 'period': 7, 'fourier_order': 3}]
+        if rng.random() < 0.7:
+            seas.append({'name': 'yearly', 'period': 365.25, 'fourier_order': int(rng.choice([4, 10]))})
+        Kd = sum(2 * s_['fourier_order'] for s_ in seas)
+        n_ind = int(rng.integers(max(4, 29 - Kd), 33))
+        if Kd + n_ind <= 28:
+            n_ind = 29 - Kd + 3
+        ex = np.zeros((n_ind, T))
+        for j in range(n_ind):
+            k = int(rng.integers(1, 10 if trial % 7 == 3 else 6))
+            ex[j, rng.choice(T, size=k, replace=False)] = 1.0
+        if trial % 5 == 2:                                  # two indicators on the same rows, a window of consecutive days
+            ex[1] = ex[0]
+            ex[2, 1:] = ex[0, :-1]
+        N = 3
+        ds = synth.daily_grid(T)
+        _, y = synth.make_panel(N, T, growth, seed=100 + trial, holidays=ex if mode == 'multiplicative' else None)
+        spec = fc.ModelSpec(growth=growth, seasonality_mode=mode, seasonalities=seas, max_iter=120,
+                            extra=[{'name': 'i%02d' % j} for j in range(n_ind)], eval_form=1)
+        cap = y.max(axis=1) * 1.1
+        out = {}
+        for tag in ('sparse', 'dense'):
+            if tag == 'dense':
+                os.environ['TSF_SPARSE_EXTRA'] = '0'
+            try:
+                out[tag] = fc.fit_aligned(spec, ds, y, floor=np.zeros(N), cap=cap, extra=ex)
+                n_sparse += int(_used_sparse_columns(fc))
+            finally:
+                os.environ.pop('TSF_SPARSE_EXTRA', None)
+        for name in ('theta', 'fval', 'n_iter', 'n_eval', 'status'):
+            assert np.array_equal(getattr(out['sparse'], name), getattr(out['dense'], name), equal_nan=True), (trial, name)
+        r = out['sparse']
+        o = cl.fit(helpers.oracle_spec(spec), ds, y[0], 0.0, cap[0], ex)
+        assert (r.n_iter[0], r.n_eval[0], r.status[0]) == (o['n_iter'], o['n_eval'], o['status']), trial
+        assert n_bit_diff(r.theta[0][:len(o['theta'])], o['theta']) == 0 and n_bit_diff(r.fval[0], o['f']) == 0, trial
+    assert 12 <= n_sparse <= 27, n_sparse        # most layouts qualify, some are refused (the dense runs never count)
 
 
 def test_one_host_thread_per_device_gives_identical_bits(env, monkeypatch):

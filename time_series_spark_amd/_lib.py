@@ -79,7 +79,7 @@ EXPORTS = ['tsf_create', 'tsf_destroy', 'tsf_last_error', 'tsf_device_count', 't
            'tsf_spec_size', 'tsf_grid_info_size', 'tsf_spec_K', 'tsf_theta_stride',
            'tsf_fit_aligned', 'tsf_fit_aligned_dev', 'tsf_fit_ragged', 'tsf_fit_ragged_dev',
            'tsf_predict', 'tsf_predict_dev', 'tsf_predict_intervals', 'tsf_predict_intervals_dev', 'tsf_eval', 'tsf_eval_quadratic', 'tsf_design', 'tsf_selftest_math',
-           'tsf_set_cost_hints', 'tsf_set_profiling', 'tsf_profile_read', 'tsf_last_fit_kernel_ms',
+           'tsf_set_cost_hints', 'tsf_set_profiling', 'tsf_profile_read', 'tsf_last_fit_kernel_ms', 'tsf_last_fit_route',
            'tsf_pack_rows', 'tsf_pack_fetch', 'tsf_pack_free',
            'tsf_csv_read', 'tsf_csv_fetch', 'tsf_csv_columns', 'tsf_csv_malformed', 'tsf_csv_free', 'tsf_csv_write_forecasts', 'tsf_csv_write_forecasts_i32',
            'tsf_csv_discover', 'tsf_csv_discover_load', 'tsf_csv_read_loaded', 'tsf_csv_dir_paths', 'tsf_csv_dir_series_id', 'tsf_csv_dir_error_path', 'tsf_csv_dir_free']
@@ -137,6 +137,7 @@ def load():
     L.tsf_set_profiling.argtypes = [vp, i32]
     L.tsf_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_float), i32, ctypes.POINTER(i32)]
     L.tsf_last_fit_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+    L.tsf_last_fit_route.argtypes = [vp, ctypes.POINTER(ctypes.c_int32)]
     L.tsf_pack_rows.argtypes = [i64, vp, vp, vp, vp, i32, ctypes.POINTER(vp), ctypes.POINTER(i64),
                                 ctypes.POINTER(i64), ctypes.POINTER(i32)]
     L.tsf_pack_fetch.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]

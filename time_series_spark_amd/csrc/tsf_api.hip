@@ -47,6 +47,7 @@ struct tsf_ctx {
     hipEvent_t order_ev[2]; // recorded behind the launch that reads order_dev[b]: the buffer is rewritten only after it
     int order_busy[2];
     int n_cu;               // compute units of the device (persistent kernels: one workgroup each)
+    const int *last_sp_flag;  // sparse-column route of the last fit call: its device flag (in the workspace), or null
     int profiling;
     hipEvent_t ev0[TSF_PROFILE_RING], ev1[TSF_PROFILE_RING];
     int ev_created;
@@ -90,6 +91,7 @@ extern "C" int tsf_create(int device_id, tsf_ctx **out)
     c->order_dev[0] = c->order_dev[1] = nullptr; c->order_cap[0] = c->order_cap[1] = 0; c->order_next = 0; c->order_n = 0;
     c->order_ev[0] = c->order_ev[1] = nullptr; c->order_busy[0] = c->order_busy[1] = 0;
     c->profiling = 0; c->ev_created = 0; c->ev_count = 0;
+    c->last_sp_flag = nullptr;
     if (hipMalloc((void **)&c->d_spec, sizeof(DevSpec)) != hipSuccess) { delete c; return -2; }
     {
         hipDeviceProp_t prop;
@@ -563,9 +565,11 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     a.theta_in = theta_in; a.grad_out = grad_out;
     a.uw = (const int32_t *)(ws + l.uw); a.Xu = (const double *)(ws + l.Xu); a.xidx = lat_U > 0 ? 1 : 0;
     a.grid_of = grid_of;
+    ctx->last_sp_flag = nullptr;
     if (sparse_try) {
         a.sp_meta = (const uint32_t *)(ws + l.spm); a.sp_prog = (const unsigned long long *)(ws + l.spp);
         a.sp_flag = (int *)(ws + l.counter) + 8;
+        ctx->last_sp_flag = a.sp_flag;
     }
     // scheduling hints of tsf_set_cost_hints: for this call if they were given for this many series; used once
     const int order_buf = (ctx->order_n == N && !theta_in) ? (ctx->order_next ^ 1) : -1;
@@ -1504,6 +1508,19 @@ extern "C" int tsf_profile_read(tsf_ctx *ctx, float *ms_out, int32_t max_n, int3
         HIP_TRY(ctx, hipEventElapsedTime(&ms_out[i], ctx->ev0[slot], ctx->ev1[slot]));
     }
     *n_out = (int32_t)n;
+    return 0;
+}
+
+extern "C" int tsf_last_fit_route(tsf_ctx *ctx, int32_t *sparse_columns)
+{
+    if (!ctx || !sparse_columns) return -1;
+    *sparse_columns = 0;
+    if (!ctx->last_sp_flag) return 0;
+    int bad = 1;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    HIP_TRY(ctx, hipMemcpy(&bad, ctx->last_sp_flag, sizeof(int), hipMemcpyDeviceToHost));
+    *sparse_columns = bad ? 0 : 1;
     return 0;
 }
 
