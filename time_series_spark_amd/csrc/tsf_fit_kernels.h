@@ -83,6 +83,8 @@ __host__ __device__ inline size_t wave_lds_bytes(int history)
 
 __device__ __forceinline__ int lane_id() { return (int)threadIdx.x & (W - 1); }
 
+static_assert(3 + TSF_MAX_S <= W, "the changepoint parameters delta_j (p = 3 + j) live in slot 0 of every lane layout: "
+                                  "readlane_f64(th[0], 3 + j) in the recurrences");
 // theta[p] for a wave-uniform p, straight from the owning lane's register
 template <int PPL>
 __device__ __forceinline__ double theta_at(const double (&th)[PPL], int p)
@@ -185,7 +187,7 @@ __device__ __forceinline__ void segment_tables(const SeriesView &sv, L &lds, con
     const double tcl = sv.tc_l;
     if (GROWTH == 0) {
         TSF_UNROLL4_UP(j, 0, S, {
-            const double dj = theta_at<PPL>(th, 3 + j);
+            const double dj = readlane_f64(th[0], 3 + j);
             const double ksn = ksv + dj;
             const double mcn = mcv + ((-readlane_f64(tcl, j)) * dj);
             if (j < lane) { ksv = ksn; mcv = mcn; }
@@ -196,7 +198,7 @@ __device__ __forceinline__ void segment_tables(const SeriesView &sv, L &lds, con
         // the operands of the sequential form), and the mc chain reads them by lane.
         double ks_next = k;
         TSF_UNROLL4_UP(j, 0, S, {
-            const double ksn = ksv + theta_at<PPL>(th, 3 + j);
+            const double ksn = ksv + readlane_f64(th[0], 3 + j);
             if (j == lane) ks_next = ksn;
             if (j < lane) ksv = ksn;
         });
@@ -371,8 +373,15 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
     segment_tables<GROWTH, PPL>(sv, lds, th);
     double bs[HOLD ? KP : 1];
     if (HOLD) {
+        if (PPL == 2 && 3 + S + KP <= W) {
+            // two parameters per lane, but every held coefficient lives in slot 0 (25 changepoints: p = 28 .. 55): one
+            // lane read each instead of two and a select
 #pragma unroll
-        for (int j = 0; j < (HOLD ? KP : 1); ++j) bs[j] = (3 + S + j < PPL * W) ? theta_at<PPL>(th, 3 + S + j) : 0.0;
+            for (int j = 0; j < (HOLD ? KP : 1); ++j) bs[j] = readlane_f64(th[0], 3 + S + j);
+        } else {
+#pragma unroll
+            for (int j = 0; j < (HOLD ? KP : 1); ++j) bs[j] = (3 + S + j < PPL * W) ? theta_at<PPL>(th, 3 + S + j) : 0.0;
+        }
     }
     TSF_WAVE_SYNC();
     FT_LAP(1);

@@ -483,7 +483,7 @@ __device__ __forceinline__ bool resid_eval_q(const SeriesView &sv, QuadLds<KP, P
         double ksv = readlane_f64(th[0], 0), mcv = readlane_f64(th[0], 1);
         const double tcl = sv.tc_l;
         for (int j = 0; j < S; ++j) {
-            const double dj = theta_at<PPL>(th, 3 + j);
+            const double dj = readlane_f64(th[0], 3 + j);
             const double ksn = ksv + dj;
             const double mcn = mcv + ((-readlane_f64(tcl, j)) * dj);
             if (j < lane) { ksv = ksn; mcv = mcn; }

@@ -19,7 +19,7 @@ extra, names = synth.holiday_matrix(ds, 10)
 for N in (128, 20000):
     _, y = synth.make_panel(N, T, 'logistic', seed=751, holidays=extra)
     spec = fc.ModelSpec(growth='logistic', seasonality_mode='multiplicative', seasonalities=[YEARLY, WEEKLY],
-                        extra=[{'name': n} for n in names], max_iter=150, residual_kernel=_lib.RK_WAVE)
+                        extra=[{'name': n} for n in names], max_iter=150)
     fc.fit_aligned(spec, ds, y, floor=np.zeros(N), cap=y.max(axis=1) * 1.1, extra=extra)
     r = fc.fit_aligned(spec, ds, y, floor=np.zeros(N), cap=y.max(axis=1) * 1.1, extra=extra)
     print('N', N, 'mean evals', r.n_eval.mean(), flush=True)
