@@ -312,6 +312,7 @@ static int ensure_ws(tsf_ctx *ctx, size_t bytes, int64_t N = 0, int NTmax = 0, i
         }
         (void)hipGetLastError();
     }
+    ctx->last_sp_flag = nullptr;       // (it points into the workspace that goes away here)
     if (ctx->ws) { HIP_TRY(ctx, hipFree(ctx->ws)); ctx->ws = nullptr; ctx->ws_bytes = 0; }
     HIP_TRY(ctx, hipMalloc(&ctx->ws, bytes));
     ctx->ws_bytes = bytes;
@@ -930,7 +931,7 @@ static int fit_host_one(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int align
                 // segments dealt out one position each in turn -- block b of a one-wave launch runs on XCD b % 8
                 // (observed, MI355X_MICROARCH: for speed only), so every XCD works its way through ITS segment and its
                 // 4 MB of L2 hold the two or three grids its resident blocks are on, instead of a share of all of them
-                // (10 000 series on 91 grids, the reference's model: 205 -> see profiles/r04_final3/ragged.txt).  Used
+                // (10 000 series on 91 grids, the reference's model: 205 -> 172 ms, tools/bench_ragged.py).  Used
                 // when the caller gave no cost hints; results do not depend on the order.
                 std::vector<int32_t> byg((size_t)N), ord((size_t)N);
                 {
