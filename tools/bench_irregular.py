@@ -1,0 +1,49 @@
+"""Times the fit path on a panel shaped like the reference's own fixture (tests/fixtures/model-input: every
+(series_id, dim_id) observed at its OWN irregular timestamps): N series of 600..730 rows, each with its own random
+gaps -- no two series share a timestamp vector, the timestamps lie on no lattice, so every series carries its own
+design table (172 KB for 26 columns) and the residual-form kernel streams it from HBM at every evaluation.
+Reference settings (logistic growth, multiplicative seasonality) and cfg2's model (quadratic form).
+    python tools/bench_irregular.py [N]"""
+import ctypes
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from time_series_spark_amd import _lib, forecaster as fc, synth  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+T = 730
+rng = np.random.default_rng(11)
+lens = rng.integers(600, T + 1, N)
+off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+YEARLY = {'name': 'yearly', 'period': 365.25, 'fourier_order': 10}
+WEEKLY = {'name': 'weekly', 'period': 7, 'fourier_order': 3}
+for growth, mode in (('logistic', 'multiplicative'), ('linear', 'additive')):
+    ds, y = synth.make_panel(N, T, growth, seed=751)
+    # own timestamps: the daily grid plus a per-row jitter of up to +-6 h (order kept), different for every series
+    dsr = np.concatenate([ds[:c] + rng.integers(-6 * 3600, 6 * 3600, c) * 1_000_000_000 for c in lens])
+    yr = np.concatenate([y[i][:c] for i, c in enumerate(lens)])
+    cap = np.array([y[i][:c].max() * 1.1 for i, c in enumerate(lens)])
+    spec = fc.ModelSpec(growth=growth, seasonality_mode=mode, seasonalities=[YEARLY, WEEKLY])
+    ctx = fc.get_context()
+    L = _lib.load()
+    ms = ctypes.c_float(0.0)
+    out = []
+    for rep in range(3):
+        ctx.check(L.tsf_set_profiling(ctx.handle, 1))
+        r = fc.fit_ragged(spec, off, dsr, yr, floor=np.zeros(N), cap=cap)
+        ctx.check(L.tsf_last_fit_kernel_ms(ctx.handle, ctypes.byref(ms)))
+        out.append(float(ms.value))
+    evals = float(r.n_eval.sum())
+    rows = float(lens.sum())
+    k = min(out) * 1e-3
+    # the design table of a series ([NT][KP = 28][64] doubles) is read once per evaluation of the residual form
+    x_bytes = float(np.sum(np.ceil(lens / 64) * 28 * 64 * 8 * r.n_eval)) if growth == 'logistic' else None
+    print(json.dumps({'panel': '%d series of 600..730 rows at their own irregular timestamps' % N, 'growth': growth, 'mode': mode,
+                      'fit_kernel_ms': out, 'series_per_s_kernel': N / k, 'mean_evals': evals / N,
+                      'design_table_bytes_read_by_the_evaluations': x_bytes,
+                      'design_table_GBps': None if x_bytes is None else x_bytes / k / 1e9,
+                      'status_ok': int((r.status > 0).sum())}), flush=True)
