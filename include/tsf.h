@@ -167,6 +167,32 @@ void tsf_destroy(tsf_ctx *ctx);
 const char *tsf_last_error(const tsf_ctx *ctx);
 int tsf_device_count(void);
 
+/* Route switches of ONE context (round 5; until round 4 these were process-wide environment variables read inside
+ * the library).  No result depends on a route -- the GPU tests compare the routes bit for bit, which is what the
+ * switches exist for, beside measurements.  value -1 (the state after tsf_create) = the library's own choice; what
+ * the other values mean is stated per option.  Not part of what the reference's path needs: a drop-in caller never
+ * calls this. */
+enum {
+    TSF_OPT_HARM = 0,        /* 0: the residual-form kernel streams every design column from the table instead of
+                                expanding the Fourier columns from the rows' base pairs */
+    TSF_OPT_LATTICE,         /* 0 / 1: never / always the shared lattice table of a ragged call on regular timestamps */
+    TSF_OPT_SPARSE_EXTRA,    /* 0: holiday columns of a wide model as dense columns */
+    TSF_OPT_FIT_GROUPED,     /* 0: wide models on the workgroup kernel from the first evaluation */
+    TSF_OPT_GRAM_SHARE,      /* 0: a ragged quadratic-form call builds Z^T Z per series even where calendars are shared */
+    TSF_OPT_GRID_ORDER,      /* 0: a ragged call does not start its series grouped by calendar */
+    TSF_OPT_GRID_SHARE,      /* 0: a ragged call keeps one set of grid tables per series */
+    TSF_OPT_RAGGED_SPLIT,    /* 0: tsf_fit_ragged never cuts a call into length classes; 2: always */
+    TSF_OPT_QUAD_REG,        /* quadratic-form kernel variant: 0 Z^T Z in LDS, 1 in registers */
+    TSF_OPT_QUAD_M2_LDS,     /* 0: the two-slot quadratic-form kernel reads Z^T Z from global memory */
+    TSF_OPT_QUAD_W4,         /* waves per workgroup of the aligned quadratic-form kernel: 8, 12 or 16 */
+    TSF_OPT_QUAD_RREG,       /* 0: residual-pass weights staged through memory */
+    TSF_OPT_NEWTON_BATCH,    /* series per resident wave from which Newton runs several series per wave (0: never) */
+    TSF_OPT_NEWTON_FLAGS, TSF_OPT_NEWTON_NS, TSF_OPT_NEWTON_LCAP, TSF_OPT_NEWTON_FILL,   /* dev knobs of that kernel */
+    TSF_OPT_COUNT
+};
+int tsf_set_option(tsf_ctx *ctx, int option, int value);
+int tsf_get_option(const tsf_ctx *ctx, int option);       /* -1: default (or a bad argument) */
+
 void tsf_spec_default(tsf_spec *spec);
 int tsf_spec_size(void);                      /* sizeof(tsf_spec), for binding self-checks */
 int tsf_grid_info_size(void);

@@ -191,14 +191,30 @@ static void free_series(cn_series *se)
 
 /* fbprophet fourier_series argument: 2.0*(i+1)*np.pi*t/period with
  * t = (1e-9 * ns) / 86400. (pandas 0.25 Timedelta.total_seconds = 1e-9 * asi8). */
+/* Canonical design values (round 5): only the FIRST harmonic of a seasonality goes through
+ * det_sincos, at fbprophet's own argument 2.0*1*pi*t/period; harmonic h + 1 follows from the
+ * three-term recurrence u[h+1] = 2 cos(theta) u[h] - u[h-1] (sin and cos both satisfy it;
+ * u[0] = 0 resp. 1), one fma per value.  A design row is then a function of two numbers per
+ * seasonality, which is what the residual-form kernel keeps per row and expands in registers
+ * (tsf_fit_kernels.h, eval_fg HARM) instead of streaming 2*order columns.  Against sin / cos of
+ * fbprophet's argument of harmonic h the values differ by <= ~h times the rounding of the base
+ * argument (<= 3e-11 for 15 years of daily seasonality; tests/test_oracle.py pins <= 1e-9). */
 static void fourier_row(const cn_spec *sp, int64_t ns, double *row /* original order */)
 {
     const double tdays = (1e-9 * (double)ns) / 86400.0;
     int col = 0;
     for (int s = 0; s < sp->n_seas; ++s) {
+        const double arg = (2.0 * 3.141592653589793 * tdays) / sp->seas_period[s];
+        double s1, c1;
+        det_sincos(arg, &s1, &c1);
+        const double c2 = 2.0 * c1;
+        double sp_ = 0.0, cp_ = 1.0, sc = s1, cc = c1;
         for (int h = 0; h < sp->seas_order[s]; ++h) {
-            const double arg = ((2.0 * (double)(h + 1)) * 3.141592653589793 * tdays) / sp->seas_period[s];
-            det_sincos(arg, &row[col], &row[col + 1]);
+            if (h > 0) {
+                const double sn = fma(c2, sc, -sp_), cn = fma(c2, cc, -cp_);
+                sp_ = sc; cp_ = cc; sc = sn; cc = cn;
+            }
+            row[col] = sc; row[col + 1] = cc;
             col += 2;
         }
     }

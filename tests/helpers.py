@@ -1,4 +1,5 @@
 """Shared test helpers: oracle <-> product spec conversion, bit comparison, case definitions."""
+import contextlib
 import os
 import sys
 
@@ -10,6 +11,33 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 DAY_NS = 86400 * 10 ** 9
+
+
+def canonical_fourier(dates, period, series_order):
+    """The CANONICAL design values of one seasonality (oracle/prophet_canon.c fourier_row, round 5): the first
+    harmonic from the deterministic sincos at fbprophet's argument, the others by the three-term recurrence --
+    in fbprophet's column order [sin 1, cos 1, sin 2, ...].  Drop-in for fbprophet_restated.fourier_series."""
+    import pandas as pd
+    from oracle import canon_lib as cl
+    ns = np.ascontiguousarray(pd.DatetimeIndex(dates).asi8, dtype=np.int64)
+    pad = np.concatenate([ns, [ns.max() + DAY_NS]])       # (the oracle wants >= 2 rows and a non-zero time span)
+    sp = cl.make_spec(seasonalities=[(period, series_order, 'additive', 10.0)], n_changepoints=0)
+    return cl.design(sp, pad, np.arange(float(pad.size)))['X'][:ns.size].copy()
+
+
+@contextlib.contextmanager
+def literal_on_canonical_design():
+    """Inside: the LITERAL restatement (oracle/fbprophet_restated.py) builds its seasonal features from the canonical
+    design values instead of numpy's sin / cos of every harmonic's argument.  The parity statements are split
+    (round-4 review, item 1): canonical X against literal X to 1e-9 (test_canonical_eval_matches_literal_stan), and
+    log-posterior / gradient / predict on the SAME X to the tolerances they always had (1e-12 / 1e-11 / 16 ulp)."""
+    import oracle.fbprophet_restated as fr
+    orig = fr.fourier_series
+    fr.fourier_series = canonical_fourier
+    try:
+        yield
+    finally:
+        fr.fourier_series = orig
 
 
 def bits(a):

@@ -34,7 +34,12 @@ def test_det_math_close_to_libm():
     assert L.cn_det_exp(800.0) == float('inf') and L.cn_det_exp(-800.0) == 0.0
 
 
-def _literal(case, n=0):
+def _literal(case, n=0, canonical_design=True):
+    """The literal model of a test case.  canonical_design: its seasonal features are the canonical design values
+    (helpers.literal_on_canonical_design), so that what is compared downstream is arithmetic on the SAME X."""
+    if canonical_design:
+        with helpers.literal_on_canonical_design():
+            return _literal(case, n, False)
     spec, ds, y, floor, cap, extra, fut, extra_future = helpers.make_case(case)
     growth, mode = spec.growth, spec.seasonality_mode
     # fbprophet: yearly_seasonality accepts a Fourier order as well as True/False
@@ -71,7 +76,16 @@ def test_canonical_eval_matches_literal_stan(case):
     csp = helpers.oracle_spec(spec)
     des = cl.design(csp, ds, y[0], floor[0], cap[0], extra)
     assert des['X'].shape == dat['X'].shape
-    assert np.max(np.abs(des['X'] - dat['X'])) <= 2 * ULP          # det_sincos vs np.sin/cos
+    # (1) the canonical design values against fbprophet's (numpy sin / cos of every harmonic's own argument): the
+    # base pair to 2 ulp (det_sincos), the recurrence's harmonics to h x the rounding of the base argument
+    X_lit = _literal(case, 0, canonical_design=False)[1]['X']
+    assert np.max(np.abs(des['X'] - X_lit)) <= 1e-9
+    nb = 0
+    for s in spec.seasonalities:
+        assert np.max(np.abs(des['X'][:, nb:nb + 2] - X_lit[:, nb:nb + 2])) <= 2 * ULP
+        nb += 2 * s['fourier_order']
+    # (2) everything below: the literal model ON the canonical X
+    assert np.array_equal(des['X'], dat['X'])
     assert np.array_equal(des['t'], dat['t'])
     assert np.array_equal(des['y_scaled'], dat['y'])
     assert np.array_equal(des['t_change'], dat['t_change'])
@@ -403,7 +417,8 @@ def test_upstream_known_answer_vectors_fourier_series():
         sp = cl.make_spec(seasonalities=[(u['period'], u['order'], 'additive', 10.0)])
         des = cl.design(sp, ds.asi8, np.arange(5.0))
         assert np.sum((des['X'][0] - true) ** 2) < 1e-13
-        assert np.max(np.abs(des['X'] - lit)) <= 2 * ULP
+        assert np.max(np.abs(des['X'][:, :2] - lit[:, :2])) <= 2 * ULP      # the base pair: det_sincos
+        assert np.max(np.abs(des['X'] - lit)) <= 1e-10                      # the recurrence's harmonics
 
 
 def test_upstream_auto_weekly_seasonality_and_zero_changepoints():
@@ -460,14 +475,23 @@ def test_canonical_predict_matches_literal_predict(case):
     m2 = type(m)(growth=spec.growth, seasonality_mode=spec.seasonality_mode,
                  yearly_seasonality=m.yearly_seasonality, weekly_seasonality=True, daily_seasonality=False,
                  holidays=m.holidays)
-    m2.fit(df, optimizer=lambda dat_, th0_, **kw: (o['theta'].copy(), {'status': o['status']}))
     fdf = pd.DataFrame({'ds': pd.to_datetime(fut)})
     if spec.growth == 'logistic':
         fdf['floor'], fdf['cap'] = floor[0], cap[0]
-    lit = m2.predict(fdf)
+    with helpers.literal_on_canonical_design():          # the literal predict on the canonical design values
+        m2.fit(df, optimizer=lambda dat_, th0_, **kw: (o['theta'].copy(), {'status': o['status']}))
+        lit = m2.predict(fdf)
     yhat, trend = cl.predict(csp, o, fut, floor[0], cap[0], exf)
     assert np.max(np.abs(yhat - lit['yhat'].values) / np.abs(lit['yhat'].values)) <= 16 * ULP
     assert np.max(np.abs(trend - lit['trend'].values) / np.abs(lit['trend'].values)) <= 16 * ULP
+    # ... and on fbprophet's own sin / cos of every harmonic: the design values differ by <= 1e-9 (above), the
+    # forecast by that times the seasonal coefficients
+    m3 = type(m)(growth=spec.growth, seasonality_mode=spec.seasonality_mode,
+                 yearly_seasonality=m.yearly_seasonality, weekly_seasonality=True, daily_seasonality=False,
+                 holidays=m.holidays)
+    m3.fit(df, optimizer=lambda dat_, th0_, **kw: (o['theta'].copy(), {'status': o['status']}))
+    lit = m3.predict(fdf)
+    assert np.max(np.abs(yhat - lit['yhat'].values) / np.abs(lit['yhat'].values)) <= 1e-9
 
 
 @pytest.mark.parametrize('growth', ['linear', 'logistic'])

@@ -3,6 +3,7 @@
 This is the only place Python touches the native library.  There is NO CPU fallback: if the
 shared library is missing or no GPU is visible, the functions raise.
 """
+import contextlib
 import ctypes
 import os
 
@@ -79,12 +80,17 @@ EXPORTS = ['tsf_create', 'tsf_destroy', 'tsf_last_error', 'tsf_device_count', 't
            'tsf_spec_size', 'tsf_grid_info_size', 'tsf_spec_K', 'tsf_theta_stride',
            'tsf_fit_aligned', 'tsf_fit_aligned_dev', 'tsf_fit_ragged', 'tsf_fit_ragged_dev',
            'tsf_predict', 'tsf_predict_dev', 'tsf_predict_intervals', 'tsf_predict_intervals_dev', 'tsf_eval', 'tsf_eval_quadratic', 'tsf_design', 'tsf_selftest_math',
-           'tsf_set_cost_hints', 'tsf_set_profiling', 'tsf_profile_read', 'tsf_last_fit_kernel_ms', 'tsf_last_fit_route',
+           'tsf_set_option', 'tsf_get_option', 'tsf_set_cost_hints', 'tsf_set_profiling', 'tsf_profile_read', 'tsf_last_fit_kernel_ms', 'tsf_last_fit_route',
            'tsf_pack_rows', 'tsf_pack_fetch', 'tsf_pack_free',
            'tsf_csv_read', 'tsf_csv_fetch', 'tsf_csv_columns', 'tsf_csv_malformed', 'tsf_csv_free', 'tsf_csv_write_forecasts', 'tsf_csv_write_forecasts_i32',
            'tsf_csv_discover', 'tsf_csv_discover_load', 'tsf_csv_read_loaded', 'tsf_csv_dir_paths', 'tsf_csv_dir_series_id', 'tsf_csv_dir_error_path', 'tsf_csv_dir_free']
 
 CSV_E_OPEN, CSV_E_PARSE, CSV_E_CODEC = -10, -11, -12          # TSF_CSV_E_* (include/tsf.h)
+
+# TSF_OPT_* (include/tsf.h): route switches of one context
+OPTIONS = ['harm', 'lattice', 'sparse_extra', 'fit_grouped', 'gram_share', 'grid_order', 'grid_share', 'ragged_split',
+           'quad_reg', 'quad_m2_lds', 'quad_w4', 'quad_rreg', 'newton_batch', 'newton_flags', 'newton_ns', 'newton_lcap',
+           'newton_fill']
 
 _lib = None
 
@@ -134,6 +140,8 @@ def load():
     L.tsf_design.argtypes = [vp, psp, i32, vp, vp, vp, vp, vp]
     L.tsf_selftest_math.argtypes = [vp, i32, i64, vp, vp, vp]
     L.tsf_set_cost_hints.argtypes = [vp, vp, i64]
+    L.tsf_set_option.argtypes = [vp, i32, i32]
+    L.tsf_get_option.argtypes = [vp, i32]
     L.tsf_set_profiling.argtypes = [vp, i32]
     L.tsf_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_float), i32, ctypes.POINTER(i32)]
     L.tsf_last_fit_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
@@ -186,6 +194,11 @@ class Context(object):
                            'This library has no CPU fallback.' % (device, rc))
         self._h = h
         self.device = int(device)
+        # measurement tools: TSF_OPTIONS="harm=0,sparse_extra=0" sets route switches on every context this PROCESS
+        # creates (read here, in the Python host layer; the library itself reads no environment variable for routes)
+        for item in filter(None, os.environ.get('TSF_OPTIONS', '').split(',')):
+            k, v = item.split('=')
+            self.set_option(k.strip(), int(v))
 
     def close(self):
         if getattr(self, '_h', None):
@@ -206,6 +219,26 @@ class Context(object):
     @property
     def handle(self):
         return self._h
+
+    def set_option(self, name, value=-1):
+        """tsf_set_option: a route switch of THIS context (name: one of OPTIONS; -1 / None = the library's default).
+        Results never depend on a route; tests and measurements use this."""
+        self.check(load().tsf_set_option(self._h, OPTIONS.index(name), -1 if value is None else int(value)))
+
+    def get_option(self, name):
+        return int(load().tsf_get_option(self._h, OPTIONS.index(name)))
+
+    @contextlib.contextmanager
+    def options(self, **kw):
+        """with ctx.options(harm=0, sparse_extra=0): ... -- set, run, restore."""
+        old = {k: self.get_option(k) for k in kw}
+        try:
+            for k, v in kw.items():
+                self.set_option(k, v)
+            yield self
+        finally:
+            for k, v in old.items():
+                self.set_option(k, v)
 
 
 def default_spec():

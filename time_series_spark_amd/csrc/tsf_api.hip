@@ -48,6 +48,7 @@ struct tsf_ctx {
     int order_busy[2];
     int n_cu;               // compute units of the device (persistent kernels: one workgroup each)
     const int *last_sp_flag;  // sparse-column route of the last fit call: its device flag (in the workspace), or null
+    int opt[TSF_OPT_COUNT];   // tsf_set_option: route switches of THIS context (-1 = the library's default)
     int profiling;
     hipEvent_t ev0[TSF_PROFILE_RING], ev1[TSF_PROFILE_RING];
     int ev_created;
@@ -92,6 +93,7 @@ extern "C" int tsf_create(int device_id, tsf_ctx **out)
     c->order_ev[0] = c->order_ev[1] = nullptr; c->order_busy[0] = c->order_busy[1] = 0;
     c->profiling = 0; c->ev_created = 0; c->ev_count = 0;
     c->last_sp_flag = nullptr;
+    for (int i = 0; i < TSF_OPT_COUNT; ++i) c->opt[i] = -1;
     if (hipMalloc((void **)&c->d_spec, sizeof(DevSpec)) != hipSuccess) { delete c; return -2; }
     {
         hipDeviceProp_t prop;
@@ -123,6 +125,20 @@ extern "C" void tsf_destroy(tsf_ctx *ctx)
 }
 
 extern "C" const char *tsf_last_error(const tsf_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+extern "C" int tsf_set_option(tsf_ctx *ctx, int option, int value)
+{
+    if (!ctx) return -1;
+    if (option < 0 || option >= TSF_OPT_COUNT) return fail(ctx, "unknown option");
+    ctx->opt[option] = value;
+    return 0;
+}
+
+extern "C" int tsf_get_option(const tsf_ctx *ctx, int option)
+{
+    if (!ctx || option < 0 || option >= TSF_OPT_COUNT) return -1;
+    return ctx->opt[option];
+}
 
 extern "C" void tsf_spec_default(tsf_spec *s)
 {
@@ -190,10 +206,8 @@ static int build_devspec(tsf_ctx *ctx, const tsf_spec *s, DevSpec *d, int *mode_
     for (int i = 0; i < s->n_seas; ++i) {
         if (s->seas_order[i] < 1) return fail(ctx, "fourier order must be >= 1");
         if (!(s->seas_prior_scale[i] > 0.0) || !(s->seas_period[i] > 0.0)) return fail(ctx, "bad seasonality prior scale / period");
+        d->seas_period[i] = s->seas_period[i]; d->seas_order[i] = s->seas_order[i]; d->seas_col[i] = col;
         for (int h = 0; h < s->seas_order[i]; ++h) {
-            d->pair_period[np] = s->seas_period[i];
-            d->pair_mult[np] = 2.0 * (double)(h + 1);
-            d->pair_col[np] = col;
             np++;
             mode[col] = s->seas_mode[i]; pr[col] = s->seas_prior_scale[i]; col++;
             mode[col] = s->seas_mode[i]; pr[col] = s->seas_prior_scale[i]; col++;
@@ -213,6 +227,15 @@ static int build_devspec(tsf_ctx *ctx, const tsf_spec *s, DevSpec *d, int *mode_
     d->KP = pick_KP(K, s->n_changepoints, m == 2);
     d->n_seas = s->n_seas; d->n_extra = s->n_extra; d->n_pairs = np;
     d->max_iter = s->max_iter; d->history = s->history;
+    // harmonic structure (harm_code): one column mode (then the internal column order is fbprophet's: the seasonalities'
+    // Fourier columns first, in order) and at most three seasonalities; whether a kernel is compiled for it is the
+    // launch function's business (tsf_inst.inc)
+    d->harm = 0;
+    if (m != 2 && s->n_seas >= 1 && s->n_seas <= 3) {
+        bool ok = true;
+        for (int i = 0; i < s->n_seas; ++i) ok = ok && s->seas_order[i] <= 255;
+        if (ok) d->harm = harm_code(s->seas_order[0], s->n_seas > 1 ? s->seas_order[1] : 0, s->n_seas > 2 ? s->seas_order[2] : 0);
+    }
     d->cp_range = s->changepoint_range; d->tau = s->changepoint_prior_scale;
     d->init_alpha = s->init_alpha; d->tol_obj = s->tol_obj; d->tol_rel_obj = s->tol_rel_obj;
     d->tol_grad = s->tol_grad; d->tol_rel_grad = s->tol_rel_grad; d->tol_param = s->tol_param;
@@ -223,7 +246,7 @@ static int build_devspec(tsf_ctx *ctx, const tsf_spec *s, DevSpec *d, int *mode_
 // ---- workspace ------------------------------------------------------------------------------
 
 struct WsLayout {
-    size_t gtab, stab, tw, cw, Xw, yw, Mg, Mslot, rbuf, counter, uw, Xu, spm, spp;
+    size_t gtab, stab, tw, cw, Xw, yw, Mg, Mslot, rbuf, counter, uw, Xu, spm, spp, Bw;
     size_t mXF, mXB, mXT, mtq, mcq, mcpof, myq, mhist;      // matrix-core path (tsf_mfma_kernels.h)
     size_t clist, cslots;                                   // cooperative tail (tsf_coop_kernels.h)
     size_t total;
@@ -251,7 +274,7 @@ static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 static WsLayout ws_layout(int64_t N, int64_t n_grids, int NTmax, int KP, int quad_P4 = 0,
                           int quad_slots = 0, int quad_ragged = 0, int64_t lat_U = 0,
                           const MfmaPlan *mp = nullptr, int coop_slots = 0, int coop_stride = 0, int64_t quad_pre = 0,
-                          bool sparse = false)
+                          bool sparse = false, int bw_ns = 0)
 {
     WsLayout l;
     size_t off = 0;
@@ -271,6 +294,8 @@ static WsLayout ws_layout(int64_t N, int64_t n_grids, int NTmax, int KP, int qua
     // sparse indicator columns (SP_* in tsf_fit_kernels.h): the lanes' entries and the columns' fold programs per grid
     l.spm = off; off = align_up(off + (sparse ? sizeof(uint32_t) * (size_t)n_grids * SP_M * W : 0));
     l.spp = off; off = align_up(off + (sparse ? sizeof(unsigned long long) * (size_t)n_grids * SP_MAXC : 0));
+    // base pairs of the Fourier columns (fit_kernel<..., HARM>): two doubles per seasonality and row
+    l.Bw = off; off = align_up(off + sizeof(double) * (size_t)n_grids * NTmax * bw_ns * 2 * W);
     l.uw = off; off = align_up(off + (lat_U > 0 ? sizeof(int32_t) * (size_t)n_grids * NTmax * W : 0));
     l.Xu = off; off = align_up(off + (lat_U > 0 ? sizeof(double) * (size_t)lat_U * KP : 0));
     const bool mf = mp && mp->on;
@@ -510,8 +535,20 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     // instead of once per series inside the fit kernel -- when that at least halves the builds (TSF_GRAM_SHARE=0: never)
     const char *egs = getenv("TSF_GRAM_SHARE");
     const int64_t quad_pre = (quad && !aligned && grid_of && n_grids * 2 <= N && !(egs && atoi(egs) == 0)) ? n_grids : 0;
+    // Fourier columns expanded from the rows' base pairs (eval_fg HARM): the residual-form one-wave kernel of models
+    // whose harmonic structure has a compiled kernel -- yearly 10 + weekly 3 on the 28-column kernel and its
+    // sparse-column form, weekly 3 + daily 4 (16 columns), weekly 3 (8 columns); never with the lattice table or the
+    // matrix-core / workgroup-from-the-start routes.  tsf_set_option(TSF_OPT_HARM, 0): never.
+    int harm = 0;
+    if (!quad && !newton && !mp.on && theta_in == nullptr && lat_U == 0 && ctx->opt[TSF_OPT_HARM] != 0 &&
+        !(coop && coop_after == COOP_DIRECT) && spec->residual_kernel != TSF_RK_COOP) {
+        if ((hs.harm == HARM_Y10_W3 && (hs.KP == 28 || sparse_try)) || (hs.harm == HARM_W3_D4 && hs.KP == 16) ||
+            (hs.harm == HARM_W3 && hs.KP == 8))
+            harm = hs.harm;
+    }
+    const int bw_ns = harm ? hs.n_seas : 0;
     const WsLayout l = ws_layout(N, n_grids, NTmax, hs.KP, qp.P4, qp.slots, (quad || newton_quad) && !aligned, lat_U, &mp,
-                                 coop_slots, coop_stride, quad_pre, sparse_try);
+                                 coop_slots, coop_stride, quad_pre, sparse_try, bw_ns);
     rc = ensure_ws(ctx, l.total, N, NTmax, !aligned);
     if (rc) return rc;
     char *ws = (char *)ctx->ws;
@@ -525,7 +562,7 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     if (lat_U > 0) {
         double *Xu = (double *)(ws + l.Xu);
         HIP_TRY(ctx, hipMemsetAsync(Xu, 0, sizeof(double) * (size_t)lat_U * hs.KP, st));
-        const int64_t work = lat_U * (hs.n_pairs > 0 ? hs.n_pairs : 1);
+        const int64_t work = lat_U * (hs.n_seas > 0 ? hs.n_seas : 1);
         hipLaunchKernelGGL(setup_lattice_kernel, dim3((unsigned)((work + 255) / 256 > 65535 ? 65535 : (work + 255) / 256)),
                            dim3(256), 0, st, ctx->d_spec, lat_U, lat_base, lat_step, Xu);
         HIP_TRY(ctx, hipGetLastError());
@@ -536,7 +573,8 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     hipLaunchKernelGGL(setup_grid_kernel, dim3((unsigned)n_grids), dim3(256), 0, st, ctx->d_spec,
                        (int)n_grids, aligned ? nullptr : offsets, T, ds, extra,
                        aligned ? (int64_t)T : total_rows, NTmax, gtab, tw, cw, Xw,
-                       (int32_t *)(ws + l.uw), lat_base, lat_U > 0 ? lat_step : (int64_t)0, grid_rows);
+                       (int32_t *)(ws + l.uw), lat_base, lat_U > 0 ? lat_step : (int64_t)0, grid_rows,
+                       harm ? (double *)(ws + l.Bw) : (double *)nullptr);
     HIP_TRY(ctx, hipGetLastError());
     if (sparse_try) {
         int *sp_bad = (int *)(ws + l.counter) + 8;
@@ -566,6 +604,7 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     a.theta_in = theta_in; a.grad_out = grad_out;
     a.uw = (const int32_t *)(ws + l.uw); a.Xu = (const double *)(ws + l.Xu); a.xidx = lat_U > 0 ? 1 : 0;
     a.grid_of = grid_of;
+    a.Bw = harm ? (const double *)(ws + l.Bw) : nullptr; a.bw_ns = bw_ns; a.harm = harm;
     ctx->last_sp_flag = nullptr;
     if (sparse_try) {
         a.sp_meta = (const uint32_t *)(ws + l.spm); a.sp_prog = (const unsigned long long *)(ws + l.spp);
@@ -1139,8 +1178,8 @@ static int launch_predict(tsf_ctx *ctx, const DevSpec &hs, PredictArgs a, int64_
             HIP_TRY(ctx, hipMalloc((void **)&ctx->fut_tab, need));
             ctx->fut_tab_bytes = need;
         }
-        if (!*tab_ready && hs.n_pairs > 0) {
-            const int work = a.H * hs.n_pairs;
+        if (!*tab_ready && hs.n_seas > 0) {
+            const int work = a.H * hs.n_seas;
             hipLaunchKernelGGL(future_design_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st,
                                ctx->d_spec, a.H, a.ds_future, ctx->fut_tab);
             HIP_TRY(ctx, hipGetLastError());

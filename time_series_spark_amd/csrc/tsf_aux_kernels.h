@@ -113,7 +113,8 @@ __global__ void setup_grid_kernel(const DevSpec *__restrict__ sp, int n_grids,
                                   double *__restrict__ tw_all, uint16_t *__restrict__ cw_all,
                                   double *__restrict__ Xw_all, int32_t *__restrict__ uw_all,
                                   int64_t lat_base, int64_t lat_step,
-                                  const int64_t *__restrict__ grid_rows = nullptr)
+                                  const int64_t *__restrict__ grid_rows = nullptr,
+                                  double *__restrict__ Bw_all = nullptr)
 {
     const int g = blockIdx.x;
     if (g >= n_grids) return;
@@ -184,18 +185,22 @@ __global__ void setup_grid_kernel(const DevSpec *__restrict__ sp, int n_grids,
         if (lat_step > 0) uw[q * W + L] = (int32_t)((ds[i] - lat_base) / lat_step);
     }
     if (lat_step > 0) return;       // design rows come from the shared lattice table (setup_lattice_kernel)
-    // Fourier columns: one (row, harmonic) pair per work item
-    const int n_pairs = sp->n_pairs;
-    for (int w = threadIdx.x; w < T * n_pairs; w += blockDim.x) {
-        const int i = w / n_pairs, pr = w - i * n_pairs;
+    // Fourier columns: one (row, seasonality) per work item -- the base pair from dm_sincos, the harmonics by the
+    // recurrence (fourier_harmonics, tsf_common.h).  Bw (where given): the base pairs alone, [step][seasonality][lane][2],
+    // the table of the residual-form kernel that expands the harmonics in registers (eval_fg HARM).
+    const int n_seas = sp->n_seas;
+    double *Bw = Bw_all ? Bw_all + (size_t)g * NTmax * n_seas * 2 * W : nullptr;
+    for (int w = threadIdx.x; w < T * n_seas; w += blockDim.x) {
+        const int i = w / n_seas, se = w - i * n_seas;
         const int L = i / NT, q = i - L * NT;
-        const double tdays = (1e-9 * (double)ds[i]) / 86400.0;
-        const double arg = (sp->pair_mult[pr] * 3.141592653589793 * tdays) / sp->pair_period[pr];
-        double s, c;
-        dm_sincos(arg, s, c);
-        const int col = sp->pair_col[pr];
-        Xw[((size_t)q * KP + sp->inv_perm[col]) * W + L] = s;
-        Xw[((size_t)q * KP + sp->inv_perm[col + 1]) * W + L] = c;
+        double s1, c1;
+        dm_sincos(fourier_base_arg(ds[i], sp->seas_period[se]), s1, c1);
+        if (Bw) { Bw[(((size_t)q * n_seas + se) * W + L) * 2] = s1; Bw[(((size_t)q * n_seas + se) * W + L) * 2 + 1] = c1; }
+        const int col0 = sp->seas_col[se];
+        fourier_harmonics(s1, c1, sp->seas_order[se], [&](int h, double sv, double cv) {
+            Xw[((size_t)q * KP + sp->inv_perm[col0 + 2 * (h - 1)]) * W + L] = sv;
+            Xw[((size_t)q * KP + sp->inv_perm[col0 + 2 * (h - 1) + 1]) * W + L] = cv;
+        });
     }
     const int nf = sp->K - sp->n_extra;
     for (int w = threadIdx.x; w < T * sp->n_extra; w += blockDim.x) {
@@ -211,20 +216,20 @@ __global__ void setup_grid_kernel(const DevSpec *__restrict__ sp, int n_grids,
 __global__ void setup_lattice_kernel(const DevSpec *__restrict__ sp, int64_t U, int64_t lat_base,
                                      int64_t lat_step, double *__restrict__ Xu)
 {
-    const int n_pairs = sp->n_pairs, KP = sp->KP;
-    const int64_t total = U * n_pairs;
+    const int n_seas = sp->n_seas, KP = sp->KP;
+    const int64_t total = U * n_seas;
     for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < total;
          w += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t u = w / n_pairs;
-        const int pr = (int)(w - u * n_pairs);
+        const int64_t u = w / n_seas;
+        const int se = (int)(w - u * n_seas);
         const int64_t ts = lat_base + u * lat_step;
-        const double tdays = (1e-9 * (double)ts) / 86400.0;
-        const double arg = (sp->pair_mult[pr] * 3.141592653589793 * tdays) / sp->pair_period[pr];
-        double s, c;
-        dm_sincos(arg, s, c);
-        const int col = sp->pair_col[pr];
-        Xu[(size_t)u * KP + sp->inv_perm[col]] = s;
-        Xu[(size_t)u * KP + sp->inv_perm[col + 1]] = c;
+        double s1, c1;
+        dm_sincos(fourier_base_arg(ts, sp->seas_period[se]), s1, c1);
+        const int col0 = sp->seas_col[se];
+        fourier_harmonics(s1, c1, sp->seas_order[se], [&](int h, double sv, double cv) {
+            Xu[(size_t)u * KP + sp->inv_perm[col0 + 2 * (h - 1)]] = sv;
+            Xu[(size_t)u * KP + sp->inv_perm[col0 + 2 * (h - 1) + 1]] = cv;
+        });
     }
 }
 
@@ -347,14 +352,15 @@ struct PredictArgs {
 __global__ void future_design_kernel(const DevSpec *sp, int H, const int64_t *ds_future, double *Xf)
 {
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (i >= H * sp->n_pairs) return;
-    const int pr = i / H, h = i - pr * H;
-    const double tdays = (1e-9 * (double)ds_future[h]) / 86400.0;
-    const double arg = (sp->pair_mult[pr] * 3.141592653589793 * tdays) / sp->pair_period[pr];
-    double sv, cv;
-    dm_sincos(arg, sv, cv);
-    Xf[(size_t)sp->pair_col[pr] * H + h] = sv;
-    Xf[(size_t)(sp->pair_col[pr] + 1) * H + h] = cv;
+    if (i >= H * sp->n_seas) return;
+    const int se = i / H, h = i - se * H;
+    double s1, c1;
+    dm_sincos(fourier_base_arg(ds_future[h], sp->seas_period[se]), s1, c1);
+    const int col0 = sp->seas_col[se];
+    fourier_harmonics(s1, c1, sp->seas_order[se], [&](int hh, double sv, double cv) {
+        Xf[(size_t)(col0 + 2 * (hh - 1)) * H + h] = sv;
+        Xf[(size_t)(col0 + 2 * (hh - 1) + 1) * H + h] = cv;
+    });
 }
 
 constexpr int PREDICT_WAVES = 4;        // series per workgroup
@@ -415,17 +421,18 @@ __global__ __launch_bounds__(PREDICT_WAVES * 64) void predict_kernel(PredictArgs
                 else xm = __builtin_fma(xv, beta[col], xm);
             }
         } else {
-            const double tdays = (1e-9 * (double)dsv) / 86400.0;
             for (int pass = 0; pass < 2; ++pass) {
                 double acc = 0.0;
-                for (int pr = 0; pr < sp->n_pairs; ++pr) {
-                    const int col = sp->pair_col[pr];
-                    if ((sp->inv_perm[col] < Ka) != (pass == 0)) continue;
-                    const double arg = (sp->pair_mult[pr] * 3.141592653589793 * tdays) / sp->pair_period[pr];
-                    double sv, cv;
-                    dm_sincos(arg, sv, cv);
-                    acc = __builtin_fma(sv, beta[col], acc);
-                    acc = __builtin_fma(cv, beta[col + 1], acc);
+                for (int se = 0; se < sp->n_seas; ++se) {
+                    const int col0 = sp->seas_col[se];
+                    if ((sp->inv_perm[col0] < Ka) != (pass == 0)) continue;       // (a seasonality's columns share one mode)
+                    double s1, c1;
+                    dm_sincos(fourier_base_arg(dsv, sp->seas_period[se]), s1, c1);
+                    fourier_harmonics(s1, c1, sp->seas_order[se], [&](int hh, double sv, double cv) {
+                        const int col = col0 + 2 * (hh - 1);
+                        acc = __builtin_fma(sv, beta[col], acc);
+                        acc = __builtin_fma(cv, beta[col + 1], acc);
+                    });
                 }
                 for (int e = 0; e < sp->n_extra; ++e) {
                     const int col = nf + e;

@@ -70,10 +70,47 @@ struct DevSpec {
     int32_t inv_perm[TSF_MAX_P];        // original column -> internal column
     int32_t perm[TSF_MAX_P];            // internal column -> original column
     double prior[TSF_MAX_P];            // prior scale per internal column
-    double pair_period[TSF_MAX_K];      // per (seasonality, harmonic) pair
-    double pair_mult[TSF_MAX_K];        // 2.0 * (h + 1)
-    int32_t pair_col[TSF_MAX_K];        // original column of the sin term
+    double seas_period[TSF_MAX_SEAS];   // per seasonality: period in days,
+    int32_t seas_order[TSF_MAX_SEAS];   // Fourier order,
+    int32_t seas_col[TSF_MAX_SEAS];     // original column of sin(1 theta) (columns: sin 1, cos 1, sin 2, cos 2, ...)
+    int32_t harm;                       // harmonic structure the residual-form kernel is compiled for (HARM_*), 0 = none
+    int32_t pad_;
 };
+
+// Canonical design values (round 5; oracle fourier_row): the FIRST harmonic of a seasonality from dm_sincos at
+// fbprophet's argument 2 pi t / period, harmonic h + 1 by u[h+1] = 2 cos(theta) u[h] - u[h-1] (one fma per value;
+// u[0] = 0 for the sines, 1 for the cosines).  A design row is a function of the base pair (sin theta, cos theta) of
+// each seasonality: the residual-form kernel keeps only those per row (FitArgs::Bw) and expands them in registers.
+__device__ __forceinline__ double fourier_base_arg(int64_t ds_ns, double period)
+{
+    const double tdays = (1e-9 * (double)ds_ns) / 86400.0;
+    return (2.0 * 3.141592653589793 * tdays) / period;
+}
+// emit(h, sin(h theta), cos(h theta)) for h = 1 .. order
+template <class F>
+__device__ __forceinline__ void fourier_harmonics(double s1, double c1, int order, F &&emit)
+{
+    const double c2 = 2.0 * c1;
+    double sp = 0.0, cp = 1.0, sc = s1, cc = c1;
+    for (int h = 1; h <= order; ++h) {
+        if (h > 1) {
+            const double sn = __builtin_fma(c2, sc, -sp), cn = __builtin_fma(c2, cc, -cp);
+            sp = sc; cp = cc; sc = sn; cc = cn;
+        }
+        emit(h, sc, cc);
+    }
+}
+
+// Harmonic structure of a model as a compile-time code: the Fourier orders of up to three seasonalities, one byte
+// each, in column order (fit_kernel<..., HARM>: the kernel that reads the base pairs FitArgs::Bw and expands the
+// harmonics in registers).  0 = none (design values streamed from the table Xw).
+constexpr int harm_code(int o0, int o1 = 0, int o2 = 0) { return o0 | (o1 << 8) | (o2 << 16); }
+constexpr int harm_order(int harm, int s) { return (harm >> (8 * s)) & 255; }
+constexpr int harm_ns(int harm) { return (harm_order(harm, 0) > 0) + (harm_order(harm, 1) > 0) + (harm_order(harm, 2) > 0); }
+constexpr int harm_kf(int harm) { return 2 * (harm_order(harm, 0) + harm_order(harm, 1) + harm_order(harm, 2)); }
+constexpr int HARM_Y10_W3 = harm_code(10, 3);       // yearly + weekly: daily data of two years or more (K = 26)
+constexpr int HARM_W3_D4 = harm_code(3, 4);         // weekly + daily: sub-daily data of less than two years (K = 14: the reference's fixture)
+constexpr int HARM_W3 = harm_code(3);               // weekly alone (K = 6)
 
 // Per-grid derived tables (one grid per call for aligned panels, one per series for ragged).
 struct GridTab {

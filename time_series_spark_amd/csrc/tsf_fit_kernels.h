@@ -17,6 +17,8 @@ struct SeriesView {
     const unsigned short *sp_list;      // (SPARSE kernels) [SP_M + 1][64] entry words of the lanes, last row first, in LDS
     int S_out;                          // changepoints in the caller's layout (S = 1 > S_out = 0: dummy changepoint)
     const double *tw, *yw, *Xw;         // step-major tables
+    const double *Bw;                   // (HARM kernels) base pairs [NT][seasonality][64][2]: sin theta, cos theta of the row
+    int n_xd;                           // (HARM kernels) dense explicit columns behind the Fourier columns (read from Xw)
     const int32_t *uw;                  // (lattice panels) row -> row of the shared table Xu, step-major
     const double *Xu;                   // (lattice panels) [U][KP] design rows of the timestamp lattice
     const uint16_t *cw;
@@ -339,7 +341,42 @@ __device__ __forceinline__ bool eval_tail(const DevSpec *__restrict__ sp, const 
     return __any(bad);
 }
 
+// The Fourier columns of one seasonality from its base pair, in column order (sin h, cos h; h = 1 .. O): the canonical
+// recurrence of fourier_harmonics (tsf_common.h) written out at compile time -- emit(column, value) sees a constant column.
+template <int O, int COL0, class F>
+__device__ __forceinline__ void harm_columns(double s1, double c1, F &&emit)
+{
+    if constexpr (O > 0) {
+        const double c2 = 2.0 * c1;
+        double sp = 0.0, cp = 1.0, sc = s1, cc = c1;
+#pragma unroll
+        for (int h = 1; h <= O; ++h) {
+            if (h > 1) {
+                const double sn = __builtin_fma(c2, sc, -sp), cn = __builtin_fma(c2, cc, -cp);
+                sp = sc; cp = cc; sc = sn; cc = cn;
+            }
+            emit(COL0 + 2 * (h - 1), sc);
+            emit(COL0 + 2 * (h - 1) + 1, cc);
+        }
+    }
+}
+// all Fourier columns of a row: bp[s] = (sin theta_s, cos theta_s)
+template <int HARM, class F>
+__device__ __forceinline__ void harm_row(const double2 *bp, F &&emit)
+{
+    constexpr int O0 = harm_order(HARM, 0), O1 = harm_order(HARM, 1), O2 = harm_order(HARM, 2);
+    harm_columns<O0, 0>(bp[0].x, bp[0].y, emit);
+    if constexpr (O1 > 0) harm_columns<O1, 2 * O0>(bp[1].x, bp[1].y, emit);
+    if constexpr (O2 > 0) harm_columns<O2, 2 * (O0 + O1)>(bp[2].x, bp[2].y, emit);
+}
+
 // MODE: 0 all columns additive, 1 all multiplicative, 2 mixed (Ka additive first)
+// HARM != 0 (round 5): the Fourier columns are not read but EXPANDED from the row's base pairs (FitArgs::Bw: two
+// doubles per seasonality and row instead of 2 x order) by the recurrence that defines the canonical design values --
+// the same bits as the table Xw holds --, once for X.beta and once more for the per-column sums: no design row is held,
+// the kernel runs at three waves per SIMD, and a series' per-evaluation traffic is its base pairs, t, y and the segment
+// word (38 KB for 730 rows of the yearly + weekly model instead of 185 KB).  Dense explicit columns behind the Fourier
+// columns (sv.n_xd of them) still come from Xw.
 // L: the wave's LDS carve-up (WaveLds, or NewtonLds: any struct with th, ks, mc, tp1, tp2, tot1,
 // tot2, d1, d2, rb, ab, accR)
 // GNTR > 0 (wide models, KP > 32, series of <= 64 GNTR rows): the per-column sums in groups of 8 columns AFTER
@@ -347,7 +384,7 @@ __device__ __forceinline__ bool eval_tail(const DevSpec *__restrict__ sp, const 
 // With all 64 accumulators live the kernel needs 379 registers (one wave per SIMD, design values through AGPRs);
 // grouped it runs at two.  Column by column the fma chain (rows q descending) and the reduction network are those
 // of the ungrouped form: same bits.
-template <int KP, int GROWTH, int MODE, int PPL, bool XIDX = false, class L = WaveLds<KP, PPL>, int GNTR = 0, bool SPARSE = false>
+template <int KP, int GROWTH, int MODE, int PPL, bool XIDX = false, class L = WaveLds<KP, PPL>, int GNTR = 0, bool SPARSE = false, int HARM = 0>
 __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesView &sv,
                                         L &lds, const double (&th)[PPL],
                                         double &f_out, double (&g)[PPL] FT_ARGS)
@@ -361,6 +398,9 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
 #endif
     constexpr bool HOLD = KP <= TSF_FIT_HOLD_MAX;
     static_assert(!SPARSE || (KP == SP_DENSE && HOLD && !XIDX && GNTR == 0 && MODE != 2), "sparse columns: the 28-column row in registers, one column mode");
+    static_assert(HARM == 0 || (HOLD && !XIDX && GNTR == 0 && MODE != 2 && harm_kf(HARM) <= KP), "harmonics in registers: the 28-column row form, one column mode");
+    constexpr int KF = harm_kf(HARM), NS = harm_ns(HARM) > 0 ? harm_ns(HARM) : 1;
+    constexpr int NXD = HARM != 0 ? KP - KF : 0;            // dense explicit columns at most
     constexpr int XCOLS = SPARSE ? 64 : KP;     // columns per row of the design table
     sv.n_eval++;
     const double k = theta_at<PPL>(th, 0), m = theta_at<PPL>(th, 1), ls = theta_at<PPL>(th, 2);
@@ -408,9 +448,24 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
             const double yi = sv.yw[idx];
             constexpr int XS = XIDX ? 1 : W;      // stride between the columns of a design row
             const double *xp = XIDX ? sv.Xu + (size_t)sv.uw[idx] * KP : sv.Xw + (size_t)q * XCOLS * W + lane;
-            double x[HOLD ? KP : 1];
+            double x[(HOLD && HARM == 0) ? KP : 1];
             double xa = 0.0, xm = 0.0;
-            if (HOLD) {
+            double2 bp[NS];
+            double xd[NXD > 0 ? NXD : 1];
+            if constexpr (HARM != 0) {
+                const double2 *bq = reinterpret_cast<const double2 *>(sv.Bw) + (size_t)q * NS * W + lane;
+#pragma unroll
+                for (int se = 0; se < NS; ++se) bp[se] = bq[se * W];
+                double ch = 0.0;
+                harm_row<HARM>(bp, [&](int j, double v) { ch = __builtin_fma(v, bs[j], ch); });
+                if (NXD > 0 && sv.n_xd > 0) {
+#pragma unroll
+                    for (int j = 0; j < NXD; ++j) xd[j] = xp[(KF + j) * XS];
+#pragma unroll
+                    for (int j = 0; j < NXD; ++j) ch = __builtin_fma(xd[j], bs[KF + j], ch);
+                }
+                if (MODE == 0) xa = ch; else xm = ch;
+            } else if (HOLD) {
 #pragma unroll
                 for (int j = 0; j < (HOLD ? KP : 1); ++j) {
                     if (XIDX) {       // gathered row: 16-byte loads (rows are KP*8 bytes, KP even)
@@ -468,7 +523,21 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
             const double r = yi - mu;
             sse = __builtin_fma(r, r, sse);
             const double rg = r * gtr;
-            if constexpr (GROUPED) {
+            if constexpr (HARM != 0) {
+                // per-column partial sums: the harmonics once more (same recurrence, same bits).  The empty asm keeps the
+                // compiler from recognising the second expansion as the first and holding all 2 x order values of the
+                // row across the trend arithmetic (52 registers for yearly + weekly: spills at three waves per SIMD).
+#ifndef TSF_HARM_HOLD
+#pragma unroll
+                for (int se = 0; se < NS; ++se) { asm volatile("" : "+v"(bp[se].x)); asm volatile("" : "+v"(bp[se].y)); }
+#endif
+                const double wv = (MODE == 0) ? r : rg;
+                harm_row<HARM>(bp, [&](int j, double v) { acc[j] = __builtin_fma(v, wv, acc[j]); });
+                if (NXD > 0 && sv.n_xd > 0) {
+#pragma unroll
+                    for (int j = 0; j < NXD; ++j) acc[KF + j] = __builtin_fma(xd[j], wv, acc[KF + j]);
+                }
+            } else if constexpr (GROUPED) {
                 wr[GROUPED ? q : 0] = r;
                 if (MODE != 0) wg[(GROUPED && MODE != 0) ? q : 0] = rg;
             } else {
@@ -656,6 +725,9 @@ struct FitArgs {
     // ragged panel whose timestamps all lie on one lattice base + u*step: the design row of a
     // timestamp is a function of the timestamp only, so ONE table over the lattice serves every
     // series (L2 resident) instead of a per-series copy streamed from HBM at every evaluation
+    // base pairs of the Fourier columns (setup_grid_kernel; fit_kernel<..., HARM>): [grid][NTmax][bw_ns][64][2]
+    const double *Bw;
+    int bw_ns, harm;                    // seasonalities per row of Bw; the model's harmonic structure (harm_code), 0 = none compiled
     const int32_t *uw;                  // [grid][NTmax][64] lattice row of each series row
     const double *Xu;                   // [U][KP]
     int xidx;
@@ -755,6 +827,8 @@ __device__ __forceinline__ void make_view(const FitArgs &a, int64_t n, SeriesVie
     sv.Xw = a.Xw + (size_t)g * a.NTmax * KP * W;
     sv.uw = a.uw + (size_t)g * a.NTmax * W;
     sv.Xu = a.Xu;
+    sv.Bw = a.Bw ? a.Bw + (size_t)g * a.NTmax * a.bw_ns * 2 * W : nullptr;
+    sv.n_xd = 0;
     sv.yw = a.yw + (size_t)n * a.NTmax * W;
     sv.Lj = gt.Lj;
     sv.t_change = gt.info.t_change;
@@ -830,8 +904,11 @@ __global__ __launch_bounds__(64) void eval_kernel(FitArgs a)
 #ifndef TSF_FIT_WPS
 #define TSF_FIT_WPS 1
 #endif
-template <int KP, int GROWTH, int MODE, int PPL, bool XIDX = false, int GNTR = 0, bool SPARSE = false>
-__global__ __launch_bounds__(64, (GNTR > 0 || SPARSE) ? 2 : TSF_FIT_WPS) void fit_kernel(FitArgs a)
+#ifndef TSF_HARM_WPS
+#define TSF_HARM_WPS 3      // waves per SIMD the HARM kernels are compiled for (<= 168 registers)
+#endif
+template <int KP, int GROWTH, int MODE, int PPL, bool XIDX = false, int GNTR = 0, bool SPARSE = false, int HARM = 0>
+__global__ __launch_bounds__(64, HARM != 0 ? TSF_HARM_WPS : ((GNTR > 0 || SPARSE) ? 2 : TSF_FIT_WPS)) void fit_kernel(FitArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int KL = SPARSE ? 64 : KP;            // SPARSE: tables and LDS of the 64-column model, registers of the 28-column one
@@ -847,6 +924,10 @@ __global__ __launch_bounds__(64, (GNTR > 0 || SPARSE) ? 2 : TSF_FIT_WPS) void fi
     const DevSpec *sp = a.sp;
     SeriesView sv;
     make_view<KL, PPL>(a, n, sv);
+    if constexpr (HARM != 0) {
+        const int kd = a.sp->K < KP ? a.sp->K : KP;         // dense columns of the model
+        sv.n_xd = kd - harm_kf(HARM);
+    }
     if constexpr (SPARSE) {
         const int64_t g = grid_index(a, n);
         sv.sp_prog = lane < SP_MAXC ? a.sp_prog[(size_t)g * SP_MAXC + lane] : 0ull;
@@ -970,7 +1051,7 @@ __global__ __launch_bounds__(64, (GNTR > 0 || SPARSE) ? 2 : TSF_FIT_WPS) void fi
             }
             double f1;
             FT_LAP(0);
-            const bool bad = eval_fg<KP, GROWTH, MODE, PPL, XIDX, WL, GNTR, SPARSE>(sp, sv, lds, xk1, f1, gk1 FT_PASS);
+            const bool bad = eval_fg<KP, GROWTH, MODE, PPL, XIDX, WL, GNTR, SPARSE, HARM>(sp, sv, lds, xk1, f1, gk1 FT_PASS);
             f1 = uniform_f64(f1);       // every lane holds the same bits: let the compiler know (scalar branches)
             if (stage == ST_INIT) {
                 if (bad) { ret = TSF_ST_INIT_NONFINITE; fk = f1; break; }
