@@ -40,6 +40,37 @@ def literal_on_canonical_design():
         fr.fourier_series = orig
 
 
+class _Routes(object):
+    """The route switches of the default context (tsf_set_option; `Context.set_option`), addressed by the names the
+    GPU tests used while these were process-wide environment variables read inside the library (until round 4):
+    `helpers.routes['TSF_SPARSE_EXTRA'] = '0'` ... `helpers.routes.pop('TSF_SPARSE_EXTRA')` (back to the default)."""
+    NAMES = {'TSF_HARM': 'harm', 'TSF_LATTICE': 'lattice', 'TSF_SPARSE_EXTRA': 'sparse_extra', 'TSF_FIT_GROUPED': 'fit_grouped',
+             'TSF_GRAM_SHARE': 'gram_share', 'TSF_GRID_ORDER': 'grid_order', 'TSF_GRID_SHARE': 'grid_share',
+             'TSF_RAGGED_SPLIT': 'ragged_split', 'TSF_QUAD_REG': 'quad_reg', 'TSF_QUAD_M2_LDS': 'quad_m2_lds',
+             'TSF_QUAD_W4': 'quad_w4', 'TSF_QUAD_RREG': 'quad_rreg', 'TSF_NEWTON_BATCH': 'newton_batch',
+             'TSF_NEWTON_LCAP': 'newton_lcap'}
+
+    @staticmethod
+    def _ctx():
+        from time_series_spark_amd import forecaster
+        return forecaster.get_context()
+
+    def __setitem__(self, k, v):
+        self._ctx().set_option(self.NAMES[k], int(v))
+
+    def pop(self, k, default=None):
+        self._ctx().set_option(self.NAMES[k], -1)
+
+    __delitem__ = pop
+
+    def update(self, d):
+        for k, v in d.items():
+            self[k] = v
+
+
+routes = _Routes()
+
+
 def bits(a):
     return np.ascontiguousarray(a, dtype=np.float64).view(np.int64)
 

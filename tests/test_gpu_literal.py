@@ -114,13 +114,21 @@ def test_hip_fit_and_predict_against_the_literal_prophet(fc, case):
     m2 = type(m)(growth=spec.growth, seasonality_mode=spec.seasonality_mode,
                  yearly_seasonality=m.yearly_seasonality, weekly_seasonality=True, daily_seasonality=False,
                  holidays=m.holidays)
-    m2.fit(df, optimizer=lambda dat_, th0_, **kw: (r.theta[0].copy(), {'status': int(r.status[0])}))
-    assert abs(m2.y_scale - r.y_scale[0]) <= 4 * ULP * m2.y_scale
     fdf = pd.DataFrame({'ds': pd.to_datetime(fut)})
     if spec.growth == 'logistic':
         fdf['floor'], fdf['cap'] = floor[0], cap[0]
-    lit = m2.predict(fdf)['yhat'].values
+    with helpers.literal_on_canonical_design():        # the literal predict on the canonical design values (round 5)
+        m2.fit(df, optimizer=lambda dat_, th0_, **kw: (r.theta[0].copy(), {'status': int(r.status[0])}))
+        assert abs(m2.y_scale - r.y_scale[0]) <= 4 * ULP * m2.y_scale
+        lit = m2.predict(fdf)['yhat'].values
     assert np.max(np.abs(yhat - lit) / np.abs(lit)) <= 16 * ULP
+    # ... and on fbprophet's own sin / cos of every harmonic: design values within 1e-9, the forecast with them
+    m3 = type(m)(growth=spec.growth, seasonality_mode=spec.seasonality_mode,
+                 yearly_seasonality=m.yearly_seasonality, weekly_seasonality=True, daily_seasonality=False,
+                 holidays=m.holidays)
+    m3.fit(df, optimizer=lambda dat_, th0_, **kw: (r.theta[0].copy(), {'status': int(r.status[0])}))
+    lit = m3.predict(fdf)['yhat'].values
+    assert np.max(np.abs(yhat - lit) / np.abs(lit)) <= 1e-9
 
 
 @pytest.mark.parametrize('case', ['cfg2_linear_additive', 'ref_logistic_multiplicative', 'short_90',

@@ -440,11 +440,11 @@ def test_ragged_call_is_cut_into_length_classes(env):
         cap = np.array([ym[i][:c].max() * 1.1 for i, c in enumerate(lens)])
         res = {}
         for mode_ in ('0', '1'):
-            os.environ['TSF_RAGGED_SPLIT'] = mode_
+            helpers.routes['TSF_RAGGED_SPLIT'] = mode_
             try:
                 res[mode_] = fc.fit_ragged(spec, off, dsr, yr, floor=np.zeros(N), cap=cap, extra=exr)
             finally:
-                os.environ.pop('TSF_RAGGED_SPLIT', None)
+                helpers.routes.pop('TSF_RAGGED_SPLIT', None)
         for name in ('theta', 'fval', 'n_iter', 'n_eval', 'status', 'y_scale'):
             assert np.array_equal(getattr(res['0'], name), getattr(res['1'], name), equal_nan=True), (growth, nh, name)
         assert res['0'].grid.tobytes() == res['1'].grid.tobytes()
@@ -498,12 +498,12 @@ def test_ragged_series_with_equal_timestamps_share_grid_tables(env):
             spec = type(spec).from_dict(dict(spec.to_dict(), lbfgs=dict(spec.lbfgs, algorithm=algo)))
         res = {}
         for tag, envs in (('shared', {}), ('own_grids', {'TSF_GRID_SHARE': '0'}), ('own_gram', {'TSF_GRAM_SHARE': '0'})):
-            os.environ.update(envs)
+            helpers.routes.update(envs)
             try:
                 res[tag] = fc.fit_ragged(spec, off, dsr, yr, floor=np.zeros(N), cap=cap)
             finally:
                 for k in envs:
-                    os.environ.pop(k, None)
+                    helpers.routes.pop(k, None)
         for tag in ('own_grids', 'own_gram'):
             for name in ('theta', 'fval', 'n_iter', 'n_eval', 'status', 'y_scale'):
                 assert np.array_equal(getattr(res['shared'], name), getattr(res[tag], name), equal_nan=True), (growth, mode, algo, tag, name)
@@ -544,12 +544,12 @@ def test_sparse_indicator_columns_equal_dense_columns(env):
         out = {}
         for tag in ('sparse', 'dense'):
             if tag == 'dense':
-                os.environ['TSF_SPARSE_EXTRA'] = '0'
+                helpers.routes['TSF_SPARSE_EXTRA'] = '0'
             try:
                 out[tag] = call()
                 assert _used_sparse_columns(fc) == (tag == 'sparse' and want_sparse), (tag, want_sparse)
             finally:
-                os.environ.pop('TSF_SPARSE_EXTRA', None)
+                helpers.routes.pop('TSF_SPARSE_EXTRA', None)
         for name in ('theta', 'fval', 'n_iter', 'n_eval', 'status', 'y_scale'):
             assert np.array_equal(getattr(out['sparse'], name), getattr(out['dense'], name), equal_nan=True), name
         return out['sparse']
@@ -648,12 +648,12 @@ def test_randomised_sparse_indicator_layouts(env):
         out = {}
         for tag in ('sparse', 'dense'):
             if tag == 'dense':
-                os.environ['TSF_SPARSE_EXTRA'] = '0'
+                helpers.routes['TSF_SPARSE_EXTRA'] = '0'
             try:
                 out[tag] = fc.fit_aligned(spec, ds, y, floor=np.zeros(N), cap=cap, extra=ex)
                 n_sparse += int(_used_sparse_columns(fc))
             finally:
-                os.environ.pop('TSF_SPARSE_EXTRA', None)
+                helpers.routes.pop('TSF_SPARSE_EXTRA', None)
         for name in ('theta', 'fval', 'n_iter', 'n_eval', 'status'):
             assert np.array_equal(getattr(out['sparse'], name), getattr(out['dense'], name), equal_nan=True), (trial, name)
         r = out['sparse']
@@ -827,6 +827,26 @@ def test_newton_with_two_parameters_per_lane(env):
         o = cl.fit_newton(csp, ds, y[n])
         assert (r.status[n], r.n_iter[n], r.n_eval[n]) == (o['status'], o['n_iter'], o['n_eval']), n
         assert n_bit_diff(r.theta[n], o['theta']) == 0 and n_bit_diff(r.fval[n], o['f']) == 0, n
+    # the 64 / 65 boundary (round-4 advice: the launcher chose on P | 1, which is 65 for both, and sent the
+    # 65-parameter model to the one-parameter-per-lane kernel): yearly + weekly + daily with 2 and 3 explicit columns
+    dsb = np.datetime64('2019-03-01T00:00:00', 'ns').astype(np.int64) + 900 * 10 ** 9 * np.arange(96)
+    _, yb = synth.make_panel(2, 96, 'logistic', seed=31)
+    rngb = np.random.default_rng(5)
+    for n_x, P in ((2, 64), (3, 65)):
+        xb = np.ascontiguousarray(rngb.normal(0, 1, (n_x, 96)))
+        spec = fc.ModelSpec(growth='logistic', seasonality_mode='multiplicative',
+                            seasonalities=[helpers.YEARLY, helpers.WEEKLY, helpers.DAILY],
+                            extra=[{'name': 'x%d' % i} for i in range(n_x)], algorithm=_lib.ALGO_NEWTON)
+        assert spec.theta_stride == P
+        capb = yb.max(axis=1) * 1.1
+        r = fc.fit_aligned(spec, dsb, yb, floor=np.zeros(2), cap=capb, extra=xb)
+        csp = helpers.oracle_spec(spec)
+        csp.eval_mode = 0
+        for n in range(2):
+            o = cl.fit_newton(csp, dsb, yb[n], 0.0, capb[n], xb)
+            assert (r.status[n], r.n_iter[n], r.n_eval[n]) == (o['status'], o['n_iter'], o['n_eval']), (P, n)
+            assert n_bit_diff(r.theta[n], o['theta']) == 0 and n_bit_diff(r.fval[n], o['f']) == 0, (P, n)
+    ds, y = synth.make_panel(2, 80, 'linear', seed=6)
     # more than 128 parameters (3 + 40 + 26 + 60): no kernel of the library takes the model, Newton or not
     with pytest.raises(_lib.TsfError):
         fc.fit_aligned(fc.ModelSpec(growth='linear', seasonalities=[dict(helpers.YEARLY), dict(helpers.WEEKLY)], n_changepoints=40,
@@ -1207,13 +1227,13 @@ def test_quadratic_form_kernels_for_small_and_large_panels_give_the_same_bits(en
     res = {}
     for mode in ('0', '1', None):
         if mode is None:
-            os.environ.pop('TSF_QUAD_REG', None)
+            helpers.routes.pop('TSF_QUAD_REG', None)
         else:
-            os.environ['TSF_QUAD_REG'] = mode
+            helpers.routes['TSF_QUAD_REG'] = mode
         try:
             res[mode] = fc.fit_aligned(spec, ds, y)
         finally:
-            os.environ.pop('TSF_QUAD_REG', None)
+            helpers.routes.pop('TSF_QUAD_REG', None)
     for name in ('theta', 'fval', 'n_iter', 'n_eval', 'status'):
         assert np.array_equal(getattr(res['0'], name), getattr(res['1'], name), equal_nan=True), name
         assert np.array_equal(getattr(res['0'], name), getattr(res[None], name), equal_nan=True), name
@@ -1243,17 +1263,17 @@ def test_quadratic_form_kernel_routes_for_large_aligned_panels_give_the_same_bit
     res = {}
     legs = (('w4', {'TSF_QUAD_W4': '16'}), ('w4_one_copy', {'TSF_QUAD_W4': '1'}), ('w3_reg', {}),
             ('w3_glob', {'TSF_QUAD_RREG': '0'}))
-    os.environ['TSF_QUAD_REG'] = '0'
+    helpers.routes['TSF_QUAD_REG'] = '0'
     try:
         for tag, envs in legs:
-            os.environ.update(envs)
+            helpers.routes.update(envs)
             try:
                 res[tag] = fc.fit_aligned(spec, ds, y)
             finally:
                 for k in envs:
-                    os.environ.pop(k, None)
+                    helpers.routes.pop(k, None)
     finally:
-        os.environ.pop('TSF_QUAD_REG', None)
+        helpers.routes.pop('TSF_QUAD_REG', None)
     for tag, _ in legs[1:]:
         for name in ('theta', 'fval', 'n_iter', 'n_eval', 'status'):
             assert np.array_equal(getattr(res['w4'], name), getattr(res[tag], name), equal_nan=True), (tag, name)
@@ -1265,14 +1285,14 @@ def test_quadratic_form_kernel_routes_for_large_aligned_panels_give_the_same_bit
         assert n_bit_diff(r.theta[n], o['theta']) == 0 and n_bit_diff(r.fval[n], o['f']) == 0, n
     ds, y = synth.make_panel(4000, 90, 'linear', seed=78)
     spec = fc.ModelSpec(growth='linear', seasonalities=fc.ModelSpec.auto_seasonalities(ds))
-    os.environ['TSF_QUAD_REG'] = '0'
+    helpers.routes['TSF_QUAD_REG'] = '0'
     try:
         w3 = fc.fit_aligned(spec, ds, y)
-        os.environ['TSF_QUAD_W4'] = '16'
+        helpers.routes['TSF_QUAD_W4'] = '16'
         w4 = fc.fit_aligned(spec, ds, y)
     finally:
-        os.environ.pop('TSF_QUAD_W4', None)
-        os.environ.pop('TSF_QUAD_REG', None)
+        helpers.routes.pop('TSF_QUAD_W4', None)
+        helpers.routes.pop('TSF_QUAD_REG', None)
     for name in ('theta', 'fval', 'n_iter', 'n_eval', 'status'):
         assert np.array_equal(getattr(w3, name), getattr(w4, name), equal_nan=True), name
     # LONG series on the pooled 16-wave route (what BASELINE cfg3 whole, 100 000 x 1 095, takes): the trend tables
@@ -1286,17 +1306,17 @@ def test_quadratic_form_kernel_routes_for_large_aligned_panels_give_the_same_bit
         spec = fc.ModelSpec(growth='linear', seasonalities=fc.ModelSpec.auto_seasonalities(ds))
         assert spec.K == 26
         res = {}
-        os.environ['TSF_QUAD_REG'] = '0'
+        helpers.routes['TSF_QUAD_REG'] = '0'
         try:
             for tag, envs in legs:
-                os.environ.update(envs)
+                helpers.routes.update(envs)
                 try:
                     res[tag] = fc.fit_aligned(spec, ds, y)
                 finally:
                     for k in envs:
-                        os.environ.pop(k, None)
+                        helpers.routes.pop(k, None)
         finally:
-            os.environ.pop('TSF_QUAD_REG', None)
+            helpers.routes.pop('TSF_QUAD_REG', None)
         for tag, _ in legs[1:]:
             for name in ('theta', 'fval', 'n_iter', 'n_eval', 'status'):
                 assert np.array_equal(getattr(res['w4'], name), getattr(res[tag], name), equal_nan=True), (T, tag, name)
@@ -1363,14 +1383,14 @@ def test_newton_several_series_per_wave_equals_one_series_per_wave(env):
     N, T = 12000, 90
     ds, y = synth.make_panel(N, T, 'linear', seed=99)
     spec = fc.ModelSpec(growth='linear', seasonalities=fc.ModelSpec.auto_seasonalities(ds), algorithm=_lib.ALGO_NEWTON)
-    os.environ['TSF_NEWTON_BATCH'] = '2'                 # slots from two series per resident wave on (default: twelve)
+    helpers.routes['TSF_NEWTON_BATCH'] = '2'                 # slots from two series per resident wave on (default: twelve)
     try:
         big = fc.fit_aligned(spec, ds, y)
-        os.environ['TSF_NEWTON_LCAP'] = '50'
+        helpers.routes['TSF_NEWTON_LCAP'] = '50'
         over = fc.fit_aligned(spec, ds, y)               # every decomposition overflows its list
     finally:
-        os.environ.pop('TSF_NEWTON_LCAP', None)
-        del os.environ['TSF_NEWTON_BATCH']
+        helpers.routes.pop('TSF_NEWTON_LCAP', None)
+        helpers.routes.pop('TSF_NEWTON_BATCH')
     sub = np.arange(0, N, 37)[:300]
     small = fc.fit_aligned(spec, ds, y[sub])             # one series per wave
     for name in ('theta', 'fval', 'n_iter', 'n_eval', 'status'):

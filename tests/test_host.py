@@ -955,3 +955,20 @@ def test_holiday_windows_and_names_follow_fbprophet():
         features.normalize_holidays([{'holiday': 'x_delim_y', 'ds': ['2019-01-01']}])
     with pytest.raises(ValueError, match='reserved'):
         features.normalize_holidays([{'holiday': 'weekly', 'ds': ['2019-01-01']}])
+
+
+def test_model_frames_with_iteration_counts_concatenate():
+    """Round-4 advice: the frame model_panel returns carries its iteration counts in DataFrame.attrs (scheduling hints
+    for persist_models' side file); pandas compares attrs with == when frames are concatenated, and a bare ndarray of
+    more than one element raised there.  The counts are one comparable value now."""
+    from time_series_spark_amd.jobs import prophet_modeler as pm
+    frames = []
+    for k in range(2):
+        f = pd.DataFrame({'series_id': np.arange(3, dtype=np.int32) + 10 * k, 'dim_id': np.zeros(3, dtype=np.int32)})
+        f.attrs['tsf_cost'] = pm._CostVector(np.array([5, 6, 7]) + k)
+        frames.append(f)
+    both = pd.concat(frames, ignore_index=True)            # (used to raise: truth value of an array is ambiguous)
+    assert len(both) == 6
+    same = pd.concat([frames[0], frames[0].copy()], ignore_index=True)
+    assert len(same) == 6
+    assert np.array_equal(np.asarray(frames[1].attrs['tsf_cost'], dtype=np.int64), [6, 7, 8]) and len(frames[1].attrs['tsf_cost']) == 3

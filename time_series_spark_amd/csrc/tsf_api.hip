@@ -44,6 +44,7 @@ struct tsf_ctx {
     size_t order_cap[2];    // turn: a fit that is still running on its stream keeps reading the one it was given)
     int order_next;
     int64_t order_n;        // series count the pending hints are for (0: none pending)
+    std::vector<int32_t> cost_host;   // the pending hints themselves: a ragged call cut into length classes hands every class its share
     hipEvent_t order_ev[2]; // recorded behind the launch that reads order_dev[b]: the buffer is rewritten only after it
     int order_busy[2];
     int n_cu;               // compute units of the device (persistent kernels: one workgroup each)
@@ -354,6 +355,7 @@ static int quad_plan(tsf_ctx *ctx, const DevSpec &hs, int64_t N, QuadPlan *qp)
     qp->P4 = (qp->PPL == 2) ? ((P + 3) & ~3) : (P <= 40 ? 40 : (P <= 56 ? 56 : 64));
     qp->NW = quad_waves_per_block(qp->PPL);       // the most any variant launches: sizes the slots
     qp->n_cu = ctx->n_cu;
+    qp->opt = ctx->opt;
     int64_t blocks = ctx->n_cu;                     // persistent: LDS admits one workgroup per CU
     const int64_t need = (N + qp->NW - 1) / qp->NW;
     if (blocks > need) blocks = need;
@@ -457,10 +459,10 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
         // Series that share timestamp vectors (grid_of) have step-major tables per DISTINCT vector: where those fit the
         // caches (<= 64 MB of design tables) every wave reads them coalesced, as on an aligned panel, and the lattice
         // table with its gathered rows (64 cache lines per load instruction) is the slower of the two.
-        // TSF_LATTICE=0: never the lattice table; =1: always where it applies.
-        const char *el = getenv("TSF_LATTICE");
+        // tsf_set_option(TSF_OPT_LATTICE, 0): never the lattice table; 1: always where it applies.
+        const int el = ctx->opt[TSF_OPT_LATTICE];
         const size_t tab = sizeof(double) * (size_t)n_grids * (size_t)NTmax * hs.KP * W;
-        if (el ? atoi(el) == 0 : (grid_of != nullptr && tab <= ((size_t)64 << 20))) lat_U = 0;
+        if (el >= 0 ? el == 0 : (grid_of != nullptr && tab <= ((size_t)64 << 20))) lat_U = 0;
     }
     // matrix-core residual kernel (tsf_mfma_kernels.h): aligned panel, L-BFGS, one parameter per lane
     // (KP <= 28 implies one column mode and P <= 64), at most MT_SP changepoints, and an upper bound
@@ -511,20 +513,18 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     // of 8 (eval_fg GNTR: 187 instead of 379 registers, two waves per SIMD) and allocates only the history pairs
     // it uses (wave_lds_bytes: eight blocks per CU instead of six): 17.0 M evaluations/s on cfg4 against the
     // workgroup kernel's 15.4 M (2.27 against 2.50 s) -- so AUTO runs it, with the workgroup kernel for the tail
-    // as for the narrower models.  TSF_FIT_GROUPED=0: every series on the workgroup kernel, as before.
+    // as for the narrower models.  tsf_set_option(TSF_OPT_FIT_GROUPED, 0): every series on the workgroup kernel, as before.
     // Wide models (64-column tables) whose columns from the 29th on are explicit columns -- holidays: 0 / 1 indicators,
     // almost all 0 -- are tried on the sparse-column form of the 28-column kernel (eval_fg<..., SPARSE>, tsf_fit_kernels.h):
     // sparse_extra_kernel decides on the device whether every grid qualifies, the dense route is launched behind it
     // with the opposite guard (series of <= 768 rows: the grouped one-wave kernel; up to 4 096 rows: the workgroup
-    // kernel from the first evaluation; longer: the ungrouped one-wave kernel).  TSF_SPARSE_EXTRA=0: never.
-    const char *esp = getenv("TSF_SPARSE_EXTRA");
+    // kernel from the first evaluation; longer: the ungrouped one-wave kernel).  tsf_set_option(TSF_OPT_SPARSE_EXTRA, 0): never.
     const bool sparse_try = !quad && !newton && !mp.on && theta_in == nullptr && lat_U == 0 && hs.KP == 64 && mode != 2 &&
                             spec->residual_kernel == TSF_RK_AUTO && hs.K > SP_DENSE && hs.K <= SP_DENSE + SP_MAXC &&
-                            hs.K - hs.n_extra <= SP_DENSE && NTmax <= SP_MAX_NT && !(esp && atoi(esp) == 0);
+                            hs.K - hs.n_extra <= SP_DENSE && NTmax <= SP_MAX_NT && ctx->opt[TSF_OPT_SPARSE_EXTRA] != 0;
     int coop_after = spec->residual_kernel == TSF_RK_COOP ? COOP_DIRECT : spec->coop_after;
     if (coop) {
-        const char *eg = getenv("TSF_FIT_GROUPED");
-        const bool grouped = NTmax <= 12 && !(eg && atoi(eg) == 0) && lat_U == 0;
+        const bool grouped = NTmax <= 12 && ctx->opt[TSF_OPT_FIT_GROUPED] != 0 && lat_U == 0;
         // (with sparse_try the slots of the tail exist either way: the dense route of longer series is then launched
         // in direct mode by the launch function itself)
         if (spec->residual_kernel == TSF_RK_AUTO && spec->coop_after < 0 && hs.KP == 64 && !grouped && !sparse_try) coop_after = COOP_DIRECT;
@@ -532,9 +532,8 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     const int coop_slots = coop ? coop_slots_for(N, coop_after, ctx->n_cu) : 0;
     const int coop_stride = coop ? coop_slot_doubles(hs.KP == 64 ? 2 : 1) : 0;
     // ragged panel, quadratic form, series sharing timestamp vectors: Z^T Z once per distinct vector (gram_grids_kernel)
-    // instead of once per series inside the fit kernel -- when that at least halves the builds (TSF_GRAM_SHARE=0: never)
-    const char *egs = getenv("TSF_GRAM_SHARE");
-    const int64_t quad_pre = (quad && !aligned && grid_of && n_grids * 2 <= N && !(egs && atoi(egs) == 0)) ? n_grids : 0;
+    // instead of once per series inside the fit kernel -- when that at least halves the builds (TSF_OPT_GRAM_SHARE 0: never)
+    const int64_t quad_pre = (quad && !aligned && grid_of && n_grids * 2 <= N && ctx->opt[TSF_OPT_GRAM_SHARE] != 0) ? n_grids : 0;
     // Fourier columns expanded from the rows' base pairs (eval_fg HARM): the residual-form one-wave kernel of models
     // whose harmonic structure has a compiled kernel -- yearly 10 + weekly 3 on the 28-column kernel and its
     // sparse-column form, weekly 3 + daily 4 (16 columns), weekly 3 (8 columns); never with the lattice table or the
@@ -614,7 +613,7 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     // scheduling hints of tsf_set_cost_hints: for this call if they were given for this many series; used once
     const int order_buf = (ctx->order_n == N && !theta_in) ? (ctx->order_next ^ 1) : -1;
     if (order_buf >= 0) a.order = ctx->order_dev[order_buf];
-    else if (grid_order && !getenv("TSF_GRID_ORDER_OFF")) a.order = grid_order;       // series grouped by shared grid (fit_host_one)
+    else if (grid_order && ctx->opt[TSF_OPT_GRID_ORDER] != 0) a.order = grid_order;       // series grouped by shared grid (fit_host_one)
     ctx->order_n = 0;
     const int slot = (int)(ctx->ev_count % TSF_PROFILE_RING);
     if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev0[slot], st));
@@ -626,7 +625,7 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
         qa.rbuf = (double *)(ws + l.rbuf);
         qa.counter = (int *)(ws + l.counter); qa.P4 = qp.P4;
         if (aligned) {
-            const size_t need = newton_batch_scratch_bytes(hs.KP, fit_P(hs.n_cp, hs.K) | 1, N, NTmax, ctx->n_cu);
+            const size_t need = newton_batch_scratch_bytes(hs.KP, fit_P(hs.n_cp, hs.K) | 1, N, NTmax, ctx->n_cu, ctx->opt);
             if (need > ctx->nb_ws_bytes) {
                 if (ctx->nb_ws) { HIP_TRY(ctx, hipFree(ctx->nb_ws)); ctx->nb_ws = nullptr; ctx->nb_ws_bytes = 0; }
                 if (hipMalloc(&ctx->nb_ws, need) == hipSuccess) ctx->nb_ws_bytes = need;
@@ -637,9 +636,9 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
         HIP_TRY(ctx, hipMemsetAsync(qa.counter, 0, sizeof(int), st));
         lrc = launch_newton_quad(hs.KP, qp, qa, (double *)(ws + l.Mg), fit_P(hs.n_cp, hs.K) | 1, ctx->n_cu, st);
         // (-1: this shape does not fit the quadratic-form Newton kernel's LDS -- the residual-form kernel has no such limit)
-        if (lrc == -1) lrc = pick_newton_launch(hs.growth, mode)(hs.KP, a, fit_P(hs.n_cp, hs.K) | 1, st);
+        if (lrc == -1) lrc = pick_newton_launch(hs.growth, mode)(hs.KP, a, fit_P(hs.n_cp, hs.K), st);
     } else if (newton) {
-        lrc = pick_newton_launch(hs.growth, mode)(hs.KP, a, fit_P(hs.n_cp, hs.K) | 1, st);
+        lrc = pick_newton_launch(hs.growth, mode)(hs.KP, a, fit_P(hs.n_cp, hs.K), st);
     } else if (quad_eval) {
         QuadArgs qa;
         memset(&qa, 0, sizeof(qa));
@@ -902,8 +901,7 @@ static int fit_host_one(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int align
     DevBuf d_gof, d_grows, d_gord;
     int64_t n_distinct = 0;
     {
-        const char *e_share = getenv("TSF_GRID_SHARE");
-        if (!aligned && !theta_in && spec->n_extra == 0 && N >= 2 && !(e_share && atoi(e_share) == 0)) {
+        if (!aligned && !theta_in && spec->n_extra == 0 && N >= 2 && ctx->opt[TSF_OPT_GRID_SHARE] != 0) {
             struct Key { int64_t len; uint64_t h; int64_t n; };
             std::vector<Key> keys((size_t)N);
             {
@@ -1029,8 +1027,8 @@ static int fit_host_one(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int align
 // series and every series at least half as long, then the same again for the rest: at most ~11 classes, each
 // padded by < 2 x -- and runs one fit call per class on the gathered rows: workspace proportional to the rows
 // that exist.  Every series is fitted by itself, so the results do not depend on the grouping (GPU test:
-// bit-identical to the single call).  Scheduling hints (tsf_set_cost_hints) are for whole calls and are not
-// applied to the classes.  tsf_fit_ragged_dev (device pointers: the lengths are not on the host) leaves
+// bit-identical to the single call).  Scheduling hints (tsf_set_cost_hints) given for the whole call are handed to
+// the classes series by series.  tsf_fit_ragged_dev (device pointers: the lengths are not on the host) leaves
 // this to its caller.
 static int fit_host(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, int32_t T,
                     const int64_t *offsets, const int64_t *ds, const void *y, int32_t y_dtype,
@@ -1039,7 +1037,10 @@ static int fit_host(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, 
                     const double *theta_ref = nullptr)
 {
     if (!ctx) return -1;
-    if (aligned || theta_in || !offsets || !spec || N < 2 || y_dtype < TSF_Y_F64 || y_dtype > TSF_Y_I32)
+    // (anything fit_host_one rejects -- NULL inputs, offsets that do not start at 0 -- goes to it for the error: the
+    // split below indexes ds / y / extra with the caller's offsets; round-4 advice)
+    if (aligned || theta_in || !offsets || !spec || N < 2 || y_dtype < TSF_Y_F64 || y_dtype > TSF_Y_I32 ||
+        !ds || !y || !out || offsets[0] != 0 || (spec->n_extra > 0 && !extra))
         return fit_host_one(ctx, spec, N, aligned, T, offsets, ds, y, y_dtype, floor_, cap, extra, out, theta_in,
                             f_out, grad_out, theta_ref);
     int64_t sum_nt = 0, nt_max = 0;
@@ -1052,8 +1053,7 @@ static int fit_host(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, 
         sum_nt += nt;
         if (nt > nt_max) nt_max = nt;
     }
-    static const char *e_split = getenv("TSF_RAGGED_SPLIT");        // 0: never, 1: whenever the padding rule says so (tests)
-    const int force = e_split ? atoi(e_split) : -1;
+    const int force = ctx->opt[TSF_OPT_RAGGED_SPLIT];       // 0: never, 1: whenever the padding rule says so (tests)
     const double padded = (double)N * (double)nt_max;
     const bool small = padded * 512.0 * (3 + tsf_spec_K(spec)) < 256e6;
     if (force == 0 || padded <= 2.0 * (double)sum_nt || (small && force != 1))
@@ -1067,6 +1067,12 @@ static int fit_host(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, 
     const int stride = tsf_theta_stride(spec);
     const size_t ys = (y_dtype == TSF_Y_F64) ? 8 : 4;
     const int64_t total = offsets[N] - offsets[0];
+    // scheduling hints given for this call (tsf_set_cost_hints with N entries): every class gets its series' share
+    // (round-4 advice: they used to be dropped on this path without a word)
+    std::vector<int32_t> hints;
+    if (ctx->order_n == N && (int64_t)ctx->cost_host.size() == N) hints = ctx->cost_host;
+    ctx->order_n = 0;
+    std::vector<int32_t> hb;
     for (int64_t b0 = 0; b0 < N;) {
         const int64_t top = (offsets[order[(size_t)b0] + 1] - offsets[order[(size_t)b0]] + W - 1) / W;
         int64_t b1 = b0;
@@ -1101,6 +1107,12 @@ static int fit_host(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, 
         tsf_fit_out ob;
         ob.theta = th.data(); ob.y_scale = ysc.data(); ob.fval = fv.data(); ob.status = st.data();
         ob.n_iter = it.data(); ob.n_eval = ev.data(); ob.grid = gr.data();
+        if (!hints.empty()) {
+            hb.resize((size_t)nb);
+            for (int64_t i = 0; i < nb; ++i) hb[(size_t)i] = hints[(size_t)idx[(size_t)i]];
+            const int hrc = tsf_set_cost_hints(ctx, hb.data(), nb);
+            if (hrc) return hrc;
+        }
         const int rc = fit_host_one(ctx, spec, nb, 0, 0, off.data(), dsb.data(), yb.data(), y_dtype,
                                     floor_ ? flb.data() : nullptr, cap ? cpb.data() : nullptr,
                                     exb.empty() ? (spec->n_extra > 0 ? extra : nullptr) : exb.data(), &ob, nullptr, nullptr, nullptr);
@@ -1515,6 +1527,7 @@ extern "C" int tsf_set_cost_hints(tsf_ctx *ctx, const int32_t *cost, int64_t n)
     HIP_TRY(ctx, hipMemcpy(ctx->order_dev[b], order.data(), need, hipMemcpyHostToDevice));
     ctx->order_next = b ^ 1;
     ctx->order_n = n;
+    if (cost != ctx->cost_host.data()) ctx->cost_host.assign(cost, cost + n);
     return 0;
 }
 

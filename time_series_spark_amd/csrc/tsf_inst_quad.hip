@@ -108,9 +108,9 @@ static int launch_quad_one(const QuadPlan &qp, const QuadArgs &qa, double *Mg, h
         // bound by its longest series, not by throughput -- measured (cfg2 model, ms per fit + forecast, LDS /
         // registers): 1 250 series 3.99 / 3.31, 2 500: 4.74 / 4.55, 5 000: 6.79 / 6.66, 10 000: 9.36 / 9.85 -- so up
         // to three series per slot of the register kernel it takes the call.  This is also what a rank of a
-        // strong-scaled 10 000-series panel sees (1 250 series on each of 8 GPUs).  TSF_QUAD_REG = 0 / 1 forces.
-        const char *e = getenv("TSF_QUAD_REG");
-        const bool use_reg = e ? atoi(e) != 0 : qa.f.N <= (int64_t)3 * 8 * qp.n_cu;
+        // strong-scaled 10 000-series panel sees (1 250 series on each of 8 GPUs).  tsf_set_option(TSF_OPT_QUAD_REG, 0 / 1) forces.
+        const int e = qp.opt ? qp.opt[TSF_OPT_QUAD_REG] : -1;
+        const bool use_reg = e >= 0 ? e != 0 : qa.f.N <= (int64_t)3 * 8 * qp.n_cu;
         if (use_reg) {
             const int rc = launch_quad_aligned_reg(KP, qp, qa, Mg, st);      // tsf_inst_quad4.hip (-2: no such variant)
             if (rc != -2) return rc;
@@ -120,12 +120,12 @@ static int launch_quad_one(const QuadPlan &qp, const QuadArgs &qa, double *Mg, h
     else {
         // Two parameters per lane (64 < P <= 128).  Z^T Z is [P4][2][64] doubles: up to P4 = 88 it fits in LDS beside
         // the state of the kernel's four waves (cfg2 + 30 holiday columns, P4 = 84: 86 KB + 4 x 17 KB), and an
-        // evaluation then reads its 86 KB from LDS instead of L2.  TSF_QUAD_M2_LDS=0: from L2 as before.
-        const char *e = getenv("TSF_QUAD_M2_LDS");
+        // evaluation then reads its 86 KB from LDS instead of L2.  TSF_OPT_QUAD_M2_LDS 0: from L2 as before.
+        const int e = qp.opt ? qp.opt[TSF_OPT_QUAD_M2_LDS] : -1;
         constexpr int NW = QuadShape<PPL, QM_LDS>::NW;
         const size_t lds = sizeof(double) * (size_t)qp.P4 * PPL * W + quad_lanec_bytes<PPL>() +
                            (sizeof(QuadLds<KP, PPL>) + quad_hist_bytes<PPL>(true)) * NW;
-        if (lds <= 160 * 1024 && !(e && atoi(e) == 0)) return launch_quad_mm<KP, PPL, QM_LDS, PQ>(qp, qa, Mg, st);
+        if (lds <= 160 * 1024 && e != 0) return launch_quad_mm<KP, PPL, QM_LDS, PQ>(qp, qa, Mg, st);
         return launch_quad_mm<KP, PPL, QM_GLOBAL, PQ>(qp, qa, Mg, st);
     }
 }
@@ -195,14 +195,14 @@ static int launch_newton_quad_rg(const QuadPlan &qp, const QuadArgs &qa, double 
 // bytes of slot records (the caller provides them: QuadArgs::nb_buf).  false: this call does not take that kernel.
 template <int KP>
 static bool newton_batch_shape(int PM, int64_t N, int NTmax, int n_cu, NewtonBatchArgs &nb, int64_t &blocks, size_t &lds,
-                               int &per_cu, size_t &rec_bytes, size_t &idx_bytes)
+                               int &per_cu, size_t &rec_bytes, size_t &idx_bytes, const int *opt)
 {
-    // TSF_NEWTON_BATCH: 0 never, 2 whenever there are two series per wave (tests); default: from twelve series per
+    // TSF_OPT_NEWTON_BATCH: 0 never, 2 whenever there are two series per wave (tests); default: from twelve series per
     // resident wave on -- measured on MI355X (profiles/r03_newton): 20 000 x 90 0.72 s here against 0.64 s on the
     // one-series-per-wave kernel (few rounds, and the longest series advances one iteration per round of NS
     // slots), 100 000: 3.16 against 3.69 s, 1 000 000: 15.1 against 26.0 s
-    const char *mode_env = getenv("TSF_NEWTON_BATCH");
-    const int mode = mode_env ? atoi(mode_env) : 1;
+    auto optv = [opt](int k) { return opt ? opt[k] : -1; };
+    const int mode = optv(TSF_OPT_NEWTON_BATCH) >= 0 ? optv(TSF_OPT_NEWTON_BATCH) : 1;
     if (mode == 0) return false;
     lds = newton_batch_lds_bytes<KP>(PM, NTmax);
     if (lds > 160 * 1024) return false;
@@ -214,12 +214,12 @@ static bool newton_batch_shape(int PM, int64_t N, int NTmax, int n_cu, NewtonBat
     if (N < (mode == 2 ? 2 : 12) * blocks) return false;
     nb.NS = (int)((N + blocks - 1) / blocks);
     if (nb.NS > NB_MAX_SLOTS) nb.NS = NB_MAX_SLOTS;
-    nb.flags = getenv("TSF_NEWTON_FLAGS") ? atoi(getenv("TSF_NEWTON_FLAGS")) : 0;
-    if (const char *e = getenv("TSF_NEWTON_NS")) { const int v = atoi(e); if (v >= 1 && v <= NB_MAX_SLOTS) nb.NS = v; }   // dev
+    nb.flags = optv(TSF_OPT_NEWTON_FLAGS) >= 0 ? optv(TSF_OPT_NEWTON_FLAGS) : 0;
+    { const int v = optv(TSF_OPT_NEWTON_NS); if (v >= 1 && v <= NB_MAX_SLOTS) nb.NS = v; }   // dev
     const int P = PM & ~1;      // PM = P | 1
     nb.LCAP = nb_lcap(P > 0 ? P : 1);
-    if (const char *e = getenv("TSF_NEWTON_LCAP")) {       // tests: a list too short for any decomposition -> the in-wave chain
-        const int v = atoi(e);
+    {       // tests: a list too short for any decomposition -> the in-wave chain
+        const int v = optv(TSF_OPT_NEWTON_LCAP);
         if (v >= 2 && v < nb.LCAP) nb.LCAP = v & ~1;
     }
     nb.rec_stride = (nb_rec_doubles(PM, nb.LCAP) + 1) & ~1LL;
@@ -230,7 +230,7 @@ static bool newton_batch_shape(int PM, int64_t N, int NTmax, int n_cu, NewtonBat
     return true;
 }
 
-size_t newton_batch_scratch_bytes(int KP, int PM, int64_t N, int NTmax, int n_cu)
+size_t newton_batch_scratch_bytes(int KP, int PM, int64_t N, int NTmax, int n_cu, const int *opt)
 {
     NewtonBatchArgs nb;
     int64_t blocks = 0;
@@ -238,9 +238,9 @@ size_t newton_batch_scratch_bytes(int KP, int PM, int64_t N, int NTmax, int n_cu
     int per_cu = 0;
     bool ok = false;
     switch (KP) {
-    case 8: ok = newton_batch_shape<8>(PM, N, NTmax, n_cu, nb, blocks, lds, per_cu, rb, ib); break;
-    case 16: ok = newton_batch_shape<16>(PM, N, NTmax, n_cu, nb, blocks, lds, per_cu, rb, ib); break;
-    case 28: ok = newton_batch_shape<28>(PM, N, NTmax, n_cu, nb, blocks, lds, per_cu, rb, ib); break;
+    case 8: ok = newton_batch_shape<8>(PM, N, NTmax, n_cu, nb, blocks, lds, per_cu, rb, ib, opt); break;
+    case 16: ok = newton_batch_shape<16>(PM, N, NTmax, n_cu, nb, blocks, lds, per_cu, rb, ib, opt); break;
+    case 28: ok = newton_batch_shape<28>(PM, N, NTmax, n_cu, nb, blocks, lds, per_cu, rb, ib, opt); break;
     default: break;
     }
     return ok ? rb + ib : 0;
@@ -254,7 +254,7 @@ static int launch_newton_batch(const QuadPlan &qp, const QuadArgs &qa, double *M
     int64_t blocks = 0;
     size_t lds = 0, rec_bytes = 0, idx_bytes = 0;
     int per_cu = 0;
-    if (!newton_batch_shape<KP>(PM, qa.f.N, qa.f.NTmax, n_cu, nb, blocks, lds, per_cu, rec_bytes, idx_bytes)) return -2;
+    if (!newton_batch_shape<KP>(PM, qa.f.N, qa.f.NTmax, n_cu, nb, blocks, lds, per_cu, rec_bytes, idx_bytes, qp.opt)) return -2;
     // The records come from the caller's cached workspace, NOT from hipMallocAsync: with stream-ordered
     // scratch of this size (gigabytes, above the pool's release threshold) fits went wrong intermittently
     // after a large call on this ROCm (tools/dev/nb_debug.py; plain hipMalloc: never)
@@ -262,7 +262,7 @@ static int launch_newton_batch(const QuadPlan &qp, const QuadArgs &qa, double *M
     void *buf = qa.nb_buf;
     nb.rec = (double *)buf;
     nb.rot_idx = (int *)((char *)buf + rec_bytes);
-    if (const char *e = getenv("TSF_NEWTON_FILL")) hipMemsetAsync(buf, atoi(e), rec_bytes + idx_bytes, st);   // dev: 255 = NaN everywhere
+    if (qp.opt && qp.opt[TSF_OPT_NEWTON_FILL] >= 0) hipMemsetAsync(buf, qp.opt[TSF_OPT_NEWTON_FILL], rec_bytes + idx_bytes, st);   // dev: 255 = NaN everywhere
     hipLaunchKernelGGL((gram_build_kernel<KP, 1>), dim3((unsigned)qp.P4), dim3(64), 0, st, qa, Mg);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;

@@ -7,7 +7,7 @@ namespace tsf {
 struct FitArgs;
 struct QuadArgs;
 struct MfmaTabs;
-struct QuadPlan { int P4, PPL, NW, blocks, slots, n_cu; };
+struct QuadPlan { int P4, PPL, NW, blocks, slots, n_cu; const int *opt; };      // opt: the context's route switches (TSF_OPT_*, -1 = default)
 int quad_waves_per_block(int PPL);
 // gram_build_kernel + fit_quad_kernel (tsf_inst_quad.hip)
 int launch_quad(int KP, const QuadPlan &qp, const QuadArgs &qa, double *Mg, hipStream_t st);
@@ -18,7 +18,7 @@ int launch_quad_aligned_reg(int KP, const QuadPlan &qp, const QuadArgs &qa, doub
 // gram_build_kernel + newton_quad_kernel (Stan's Newton, quadratic-form evaluations; tsf_inst_quad.hip)
 int launch_newton_quad(int KP, const QuadPlan &qp, const QuadArgs &qa, double *Mg, int PM, int n_cu, hipStream_t st);
 // bytes of slot records the several-series-per-wave Newton kernel needs for this call (QuadArgs::nb_buf); 0: not that kernel
-size_t newton_batch_scratch_bytes(int KP, int PM, int64_t N, int NTmax, int n_cu);
+size_t newton_batch_scratch_bytes(int KP, int PM, int64_t N, int NTmax, int n_cu, const int *opt);
 int launch_g0m0(int KP, const FitArgs &a, int eval_only, hipStream_t st);
 int launch_g0m1(int KP, const FitArgs &a, int eval_only, hipStream_t st);
 int launch_g0m2(int KP, const FitArgs &a, int eval_only, hipStream_t st);
@@ -32,10 +32,10 @@ int launch_mfma_layout(const FitArgs &a, int KP, const MfmaTabs &mt, double *XF,
                        double *tq, uint16_t *cq, int8_t *cpof, double *yq, int *overflow, hipStream_t st);
 int launch_mfma(int KP, int growth, int mode, const FitArgs &a, const MfmaTabs &mt, int blocks, hipStream_t st);
 // newton_kernel (Stan's Newton optimiser; P <= 64, one explicit-mode kernels only)
-int launch_newton_g0m0(int KP, const FitArgs &a, int PM, hipStream_t st);
-int launch_newton_g0m1(int KP, const FitArgs &a, int PM, hipStream_t st);
-int launch_newton_g0m2(int KP, const FitArgs &a, int PM, hipStream_t st);
-int launch_newton_g1m0(int KP, const FitArgs &a, int PM, hipStream_t st);
-int launch_newton_g1m1(int KP, const FitArgs &a, int PM, hipStream_t st);
-int launch_newton_g1m2(int KP, const FitArgs &a, int PM, hipStream_t st);
+int launch_newton_g0m0(int KP, const FitArgs &a, int P, hipStream_t st);
+int launch_newton_g0m1(int KP, const FitArgs &a, int P, hipStream_t st);
+int launch_newton_g0m2(int KP, const FitArgs &a, int P, hipStream_t st);
+int launch_newton_g1m0(int KP, const FitArgs &a, int P, hipStream_t st);
+int launch_newton_g1m1(int KP, const FitArgs &a, int P, hipStream_t st);
+int launch_newton_g1m2(int KP, const FitArgs &a, int P, hipStream_t st);
 }  // namespace tsf

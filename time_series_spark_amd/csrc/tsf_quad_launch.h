@@ -119,9 +119,9 @@ static int launch_quad_mm(const QuadPlan &qp, const QuadArgs &qa, double *Mg, hi
         // 10 000 (9.7 -> 10.4 ms), where the launch is its longest fits and not throughput.  Hence from
         // TSF_QUAD_W4_MIN_PER_SLOT series per wave slot on.  The weights of a residual pass ride in the pool slot
         // when they are short (cfg5), else they go through the global scratch.
-        // TSF_QUAD_W4 = 0: never; n > 0: always, with at most n copies (tests, measurements).
-        const char *e = getenv("TSF_QUAD_W4");
-        const int forced = e ? atoi(e) : TSF_QUAD_W4_DEFAULT;
+        // TSF_OPT_QUAD_W4 0: never; n > 0: always, with at most n copies (tests, measurements).
+        const int e = qp.opt ? qp.opt[TSF_OPT_QUAD_W4] : -1;
+        const int forced = e >= 0 ? e : TSF_QUAD_W4_DEFAULT;
         const size_t pbase = quad_pool_base_bytes<PPL>(qp.P4, TSF_QUAD_NW4);
         const size_t avail = pbase < 160 * 1024 ? 160 * 1024 - pbase : 0;
         // short series: the staging rows ride in the slot when that still leaves TSF_QUAD_POOL_RB_MIN copies
@@ -140,10 +140,9 @@ static int launch_quad_mm(const QuadPlan &qp, const QuadArgs &qa, double *Mg, hi
     if (base + rbytes <= 160 * 1024) return launch_quad_rl<KP, PPL, MMODE, PQ, true>(qp, qa, Mg, st);
     // no room in LDS (the 12-waves-per-CU kernel on series of >= ~600 rows): the weights of the first
     // TSF_QUAD_NTR steps of a pass stay in registers (cfg2: all 12), those of later steps go through the
-    // global scratch (cfg3, 1 095 rows: 6 of 18).  TSF_QUAD_RREG=0: all of them (round 2's route; tests).
+    // global scratch (cfg3, 1 095 rows: 6 of 18).  TSF_OPT_QUAD_RREG 0: all of them (round 2's route; tests).
     if constexpr (MMODE == QM_LDS && PPL == 1 && PQ > 0) {
-        const char *e = getenv("TSF_QUAD_RREG");
-        if (!(e && atoi(e) == 0))
+        if (!(qp.opt && qp.opt[TSF_OPT_QUAD_RREG] == 0))
             return launch_quad_rl<KP, PPL, MMODE, PQ, false, TSF_QUAD_NTR>(qp, qa, Mg, st);
     }
     return launch_quad_rl<KP, PPL, MMODE, PQ, false>(qp, qa, Mg, st);

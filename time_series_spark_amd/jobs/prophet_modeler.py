@@ -85,6 +85,30 @@ def previous_run_cost(models, sidecar_only=False):
 COST_SIDECAR = '_tsf_cost.npz'         # leading underscore: Spark and pyarrow skip it when they read the directory
 
 
+class _CostVector(object):
+    """The iteration counts of a model frame as ONE value of DataFrame.attrs.  pandas compares attrs dicts with `==`
+    when frames are concatenated (`__finalize__`): a bare ndarray there raises "truth value of an array is ambiguous"
+    as soon as two frames of more than one series meet (round-4 advice); this compares as a whole."""
+    __slots__ = ('values',)
+
+    def __init__(self, values):
+        self.values = np.asarray(values)
+
+    def __eq__(self, other):
+        return isinstance(other, _CostVector) and np.array_equal(self.values, other.values)
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    __hash__ = None
+
+    def __len__(self):
+        return len(self.values)
+
+    def __array__(self, dtype=None, copy=None):
+        return self.values if dtype is None else self.values.astype(dtype)
+
+
 def _write_cost_sidecar(path, part, model_df):
     """The iteration counts persist_models' frame carries (model_df.attrs['tsf_cost'], set by _model_packed) next to
     the parquet part, with that part's size and mtime: previous_run_cost then reads 10 000 counts in under a
@@ -304,7 +328,7 @@ def _model_packed(config, panel, n_rows, execution_time, previous=None):
                         'floor': np.full(len(keep), floor), 'cap': cap[keep],
                         'model': pd.Series([blobs[n] for n in keep], dtype=object)},
                        columns=MODEL_OUTPUT_COLUMNS)
-    out.attrs['tsf_cost'] = n_iter[keep]            # persist_models writes them beside the parquet (scheduling hints of the next run)
+    out.attrs['tsf_cost'] = _CostVector(n_iter[keep])   # persist_models writes them beside the parquet (scheduling hints of the next run)
     print(f"Modeled {panel.N} series ({n_rows} rows) in {time.time() - execution_time}")
     return out
 

@@ -3,7 +3,7 @@ tables): the cfg2 series with lengths 640..730, linear/additive (quadratic form,
 Z^T Z built in-kernel) and the reference's logistic/multiplicative settings (residual form).
 The panel's 10 000 series share 91 distinct timestamp vectors (lengths 640..730 of one daily calendar), which since
 round 4 share grid tables and one prebuilt Z^T Z per vector: every (model) is timed that way ("grids": "shared", the
-default) and with TSF_GRID_SHARE=0 ("own": a grid per series, what a panel of unrelated calendars costs).
+default) and with the context option grid_share = 0 ("own": a grid per series, what a panel of unrelated calendars costs).
 Host entry point (PCIe copies outside the kernel time, which comes from the library's HIP events)."""
 import ctypes
 import json
@@ -33,7 +33,7 @@ for growth, mode in (('linear', 'additive'), ('logistic', 'multiplicative')):
     ms = ctypes.c_float(0.0)
     for grids in ('shared', 'own'):
         if grids == 'own':
-            os.environ['TSF_GRID_SHARE'] = '0'
+            ctx.set_option('grid_share', 0)
         out, wall = [], []
         import time
         for rep in range(3):
@@ -43,7 +43,7 @@ for growth, mode in (('linear', 'additive'), ('logistic', 'multiplicative')):
             wall.append((time.perf_counter() - t0) * 1e3)
             ctx.check(L.tsf_last_fit_kernel_ms(ctx.handle, ctypes.byref(ms)))
             out.append(float(ms.value))
-        os.environ.pop('TSF_GRID_SHARE', None)
+        ctx.set_option('grid_share', -1)
         print(json.dumps({'panel': 'ragged 10000 series, 640..730 rows, 91 distinct timestamp vectors', 'grids': grids,
                           'growth': growth, 'mode': mode, 'residual_kernel': os.environ.get('RK', 'auto'),
                           'fit_kernel_ms': out, 'host_call_ms': wall, 'series_per_s_kernel': N / (min(out) * 1e-3),

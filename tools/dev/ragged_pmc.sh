@@ -7,7 +7,7 @@ OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 for share in 0 1; do
-( cd /tmp && TSF_GRID_SHARE=$share timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/prof_fetch_share$share -o f --output-format csv -- python $OLDPWD/tools/bench_ragged.py > $OUT/run_share$share.log 2>&1 ); echo "share=$share rc=$?" | tee -a $OUT/summary.txt
+( cd /tmp && TSF_OPTIONS=grid_share=$share timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/prof_fetch_share$share -o f --output-format csv -- python $OLDPWD/tools/bench_ragged.py > $OUT/run_share$share.log 2>&1 ); echo "share=$share rc=$?" | tee -a $OUT/summary.txt
 python - <<PY | tee -a $OUT/summary.txt
 import csv, glob, collections
 per = collections.defaultdict(lambda: collections.defaultdict(float))
