@@ -166,6 +166,85 @@ static void suffix_scan(double v[CN_W])
     }
 }
 
+/* inclusive prefix sum over the 64 lanes, the mirror image of suffix_scan: Hillis-Steele (1,2,4,8) inside each
+ * group of 16 (out-of-group terms an explicit + 0.0), then the totals of the EARLIER groups as one carry:
+ * group 1 += T0, group 2 += T0 + T1, group 3 += (T0 + T1) + T2, group 0 += 0.0 */
+static void prefix_scan(double v[CN_W])
+{
+    double n[CN_W];
+    for (int off = 1; off < 16; off <<= 1) {
+        for (int L = 0; L < CN_W; ++L) n[L] = v[L] + (((L & 15) >= off) ? v[L - off] : 0.0);
+        memcpy(v, n, sizeof(n));
+    }
+    const double t0 = v[15], t1 = v[31], t2 = v[47];
+    const double s1 = t0 + t1;
+    const double s2 = s1 + t2;
+    for (int L = 0; L < CN_W; ++L) {
+        const int row = L >> 4;
+        const double carry = (row == 0) ? 0.0 : (row == 1 ? t0 : (row == 2 ? s1 : s2));
+        v[L] = v[L] + carry;
+    }
+}
+
+/* Scans of affine maps x -> a x + b over the 64 lanes (round 5: the changepoint recurrences of the logistic trend
+ * and their adjoint as scans instead of S-step chains).  compose(later, earlier) = later o earlier:
+ * (a2, b2) o (a1, b1) = (a2 a1, fma(a2, b1, b2)); out-of-group operands are the identity (1, 0).
+ * affine_prefix_scan: lane L ends with f_L o f_(L-1) o ... o f_0 -- Hillis-Steele (1,2,4,8) inside each group of 16
+ * (later = own, earlier = lane - off), then the composed maps of the earlier groups as one carry, applied as the
+ * EARLIER map: group 1: T0; group 2: T1 o T0; group 3: T2 o (T1 o T0) (T_r = lane 16 r + 15 after the in-group stages).
+ * affine_suffix_scan: lane L ends with f_L o f_(L+1) o ... o f_63 -- the mirror image (own = the LATER-applied...
+ * careful: in f_L o f_(L+1) the map of lane L is applied LAST, so own is `later` again and lane + off is `earlier`);
+ * carry of group 2: T3, group 1: T2 o T3, group 0: T1 o (T2 o T3) (T_r = lane 16 r after the in-group stages). */
+static void affine_prefix_scan(double a[CN_W], double b[CN_W])
+{
+    double na[CN_W], nb[CN_W];
+    for (int off = 1; off < 16; off <<= 1) {
+        for (int L = 0; L < CN_W; ++L) {
+            const int in = (L & 15) >= off;
+            const double ea = in ? a[L - off] : 1.0, eb = in ? b[L - off] : 0.0;
+            na[L] = a[L] * ea;
+            nb[L] = fma(a[L], eb, b[L]);
+        }
+        memcpy(a, na, sizeof(na)); memcpy(b, nb, sizeof(nb));
+    }
+    const double a0 = a[15], b0 = b[15], a1 = a[31], b1 = b[31], a2 = a[47], b2 = b[47];
+    const double c2a = a1 * a0, c2b = fma(a1, b0, b1);           /* T1 o T0 */
+    const double c3a = a2 * c2a, c3b = fma(a2, c2b, b2);         /* T2 o (T1 o T0) */
+    for (int L = 0; L < CN_W; ++L) {
+        const int row = L >> 4;
+        const double ea = (row == 0) ? 1.0 : (row == 1 ? a0 : (row == 2 ? c2a : c3a));
+        const double eb = (row == 0) ? 0.0 : (row == 1 ? b0 : (row == 2 ? c2b : c3b));
+        na[L] = a[L] * ea;
+        nb[L] = fma(a[L], eb, b[L]);
+    }
+    memcpy(a, na, sizeof(na)); memcpy(b, nb, sizeof(nb));
+}
+
+static void affine_suffix_scan(double a[CN_W], double b[CN_W])
+{
+    double na[CN_W], nb[CN_W];
+    for (int off = 1; off < 16; off <<= 1) {
+        for (int L = 0; L < CN_W; ++L) {
+            const int in = (L & 15) + off < 16;
+            const double ea = in ? a[L + off] : 1.0, eb = in ? b[L + off] : 0.0;
+            na[L] = a[L] * ea;
+            nb[L] = fma(a[L], eb, b[L]);
+        }
+        memcpy(a, na, sizeof(na)); memcpy(b, nb, sizeof(nb));
+    }
+    const double a1 = a[16], b1 = b[16], a2 = a[32], b2 = b[32], a3 = a[48], b3 = b[48];
+    const double c1a = a2 * a3, c1b = fma(a2, b3, b2);           /* T2 o T3 */
+    const double c0a = a1 * c1a, c0b = fma(a1, c1b, b1);         /* T1 o (T2 o T3) */
+    for (int L = 0; L < CN_W; ++L) {
+        const int row = L >> 4;
+        const double ea = (row == 3) ? 1.0 : (row == 2 ? a3 : (row == 1 ? c1a : c0a));
+        const double eb = (row == 3) ? 0.0 : (row == 2 ? b3 : (row == 1 ? c1b : c0b));
+        na[L] = a[L] * ea;
+        nb[L] = fma(a[L], eb, b[L]);
+    }
+    memcpy(a, na, sizeof(na)); memcpy(b, nb, sizeof(nb));
+}
+
 /* dot over (zero padded) 128-vectors */
 static double dotc(const double *a, const double *b)
 {
@@ -276,7 +355,7 @@ static cn_series *cn_prepare(const cn_spec *sp, int T, const int64_t *ds, const 
     int S = sp->n_changepoints;
     if (S + 1 > hist) S = hist - 1;
     if (S < 0) S = 0;
-    if (S > CN_MAX_S) { *err = CN_ERR_SIZE; free_series(se); return NULL; }
+    if (S > CN_MAX_S || 3 + S > CN_W - 1) { *err = CN_ERR_SIZE; free_series(se); return NULL; }     /* (the deltas live in lanes 3 .. 3 + S - 1) */
     se->S_out = S;
     if (S == 0) {
         /* fbprophet set_changepoints: no changepoints -> one dummy changepoint at t = 0.  The
@@ -350,10 +429,26 @@ static int cn_eval(cn_series *se, const double *th, double *f_out, double *g)
     if (se->growth == 0) {
         for (int j = 0; j < S; ++j) mc[j + 1] = mc[j] + ((-se->t_change[j]) * delta[j]);
     } else {
-        for (int j = 0; j < S; ++j) {
-            const double gamma = (se->t_change[j] - mc[j]) * (1.0 - ks[j] / ks[j + 1]);
-            mc[j + 1] = mc[j] + gamma;
+        /* Logistic growth, round 5: the two S-step chains as scans over the parameter lanes (delta_j lives in lane
+         * 3 + j, as in theta): ks[j+1] = k + (inclusive prefix sum of delta)[3 + j]  (prophet.stan:
+         * k + cumulative_sum(delta)); the offset recurrence m[j+1] = m[j] + (t_j - m[j]) (1 - ks[j] / ks[j+1]) is the
+         * affine map m -> rho_j m + t_j (1 - rho_j), rho_j = ks[j] / ks[j+1], and m[j+1] = A m + B with (A, B) the
+         * prefix composition of those maps. */
+        double pd[CN_W], fa[CN_W], fb[CN_W];
+        for (int L = 0; L < CN_W; ++L) pd[L] = (L >= 3 && L < 3 + S) ? delta[L - 3] : 0.0;
+        prefix_scan(pd);
+        for (int j = 0; j < S; ++j) ks[j + 1] = k + pd[3 + j];
+        for (int L = 0; L < CN_W; ++L) {
+            fa[L] = 1.0; fb[L] = 0.0;
+            if (L >= 3 && L < 3 + S) {
+                const int j = L - 3;
+                const double rho = ks[j] / ks[j + 1];
+                fa[L] = rho;
+                fb[L] = se->t_change[j] * (1.0 - rho);
+            }
         }
+        affine_prefix_scan(fa, fb);
+        for (int j = 0; j < S; ++j) mc[j + 1] = fma(fa[3 + j], m, fb[3 + j]);
     }
     double sseL[CN_W], tot1[CN_W], tot2[CN_W];
     double tp1[CN_MAX_S + 1], tp2[CN_MAX_S + 1];
@@ -462,18 +557,29 @@ static int cn_eval(cn_series *se, const double *th, double *f_out, double *g)
             D1[c] = A - mc[c] * B;
             D2[c] = -(ks[c] * B);
         }
-        double abar = D2[S];
-        for (int c = S - 1; c >= 0; --c) {
-            const double ratio = ks[c] / ks[c + 1];
-            const double rho_bar = abar * (se->t_change[c] - mc[c]);
-            D1[c] = D1[c] + rho_bar * (-1.0 / ks[c + 1]);
-            D1[c + 1] = D1[c + 1] + rho_bar * (ratio / ks[c + 1]);
-            abar = D2[c] + abar * ratio;
+        /* Reverse sweep through the offset recurrence, round 5: abar[c] = D2[c] + rho_c abar[c+1] (abar[S] = D2[S])
+         * as a suffix composition of the maps x -> rho_c x + D2[c] over the lanes c = 0 .. S (lane S: the constant map
+         * x -> D2[S]); rho_bar[c] = abar[c+1] (t_c - mc[c]); the two adjustments of D1 lane-parallel (own first, then
+         * the one from the segment before); the slope gradient's running sums as one suffix scan. */
+        double fa[CN_W], fb[CN_W], rb[CN_MAX_S + 1], ab[CN_W];
+        for (int L = 0; L < CN_W; ++L) {
+            fa[L] = 1.0; fb[L] = 0.0;
+            if (L < S) { fa[L] = ks[L] / ks[L + 1]; fb[L] = D2[L]; }
+            else if (L == S) { fa[L] = 0.0; fb[L] = D2[S]; }
         }
-        double sK = 0.0;
-        for (int c = S; c >= 1; --c) { sK = sK + D1[c]; gd[c - 1] = nis * sK; }
-        gk = nis * (sK + D1[0]);
-        gm = nis * abar;
+        affine_suffix_scan(fa, fb);                       /* abar[c] = fb[c] */
+        for (int c = 0; c < S; ++c) rb[c] = fb[c + 1] * (se->t_change[c] - mc[c]);
+        for (int L = 0; L < CN_W; ++L) ab[L] = 0.0;
+        for (int c = 0; c <= S; ++c) {
+            double d = D1[c];
+            if (c < S) d = d + rb[c] * (-1.0 / ks[c + 1]);
+            if (c >= 1) d = d + rb[c - 1] * ((ks[c - 1] / ks[c]) / ks[c]);
+            ab[c] = d;
+        }
+        suffix_scan(ab);
+        for (int c = S; c >= 1; --c) gd[c - 1] = nis * ab[c];
+        gk = nis * ab[0];
+        gm = nis * fb[0];
     }
     g[0] = gk + k / 25.0;
     g[1] = gm + m / 25.0;

@@ -289,6 +289,74 @@ __device__ __forceinline__ double suffix_scan(double v)
     return v + carry;
 }
 
+// ---- scans of round 5 (oracle prefix_scan / affine_prefix_scan / affine_suffix_scan) -----------------------------
+#define DPP_ROW_SHR(n) (0x110 + (n))    // lane i reads lane i-n of its 16-lane row
+constexpr int DPP_WAVE_SHL1 = 0x130;    // lane i reads lane i+1 of the WAVE (lane 63: nothing)
+constexpr int DPP_WAVE_SHR1 = 0x138;    // lane i reads lane i-1 of the WAVE (lane 0: nothing)
+
+// inclusive prefix sum over the 64 lanes, the mirror image of suffix_scan: Hillis-Steele (1,2,4,8) inside each 16-lane
+// row, then the totals of the earlier rows as one carry ((T0), (T0+T1), ((T0+T1)+T2))
+__device__ __forceinline__ double prefix_scan(double v)
+{
+    v = v + dpp_mov<DPP_ROW_SHR(1)>(v);
+    v = v + dpp_mov<DPP_ROW_SHR(2)>(v);
+    v = v + dpp_mov<DPP_ROW_SHR(4)>(v);
+    v = v + dpp_mov<DPP_ROW_SHR(8)>(v);
+    const double t0 = readlane_f64(v, 15), t1 = readlane_f64(v, 31), t2 = readlane_f64(v, 47);
+    const double s1 = t0 + t1;
+    const double s2 = s1 + t2;
+    const int row = ((int)threadIdx.x & (W - 1)) >> 4;
+    const double carry = (row == 0) ? 0.0 : (row == 1 ? t0 : (row == 2 ? s1 : s2));
+    return v + carry;
+}
+
+// Scans of affine maps x -> a x + b, one map per lane; (a2, b2) o (a1, b1) = (a2 a1, fma(a2, b1, b2)), out-of-row
+// operands the identity (1, 0).  Prefix: lane L ends with f_L o f_(L-1) o ... o f_0; suffix: f_L o f_(L+1) o ... o f_63
+// (own map applied last in both).  In-row Hillis-Steele stages 1,2,4,8, then the composed maps of the rows before
+// (after) as one carry -- prefix: T0 | T1 o T0 | T2 o (T1 o T0); suffix: T3 | T2 o T3 | T1 o (T2 o T3).
+template <int CTRL>
+__device__ __forceinline__ void affine_stage(double &a, double &b)
+{
+    const double ea = dpp_mov_masked<CTRL, 0xF>(1.0, a), eb = dpp_mov<CTRL>(b);
+    const double na = a * ea;
+    b = __builtin_fma(a, eb, b);
+    a = na;
+}
+__device__ __forceinline__ void affine_prefix_scan(double &a, double &b)
+{
+    affine_stage<DPP_ROW_SHR(1)>(a, b);
+    affine_stage<DPP_ROW_SHR(2)>(a, b);
+    affine_stage<DPP_ROW_SHR(4)>(a, b);
+    affine_stage<DPP_ROW_SHR(8)>(a, b);
+    const double a0 = readlane_f64(a, 15), b0 = readlane_f64(b, 15), a1 = readlane_f64(a, 31), b1 = readlane_f64(b, 31),
+                 a2 = readlane_f64(a, 47), b2 = readlane_f64(b, 47);
+    const double c2a = a1 * a0, c2b = __builtin_fma(a1, b0, b1);
+    const double c3a = a2 * c2a, c3b = __builtin_fma(a2, c2b, b2);
+    const int row = ((int)threadIdx.x & (W - 1)) >> 4;
+    const double ea = (row == 0) ? 1.0 : (row == 1 ? a0 : (row == 2 ? c2a : c3a));
+    const double eb = (row == 0) ? 0.0 : (row == 1 ? b0 : (row == 2 ? c2b : c3b));
+    const double na = a * ea;
+    b = __builtin_fma(a, eb, b);
+    a = na;
+}
+__device__ __forceinline__ void affine_suffix_scan(double &a, double &b)
+{
+    affine_stage<DPP_ROW_SHL(1)>(a, b);
+    affine_stage<DPP_ROW_SHL(2)>(a, b);
+    affine_stage<DPP_ROW_SHL(4)>(a, b);
+    affine_stage<DPP_ROW_SHL(8)>(a, b);
+    const double a1 = readlane_f64(a, 16), b1 = readlane_f64(b, 16), a2 = readlane_f64(a, 32), b2 = readlane_f64(b, 32),
+                 a3 = readlane_f64(a, 48), b3 = readlane_f64(b, 48);
+    const double c1a = a2 * a3, c1b = __builtin_fma(a2, b3, b2);
+    const double c0a = a1 * c1a, c0b = __builtin_fma(a1, c1b, b1);
+    const int row = ((int)threadIdx.x & (W - 1)) >> 4;
+    const double ea = (row == 3) ? 1.0 : (row == 2 ? a3 : (row == 1 ? c1a : c0a));
+    const double eb = (row == 3) ? 0.0 : (row == 2 ? b3 : (row == 1 ? c1b : c0b));
+    const double na = a * ea;
+    b = __builtin_fma(a, eb, b);
+    a = na;
+}
+
 // dot product over the parameter axis: slot 0 product, slot 1 fma'd in, then butterfly
 template <int PPL>
 __device__ __forceinline__ double pdot_part(const double (&a)[PPL], const double (&b)[PPL])

@@ -246,38 +246,12 @@ __device__ __forceinline__ void coop_segment_tables(const SeriesView &sv, L &w)
             }
         }
     } else {
-        if (lane == 0) {
-            double ksv = w.th[0];
-            w.ks[0] = ksv;
-            for (int j0 = 0; j0 < S; j0 += 8) {
-                double dj[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) dj[u] = w.th[3 + j0 + u];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) { ksv = ksv + dj[u]; w.ks[j0 + u + 1] = ksv; }
-            }
-        }
-        wave_sync();
-        // gamma_j = (t_change[j] - mc[j]) * (1 - ks[j] / ks[j+1]): the S quotients are one lane-parallel
-        // division (lane j), the chain reads them back
-        w.d1[lane] = (lane < S) ? 1.0 - w.ks[lane] / w.ks[lane + 1] : 0.0;
-        w.d2[lane] = sv.tc_l;
-        wave_sync();
-        if (lane == 0) {
-            double mcv = w.th[1];
-            w.mc[0] = mcv;
-            for (int j0 = 0; j0 < S; j0 += 8) {
-                double om[8], tc[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) { om[u] = w.d1[j0 + u]; tc[u] = w.d2[j0 + u]; }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const double gamma = (tc[u] - mcv) * om[u];
-                    mcv = mcv + gamma;
-                    w.mc[j0 + u + 1] = mcv;
-                }
-            }
-        }
+        // logistic (round 5): the chains as scans over the parameter lanes (logistic_tables_lanes, tsf_fit_kernels.h) --
+        // theta from the owner's LDS copy, lane p = parameter p
+        double ksn, mcn;
+        logistic_tables_lanes(w.th[0], w.th[1], w.th[lane], sv.tcp_l[0], S, ksn, mcn);
+        if (lane >= 3 && lane < 3 + S) { w.ks[lane - 2] = ksn; w.mc[lane - 2] = mcn; }
+        if (lane == 0) { w.ks[0] = w.th[0]; w.mc[0] = w.th[1]; }
     }
     wave_sync();
 }
@@ -295,54 +269,11 @@ __device__ __forceinline__ void coop_tail_trend(const SeriesView &sv, CoopLds<KP
     const double TA = lds.tot1[0], TB = lds.tot2[0];
     double gk, gm, gd = 0.0;
     if (GROWTH == 1) {
-        // per-segment sums from suffix sums, then reverse sweep through the gamma recurrence
-        {
-            const int c = lane;
-            if (c <= S) {
-                const int Ljm = (c > 0) ? sv.Ljm1_l : 0, Ljc = (c < S) ? sv.Lj_l : 0;
-                const double hiA = (c == 0) ? TA : lds.tp1[c - 1] + lds.tot1[Ljm + 1];
-                const double hiB = (c == 0) ? TB : lds.tp2[c - 1] + lds.tot2[Ljm + 1];
-                const double loA = (c == S) ? 0.0 : lds.tp1[c] + lds.tot1[Ljc + 1];
-                const double loB = (c == S) ? 0.0 : lds.tp2[c] + lds.tot2[Ljc + 1];
-                const double A = hiA - loA, B = hiB - loB;
-                lds.d1[c] = A - lds.mc[c] * B;
-                lds.d2[c] = -(lds.ks[c] * B);
-            }
-        }
-        wave_sync();
-        {
-            const int cl_ = lane <= S ? lane : S;
-            const double ratio_l = (lane < S) ? lds.ks[cl_] / lds.ks[cl_ + 1] : 0.0;
-            const double tmc_l = (lane < S) ? sv.tc_l - lds.mc[cl_] : 0.0;
-            const double d2_l = lds.d2[cl_];
-            double abar = readlane_f64(d2_l, S);
-            double rb_l = 0.0;
-            TSF_UNROLL4_DOWN(c, S - 1, 0, {
-                const double rbc = abar * readlane_f64(tmc_l, c);
-                if (lane == c) rb_l = rbc;
-                abar = readlane_f64(d2_l, c) + abar * readlane_f64(ratio_l, c);
-            });
-            if (lane < S) lds.rb[lane] = rb_l;
-            gm = nis * abar;
-        }
-        wave_sync();
-        {
-            const int c = lane;
-            if (c <= S) {
-                double d = lds.d1[c];
-                if (c < S) d = d + lds.rb[c] * (-1.0 / lds.ks[c + 1]);
-                if (c >= 1) d = d + lds.rb[c - 1] * ((lds.ks[c - 1] / lds.ks[c]) / lds.ks[c]);
-                lds.ab[c] = d;
-            }
-        }
-        wave_sync();
-        const double ab_l = lds.ab[lane <= S ? lane : S];
-        double sK = 0.0;
-        TSF_UNROLL4_DOWN(c, S, 1, {
-            sK = sK + readlane_f64(ab_l, c);
-            if (lane == 3 + (c - 1)) gd = nis * sK;
-        });
-        gk = nis * (sK + readlane_f64(ab_l, 0));
+        // (round 5) the reverse sweep and the running sums as scans: logistic_reverse_lanes, tsf_fit_kernels.h
+        double gd_l;
+        logistic_reverse_lanes(sv, lds, TA, TB, gk, gm, gd_l);
+        gk = nis * gk; gm = nis * gm;
+        if (lane >= 3 && lane < 3 + S) gd = nis * gd_l;
     } else {
         gk = nis * TA;
         gm = nis * TB;

@@ -175,6 +175,28 @@ __device__ __forceinline__ void column_sums_g(double (&acc)[G], double *accR)
 #define TSF_UNROLL4_UP(j, lo, hi, BODY) do { int j = (lo); for (; j + 4 <= (hi); ) { BODY; ++j; BODY; ++j; BODY; ++j; BODY; ++j; } for (; j < (hi); ++j) { BODY; } } while (0)
 #define TSF_UNROLL4_DOWN(c, hi, lo, BODY) do { int c = (hi); for (; c - 3 >= (lo); ) { BODY; --c; BODY; --c; BODY; --c; BODY; --c; } for (; c >= (lo); --c) { BODY; } } while (0)
 
+// Logistic growth, slope and offset of the trend segments as SCANS over the parameter lanes (round 5; oracle cn_eval):
+// lane p = 3 + j holds delta_j (th_l) and t_change[j] (tcp_l).  ks[j+1] = k + (inclusive prefix sum of delta)[p]
+// (prophet.stan: k + cumulative_sum(delta)); the offset recurrence m[j+1] = m[j] + (t_j - m[j]) (1 - ks[j] / ks[j+1]) is
+// the affine map m -> rho_j m + t_j (1 - rho_j), rho_j = ks[j] / ks[j+1] (ONE lane-parallel division), and
+// m[j+1] = fma(A, m, B) with (A, B) the prefix composition of those maps.  Out: lane 3 + j holds ks[j+1], mc[j+1].
+// ~110 vector instructions and 10 dependent stages instead of two chains of S steps (~12 instructions per step).
+__device__ __forceinline__ void logistic_tables_lanes(double k, double m, double th_l, double tcp_l, int S,
+                                                      double &ksn_out, double &mcn_out)
+{
+    const int lane = (int)threadIdx.x & (W - 1);
+    const bool isd = lane >= 3 && lane < 3 + S;
+    const double pd = prefix_scan(isd ? th_l : 0.0);
+    const double ksn = k + pd;
+    double ksp = dpp_mov<DPP_WAVE_SHR1>(ksn);              // ks[j] for j >= 1
+    if (lane == 3) ksp = k;
+    const double rho = isd ? ksp / ksn : 1.0;
+    double fa = rho, fb = isd ? tcp_l * (1.0 - rho) : 0.0;
+    affine_prefix_scan(fa, fb);
+    ksn_out = ksn;
+    mcn_out = __builtin_fma(fa, m, fb);
+}
+
 // Segment tables ks[c], mc[c] (slope and offset of trend segment c): sequential recurrences over
 // the changepoints.  Every lane runs the same S steps and lane c stops updating after its first c
 // terms, so lane c ends with exactly the sequentially rounded ks[c], mc[c] (no per-step LDS write /
@@ -194,24 +216,55 @@ __device__ __forceinline__ void segment_tables(const SeriesView &sv, L &lds, con
             const double mcn = mcv + ((-readlane_f64(tcl, j)) * dj);
             if (j < lane) { ksv = ksn; mcv = mcn; }
         });
+        if (lane <= S) { lds.ks[lane] = ksv; lds.mc[lane] = mcv; }
     } else {
-        // logistic: gamma_j needs ks[j] / ks[j+1].  ks does not depend on mc, so the ks chain
-        // runs first, the S quotients are ONE lane-parallel division (lane j: ks[j]/ks[j+1],
-        // the operands of the sequential form), and the mc chain reads them by lane.
-        double ks_next = k;
-        TSF_UNROLL4_UP(j, 0, S, {
-            const double ksn = ksv + readlane_f64(th[0], 3 + j);
-            if (j == lane) ks_next = ksn;
-            if (j < lane) ksv = ksn;
-        });
-        const double ratio = ksv / ks_next;
-        TSF_UNROLL4_UP(j, 0, S, {
-            const double gamma = (readlane_f64(tcl, j) - mcv) * (1.0 - readlane_f64(ratio, j));
-            const double mcn = mcv + gamma;
-            if (j < lane) mcv = mcn;
-        });
+        // logistic (round 5): the two S-step chains as scans, see logistic_tables_lanes
+        double ksn, mcn;
+        logistic_tables_lanes(k, m, th[0], sv.tcp_l[0], S, ksn, mcn);
+        if (lane >= 3 && lane < 3 + S) { lds.ks[lane - 2] = ksn; lds.mc[lane - 2] = mcn; }
+        if (lane == 0) { lds.ks[0] = k; lds.mc[0] = m; }
     }
-    if (lane <= S) { lds.ks[lane] = ksv; lds.mc[lane] = mcv; }
+}
+
+// Logistic growth, the trend part of the gradient as scans (round 5; oracle cn_eval): per-segment sums from the suffix
+// sums (lane c <= S), the reverse sweep through the offset recurrence abar[c] = D2[c] + rho_c abar[c+1] (abar[S] = D2[S])
+// as the suffix composition of the maps x -> rho_c x + D2[c] (lane S: the constant map), rho_bar[c] = abar[c+1]
+// (t_c - mc[c]), the two adjustments of D1 lane-parallel, and the slope gradient's running sums as one suffix scan.
+// Out (without the factor -1/sigma^2): gk_raw = sum of all adjusted D1, gm_raw = abar[0], and in lane 3 + j the running
+// sum that belongs to delta_j.  Reads lds.tot1 / tot2 / tp1 / tp2 / ks / mc; no scratch.
+template <class L>
+__device__ __forceinline__ void logistic_reverse_lanes(const SeriesView &sv, L &lds, double TA, double TB,
+                                                       double &gk_raw, double &gm_raw, double &gd_l)
+{
+    const int lane = (int)threadIdx.x & (W - 1);
+    const int S = sv.S, c = lane;
+    const bool seg = c <= S;
+    const int cc = seg ? c : S;                             // (lanes past S read in-range entries and are masked)
+    const double ks_c = lds.ks[cc], mc_c = lds.mc[cc];
+    const double ks_n = lds.ks[cc < S ? cc + 1 : S], ks_p = lds.ks[cc > 0 ? cc - 1 : 0];
+    double D1 = 0.0, D2 = 0.0;
+    if (seg) {
+        const int Ljm = (c > 0) ? sv.Ljm1_l : 0, Ljc = (c < S) ? sv.Lj_l : 0;
+        const double hiA = (c == 0) ? TA : lds.tp1[c - 1] + lds.tot1[Ljm + 1];
+        const double hiB = (c == 0) ? TB : lds.tp2[c - 1] + lds.tot2[Ljm + 1];
+        const double loA = (c == S) ? 0.0 : lds.tp1[c] + lds.tot1[Ljc + 1];
+        const double loB = (c == S) ? 0.0 : lds.tp2[c] + lds.tot2[Ljc + 1];
+        const double A = hiA - loA, B = hiB - loB;
+        D1 = A - mc_c * B;
+        D2 = -(ks_c * B);
+    }
+    double fa = (c < S) ? ks_c / ks_n : (c == S ? 0.0 : 1.0), fb = seg ? D2 : 0.0;
+    affine_suffix_scan(fa, fb);                             // fb: abar[c]
+    const double ab_next = dpp_mov<DPP_WAVE_SHL1>(fb);      // abar[c + 1]
+    const double rb = (c < S) ? ab_next * (sv.tc_l - mc_c) : 0.0;
+    const double rb_prev = dpp_mov<DPP_WAVE_SHR1>(rb);      // rb[c - 1]
+    double d = D1;
+    if (c < S) d = d + rb * (-1.0 / ks_n);
+    if (c >= 1 && seg) d = d + rb_prev * ((ks_p / ks_c) / ks_c);
+    const double ss = suffix_scan(seg ? d : 0.0);
+    gk_raw = readlane_f64(ss, 0);
+    gm_raw = readlane_f64(fb, 0);
+    gd_l = dpp_mov<DPP_WAVE_SHR1>(dpp_mov<DPP_WAVE_SHR1>(ss));      // lane 3 + j: ss[j + 1]
 }
 
 // f and the gradient from the time-axis sums of one evaluation: lds.tot1 / tot2 (suffix sums of the
@@ -248,60 +301,13 @@ __device__ __forceinline__ bool eval_tail(const DevSpec *__restrict__ sp, const 
 
     const double nis = -inv_s2;
     double gk = 0.0, gm = 0.0;
-    if (GROWTH == 1) {
-        // per-segment sums from suffix sums, then reverse sweep through the gamma recurrence
-        for (int c = lane; c <= S; c += W) {
-            const int Ljm = (c > 0) ? sv.Ljm1_l : 0, Ljc = (c < S) ? sv.Lj_l : 0;     // c == lane (S < 64)
-            const double hiA = (c == 0) ? TA : lds.tp1[c - 1] + lds.tot1[Ljm + 1];
-            const double hiB = (c == 0) ? TB : lds.tp2[c - 1] + lds.tot2[Ljm + 1];
-            const double loA = (c == S) ? 0.0 : lds.tp1[c] + lds.tot1[Ljc + 1];
-            const double loB = (c == S) ? 0.0 : lds.tp2[c] + lds.tot2[Ljc + 1];
-            const double A = hiA - loA, B = hiB - loB;
-            scr.d1[c] = A - lds.mc[c] * B;
-            scr.d2[c] = -(lds.ks[c] * B);
-        }
-        TSF_WAVE_SYNC();
-        {
-            // reverse sweep through the gamma recurrence: the per-step operands (ks[c]/ks[c+1],
-            // t_change[c] - mc[c], d2[c]) are prepared lane-parallel (lane c), the sequential
-            // chain itself only multiplies and adds
-            const int cl = lane <= S ? lane : S;
-            const double ratio_l = (lane < S) ? lds.ks[cl] / lds.ks[cl + 1] : 0.0;
-            const double tmc_l = (lane < S) ? sv.tc_l - lds.mc[cl] : 0.0;
-            const double d2_l = scr.d2[cl];
-            double abar = readlane_f64(d2_l, S);
-            double rb_l = 0.0;                  // lane c keeps rb[c]; one LDS write after the chain
-            TSF_UNROLL4_DOWN(c, S - 1, 0, {
-                const double rbc = abar * readlane_f64(tmc_l, c);
-                if (lane == c) rb_l = rbc;
-                abar = readlane_f64(d2_l, c) + abar * readlane_f64(ratio_l, c);
-            });
-            if (lane < S) scr.rb[lane] = rb_l;
-            gm = nis * abar;
-        }
-        TSF_WAVE_SYNC();
-        for (int c = lane; c <= S; c += W) {
-            double d = scr.d1[c];
-            if (c < S) d = d + scr.rb[c] * (-1.0 / lds.ks[c + 1]);
-            if (c >= 1) d = d + scr.rb[c - 1] * ((lds.ks[c - 1] / lds.ks[c]) / lds.ks[c]);
-            scr.ab[c] = d;
-        }
-        TSF_WAVE_SYNC();
-    }
-
 #pragma unroll
     for (int s = 0; s < PPL; ++s) g[s] = 0.0;
     if (GROWTH == 1) {
-        // sequential suffix of the adjusted per-segment sums: gd[c-1] = nis * sum_{c'>=c} D1[c']
-        // (ab[c] read once, lane c holding ab[c]; the chain takes it from there with v_readlane)
-        const double ab_l = scr.ab[lane <= S ? lane : S];
-        double sK = 0.0;
-        TSF_UNROLL4_DOWN(c, S, 1, {
-            sK = sK + readlane_f64(ab_l, c);
-            if (lane == 3 + (c - 1)) g[0] = nis * sK;
-            if (PPL == 2 && lane + W == 3 + (c - 1)) g[PPL - 1] = nis * sK;
-        });
-        gk = nis * (sK + readlane_f64(ab_l, 0));
+        double gd_l;
+        logistic_reverse_lanes(sv, lds, TA, TB, gk, gm, gd_l);
+        gk = nis * gk; gm = nis * gm;
+        if (lane >= 3 && lane < 3 + S) g[0] = nis * gd_l;
     } else {
         gk = nis * TA;
         gm = nis * TB;
@@ -907,8 +913,11 @@ __global__ __launch_bounds__(64) void eval_kernel(FitArgs a)
 #ifndef TSF_HARM_WPS
 #define TSF_HARM_WPS 3      // waves per SIMD the HARM kernels are compiled for (<= 168 registers)
 #endif
+#ifndef TSF_HARM_SPARSE_WPS
+#define TSF_HARM_SPARSE_WPS 2   // ... and their sparse-column form (the entry lists' cursors and the two-slot optimiser vectors
+#endif                          // do not fit 168 registers: at three waves per SIMD it spills 69 of them and loses to the table kernel)
 template <int KP, int GROWTH, int MODE, int PPL, bool XIDX = false, int GNTR = 0, bool SPARSE = false, int HARM = 0>
-__global__ __launch_bounds__(64, HARM != 0 ? TSF_HARM_WPS : ((GNTR > 0 || SPARSE) ? 2 : TSF_FIT_WPS)) void fit_kernel(FitArgs a)
+__global__ __launch_bounds__(64, HARM != 0 ? (SPARSE ? TSF_HARM_SPARSE_WPS : TSF_HARM_WPS) : ((GNTR > 0 || SPARSE) ? 2 : TSF_FIT_WPS)) void fit_kernel(FitArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int KL = SPARSE ? 64 : KP;            // SPARSE: tables and LDS of the 64-column model, registers of the 28-column one

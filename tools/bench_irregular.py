@@ -40,10 +40,18 @@ for growth, mode in (('logistic', 'multiplicative'), ('linear', 'additive')):
     evals = float(r.n_eval.sum())
     rows = float(lens.sum())
     k = min(out) * 1e-3
-    # the design table of a series ([NT][KP = 28][64] doubles) is read once per evaluation of the residual form
-    x_bytes = float(np.sum(np.ceil(lens / 64) * 28 * 64 * 8 * r.n_eval)) if growth == 'logistic' else None
+    # what an evaluation of the residual form reads per row: round 4 the design row ([KP = 28] doubles) + t, y, the
+    # segment word; round 5 (base-pair kernel) two doubles per seasonality + t, y, the segment word
+    harm = ctx.get_option('harm') != 0
+    row_bytes = (2 * 2 * 8 if harm else 28 * 8) + 8 + 8 + 2
+    x_bytes = float(np.sum(np.ceil(lens / 64) * 64 * row_bytes * r.n_eval)) if growth == 'logistic' else None
+    # SURVEY 8d's algorithmic bytes: ds + y in, theta out, once per series (no forecast in this tool)
+    alg = float(np.sum(lens * 16 + 54 * 8))
     print(json.dumps({'panel': '%d series of 600..730 rows at their own irregular timestamps' % N, 'growth': growth, 'mode': mode,
-                      'fit_kernel_ms': out, 'series_per_s_kernel': N / k, 'mean_evals': evals / N,
-                      'design_table_bytes_read_by_the_evaluations': x_bytes,
-                      'design_table_GBps': None if x_bytes is None else x_bytes / k / 1e9,
+                      'fit_kernel_ms': out, 'series_per_s_kernel': N / k, 'mean_evals': evals / N, 'max_evals': int(r.n_eval.max()),
+                      'status_counts': {str(int(a)): int(b) for a, b in zip(*np.unique(r.status, return_counts=True))},
+                      'base_pair_kernel': bool(harm and growth == 'logistic'),
+                      'row_bytes_read_by_the_evaluations': x_bytes,
+                      'row_bytes_GBps': None if x_bytes is None else x_bytes / k / 1e9,
+                      'algorithmic_bytes': alg, 'algorithmic_GBps': alg / k / 1e9,
                       'status_ok': int((r.status > 0).sum())}), flush=True)
