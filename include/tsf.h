@@ -188,6 +188,10 @@ enum {
     TSF_OPT_QUAD_RREG,       /* 0: residual-pass weights staged through memory */
     TSF_OPT_NEWTON_BATCH,    /* series per resident wave from which Newton runs several series per wave (0: never) */
     TSF_OPT_NEWTON_FLAGS, TSF_OPT_NEWTON_NS, TSF_OPT_NEWTON_LCAP, TSF_OPT_NEWTON_FILL,   /* dev knobs of that kernel */
+    TSF_OPT_DEBUG_ASYNC_SCRATCH, /* dev (tools/dev/nb_debug.py): bit 0 the slot records of that kernel from hipMallocAsync /
+                                hipFreeAsync as in round 3 instead of the context's cached block; bit 1 synchronise the
+                                stream before the free; bit 2 canary pages either side of the records, checked after the
+                                kernel (count on stderr); bit 3 the default pool never releases memory */
     TSF_OPT_COUNT
 };
 int tsf_set_option(tsf_ctx *ctx, int option, int value);

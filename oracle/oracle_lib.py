@@ -107,6 +107,16 @@ def neg_log_prob_grad(dat, theta):
     return f.value, g, rc
 
 
+def neg_log_prob_grad_packed(packed, theta):
+    """neg_log_prob_grad on a `pack(dat)` result (callers that evaluate one series thousands of times)."""
+    d, keep = packed
+    theta = _f64(theta)
+    g = np.zeros_like(theta)
+    f = ctypes.c_double(0.0)
+    rc = lib().oracle_fg(ctypes.byref(d), theta.ctypes.data, ctypes.byref(f), g.ctypes.data)
+    return f.value, g, rc
+
+
 def stan_lbfgs(dat, theta0, **opts):
     """Run the restated Stan L-BFGS from theta0; returns (theta, info)."""
     d, keep = pack(dat)

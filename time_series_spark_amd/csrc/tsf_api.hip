@@ -624,7 +624,7 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
         qa.f = a; qa.Mg = (const double *)(ws + l.Mg); qa.Mslot = (double *)(ws + l.Mslot);
         qa.rbuf = (double *)(ws + l.rbuf);
         qa.counter = (int *)(ws + l.counter); qa.P4 = qp.P4;
-        if (aligned) {
+        if (aligned && !(ctx->opt[TSF_OPT_DEBUG_ASYNC_SCRATCH] > 0 && (ctx->opt[TSF_OPT_DEBUG_ASYNC_SCRATCH] & 1))) {
             const size_t need = newton_batch_scratch_bytes(hs.KP, fit_P(hs.n_cp, hs.K) | 1, N, NTmax, ctx->n_cu, ctx->opt);
             if (need > ctx->nb_ws_bytes) {
                 if (ctx->nb_ws) { HIP_TRY(ctx, hipFree(ctx->nb_ws)); ctx->nb_ws = nullptr; ctx->nb_ws_bytes = 0; }

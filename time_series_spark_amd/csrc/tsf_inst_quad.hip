@@ -258,8 +258,24 @@ static int launch_newton_batch(const QuadPlan &qp, const QuadArgs &qa, double *M
     // The records come from the caller's cached workspace, NOT from hipMallocAsync: with stream-ordered
     // scratch of this size (gigabytes, above the pool's release threshold) fits went wrong intermittently
     // after a large call on this ROCm (tools/dev/nb_debug.py; plain hipMalloc: never)
-    if (!qa.nb_buf || qa.nb_bytes < rec_bytes + idx_bytes) return -2;
+    // TSF_OPT_DEBUG_ASYNC_SCRATCH (dev): round 3's stream-ordered scratch again, with the instruments of the round-4
+    // review around it -- canary pages, a synchronisation before the free, a pool that never releases
+    const int dbg_async = (qp.opt && qp.opt[TSF_OPT_DEBUG_ASYNC_SCRATCH] > 0) ? qp.opt[TSF_OPT_DEBUG_ASYNC_SCRATCH] : 0;
+    constexpr size_t CANARY = (size_t)1 << 20;
+    void *async_base = nullptr;
     void *buf = qa.nb_buf;
+    if (dbg_async & 1) {
+        if (dbg_async & 8) {
+            hipMemPool_t pool; int dev = 0; hipGetDevice(&dev);
+            if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) { uint64_t thr = UINT64_MAX; hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr); }
+        }
+        const size_t pad = (dbg_async & 4) ? CANARY : 0;
+        if (hipMallocAsync(&async_base, rec_bytes + idx_bytes + 2 * pad, st) != hipSuccess) { (void)hipGetLastError(); return -2; }
+        buf = (char *)async_base + pad;
+        if (pad) { hipMemsetAsync(async_base, 0x5C, pad, st); hipMemsetAsync((char *)buf + rec_bytes + idx_bytes, 0x5C, pad, st); }
+    } else if (!qa.nb_buf || qa.nb_bytes < rec_bytes + idx_bytes) {
+        return -2;
+    }
     nb.rec = (double *)buf;
     nb.rot_idx = (int *)((char *)buf + rec_bytes);
     if (qp.opt && qp.opt[TSF_OPT_NEWTON_FILL] >= 0) hipMemsetAsync(buf, qp.opt[TSF_OPT_NEWTON_FILL], rec_bytes + idx_bytes, st);   // dev: 255 = NaN everywhere
@@ -286,7 +302,21 @@ static int launch_newton_batch(const QuadPlan &qp, const QuadArgs &qa, double *M
     }
 #endif
     hipLaunchKernelGGL((newton_batch_kernel<KP>), dim3((unsigned)blocks), dim3(64), lds, st, qa, PM, nb);
-    return (int)hipGetLastError();
+    const int lrc = (int)hipGetLastError();
+    if (async_base) {
+        if (dbg_async & 4) {
+            std::vector<unsigned char> h(2 * CANARY);
+            hipMemcpyAsync(h.data(), async_base, CANARY, hipMemcpyDeviceToHost, st);
+            hipMemcpyAsync(h.data() + CANARY, (char *)buf + rec_bytes + idx_bytes, CANARY, hipMemcpyDeviceToHost, st);
+            hipStreamSynchronize(st);
+            size_t bad = 0;
+            for (unsigned char c : h) bad += c != 0x5C;
+            fprintf(stderr, "[async-scratch] %zu bytes of records, canary bytes overwritten: %zu\n", rec_bytes + idx_bytes, bad);
+        }
+        if (dbg_async & 2) hipStreamSynchronize(st);
+        hipFreeAsync(async_base, st);
+    }
+    return lrc;
 }
 
 template <int KP>
