@@ -4,6 +4,8 @@ vectors.  Bar: floating-point forecasts within the north-star 1e-4 relative tole
 (BASELINE.json); because product and oracle share one canonical arithmetic the tests also
 assert the much sharper "identical bits" wherever both are run.  Parity is vs the restated
 oracle, NOT real fbprophet (parity unpinned, see oracle/ headers)."""
+import os
+
 import numpy as np
 import pandas as pd
 import pytest
@@ -1739,3 +1741,23 @@ def test_randomised_newton_shapes_against_oracle(env):
                 assert n_bit_diff(rr.theta[n][:3 + S], o['theta'][:3 + S]) == 0, (trial, n, 'ragged')
                 n_cases += 1
     assert n_cases >= 30
+
+
+def test_stream_ordered_allocator_probe(env):
+    """tools/probes/mallocasync_probe.hip (no library code; profiles/r05_mallocasync/README.md): hipMallocAsync blocks of
+    gigabytes, a kernel that writes and re-reads them in rounds, hipFreeAsync right behind the launches.  With a pool
+    that never releases memory (mode 1) the program must be clean -- the kernels and the checks themselves are sound --;
+    with the default pool attributes (mode 14: the bare pattern) ROCm 7.2.0 corrupts the running kernel's block, which is
+    why the library allocates no stream-ordered scratch.  The default-mode outcome is printed, not asserted."""
+    import shutil
+    import subprocess
+    src = os.path.join(helpers.ROOT, 'tools', 'probes', 'mallocasync_probe.hip')
+    exe = os.path.join(helpers.ROOT, 'tools', 'probes', 'bin', 'mallocasync_probe')
+    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+        hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+        os.makedirs(os.path.dirname(exe), exist_ok=True)
+        subprocess.check_call([hipcc, '--offload-arch=gfx950', '-O3', '-w', src, '-o', exe])
+    clean = subprocess.run([exe, '1'], capture_output=True, text=True, timeout=600)
+    assert clean.returncode == 0 and 'MALLOCASYNC_PROBE_CLEAN' in clean.stdout, clean.stdout[-2000:]
+    bare = subprocess.run([exe, '14'], capture_output=True, text=True, timeout=600)
+    print('default pool attributes, bare pattern:', bare.stdout.strip().splitlines()[-1])

@@ -972,3 +972,27 @@ def test_model_frames_with_iteration_counts_concatenate():
     same = pd.concat([frames[0], frames[0].copy()], ignore_index=True)
     assert len(same) == 6
     assert np.array_equal(np.asarray(frames[1].attrs['tsf_cost'], dtype=np.int64), [6, 7, 8]) and len(frames[1].attrs['tsf_cost']) == 3
+
+
+def test_no_stream_ordered_allocation_in_product_paths():
+    """profiles/r05_mallocasync/README.md: on ROCm 7.2.0 a gigabyte-sized hipMallocAsync block freed with hipFreeAsync
+    behind the launches that use it is released while they still run (default pool release threshold; standalone
+    reproducer tools/probes/mallocasync_probe.hip) -- the cause of round 3's intermittently wrong Newton fits.  The
+    library therefore takes every scratch buffer from cached hipMalloc blocks of the context; the only stream-ordered
+    allocation left is the debug path behind TSF_OPT_DEBUG_ASYNC_SCRATCH in launch_newton_batch."""
+    import glob
+    import re
+    root = os.path.join(helpers.ROOT, 'time_series_spark_amd', 'csrc')
+    hits = []
+    for f in sorted(glob.glob(os.path.join(root, '*'))):
+        if not f.endswith(('.h', '.hip', '.inc', '.cpp')):
+            continue
+        src = open(f).read()
+        code = re.sub(r'//[^\n]*', '', src)                 # comments may talk about it
+        for m in re.finditer(r'hip(Malloc|Free)Async|hipMallocFromPoolAsync', code):
+            hits.append((os.path.basename(f), code[:m.start()].count('\n') + 1))
+    files = {h[0] for h in hits}
+    assert files <= {'tsf_inst_quad.hip'}, hits
+    q = open(os.path.join(root, 'tsf_inst_quad.hip')).read()
+    # ... and there only under the debug switch
+    assert 'dbg_async & 1' in q and q.count('hipMallocAsync(') == 1 and q.count('hipFreeAsync(') == 1

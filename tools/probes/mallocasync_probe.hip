@@ -11,7 +11,9 @@
 //   buffer (ensure_ws growing: hipFree synchronises the device and may hand the pool's memory back), a long-lived
 //   hipMalloc'd "workspace" whose contents are re-verified after every call (aliasing with pool memory), and a second
 //   stream that allocates from the same pool while the first stream's kernels still run.
-// Modes (argv[1]): 0 default pool attributes; 1 release threshold = max (the pool never returns memory).
+// Modes (argv[1], bit mask): 1 release threshold = max (the pool never returns memory); 2 no second stream;
+// 4 no unrelated hipMalloc / hipFree between the calls; 8 no synchronous hipMemcpy behind the free (only the
+// hipDeviceSynchronize at the end of the call).
 // Prints the number of corrupted words per phase; exit code 0 = nothing wrong seen.
 //   hipcc --offload-arch=gfx950 -O3 tools/probes/mallocasync_probe.hip -o tools/probes/bin/mallocasync_probe
 #include <hip/hip_runtime.h>
@@ -60,7 +62,7 @@ int main(int argc, char **argv)
     hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0));
     printf("device %s, HIP runtime %d, driver %d, mode %d\n", prop.name, rt, drv, mode);
     hipStream_t s1, s2; CHECK(hipStreamCreate(&s1)); CHECK(hipStreamCreate(&s2));
-    if (mode == 1) {
+    if (mode & 1) {
         hipMemPool_t pool; CHECK(hipDeviceGetDefaultMemPool(&pool, 0));
         uint64_t thr = UINT64_MAX; CHECK(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr));
     }
@@ -82,18 +84,20 @@ int main(int argc, char **argv)
             k_write<<<1024, 64, 0, st>>>(p, n, (uint64_t)call + 100 * streams, 6);
             k_verify<<<2048, 256, 0, st>>>(p, n, (uint64_t)call + 100 * streams, bad);
             // a second stream takes pool memory while the kernels above are still running
-            uint64_t *q = nullptr;
-            const size_t qn = (size_t)32 << 20;
-            CHECK(hipMallocAsync((void **)&q, qn * 8, s2));
-            k_fill<<<512, 256, 0, s2>>>(q, qn, 5000 + call);
-            k_verify<<<512, 256, 0, s2>>>(q, qn, 5000 + call, bad + 1);
-            CHECK(hipFreeAsync(q, s2));
+            if (!(mode & 2)) {
+                uint64_t *q = nullptr;
+                const size_t qn = (size_t)32 << 20;
+                CHECK(hipMallocAsync((void **)&q, qn * 8, s2));
+                k_fill<<<512, 256, 0, s2>>>(q, qn, 5000 + call);
+                k_verify<<<512, 256, 0, s2>>>(q, qn, 5000 + call, bad + 1);
+                CHECK(hipFreeAsync(q, s2));
+            }
             unsigned long long inner = 0;
             CHECK(hipMemcpyAsync(&inner, p + n, 8, hipMemcpyDeviceToHost, st));
             CHECK(hipFreeAsync(p, st));                    // right behind the launches, as the library did
             // what the host-pointer wrappers do next: a synchronous copy on the null stream
-            CHECK(hipMemcpy(host.data(), ws, host.size() * 8, hipMemcpyDeviceToHost));
-            if (call % 3 == 1) {                           // ensure_ws growing: an unrelated hipMalloc + hipFree (device sync)
+            if (!(mode & 8)) CHECK(hipMemcpy(host.data(), ws, host.size() * 8, hipMemcpyDeviceToHost));
+            if (call % 3 == 1 && !(mode & 4)) {                           // ensure_ws growing: an unrelated hipMalloc + hipFree (device sync)
                 void *u = nullptr; CHECK(hipMalloc(&u, (size_t)(1 + call % 4) << 28)); CHECK(hipMemset(u, 0xA5, 1 << 20)); CHECK(hipFree(u));
             }
             CHECK(hipStreamSynchronize(s2)); CHECK(hipDeviceSynchronize());

@@ -16,7 +16,10 @@ import multiprocessing as mp
 import os
 import sys
 
-import numpy as np
+for _v in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS'):      # one series per process: no BLAS threads under the pool
+    os.environ.setdefault(_v, '1')
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
