@@ -134,12 +134,14 @@ def test_hip_fit_and_predict_against_the_literal_prophet(fc, case):
 @pytest.mark.parametrize('case', ['cfg2_linear_additive', 'ref_logistic_multiplicative', 'short_90',
                                   'logistic_additive_400', 'cfg4_holidays', 'short_90@newton'])
 def test_hip_map_estimate_against_an_independent_optimiser(fc, case):
-    """scipy's L-BFGS-B (own line search, own stopping rule, tight tolerance) on the LITERAL numpy
-    log-posterior from fbprophet's initial values, against the end point of the HIP fit (Stan's
-    L-BFGS, or Stan's Newton for the 90-row case): the objective within a small gap of scipy's
-    minimum and the in-sample curves within a fraction of the fitted noise level.  Same bounds as the
-    CPU twin of this test (tests/test_oracle.py), measured there."""
-    from scipy.optimize import minimize
+    """The end point of the HIP fit (Stan's L-BFGS, or Stan's Newton for the 90-row case) against the TRUE MAP of the
+    LITERAL numpy log-posterior (oracle/true_map.py: the Laplace prior made linear by splitting delta, L-BFGS-B with
+    bounds to a projected gradient of ~1e-7, from two starting points that must agree): the HIP objective is never
+    below the optimum and above it by no more than the band measured on 256 + 64 series
+    (profiles/r05_true_map/report.json), and the in-sample curves agree within a fraction of the fitted noise level.
+    Same statement as the CPU twin of this test (tests/test_oracle.py); round 4 allowed +-0.5 against an optimiser
+    that stalls on the kinks like Stan does."""
+    from oracle import true_map
     from oracle.fbprophet_restated import stan_neg_log_prob_grad, stan_trend, unpack_theta
     from time_series_spark_amd import _lib
     newton = case.endswith('@newton')
@@ -148,15 +150,17 @@ def test_hip_map_estimate_against_an_independent_optimiser(fc, case):
         spec = type(spec).from_dict(dict(spec.to_dict(), lbfgs=dict(spec.lbfgs, algorithm=_lib.ALGO_NEWTON)))
     r = fc.fit_aligned(spec, ds, y[:1], floor=floor[:1], cap=cap[:1], extra=extra)
     assert r.status[0] > 0
-    res = minimize(lambda th: stan_neg_log_prob_grad(dat, th), th0, jac=True, method='L-BFGS-B',
-                   options=dict(maxiter=50000, maxfun=200000, ftol=1e-15, gtol=1e-7, maxcor=20))
     f_hip, _ = stan_neg_log_prob_grad(dat, r.theta[0])
-    gap = f_hip - res.fun
-    assert -0.5 <= gap <= 0.5, (case, gap)
+    th_a, info_a = true_map.solve(dat, r.theta[0])
+    th_b, info_b = true_map.solve(dat, th0)
+    assert abs(info_a['f'] - info_b['f']) <= 1e-7 * max(1.0, abs(info_a['f'])), (case, info_a, info_b)
+    gap = f_hip - min(info_a['f'], info_b['f'])
+    assert -1e-6 <= gap <= (8.0 if spec.growth == 'linear' else 50.0), (case, gap)
+    res_x = th_a if info_a['f'] <= info_b['f'] else th_b
 
     def fitted(th):
         k, mm, ls, delta, beta = unpack_theta(th, dat['S'], dat['K'])
         X = dat['X']
         return stan_trend(dat, k, mm, delta) * (1 + X @ (beta * dat['s_m'])) + X @ (beta * dat['s_a'])
-    a, b = fitted(r.theta[0]), fitted(res.x)
-    assert np.sqrt(np.mean((a - b) ** 2)) <= 0.05 * np.exp(res.x[2]), case
+    a, b = fitted(r.theta[0]), fitted(res_x)
+    assert np.sqrt(np.mean((a - b) ** 2)) <= 0.05 * np.exp(res_x[2]), case

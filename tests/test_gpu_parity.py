@@ -1761,3 +1761,33 @@ def test_stream_ordered_allocator_probe(env):
     assert clean.returncode == 0 and 'MALLOCASYNC_PROBE_CLEAN' in clean.stdout, clean.stdout[-2000:]
     bare = subprocess.run([exe, '14'], capture_output=True, text=True, timeout=600)
     print('default pool attributes, bare pattern:', bare.stdout.strip().splitlines()[-1])
+
+
+def test_baseline_config_1_every_series_against_the_oracle(env):
+    """BASELINE config 1 -- 100 synthetic daily series x 365 points with the reference's own settings (logistic growth,
+    floor 0, cap = 1.1 max y, multiplicative seasonality, fbprophet's auto rule: 364 days -> weekly only) -- is timed
+    by bench.py (`other_baseline_configs.cfg1`) and had no test of its own (round-4 review): all 100 series, fit and
+    90-step forecast, bit for bit against the oracle; the route is the base-pair kernel (HARM_W3, 8 columns) with the
+    cooperative tail, and the table kernel must give the same bits."""
+    fc, cl = env
+    from time_series_spark_amd import synth
+    N, T, H = 100, 365, 90
+    ds, y = synth.make_panel(N, T, 'logistic', seed=751)
+    seas = fc.ModelSpec.auto_seasonalities(ds, seasonality_mode='multiplicative')
+    assert [s['name'] for s in seas] == ['weekly']
+    spec = fc.ModelSpec(growth='logistic', seasonality_mode='multiplicative', seasonalities=seas)
+    floor, cap = np.zeros(N), y.max(axis=1) * 1.1
+    fut = ds[-1] + helpers.DAY_NS * np.arange(1, H + 1)
+    r = fc.fit_aligned(spec, ds, y, floor=floor, cap=cap)
+    yhat = fc.predict(spec, r.theta, r.y_scale, r.grid, fut, floor=floor, cap=cap)
+    csp = helpers.oracle_spec(spec)
+    for n in range(N):
+        o = cl.fit(csp, ds, y[n], 0.0, cap[n])
+        assert (r.status[n], r.n_iter[n], r.n_eval[n]) == (o['status'], o['n_iter'], o['n_eval']), n
+        assert n_bit_diff(r.theta[n], o['theta']) == 0 and n_bit_diff(r.fval[n], o['f']) == 0, n
+        yo, _ = cl.predict(csp, o, fut, 0.0, cap[n])
+        assert n_bit_diff(yhat[n], yo) == 0, n
+    with fc.get_context().options(harm=0):
+        r2 = fc.fit_aligned(spec, ds, y, floor=floor, cap=cap)
+    for name in ('theta', 'fval', 'n_iter', 'n_eval', 'status'):
+        assert np.array_equal(getattr(r, name), getattr(r2, name)), name

@@ -642,34 +642,37 @@ def test_seeded_intervals_agree_with_the_literal_sampler(case):
 @pytest.mark.parametrize('case', ['cfg2_linear_additive', 'ref_logistic_multiplicative', 'short_90',
                                   'logistic_additive_400', 'cfg4_holidays', 'short_90@newton'])
 def test_map_estimate_against_an_independent_optimiser(case):
-    """A pin that does not go through this repo's restatement of Stan's optimiser: scipy's L-BFGS-B
-    (its own line search, its own stopping rule, run to a tight tolerance) on the LITERAL numpy
-    prophet.stan log-posterior, from fbprophet's initial values.  Stan stops on loose relative
-    tolerances, so the canonical fit ends a little above the exact MAP: its objective must lie within
-    a small gap of scipy's minimum (never far below it: same function), and the in-sample fitted
-    curve of the two end points must agree to a fraction of the noise level."""
-    from scipy.optimize import minimize
+    """A pin that does not go through this repo's restatement of Stan's optimiser: the TRUE MAP of the LITERAL
+    prophet.stan log-posterior (oracle/true_map.py: delta split into positive and negative parts -- the Laplace
+    prior becomes linear, the problem smooth with bounds --, scipy's L-BFGS-B to a projected gradient of ~1e-7, from
+    TWO starting points that must agree).  Round 4 compared with plain L-BFGS-B on the kinked function, which stalls
+    like Stan does, and had to allow +-0.5 either way.  Against the true optimum the statement is one-sided and
+    sharp: the canonical fit's objective is NEVER below the MAP (same function: -1e-6 is the solver's own tolerance)
+    and above it by no more than the band measured on 256 + 64 series (profiles/r05_true_map/report.json: linear /
+    additive median 0.13, max 5.4; logistic median 1.4, max 33), and the in-sample fitted curves of the two end
+    points agree to a fraction of the noise level."""
+    from oracle import true_map
     newton = case.endswith('@newton')      # Stan's Newton (fbprophet's choice below 100 rows)
     m, dat, th0, (spec, ds, y, floor, cap, extra, fut, exf) = _literal(case.split('@')[0])
     csp = helpers.oracle_spec(spec)
     r = (cl.fit_newton if newton else cl.fit)(csp, ds, y[0], floor[0], cap[0], extra)
     assert r['status'] > 0
-    res = minimize(lambda th: stan_neg_log_prob_grad(dat, th), th0, jac=True, method='L-BFGS-B',
-                   options=dict(maxiter=50000, maxfun=200000, ftol=1e-15, gtol=1e-7, maxcor=20))
     f_canon, _ = stan_neg_log_prob_grad(dat, r['theta'])
     assert abs(f_canon - r['f']) <= 1e-9 * abs(f_canon)
-    gap = f_canon - res.fun
-    T = dat['T']
-    # measured: 0.01 .. 0.27 above scipy's end point on objectives of -270 .. -2240 for L-BFGS; Stan's
-    # Newton ends 0.20 BELOW it on the 90-row series (L-BFGS-B stalls on the |delta| kinks; f_canon
-    # above is the literal function's own value, so "below" is a better point, not a different function)
-    assert -0.5 <= gap <= 0.5, (case, gap, res.fun, res.message)
+    th_a, info_a = true_map.solve(dat, r['theta'])
+    th_b, info_b = true_map.solve(dat, th0)
+    assert abs(info_a['f'] - info_b['f']) <= 1e-7 * max(1.0, abs(info_a['f'])), (case, info_a, info_b)   # one optimum, found twice
+    f_map = min(info_a['f'], info_b['f'])
+    gap = f_canon - f_map
+    band = 8.0 if spec.growth == 'linear' else 50.0
+    assert -1e-6 <= gap <= band, (case, gap, f_map)
+    res_x = th_a if info_a['f'] <= info_b['f'] else th_b
 
     def fitted(th):
         k, mm, ls, delta, beta = unpack_theta(th, dat['S'], dat['K'])
         X = dat['X']
         return stan_trend(dat, k, mm, delta) * (1 + X @ (beta * dat['s_m'])) + X @ (beta * dat['s_a'])
-    a, b = fitted(r['theta']), fitted(res.x)
-    sigma = np.exp(res.x[2])
+    a, b = fitted(r['theta']), fitted(res_x)
+    sigma = np.exp(res_x[2])
     # measured: 0.1 % .. 2.3 % of the fitted noise level
     assert np.sqrt(np.mean((a - b) ** 2)) <= 0.05 * sigma, (case, np.sqrt(np.mean((a - b) ** 2)), sigma)
