@@ -247,7 +247,7 @@ static int build_devspec(tsf_ctx *ctx, const tsf_spec *s, DevSpec *d, int *mode_
 // ---- workspace ------------------------------------------------------------------------------
 
 struct WsLayout {
-    size_t gtab, stab, tw, cw, Xw, yw, Mg, Mslot, rbuf, counter, uw, Xu, spm, spp, Bw;
+    size_t gtab, stab, tw, cw, Xw, yw, Mg, Mslot, rbuf, counter, uw, Xu, spm, spp, Bw, yrec, yq;
     size_t mXF, mXB, mXT, mtq, mcq, mcpof, myq, mhist;      // matrix-core path (tsf_mfma_kernels.h)
     size_t clist, cslots;                                   // cooperative tail (tsf_coop_kernels.h)
     size_t total;
@@ -275,7 +275,7 @@ static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 static WsLayout ws_layout(int64_t N, int64_t n_grids, int NTmax, int KP, int quad_P4 = 0,
                           int quad_slots = 0, int quad_ragged = 0, int64_t lat_U = 0,
                           const MfmaPlan *mp = nullptr, int coop_slots = 0, int coop_stride = 0, int64_t quad_pre = 0,
-                          bool sparse = false, int bw_ns = 0)
+                          bool sparse = false, int bw_ns = 0, bool yield = false)
 {
     WsLayout l;
     size_t off = 0;
@@ -297,6 +297,9 @@ static WsLayout ws_layout(int64_t N, int64_t n_grids, int NTmax, int KP, int qua
     l.spp = off; off = align_up(off + (sparse ? sizeof(unsigned long long) * (size_t)n_grids * SP_MAXC : 0));
     // base pairs of the Fourier columns (fit_kernel<..., HARM>): two doubles per seasonality and row
     l.Bw = off; off = align_up(off + sizeof(double) * (size_t)n_grids * NTmax * bw_ns * 2 * W);
+    // time slicing of the quadratic-form kernel (QuadArgs::yield_evals): a record per series and the queue of suspended fits
+    l.yrec = off; off = align_up(off + (yield ? sizeof(double) * (size_t)N * YREC_D : 0));
+    l.yq = off; off = align_up(off + (yield ? sizeof(int) * (8 + 2 * (size_t)N) : 0));
     l.uw = off; off = align_up(off + (lat_U > 0 ? sizeof(int32_t) * (size_t)n_grids * NTmax * W : 0));
     l.Xu = off; off = align_up(off + (lat_U > 0 ? sizeof(double) * (size_t)lat_U * KP : 0));
     const bool mf = mp && mp->on;
@@ -546,8 +549,19 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
             harm = hs.harm;
     }
     const int bw_ns = harm ? hs.n_seas : 0;
+    // Time slicing of the aligned one-slot quadratic-form kernels (tsf_quad_kernels.h, QuadArgs::yield_evals): a wave
+    // hands a fit back after `quantum` evaluations while other series wait.  On for panels of up to 24 series per wave
+    // slot (beyond that the launch is throughput, not its longest fits, and the records would be gigabytes);
+    // tsf_set_option(TSF_OPT_QUAD_YIELD, 0) switches it off, n > 0 sets the quantum, n < -1 suspends after every |n|
+    // evaluations whether or not anyone waits (tests).
+    int yield_evals = 0;
+    if (quad && aligned && hs.KP != 64) {
+        const int o = ctx->opt[TSF_OPT_QUAD_YIELD];
+        if (o == -1) yield_evals = (N <= (int64_t)24 * 12 * ctx->n_cu) ? 256 : 0;
+        else yield_evals = o;
+    }
     const WsLayout l = ws_layout(N, n_grids, NTmax, hs.KP, qp.P4, qp.slots, (quad || newton_quad) && !aligned, lat_U, &mp,
-                                 coop_slots, coop_stride, quad_pre, sparse_try, bw_ns);
+                                 coop_slots, coop_stride, quad_pre, sparse_try, bw_ns, yield_evals != 0);
     rc = ensure_ws(ctx, l.total, N, NTmax, !aligned);
     if (rc) return rc;
     char *ws = (char *)ctx->ws;
@@ -647,6 +661,7 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
         lrc = launch_eval_quad(hs.KP, qp, qa, (double *)(ws + l.Mg), theta_ref, st);
     } else if (quad) {
         QuadArgs qa;
+        memset(&qa, 0, sizeof(qa));
         qa.f = a; qa.Mg = (const double *)(ws + l.Mg); qa.Mslot = (double *)(ws + l.Mslot);
         qa.rbuf = (double *)(ws + l.rbuf);
         qa.counter = (int *)(ws + l.counter); qa.P4 = qp.P4;
@@ -654,6 +669,10 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
         qa.dbg = nullptr; qa.nb_buf = nullptr; qa.nb_bytes = 0;
         qa.Mpre = quad_pre ? qa.Mg : nullptr; qa.n_pre = quad_pre;
         HIP_TRY(ctx, hipMemsetAsync(qa.counter, 0, sizeof(int), st));
+        if (yield_evals != 0) {
+            qa.yield_evals = yield_evals; qa.yrec = (double *)(ws + l.yrec); qa.yq = (int *)(ws + l.yq);
+            HIP_TRY(ctx, hipMemsetAsync(qa.yq, 0, sizeof(int) * (8 + 2 * (size_t)N), st));
+        }
         lrc = launch_quad(hs.KP, qp, qa, (double *)(ws + l.Mg), st);
     } else if (mp.on) {
         MfmaTabs mt;

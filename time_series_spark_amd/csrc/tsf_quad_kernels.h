@@ -58,7 +58,22 @@ struct QuadArgs {
     long long *dbg;                     // -DTSF_QUAD_TIMING builds only: [N][8] cycles per phase
     void *nb_buf;                       // slot records of newton_batch_kernel (tsf_newton_batch.h), or null
     size_t nb_bytes;
+    // Time slicing (round 5; aligned shared-M kernels): a launch lasts as long as the fits of its busiest wave slot, and
+    // nothing cheap predicts which series are long -- so a wave that has spent yield_evals evaluations on a series while
+    // others wait (unstarted series, or suspended ones) writes the fit's state to the series' record, appends the series
+    // to the queue of suspended fits and takes the next one; whoever pops it later resumes it at the top of its next
+    // L-BFGS iteration.  Round robin needs no knowledge of the costs and ends within a few per cent of the best
+    // possible order (longest first); the state is copied bit for bit, so no result depends on it.
+    // yield_evals: 0 off; > 0 quantum; < 0 (tests) suspend after every |yield_evals| evaluations whether or not anyone waits.
+    int yield_evals;
+    double *yrec;                       // [N][YREC_D] suspended fits
+    int *yq;                            // [0] pop ticket, [1] push ticket, [8 ..] ring of N series ids, then N publish words
 };
+
+// record of a suspended fit (doubles): 32 scalars, then the vectors x, g, x_prev, g_prev, p, ref, c and the history ring
+// S[QH], Y[QH], one row of 64 each (one-slot kernels)
+constexpr int YREC_NV = 7 + 2 * 5;
+constexpr int YREC_D = 32 + YREC_NV * W;
 
 template <int KP, int PPL>
 struct QuadLds {
@@ -846,12 +861,15 @@ __global__ __launch_bounds__(64) void gram_grids_kernel(QuadArgs qa, double *Mpr
 // evaluations (D, ref, c) sit in the wave's QuadWave `qw`.
 template <int KP, int PPL, int PQ, bool RAGGED, int MRS = W, bool HLDS = false, int MBATCH = 16, bool MREG = false, int NTR = 0, bool POOL = false,
           bool MPIPE = (TSF_QUAD_MPIPE != 0) && !POOL>     // (the 128-register kernel has no room for a second batch in flight)
-__device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL> *wlp, double *rb,
+__device__ __forceinline__ bool fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL> *wlp, double *rb,
                                           const double *Mp, double *Mown, int64_t n, double *lanec,
                                           double *hist = nullptr, GramX *gx = nullptr,
-                                          QuadWave<PPL> *qw = nullptr, const QuadPool *pool = nullptr)
+                                          QuadWave<PPL> *qw = nullptr, const QuadPool *pool = nullptr, bool resume = false)
 {
     static_assert(!POOL || (!RAGGED && PQ > 0 && PPL == 1), "pooled trend tables: the shared-M one-slot kernel");
+    // time slicing: the kernels whose whole optimiser state is a handful of scalars, five registers per lane and LDS rows
+    // (not the pooled 16-wave kernel: it serves launches that are throughput, and at 128 registers the extra paths spill)
+    constexpr bool YIELD = HLDS && !RAGGED && !MREG && PPL == 1 && PQ > 0 && !POOL;
     double *const dl_w = POOL ? qw->dl : wlp->th;
     double *const ref_w = POOL ? qw->ref : wlp->ref;
     double *const cvec_w = POOL ? qw->cvec : wlp->cvec;
@@ -883,7 +901,7 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
         }
         store_theta<PPL>(a, sv, n, xk, a.theta);
         if (lane == 0) { a.status[n] = st.status0; a.n_iter[n] = 0; a.n_eval[n] = 0; a.fval[n] = 0.0; }
-        return;
+        return false;
     }
     LaneConst<PPL> lk;
     quad_const_table(lanec + 3 * PPL * W, a.opt, qa.recenter_ratio);
@@ -1025,6 +1043,33 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
     // update and the termination tests for x_k] + the line search from x_k; each evaluation form
     // still has a single call site.
     bool first = true, do_resid = true;
+    int ev_slice0 = 0;                  // evaluations of this series when this wave took it
+    if constexpr (YIELD) {
+        if (resume) {
+            // a suspended fit: everything the loop below carries from one iteration to the next, bit for bit
+            // (the record's address goes through an empty asm at both sites: otherwise the compiler computes the row
+            // addresses of the save below -- beyond the 4 KB an instruction's offset reaches -- once per series, up here,
+            // and keeps ten address pairs alive, i.e. spilled, through the whole fit)
+            long long roff = (long long)n * YREC_D;
+            asm volatile("" : "+s"(roff));
+            const double *rec = qa.yrec + roff;
+            const double *rv = rec + 32 + lane;
+            xk[0] = rv[0 * W]; gk[0] = rv[1 * W]; xk1[0] = rv[2 * W]; gk1[0] = rv[3 * W]; pk[0] = rv[4 * W];
+            ref_w[lane] = rv[5 * W]; cvec_w[lane] = rv[6 * W];
+#pragma unroll
+            for (int h = 0; h < QH; ++h) { histS[h * W + lane] = rv[(7 + h) * W]; histY[h * W + lane] = rv[(7 + QH + h) * W]; }
+            if (lane < QH) histR[lane] = rec[16 + lane];
+            fk = UQ(rec[0]); fk1 = UQ(rec[1]); alpha = UQ(rec[2]); dfp = UQ(rec[3]); gp1s = UQ(rec[4]); s0 = UQ(rec[5]); q2 = UQ(rec[6]);
+            const int *ri = reinterpret_cast<const int *>(rec + 8);
+            itNum = __builtin_amdgcn_readfirstlane(ri[0]); hist_len = __builtin_amdgcn_readfirstlane(ri[1]);
+            h0 = __builtin_amdgcn_readfirstlane(ri[2]); since_rc = __builtin_amdgcn_readfirstlane(ri[3]);
+            do_resid = __builtin_amdgcn_readfirstlane(ri[4]) != 0; pk1_scaled = __builtin_amdgcn_readfirstlane(ri[5]) != 0;
+            sv.n_eval = __builtin_amdgcn_readfirstlane(ri[6]); resetB = __builtin_amdgcn_readfirstlane(ri[7]);
+            first = false;
+            wave_sync();
+        }
+        ev_slice0 = sv.n_eval;
+    }
     for (;;) {
         QT_LAP(0);
         if (do_resid) {
@@ -1314,10 +1359,52 @@ __device__ __forceinline__ void fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
         }
         since_rc++;
         do_resid = q2 > (CT ? qc(ct, QC_RC_RATIO) : qa.recenter_ratio) * s0 || since_rc >= qa.recenter_every;
+        if constexpr (YIELD) {
+            const int ye = qa.yield_evals;
+            if (ye != 0 && sv.n_eval - ev_slice0 >= (ye < 0 ? -ye : ye)) {
+                bool waiting = ye < 0;
+                if (!waiting) {
+                    // anyone waiting?  an unstarted series, or a suspended one
+                    const int c0 = __hip_atomic_load(qa.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int qh = __hip_atomic_load(qa.yq + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int qt = __hip_atomic_load(qa.yq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    waiting = __builtin_amdgcn_readfirstlane((c0 < (int)a.N || qt > qh) ? 1 : 0) != 0;
+                }
+                if (waiting) {
+                    long long woff = (long long)n * YREC_D;
+                    asm volatile("" : "+s"(woff));
+                    double *rec = qa.yrec + woff;
+                    double *rv = rec + 32 + lane;
+                    rv[0 * W] = xk[0]; rv[1 * W] = gk[0]; rv[2 * W] = xk1[0]; rv[3 * W] = gk1[0]; rv[4 * W] = pk[0];
+                    rv[5 * W] = ref_w[lane]; rv[6 * W] = cvec_w[lane];
+#pragma unroll
+                    for (int h = 0; h < QH; ++h) { rv[(7 + h) * W] = histS[h * W + lane]; rv[(7 + QH + h) * W] = histY[h * W + lane]; }
+                    if (lane < QH) rec[16 + lane] = histR[lane];
+                    if (lane == 0) {
+                        rec[0] = fk; rec[1] = fk1; rec[2] = alpha; rec[3] = dfp; rec[4] = gp1s; rec[5] = s0; rec[6] = q2;
+                        int *ri = reinterpret_cast<int *>(rec + 8);
+                        ri[0] = itNum; ri[1] = hist_len; ri[2] = h0; ri[3] = since_rc; ri[4] = do_resid ? 1 : 0;
+                        ri[5] = pk1_scaled ? 1 : 0; ri[6] = sv.n_eval; ri[7] = resetB;
+                    }
+                    // publish: the record first (agent-scope release: another CU, maybe another XCD, resumes it), then the
+                    // series id in the ring slot of this push ticket, then the slot's publish word = ticket + 1
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    if (lane == 0) {
+                        const int tk = __hip_atomic_fetch_add(qa.yq + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const int slot = (int)((unsigned)tk % (unsigned)a.N);
+                        qa.yq[8 + slot] = (int)n;
+                        __hip_atomic_store(qa.yq + 8 + (size_t)a.N + slot, tk + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    return true;
+                }
+                ev_slice0 = sv.n_eval;          // nobody waits: a fresh slice
+            }
+        }
     }
     store_theta<PPL>(a, sv, n, xk, a.theta);
     if (lane == 0) { a.status[n] = ret; a.n_iter[n] = itNum; a.n_eval[n] = sv.n_eval; a.fval[n] = fk; }
     QT_FLUSH();
+    return false;
 }
 
 // MMODE: where M lives -- 0 aligned panel, shared M in LDS; 1 aligned panel, shared M in global
@@ -1408,13 +1495,44 @@ __global__ __launch_bounds__(NW * 64, quad_waves_per_simd(quad_three_waves(MMODE
         // here, the compiler threaded lane 0's path from the lane-0-only epilogue stores of the
         // previous series straight into this block, and lanes 1..63 re-entered the loop (and
         // the readfirstlane below) without lane 0: an endless loop on the hardware.
-        int n32 = atomicAdd(qa.counter, lane == 0 ? 1 : 0);
-        n32 = __builtin_amdgcn_readfirstlane(n32);
-        if (n32 >= a.N) break;
-        const int64_t n = a.order ? (int64_t)a.order[n32] : (int64_t)n32;   // (cost hints: longest fits first)
+        // (the counter stops at N: with time slicing a wave may come here many times after the last unstarted series)
+        int n32 = (int)a.N;
+        if (__hip_atomic_load(qa.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)a.N) {
+            n32 = atomicAdd(qa.counter, lane == 0 ? 1 : 0);
+            n32 = __builtin_amdgcn_readfirstlane(n32);
+        }
+        int64_t n;
+        bool resume = false;
+        if (n32 < a.N) {
+            n = a.order ? (int64_t)a.order[n32] : (int64_t)n32;   // (cost hints: longest fits first)
+        } else {
+            // no unstarted series left: a suspended fit, oldest first -- or the end of this wave's work (a fit that is
+            // still running somewhere will not suspend any more: nobody waits for its slot)
+            if (qa.yield_evals == 0) break;
+            int got = -1;
+            if (lane == 0) {
+                int h = __hip_atomic_load(qa.yq + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (;;) {
+                    const int t = __hip_atomic_load(qa.yq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (h >= t) break;
+                    if (__hip_atomic_compare_exchange_strong(qa.yq + 0, &h, h + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { got = h; break; }
+                }
+                if (got >= 0) {
+                    const int slot = (int)((unsigned)got % (unsigned)a.N);
+                    // the pusher took its ticket before it wrote the slot: wait for the publish word of THIS ticket
+                    while (__hip_atomic_load(qa.yq + 8 + (size_t)a.N + slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != got + 1) __builtin_amdgcn_s_sleep(2);
+                    got = qa.yq[8 + slot];
+                }
+            }
+            got = __builtin_amdgcn_readfirstlane(got);
+            if (got < 0) break;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");       // the record of the fit, written by another CU
+            n = got;
+            resume = true;
+        }
         fit_one_quad<KP, PPL, PQ, RAGGED_K, MRS, HLDS,
                      ((quad_three_waves(MMODE, PPL, HLDS) || MMODE == QM_RAGGED_REG || MMODE == QM_GLOBAL_REG) ? 8 : 16),
-                     MMODE == QM_RAGGED_REG || MMODE == QM_GLOBAL_REG, NTR, RPOOL>(qa, wlp, rb, Mp, Mown, n, lanec, hist, gx, qw, &pool);
+                     MMODE == QM_RAGGED_REG || MMODE == QM_GLOBAL_REG, NTR, RPOOL>(qa, wlp, rb, Mp, Mown, n, lanec, hist, gx, qw, &pool, resume);
     }
 }
 

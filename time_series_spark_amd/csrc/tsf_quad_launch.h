@@ -61,11 +61,14 @@ static size_t quad_pool_base_bytes(int P4, int nw)
 }
 
 template <int KP, int PPL, int MMODE, int PQ, bool RLDS, int NTR = 0, bool RPOOL = false>
-static int launch_quad_rl(const QuadPlan &qp, const QuadArgs &qa, double *Mg, hipStream_t st, int pool_slots = 0, int pool_slot_bytes = 0)
+static int launch_quad_rl(const QuadPlan &qp, const QuadArgs &qa_in, double *Mg, hipStream_t st, int pool_slots = 0, int pool_slot_bytes = 0)
 {
     constexpr int NW = RPOOL ? TSF_QUAD_NW4 : QuadShape<PPL, MMODE>::NW;
     constexpr bool MLDS = MMODE == QM_LDS;
     constexpr bool HL = QuadShape<PPL, MMODE>::HL;
+    // time slicing exists in the aligned one-slot kernels with the history ring in LDS (fit_one_quad YIELD)
+    QuadArgs qa = qa_in;
+    if (!(HL && MMODE == QM_LDS && PPL == 1 && PQ > 0 && !RPOOL)) qa.yield_evals = 0;
     int64_t blocks = qp.n_cu;                       // persistent: LDS admits one workgroup per CU
     if (blocks > (qa.f.N + NW - 1) / NW) blocks = (qa.f.N + NW - 1) / NW;
     if (blocks < 1) blocks = 1;
