@@ -120,6 +120,22 @@ def cpu_baseline_python(budget_series=4096, timeout_s=240):
     return json.loads(out.stdout.strip().splitlines()[-1])
 
 
+def vs_true_map(n_cfg2=48, n_ref=16, timeout_s=420):
+    """Distance of stopped fits to the TRUE MAP (round-4 review, item 3): tools/true_map_report.py on the first series
+    of this panel and of the reference-model panel, in its own process (CPU only: the canonical oracle is the GPU's
+    arithmetic bit for bit, and nothing may fork the process that holds the HIP context).  The full-size run
+    (256 + 64 series) is committed under profiles/r05_true_map/report.json."""
+    import subprocess
+    env = dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'true_map_report.py'), str(n_cfg2), str(n_ref)],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout_s)
+    if out.returncode != 0:
+        raise RuntimeError('tools/true_map_report.py failed: %s' % out.stderr[-400:])
+    d = json.loads(out.stdout)
+    d['full_size_run'] = 'profiles/r05_true_map/report.json (256 cfg2 + 64 reference-model series)'
+    return d
+
+
 def kernel_sources_digest():
     """sha256 (first 16 hex digits) over the HIP sources + the C-ABI header, in name order."""
     import glob
@@ -232,6 +248,23 @@ def pmc_traffic(kernel):
         return None, 'unavailable: %s' % e
 
 
+def pmc_step_traffic():
+    """HBM bytes of ONE STEP -- every kernel of the fit + forecast (setup_grid, setup_series, gram_build, fit_quad,
+    future_design, predict), each launched once per step -- from the same committed PMC passes: sum over kernels of
+    2 x FETCH_SIZE + WRITE_SIZE (the factor 2 calibrated for every load shape of this library:
+    profiles/r05_fetch_calib).  roofline.traffic is the DOMINANT kernel's share of this."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_latest.json')
+    try:
+        with open(path) as fh:
+            d = json.load(fh)
+        if d.get('kernel_sources_sha16') != kernel_sources_digest() or d.get('series_per_launch') != N_SERIES:
+            return None
+        per = {k: (2.0 * v.get('FETCH_SIZE_KiB', 0.0) + v.get('WRITE_SIZE_KiB', 0.0)) * 1024.0 for k, v in d.get('step_kernels', {}).items()}
+        return {'bytes': float(sum(per.values())), 'per_kernel_bytes': per} if per else None
+    except Exception:
+        return None
+
+
 def pmc_valu(kernel, kernel_ms, total_evals, n_cu):
     """The bound that actually binds this kernel (not HBM): vector-instruction issue.  From the
     same committed PMC passes (SQ_INSTS_VALU per launch): wave-instructions per evaluation, and the
@@ -287,9 +320,15 @@ def other_baseline_configs(dev, local):
         f.set_profiling(False)
         ne = o.n_eval.cpu().numpy().astype(np.int64)
         st = o.status.cpu().numpy()
+        fk = float(np.mean(kms)) if kms else None
         out[name] = {'workload': desc, 'series': N, 'series_per_s': N / dt_, 'ms_per_step': 1e3 * dt_,
-                     'fit_kernel_ms': float(np.mean(kms)) if kms else None, 'mean_evals': float(ne.mean()),
+                     'fit_kernel_ms': fk, 'mean_evals': float(ne.mean()),
                      'max_evals': int(ne.max()), 'fitted': int((st > 0).sum()),
+                     # a launch cannot end before its longest fit: Stan's iteration limit (10 000, status 40) makes a few
+                     # series in 10 000 run 30 000 evaluations, and they are the launch time of a 10 000-series panel --
+                     # the evaluation rate is the figure that describes the kernel
+                     'evaluations_per_s': None if not fk else float(ne.sum()) / (fk * 1e-3),
+                     'status_counts': {str(int(k)): int(v) for k, v in zip(*np.unique(st, return_counts=True))},
                      'finite_forecasts': bool(torch.isfinite(yh[o.status > 0]).all().item())}
 
     ref = fc.ModelSpec(growth='logistic', seasonality_mode='multiplicative', seasonalities=[yearly, weekly])
@@ -311,7 +350,67 @@ def other_baseline_configs(dev, local):
         '(30 indicator columns, P = 84: the sparse-column kernel, DESIGN.md 5g)',
         fc.ModelSpec(growth='logistic', seasonality_mode='multiplicative', seasonalities=[yearly, weekly],
                      extra=[{'name': n} for n in names]), ds4, y4, y4.max(axis=1) * 1.1, ex4, exf4, 1)
+    try:
+        out['irregular_reference_model'] = irregular_leg(ref)
+    except Exception as e:
+        out['irregular_reference_model'] = {'error': str(e)}
     return out
+
+
+def irregular_leg(spec, N=10000):
+    """The reference's own call (prophet_modeler.py:65: logistic growth, multiplicative seasonality) on the reference's
+    own DATA SHAPE (its fixture: every (series_id, dim_id) at its own irregular timestamps): N series of 600..730 rows,
+    no two sharing a timestamp vector, none on a lattice (tools/bench_irregular.py's panel).  Host-pointer ragged entry
+    point; fit-path kernel time from the library's events.  Algorithmic bytes as SURVEY 8d defines them (ds + y in,
+    theta out, once per series); counter traffic from the committed PMC pass of tools/bench_irregular.py."""
+    import ctypes
+    from time_series_spark_amd import _lib
+    T = 730
+    rng = np.random.default_rng(11)
+    lens = rng.integers(600, T + 1, N)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    ds, y = synth.make_panel(N, T, 'logistic', seed=751)
+    dsr = np.concatenate([ds[:c] + rng.integers(-6 * 3600, 6 * 3600, c) * 1_000_000_000 for c in lens])
+    yr = np.concatenate([y[i][:c] for i, c in enumerate(lens)])
+    cap = np.array([y[i][:c].max() * 1.1 for i, c in enumerate(lens)])
+    ctx = fc.get_context()
+    L = _lib.load()
+    ms = ctypes.c_float(0.0)
+    kms = []
+    for rep in range(2):
+        ctx.check(L.tsf_set_profiling(ctx.handle, 1))
+        r = fc.fit_ragged(spec, off, dsr, yr, floor=np.zeros(N), cap=cap)
+        ctx.check(L.tsf_last_fit_kernel_ms(ctx.handle, ctypes.byref(ms)))
+        kms.append(float(ms.value))
+    ctx.check(L.tsf_set_profiling(ctx.handle, 0))
+    k = min(kms) * 1e-3
+    P = 3 + spec.n_changepoints + spec.K
+    alg = float(np.sum(lens * 16 + P * 8))
+    row_bytes = float(np.sum(np.ceil(lens / 64) * 64 * (2 * 2 * 8 + 8 + 8 + 2) * r.n_eval))
+    res = {'workload': '%d series of 600..730 rows, each at its own irregular timestamps (the shape of the reference\'s fixture), '
+                       'logistic growth + multiplicative yearly(10) + weekly(3): prophet_modeler.py:65' % N,
+           'series': N, 'rows': int(lens.sum()), 'fit_kernel_ms': kms, 'series_per_s_kernel': N / k,
+           'mean_evals': float(r.n_eval.mean()), 'max_evals': int(r.n_eval.max()),
+           'evaluations_per_s': float(r.n_eval.sum()) / k, 'fitted': int((r.status > 0).sum()),
+           'status_counts': {str(int(a)): int(b) for a, b in zip(*np.unique(r.status, return_counts=True))},
+           'algorithmic_bytes': alg, 'algorithmic_GBps': alg / k / 1e9, 'roofline_frac_of_8TBps': alg / k / 1e9 / HBM_PEAK_GBPS,
+           'bytes_read_by_the_evaluations': row_bytes, 'bytes_read_by_the_evaluations_over_algorithmic': row_bytes / alg,
+           'kernel': 'fit_kernel<28, logistic, multiplicative, HARM yearly 10 + weekly 3> (base pairs per row, harmonics in '
+                     'registers) + cooperative tail'}
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'irregular_pmc_latest.json')) as fh:
+            d = json.load(fh)
+        if d.get('kernel_sources_sha16') == kernel_sources_digest():
+            res['traffic'] = 2.0 * d['fit_kernel_FETCH_SIZE_KiB'] * 1024.0
+            res['traffic_over_algorithmic'] = res['traffic'] / alg
+            res['traffic_source'] = d.get('source')
+        else:
+            res['traffic'] = None
+            res['traffic_source'] = 'profiles/irregular_pmc_latest.json was collected on other kernel sources'
+    except Exception as e:
+        res['traffic'] = None
+        res['traffic_source'] = 'unavailable: %s' % e
+    return res
 
 
 def main():
@@ -499,7 +598,11 @@ def main():
         'roofline': {'bound': 'hbm', 'kernel': kernel, 'achieved': achieved,
                      'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS,
                      'peak_measured_device_copy': copy_gbps,
-                     'traffic': traffic, 'traffic_source': traffic_src,
+                     'traffic': traffic, 'traffic_kernel': kernel + ' (the dominant kernel only; step_traffic = all kernels of the step)',
+                     'traffic_source': traffic_src,
+                     'fetch_size_factor': '2 x FETCH_SIZE: calibrated on 4 GiB streamed once with each load shape of the library '
+                                          '(8 B, 16 B, 2 B per lane, strided design rows): counter / bytes = 0.5000 for all four '
+                                          '(profiles/r05_fetch_calib/calibration.json)',
                      'algorithmic_bytes_per_launch': bytes_per_series * n_local,
                      'kernel_ms_avg': fit_ms, 'launches_timed': len(kernel_ms),
                      'note': 'HBM sees each series once in and once out; the fit itself is a '
@@ -522,6 +625,11 @@ def main():
         v = pmc_valu(kernel, fit_ms, int(n_eval.sum()), n_cu)
         if v is not None:
             res['roofline'].update(v)
+        stt = pmc_step_traffic()
+        if stt is not None:
+            res['roofline']['step_traffic'] = stt['bytes']
+            res['roofline']['step_traffic_per_kernel'] = stt['per_kernel_bytes']
+            res['roofline']['step_traffic_over_algorithmic'] = stt['bytes'] / float(bytes_per_series * n_local)
     if weak is not None:
         res['weak_scaling'] = weak
     if cfg3 is not None:
@@ -614,10 +722,21 @@ def main():
         except Exception as e:
             res['strong_scaling_rank_by_rank_on_one_gpu'] = {'error': str(e)}
     if world == 1:
+        # ONE expectation per leg for the 8-GPU run (round-4 review: two estimates stood side by side): cfg2 -- each
+        # rank's share MEASURED on this GPU (above), the slowest rank decides; cfg3 -- the queue model (its shares do
+        # not fit a rank-by-rank replay in the default run time).  strong_scaling_expectation keeps the model's curves.
         try:
-            res['strong_scaling_simulated'] = simulate_strong_scaling(n_eval, fit_ms, n_cu)
+            rr8 = res.get('strong_scaling_rank_by_rank_on_one_gpu', {}).get('gpus', {}).get('8')
+            e8 = {}
+            if rr8:
+                e8['cfg2'] = {'speedup_vs_1': rr8['series_per_s'] / res['value'],
+                              'source': 'each of the 8 shares of the one panel timed on this GPU; slowest share = the step'}
+            c3 = res.get('strong_scaling_expectation', {}).get('cfg3', {}).get('gpus', {}).get('8')
+            if c3 and c3.get('speedup_vs_1'):
+                e8['cfg3'] = {'speedup_vs_1': c3['speedup_vs_1'], 'source': 'queue model calibrated on this run (strong_scaling_expectation.cfg3)'}
+            res['expected_8gpu_speedup'] = e8
         except Exception as e:
-            res['strong_scaling_simulated'] = {'error': str(e)}
+            res['expected_8gpu_speedup'] = {'error': str(e)}
     # the same panel re-fitted with the evaluation counts of the previous fit as scheduling hints
     # (tsf_set_cost_hints: what a job that re-fits its panel regularly can do); never `value` -- the
     # headline has no such knowledge -- but it says how much of the launch is its tail
@@ -668,6 +787,11 @@ def main():
             res['parity_context'] = parity_context(f, spec, ds, y, fut, yhat)
         except Exception as e:
             res['parity_context'] = {'error': str(e)}
+        if not args.no_cpu_baseline:
+            try:
+                res['parity_context']['vs_true_map'] = vs_true_map()
+            except Exception as e:
+                res['parity_context']['vs_true_map'] = {'error': str(e)}
     # cpu_baseline leg (rank 0, N=1 only): the CPU oracle timed on the host cores, and -- the
     # same leg, the oracle as checker -- the GPU forecasts of the sampled series compared with it
     if world == 1 and not args.no_cpu_baseline and not args.timed_only:

@@ -231,6 +231,16 @@ def test_input_discovery_follows_spark_rules(tmp_path):
     with pytest.raises(OSError, match='corrupt or truncated compressed stream in .*part-00004.csv.gz'):
         pm.read_model_input(*pm.find_model_input(str(root))[:1], str(root))
     os.remove(root / 'series_id=7' / 'part-00004.csv.gz')
+    # (round-4 advice) the codec follows the SUFFIX, as Spark's does: a plain part whose first bytes happen to look like
+    # a zlib header ("x^") is parsed as text -- a malformed record in FAILFAST mode, not a "corrupt compressed stream"
+    (root / 'series_id=7' / 'part-00006.csv').write_bytes(b'x^1,2020-02-01 00:00:00,5\n')
+    with pytest.raises(ValueError) as ei:
+        pm.read_model_input(*pm.find_model_input(str(root))[:1], str(root))
+    assert 'compressed' not in str(ei.value) and 'part-00006.csv' in str(ei.value)
+    os.remove(root / 'series_id=7' / 'part-00006.csv')
+    # ... and the views the in-place reader hands out are read-only
+    cols = pm.read_model_input_dir(str(root))
+    assert not cols[3].flags.writeable
     (root / 'series_id=7' / 'part-00005.csv.bz2').write_bytes(b'BZh9')
     with pytest.raises(ValueError, match='compressed input file'):
         pm.find_model_input(str(root))

@@ -335,11 +335,20 @@ bool inflate_all(const FileBuf &in, std::vector<char> &out) {
     if (inflateInit2(&zs, 15 + 32) != Z_OK) return false;       // + 32: gzip or zlib header, detected
     out.clear();
     out.resize(in.n * 6 + 4096);
+    // (avail_in is 32 bits wide: a compressed part of 4 GB or more is fed in pieces of at most 1 GB -- round-4 advice:
+    // the cast used to truncate it and the file was reported corrupt)
+    size_t fed = std::min<size_t>(in.n, (size_t)1 << 30);
     zs.next_in = (Bytef *)in.p;
-    zs.avail_in = (uInt)in.n;
+    zs.avail_in = (uInt)fed;
     size_t have = 0;
     bool ok = true;
     for (;;) {
+        if (zs.avail_in == 0 && fed < in.n) {
+            const size_t k = std::min<size_t>(in.n - fed, (size_t)1 << 30);
+            zs.next_in = (Bytef *)in.p + fed;
+            zs.avail_in = (uInt)k;
+            fed += k;
+        }
         if (have == out.size()) out.resize(out.size() * 2);
         zs.next_out = (Bytef *)out.data() + have;
         zs.avail_out = (uInt)std::min<size_t>(out.size() - have, (size_t)1 << 30);
@@ -347,22 +356,30 @@ bool inflate_all(const FileBuf &in, std::vector<char> &out) {
         const int rc = inflate(&zs, Z_NO_FLUSH);
         have += before - zs.avail_out;
         if (rc == Z_STREAM_END) {
-            if (zs.avail_in == 0) break;
+            if (zs.avail_in == 0 && fed == in.n) break;
             if (inflateReset(&zs) != Z_OK) { ok = false; break; }   // next member
             continue;
         }
         if (rc != Z_OK) { ok = false; break; }
-        if (zs.avail_in == 0 && zs.avail_out != 0) { ok = false; break; }      // truncated
+        if (zs.avail_in == 0 && fed == in.n && zs.avail_out != 0) { ok = false; break; }      // truncated
     }
     inflateEnd(&zs);
     out.resize(have);
     return ok;
 }
 
-bool is_deflated(const FileBuf &b) {
+// Spark picks the codec by the file's SUFFIX (.gz -> GzipCodec, .deflate -> DefaultCodec); so does this reader, and
+// the gzip magic is accepted under any name (no CSV record starts with 0x1f 0x8b).  A zlib header, two printable-range
+// bytes such as "x^", is NOT sniffed from the content any more: a plain file may start with it (round-4 advice).
+bool has_suffix(const char *path, const char *suf) {
+    const size_t n = std::strlen(path), k = std::strlen(suf);
+    return n >= k && std::strcmp(path + n - k, suf) == 0;
+}
+bool is_deflated(const FileBuf &b, const char *path) {
     if (b.n < 2) return false;
     const unsigned char b0 = (unsigned char)b.p[0], b1 = (unsigned char)b.p[1];
     if (b0 == 0x1f && b1 == 0x8b) return true;                                  // gzip
+    if (!(path && has_suffix(path, ".deflate"))) return false;
     return (b0 & 0x0f) == 8 && (b0 >> 4) <= 7 && ((b0 << 8) | b1) % 31 == 0 && b0 == 0x78;    // zlib, 32 K window
 }
 
@@ -383,7 +400,7 @@ bool read_whole(const char *path, FileBuf &buf, bool *corrupt, Arena *arena = nu
     }
     ::close(fd);
     if (got != buf.n) return false;
-    if (is_deflated(buf)) {
+    if (is_deflated(buf, path)) {
         std::vector<char> raw;
         if (!inflate_all(buf, raw)) { *corrupt = true; return false; }
         if (!buf.alloc(raw.size())) throw std::bad_alloc();

@@ -67,8 +67,19 @@ struct QuadArgs {
     // yield_evals: 0 off; > 0 quantum; < 0 (tests) suspend after every |yield_evals| evaluations whether or not anyone waits.
     int yield_evals;
     double *yrec;                       // [N][YREC_D] suspended fits
-    int *yq;                            // [0] pop ticket, [1] push ticket, [8 ..] ring of N series ids, then N publish words
+    int *yq;                            // [1] suspensions so far, [2] series finished, [8 ..] ring of N series ids, then N publish words
+                                        // (tickets come from `counter`: 0 .. N-1 unstarted series, N + k the k-th suspension)
 };
+
+// Loads and stores of the records and the queue: RELAXED ATOMICS at agent scope (sc1 accesses: coherent across the
+// XCDs' L2s word by word) with a plain s_waitcnt between the data and the publish word -- NOT agent-scope fences: on
+// this part a release / acquire fence writes back / invalidates the whole L2 of the XCD, and a few thousand of them per
+// launch stalled every wave of the chip (measured: 9 -> 346 ms; profiles/r05_yield).
+__device__ __forceinline__ void st_agent(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_agent(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int ld_agent(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // record of a suspended fit (doubles): 32 scalars, then the vectors x, g, x_prev, g_prev, p, ref, c and the history ring
 // S[QH], Y[QH], one row of 64 each (one-slot kernels)
@@ -1054,17 +1065,19 @@ __device__ __forceinline__ bool fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
             asm volatile("" : "+s"(roff));
             const double *rec = qa.yrec + roff;
             const double *rv = rec + 32 + lane;
-            xk[0] = rv[0 * W]; gk[0] = rv[1 * W]; xk1[0] = rv[2 * W]; gk1[0] = rv[3 * W]; pk[0] = rv[4 * W];
-            ref_w[lane] = rv[5 * W]; cvec_w[lane] = rv[6 * W];
+            xk[0] = ld_agent(rv + 0 * W); gk[0] = ld_agent(rv + 1 * W); xk1[0] = ld_agent(rv + 2 * W); gk1[0] = ld_agent(rv + 3 * W);
+            pk[0] = ld_agent(rv + 4 * W);
+            ref_w[lane] = ld_agent(rv + 5 * W); cvec_w[lane] = ld_agent(rv + 6 * W);
 #pragma unroll
-            for (int h = 0; h < QH; ++h) { histS[h * W + lane] = rv[(7 + h) * W]; histY[h * W + lane] = rv[(7 + QH + h) * W]; }
-            if (lane < QH) histR[lane] = rec[16 + lane];
-            fk = UQ(rec[0]); fk1 = UQ(rec[1]); alpha = UQ(rec[2]); dfp = UQ(rec[3]); gp1s = UQ(rec[4]); s0 = UQ(rec[5]); q2 = UQ(rec[6]);
+            for (int h = 0; h < QH; ++h) { histS[h * W + lane] = ld_agent(rv + (7 + h) * W); histY[h * W + lane] = ld_agent(rv + (7 + QH + h) * W); }
+            if (lane < QH) histR[lane] = ld_agent(rec + 16 + lane);
+            fk = UQ(ld_agent(rec + 0)); fk1 = UQ(ld_agent(rec + 1)); alpha = UQ(ld_agent(rec + 2)); dfp = UQ(ld_agent(rec + 3));
+            gp1s = UQ(ld_agent(rec + 4)); s0 = UQ(ld_agent(rec + 5)); q2 = UQ(ld_agent(rec + 6));
             const int *ri = reinterpret_cast<const int *>(rec + 8);
-            itNum = __builtin_amdgcn_readfirstlane(ri[0]); hist_len = __builtin_amdgcn_readfirstlane(ri[1]);
-            h0 = __builtin_amdgcn_readfirstlane(ri[2]); since_rc = __builtin_amdgcn_readfirstlane(ri[3]);
-            do_resid = __builtin_amdgcn_readfirstlane(ri[4]) != 0; pk1_scaled = __builtin_amdgcn_readfirstlane(ri[5]) != 0;
-            sv.n_eval = __builtin_amdgcn_readfirstlane(ri[6]); resetB = __builtin_amdgcn_readfirstlane(ri[7]);
+            itNum = __builtin_amdgcn_readfirstlane(ld_agent(ri + 0)); hist_len = __builtin_amdgcn_readfirstlane(ld_agent(ri + 1));
+            h0 = __builtin_amdgcn_readfirstlane(ld_agent(ri + 2)); since_rc = __builtin_amdgcn_readfirstlane(ld_agent(ri + 3));
+            do_resid = __builtin_amdgcn_readfirstlane(ld_agent(ri + 4)) != 0; pk1_scaled = __builtin_amdgcn_readfirstlane(ld_agent(ri + 5)) != 0;
+            sv.n_eval = __builtin_amdgcn_readfirstlane(ld_agent(ri + 6)); resetB = __builtin_amdgcn_readfirstlane(ld_agent(ri + 7));
             first = false;
             wave_sync();
         }
@@ -1365,35 +1378,40 @@ __device__ __forceinline__ bool fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
                 bool waiting = ye < 0;
                 if (!waiting) {
                     // anyone waiting?  an unstarted series, or a suspended one
-                    const int c0 = __hip_atomic_load(qa.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const int qh = __hip_atomic_load(qa.yq + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const int qt = __hip_atomic_load(qa.yq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    waiting = __builtin_amdgcn_readfirstlane((c0 < (int)a.N || qt > qh) ? 1 : 0) != 0;
+                    // (work items are numbered in ONE ticket space, handed out by qa.counter: 0 .. N-1 the unstarted series,
+                    // N + k the k-th suspended fit; pushed = yq[1])
+                    const int c0 = ld_agent(qa.counter), pushed = ld_agent(qa.yq + 1);
+                    waiting = __builtin_amdgcn_readfirstlane((c0 < (int)a.N || pushed > c0 - (int)a.N) ? 1 : 0) != 0;
                 }
                 if (waiting) {
                     long long woff = (long long)n * YREC_D;
                     asm volatile("" : "+s"(woff));
                     double *rec = qa.yrec + woff;
                     double *rv = rec + 32 + lane;
-                    rv[0 * W] = xk[0]; rv[1 * W] = gk[0]; rv[2 * W] = xk1[0]; rv[3 * W] = gk1[0]; rv[4 * W] = pk[0];
-                    rv[5 * W] = ref_w[lane]; rv[6 * W] = cvec_w[lane];
+                    st_agent(rv + 0 * W, xk[0]); st_agent(rv + 1 * W, gk[0]); st_agent(rv + 2 * W, xk1[0]); st_agent(rv + 3 * W, gk1[0]);
+                    st_agent(rv + 4 * W, pk[0]);
+                    st_agent(rv + 5 * W, ref_w[lane]); st_agent(rv + 6 * W, cvec_w[lane]);
 #pragma unroll
-                    for (int h = 0; h < QH; ++h) { rv[(7 + h) * W] = histS[h * W + lane]; rv[(7 + QH + h) * W] = histY[h * W + lane]; }
-                    if (lane < QH) rec[16 + lane] = histR[lane];
+                    for (int h = 0; h < QH; ++h) { st_agent(rv + (7 + h) * W, histS[h * W + lane]); st_agent(rv + (7 + QH + h) * W, histY[h * W + lane]); }
+                    if (lane < QH) st_agent(rec + 16 + lane, histR[lane]);
                     if (lane == 0) {
-                        rec[0] = fk; rec[1] = fk1; rec[2] = alpha; rec[3] = dfp; rec[4] = gp1s; rec[5] = s0; rec[6] = q2;
+                        st_agent(rec + 0, fk); st_agent(rec + 1, fk1); st_agent(rec + 2, alpha); st_agent(rec + 3, dfp);
+                        st_agent(rec + 4, gp1s); st_agent(rec + 5, s0); st_agent(rec + 6, q2);
                         int *ri = reinterpret_cast<int *>(rec + 8);
-                        ri[0] = itNum; ri[1] = hist_len; ri[2] = h0; ri[3] = since_rc; ri[4] = do_resid ? 1 : 0;
-                        ri[5] = pk1_scaled ? 1 : 0; ri[6] = sv.n_eval; ri[7] = resetB;
+                        st_agent(ri + 0, itNum); st_agent(ri + 1, hist_len); st_agent(ri + 2, h0); st_agent(ri + 3, since_rc);
+                        st_agent(ri + 4, do_resid ? 1 : 0); st_agent(ri + 5, pk1_scaled ? 1 : 0); st_agent(ri + 6, sv.n_eval);
+                        st_agent(ri + 7, resetB);
                     }
-                    // publish: the record first (agent-scope release: another CU, maybe another XCD, resumes it), then the
-                    // series id in the ring slot of this push ticket, then the slot's publish word = ticket + 1
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    // publish: every lane's record stores are through (they are agent-coherent stores: another CU, maybe
+                    // another XCD, resumes the fit), then the series id in the ring slot of this push ticket, then the
+                    // slot's publish word = ticket + 1
+                    wait_vmem();
                     if (lane == 0) {
                         const int tk = __hip_atomic_fetch_add(qa.yq + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         const int slot = (int)((unsigned)tk % (unsigned)a.N);
-                        qa.yq[8 + slot] = (int)n;
-                        __hip_atomic_store(qa.yq + 8 + (size_t)a.N + slot, tk + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                        st_agent(qa.yq + 8 + slot, (int)n);
+                        wait_vmem();
+                        st_agent(qa.yq + 8 + (int)a.N + slot, tk + 1);
                     }
                     return true;
                 }
@@ -1495,44 +1513,37 @@ __global__ __launch_bounds__(NW * 64, quad_waves_per_simd(quad_three_waves(MMODE
         // here, the compiler threaded lane 0's path from the lane-0-only epilogue stores of the
         // previous series straight into this block, and lanes 1..63 re-entered the loop (and
         // the readfirstlane below) without lane 0: an endless loop on the hardware.
-        // (the counter stops at N: with time slicing a wave may come here many times after the last unstarted series)
-        int n32 = (int)a.N;
-        if (__hip_atomic_load(qa.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)a.N) {
-            n32 = atomicAdd(qa.counter, lane == 0 ? 1 : 0);
-            n32 = __builtin_amdgcn_readfirstlane(n32);
-        }
+        // One ticket space for all work (a plain fetch-add: a compare-and-swap loop on a queue head, with 3 072 waves
+        // arriving together, spent the launch in failed exchanges -- 9 -> 300 ms, profiles/r05_yield): tickets 0 .. N-1
+        // are the unstarted series, ticket N + k is the k-th suspended fit.  A wave whose ticket is a suspension that has
+        // not happened yet waits for it (its own publish word: no shared polling) -- or for the end: done = N.
+        int h32 = atomicAdd(qa.counter, lane == 0 ? 1 : 0);
+        h32 = __builtin_amdgcn_readfirstlane(h32);
         int64_t n;
         bool resume = false;
-        if (n32 < a.N) {
-            n = a.order ? (int64_t)a.order[n32] : (int64_t)n32;   // (cost hints: longest fits first)
+        if (h32 < a.N) {
+            n = a.order ? (int64_t)a.order[h32] : (int64_t)h32;   // (cost hints: longest fits first)
         } else {
-            // no unstarted series left: a suspended fit, oldest first -- or the end of this wave's work (a fit that is
-            // still running somewhere will not suspend any more: nobody waits for its slot)
             if (qa.yield_evals == 0) break;
+            const int k = h32 - (int)a.N, slot = (int)((unsigned)k % (unsigned)a.N);
             int got = -1;
             if (lane == 0) {
-                int h = __hip_atomic_load(qa.yq + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 for (;;) {
-                    const int t = __hip_atomic_load(qa.yq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (h >= t) break;
-                    if (__hip_atomic_compare_exchange_strong(qa.yq + 0, &h, h + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { got = h; break; }
-                }
-                if (got >= 0) {
-                    const int slot = (int)((unsigned)got % (unsigned)a.N);
-                    // the pusher took its ticket before it wrote the slot: wait for the publish word of THIS ticket
-                    while (__hip_atomic_load(qa.yq + 8 + (size_t)a.N + slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != got + 1) __builtin_amdgcn_s_sleep(2);
-                    got = qa.yq[8 + slot];
+                    if (ld_agent(qa.yq + 8 + (int)a.N + slot) == k + 1) { got = ld_agent(qa.yq + 8 + slot); break; }
+                    if (ld_agent(qa.yq + 2) >= (int)a.N) break;               // every series finished
+                    __builtin_amdgcn_s_sleep(64);
                 }
             }
             got = __builtin_amdgcn_readfirstlane(got);
             if (got < 0) break;
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");       // the record of the fit, written by another CU
-            n = got;
+            n = got;                                    // (its record is read with agent-coherent loads: fit_one_quad)
             resume = true;
         }
+        const bool yielded =
         fit_one_quad<KP, PPL, PQ, RAGGED_K, MRS, HLDS,
                      ((quad_three_waves(MMODE, PPL, HLDS) || MMODE == QM_RAGGED_REG || MMODE == QM_GLOBAL_REG) ? 8 : 16),
                      MMODE == QM_RAGGED_REG || MMODE == QM_GLOBAL_REG, NTR, RPOOL>(qa, wlp, rb, Mp, Mown, n, lanec, hist, gx, qw, &pool, resume);
+        if (qa.yield_evals != 0 && !yielded && lane == 0) __hip_atomic_fetch_add(qa.yq + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

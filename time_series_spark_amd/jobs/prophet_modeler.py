@@ -456,7 +456,9 @@ class _CsvTable:
                 continue
             buf = (ctypes.c_char * (8 * self.n_rows)).from_address(p.value)
             buf._owner = self                   # the ctypes view keeps the table; the array keeps the view
-            out.append(np.frombuffer(buf, dtype=dt))
+            arr = np.frombuffer(buf, dtype=dt)
+            arr.setflags(write=False)           # views of the native table: read-only, as documented (round-4 advice)
+            out.append(arr)
         return tuple(out)
 
 

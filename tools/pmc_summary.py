@@ -37,10 +37,22 @@ for f in sorted(glob.glob(os.path.join(out, 'prof_*', '**', '*counter_collection
     for (k, c), d in per.items():
         # HBM counters are in KiB; the SQ counters are plain counts (summed over the shader engines)
         want.setdefault(k, {})[c + ('_KiB' if c in ('FETCH_SIZE', 'WRITE_SIZE') else '')] = sum(d.values()) / len(d)
+# every kernel of the step (setup, Gram build, fit, future design, predict): HBM counters per launch -> roofline.step_traffic
+step = {}
+for f in sorted(glob.glob(os.path.join(out, 'prof_*', '**', '*counter_collection.csv'), recursive=True)):
+    per = defaultdict(lambda: defaultdict(float))
+    with open(f) as fh:
+        for row in csv.DictReader(fh):
+            if row['Counter_Name'] in ('FETCH_SIZE', 'WRITE_SIZE'):
+                k = row['Kernel_Name'].split('(')[0].replace('void ', '').replace('tsf::', '').split('<')[0].strip()
+                per[(k, row['Counter_Name'])][row['Dispatch_Id']] += float(row['Counter_Value'])
+    for (k, c), d in per.items():
+        step.setdefault(k, {})[c + '_KiB'] = sum(d.values()) / len(d)
+        step[k]['launches'] = len(d)
 if want:
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
-    js = {'kernels': want, 'kernel_sources_sha16': bench.kernel_sources_digest(),
+    js = {'kernels': want, 'step_kernels': step, 'kernel_sources_sha16': bench.kernel_sources_digest(),
           'series_per_launch': int(os.environ.get('BENCH_N', '10000')),
           'points': int(os.environ.get('BENCH_T', '730')),
           'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) around bench.py, '

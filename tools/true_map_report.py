@@ -87,7 +87,7 @@ def main():
     jobs += [('cfg2', n, ds, y[n].astype(np.float64), 0.0) for n in range(n_cfg2)]
     ds2, y2 = synth.make_panel(n_ref, 730, 'logistic', seed=751)       # tools/bench_configs.py ref10k: its first n series
     jobs += [('ref', n, ds2, y2[n].astype(np.float64), float(y2[n].max() * 1.1)) for n in range(n_ref)]
-    with mp.Pool(min(os.cpu_count(), 32)) as pool:
+    with mp.Pool(min(os.cpu_count(), 64, len(jobs))) as pool:
         rows = pool.map(_one, jobs, chunksize=2)
     rep = {'what': 'distance of stopped fits to the TRUE MAP (oracle/true_map.py); per series the median over a 90-day horizon of '
                    '|yhat - yhat_MAP| / |yhat_MAP|, then median / p90 over series; gap = f(stopped) - f(MAP) >= 0',
