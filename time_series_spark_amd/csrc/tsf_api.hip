@@ -555,7 +555,8 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     // tsf_set_option(TSF_OPT_QUAD_YIELD, 0) switches it off, n > 0 sets the quantum, n < -1 suspends after every |n|
     // evaluations whether or not anyone waits (tests).
     int yield_evals = 0;
-    if (quad && aligned && hs.KP != 64) {
+    // (not when the caller gave scheduling hints: its order -- longest first -- is what a hand-back would undo)
+    if (quad && aligned && hs.KP != 64 && !(ctx->order_n == N && !theta_in)) {
         const int o = ctx->opt[TSF_OPT_QUAD_YIELD];
         if (o == -1) yield_evals = (N <= (int64_t)24 * 12 * ctx->n_cu) ? 256 : 0;
         else yield_evals = o;
