@@ -188,8 +188,8 @@ enum {
     TSF_OPT_QUAD_RREG,       /* 0: residual-pass weights staged through memory */
     TSF_OPT_NEWTON_BATCH,    /* series per resident wave from which Newton runs several series per wave (0: never) */
     TSF_OPT_NEWTON_FLAGS, TSF_OPT_NEWTON_NS, TSF_OPT_NEWTON_LCAP, TSF_OPT_NEWTON_FILL,   /* dev knobs of that kernel */
-    TSF_OPT_QUAD_YIELD,      /* time slicing of the aligned quadratic-form kernel: 0 off; n > 0 a fit is handed back after n
-                                evaluations while other series wait (default 256 for panels of up to 24 series per wave
+    TSF_OPT_QUAD_YIELD,      /* time slicing of the aligned quadratic-form kernel (default: off): n > 0 a fit is handed
+                                back after n evaluations while other series wait (panels of up to 24 series per wave
                                 slot); n < -1 after every |n| evaluations whether or not anyone waits (tests) */
     TSF_OPT_DEBUG_ASYNC_SCRATCH, /* dev (tools/dev/nb_debug.py): bit 0 the slot records of that kernel from hipMallocAsync /
                                 hipFreeAsync as in round 3 instead of the context's cached block; bit 1 synchronise the

@@ -1744,11 +1744,12 @@ def test_randomised_newton_shapes_against_oracle(env):
 
 
 def test_stream_ordered_allocator_probe(env):
-    """tools/probes/mallocasync_probe.hip (no library code; profiles/r05_mallocasync/README.md): hipMallocAsync blocks of
-    gigabytes, a kernel that writes and re-reads them in rounds, hipFreeAsync right behind the launches.  With a pool
-    that never releases memory (mode 1) the program must be clean -- the kernels and the checks themselves are sound --;
-    with the default pool attributes (mode 14: the bare pattern) ROCm 7.2.0 corrupts the running kernel's block, which is
-    why the library allocates no stream-ordered scratch.  The default-mode outcome is printed, not asserted."""
+    """tools/probes/mallocasync_probe.hip (no library code; profiles/r05_mallocasync/README.md): blocks of 0.05 .. 6 GB, a
+    kernel that writes and re-reads them in rounds, a verify kernel.  On plain hipMalloc / hipFree blocks (mode 16, the
+    control: what the library does) the program must be clean -- the kernels and the checks themselves are sound.  On
+    hipMallocAsync / hipFreeAsync blocks ROCm 7.2.0 corrupts the running kernel's multi-gigabyte blocks (intermittently;
+    rarer with the pool's release threshold raised), which is why the library allocates no stream-ordered scratch: that
+    outcome is printed, not asserted."""
     import shutil
     import subprocess
     src = os.path.join(helpers.ROOT, 'tools', 'probes', 'mallocasync_probe.hip')
@@ -1757,10 +1758,10 @@ def test_stream_ordered_allocator_probe(env):
         hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
         os.makedirs(os.path.dirname(exe), exist_ok=True)
         subprocess.check_call([hipcc, '--offload-arch=gfx950', '-O3', '-w', src, '-o', exe])
-    clean = subprocess.run([exe, '1'], capture_output=True, text=True, timeout=600)
-    assert clean.returncode == 0 and 'MALLOCASYNC_PROBE_CLEAN' in clean.stdout, clean.stdout[-2000:]
+    control = subprocess.run([exe, '16'], capture_output=True, text=True, timeout=600)
+    assert control.returncode == 0 and 'MALLOCASYNC_PROBE_CLEAN' in control.stdout, control.stdout[-2000:]
     bare = subprocess.run([exe, '14'], capture_output=True, text=True, timeout=600)
-    print('default pool attributes, bare pattern:', bare.stdout.strip().splitlines()[-1])
+    print('stream-ordered blocks, bare pattern:', bare.stdout.strip().splitlines()[-1])
 
 
 def test_baseline_config_1_every_series_against_the_oracle(env):
@@ -1797,8 +1798,8 @@ def test_quadratic_form_time_slicing_changes_no_bit(env):
     """Round 5: the aligned quadratic-form kernel hands a fit back after a quantum of evaluations while other series
     wait (tsf_quad_kernels.h, QuadArgs::yield_evals): the optimiser state goes to a record in global memory, the series
     to a queue, and whichever wave pops it -- on another CU, maybe another XCD -- resumes it at the top of its next
-    L-BFGS iteration.  The state is copied bit for bit, so nothing may change: off, the default quantum (256, only
-    while someone waits), a quantum of 32, and unconditional suspension after every 8 and every 64 evaluations (a fit
+    L-BFGS iteration.  The state is copied bit for bit, so nothing may change: off (also the default), quanta of 256 and 32
+    (only while someone waits), and unconditional suspension after every 8 and every 64 evaluations (a fit
     of 1 500 evaluations then changes waves ~190 times) give identical outputs on a 7 000-series panel (the 12-wave
     kernel; 2.3 series per wave slot) and on its first 200 series (nobody ever waits), and a sample incl. the longest
     fit matches the oracle."""
@@ -1809,7 +1810,7 @@ def test_quadratic_form_time_slicing_changes_no_bit(env):
     spec = fc.ModelSpec(growth='linear', seasonalities=[helpers.YEARLY, helpers.WEEKLY])
     ctx = fc.get_context()
     res = {}
-    for tag, q in (('off', 0), ('default', -1), ('q32', 32), ('every8', -8), ('every64', -64)):
+    for tag, q in (('off', 0), ('default', -1), ('q256', 256), ('q32', 32), ('every8', -8), ('every64', -64)):
         with ctx.options(quad_yield=q, quad_reg=0):
             res[tag] = fc.fit_aligned(spec, ds, y)
             if tag in ('off', 'every8'):

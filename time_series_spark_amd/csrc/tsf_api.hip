@@ -550,16 +550,16 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     }
     const int bw_ns = harm ? hs.n_seas : 0;
     // Time slicing of the aligned one-slot quadratic-form kernels (tsf_quad_kernels.h, QuadArgs::yield_evals): a wave
-    // hands a fit back after `quantum` evaluations while other series wait.  On for panels of up to 24 series per wave
-    // slot (beyond that the launch is throughput, not its longest fits, and the records would be gigabytes);
-    // tsf_set_option(TSF_OPT_QUAD_YIELD, 0) switches it off, n > 0 sets the quantum, n < -1 suspends after every |n|
-    // evaluations whether or not anyone waits (tests).
+    // hands a fit back after `quantum` evaluations while other series wait.  OFF unless asked for
+    // (tsf_set_option(TSF_OPT_QUAD_YIELD, n): n > 0 the quantum; n < -1 suspend after every |n| evaluations whether or
+    // not anyone waits -- tests): measured, it is worth 2-7 % of a launch and writes and re-reads a 9 KB
+    // record per hand-back -- 355 instead of 78 MB of HBM traffic on the headline panel, whose figure of merit next to
+    // its rate is exactly that traffic.  Never with scheduling hints (it would undo the caller's order), never beyond 24
+    // series per wave slot (throughput launches; the records would be gigabytes).
     int yield_evals = 0;
-    // (not when the caller gave scheduling hints: its order -- longest first -- is what a hand-back would undo)
-    if (quad && aligned && hs.KP != 64 && !(ctx->order_n == N && !theta_in)) {
+    if (quad && aligned && hs.KP != 64 && !(ctx->order_n == N && !theta_in) && N <= (int64_t)24 * 12 * ctx->n_cu) {
         const int o = ctx->opt[TSF_OPT_QUAD_YIELD];
-        if (o == -1) yield_evals = (N <= (int64_t)24 * 12 * ctx->n_cu) ? 256 : 0;
-        else yield_evals = o;
+        yield_evals = (o == -1) ? 0 : o;
     }
     const WsLayout l = ws_layout(N, n_grids, NTmax, hs.KP, qp.P4, qp.slots, (quad || newton_quad) && !aligned, lat_U, &mp,
                                  coop_slots, coop_stride, quad_pre, sparse_try, bw_ns, yield_evals != 0);

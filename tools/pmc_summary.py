@@ -45,6 +45,9 @@ for f in sorted(glob.glob(os.path.join(out, 'prof_*', '**', '*counter_collection
         for row in csv.DictReader(fh):
             if row['Counter_Name'] in ('FETCH_SIZE', 'WRITE_SIZE'):
                 k = row['Kernel_Name'].split('(')[0].replace('void ', '').replace('tsf::', '').split('<')[0].strip()
+                # the library's kernels and its workspace memsets; not torch's (bench.py's device-copy probe, its fills)
+                if 'tsf::' not in row['Kernel_Name'] and 'fillBufferAligned' not in k:
+                    continue
                 per[(k, row['Counter_Name'])][row['Dispatch_Id']] += float(row['Counter_Value'])
     for (k, c), d in per.items():
         step.setdefault(k, {})[c + '_KiB'] = sum(d.values()) / len(d)

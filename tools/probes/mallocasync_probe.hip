@@ -13,7 +13,8 @@
 //   stream that allocates from the same pool while the first stream's kernels still run.
 // Modes (argv[1], bit mask): 1 release threshold = max (the pool never returns memory); 2 no second stream;
 // 4 no unrelated hipMalloc / hipFree between the calls; 8 no synchronous hipMemcpy behind the free (only the
-// hipDeviceSynchronize at the end of the call).
+// hipDeviceSynchronize at the end of the call); 16 CONTROL: the same kernels and checks on plain hipMalloc / hipFree
+// blocks (hipFree after the device has been synchronised) -- what the library does.
 // Prints the number of corrupted words per phase; exit code 0 = nothing wrong seen.
 //   hipcc --offload-arch=gfx950 -O3 tools/probes/mallocasync_probe.hip -o tools/probes/bin/mallocasync_probe
 #include <hip/hip_runtime.h>
@@ -79,7 +80,8 @@ int main(int argc, char **argv)
         for (int call = 0; call < 16; ++call) {
             const size_t n = (size_t)(gb[call] * 1e9 / 8);
             uint64_t *p = nullptr;
-            CHECK(hipMallocAsync((void **)&p, (n + 8) * 8, st));
+            if (mode & 16) CHECK(hipMalloc((void **)&p, (n + 8) * 8));
+            else CHECK(hipMallocAsync((void **)&p, (n + 8) * 8, st));
             CHECK(hipMemsetAsync(p + n, 0, 64, st));
             k_write<<<1024, 64, 0, st>>>(p, n, (uint64_t)call + 100 * streams, 6);
             k_verify<<<2048, 256, 0, st>>>(p, n, (uint64_t)call + 100 * streams, bad);
@@ -94,13 +96,14 @@ int main(int argc, char **argv)
             }
             unsigned long long inner = 0;
             CHECK(hipMemcpyAsync(&inner, p + n, 8, hipMemcpyDeviceToHost, st));
-            CHECK(hipFreeAsync(p, st));                    // right behind the launches, as the library did
+            if (!(mode & 16)) CHECK(hipFreeAsync(p, st));  // right behind the launches, as the library did
             // what the host-pointer wrappers do next: a synchronous copy on the null stream
             if (!(mode & 8)) CHECK(hipMemcpy(host.data(), ws, host.size() * 8, hipMemcpyDeviceToHost));
             if (call % 3 == 1 && !(mode & 4)) {                           // ensure_ws growing: an unrelated hipMalloc + hipFree (device sync)
                 void *u = nullptr; CHECK(hipMalloc(&u, (size_t)(1 + call % 4) << 28)); CHECK(hipMemset(u, 0xA5, 1 << 20)); CHECK(hipFree(u));
             }
             CHECK(hipStreamSynchronize(s2)); CHECK(hipDeviceSynchronize());
+            if (mode & 16) CHECK(hipFree(p));
             unsigned long long hb[8];
             CHECK(hipMemcpy(hb, bad, 64, hipMemcpyDeviceToHost));
             // the workspace must be untouched
