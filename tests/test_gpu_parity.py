@@ -1748,8 +1748,8 @@ def test_stream_ordered_allocator_probe(env):
     kernel that writes and re-reads them in rounds, a verify kernel.  On plain hipMalloc / hipFree blocks (mode 16, the
     control: what the library does) the program must be clean -- the kernels and the checks themselves are sound.  On
     hipMallocAsync / hipFreeAsync blocks ROCm 7.2.0 corrupts the running kernel's multi-gigabyte blocks (intermittently;
-    rarer with the pool's release threshold raised), which is why the library allocates no stream-ordered scratch: that
-    outcome is printed, not asserted."""
+    rarer with the pool's release threshold raised), which is why the library allocates no stream-ordered scratch: those
+    runs are committed under profiles/r05_mallocasync/, this test keeps the control honest."""
     import shutil
     import subprocess
     src = os.path.join(helpers.ROOT, 'tools', 'probes', 'mallocasync_probe.hip')
@@ -1760,8 +1760,9 @@ def test_stream_ordered_allocator_probe(env):
         subprocess.check_call([hipcc, '--offload-arch=gfx950', '-O3', '-w', src, '-o', exe])
     control = subprocess.run([exe, '16'], capture_output=True, text=True, timeout=600)
     assert control.returncode == 0 and 'MALLOCASYNC_PROBE_CLEAN' in control.stdout, control.stdout[-2000:]
-    bare = subprocess.run([exe, '14'], capture_output=True, text=True, timeout=600)
-    print('stream-ordered blocks, bare pattern:', bare.stdout.strip().splitlines()[-1])
+    # (the stream-ordered modes are NOT run here: a program known to corrupt its own memory has no place in a suite
+    # other jobs share a GPU with; tools/dev/async_scratch_hunt.sh and tools/dev/r05_f.sh run them, results under
+    # profiles/r05_mallocasync/)
 
 
 def test_baseline_config_1_every_series_against_the_oracle(env):

@@ -871,6 +871,8 @@ __global__ __launch_bounds__(64) void gram_grids_kernel(QuadArgs qa, double *Mpr
 // POOL: wlp is null; a residual pass borrows a QuadLds of `pool` and the vectors that live across
 // evaluations (D, ref, c) sit in the wave's QuadWave `qw`.
 template <int KP, int PPL, int PQ, bool RAGGED, int MRS = W, bool HLDS = false, int MBATCH = 16, bool MREG = false, int NTR = 0, bool POOL = false,
+          bool YK = false,                                 // the time-slicing build of the kernel (a separate instantiation:
+                                                           // compiled into the default one its paths cost the headline 3-4 %)
           bool MPIPE = (TSF_QUAD_MPIPE != 0) && !POOL>     // (the 128-register kernel has no room for a second batch in flight)
 __device__ __forceinline__ bool fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL> *wlp, double *rb,
                                           const double *Mp, double *Mown, int64_t n, double *lanec,
@@ -880,7 +882,7 @@ __device__ __forceinline__ bool fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
     static_assert(!POOL || (!RAGGED && PQ > 0 && PPL == 1), "pooled trend tables: the shared-M one-slot kernel");
     // time slicing: the kernels whose whole optimiser state is a handful of scalars, five registers per lane and LDS rows
     // (not the pooled 16-wave kernel: it serves launches that are throughput, and at 128 registers the extra paths spill)
-    constexpr bool YIELD = HLDS && !RAGGED && !MREG && PPL == 1 && PQ > 0 && !POOL;
+    constexpr bool YIELD = YK && HLDS && !RAGGED && !MREG && PPL == 1 && PQ > 0 && !POOL;
     double *const dl_w = POOL ? qw->dl : wlp->th;
     double *const ref_w = POOL ? qw->ref : wlp->ref;
     double *const cvec_w = POOL ? qw->cvec : wlp->cvec;
@@ -1439,7 +1441,7 @@ constexpr size_t quad_hist_bytes(bool hlds) { return hlds ? sizeof(double) * (2 
 
 // NTR > 0: residual-pass weights of the first NTR steps in registers (RLDS false; steps beyond: global scratch)
 // RPOOL (NW = 16, four waves per SIMD at <= 128 registers): trend tables from a pool of pool_slots QuadLds
-template <int KP, int PPL, int NW, int MMODE, int PQ, bool RLDS, bool HLDS = false, int NTR = 0, bool RPOOL = false>
+template <int KP, int PPL, int NW, int MMODE, int PQ, bool RLDS, bool HLDS = false, int NTR = 0, bool RPOOL = false, bool YK = false>
 __global__ __launch_bounds__(NW * 64, quad_waves_per_simd(quad_three_waves(MMODE, PPL, HLDS), NW)) void fit_quad_kernel(QuadArgs qa, int pool_slots, int pool_slot_bytes)
 {
     static_assert(NTR == 0 || (!RLDS && MMODE == QM_LDS), "register-resident weights: the shared-M kernel without LDS staging");
@@ -1513,6 +1515,15 @@ __global__ __launch_bounds__(NW * 64, quad_waves_per_simd(quad_three_waves(MMODE
         // here, the compiler threaded lane 0's path from the lane-0-only epilogue stores of the
         // previous series straight into this block, and lanes 1..63 re-entered the loop (and
         // the readfirstlane below) without lane 0: an endless loop on the hardware.
+        if constexpr (!YK) {
+            int n32 = atomicAdd(qa.counter, lane == 0 ? 1 : 0);
+            n32 = __builtin_amdgcn_readfirstlane(n32);
+            if (n32 >= a.N) break;
+            const int64_t n = a.order ? (int64_t)a.order[n32] : (int64_t)n32;   // (cost hints: longest fits first)
+            fit_one_quad<KP, PPL, PQ, RAGGED_K, MRS, HLDS,
+                         ((quad_three_waves(MMODE, PPL, HLDS) || MMODE == QM_RAGGED_REG || MMODE == QM_GLOBAL_REG) ? 8 : 16),
+                         MMODE == QM_RAGGED_REG || MMODE == QM_GLOBAL_REG, NTR, RPOOL>(qa, wlp, rb, Mp, Mown, n, lanec, hist, gx, qw, &pool);
+        } else {
         // One ticket space for all work (a plain fetch-add: a compare-and-swap loop on a queue head, with 3 072 waves
         // arriving together, spent the launch in failed exchanges -- 9 -> 300 ms, profiles/r05_yield): tickets 0 .. N-1
         // are the unstarted series, ticket N + k is the k-th suspended fit.  A wave whose ticket is a suspension that has
@@ -1542,8 +1553,9 @@ __global__ __launch_bounds__(NW * 64, quad_waves_per_simd(quad_three_waves(MMODE
         const bool yielded =
         fit_one_quad<KP, PPL, PQ, RAGGED_K, MRS, HLDS,
                      ((quad_three_waves(MMODE, PPL, HLDS) || MMODE == QM_RAGGED_REG || MMODE == QM_GLOBAL_REG) ? 8 : 16),
-                     MMODE == QM_RAGGED_REG || MMODE == QM_GLOBAL_REG, NTR, RPOOL>(qa, wlp, rb, Mp, Mown, n, lanec, hist, gx, qw, &pool, resume);
+                     MMODE == QM_RAGGED_REG || MMODE == QM_GLOBAL_REG, NTR, RPOOL, YK>(qa, wlp, rb, Mp, Mown, n, lanec, hist, gx, qw, &pool, resume);
         if (qa.yield_evals != 0 && !yielded && lane == 0) __hip_atomic_fetch_add(qa.yq + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 

@@ -103,6 +103,14 @@ static int launch_quad_rl(const QuadPlan &qp, const QuadArgs &qa_in, double *Mg,
         return (int)hipGetLastError();
     }
 #endif
+    if constexpr (HL && MMODE == QM_LDS && PPL == 1 && PQ > 0 && !RPOOL) {
+        if (qa.yield_evals != 0) {          // the time-slicing build (tsf_set_option(TSF_OPT_QUAD_YIELD, ...))
+            hipFuncSetAttribute((const void *)fit_quad_kernel<KP, PPL, NW, MMODE, PQ, RLDS, HL, NTR, RPOOL, true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipLaunchKernelGGL((fit_quad_kernel<KP, PPL, NW, MMODE, PQ, RLDS, HL, NTR, RPOOL, true>), dim3((unsigned)blocks), dim3(NW * 64), lds, st, qa, pool_slots, pool_slot_bytes);
+            return (int)hipGetLastError();
+        }
+    }
     hipLaunchKernelGGL((fit_quad_kernel<KP, PPL, NW, MMODE, PQ, RLDS, HL, NTR, RPOOL>), dim3((unsigned)blocks), dim3(NW * 64), lds, st, qa, pool_slots, pool_slot_bytes);
     return (int)hipGetLastError();
 }
