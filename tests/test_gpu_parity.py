@@ -474,8 +474,9 @@ def test_ragged_series_with_equal_timestamps_share_grid_tables(env):
     """Series of a ragged call whose timestamp vectors are byte-identical share one set of grid tables (t, changepoint
     counts, design matrix) and, on the quadratic form, one prebuilt Z^T Z (tsf_api.hip fit_host_one: hash + memcmp
     classes; gram_grids_kernel).  Sharing changes where a table lives, not a bit of any result: default against
-    TSF_GRID_SHARE=0 (a grid per series) against TSF_GRAM_SHARE=0 (shared tables, every wave builds its own Z^T Z),
-    three models and Newton; a series with the same LENGTH but timestamps one day later is its own class; a sample
+    TSF_GRID_SHARE=0 (a grid per series) against TSF_GRAM_SHARE=0 (shared tables, every wave builds its own Z^T Z: three
+    columns per pass with the Fourier columns expanded from the rows' base pairs, gram_columns_harm -- or, with
+    TSF_HARM=0 on top, two columns per pass from the design tables, gram_columns2), three models and Newton; a series with the same LENGTH but timestamps one day later is its own class; a sample
     against the oracle."""
     import os
     fc, cl = env
@@ -499,14 +500,15 @@ def test_ragged_series_with_equal_timestamps_share_grid_tables(env):
         if algo is not None:
             spec = type(spec).from_dict(dict(spec.to_dict(), lbfgs=dict(spec.lbfgs, algorithm=algo)))
         res = {}
-        for tag, envs in (('shared', {}), ('own_grids', {'TSF_GRID_SHARE': '0'}), ('own_gram', {'TSF_GRAM_SHARE': '0'})):
+        for tag, envs in (('shared', {}), ('own_grids', {'TSF_GRID_SHARE': '0'}), ('own_gram', {'TSF_GRAM_SHARE': '0'}),
+                          ('own_gram_from_tables', {'TSF_GRAM_SHARE': '0', 'TSF_HARM': '0'})):
             helpers.routes.update(envs)
             try:
                 res[tag] = fc.fit_ragged(spec, off, dsr, yr, floor=np.zeros(N), cap=cap)
             finally:
                 for k in envs:
                     helpers.routes.pop(k, None)
-        for tag in ('own_grids', 'own_gram'):
+        for tag in ('own_grids', 'own_gram', 'own_gram_from_tables'):
             for name in ('theta', 'fval', 'n_iter', 'n_eval', 'status', 'y_scale'):
                 assert np.array_equal(getattr(res['shared'], name), getattr(res[tag], name), equal_nan=True), (growth, mode, algo, tag, name)
             assert res['shared'].grid.tobytes() == res[tag].grid.tobytes()
@@ -519,6 +521,44 @@ def test_ragged_series_with_equal_timestamps_share_grid_tables(env):
                 assert (r.n_iter[n], r.n_eval[n], r.status[n]) == (o['n_iter'], o['n_eval'], o['status']), (growth, mode, n)
                 P = len(o['theta'])
                 assert n_bit_diff(r.theta[n][:P], o['theta']) == 0 and n_bit_diff(r.fval[n], o['f']) == 0, (growth, mode, n)
+
+
+def test_ragged_quadratic_form_with_a_calendar_per_series_reads_base_pairs(env):
+    """Round 5: a ragged quadratic-form panel whose series have a calendar each builds Z^T Z per series inside the fit
+    kernel; the rows are then read as their BASE sin / cos pairs (32 B instead of 224 B per row) and the Fourier columns
+    expanded in registers, three columns of Z^T Z per pass (gram_columns_harm) and in the residual passes at the
+    re-centrings (resid_eval_q HARM) -- 2.4 instead of 32 GB of reads per 10 000-series launch.  Same operands in the
+    same order: with 0, 1 and 2 dense regressor columns behind the Fourier block (still read from the tables) the
+    results equal, bit for bit, those of the table route (context option harm = 0) and the oracle's."""
+    fc, cl = env
+    from time_series_spark_amd import synth
+    rng = np.random.default_rng(77)
+    N, Tm = 24, 800
+    dsm = synth.daily_grid(Tm)
+    _, ym = synth.make_panel(N, Tm, 'linear', seed=31)
+    keep = [np.sort(rng.choice(Tm, size=int(rng.integers(600, 731)), replace=False)) for _ in range(N)]
+    lens = np.array([len(k) for k in keep])
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    dsr = np.concatenate([dsm[k] for k in keep])
+    yr = np.concatenate([ym[i][k] for i, k in enumerate(keep)])
+    for n_extra in (0, 1, 2):
+        exr = rng.normal(0, 1, (n_extra, len(dsr))) if n_extra else None
+        spec = fc.ModelSpec(growth='linear', seasonalities=[helpers.YEARLY, helpers.WEEKLY],
+                            extra=[{'name': 'x%d' % e} for e in range(n_extra)])
+        assert helpers.uses_quadratic_form(spec)
+        r = fc.fit_ragged(spec, off, dsr, yr, extra=exr)
+        with fc.get_context().options(harm=0):
+            r0 = fc.fit_ragged(spec, off, dsr, yr, extra=exr)
+        for name in ('theta', 'fval', 'n_iter', 'n_eval', 'status', 'y_scale'):
+            assert np.array_equal(getattr(r, name), getattr(r0, name), equal_nan=True), (n_extra, name)
+        assert (r.status > 0).all()
+        csp = helpers.oracle_spec(spec)
+        for n in (0, 11, N - 1):
+            sl = slice(off[n], off[n + 1])
+            o = cl.fit(csp, dsr[sl], yr[sl], 0.0, 0.0, None if exr is None else exr[:, sl])
+            assert (r.n_iter[n], r.n_eval[n], r.status[n]) == (o['n_iter'], o['n_eval'], o['status']), (n_extra, n)
+            P = len(o['theta'])
+            assert n_bit_diff(r.theta[n][:P], o['theta']) == 0 and n_bit_diff(r.fval[n], o['f']) == 0, (n_extra, n)
 
 
 def _used_sparse_columns(fc):

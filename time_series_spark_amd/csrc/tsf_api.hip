@@ -548,7 +548,13 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
             (hs.harm == HARM_W3 && hs.KP == 8))
             harm = hs.harm;
     }
-    const int bw_ns = harm ? hs.n_seas : 0;
+    // The same base pairs for the Gram build of a ragged quadratic-form panel whose series have a calendar each (the M-in-
+    // registers kernel builds Z^T Z per series: gram_columns_harm, tsf_quad_kernels.h); shared calendars build once per
+    // calendar (quad_pre) and keep reading the tables.
+    int gram_harm = 0;
+    if (quad && !aligned && !quad_pre && lat_U == 0 && hs.harm == HARM_Y10_W3 && hs.KP == 28 && ctx->opt[TSF_OPT_HARM] != 0)
+        gram_harm = hs.harm;
+    const int bw_ns = (harm || gram_harm) ? hs.n_seas : 0;
     // Time slicing of the aligned one-slot quadratic-form kernels (tsf_quad_kernels.h, QuadArgs::yield_evals): a wave
     // hands a fit back after `quantum` evaluations while other series wait.  OFF unless asked for
     // (tsf_set_option(TSF_OPT_QUAD_YIELD, n): n > 0 the quantum; n < -1 suspend after every |n| evaluations whether or
@@ -588,7 +594,7 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
                        (int)n_grids, aligned ? nullptr : offsets, T, ds, extra,
                        aligned ? (int64_t)T : total_rows, NTmax, gtab, tw, cw, Xw,
                        (int32_t *)(ws + l.uw), lat_base, lat_U > 0 ? lat_step : (int64_t)0, grid_rows,
-                       harm ? (double *)(ws + l.Bw) : (double *)nullptr);
+                       bw_ns ? (double *)(ws + l.Bw) : (double *)nullptr);
     HIP_TRY(ctx, hipGetLastError());
     if (sparse_try) {
         int *sp_bad = (int *)(ws + l.counter) + 8;
@@ -618,7 +624,7 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     a.theta_in = theta_in; a.grad_out = grad_out;
     a.uw = (const int32_t *)(ws + l.uw); a.Xu = (const double *)(ws + l.Xu); a.xidx = lat_U > 0 ? 1 : 0;
     a.grid_of = grid_of;
-    a.Bw = harm ? (const double *)(ws + l.Bw) : nullptr; a.bw_ns = bw_ns; a.harm = harm;
+    a.Bw = bw_ns ? (const double *)(ws + l.Bw) : nullptr; a.bw_ns = bw_ns; a.harm = harm;
     ctx->last_sp_flag = nullptr;
     if (sparse_try) {
         a.sp_meta = (const uint32_t *)(ws + l.spm); a.sp_prog = (const unsigned long long *)(ws + l.spp);
@@ -669,6 +675,7 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
         qa.recenter_every = spec->recenter_every; qa.recenter_ratio = spec->recenter_ratio;
         qa.dbg = nullptr; qa.nb_buf = nullptr; qa.nb_bytes = 0;
         qa.Mpre = quad_pre ? qa.Mg : nullptr; qa.n_pre = quad_pre;
+        qa.gram_harm = gram_harm;
         HIP_TRY(ctx, hipMemsetAsync(qa.counter, 0, sizeof(int), st));
         if (yield_evals != 0) {
             qa.yield_evals = yield_evals; qa.yrec = (double *)(ws + l.yrec); qa.yq = (int *)(ws + l.yq);

@@ -50,10 +50,13 @@ static int launch_quad_ragged_lds(const QuadPlan &qp, const QuadArgs &qa, hipStr
 // workgroup (two per SIMD, 256 registers each), history ring and residual staging in LDS; -2 when the
 // staging does not fit (long series)
 template <int KP, int PQ>
-static int launch_quad_ragged_reg(const QuadPlan &qp, const QuadArgs &qa, hipStream_t st)
+static int launch_quad_ragged_reg(const QuadPlan &qp, const QuadArgs &qa_, hipStream_t st)
 {
     constexpr int NWR = 8;
     if (qp.P4 != PQ) return -2;
+    QuadArgs qa = qa_;
+    // the base-pair build keeps three columns' trend tables: two GramX in the staging rows, else the two-column build
+    if (sizeof(double) * (size_t)qa.f.NTmax * W < 2 * sizeof(GramX) || !qa.f.Bw || qa.Mpre) qa.gram_harm = 0;
     const size_t lds = (quad_lanec_bytes<1>() + sizeof(QuadLds<KP, 1>) + quad_hist_bytes<1>(true) +
                         sizeof(double) * (size_t)qa.f.NTmax * W) * NWR;
     if (lds > 160 * 1024) return -2;

@@ -66,6 +66,8 @@ struct QuadArgs {
     // possible order (longest first); the state is copied bit for bit, so no result depends on it.
     // yield_evals: 0 off; > 0 quantum; < 0 (tests) suspend after every |yield_evals| evaluations whether or not anyone waits.
     int yield_evals;
+    int gram_harm;                      // ragged, a grid per series, M in registers: harm_code of the model when the build expands the
+                                        // Fourier columns from the rows' base pairs (FitArgs::Bw; gram_columns_harm), else 0
     double *yrec;                       // [N][YREC_D] suspended fits
     int *yq;                            // [1] suspensions so far, [2] series finished, [8 ..] ring of N series ids, then N publish words
                                         // (tickets come from `counter`: 0 .. N-1 unstarted series, N + k the k-th suspension)
@@ -189,6 +191,42 @@ __device__ __forceinline__ void column_group(const SeriesView &sv, const double 
     column_sums_g<G>(acc, accR + g0);
 }
 
+// column_group for a series whose rows are kept as BASE PAIRS (SeriesView::Bw; a ragged panel with a calendar per
+// series, round 5): the Fourier columns G0 .. G0 + G - 1 of a row expanded from its pairs (harm_row: the recurrence runs
+// up to the group's last harmonic, the rest is dead code), dense columns behind the Fourier block from Xw where the
+// model has any.  Same chains as column_group: the values are the bits Xw holds.
+template <int KP, int HARM, int G0, int G>
+__device__ __forceinline__ void column_group_harm(const SeriesView &sv, const double *rb, double *accR, bool has_xd)
+{
+    constexpr int KF = harm_kf(HARM), NS = harm_ns(HARM);
+    const int lane = lane_id();
+    double acc[G];
+#pragma unroll
+    for (int j = 0; j < G; ++j) acc[j] = 0.0;
+#pragma unroll 2
+    for (int q = sv.NT - 1; q >= 0; --q) {
+        const double r = rb[q * W + lane];
+        const bool valid = q < sv.cnt;
+        const double2 *bq = reinterpret_cast<const double2 *>(sv.Bw) + (size_t)q * NS * W + lane;
+        double2 bp[NS];
+#pragma unroll
+        for (int se = 0; se < NS; ++se) {
+            // (rows a chunk does not have were never written in Bw: any finite pair, their weight is 0)
+            const double2 b = bq[se * W];
+            bp[se].x = valid ? b.x : 0.0; bp[se].y = valid ? b.y : 0.0;
+        }
+        harm_row<HARM>(bp, [&](int j, double v) {
+            if (j >= G0 && j < G0 + G) acc[j - G0 < 0 ? 0 : (j - G0 < G ? j - G0 : 0)] = __builtin_fma(v, r, acc[j - G0 < 0 ? 0 : (j - G0 < G ? j - G0 : 0)]);
+        });
+        if (G0 + G > KF && has_xd) {
+#pragma unroll
+            for (int j = (G0 > KF ? G0 : KF); j < G0 + G; ++j)
+                acc[j - G0] = __builtin_fma(sv.Xw[((size_t)q * KP + j) * W + lane], r, acc[j - G0]);
+        }
+    }
+    column_sums_g<G>(acc, accR + G0);
+}
+
 // Z^T r and r.r, in the operation order of eval_fg<GROWTH 0, MODE 0> (cn_ztr).  The weight of
 // row lane*NT+q comes from gen(q, idx, c, ti) (called for valid rows only, q descending); it is
 // parked in rb[q*64+lane] for the per-column passes (0 for rows past the end of the series).
@@ -199,7 +237,7 @@ __device__ __forceinline__ void column_group(const SeriesView &sv, const double 
 // lane for cfg2, which the 168-register budget of the 12-waves-per-CU kernel has room for (138 used).  Round 2
 // staged them through global memory (the LDS is full at 12 waves): 7 x the algorithmic HBM bytes.  The array is
 // indexed by the wave-uniform step q (s_set_gpr_idx / v_movrel, no scratch).
-template <int KP, int PPL, int NTR = 0, class RGen>
+template <int KP, int PPL, int NTR = 0, int HARM = 0, class RGen>
 __device__ __forceinline__ void ztr_pass(const SeriesView &sv, QuadLds<KP, PPL> &wl, double *rb,
                                          RGen gen, double &sse_out, double (&ztr)[PPL])
 {
@@ -240,9 +278,18 @@ __device__ __forceinline__ void ztr_pass(const SeriesView &sv, QuadLds<KP, PPL> 
     wl.tot1[lane] = s1; wl.tot2[lane] = s2v;
     if (lane == 0) { wl.tot1[W] = 0.0; wl.tot2[W] = 0.0; }
     constexpr int G8 = (KP / 8) * 8;
+    if constexpr (HARM != 0) {
+        static_assert(HARM == 0 || (KP == 28 && NTR == 0), "base-pair rows: the 28-column kernels, weights in the staging rows");
+        const bool has_xd = sv.P - 3 - S > harm_kf(HARM);
+        column_group_harm<KP, HARM, 0, 8>(sv, rb, wl.accR, has_xd);
+        column_group_harm<KP, HARM, 8, 8>(sv, rb, wl.accR, has_xd);
+        column_group_harm<KP, HARM, 16, 8>(sv, rb, wl.accR, has_xd);
+        column_group_harm<KP, HARM, 24, 4>(sv, rb, wl.accR, has_xd);
+    } else {
 #pragma unroll 1
     for (int g0 = 0; g0 < G8; g0 += 8) column_group<KP, 8, NTR>(sv, rb, g0, wl.accR, rr);
     if (KP % 8 != 0) column_group<KP, 4, NTR>(sv, rb, G8, wl.accR, rr);
+    }
     wave_sync();
 #pragma unroll
     for (int s = 0; s < PPL; ++s) {
@@ -494,7 +541,7 @@ __device__ __forceinline__ bool assemble_q(const SeriesView &sv, const LaneConst
 }
 
 // residual-form evaluation (cn_resid_q): r -> rb, then Z^T r, then assemble_q
-template <int KP, int PPL, int NTR = 0>
+template <int KP, int PPL, int NTR = 0, int HARM = 0>
 __device__ __forceinline__ bool resid_eval_q(const SeriesView &sv, QuadLds<KP, PPL> &wl,
                                              const LaneConst<PPL> &lk, double *rb,
                                              const double (&th)[PPL], double &f_out,
@@ -521,16 +568,31 @@ __device__ __forceinline__ bool resid_eval_q(const SeriesView &sv, QuadLds<KP, P
     auto gen = [&](int q, int idx, int c, double ti) -> double {
         const double yi = sv.yw[idx];
         const double *xp = sv.Xw + (size_t)q * KP * W + lane;
-        double x[KP];
-#pragma unroll
-        for (int j = 0; j < KP; ++j) x[j] = xp[j * W];
         double xa = 0.0;
+        if constexpr (HARM != 0) {
+            // (round 5) the row as its base pairs, the Fourier columns expanded (harm_row); a row the chunk does not have
+            // reads whatever Bw holds there: ztr_pass drops its r
+            constexpr int KF = harm_kf(HARM), NS = harm_ns(HARM);
+            const double2 *bq = reinterpret_cast<const double2 *>(sv.Bw) + (size_t)q * NS * W + lane;
+            double2 bp[NS];
 #pragma unroll
-        for (int j = 0; j < KP; ++j) xa = __builtin_fma(x[j], beta[j], xa);
+            for (int se = 0; se < NS; ++se) bp[se] = bq[se * W];
+            harm_row<HARM>(bp, [&](int j, double v) { xa = __builtin_fma(v, beta[j], xa); });
+            if (sv.P - 3 - S > KF) {
+#pragma unroll
+                for (int j = KF; j < KP; ++j) xa = __builtin_fma(xp[j * W], beta[j], xa);
+            }
+        } else {
+            double x[KP];
+#pragma unroll
+            for (int j = 0; j < KP; ++j) x[j] = xp[j * W];
+#pragma unroll
+            for (int j = 0; j < KP; ++j) xa = __builtin_fma(x[j], beta[j], xa);
+        }
         const double gtr = __builtin_fma(wl.ks[c], ti, wl.mc[c]);
         return yi - (gtr + xa);
     };
-    ztr_pass<KP, PPL, NTR>(sv, wl, rb, gen, sse_out, ztr);
+    ztr_pass<KP, PPL, NTR, HARM>(sv, wl, rb, gen, sse_out, ztr);
     return assemble_q<PPL>(sv, lk, th, sse_out, ztr, f_out, g);
 }
 
@@ -686,6 +748,7 @@ __device__ __forceinline__ void make_view_grid(const FitArgs &a, int64_t g, int6
     sv.tw = a.tw + (size_t)g * a.NTmax * W;
     sv.cw = a.cw + (size_t)g * a.NTmax * W;
     sv.Xw = a.Xw + (size_t)g * a.NTmax * KP * W;
+    sv.Bw = a.Bw ? a.Bw + (size_t)g * a.NTmax * a.bw_ns * 2 * W : nullptr;
     sv.yw = a.yw + (size_t)n * a.NTmax * W;
     sv.Lj = gt.Lj;
     sv.t_change = gt.info.t_change;
@@ -802,6 +865,148 @@ __device__ __forceinline__ void gram_columns2(const SeriesView &sv, QuadLds<KP, 
             va = wl.accR[p - 3 - S]; vb = gx.accR[p - 3 - S];
         }
         za = va; zb = vb;
+    }
+    wave_sync();
+}
+
+// NC columns of M in one pass over the rows, the Fourier columns of a row EXPANDED from its base pairs (FitArgs::Bw,
+// harm_row of tsf_fit_kernels.h: the values are the bits setup_grid_kernel wrote into Xw) instead of read: a pass
+// loads the row's base pairs, its dense columns behind the Fourier block and the NC weights -- 9 values where
+// gram_columns2 loads 30 -- and without the row's 28 values in registers a third column's accumulators fit, so a
+// series' Z^T Z takes 18 passes instead of 27 (round 5: a ragged panel with a calendar per series read its tables
+// 27 times per series, 31-33 GB per launch).  Entry by entry the chains are gram_columns2's: same operands, same
+// order, same bits.  qs[c] < 0: no such column (the last pass), its results are dropped.
+template <int KP, int HARM, int NC>
+__device__ __forceinline__ void gram_columns_harm(const SeriesView &sv, QuadLds<KP, 1> &wl, GramX *gx,
+                                                  const int (&qs)[NC], double (&z)[NC])
+{
+    static_assert(NC >= 1 && NC <= 3 && KP == 28, "written for the 28-column kernel");
+    constexpr int KF = harm_kf(HARM), NS = harm_ns(HARM);
+    const int lane = lane_id();
+    const int S = sv.S;
+    double acc[NC][KP];
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int j = 0; j < KP; ++j) acc[c][j] = 0.0;
+    double rt1[NC], rt2[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { rt1[c] = 0.0; rt2[c] = 0.0; }
+    double *tp1[NC], *tp2[NC], *tot1[NC], *tot2[NC], *accR[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        tp1[c] = c == 0 ? wl.tp1 : gx[c - 1].tp1; tp2[c] = c == 0 ? wl.tp2 : gx[c - 1].tp2;
+        tot1[c] = c == 0 ? wl.tot1 : gx[c - 1].tot1; tot2[c] = c == 0 ? wl.tot2 : gx[c - 1].tot2;
+        accR[c] = c == 0 ? wl.accR : gx[c - 1].accR;
+    }
+    // The loads of step q - 1 are issued before the arithmetic of step q (a step is ~140 dependent-free fmas: enough to
+    // cover them); the dense columns behind the Fourier block only where the model has any (n_xd).
+    const bool has_xd = sv.P - 3 - S > KF;
+    bool wdes[NC];                      // the weight is a design column (read), not a trend column (formed from t)
+    int wcol[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { wdes[c] = qs[c] >= 3 + S; wcol[c] = wdes[c] ? qs[c] - 3 - S : 0; }
+    double tcq[NC];                     // the changepoint time of a trend column (read once per pass, not per row)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) tcq[c] = (qs[c] >= 3 && qs[c] < 3 + S) ? sv.t_change[qs[c] - 3] : 0.0;
+    struct Row { double2 bp[NS]; double w[NC]; double ti; unsigned cwv; };
+    auto fetch = [&](int q, Row &rw) {
+        const int idx = q * W + lane;
+        rw.cwv = (unsigned)sv.cw[idx];
+        rw.ti = sv.tw[idx];
+        const double *xp = sv.Xw + (size_t)q * KP * W + lane;
+        const double2 *bq = reinterpret_cast<const double2 *>(sv.Bw) + (size_t)q * NS * W + lane;
+#pragma unroll
+        for (int se = 0; se < NS; ++se) rw.bp[se] = bq[se * W];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) rw.w[c] = wdes[c] ? xp[(size_t)wcol[c] * W] : 0.0;
+    };
+    Row cur;
+    fetch(sv.NT - 1, cur);
+#pragma unroll 1
+    for (int q = sv.NT - 1; q >= 0; --q) {
+        Row nxt;
+        fetch(q > 0 ? q - 1 : 0, nxt);
+        const bool valid = q < sv.cnt;
+        const unsigned cwv = valid ? cur.cwv : 0u;
+        const int cseg = (int)(cwv & 0xffu), cprev = (int)(cwv >> 8);
+        const double ti = valid ? cur.ti : 0.0;
+        double2 bp[NS];
+#pragma unroll
+        for (int se = 0; se < NS; ++se) {
+            // (rows a chunk does not have were never written in Bw; any finite pair will do: their weights are 0)
+            bp[se].x = valid ? cur.bp[se].x : 0.0; bp[se].y = valid ? cur.bp[se].y : 0.0;
+        }
+        double r[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int qq = qs[c];
+            double rv;
+            if (qq == 0) rv = ti;
+            else if (qq == 1) rv = 1.0;
+            else if (qq < 3 + S) rv = (cseg > qq - 3) ? ti - tcq[c] : 0.0;
+            else rv = cur.w[c];
+            r[c] = (valid && qq >= 0) ? rv : 0.0;
+            rt1[c] = __builtin_fma(r[c], ti, rt1[c]); rt2[c] = rt2[c] + r[c];
+        }
+        for (int j = cprev; j < cseg; ++j) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) { tp1[c][j] = rt1[c]; tp2[c][j] = rt2[c]; }
+        }
+        harm_row<HARM>(bp, [&](int j, double v) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[c][j] = __builtin_fma(v, r[c], acc[c][j]);
+        });
+        if (has_xd) {
+            const double *xp = sv.Xw + (size_t)q * KP * W + lane;
+#pragma unroll
+            for (int j = KF; j < KP; ++j) {
+                const double xv = xp[j * W];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) acc[c][j] = __builtin_fma(xv, r[c], acc[c][j]);
+            }
+        }
+        cur = nxt;
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const double s1 = suffix_scan(rt1[c]), s2v = suffix_scan(rt2[c]);
+        tot1[c][lane] = s1; tot2[c][lane] = s2v;
+        if (lane == 0) { tot1[c][W] = 0.0; tot2[c][W] = 0.0; }
+    }
+    constexpr int G8 = (KP / 8) * 8;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+#pragma unroll
+        for (int g0 = 0; g0 < G8; g0 += 8) {
+            double ta[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) ta[u] = acc[c][g0 + u];
+            column_sums_g<8>(ta, accR[c] + g0);
+        }
+        if (KP % 8 != 0) {
+            double ta[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ta[u] = acc[c][(G8 + u) < KP ? G8 + u : 0];
+            column_sums_g<4>(ta, accR[c] + G8);
+        }
+    }
+    wave_sync();
+    {
+        const int p = lane;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            double v = 0.0;
+            if (p == 0) v = tot1[c][0];
+            else if (p == 1) v = tot2[c][0];
+            else if (p >= 3 && p < 3 + S) {
+                const int j = p - 3, Lj = sv.Ljp_l[0];
+                v = (tp1[c][j] + tot1[c][Lj + 1]) - sv.tcp_l[0] * (tp2[c][j] + tot2[c][Lj + 1]);
+            } else if (p >= 3 + S && p < sv.P) {
+                v = accR[c][p - 3 - S];
+            }
+            z[c] = v;
+        }
     }
     wave_sync();
 }
@@ -936,7 +1141,30 @@ __device__ __forceinline__ bool fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
         // ragged panel: this series has its own grid, hence its own M = Z^T Z.  The wave builds
         // it column by column into its slot of global memory; lane p writes and later reads only
         // entries of its own row p, so no fence is needed.
-        if constexpr (MREG && PPL == 1) {
+        bool built = false;
+        if constexpr (MREG && PPL == 1 && KP == 28) {
+            if (qa.gram_harm == HARM_Y10_W3) {
+                // three columns per pass, the Fourier columns expanded from the rows' base pairs (gram_columns_harm)
+                int qs[3] = {-1, -1, -1}, nq = 0;
+#pragma unroll 1
+                for (int q = 0; q <= P4; ++q) {
+                    if (q < P4) {
+                        const bool real = q != 2 && q < sv.P;
+                        if (!real) { Mown[(size_t)q * W + lane] = 0.0; continue; }
+                        qs[nq++] = q;
+                        if (nq < 3) continue;
+                    } else if (nq == 0) break;
+                    double z[3];
+                    gram_columns_harm<KP, HARM_Y10_W3, 3>(sv, *wlp, gx, qs, z);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) if (qs[c] >= 0) Mown[(size_t)qs[c] * W + lane] = z[c];
+                    qs[0] = -1; qs[1] = -1; qs[2] = -1; nq = 0;
+                }
+                built = true;
+            }
+        }
+        if (built) {
+        } else if constexpr (MREG && PPL == 1) {
             // two columns per pass (gram_columns2); rows 2 and >= P of M are zero
             int qprev = -1;
 #pragma unroll 1
@@ -1031,6 +1259,10 @@ __device__ __forceinline__ bool fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
             double *rbs = pool->slot_bytes > sizeof(QuadLds<KP, PPL>) ? reinterpret_cast<double *>(sl + sizeof(QuadLds<KP, PPL>)) : rb;
             bad = resid_eval_q<KP, PPL, NTR>(sv, *reinterpret_cast<QuadLds<KP, PPL> *>(sl), lk, rbs, xe, fe, ge, sse_e, ztr_e);
             pool_release(*pool, slot);
+        } else if constexpr (RAGGED && MREG && PPL == 1 && KP == 28 && NTR == 0) {
+            // a calendar per series: the rows as base pairs here too (QuadArgs::gram_harm)
+            if (qa.gram_harm == HARM_Y10_W3) bad = resid_eval_q<KP, PPL, NTR, HARM_Y10_W3>(sv, *wlp, lk, rb, xe, fe, ge, sse_e, ztr_e);
+            else bad = resid_eval_q<KP, PPL, NTR>(sv, *wlp, lk, rb, xe, fe, ge, sse_e, ztr_e);
         } else {
             bad = resid_eval_q<KP, PPL, NTR>(sv, *wlp, lk, rb, xe, fe, ge, sse_e, ztr_e);
         }

@@ -17,6 +17,8 @@ from time_series_spark_amd import _lib, forecaster as fc, synth  # noqa: E402
 
 N, T = 10000, 730
 for growth, mode in (('linear', 'additive'), ('logistic', 'multiplicative')):
+    if os.environ.get('ONLY') not in (None, '', growth):      # ONLY=linear | logistic: one model (A/B runs)
+        continue
     ds, y = synth.make_panel(N, T, growth, seed=751)
     lens = 640 + (np.arange(N) * 37) % 91
     off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
