@@ -542,8 +542,7 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     // sparse-column form, weekly 3 + daily 4 (16 columns), weekly 3 (8 columns); never with the lattice table or the
     // matrix-core / workgroup-from-the-start routes.  tsf_set_option(TSF_OPT_HARM, 0): never.
     int harm = 0;
-    if (!quad && !newton && !mp.on && theta_in == nullptr && lat_U == 0 && ctx->opt[TSF_OPT_HARM] != 0 &&
-        !(coop && coop_after == COOP_DIRECT) && spec->residual_kernel != TSF_RK_COOP) {
+    if (!quad && !newton && !mp.on && theta_in == nullptr && lat_U == 0 && ctx->opt[TSF_OPT_HARM] != 0) {
         if ((hs.harm == HARM_Y10_W3 && (hs.KP == 28 || sparse_try)) || (hs.harm == HARM_W3_D4 && hs.KP == 16) ||
             (hs.harm == HARM_W3 && hs.KP == 8))
             harm = hs.harm;
@@ -625,6 +624,7 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     a.uw = (const int32_t *)(ws + l.uw); a.Xu = (const double *)(ws + l.Xu); a.xidx = lat_U > 0 ? 1 : 0;
     a.grid_of = grid_of;
     a.Bw = bw_ns ? (const double *)(ws + l.Bw) : nullptr; a.bw_ns = bw_ns; a.harm = harm;
+    a.coop_harm = (harm != 0 && hs.K == harm_kf(harm) && mode != 2) ? 1 : 0;
     ctx->last_sp_flag = nullptr;
     if (sparse_try) {
         a.sp_meta = (const uint32_t *)(ws + l.spm); a.sp_prog = (const unsigned long long *)(ws + l.spp);

@@ -47,7 +47,9 @@ enum { COOP_EVAL = 1, COOP_EXIT = 2 };
 #endif
 
 // LDS of the resident rows' first XL values: [step][XL][64]
-__host__ __device__ constexpr size_t coop_xl_bytes(int KP, int NTmax) { return (KP == 28 && NTmax <= 12) ? sizeof(double) * 12 * 14 * W : 0; }
+// (table variant: 14 values of each of 12 x 64 rows; base-pair variant: the owner's 4 columns, then 2 of the 4 columns of each
+// of the 6 row waves, 12 steps each)
+__host__ __device__ constexpr size_t coop_xl_bytes(int KP, int NTmax) { return (KP == 28 && NTmax <= 12) ? sizeof(double) * 12 * 16 * W : 0; }
 // row buffers r, r g, v: [rows][64] each, rows = max(NTmax, COOP_NTB) (coop_rb_rows)
 __host__ __device__ constexpr int coop_rb_rows(int NTmax) { return NTmax > 16 ? NTmax : 16; }
 template <int KP, int PPL>
@@ -57,10 +59,10 @@ __host__ __device__ constexpr size_t coop_lds_bytes(int NTmax)
 }
 
 #ifdef TSF_COOP_TIMING      // dev only: owner-wave cycles per phase, summed per series
-#define CT_DECL long long ct_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long ct_t0 = __builtin_readcyclecounter(), ct_start = ct_t0
+#define CT_DECL long long ct_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long ct_t0 = __builtin_readcyclecounter(), ct_start = ct_t0
 #define CT_LAP(k) do { const long long t_ = __builtin_readcyclecounter(); ct_acc[k] += t_ - ct_t0; ct_t0 = t_; } while (0)
-#define CT_FLUSH(dst, n) do { if ((dst) && lane_id() == 0) { ct_acc[7] = __builtin_readcyclecounter() - ct_start; for (int k_ = 0; k_ < 8; ++k_) ((long long *)(dst))[(size_t)(n) * 16 + k_] = ct_acc[k_]; } } while (0)
-#define CT_ARGS , long long (&ct_acc)[8], long long &ct_t0
+#define CT_FLUSH(dst, n) do { if ((dst) && lane_id() == 0) { ct_acc[7] = __builtin_readcyclecounter() - ct_start; for (int k_ = 0; k_ < 8; ++k_) ((long long *)(dst))[(size_t)(n) * 64 + k_] = ct_acc[k_]; for (int k_ = 8; k_ < 12; ++k_) ((long long *)(dst))[(size_t)(n) * 64 + 40 + k_] = ct_acc[k_]; } } while (0)
+#define CT_ARGS , long long (&ct_acc)[12], long long &ct_t0
 #define CT_PASS , ct_acc, ct_t0
 #else
 #define CT_ARGS
@@ -260,7 +262,7 @@ __device__ __forceinline__ void coop_segment_tables(const SeriesView &sv, L &w)
 // prior terms) from the time-axis sums the trend wave has just produced: cl.gtr.  Runs on the trend
 // wave while the other waves finish their columns.  Scratch: w.d1, w.d2, w.rb, w.ab.
 template <int GROWTH, int KP, int PPL>
-__device__ __forceinline__ void coop_tail_trend(const SeriesView &sv, CoopLds<KP, PPL> &cl)
+__device__ __forceinline__ void coop_tail_trend(const SeriesView &sv, CoopLds<KP, PPL> &cl, const LogisticReversePre *pre = nullptr)
 {
     const int lane = lane_id();
     const int S = sv.S;
@@ -271,7 +273,9 @@ __device__ __forceinline__ void coop_tail_trend(const SeriesView &sv, CoopLds<KP
     if (GROWTH == 1) {
         // (round 5) the reverse sweep and the running sums as scans: logistic_reverse_lanes, tsf_fit_kernels.h
         double gd_l;
-        logistic_reverse_lanes(sv, lds, TA, TB, gk, gm, gd_l);
+        // (pre: the quotients of the segment tables, formed by the caller while the rows were still running)
+        if (pre) logistic_reverse_post(sv, lds, *pre, TA, TB, gk, gm, gd_l);
+        else logistic_reverse_lanes(sv, lds, TA, TB, gk, gm, gd_l);
         gk = nis * gk; gm = nis * gm;
         if (lane >= 3 && lane < 3 + S) gd = nis * gd_l;
     } else {
@@ -293,6 +297,55 @@ __device__ __forceinline__ void coop_tail_trend(const SeriesView &sv, CoopLds<KP
 // (its release fence is s_waitcnt vmcnt(0)).  Everything the waves exchange goes through LDS.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+
+// X.beta chains of R rows side by side over the Fourier columns (base pairs bp[i][se]; coefficients bl[j] in LDS):
+// harm_columns' recurrence and eval_fg's fma order, harmonic by harmonic.  The coefficients come in batches of 8 columns,
+// two batches ahead of their use (32 registers instead of 2 KF).  The empty asm statements tie the recurrence to the
+// chain and the batches to their place: left free, the scheduler runs the recurrences of all rows ahead of the
+// coefficient reads and holds every harmonic of every row in registers (measured: 165 registers spilled, 12 instead of
+// 6 us per evaluation).
+template <int O, int COL0, int R, int SE, int NSX, int KFX>
+__device__ __forceinline__ void harm_chain_season(const double2 (&bp)[R][NSX], const double *bl, double (&bj)[KFX], double (&ch)[R])
+{
+    if constexpr (O > 0) {
+        double c2[R], sp[R], cp[R], sc[R], cc[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) { c2[i] = 2.0 * bp[i][SE].y; sp[i] = 0.0; cp[i] = 1.0; sc[i] = bp[i][SE].x; cc[i] = bp[i][SE].y; }
+#pragma unroll
+        for (int h = 1; h <= O; ++h) {
+            constexpr int B = 8;
+            const int col = COL0 + 2 * (h - 1);
+            if (col % B == 0 && col > 0 && col + B < KFX) {     // the batch after next
+#pragma unroll
+                for (int j = col + B; j < col + 2 * B; ++j) if (j < KFX) bj[j] = bl[j];
+                asm volatile("" ::: "memory");
+            }
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                if (h > 1) {
+                    const double sn = __builtin_fma(c2[i], sc[i], -sp[i]), cn = __builtin_fma(c2[i], cc[i], -cp[i]);
+                    sp[i] = sc[i]; cp[i] = cc[i]; sc[i] = sn; cc[i] = cn;
+                }
+                ch[i] = __builtin_fma(sc[i], bj[col], ch[i]);
+                ch[i] = __builtin_fma(cc[i], bj[col + 1], ch[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < R; ++i) asm volatile("" : "+v"(ch[i]), "+v"(sc[i]), "+v"(cc[i]));
+        }
+    }
+}
+template <int HARM, int R>
+__device__ __forceinline__ void harm_chain_rows(const double2 (&bp)[R][harm_ns(HARM)], const double *bl, double (&ch)[R])
+{
+    constexpr int KF = harm_kf(HARM), NS = harm_ns(HARM), O0 = harm_order(HARM, 0), O1 = harm_order(HARM, 1), O2 = harm_order(HARM, 2);
+    double bj[KF];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) if (j < KF) bj[j] = bl[j];
+    asm volatile("" ::: "memory");
+    harm_chain_season<O0, 0, R, 0, NS, KF>(bp, bl, bj, ch);
+    harm_chain_season<O1, 2 * O0, R, 1, NS, KF>(bp, bl, bj, ch);
+    harm_chain_season<O2, 2 * (O0 + O1), R, 2 < NS ? 2 : 0, NS, KF>(bp, bl, bj, ch);
+}
 
 // generic loops (any NT <= COOP_MAX_NT): every load inside its phase
 template <int KP, int GROWTH, int MODE, int PPL, int NW, bool XIDX>
@@ -327,41 +380,63 @@ __device__ __forceinline__ void coop_helper(const DevSpec *__restrict__ sp, cons
 // Straight-line code: requests that have no row / column / step behind them are clamped to row 0 /
 // column 0 / step 0 and their results dropped or multiplied by the zero rows [NT, COOP_NTB) of the row
 // buffers (cleared once per series by the caller).
-template <int KP, int NW, int NTB>
+template <int KP, int NW, int NTB, int HARM = 0>
 struct CoopShape {
     static constexpr int RPW = 2;                               // rows of a wave held at a time
     static constexpr int XB = KP <= 32 ? KP : 32;               // design values of a row held at a time
     static constexpr int NXB = KP / XB;                         // KP = 8, 16, 28: 1;  64: 2
-    static constexpr int CPW_RES = (KP + NW - 2) / (NW - 1);    // columns per wave, resident mode (owner + row waves)
+    // columns per wave, resident mode: owner + row waves; HARM: the row waves alone (the registers the rows' design values
+    // took hold a fifth column per wave, and the owner's evaluation has no loads left: they made it the last to arrive at
+    // a barrier, measured)
+    static constexpr bool OWNER_COLS = HARM == 0;
+    // HARM, 28 columns: four per row wave (24), the last four summed by the owner from an LDS copy (OWN_L; the staging
+    // region of the table variant, unused here) -- a fifth column per row wave spilled 25 registers into its loop
+    static constexpr int OWN_L = (HARM != 0 && KP == 28) ? KP - 4 * (NW - 2) : 0;
+    static constexpr int CPW_RES = OWNER_COLS ? (KP + NW - 2) / (NW - 1) : (OWN_L > 0 ? 4 : (KP + NW - 3) / (NW - 2));
     // resident mode, 28 columns x 12 steps: the first XL design values of every row live in LDS instead
     // of registers (with all of 2 rows x 28 + 4 columns x 12 values in registers the row waves spill
     // ~30 of them, and every reload is a dependent scratch round trip inside the row chain: 7.4 k
     // instead of ~2 k cycles per phase A)
-    static constexpr int XL = (KP == 28 && NTB == 12) ? 14 : 0;
-    static constexpr bool RES = NXB == 1 && RPW * (XB - XL) + CPW_RES * NTB <= 76;
-    static constexpr int NCW = RES ? NW - 1 : NW - 2;           // waves that take columns
+    // HARM (round 5): a row is its base pairs (FitArgs::Bw; NS double2 per row, resident) and the Fourier columns are
+    // expanded in registers inside the X.beta chain -- no design values of the rows in registers or LDS at all, and the
+    // coefficients of an evaluation fit the registers that frees (one batch of LDS reads instead of one per fma)
+    static constexpr int XL = (HARM == 0 && KP == 28 && NTB == 12) ? 14 : 0;
+    static constexpr bool RES = NXB == 1 && (HARM != 0 ? 0 : RPW * (XB - XL)) + CPW_RES * NTB <= 76;
+    static constexpr int NCW = (RES && OWNER_COLS) ? NW - 1 : NW - 2;           // waves that take columns
     static constexpr int CPW = (KP + NCW - 1) / NCW;
     static constexpr int CB = RES ? CPW : 3;                    // columns held at a time
     static constexpr int NCB = (CPW + CB - 1) / CB;
 };
-template <int KP, int GROWTH, int MODE, int PPL, int NW, bool XIDX, int NTB, bool TREND>
+template <int KP, int GROWTH, int MODE, int PPL, int NW, bool XIDX, int NTB, bool TREND, int HARM = 0>
 __device__ __forceinline__ void coop_helper_pf(const DevSpec *__restrict__ sp, const SeriesView &sv,
                                                CoopLds<KP, PPL> &cl, double *rbR, double *rbU, double *rbV, double *xl, int wid)
 {
 #ifdef TSF_COOP_TIMING
     long long ht_a = 0, ht_b = 0, ht_t = 0;     // busy cycles of this wave in phase A / phase B
+    long long htx[8] = {0, 0, 0, 0, 0, 0, 0, 0}, htx_t = 0;    // finer laps of the same wave (dbg[16 ..] row wave 1, dbg[24 ..] trend wave)
 #define HT_START() ht_t = __builtin_readcyclecounter()
 #define HT_STOP(acc) acc += __builtin_readcyclecounter() - ht_t
+#define HX_START() htx_t = __builtin_readcyclecounter()
+#define HX_LAP(k) do { const long long t_ = __builtin_readcyclecounter(); htx[k] += t_ - htx_t; htx_t = t_; } while (0)
 #else
 #define HT_START() do { } while (0)
 #define HT_STOP(acc) do { } while (0)
+#define HX_START() do { } while (0)
+#define HX_LAP(k) do { } while (0)
 #endif
-    using SH = CoopShape<KP, NW, NTB>;
+    using SH = CoopShape<KP, NW, NTB, HARM>;
     constexpr int NRW = NW - 2, RPW = SH::RPW, XB = SH::XB, NXB = SH::NXB, CB = SH::CB, NCB = SH::NCB, NCW = SH::NCW;
     constexpr bool RES = SH::RES;
+    static_assert(HARM == 0 || (RES && MODE != 2 && !XIDX && NXB == 1), "base-pair rows: resident mode, one column mode, own tables");
+    // base-pair rows, 28 columns: two of the wave's four columns live in LDS (behind the owner's columns in xl) instead of
+    // registers -- with all four in registers the per-series constants of the rows were reloaded from scratch in every
+    // evaluation (22 scratch reads per evaluation of a row wave)
+    constexpr int CL = (HARM != 0 && SH::OWN_L > 0 && !TREND) ? 2 : 0, CBR = CB - CL;
+    double *const xcl = xl + (size_t)12 * SH::OWN_L * W + (size_t)(wid > 0 ? wid - 1 : 0) * CL * 12 * W;
+    constexpr int HKF = HARM != 0 ? harm_kf(HARM) : 1, HNS = HARM != 0 ? harm_ns(HARM) : 1;
     constexpr int XL = RES ? SH::XL : 0;                // design values of a row kept in LDS (xl)
     constexpr bool ROWS = !TREND, COLS = !TREND;
-    const int cw0 = RES ? wid : wid - 1;                // first column of this wave (resident mode: wave 0 = the owner has one too)
+    const int cw0 = (RES && SH::OWNER_COLS) ? wid : wid - 1;    // first column of this wave (resident mode without base-pair rows: wave 0 = the owner has one too)
     const int lane = lane_id();
     const int NT = sv.NT, S = sv.S, K = sp->K;
     const int Ka = (MODE == 0) ? K : (MODE == 1 ? 0 : sp->Ka);
@@ -436,11 +511,21 @@ __device__ __forceinline__ void coop_helper_pf(const DevSpec *__restrict__ sp, c
         }
     };
 
-    double x[(ROWS && NXB == 1) ? RPW : 1][XB];
+    double x[(ROWS && NXB == 1 && HARM == 0) ? RPW : 1][XB];
+    double2 bpr[(ROWS && HARM != 0) ? RPW : 1][HNS];           // HARM: the base pairs of the wave's rows
     double xc[COLS ? CB : 1][NTB];
     double xc2[(COLS && !RES && NCB > 1) ? CB : 1][NTB];       // streaming mode: the next batch of columns
+    if constexpr (ROWS && HARM != 0) {
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            // (a row the lane's chunk does not have: whatever Bw holds there -- its r, r g, v are replaced by zeros below)
+            const double2 *bq = reinterpret_cast<const double2 *>(sv.Bw) + (size_t)qrow[i] * HNS * W + lane;
+#pragma unroll
+            for (int se = 0; se < HNS; ++se) bpr[i][se] = bq[se * W];
+        }
+    }
     if constexpr (RES && COLS) {
-        if constexpr (ROWS) {
+        if constexpr (ROWS && HARM == 0) {
 #pragma unroll
             for (int i = 0; i < RPW; ++i) {
                 load_row(i, 0, 0, x[i]);
@@ -453,6 +538,12 @@ __device__ __forceinline__ void coop_helper_pf(const DevSpec *__restrict__ sp, c
             }
         }
         load_cols(0, 0, xc);
+        if constexpr (CL > 0) {
+#pragma unroll
+            for (int u = CBR; u < CB; ++u)
+#pragma unroll
+                for (int q = 0; q < NTB; ++q) xcl[((u - CBR) * NTB + q) * W + lane] = xc[u][q];
+        }
     }
     // one half (XB values) of a row's X.beta chain
     auto chain_half = [&](int i, int h, const double (&xv_)[XB], double &xa_, double &xm_) {
@@ -484,12 +575,22 @@ __device__ __forceinline__ void coop_helper_pf(const DevSpec *__restrict__ sp, c
         lds_barrier();                                      // A
         if (cl.cmd == COOP_EXIT) break;
         HT_START();
-        if constexpr (TREND) { coop_segment_tables<GROWTH>(sv, w); lds_barrier(); }    // A2 (trend wave)
+        HX_START();
+        if constexpr (TREND) { coop_segment_tables<GROWTH>(sv, w); HX_LAP(0); lds_barrier(); HX_LAP(1); }    // A2 (trend wave)
         if constexpr (ROWS) {
             double xa[RPW], xm[RPW];
 #pragma unroll
             for (int i = 0; i < RPW; ++i) { xa[i] = 0.0; xm[i] = 0.0; }
-            if constexpr (NXB == 1) {
+            if constexpr (HARM != 0) {
+                // the chains of the wave's rows side by side: column j's value from the recurrence, fma'd in column order
+                // (eval_fg HARM: same operands, same order)
+                double ch[RPW];
+#pragma unroll
+                for (int i = 0; i < RPW; ++i) ch[i] = 0.0;
+                harm_chain_rows<HARM, RPW>(bpr, &w.th[3 + S], ch);
+#pragma unroll
+                for (int i = 0; i < RPW; ++i) { if (MODE == 0) xa[i] = ch[i]; else xm[i] = ch[i]; }
+            } else if constexpr (NXB == 1) {
 #pragma unroll
                 for (int i = 0; i < RPW; ++i) chain_half(i, 0, x[i], xa[i], xm[i]);
             } else {
@@ -514,7 +615,9 @@ __device__ __forceinline__ void coop_helper_pf(const DevSpec *__restrict__ sp, c
                 for (int i = 0; i < RPW; ++i) asm volatile("" : "+v"(xa[i]), "+v"(xm[i]));
                 load_cols(0, z, xc);
             }
+            HX_LAP(0);
             lds_barrier();                                  // A2: the trend wave's segment tables are in LDS
+            HX_LAP(1);
 #pragma unroll
             for (int i = 0; i < RPW; ++i) {
                 const double ksc = w.ks[cq[i]], mcc = w.mc[cq[i]];
@@ -538,34 +641,49 @@ __device__ __forceinline__ void coop_helper_pf(const DevSpec *__restrict__ sp, c
                 r = valid[i] ? r : 0.0; rg = valid[i] ? rg : 0.0; v = valid[i] ? v : 0.0;
                 if (row[i]) { rbR[idx[i]] = r; rbU[idx[i]] = rg; rbV[idx[i]] = v; }
             }
-            // NT beyond RPW rows per wave: the remaining rows the plain way
-            coop_rows<KP, GROWTH, MODE, PPL, XIDX>(sp, sv, w, rbR, rbU, rbV, (wid - 1) + RPW * NRW, NRW);
+            // NT beyond RPW rows per wave: the remaining rows the plain way (none where RPW rows per wave cover NTB steps: the
+            // loop would never run, but its registers -- a row of design values in flight -- were allocated across the
+            // whole evaluation loop and pushed the rows' per-series constants into scratch)
+            if constexpr (RPW * NRW < NTB)
+                coop_rows<KP, GROWTH, MODE, PPL, XIDX>(sp, sv, w, rbR, rbU, rbV, (wid - 1) + RPW * NRW, NRW);
         }
+        LogisticReversePre lrp;
+        if constexpr (TREND && GROWTH == 1) logistic_reverse_pre(sv, w, lrp);      // while the rows run: what the reverse sweep needs of ks / mc alone
         HT_STOP(ht_a);
+        HX_LAP(2);
         lds_barrier();                                      // B
+        HX_LAP(3);
         HT_START();
         if constexpr (TREND) {
             // running trend sums of every chunk, last row first (rows a chunk does not have carry
             // v = 0 and t = 0: the sums pass through unchanged), kept per step; the snapshots at the
             // changepoint rows are then one gather
             double rt1 = 0.0, rt2 = 0.0;
+            // (all reads of v ahead of the stores of the running sums: both are LDS, and a read behind a store that
+            // may alias it waits for it -- twelve round trips, 1.1 k cycles per evaluation)
+            double vq[NTB];
+#pragma unroll
+            for (int q = 0; q < NTB; ++q) vq[q] = rbV[q * W + lane];     // (zero rows beyond NT)
 #pragma unroll
             for (int q = NTB - 1; q >= 0; --q) {
-                const double v = rbV[q * W + lane];         // (zero rows beyond NT)
-                rt1 = __builtin_fma(v, twq[q], rt1);
-                rt2 = rt2 + v;
+                rt1 = __builtin_fma(vq[q], twq[q], rt1);
+                rt2 = rt2 + vq[q];
                 cl.run1[q * W + lane] = rt1; cl.run2[q * W + lane] = rt2;
             }
+            HX_LAP(4);
             const double s1 = suffix_scan(rt1), s2v = suffix_scan(rt2);
             w.tot1[lane] = s1; w.tot2[lane] = s2v;
             if (lane == 0) { w.tot1[W] = 0.0; w.tot2[W] = 0.0; }
             wave_sync();
+            HX_LAP(5);
             if (lane < S) {
                 const int at = cl.snap_q[lane] * W + cl.snap_l[lane];
                 w.tp1[lane] = cl.run1[at]; w.tp2[lane] = cl.run2[at];
             }
             wave_sync();
-            coop_tail_trend<GROWTH>(sv, cl);
+            HX_LAP(6);
+            coop_tail_trend<GROWTH>(sv, cl, GROWTH == 1 ? &lrp : nullptr);
+            HX_LAP(7);
         }
         if constexpr (COLS) {
             auto col_batch = [&](int b, const double (&xcb)[CB][NTB]) {
@@ -581,7 +699,8 @@ __device__ __forceinline__ void coop_helper_pf(const DevSpec *__restrict__ sp, c
                     for (int u = 0; u < CB; ++u) {
                         const int j = cw0 + (b * CB + u) * NCW;
                         const double ru = (MODE == 0) ? r0 : (MODE == 1 ? r1 : (j < Ka ? r0 : r1));
-                        acc[u] = __builtin_fma(xcb[u][q], ru, acc[u]);
+                        const double xv = (CL > 0 && u >= CBR) ? xcl[((u - CBR < 0 ? 0 : u - CBR) * NTB + q) * W + lane] : xcb[u][q];
+                        acc[u] = __builtin_fma(xv, ru, acc[u]);
                     }
                 }
 #pragma unroll
@@ -603,40 +722,45 @@ __device__ __forceinline__ void coop_helper_pf(const DevSpec *__restrict__ sp, c
             }
         }
         HT_STOP(ht_b);
+        if constexpr (!TREND) HX_LAP(4);
         lds_barrier();                                      // C
     }
 #ifdef TSF_COOP_TIMING
     if (cl.dbg && lane == 0 && (wid == 1 || wid == NW - 1)) {
         cl.dbg[wid == 1 ? 8 : 10] = ht_a; cl.dbg[wid == 1 ? 9 : 11] = ht_b;
+        for (int k_ = 0; k_ < 8; ++k_) cl.dbg[(wid == 1 ? 16 : 24) + k_] = htx[k_];
     }
+    if (cl.dbg && lane == 0 && wid >= 1 && wid < NW - 1) { cl.dbg[32 + 2 * wid] = htx[0]; cl.dbg[33 + 2 * wid] = htx[2]; }
 #endif
 }
 
-template <int KP, int GROWTH, int MODE, int PPL, int NW, bool XIDX, int NTB>
+template <int KP, int GROWTH, int MODE, int PPL, int NW, bool XIDX, int NTB, int HARM = 0>
 __device__ __forceinline__ void coop_helper_ntb(const DevSpec *__restrict__ sp, const SeriesView &sv,
                                                 CoopLds<KP, PPL> &cl, double *rbR, double *rbU, double *rbV, int wid)
 {
     double *xl = rbV + (size_t)COOP_NTB * W;            // (present when coop_xl_bytes() > 0: NTmax <= 12 < COOP_NTB rows of row buffers)
-    if (wid == NW - 1) coop_helper_pf<KP, GROWTH, MODE, PPL, NW, XIDX, NTB, true>(sp, sv, cl, rbR, rbU, rbV, xl, wid);
-    else coop_helper_pf<KP, GROWTH, MODE, PPL, NW, XIDX, NTB, false>(sp, sv, cl, rbR, rbU, rbV, xl, wid);
+    if (wid == NW - 1) coop_helper_pf<KP, GROWTH, MODE, PPL, NW, XIDX, NTB, true, HARM>(sp, sv, cl, rbR, rbU, rbV, xl, wid);
+    else coop_helper_pf<KP, GROWTH, MODE, PPL, NW, XIDX, NTB, false, HARM>(sp, sv, cl, rbR, rbU, rbV, xl, wid);
 }
 
 // ---- one evaluation, the owner's side ----------------------------------------------------------
 // columns the owner holds in resident mode (column j of wave-slot 0: j = 0, NW-1, 2 (NW-1), ...)
-template <int KP, int NW>
+template <int KP, int NW, int HARM = 0>
 struct CoopOwnerCols {
-    static constexpr bool ANY = CoopShape<KP, NW, 12>::RES || CoopShape<KP, NW, COOP_NTB>::RES;
-    static constexpr int OC = ANY ? CoopShape<KP, NW, 12>::CPW_RES : 1;
-    static constexpr int ONT = CoopShape<KP, NW, COOP_NTB>::RES ? COOP_NTB : 12;     // steps the owner's columns span
+    // (the base-pair rows exist for series of at most 12 steps per chunk: the 16-step helpers keep reading the tables)
+    static constexpr bool ANY = (CoopShape<KP, NW, 12, HARM>::RES && CoopShape<KP, NW, 12, HARM>::OWNER_COLS) || CoopShape<KP, NW, COOP_NTB, 0>::RES;
+    static constexpr int OC = ANY ? CoopShape<KP, NW, 12, 0>::CPW_RES : 1;
+    static constexpr int ONT = CoopShape<KP, NW, COOP_NTB, 0>::RES ? COOP_NTB : 12;     // steps the owner's columns span
 };
 
-template <int KP, int GROWTH, int MODE, int PPL, int NW, bool XIDX>
+template <int KP, int GROWTH, int MODE, int PPL, int NW, bool XIDX, int HARM = 0>
 __device__ __forceinline__ bool coop_eval_owner(const DevSpec *__restrict__ sp, SeriesView &sv,
                                                 CoopLds<KP, PPL> &cl, double *rbR, double *rbU, double *rbV,
                                                 const double (&th)[PPL], double &f_out, double (&g)[PPL],
-                                                bool res CT_ARGS)
+                                                bool res, const double *xol CT_ARGS)
 {
-    constexpr int OC = CoopOwnerCols<KP, NW>::OC, ONT = CoopOwnerCols<KP, NW>::ONT;
+    constexpr int OC = CoopOwnerCols<KP, NW, HARM>::OC, ONT = CoopOwnerCols<KP, NW, HARM>::ONT;
+    constexpr int OWN_L = CoopShape<KP, NW, 12, HARM>::OWN_L;      // columns the owner sums from its LDS copy xol[q][c][lane]
     const int lane = lane_id();
     const int S = sv.S, T = sv.T, K = sp->K;
     const int Ka = (MODE == 0) ? K : (MODE == 1 ? 0 : sp->Ka);
@@ -647,6 +771,32 @@ __device__ __forceinline__ bool coop_eval_owner(const DevSpec *__restrict__ sp, 
     if (lane == 0) cl.cmd = COOP_EVAL;
     CT_LAP(1);
     lds_barrier();                                          // A: theta is out
+    // Nothing the owner forms is needed before barrier B (1 / sigma^2: the trend wave, after B), so it passes A2 at once --
+    // the row waves' chains and the trend wave's segment tables decide when A2 happens (measured: with its arithmetic
+    // between A and A2 the owner arrived last, 2.7 k cycles after A) -- and does its own work (sigma terms, the two prior
+    // sums, the prior terms of the gradient) while the rows run.  Its share of the design columns (table variant: column 0,
+    // NW-1, ...) is requested before A2, every evaluation -- the loads stay in flight across the barrier and arrive during
+    // the rows; requested after A2 they made the owner the last at B -- instead of holding ~100 registers across the
+    // whole optimiser loop.
+    double xo[OC][ONT];
+#pragma unroll
+    for (int u = 0; u < OC; ++u) {
+        int j = u * (NW - 1);
+        j = j < K ? j : 0;
+#pragma unroll
+        for (int q = 0; q < ONT; ++q) {
+            const int qc = q < sv.NT ? q : 0;
+            double xv = 0.0;
+            if (res) {
+                if (XIDX) xv = (qc < sv.cnt) ? sv.Xu[(size_t)sv.uw[qc * W + lane] * KP + j] : 0.0;
+                else xv = (sv.Xw + ((size_t)qc * KP + j) * W)[lane];
+            }
+            xo[u][q] = xv;
+        }
+    }
+    CT_LAP(8);
+    lds_barrier();                                          // A2
+    CT_LAP(9);
     // while the trend wave walks the changepoint recurrences and the row waves their X.beta chains:
     // sigma terms and the two prior sums (eval_tail's first block)
     const double k = theta_at<PPL>(th, 0), m = theta_at<PPL>(th, 1), ls = theta_at<PPL>(th, 2);
@@ -667,29 +817,50 @@ __device__ __forceinline__ bool coop_eval_owner(const DevSpec *__restrict__ sp, 
     f = f + 2.0 * s2;
     f = f + 0.5 * sb;
     f = f + (double)T * ls;
-    // the owner's share of the design columns (resident mode of the helpers: column 0, NW-1, ...): it
-    // waits out the phases anyway, so it requests them here, every evaluation (they arrive during phase
-    // A), instead of holding ~100 registers across the whole optimiser loop
-    double xo[OC][ONT];
+    // the prior terms of the gradient (divisions by constants): formed here, while the rows run, instead of in the tail
+    double gpr[PPL];
 #pragma unroll
-    for (int u = 0; u < OC; ++u) {
-        int j = u * (NW - 1);
-        j = j < K ? j : 0;
-#pragma unroll
-        for (int q = 0; q < ONT; ++q) {
-            const int qc = q < sv.NT ? q : 0;
-            double xv = 0.0;
-            if (res) {
-                if (XIDX) xv = (qc < sv.cnt) ? sv.Xu[(size_t)sv.uw[qc * W + lane] * KP + j] : 0.0;
-                else xv = (sv.Xw + ((size_t)qc * KP + j) * W)[lane];
-            }
-            xo[u][q] = xv;
+    for (int s = 0; s < PPL; ++s) {
+        const int p = lane + s * W;
+        double gv = 0.0;
+        if (p == 0) gv = k / 25.0;
+        else if (p == 1) gv = m / 25.0;
+        else if (p == 2) gv = 4.0 * s2;
+        else if (p < 3 + S) {
+            const double dj = th[s];
+            const double sgn = (double)((dj > 0.0) - (dj < 0.0));
+            gv = sgn / sv.tau;
+        } else if (p < sv.P) {
+            const double pr = sv.prior_l[s];
+            gv = th[s] / (pr * pr);
         }
+        gpr[s] = gv;
     }
-    lds_barrier();                                          // A2
+    CT_LAP(10);
     lds_barrier();                                          // B: rows complete
     CT_LAP(2);
     const double sse_t = coop_sse(sv, rbR);
+    if constexpr (OWN_L > 0) {
+        if (xol) {
+            // base-pair rows: the columns behind the row waves' 24, from the owner's LDS copy (coop_owner), as coop_helper_pf sums its own
+            const double *ru = (MODE == 0) ? rbR : rbU;
+            double acc[OWN_L];
+#pragma unroll
+            for (int c = 0; c < OWN_L; ++c) acc[c] = 0.0;
+#pragma unroll
+            for (int q = 11; q >= 0; --q) {
+                const double rv = ru[q * W + lane];         // (zero rows beyond NT)
+#pragma unroll
+                for (int c = 0; c < OWN_L; ++c) acc[c] = __builtin_fma(xol[(q * OWN_L + c) * W + lane], rv, acc[c]);
+            }
+#pragma unroll
+            for (int c = 0; c < OWN_L; ++c) {
+                const int j = KP - OWN_L + c;
+                const double sacc = chunk_sum_1(acc[c]);
+                if (j < K && lane == 0) lds.accR[j] = sacc;
+            }
+        }
+    }
     if (res) {
         // the owner's share of the design columns (resident mode), as in coop_helper_pf
         double acc[OC];
@@ -723,18 +894,11 @@ __device__ __forceinline__ bool coop_eval_owner(const DevSpec *__restrict__ sp, 
     for (int s = 0; s < PPL; ++s) {
         const int p = lane + s * W;
         double gv = 0.0;
-        if (p == 0) gv = cl.gtr[0] + k / 25.0;
-        else if (p == 1) gv = cl.gtr[1] + m / 25.0;
-        else if (p == 2) gv = ((double)T - sse_t * inv_s2) + 4.0 * s2;
-        else if (p < 3 + S) {
-            const double dj = th[s];
-            const double sgn = (double)((dj > 0.0) - (dj < 0.0));
-            gv = cl.gtr[p] + sgn / sv.tau;
-        } else if (p < sv.P) {
-            const int j = p - 3 - S;
-            const double pr = sv.prior_l[s];
-            gv = nis * lds.accR[j] + th[s] / (pr * pr);
-        }
+        if (p == 0) gv = cl.gtr[0] + gpr[s];
+        else if (p == 1) gv = cl.gtr[1] + gpr[s];
+        else if (p == 2) gv = ((double)T - sse_t * inv_s2) + gpr[s];
+        else if (p < 3 + S) gv = cl.gtr[p] + gpr[s];
+        else if (p < sv.P) gv = nis * lds.accR[p - 3 - S] + gpr[s];
         g[s] = gv;
         bad = bad || !finite_f64(gv);
     }
@@ -748,9 +912,9 @@ __device__ __forceinline__ bool coop_eval_owner(const DevSpec *__restrict__ sp, 
 // (Stan's BFGSMinimizer<LBFGSUpdate>::step / WolfeLineSearch / WolfLSZoom as restated in fit_kernel;
 // the text below is that loop with the state restored from the checkpoint and eval_fg replaced by
 // coop_eval_owner -- keep the two in step.)
-template <int KP, int GROWTH, int MODE, int PPL, int NW, bool XIDX>
+template <int KP, int GROWTH, int MODE, int PPL, int NW, bool XIDX, int HARM = 0>
 __device__ __forceinline__ void coop_owner(const FitArgs &a, SeriesView &sv, int64_t n, const double *slot,
-                                           CoopLds<KP, PPL> &cl, double *rbR, double *rbU, double *rbV)
+                                           CoopLds<KP, PPL> &cl, double *rbR, double *rbU, double *rbV, double *xl = nullptr)
 {
     const int lane = lane_id();
     const DevSpec *sp = a.sp;
@@ -805,7 +969,26 @@ __device__ __forceinline__ void coop_owner(const FitArgs &a, SeriesView &sv, int
     sv.n_eval = cv.n_eval;
 
     // resident mode (as the helpers decide it, fit_coop_kernel): the owner then has a share of the columns
-    const bool res = sv.NT <= COOP_NTB && (a.NTmax > 12 ? CoopShape<KP, NW, COOP_NTB>::RES : CoopShape<KP, NW, 12>::RES);
+    // (base-pair rows, series of <= 12 steps: the row waves take every column, the owner none)
+    const bool res = sv.NT <= COOP_NTB && (a.NTmax > 12 ? CoopShape<KP, NW, COOP_NTB, 0>::RES
+                                                       : (CoopShape<KP, NW, 12, HARM>::RES && CoopShape<KP, NW, 12, HARM>::OWNER_COLS));
+
+    // base-pair rows (series of <= 12 steps): the owner's columns, once per series, into the LDS region the table variant
+    // stages row values in -- [step][column][lane]; rows a chunk does not have and columns beyond K are zeros in Xw
+    const double *xol = nullptr;
+    if constexpr (CoopShape<KP, NW, 12, HARM>::OWN_L > 0) {
+        constexpr int OWN_L = CoopShape<KP, NW, 12, HARM>::OWN_L;
+        if (xl && a.NTmax <= 12) {
+            for (int q = 0; q < 12; ++q) {
+                const int qc = q < sv.NT ? q : 0;
+#pragma unroll
+                for (int c = 0; c < OWN_L; ++c)
+                    xl[(q * OWN_L + c) * W + lane] = (q < sv.NT) ? (sv.Xw + ((size_t)qc * KP + (KP - OWN_L + c)) * W)[lane] : 0.0;
+            }
+            TSF_WAVE_SYNC();
+            xol = xl;
+        }
+    }
 
     enum { ST_INIT = 0, ST_START_ITER, ST_START_LS, ST_LS_PRE, ST_LS_EVAL };
     int stage = scratch ? ST_INIT : ST_LS_EVAL;
@@ -869,7 +1052,7 @@ __device__ __forceinline__ void coop_owner(const FitArgs &a, SeriesView &sv, int
             }
             double f1;
             CT_LAP(0);
-            const bool bad = coop_eval_owner<KP, GROWTH, MODE, PPL, NW, XIDX>(sp, sv, cl, rbR, rbU, rbV, xk1, f1, gk1, res CT_PASS);
+            const bool bad = coop_eval_owner<KP, GROWTH, MODE, PPL, NW, XIDX, HARM>(sp, sv, cl, rbR, rbU, rbV, xk1, f1, gk1, res, xol CT_PASS);
             f1 = uniform_f64(f1);
             if (stage == ST_INIT) {         // (direct mode only) the initial point
                 if (bad) { ret = TSF_ST_INIT_NONFINITE; fk = f1; break; }
@@ -890,6 +1073,7 @@ __device__ __forceinline__ void coop_owner(const FitArgs &a, SeriesView &sv, int
                 if (!ls_fail) continue;            // re-evaluate at the shortened step
             }
             if (!ls_fail) {
+                CT_LAP(0);
                 const double newDFp = pdot<PPL>(gk1, pk);
                 bool ls_ok = false;
                 if (!zoom) {
@@ -917,6 +1101,7 @@ __device__ __forceinline__ void coop_owner(const FitArgs &a, SeriesView &sv, int
                         alo = alpha; aloF = f1; aloDFp = newDFp;
                     }
                 }
+                CT_LAP(6);
                 if (!ls_ok) { stage = ST_LS_PRE; continue; }
                 fk1 = f1;
                 // ---- accepted step: k becomes the most recent iterate ----
@@ -952,8 +1137,8 @@ __device__ __forceinline__ void coop_owner(const FitArgs &a, SeriesView &sv, int
                 const double rho_new = readlane_f64(qv, 2);
                 {
                     int hs;
-                    if (hist_len < H) { hs = (hist_head + hist_len) % H; hist_len++; }
-                    else { hs = hist_head; hist_head = (hist_head + 1) % H; }
+                    if (hist_len < H) { hs = hist_head + hist_len; if (hs >= H) hs -= H; hist_len++; }
+                    else { hs = hist_head; hist_head = hist_head + 1; if (hist_head >= H) hist_head -= H; }
                     if (lane == 0) lds.rho[hs] = rho_new;
 #pragma unroll
                     for (int s = 0; s < PPL; ++s) {
@@ -964,33 +1149,56 @@ __device__ __forceinline__ void coop_owner(const FitArgs &a, SeriesView &sv, int
                 TSF_WAVE_SYNC();
 #pragma unroll
                 for (int s = 0; s < PPL; ++s) pk[s] = -gk[s];
-                for (int h = hist_len - 1; h >= 0; --h) {
-                    const int hs = (hist_head + h) % H;
-                    double si[PPL], yi[PPL];
+                // (the pair of the NEXT step is requested before the dot product of this one -- its LDS round trip was on the
+                // chain ten times per iteration --, and the ring index wraps by comparison: `% H` with a run-time H is an
+                // integer division, twenty per iteration)
+                auto hist_load = [&](int hs_, double (&s_)[PPL], double (&y_)[PPL], double &r_) {
 #pragma unroll
                     for (int s = 0; s < PPL; ++s) {
-                        si[s] = lds.SY[((2 * hs) * PPL + s) * W + lane];
-                        yi[s] = lds.SY[((2 * hs + 1) * PPL + s) * W + lane];
+                        s_[s] = lds.SY[((2 * hs_) * PPL + s) * W + lane];
+                        y_[s] = lds.SY[((2 * hs_ + 1) * PPL + s) * W + lane];
                     }
-                    const double aa = lane63(lds.rho[hs] * pdot_l63<PPL>(si, pk));
+                    r_ = lds.rho[hs_];
+                };
+                if (hist_len > 0) {
+                    double si[PPL], yi[PPL], rh;
+                    int hs = hist_head + hist_len - 1;
+                    if (hs >= H) hs -= H;
+                    hist_load(hs, si, yi, rh);
+                    for (int h = hist_len - 1; h >= 0; --h) {
+                        double sn[PPL], yn[PPL], rhn = 0.0;
+                        int hsn = hs - 1;
+                        if (hsn < 0) hsn += H;
+                        if (h > 0) hist_load(hsn, sn, yn, rhn);
+                        const double aa = lane63(rh * pdot_l63<PPL>(si, pk));
 #pragma unroll
-                    for (int s = 0; s < PPL; ++s) pk[s] = __builtin_fma(-aa, yi[s], pk[s]);
-                    if (lane == 0) lds.alphas[h] = aa;
+                        for (int s = 0; s < PPL; ++s) pk[s] = __builtin_fma(-aa, yi[s], pk[s]);
+                        if (lane == 0) lds.alphas[h] = aa;
+#pragma unroll
+                        for (int s = 0; s < PPL; ++s) { si[s] = sn[s]; yi[s] = yn[s]; }
+                        rh = rhn; hs = hsn;
+                    }
                 }
                 TSF_WAVE_SYNC();
 #pragma unroll
                 for (int s = 0; s < PPL; ++s) pk[s] = pk[s] * gammak;
-                for (int h = 0; h < hist_len; ++h) {
-                    const int hs = (hist_head + h) % H;
-                    double si[PPL], yi[PPL];
+                if (hist_len > 0) {
+                    double si[PPL], yi[PPL], rh;
+                    int hs = hist_head;
+                    hist_load(hs, si, yi, rh);
+                    double al = lds.alphas[0];
+                    for (int h = 0; h < hist_len; ++h) {
+                        double sn[PPL], yn[PPL], rhn = 0.0, aln = 0.0;
+                        int hsn = hs + 1;
+                        if (hsn >= H) hsn -= H;
+                        if (h + 1 < hist_len) { hist_load(hsn, sn, yn, rhn); aln = lds.alphas[h + 1]; }
+                        const double cc = lane63(al - rh * pdot_l63<PPL>(yi, pk));
 #pragma unroll
-                    for (int s = 0; s < PPL; ++s) {
-                        si[s] = lds.SY[((2 * hs) * PPL + s) * W + lane];
-                        yi[s] = lds.SY[((2 * hs + 1) * PPL + s) * W + lane];
+                        for (int s = 0; s < PPL; ++s) pk[s] = __builtin_fma(cc, si[s], pk[s]);
+#pragma unroll
+                        for (int s = 0; s < PPL; ++s) { si[s] = sn[s]; yi[s] = yn[s]; }
+                        rh = rhn; al = aln; hs = hsn;
                     }
-                    const double cc = lane63(lds.alphas[h] - lds.rho[hs] * pdot_l63<PPL>(yi, pk));
-#pragma unroll
-                    for (int s = 0; s < PPL; ++s) pk[s] = __builtin_fma(cc, si[s], pk[s]);
                 }
                 TSF_WAVE_SYNC();
                 const double dF = __builtin_fabs(fk1 - fk);
@@ -1005,6 +1213,7 @@ __device__ __forceinline__ void coop_owner(const FitArgs &a, SeriesView &sv, int
                 else if (stepNorm < a.opt.tol_param) ret = TSF_ST_ABSX;
                 else if (itNum >= a.opt.max_iter) ret = TSF_ST_MAXIT;
                 else ret = 0;
+                CT_LAP(5);
                 if (ret != 0) break;
                 stage = ST_START_ITER;
                 continue;
@@ -1045,7 +1254,7 @@ __device__ __forceinline__ void coop_report_unfitted(const FitArgs &a, const Ser
 }
 
 // ---- the kernel: persistent workgroups over the checkpoint list ---------------------------------
-template <int KP, int GROWTH, int MODE, int PPL, int NW, bool XIDX>
+template <int KP, int GROWTH, int MODE, int PPL, int NW, bool XIDX, int HARM = 0>
 __global__ __launch_bounds__(NW * 64) void fit_coop_kernel(FitArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1083,19 +1292,20 @@ __global__ __launch_bounds__(NW * 64) void fit_coop_kernel(FitArgs a)
             for (int i = sv.NT * W + (int)threadIdx.x; i < COOP_NTB * W; i += NW * W) { rbR[i] = 0.0; rbU[i] = 0.0; rbV[i] = 0.0; }
         }
 #ifdef TSF_COOP_TIMING
-        if (threadIdx.x == 0) cl.dbg = a.grad_out ? (long long *)a.grad_out + (size_t)n * 16 : nullptr;
+        if (threadIdx.x == 0) cl.dbg = a.grad_out ? (long long *)a.grad_out + (size_t)n * 64 : nullptr;
 #endif
         if (wid == 0) {
             for (int i = lane_id(); i < TSF_MAX_P + W; i += W) cl.w.th[i] = 0.0;
             TSF_WAVE_SYNC();
-            coop_owner<KP, GROWTH, MODE, PPL, NW, XIDX>(a, sv, n, direct ? nullptr : a.coop_slots + (size_t)item * a.coop_stride,
-                                                        cl, rbR, rbU, rbV);
+            coop_owner<KP, GROWTH, MODE, PPL, NW, XIDX, HARM>(a, sv, n, direct ? nullptr : a.coop_slots + (size_t)item * a.coop_stride,
+                                                              cl, rbR, rbU, rbV,
+                                                              coop_xl_bytes(KP, a.NTmax) > 0 ? rbV + (size_t)COOP_NTB * W : nullptr);
         } else if (sv.NT > COOP_NTB) {
             coop_helper<KP, GROWTH, MODE, PPL, NW, XIDX>(a.sp, sv, cl, rbR, rbU, rbV, wid);
         } else if (a.NTmax > 12) {      // (the call's longest series decides: the LDS of the 12-step variant is sized by it)
-            coop_helper_ntb<KP, GROWTH, MODE, PPL, NW, XIDX, COOP_NTB>(a.sp, sv, cl, rbR, rbU, rbV, wid);
+            coop_helper_ntb<KP, GROWTH, MODE, PPL, NW, XIDX, COOP_NTB, 0>(a.sp, sv, cl, rbR, rbU, rbV, wid);
         } else {
-            coop_helper_ntb<KP, GROWTH, MODE, PPL, NW, XIDX, 12>(a.sp, sv, cl, rbR, rbU, rbV, wid);
+            coop_helper_ntb<KP, GROWTH, MODE, PPL, NW, XIDX, 12, HARM>(a.sp, sv, cl, rbR, rbU, rbV, wid);
         }
     }
 }

@@ -232,16 +232,31 @@ __device__ __forceinline__ void segment_tables(const SeriesView &sv, L &lds, con
 // (t_c - mc[c]), the two adjustments of D1 lane-parallel, and the slope gradient's running sums as one suffix scan.
 // Out (without the factor -1/sigma^2): gk_raw = sum of all adjusted D1, gm_raw = abar[0], and in lane 3 + j the running
 // sum that belongs to delta_j.  Reads lds.tot1 / tot2 / tp1 / tp2 / ks / mc; no scratch.
+// The part of the reverse sweep that depends on the segment tables alone (ks, mc): the three quotients and the lane's
+// segment values.  A kernel whose trend wave waits for the rows (fit_coop_kernel) forms them while it waits; same
+// operations on the same operands as when they were formed inside the sweep.
+struct LogisticReversePre { double ks_c, mc_c, fa, q1, q2, tdm; };
 template <class L>
-__device__ __forceinline__ void logistic_reverse_lanes(const SeriesView &sv, L &lds, double TA, double TB,
-                                                       double &gk_raw, double &gm_raw, double &gd_l)
+__device__ __forceinline__ void logistic_reverse_pre(const SeriesView &sv, const L &lds, LogisticReversePre &o)
 {
     const int lane = (int)threadIdx.x & (W - 1);
     const int S = sv.S, c = lane;
     const bool seg = c <= S;
     const int cc = seg ? c : S;                             // (lanes past S read in-range entries and are masked)
-    const double ks_c = lds.ks[cc], mc_c = lds.mc[cc];
+    o.ks_c = lds.ks[cc]; o.mc_c = lds.mc[cc];
     const double ks_n = lds.ks[cc < S ? cc + 1 : S], ks_p = lds.ks[cc > 0 ? cc - 1 : 0];
+    o.fa = (c < S) ? o.ks_c / ks_n : (c == S ? 0.0 : 1.0);
+    o.q1 = -1.0 / ks_n;
+    o.q2 = (ks_p / o.ks_c) / o.ks_c;
+    o.tdm = sv.tc_l - o.mc_c;
+}
+template <class L>
+__device__ __forceinline__ void logistic_reverse_post(const SeriesView &sv, L &lds, const LogisticReversePre &pr, double TA, double TB,
+                                                      double &gk_raw, double &gm_raw, double &gd_l)
+{
+    const int lane = (int)threadIdx.x & (W - 1);
+    const int S = sv.S, c = lane;
+    const bool seg = c <= S;
     double D1 = 0.0, D2 = 0.0;
     if (seg) {
         const int Ljm = (c > 0) ? sv.Ljm1_l : 0, Ljc = (c < S) ? sv.Lj_l : 0;
@@ -250,21 +265,29 @@ __device__ __forceinline__ void logistic_reverse_lanes(const SeriesView &sv, L &
         const double loA = (c == S) ? 0.0 : lds.tp1[c] + lds.tot1[Ljc + 1];
         const double loB = (c == S) ? 0.0 : lds.tp2[c] + lds.tot2[Ljc + 1];
         const double A = hiA - loA, B = hiB - loB;
-        D1 = A - mc_c * B;
-        D2 = -(ks_c * B);
+        D1 = A - pr.mc_c * B;
+        D2 = -(pr.ks_c * B);
     }
-    double fa = (c < S) ? ks_c / ks_n : (c == S ? 0.0 : 1.0), fb = seg ? D2 : 0.0;
+    double fa = pr.fa, fb = seg ? D2 : 0.0;
     affine_suffix_scan(fa, fb);                             // fb: abar[c]
     const double ab_next = dpp_mov<DPP_WAVE_SHL1>(fb);      // abar[c + 1]
-    const double rb = (c < S) ? ab_next * (sv.tc_l - mc_c) : 0.0;
+    const double rb = (c < S) ? ab_next * pr.tdm : 0.0;
     const double rb_prev = dpp_mov<DPP_WAVE_SHR1>(rb);      // rb[c - 1]
     double d = D1;
-    if (c < S) d = d + rb * (-1.0 / ks_n);
-    if (c >= 1 && seg) d = d + rb_prev * ((ks_p / ks_c) / ks_c);
+    if (c < S) d = d + rb * pr.q1;
+    if (c >= 1 && seg) d = d + rb_prev * pr.q2;
     const double ss = suffix_scan(seg ? d : 0.0);
     gk_raw = readlane_f64(ss, 0);
     gm_raw = readlane_f64(fb, 0);
     gd_l = dpp_mov<DPP_WAVE_SHR1>(dpp_mov<DPP_WAVE_SHR1>(ss));      // lane 3 + j: ss[j + 1]
+}
+template <class L>
+__device__ __forceinline__ void logistic_reverse_lanes(const SeriesView &sv, L &lds, double TA, double TB,
+                                                       double &gk_raw, double &gm_raw, double &gd_l)
+{
+    LogisticReversePre pr;
+    logistic_reverse_pre(sv, lds, pr);
+    logistic_reverse_post(sv, lds, pr, TA, TB, gk_raw, gm_raw, gd_l);
 }
 
 // f and the gradient from the time-axis sums of one evaluation: lds.tot1 / tot2 (suffix sums of the
@@ -734,6 +757,7 @@ struct FitArgs {
     // base pairs of the Fourier columns (setup_grid_kernel; fit_kernel<..., HARM>): [grid][NTmax][bw_ns][64][2]
     const double *Bw;
     int bw_ns, harm;                    // seasonalities per row of Bw; the model's harmonic structure (harm_code), 0 = none compiled
+    int coop_harm;                      // the cooperative kernel's rows from the base pairs too (harm != 0 and no dense column behind the Fourier block)
     const int32_t *uw;                  // [grid][NTmax][64] lattice row of each series row
     const double *Xu;                   // [U][KP]
     int xidx;
@@ -1145,8 +1169,9 @@ __global__ __launch_bounds__(64, HARM != 0 ? (SPARSE ? TSF_HARM_SPARSE_WPS : TSF
                 const double rho_new = readlane_f64(qv, 2);
                 {
                     int slot;
-                    if (hist_len < H) { slot = (hist_head + hist_len) % H; hist_len++; }
-                    else { slot = hist_head; hist_head = (hist_head + 1) % H; }
+                    // (ring indices wrap by comparison: `% H` with a run-time H is an integer division)
+                    if (hist_len < H) { slot = hist_head + hist_len; if (slot >= H) slot -= H; hist_len++; }
+                    else { slot = hist_head; hist_head = hist_head + 1; if (hist_head >= H) hist_head -= H; }
                     if (lane == 0) lds.rho[slot] = rho_new;
 #pragma unroll
                     for (int s = 0; s < PPL; ++s) {
@@ -1158,7 +1183,8 @@ __global__ __launch_bounds__(64, HARM != 0 ? (SPARSE ? TSF_HARM_SPARSE_WPS : TSF
 #pragma unroll
                 for (int s = 0; s < PPL; ++s) pk[s] = -gk[s];
                 for (int h = hist_len - 1; h >= 0; --h) {
-                    const int slot = (hist_head + h) % H;
+                    int slot = hist_head + h;
+                    if (slot >= H) slot -= H;
                     double si[PPL], yi[PPL];
 #pragma unroll
                     for (int s = 0; s < PPL; ++s) {
@@ -1174,7 +1200,8 @@ __global__ __launch_bounds__(64, HARM != 0 ? (SPARSE ? TSF_HARM_SPARSE_WPS : TSF
 #pragma unroll
                 for (int s = 0; s < PPL; ++s) pk[s] = pk[s] * gammak;
                 for (int h = 0; h < hist_len; ++h) {
-                    const int slot = (hist_head + h) % H;
+                    int slot = hist_head + h;
+                    if (slot >= H) slot -= H;
                     double si[PPL], yi[PPL];
 #pragma unroll
                     for (int s = 0; s < PPL; ++s) {
