@@ -564,6 +564,10 @@ __device__ __forceinline__ void coop_helper_pf(const DevSpec *__restrict__ sp, c
     double xw[(ROWS && NXB == 2) ? 3 : 1][XB];          // KP = 64: rotating half-row buffers
     for (;;) {
         int z = 0;
+        // (an opaque zero per evaluation in the LDS addresses of the wave's columns: loop-invariant, the 24 addresses were
+        // hoisted out of the evaluation loop into registers, spilled, and each read then waited for a scratch round trip)
+        int zl = 0;
+        if constexpr (CL > 0) asm volatile("v_mov_b32 %0, 0" : "=v"(zl));
         if constexpr (!RES) {
             asm volatile("s_mov_b32 %0, 0" : "=s"(z));
             if constexpr (ROWS && NXB == 1) {
@@ -626,7 +630,7 @@ __device__ __forceinline__ void coop_helper_pf(const DevSpec *__restrict__ sp, c
                     gtr = __builtin_fma(ksc, tq[i], mcc);
                 } else {
                     const double z2 = ksc * (tq[i] - mcc);
-                    const double e = dm_exp_sel(-z2);
+                    const double e = dm_exp_sel(-z2);          // (dm_exp_sel_sc, literals as scalar operands: measured, 5.05 -> 5.3 us per evaluation)
                     const double sg = 1.0 / (1.0 + e);
                     gtr = sv.cap * sg;
                     qv = gtr * (1.0 - sg);
@@ -686,6 +690,7 @@ __device__ __forceinline__ void coop_helper_pf(const DevSpec *__restrict__ sp, c
             HX_LAP(7);
         }
         if constexpr (COLS) {
+            const double *const xcb_l = xcl + lane + zl;        // (one base per evaluation; the reads below differ by immediates)
             auto col_batch = [&](int b, const double (&xcb)[CB][NTB]) {
                 double acc[CB];
 #pragma unroll
@@ -699,7 +704,7 @@ __device__ __forceinline__ void coop_helper_pf(const DevSpec *__restrict__ sp, c
                     for (int u = 0; u < CB; ++u) {
                         const int j = cw0 + (b * CB + u) * NCW;
                         const double ru = (MODE == 0) ? r0 : (MODE == 1 ? r1 : (j < Ka ? r0 : r1));
-                        const double xv = (CL > 0 && u >= CBR) ? xcl[((u - CBR < 0 ? 0 : u - CBR) * NTB + q) * W + lane] : xcb[u][q];
+                        const double xv = (CL > 0 && u >= CBR) ? xcb_l[((u - CBR < 0 ? 0 : u - CBR) * NTB + q) * W] : xcb[u][q];
                         acc[u] = __builtin_fma(xv, ru, acc[u]);
                     }
                 }
@@ -739,6 +744,9 @@ __device__ __forceinline__ void coop_helper_ntb(const DevSpec *__restrict__ sp, 
                                                 CoopLds<KP, PPL> &cl, double *rbR, double *rbU, double *rbV, int wid)
 {
     double *xl = rbV + (size_t)COOP_NTB * W;            // (present when coop_xl_bytes() > 0: NTmax <= 12 < COOP_NTB rows of row buffers)
+    // issue priority: the trend wave's chains (segment tables in phase A; running sums, scans and the reverse sweep in
+    // phase B) are the longest of both phases and it shares its SIMD with a row wave (measured: 5.3 -> 5.05 us per evaluation)
+    if (wid == NW - 1) __builtin_amdgcn_s_setprio(3);
     if (wid == NW - 1) coop_helper_pf<KP, GROWTH, MODE, PPL, NW, XIDX, NTB, true, HARM>(sp, sv, cl, rbR, rbU, rbV, xl, wid);
     else coop_helper_pf<KP, GROWTH, MODE, PPL, NW, XIDX, NTB, false, HARM>(sp, sv, cl, rbR, rbU, rbV, xl, wid);
 }

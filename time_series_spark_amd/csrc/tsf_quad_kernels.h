@@ -367,54 +367,7 @@ __device__ __forceinline__ void quad_const_table(double *ct, const LbfgsOpts &op
 // MEASURED (round 4, static: tools/dev/isa_mix.sh) and NOT enabled: the asm statements pin the schedule of the
 // evaluation, the 12- and 16-wave kernels then spill ~49 registers per lane to scratch and issue MORE vector
 // instructions per evaluation (371 against 339 in the trial loop), not fewer.  Kept behind TSF_QUAD_EXPSC.
-__device__ __forceinline__ double fma_vvs(double a, double b, double c_scalar)
-{
-    double r;
-    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c_scalar));
-    return r;
-}
-__device__ __forceinline__ double fma_vsv(double a, double b_scalar, double c)
-{
-    double r;
-    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b_scalar), "v"(c));
-    return r;
-}
-__device__ __forceinline__ double mul_vs(double a, double b_scalar)
-{
-    double r;
-    asm("v_mul_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(b_scalar));
-    return r;
-}
-
-// dm_exp_sel (tsf_detmath.h) with its literals as scalar operands: the same operations on the same values
-__device__ __forceinline__ double dm_exp_sel_sc(double x)
-{
-    const double n = __builtin_rint(mul_vs(x, 1.4426950408889634));
-    double r = fma_vsv(-n, 6.93147180369123816490e-01, x);
-    r = fma_vsv(-n, 1.90821492927058770002e-10, r);
-    double p = 1.6059043836821613e-10;
-    p = fma_vvs(p, r, 2.08767569878681e-09);
-    p = fma_vvs(p, r, 2.505210838544172e-08);
-    p = fma_vvs(p, r, 2.755731922398589e-07);
-    p = fma_vvs(p, r, 2.7557319223985893e-06);
-    p = fma_vvs(p, r, 2.48015873015873e-05);
-    p = fma_vvs(p, r, 1.984126984126984e-04);
-    p = fma_vvs(p, r, 1.388888888888889e-03);
-    p = fma_vvs(p, r, 8.333333333333333e-03);
-    p = fma_vvs(p, r, 4.1666666666666664e-02);
-    p = fma_vvs(p, r, 1.6666666666666666e-01);
-    p = __builtin_fma(p, r, 0.5);
-    p = __builtin_fma(p, r, 1.0);
-    p = __builtin_fma(p, r, 1.0);
-    const bool in_range = (x <= 709.782712893384) && (x >= -745.2);
-    const int ni = in_range ? (int)n : 0;
-    const int n1 = ni / 2, n2 = ni - n1;
-    double e = (p * dm_pow2i(n1)) * dm_pow2i(n2);
-    if (x > 709.782712893384) e = __builtin_huge_val();
-    if (x < -745.2) e = 0.0;
-    if (x != x) e = x;
-    return e;
-}
+// (fma_vvs / fma_vsv / mul_vs and dm_exp_sel_sc: tsf_detmath.h)
 
 // dm_exp_sel (tsf_detmath.h) with its constants read from the table: the same operations on the same values
 __device__ __forceinline__ double dm_exp_sel_tab(double x, const double *ct)
