@@ -617,6 +617,26 @@ def test_sparse_indicator_columns_equal_dense_columns(env):
         rr = both(spec, lambda: fc.fit_ragged(spec, off, dsr, yr, floor=floor, cap=cap, extra=exr))
         for n in (0, 7):                 # full-length members of the ragged call = the aligned fit
             assert np.array_equal(rr.theta[n], r.theta[n]) and rr.n_eval[n] == r.n_eval[n], (case, n)
+    # the TAIL of the sparse kernel (round 5): fits handed over after 64 evaluations run the cooperative kernel on base-pair
+    # rows and sparse entries (fit_coop_kernel<28, ..., HARM, SPARSE>) -- against the 64-column streaming tail behind the
+    # same sparse fit kernel (option sparse_extra = 2), the dense route and the oracle
+    spec, ds, y, floor, cap, extra, fut, exf = helpers.make_case('cfg4_holidays', N=48, seed=5)
+    spec_t = type(spec).from_dict(dict(spec.to_dict(), lbfgs=dict(spec.lbfgs, coop_after=64)))
+    res = {}
+    for tag, opt in (('sparse_tail', -1), ('dense_tail', 2), ('dense', 0)):
+        with fc.get_context().options(sparse_extra=opt):
+            res[tag] = fc.fit_aligned(spec_t, ds, y, floor=floor, cap=cap, extra=extra)
+            assert _used_sparse_columns(fc) == (tag != 'dense'), tag
+    for tag in ('dense_tail', 'dense'):
+        for name in ('theta', 'fval', 'n_iter', 'n_eval', 'status', 'y_scale'):
+            assert np.array_equal(getattr(res['sparse_tail'], name), getattr(res[tag], name), equal_nan=True), (tag, name)
+    r = res['sparse_tail']
+    assert (r.n_eval > 64).sum() >= 40           # (nearly every fit was finished by the tail)
+    csp = helpers.oracle_spec(spec)
+    for n in (0, 9, 33, int(np.argmax(r.n_eval))):
+        o = cl.fit(csp, ds, y[n], floor[n], cap[n], extra)
+        assert (r.n_iter[n], r.n_eval[n], r.status[n]) == (o['n_iter'], o['n_eval'], o['status']), n
+        assert n_bit_diff(r.theta[n][:len(o['theta'])], o['theta']) == 0 and n_bit_diff(r.fval[n], o['f']) == 0, n
     # longer series: the dense route is the workgroup kernel from the first evaluation (<= 4 096 rows) or the ungrouped
     # one-wave kernel (longer); the sparse route the same one-wave kernel with the cooperative tail
     for T_long, Nl in ((1095, 20), (4200, 4)):

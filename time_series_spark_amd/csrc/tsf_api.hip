@@ -625,6 +625,7 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     a.grid_of = grid_of;
     a.Bw = bw_ns ? (const double *)(ws + l.Bw) : nullptr; a.bw_ns = bw_ns; a.harm = harm;
     a.coop_harm = (harm != 0 && hs.K == harm_kf(harm) && mode != 2) ? 1 : 0;
+    a.opt_coop_sparse = ctx->opt[TSF_OPT_SPARSE_EXTRA] != 2 ? 1 : 0;     // (2: the sparse fit kernel with the 64-column tail, for A/B runs)
     ctx->last_sp_flag = nullptr;
     if (sparse_try) {
         a.sp_meta = (const uint32_t *)(ws + l.spm); a.sp_prog = (const unsigned long long *)(ws + l.spp);

@@ -40,6 +40,11 @@ struct CoopLds {
     // without its prior terms (trend wave -> owner: [0] d/dk, [1] d/dm, [3 + j] d/d delta_j)
     double inv_s2;
     double gtr[W];
+    // sparse indicator columns (fit_coop_kernel<..., SPARSE>; SP_* in tsf_common.h): the lanes' entry words, last row first
+    // (filled by the whole workgroup when it takes a series), the slots the rows write, the columns' fold programs
+    unsigned short sp_list[(SP_M + 1) * W];
+    double sp_acc[SP_MAXC * SP_E];
+    unsigned long long sp_prog[SP_MAXC];
 };
 enum { COOP_EVAL = 1, COOP_EXIT = 2 };
 #ifndef COOP_NW
@@ -52,6 +57,13 @@ enum { COOP_EVAL = 1, COOP_EXIT = 2 };
 __host__ __device__ constexpr size_t coop_xl_bytes(int KP, int NTmax) { return (KP == 28 && NTmax <= 12) ? sizeof(double) * 12 * 16 * W : 0; }
 // row buffers r, r g, v: [rows][64] each, rows = max(NTmax, COOP_NTB) (coop_rb_rows)
 __host__ __device__ constexpr int coop_rb_rows(int NTmax) { return NTmax > 16 ? NTmax : 16; }
+// fit_coop_kernel<SP_DENSE, ..., PPL, ..., HARM, SPARSE>: the 64-column model's LDS tables, 12 rows of row buffers, the
+// 28-column kernel's LDS columns
+template <int PPL>
+__host__ __device__ constexpr size_t coop_sparse_lds_bytes()
+{
+    return sizeof(CoopLds<64, PPL>) + sizeof(double) * 3 * 12 * W + coop_xl_bytes(SP_DENSE, 12);
+}
 template <int KP, int PPL>
 __host__ __device__ constexpr size_t coop_lds_bytes(int NTmax)
 {
@@ -407,10 +419,15 @@ struct CoopShape {
     static constexpr int CB = RES ? CPW : 3;                    // columns held at a time
     static constexpr int NCB = (CPW + CB - 1) / CB;
 };
-template <int KP, int GROWTH, int MODE, int PPL, int NW, bool XIDX, int NTB, bool TREND, int HARM = 0>
+// SPARSE (with HARM, 28-column registers on the 64-column model's tables: BASELINE cfg4's stragglers): the columns from
+// the 29th on are 0 / 1 indicators kept as entry words per lane (eval_fg<..., SPARSE>): a row adds the coefficients of its
+// ones to its chain and writes its r (or r g) into the slot of each; the owner folds the slots per column after barrier B.
+template <int KP, int GROWTH, int MODE, int PPL, int NW, bool XIDX, int NTB, bool TREND, int HARM = 0, bool SPARSE = false, class CLT>
 __device__ __forceinline__ void coop_helper_pf(const DevSpec *__restrict__ sp, const SeriesView &sv,
-                                               CoopLds<KP, PPL> &cl, double *rbR, double *rbU, double *rbV, double *xl, int wid)
+                                               CLT &cl, double *rbR, double *rbU, double *rbV, double *xl, int wid)
 {
+    constexpr int XC = SPARSE ? 64 : KP;                // columns per row of the design table
+    static_assert(!SPARSE || (HARM != 0 && KP == SP_DENSE && NTB == 12 && MODE != 2), "sparse columns: base-pair rows of the 28-column kernel");
 #ifdef TSF_COOP_TIMING
     long long ht_a = 0, ht_b = 0, ht_t = 0;     // busy cycles of this wave in phase A / phase B
     long long htx[8] = {0, 0, 0, 0, 0, 0, 0, 0}, htx_t = 0;    // finer laps of the same wave (dbg[16 ..] row wave 1, dbg[24 ..] trend wave)
@@ -506,7 +523,7 @@ __device__ __forceinline__ void coop_helper_pf(const DevSpec *__restrict__ sp, c
             for (int q = 0; q < NTB; ++q) {
                 const int qc = q < NT ? q : 0;
                 if (XIDX) xc[u][q] = (qc < sv.cnt) ? sv.Xu[(size_t)sv.uw[qc * W + lane] * KP + j] : 0.0;
-                else xc[u][q] = (sv.Xw + ((size_t)qc * KP + j) * W)[lane];
+                else xc[u][q] = (sv.Xw + ((size_t)qc * XC + j) * W)[lane];
             }
         }
     };
@@ -522,6 +539,23 @@ __device__ __forceinline__ void coop_helper_pf(const DevSpec *__restrict__ sp, c
             const double2 *bq = reinterpret_cast<const double2 *>(sv.Bw) + (size_t)qrow[i] * HNS * W + lane;
 #pragma unroll
             for (int se = 0; se < HNS; ++se) bpr[i][se] = bq[se * W];
+        }
+    }
+    // SPARSE: the dense columns between the Fourier block and the sparse ones (two of them), and where the lane's entry
+    // list holds the ones of each of the wave's rows (the list is sorted by row, last row first: a run per row)
+    constexpr int NXDS = SPARSE ? SP_DENSE - HKF : 1;
+    double xds[(ROWS && SPARSE) ? RPW : 1][NXDS];
+    int sp_e0[(ROWS && SPARSE) ? RPW : 1], sp_n[(ROWS && SPARSE) ? RPW : 1];
+    if constexpr (ROWS && SPARSE) {
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+#pragma unroll
+            for (int j = 0; j < NXDS; ++j) xds[i][j] = valid[i] ? (sv.Xw + ((size_t)qrow[i] * XC + HKF + j) * W)[lane] : 0.0;
+            sp_e0[i] = 0; sp_n[i] = 0;
+            for (int e = SP_M - 1; e >= 0; --e) {
+                const unsigned wd = cl.sp_list[e * W + lane];
+                if (valid[i] && wd != SP_END && (int)(wd & 127u) == qrow[i]) { sp_e0[i] = e; sp_n[i]++; }
+            }
         }
     }
     if constexpr (RES && COLS) {
@@ -592,6 +626,23 @@ __device__ __forceinline__ void coop_helper_pf(const DevSpec *__restrict__ sp, c
 #pragma unroll
                 for (int i = 0; i < RPW; ++i) ch[i] = 0.0;
                 harm_chain_rows<HARM, RPW>(bpr, &w.th[3 + S], ch);
+                if constexpr (SPARSE) {
+                    // eval_fg<..., SPARSE>: the dense columns behind the Fourier block, then the ones of the row in
+                    // ascending column order: fma(1, b, chain) = chain + b
+#pragma unroll
+                    for (int i = 0; i < RPW; ++i) {
+#pragma unroll
+                        for (int j = 0; j < NXDS; ++j) ch[i] = __builtin_fma(xds[i][j], w.th[3 + S + HKF + j], ch[i]);
+                        int k = 0;
+                        while (__any(k < sp_n[i])) {
+                            if (k < sp_n[i]) {
+                                const unsigned wd = cl.sp_list[(sp_e0[i] + k) * W + lane];
+                                ch[i] = ch[i] + w.th[3 + S + SP_DENSE + (int)((wd >> 7) & 63u)];
+                            }
+                            ++k;
+                        }
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < RPW; ++i) { if (MODE == 0) xa[i] = ch[i]; else xm[i] = ch[i]; }
             } else if constexpr (NXB == 1) {
@@ -641,6 +692,17 @@ __device__ __forceinline__ void coop_helper_pf(const DevSpec *__restrict__ sp, c
                 double rg = r * gtr;
                 double v = r * opm;
                 if (GROWTH == 1) v = v * qv;
+                if constexpr (SPARSE) {
+                    // fma(1, w, +0) = w: the lane's partial of each of the row's sparse columns, into its slot
+                    int k = 0;
+                    while (__any(k < sp_n[i])) {
+                        if (k < sp_n[i]) {
+                            const unsigned wd = cl.sp_list[(sp_e0[i] + k) * W + lane];
+                            cl.sp_acc[((wd >> 7) & 63u) * SP_E + (wd >> 13)] = (MODE == 0) ? r : rg;
+                        }
+                        ++k;
+                    }
+                }
                 // rows past the end of a chunk: zeros (fma(x, 0, acc) leaves the chains of phase B unchanged)
                 r = valid[i] ? r : 0.0; rg = valid[i] ? rg : 0.0; v = valid[i] ? v : 0.0;
                 if (row[i]) { rbR[idx[i]] = r; rbU[idx[i]] = rg; rbV[idx[i]] = v; }
@@ -739,16 +801,16 @@ __device__ __forceinline__ void coop_helper_pf(const DevSpec *__restrict__ sp, c
 #endif
 }
 
-template <int KP, int GROWTH, int MODE, int PPL, int NW, bool XIDX, int NTB, int HARM = 0>
+template <int KP, int GROWTH, int MODE, int PPL, int NW, bool XIDX, int NTB, int HARM = 0, bool SPARSE = false, class CLT>
 __device__ __forceinline__ void coop_helper_ntb(const DevSpec *__restrict__ sp, const SeriesView &sv,
-                                                CoopLds<KP, PPL> &cl, double *rbR, double *rbU, double *rbV, int wid)
+                                                CLT &cl, double *rbR, double *rbU, double *rbV, int wid)
 {
-    double *xl = rbV + (size_t)COOP_NTB * W;            // (present when coop_xl_bytes() > 0: NTmax <= 12 < COOP_NTB rows of row buffers)
+    double *xl = rbV + (size_t)(SPARSE ? 12 : COOP_NTB) * W;    // (present when coop_xl_bytes() > 0: NTmax <= 12 < COOP_NTB rows of row buffers; SPARSE: 12 rows, coop_sparse_lds_bytes)
     // issue priority: the trend wave's chains (segment tables in phase A; running sums, scans and the reverse sweep in
     // phase B) are the longest of both phases and it shares its SIMD with a row wave (measured: 5.3 -> 5.05 us per evaluation)
     if (wid == NW - 1) __builtin_amdgcn_s_setprio(3);
-    if (wid == NW - 1) coop_helper_pf<KP, GROWTH, MODE, PPL, NW, XIDX, NTB, true, HARM>(sp, sv, cl, rbR, rbU, rbV, xl, wid);
-    else coop_helper_pf<KP, GROWTH, MODE, PPL, NW, XIDX, NTB, false, HARM>(sp, sv, cl, rbR, rbU, rbV, xl, wid);
+    if (wid == NW - 1) coop_helper_pf<KP, GROWTH, MODE, PPL, NW, XIDX, NTB, true, HARM, SPARSE>(sp, sv, cl, rbR, rbU, rbV, xl, wid);
+    else coop_helper_pf<KP, GROWTH, MODE, PPL, NW, XIDX, NTB, false, HARM, SPARSE>(sp, sv, cl, rbR, rbU, rbV, xl, wid);
 }
 
 // ---- one evaluation, the owner's side ----------------------------------------------------------
@@ -761,9 +823,9 @@ struct CoopOwnerCols {
     static constexpr int ONT = CoopShape<KP, NW, COOP_NTB, 0>::RES ? COOP_NTB : 12;     // steps the owner's columns span
 };
 
-template <int KP, int GROWTH, int MODE, int PPL, int NW, bool XIDX, int HARM = 0>
+template <int KP, int GROWTH, int MODE, int PPL, int NW, bool XIDX, int HARM = 0, bool SPARSE = false, class CLT>
 __device__ __forceinline__ bool coop_eval_owner(const DevSpec *__restrict__ sp, SeriesView &sv,
-                                                CoopLds<KP, PPL> &cl, double *rbR, double *rbU, double *rbV,
+                                                CLT &cl, double *rbR, double *rbU, double *rbV,
                                                 const double (&th)[PPL], double &f_out, double (&g)[PPL],
                                                 bool res, const double *xol CT_ARGS)
 {
@@ -892,6 +954,19 @@ __device__ __forceinline__ bool coop_eval_owner(const DevSpec *__restrict__ sp, 
             if (j < K && lane == 0) lds.accR[j] = sacc;
         }
     }
+    if constexpr (SPARSE) {
+        // the sparse columns' sums: lane c folds the slots of column c in the reduction network's order (eval_fg<..., SPARSE>)
+        if (lane < sv.P - 3 - S - SP_DENSE) {
+            const unsigned long long pg = cl.sp_prog[lane];
+            const int nm = (int)(pg & 7u), root = (int)((pg >> 3) & 7u), kl = (int)((pg >> 6) & 15u);
+            double *wsl = cl.sp_acc + lane * SP_E;
+            for (int i = 0; i < nm; ++i) {
+                const int d = (int)((pg >> (10 + 6 * i)) & 7u), r2 = (int)((pg >> (13 + 6 * i)) & 7u);
+                wsl[d] = wsl[d] + wsl[r2];
+            }
+            lds.accR[SP_DENSE + lane] = (kl > 0 ? wsl[root] : 0.0) + 0.0;
+        }
+    }
     lds_barrier();                                          // C: all sums, and the trend part of the gradient
     CT_LAP(3);
     // the rest of eval_tail: f, and the gradient from cl.gtr (k, m, delta: trend wave) and accR (beta)
@@ -920,10 +995,11 @@ __device__ __forceinline__ bool coop_eval_owner(const DevSpec *__restrict__ sp, 
 // (Stan's BFGSMinimizer<LBFGSUpdate>::step / WolfeLineSearch / WolfLSZoom as restated in fit_kernel;
 // the text below is that loop with the state restored from the checkpoint and eval_fg replaced by
 // coop_eval_owner -- keep the two in step.)
-template <int KP, int GROWTH, int MODE, int PPL, int NW, bool XIDX, int HARM = 0>
+template <int KP, int GROWTH, int MODE, int PPL, int NW, bool XIDX, int HARM = 0, bool SPARSE = false, class CLT>
 __device__ __forceinline__ void coop_owner(const FitArgs &a, SeriesView &sv, int64_t n, const double *slot,
-                                           CoopLds<KP, PPL> &cl, double *rbR, double *rbU, double *rbV, double *xl = nullptr)
+                                           CLT &cl, double *rbR, double *rbU, double *rbV, double *xl = nullptr)
 {
+    constexpr int XC = SPARSE ? 64 : KP;                // columns per row of the design table
     const int lane = lane_id();
     const DevSpec *sp = a.sp;
     auto &lds = cl.w;
@@ -991,7 +1067,7 @@ __device__ __forceinline__ void coop_owner(const FitArgs &a, SeriesView &sv, int
                 const int qc = q < sv.NT ? q : 0;
 #pragma unroll
                 for (int c = 0; c < OWN_L; ++c)
-                    xl[(q * OWN_L + c) * W + lane] = (q < sv.NT) ? (sv.Xw + ((size_t)qc * KP + (KP - OWN_L + c)) * W)[lane] : 0.0;
+                    xl[(q * OWN_L + c) * W + lane] = (q < sv.NT) ? (sv.Xw + ((size_t)qc * XC + (KP - OWN_L + c)) * W)[lane] : 0.0;
             }
             TSF_WAVE_SYNC();
             xol = xl;
@@ -1060,7 +1136,7 @@ __device__ __forceinline__ void coop_owner(const FitArgs &a, SeriesView &sv, int
             }
             double f1;
             CT_LAP(0);
-            const bool bad = coop_eval_owner<KP, GROWTH, MODE, PPL, NW, XIDX, HARM>(sp, sv, cl, rbR, rbU, rbV, xk1, f1, gk1, res, xol CT_PASS);
+            const bool bad = coop_eval_owner<KP, GROWTH, MODE, PPL, NW, XIDX, HARM, SPARSE>(sp, sv, cl, rbR, rbU, rbV, xk1, f1, gk1, res, xol CT_PASS);
             f1 = uniform_f64(f1);
             if (stage == ST_INIT) {         // (direct mode only) the initial point
                 if (bad) { ret = TSF_ST_INIT_NONFINITE; fk = f1; break; }
@@ -1262,13 +1338,16 @@ __device__ __forceinline__ void coop_report_unfitted(const FitArgs &a, const Ser
 }
 
 // ---- the kernel: persistent workgroups over the checkpoint list ---------------------------------
-template <int KP, int GROWTH, int MODE, int PPL, int NW, bool XIDX, int HARM = 0>
+// SPARSE: KP = SP_DENSE registers on the tables and the LDS of the 64-column model (KL), series of <= 12 steps only
+template <int KP, int GROWTH, int MODE, int PPL, int NW, bool XIDX, int HARM = 0, bool SPARSE = false>
 __global__ __launch_bounds__(NW * 64) void fit_coop_kernel(FitArgs a)
 {
+    constexpr int KL = SPARSE ? 64 : KP;
     extern __shared__ __align__(16) unsigned char smem[];
-    CoopLds<KP, PPL> &cl = *reinterpret_cast<CoopLds<KP, PPL> *>(smem);
-    double *rbR = reinterpret_cast<double *>(smem + sizeof(CoopLds<KP, PPL>));
-    double *rbU = rbR + (size_t)coop_rb_rows(a.NTmax) * W, *rbV = rbU + (size_t)coop_rb_rows(a.NTmax) * W;
+    CoopLds<KL, PPL> &cl = *reinterpret_cast<CoopLds<KL, PPL> *>(smem);
+    double *rbR = reinterpret_cast<double *>(smem + sizeof(CoopLds<KL, PPL>));
+    const int rb_rows = SPARSE ? 12 : coop_rb_rows(a.NTmax);      // (SPARSE: <= 12 steps by launch; 16 would not fit the LDS beside the 64-column tables)
+    double *rbU = rbR + (size_t)rb_rows * W, *rbV = rbU + (size_t)rb_rows * W;
     if (a.run_flag && (*a.run_flag != 0) != (a.run_if != 0)) return;          // launch guard (FitArgs::run_flag), as in fit_kernel
     const int wid = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);     // wave-uniform: addresses built from it stay scalar
     // direct mode: every series of the call, fitted here from its initial values; otherwise the fits
@@ -1288,16 +1367,25 @@ __global__ __launch_bounds__(NW * 64) void fit_coop_kernel(FitArgs a)
         if (item >= n_ckpt) break;
         const int64_t n = direct ? (a.order ? (int64_t)a.order[item] : (int64_t)item) : (int64_t)a.coop_list[item];      // (cost hints: tsf_set_cost_hints)
         SeriesView sv;
-        make_view<KP, PPL>(a, n, sv);
+        make_view<KL, PPL>(a, n, sv);
         if (direct && a.stab[n].status0 != 0) {
             // never reaches the optimiser (fbprophet raises: too few rows / cap <= floor; or skips the fit:
             // constant y): the owner reports it, nobody touches the series' tables (they may not exist)
-            if (wid == 0) coop_report_unfitted<KP, PPL>(a, sv, n);
+            if (wid == 0) coop_report_unfitted<KL, PPL>(a, sv, n);
             continue;
+        }
+        if constexpr (SPARSE) {
+            // the lanes' entry words and the columns' fold programs of this series' grid (as fit_kernel<..., SPARSE> stages them)
+            const int64_t g = grid_index(a, n);
+            for (int i = (int)threadIdx.x; i < SP_M * W; i += NW * W) cl.sp_list[i] = (unsigned short)a.sp_meta[(size_t)g * SP_M * W + i];
+            if (threadIdx.x < W) cl.sp_list[SP_M * W + threadIdx.x] = (unsigned short)SP_END;
+            if (threadIdx.x < SP_MAXC) cl.sp_prog[threadIdx.x] = a.sp_prog[(size_t)g * SP_MAXC + threadIdx.x];
+            __syncthreads();
         }
         // rows [NT, COOP_NTB) of the row buffers: zeros (the straight-line chains of coop_helper_pf)
         if (sv.NT < COOP_NTB) {
-            for (int i = sv.NT * W + (int)threadIdx.x; i < COOP_NTB * W; i += NW * W) { rbR[i] = 0.0; rbU[i] = 0.0; rbV[i] = 0.0; }
+            const int zr = rb_rows < COOP_NTB ? rb_rows : COOP_NTB;
+            for (int i = sv.NT * W + (int)threadIdx.x; i < zr * W; i += NW * W) { rbR[i] = 0.0; rbU[i] = 0.0; rbV[i] = 0.0; }
         }
 #ifdef TSF_COOP_TIMING
         if (threadIdx.x == 0) cl.dbg = a.grad_out ? (long long *)a.grad_out + (size_t)n * 64 : nullptr;
@@ -1305,9 +1393,11 @@ __global__ __launch_bounds__(NW * 64) void fit_coop_kernel(FitArgs a)
         if (wid == 0) {
             for (int i = lane_id(); i < TSF_MAX_P + W; i += W) cl.w.th[i] = 0.0;
             TSF_WAVE_SYNC();
-            coop_owner<KP, GROWTH, MODE, PPL, NW, XIDX, HARM>(a, sv, n, direct ? nullptr : a.coop_slots + (size_t)item * a.coop_stride,
-                                                              cl, rbR, rbU, rbV,
-                                                              coop_xl_bytes(KP, a.NTmax) > 0 ? rbV + (size_t)COOP_NTB * W : nullptr);
+            coop_owner<KP, GROWTH, MODE, PPL, NW, XIDX, HARM, SPARSE>(a, sv, n, direct ? nullptr : a.coop_slots + (size_t)item * a.coop_stride,
+                                                                      cl, rbR, rbU, rbV,
+                                                                      coop_xl_bytes(KP, a.NTmax) > 0 ? rbV + (size_t)(SPARSE ? 12 : COOP_NTB) * W : nullptr);
+        } else if constexpr (SPARSE) {
+            coop_helper_ntb<KP, GROWTH, MODE, PPL, NW, XIDX, 12, HARM, true>(a.sp, sv, cl, rbR, rbU, rbV, wid);    // (launched for NTmax <= 12 only)
         } else if (sv.NT > COOP_NTB) {
             coop_helper<KP, GROWTH, MODE, PPL, NW, XIDX>(a.sp, sv, cl, rbR, rbU, rbV, wid);
         } else if (a.NTmax > 12) {      // (the call's longest series decides: the LDS of the 12-step variant is sized by it)

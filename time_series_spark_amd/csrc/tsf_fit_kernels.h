@@ -758,6 +758,7 @@ struct FitArgs {
     const double *Bw;
     int bw_ns, harm;                    // seasonalities per row of Bw; the model's harmonic structure (harm_code), 0 = none compiled
     int coop_harm;                      // the cooperative kernel's rows from the base pairs too (harm != 0 and no dense column behind the Fourier block)
+    int opt_coop_sparse;                // the sparse-column kernel's tail on the sparse cooperative kernel (TSF_OPT_SPARSE_EXTRA != 2 ... tests: off)
     const int32_t *uw;                  // [grid][NTmax][64] lattice row of each series row
     const double *Xu;                   // [U][KP]
     int xidx;
