@@ -176,7 +176,8 @@ enum {
     TSF_OPT_HARM = 0,        /* 0: the residual-form kernel streams every design column from the table instead of
                                 expanding the Fourier columns from the rows' base pairs */
     TSF_OPT_LATTICE,         /* 0 / 1: never / always the shared lattice table of a ragged call on regular timestamps */
-    TSF_OPT_SPARSE_EXTRA,    /* 0: holiday columns of a wide model as dense columns */
+    TSF_OPT_SPARSE_EXTRA,    /* 0: holiday columns of a wide model as dense columns; 2: sparse fit kernel, but its stragglers on the
+                                64-column cooperative kernel instead of the sparse one (A/B runs, tests) */
     TSF_OPT_FIT_GROUPED,     /* 0: wide models on the workgroup kernel from the first evaluation */
     TSF_OPT_GRAM_SHARE,      /* 0: a ragged quadratic-form call builds Z^T Z per series even where calendars are shared */
     TSF_OPT_GRID_ORDER,      /* 0: a ragged call does not start its series grouped by calendar */
