@@ -466,12 +466,12 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
         // Round 5: a model whose Fourier columns have a compiled expansion reads 32-byte base pairs per row from its OWN
         // tables (eval_fg HARM) -- faster than the gathered 224-byte rows of the lattice table in the one-wave kernel (ragged
         // bench panel, a grid per series: 93 -> 60 ms) and, above all, in the cooperative tail (gathered rows stream: 11 us
-        // per evaluation against 5) -- wherever a table per series is affordable (<= 8 GB of design tables per call).
+        // per evaluation against 5) -- wherever a table per series is affordable (<= 32 GB of design tables per call: ~190 000 series of 730 rows).
         const int el = ctx->opt[TSF_OPT_LATTICE];
         const size_t tab = sizeof(double) * (size_t)n_grids * (size_t)NTmax * hs.KP * W;
         const bool harm_model = ctx->opt[TSF_OPT_HARM] != 0 && mode != 2 &&
                                 ((hs.harm == HARM_Y10_W3 && hs.KP == 28) || (hs.harm == HARM_W3_D4 && hs.KP == 16) || (hs.harm == HARM_W3 && hs.KP == 8));
-        if (el >= 0 ? el == 0 : ((grid_of != nullptr && tab <= ((size_t)64 << 20)) || (harm_model && tab <= ((size_t)8 << 30)))) lat_U = 0;
+        if (el >= 0 ? el == 0 : ((grid_of != nullptr && tab <= ((size_t)64 << 20)) || (harm_model && tab <= ((size_t)32 << 30)))) lat_U = 0;
     }
     // matrix-core residual kernel (tsf_mfma_kernels.h): aligned panel, L-BFGS, one parameter per lane
     // (KP <= 28 implies one column mode and P <= 64), at most MT_SP changepoints, and an upper bound
