@@ -174,7 +174,8 @@ int tsf_device_count(void);
  * calls this. */
 enum {
     TSF_OPT_HARM = 0,        /* 0: the residual-form kernel streams every design column from the table instead of
-                                expanding the Fourier columns from the rows' base pairs */
+                                expanding the Fourier columns from the rows' base pairs; 1 / 2: never / always the variant of
+                                that kernel that requests a row one step ahead (default: where the rows come from HBM) */
     TSF_OPT_LATTICE,         /* 0 / 1: never / always the shared lattice table of a ragged call on regular timestamps */
     TSF_OPT_SPARSE_EXTRA,    /* 0: holiday columns of a wide model as dense columns; 2: sparse fit kernel, but its stragglers on the
                                 64-column cooperative kernel instead of the sparse one (A/B runs, tests) */

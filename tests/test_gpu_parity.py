@@ -561,6 +561,42 @@ def test_ragged_quadratic_form_with_a_calendar_per_series_reads_base_pairs(env):
             assert n_bit_diff(r.theta[n][:P], o['theta']) == 0 and n_bit_diff(r.fval[n], o['f']) == 0, (n_extra, n)
 
 
+def test_base_pair_kernel_with_row_prefetch_changes_no_bit(env):
+    """Round 5: where a residual-form panel's rows come from HBM (a table per series: irregular timestamps) the launcher
+    takes the variant of the base-pair kernel that requests a row one step ahead of its use, compiled for two waves per
+    SIMD (fit_kernel<..., HARM, PF>; context option harm = 2 forces it, 1 forbids it).  Same operations on the same
+    values: the reference's model on series with calendars of their own gives identical bits with and without the
+    prefetch and from the tables (harm = 0), and matches the oracle."""
+    fc, cl = env
+    from time_series_spark_amd import synth
+    rng = np.random.default_rng(78)
+    N, Tm = 40, 800
+    dsm = synth.daily_grid(Tm)
+    _, ym = synth.make_panel(N, Tm, 'logistic', seed=32)
+    keep = [np.sort(rng.choice(Tm, size=int(rng.integers(600, 731)), replace=False)) for _ in range(N)]
+    lens = np.array([len(k) for k in keep])
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    dsr = np.concatenate([dsm[k] + int(rng.integers(0, 3600)) * 1000000000 for k in keep])      # (off the daily lattice)
+    yr = np.concatenate([ym[i][k] for i, k in enumerate(keep)])
+    cap = np.array([ym[i][k].max() * 1.1 for i, k in enumerate(keep)])
+    spec = fc.ModelSpec(growth='logistic', seasonality_mode='multiplicative', seasonalities=[helpers.YEARLY, helpers.WEEKLY])
+    res = {}
+    for tag, h in (('prefetch', 2), ('plain', 1), ('tables', 0)):
+        with fc.get_context().options(harm=h):
+            res[tag] = fc.fit_ragged(spec, off, dsr, yr, floor=np.zeros(N), cap=cap)
+    for tag in ('plain', 'tables'):
+        for name in ('theta', 'fval', 'n_iter', 'n_eval', 'status', 'y_scale'):
+            assert np.array_equal(getattr(res['prefetch'], name), getattr(res[tag], name), equal_nan=True), (tag, name)
+    r = res['prefetch']
+    assert (r.status > 0).sum() >= N - 2
+    csp = helpers.oracle_spec(spec)
+    for n in (0, 13, N - 1):
+        sl = slice(off[n], off[n + 1])
+        o = cl.fit(csp, dsr[sl], yr[sl], 0.0, cap[n])
+        assert (r.n_iter[n], r.n_eval[n], r.status[n]) == (o['n_iter'], o['n_eval'], o['status']), n
+        assert n_bit_diff(r.theta[n][:len(o['theta'])], o['theta']) == 0 and n_bit_diff(r.fval[n], o['f']) == 0, n
+
+
 def _used_sparse_columns(fc):
     import ctypes
     from time_series_spark_amd import _lib

@@ -631,6 +631,13 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     a.grid_of = grid_of;
     a.Bw = bw_ns ? (const double *)(ws + l.Bw) : nullptr; a.bw_ns = bw_ns; a.harm = harm;
     a.coop_harm = (harm != 0 && hs.K == harm_kf(harm) && mode != 2) ? 1 : 0;
+    {
+        // rows of the one-wave base-pair kernel from HBM?  (tables per grid: segment words, t, base pairs; y per series)
+        const size_t row_tabs = (size_t)n_grids * NTmax * W * (sizeof(double) + sizeof(uint16_t) + sizeof(double) * 2 * (size_t)bw_ns) +
+                                (size_t)N * NTmax * W * sizeof(double);
+        const int oh = ctx->opt[TSF_OPT_HARM];
+        a.harm_pf = (harm != 0 && (oh == 2 || (oh != 1 && !aligned && row_tabs > ((size_t)256 << 20)))) ? 1 : 0;
+    }
     a.opt_coop_sparse = ctx->opt[TSF_OPT_SPARSE_EXTRA] != 2 ? 1 : 0;     // (2: the sparse fit kernel with the 64-column tail, for A/B runs)
     ctx->last_sp_flag = nullptr;
     if (sparse_try) {

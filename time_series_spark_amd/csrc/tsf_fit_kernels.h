@@ -413,7 +413,7 @@ __device__ __forceinline__ void harm_row(const double2 *bp, F &&emit)
 // With all 64 accumulators live the kernel needs 379 registers (one wave per SIMD, design values through AGPRs);
 // grouped it runs at two.  Column by column the fma chain (rows q descending) and the reduction network are those
 // of the ungrouped form: same bits.
-template <int KP, int GROWTH, int MODE, int PPL, bool XIDX = false, class L = WaveLds<KP, PPL>, int GNTR = 0, bool SPARSE = false, int HARM = 0>
+template <int KP, int GROWTH, int MODE, int PPL, bool XIDX = false, class L = WaveLds<KP, PPL>, int GNTR = 0, bool SPARSE = false, int HARM = 0, bool PF = false>
 __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesView &sv,
                                         L &lds, const double (&th)[PPL],
                                         double &f_out, double (&g)[PPL] FT_ARGS)
@@ -468,13 +468,31 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
     unsigned sp_cur = SP_END;
     int sp_i = 0;
     if constexpr (SPARSE) sp_cur = sv.sp_list[lane];
+    // PF (round 5, HARM): the row's inputs (segment word, t, y, base pairs: 50 bytes) are requested one step AHEAD of their
+    // use, in a kernel compiled for two waves per SIMD.  A panel whose series have tables of their own (irregular
+    // timestamps: 365 MB for 10 000 series) reads them from HBM, and three waves per SIMD without the prefetch do not cover
+    // that latency: 107 -> 97 ms on the irregular bench panel; an aligned panel (tables in L2) is better off with three
+    // waves and no prefetch (0.60 against 0.64 s on 100 000 x 730): the launcher picks (FitArgs::harm_pf).
+    constexpr bool PREF = HARM != 0 && !SPARSE && PF;
+    struct RowIn { unsigned cwv; double ti, yi; double2 bp[NS]; };
+    auto row_fetch = [&](int q, RowIn &ri) {
+        const int idx = q * W + lane;
+        ri.cwv = (unsigned)sv.cw[idx]; ri.ti = sv.tw[idx]; ri.yi = sv.yw[idx];
+        const double2 *bq = reinterpret_cast<const double2 *>(sv.Bw) + (size_t)q * NS * W + lane;
+#pragma unroll
+        for (int se = 0; se < NS; ++se) ri.bp[se] = bq[se * W];
+    };
+    RowIn rin;
+    if constexpr (PREF) { if (NT > 0) row_fetch(NT - 1, rin); }
     for (int q = NT - 1; q >= 0; --q) {
+        RowIn rcur;
+        if constexpr (PREF) { rcur = rin; if (q > 0) row_fetch(q - 1, rin); }     // (two steps ahead: measured, no better)
         if (q < sv.cnt) {
             const int idx = q * W + lane;
-            const unsigned cwv = (unsigned)sv.cw[idx];
+            const unsigned cwv = PREF ? rcur.cwv : (unsigned)sv.cw[idx];
             const int c = (int)(cwv & 0xffu), cprev = (int)(cwv >> 8);
-            const double ti = sv.tw[idx];
-            const double yi = sv.yw[idx];
+            const double ti = PREF ? rcur.ti : sv.tw[idx];
+            const double yi = PREF ? rcur.yi : sv.yw[idx];
             constexpr int XS = XIDX ? 1 : W;      // stride between the columns of a design row
             const double *xp = XIDX ? sv.Xu + (size_t)sv.uw[idx] * KP : sv.Xw + (size_t)q * XCOLS * W + lane;
             double x[(HOLD && HARM == 0) ? KP : 1];
@@ -484,7 +502,7 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
             if constexpr (HARM != 0) {
                 const double2 *bq = reinterpret_cast<const double2 *>(sv.Bw) + (size_t)q * NS * W + lane;
 #pragma unroll
-                for (int se = 0; se < NS; ++se) bp[se] = bq[se * W];
+                for (int se = 0; se < NS; ++se) bp[se] = PREF ? rcur.bp[se] : bq[se * W];
                 double ch = 0.0;
                 harm_row<HARM>(bp, [&](int j, double v) { ch = __builtin_fma(v, bs[j], ch); });
                 if (NXD > 0 && sv.n_xd > 0) {
@@ -758,6 +776,7 @@ struct FitArgs {
     const double *Bw;
     int bw_ns, harm;                    // seasonalities per row of Bw; the model's harmonic structure (harm_code), 0 = none compiled
     int coop_harm;                      // the cooperative kernel's rows from the base pairs too (harm != 0 and no dense column behind the Fourier block)
+    int harm_pf;                        // HARM: the two-waves-per-SIMD kernel with the row prefetch (tables per series, read from HBM)
     int opt_coop_sparse;                // the sparse-column kernel's tail on the sparse cooperative kernel (TSF_OPT_SPARSE_EXTRA != 2 ... tests: off)
     const int32_t *uw;                  // [grid][NTmax][64] lattice row of each series row
     const double *Xu;                   // [U][KP]
@@ -941,8 +960,8 @@ __global__ __launch_bounds__(64) void eval_kernel(FitArgs a)
 #ifndef TSF_HARM_SPARSE_WPS
 #define TSF_HARM_SPARSE_WPS 2   // ... and their sparse-column form (the entry lists' cursors and the two-slot optimiser vectors
 #endif                          // do not fit 168 registers: at three waves per SIMD it spills 69 of them and loses to the table kernel)
-template <int KP, int GROWTH, int MODE, int PPL, bool XIDX = false, int GNTR = 0, bool SPARSE = false, int HARM = 0>
-__global__ __launch_bounds__(64, HARM != 0 ? (SPARSE ? TSF_HARM_SPARSE_WPS : TSF_HARM_WPS) : ((GNTR > 0 || SPARSE) ? 2 : TSF_FIT_WPS)) void fit_kernel(FitArgs a)
+template <int KP, int GROWTH, int MODE, int PPL, bool XIDX = false, int GNTR = 0, bool SPARSE = false, int HARM = 0, bool PF = false>
+__global__ __launch_bounds__(64, HARM != 0 ? ((SPARSE || PF) ? TSF_HARM_SPARSE_WPS : TSF_HARM_WPS) : ((GNTR > 0 || SPARSE) ? 2 : TSF_FIT_WPS)) void fit_kernel(FitArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int KL = SPARSE ? 64 : KP;            // SPARSE: tables and LDS of the 64-column model, registers of the 28-column one
@@ -1085,7 +1104,7 @@ __global__ __launch_bounds__(64, HARM != 0 ? (SPARSE ? TSF_HARM_SPARSE_WPS : TSF
             }
             double f1;
             FT_LAP(0);
-            const bool bad = eval_fg<KP, GROWTH, MODE, PPL, XIDX, WL, GNTR, SPARSE, HARM>(sp, sv, lds, xk1, f1, gk1 FT_PASS);
+            const bool bad = eval_fg<KP, GROWTH, MODE, PPL, XIDX, WL, GNTR, SPARSE, HARM, PF>(sp, sv, lds, xk1, f1, gk1 FT_PASS);
             f1 = uniform_f64(f1);       // every lane holds the same bits: let the compiler know (scalar branches)
             if (stage == ST_INIT) {
                 if (bad) { ret = TSF_ST_INIT_NONFINITE; fk = f1; break; }
