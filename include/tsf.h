@@ -197,6 +197,8 @@ enum {
                                 hipFreeAsync as in round 3 instead of the context's cached block; bit 1 synchronise the
                                 stream before the free; bit 2 canary pages either side of the records, checked after the
                                 kernel (count on stderr); bit 3 the default pool never releases memory */
+    TSF_OPT_COOP_TAIL,       /* residual-form launches: the fits still running are handed to the cooperative kernel once no
+                                more of them are left than this many per hundred compute units (default 200) */
     TSF_OPT_COUNT
 };
 int tsf_set_option(tsf_ctx *ctx, int option, int value);

@@ -263,7 +263,7 @@ constexpr size_t TSF_NB_KEEP = (size_t)1 << 30;
 static int coop_slots_for(int64_t N, int after, int n_cu)
 {
     if (after == COOP_DIRECT) return 0;
-    const int64_t cap = after >= 0 ? 8192 : 2 * (int64_t)n_cu;
+    const int64_t cap = after >= 0 ? 8192 : 8 * (int64_t)n_cu;      // (hand-over at up to ~4 fits per CU, twice that for the waves racing past the test)
     return (int)(N < cap ? N : cap);
 }
 
@@ -729,6 +729,14 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
             a.coop_max = coop_slots; a.coop_stride = coop_stride;
             a.coop_after = coop_after;
             a.coop_blocks = ctx->n_cu;
+            {
+                // Hand-over point of the tail rule: the one-wave kernel's waves run alone on their SIMDs by then (13.6 us per
+                // evaluation) and a cooperative workgroup needs 5.05: up to ~2.7 fits per CU the cooperative kernel has
+                // the higher aggregate rate even though they queue for its workgroups.  Default 2 per CU.
+                const int pct = ctx->opt[TSF_OPT_COOP_TAIL] > 0 ? ctx->opt[TSF_OPT_COOP_TAIL] : 200;
+                a.coop_tail_at = (int)((int64_t)ctx->n_cu * (pct > 400 ? 400 : pct) / 100);
+                if (a.coop_tail_at < 1) a.coop_tail_at = 1;
+            }
             HIP_TRY(ctx, hipMemsetAsync(a.coop_ctl, 0, 4 * sizeof(int), st));
         }
         lrc = pick_launch(hs.growth, mode)(hs.KP, a, theta_in != nullptr, st);

@@ -794,6 +794,7 @@ struct FitArgs {
     int32_t *coop_list;                 // [coop_max] series of each slot
     double *coop_slots;                 // [coop_max][coop_stride]
     int coop_max, coop_stride, coop_after, coop_blocks;
+    int coop_tail_at;                   // tail rule: suspend once no more fits than this are still running (tsf_api.hip)
     // scheduling hint (tsf_set_cost_hints): the q-th series the launch starts is order[q]; null = q
     const int32_t *order;
     // ragged panels whose series SHARE timestamp vectors (round 4): grid_of[n] = the grid (timestamp vector with its
@@ -859,7 +860,7 @@ __device__ __forceinline__ bool coop_should_suspend(const FitArgs &a, int n_eval
     const int started = __hip_atomic_load(&a.coop_ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (started < (int)a.N) return false;
     const int done = __hip_atomic_load(&a.coop_ctl[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return started - done <= a.coop_blocks;
+    return started - done <= a.coop_tail_at;
 }
 
 template <int KP, int PPL>
