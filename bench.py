@@ -143,6 +143,7 @@ def kernel_sources_digest():
     h = hashlib.sha256()
     files = sorted(glob.glob(os.path.join(ROOT, 'time_series_spark_amd', 'csrc', '*')))
     files.append(os.path.join(ROOT, 'include', 'tsf.h'))
+    files.append(os.path.join(ROOT, 'include', 'tsf_dev.h'))
     for f in files:
         if f.endswith(('.h', '.hip', '.inc', '.cpp')):
             h.update(os.path.basename(f).encode())

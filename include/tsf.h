@@ -17,9 +17,7 @@
  *       /root/reference/src/jobs/prophet_scorer.py:64-84 (future frame :64-68, predict :70,
  *       astype(int) :73, clamp :76-84).  Only `yhat` is produced: the reference keeps
  *       nothing else (:86).
- *   tsf_eval / tsf_design
- *       no reference counterpart: expose the log-posterior/gradient and the design matrix
- *       so tests can check them against the CPU oracle one evaluation at a time.
+ *   (tests and measurements -- per-evaluation hooks, route switches, kernel timers -- are NOT here: include/tsf_dev.h)
  *
  * Conventions
  *   - Every function returns 0 on success, <0 on API misuse / HIP failure
@@ -167,43 +165,6 @@ void tsf_destroy(tsf_ctx *ctx);
 const char *tsf_last_error(const tsf_ctx *ctx);
 int tsf_device_count(void);
 
-/* Route switches of ONE context (round 5; until round 4 these were process-wide environment variables read inside
- * the library).  No result depends on a route -- the GPU tests compare the routes bit for bit, which is what the
- * switches exist for, beside measurements.  value -1 (the state after tsf_create) = the library's own choice; what
- * the other values mean is stated per option.  Not part of what the reference's path needs: a drop-in caller never
- * calls this. */
-enum {
-    TSF_OPT_HARM = 0,        /* 0: the residual-form kernel streams every design column from the table instead of
-                                expanding the Fourier columns from the rows' base pairs; 1 / 2: never / always the variant of
-                                that kernel that requests a row one step ahead (default: where the rows come from HBM) */
-    TSF_OPT_LATTICE,         /* 0 / 1: never / always the shared lattice table of a ragged call on regular timestamps */
-    TSF_OPT_SPARSE_EXTRA,    /* 0: holiday columns of a wide model as dense columns; 2: sparse fit kernel, but its stragglers on the
-                                64-column cooperative kernel instead of the sparse one (A/B runs, tests) */
-    TSF_OPT_FIT_GROUPED,     /* 0: wide models on the workgroup kernel from the first evaluation */
-    TSF_OPT_GRAM_SHARE,      /* 0: a ragged quadratic-form call builds Z^T Z per series even where calendars are shared */
-    TSF_OPT_GRID_ORDER,      /* 0: a ragged call does not start its series grouped by calendar */
-    TSF_OPT_GRID_SHARE,      /* 0: a ragged call keeps one set of grid tables per series */
-    TSF_OPT_RAGGED_SPLIT,    /* 0: tsf_fit_ragged never cuts a call into length classes; 2: always */
-    TSF_OPT_QUAD_REG,        /* quadratic-form kernel variant: 0 Z^T Z in LDS, 1 in registers */
-    TSF_OPT_QUAD_M2_LDS,     /* 0: the two-slot quadratic-form kernel reads Z^T Z from global memory */
-    TSF_OPT_QUAD_W4,         /* waves per workgroup of the aligned quadratic-form kernel: 8, 12 or 16 */
-    TSF_OPT_QUAD_RREG,       /* 0: residual-pass weights staged through memory */
-    TSF_OPT_NEWTON_BATCH,    /* series per resident wave from which Newton runs several series per wave (0: never) */
-    TSF_OPT_NEWTON_FLAGS, TSF_OPT_NEWTON_NS, TSF_OPT_NEWTON_LCAP, TSF_OPT_NEWTON_FILL,   /* dev knobs of that kernel */
-    TSF_OPT_QUAD_YIELD,      /* time slicing of the aligned quadratic-form kernel (default: off): n > 0 a fit is handed
-                                back after n evaluations while other series wait (panels of up to 24 series per wave
-                                slot); n < -1 after every |n| evaluations whether or not anyone waits (tests) */
-    TSF_OPT_DEBUG_ASYNC_SCRATCH, /* dev (tools/dev/nb_debug.py): bit 0 the slot records of that kernel from hipMallocAsync /
-                                hipFreeAsync as in round 3 instead of the context's cached block; bit 1 synchronise the
-                                stream before the free; bit 2 canary pages either side of the records, checked after the
-                                kernel (count on stderr); bit 3 the default pool never releases memory */
-    TSF_OPT_COOP_TAIL,       /* residual-form launches: the fits still running are handed to the cooperative kernel once no
-                                more of them are left than this many per hundred compute units (default 200) */
-    TSF_OPT_COUNT
-};
-int tsf_set_option(tsf_ctx *ctx, int option, int value);
-int tsf_get_option(const tsf_ctx *ctx, int option);       /* -1: default (or a bad argument) */
-
 void tsf_spec_default(tsf_spec *spec);
 int tsf_spec_size(void);                      /* sizeof(tsf_spec), for binding self-checks */
 int tsf_grid_info_size(void);
@@ -275,30 +236,6 @@ int tsf_predict_intervals_dev(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int
                               uint64_t seed, double *yhat, double *yhat_lower, double *yhat_upper,
                               void *stream);
 
-/* ---- test / diagnostics hooks (host pointers) -------------------------------------------
- * tsf_eval: f = -log posterior and gradient [N][stride] at theta [N][stride] for an aligned
- * panel.  tsf_design: X [T][K] (row-major, original column order), scaled t [T]. */
-int tsf_eval(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int32_t T, const int64_t *ds,
-             const void *y, int32_t y_dtype, const double *floor, const double *cap,
-             const double *extra, const double *theta, double *f_out, double *grad_out);
-/* tsf_eval_quadratic: the QUADRATIC evaluation form (eval_form; what fit_quad_kernel evaluates at every
- * trial point of its line searches) at theta [N][stride], built around the reference point
- * theta_ref [N][stride]: s0 = |y - Z ref|^2 and c = Z^T (y - Z ref) from one residual-form pass at
- * theta_ref, M = Z^T Z once per call, then f and the gradient from (s0, c, M, theta - theta_ref).  Aligned
- * panel, linear growth, additive columns only, 3 + n_changepoints + K <= 64 (else an error).  The
- * per-evaluation check of the headline kernel's arithmetic against the literal model
- * (tests/test_gpu_literal.py); reference-side counterpart: none (Stan evaluates in residual form). */
-int tsf_eval_quadratic(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int32_t T, const int64_t *ds,
-                       const void *y, int32_t y_dtype, const double *extra, const double *theta_ref,
-                       const double *theta, double *f_out, double *grad_out);
-int tsf_design(tsf_ctx *ctx, const tsf_spec *spec, int32_t T, const int64_t *ds,
-               const double *extra, double *X_out, double *t_out, tsf_grid_info *grid_out);
-/* IEEE self test of the device arithmetic the canonical order relies on: fills out[n] with
- * op(a[n], b[n]) for op in {0:div, 1:sqrt(a), 2:det_exp(a), 3:det_log(a), 4:det_sin(a),
- * 5:det_cos(a), 6:fma(a,b,a)} computed on the GPU. */
-int tsf_selftest_math(tsf_ctx *ctx, int32_t op, int64_t n, const double *a, const double *b,
-                      double *out);
-
 /* ---- scheduling hints ---------------------------------------------------------------------
  * A launch ends with its longest fits (cfg2: 1 582 evaluations against a mean of 454), and nothing
  * cheap about a series predicts how long its fit takes -- except an earlier fit of the same
@@ -312,21 +249,6 @@ int tsf_selftest_math(tsf_ctx *ctx, int32_t op, int64_t n, const double *a, cons
  * cost: HOST pointer, copied by the call; NULL or n == 0 clears.  The hints are used once.
  * Reference interface replaced: none (Spark's scheduler knows nothing about a group's cost). */
 int tsf_set_cost_hints(tsf_ctx *ctx, const int32_t *cost, int64_t n);
-
-/* ---- measurement hooks ------------------------------------------------------------------
- * With profiling enabled every tsf_fit_*_dev call records a pair of HIP events on ITS stream
- * right before and after the fit kernel (the dominant kernel of the path); up to
- * TSF_PROFILE_RING calls are kept.  tsf_profile_read waits for the recorded events and
- * returns the kernel durations (milliseconds, oldest first) of the calls made since
- * profiling was last (re-)enabled; tsf_last_fit_kernel_ms returns the newest one. */
-#define TSF_PROFILE_RING 64
-int tsf_set_profiling(tsf_ctx *ctx, int32_t enable);
-int tsf_profile_read(tsf_ctx *ctx, float *ms_out, int32_t max_n, int32_t *n_out);
-int tsf_last_fit_kernel_ms(tsf_ctx *ctx, float *ms_out);
-/* Which route the last fit call of this context took where the library decides on the device (tests, measurements):
- * *sparse_columns = 1 if a wide model's indicator columns ran in sparse form (every grid qualified), 0 if the dense
- * kernels ran or the call was not a candidate.  Waits for the device; valid until the next fit call. */
-int tsf_last_fit_route(tsf_ctx *ctx, int32_t *sparse_columns);
 
 /* ---- host-side panel packing (no device work, no tsf_ctx) ---------------------------------
  * Regroups a long table (one row per observation) into the contiguous per-series runs
@@ -346,6 +268,12 @@ int tsf_last_fit_route(tsf_ctx *ctx, int32_t *sparse_columns);
  *                   span = last ds - first ds, min_dt = smallest positive spacing (-1 if none),
  *                   y_max -- the inputs of fbprophet's set_auto_seasonalities and of
  *                   cap = max(y) * cap_multiplier (prophet_modeler.py:59-60).
+ *   tsf_pack_flags  what tsf_pack_fetch's pass over the packed rows saw (valid after it): *aligned = 1 when every
+ *                   series is observed on the first series' timestamp vector (one shared calendar: the panel can go
+ *                   to tsf_fit_aligned as [n_series][T] without another look at ds); *has_inf = 1 when a y is
+ *                   infinite (fbprophet raises "Found infinity in column y."); *integral = 1 when every y is an
+ *                   integer that fits int32 -- the quantity column of the reference's schema
+ *                   (prophet_modeler.py:16), which may then cross to the device as TSF_Y_I32.
  * Returns 0, -1 bad arguments, -2 out of memory, -3 other failure. */
 typedef struct tsf_pack tsf_pack;
 int tsf_pack_rows(int64_t n, const int64_t *series_id, const int64_t *dim_id, const int64_t *ds,
@@ -353,7 +281,24 @@ int tsf_pack_rows(int64_t n, const int64_t *series_id, const int64_t *dim_id, co
                   int64_t *n_series, int32_t *identity);
 int tsf_pack_fetch(tsf_pack *p, int64_t *key_series_id, int64_t *key_dim_id, int64_t *offsets,
                    int64_t *ds_out, double *y_out, int64_t *span, int64_t *min_dt, double *y_max);
+int tsf_pack_flags(const tsf_pack *p, int32_t *aligned, int32_t *has_inf, int32_t *integral);
 void tsf_pack_free(tsf_pack *p);
+
+/* ---- model blobs (host side) ------------------------------------------------------------------
+ * The `model` column of the fit UDF's output -- pickle.dumps(model) per series in the reference
+ * (/root/reference/src/jobs/prophet_modeler.py:72-75) -- for a whole fitted batch at once: blob n is written at
+ * out + n * stride, stride = prefix_len + 64 + 8 * (n_theta + n_tchange): the prefix (magic, version, the constructor
+ * arguments: shared by the batch, built by the caller), then the little-endian record
+ *   f64 y_scale | i64 start_ns, t_scale_ns, last_ds_ns | i32 T, S, i1, NT, status, n_iter, n_theta, n_tchange |
+ *   f64 theta[n_theta] | f64 t_change[n_tchange]
+ * theta [N][n_theta], y_scale / status / n_iter [N] and grid [n_grids] (1 or N) are a fit's outputs (tsf_fit_out);
+ * last_ds [N] is the last history date of each series, null-y rows included (where make_future_dataframe starts,
+ * prophet_scorer.py:64-66).  One contiguous buffer with equal strides is an Arrow binary column as it stands: the model
+ * parquet (prophet_modeler.py:118-125) is written from it without a Python object per series.
+ * Returns 0, -1 bad arguments, -2 out of memory. */
+int tsf_model_blobs(int64_t N, const void *prefix, int32_t prefix_len, int32_t n_theta, const double *theta,
+                    const double *y_scale, const tsf_grid_info *grid, int32_t n_grids, const int64_t *last_ds,
+                    const int32_t *status, const int32_t *n_iter, int32_t n_tchange, void *out, int32_t n_threads);
 
 /* ---- model-input reader (host side, no device work, no tsf_ctx) ---------------------------
  * Replaces ProphetModeler.read_input_dataframe's
@@ -412,6 +357,20 @@ int tsf_csv_discover_load(const char *root, int32_t n_threads, tsf_csv_dir **out
                           int32_t *n_partitioned);
 int tsf_csv_read_loaded(tsf_csv_dir *d, int32_t first, int32_t count, const char *layout, int32_t n_threads,
                         tsf_csv **out, int64_t *n_rows, int32_t *err_file, int64_t *err_line);
+/* The input directory in chunks (round 6): tsf_csv_root_open lists the CHILDREN of `root` once (hidden names skipped;
+ * `series_id=<int>` directories first, by value, then the rest by name); tsf_csv_root_load is tsf_csv_discover_load over
+ * the subtrees of children [first, first + count) -- its handle goes to tsf_csv_read_loaded / tsf_csv_dir_* as usual.
+ * A job reads, fits and persists such ranges as a pipeline (files of chunk k + 1 are read while chunk k is on the GPU).
+ * *hive_only = 1 when every child is a `series_id=<int>` directory and no value occurs twice -- the layout the reference
+ * reads (spark.read.csv over `series_id=751/...`, prophet_modeler.py:109-114): ranges of children then hold disjoint
+ * series, so fitting range by range fits every series once, on all of its rows.  *nested = 1 from a load that met a
+ * `series_id=` directory below another one with a different value (the same series could then sit in two ranges): read
+ * the tree whole instead.  Returns as tsf_csv_discover; tsf_csv_root_open also TSF_CSV_E_OPEN if root cannot be listed. */
+typedef struct tsf_csv_root tsf_csv_root;
+int tsf_csv_root_open(const char *root, tsf_csv_root **out, int32_t *n_children, int32_t *hive_only);
+int tsf_csv_root_load(tsf_csv_root *r, int32_t first, int32_t count, int32_t n_threads, tsf_csv_dir **out,
+                      int32_t *n_files, int32_t *n_partitioned, int32_t *nested);
+void tsf_csv_root_free(tsf_csv_root *r);
 const char *const *tsf_csv_dir_paths(const tsf_csv_dir *d);
 const int64_t *tsf_csv_dir_series_id(const tsf_csv_dir *d);
 const char *tsf_csv_dir_error_path(const tsf_csv_dir *d);

@@ -1592,6 +1592,61 @@ def test_reference_contract_fit_and_forecast_udfs(env, tmp_path):
     assert len(conv) == 80 and np.array_equal(np.sort(conv['forecast_quantity'].values), np.sort(fdf['yhat'].values))
 
 
+def test_jobs_as_pipelines_over_chunks_change_no_bit(env, tmp_path, capsys):
+    """Round 6: ProphetModeler.model over ranges of partition directories (read | fit | parquet part, io.chunks) and
+    ProphetScorer.score over the row groups of the model parts (read | predict | CSV parts) on the GPU: every model blob
+    and every forecast row equal to the whole-input run's, for the reference's own model (ragged histories: two
+    calendars, one series shorter) and for BASELINE cfg2's -- and the models' forecasts equal to the oracle's."""
+    fc, cl = env
+    from time_series_spark_amd import synth
+    from time_series_spark_amd.jobs import prophet_modeler as pm, prophet_scorer as ps
+    import glob
+    N, T, H = 24, 400, 30
+    for kind, prophet in (('reference', None), ('cfg2', {'growth': 'linear', 'seasonality_mode': 'additive', 'yearly_seasonality': True})):
+        ds, y = synth.make_panel(N, T, 'logistic' if prophet is None else 'linear', seed=21)
+        stamps = pd.DatetimeIndex(ds.astype('datetime64[ns]')).strftime('%Y-%m-%d %H:%M:%S').values
+        root = tmp_path / kind / 'model-input'
+        for n in range(N):
+            d = root / ('series_id=%d' % (100 + n))
+            d.mkdir(parents=True)
+            t0 = 30 if n % 5 == 3 else 0                      # some series start a month later (their own calendar)
+            (d / 'part-00000.csv').write_text('\n'.join('%d,%s,%d' % (1 + n % 2, s, v) for s, v in zip(stamps[t0:], y[n][t0:])) + '\n')
+        out = {}
+        for tag, chunks in (('whole', 1), ('chunked', 5)):
+            mcfg = {'io': {'input': str(root), 'models': str(tmp_path / kind / ('models_' + tag)), 'chunks': chunks},
+                    'model': {'floor': 0, 'cap_multiplier': 1.1, 'schedule_from_previous_models': False}}
+            if prophet:
+                mcfg['model']['prophet'] = prophet
+            scfg = {'io': {'models': mcfg['io']['models'], 'forecasts': str(tmp_path / kind / ('fc_' + tag))},
+                    'forecast': {'periods': H, 'frequency': 'D'}}
+            assert pm.ProphetModeler.model(None, mcfg, return_frame=False) is None
+            assert ps.ProphetScorer.score(None, scfg) is None
+            models = pd.read_parquet(mcfg['io']['models']).sort_values(['series_id', 'dim_id']).reset_index(drop=True)
+            fcs = pd.concat([pd.read_csv(f) for f in sorted(glob.glob(scfg['io']['forecasts'] + '/*.csv'))], ignore_index=True)
+            fcs = fcs.sort_values(['series_id', 'dim_id', 'forecast_timestamp']).reset_index(drop=True)
+            out[tag] = (models, fcs.drop(columns=['created_timestamp']))
+            assert len(glob.glob(mcfg['io']['models'] + '/*.parquet')) == (5 if tag == 'chunked' else 1)
+        assert len(out['whole'][0]) == N and len(out['whole'][1]) == N * H
+        assert [bytes(b) for b in out['whole'][0]['model']] == [bytes(b) for b in out['chunked'][0]['model']]
+        assert out['whole'][1].equals(out['chunked'][1])
+        # ... and against the oracle: three series of the chunked run, one of them on the late calendar
+        seas = fc.ModelSpec.auto_seasonalities(ds, seasonality_mode='multiplicative') if prophet is None else \
+            [{'name': 'yearly', 'period': 365.25, 'fourier_order': 10}, {'name': 'weekly', 'period': 7, 'fourier_order': 3}]
+        mode = 'multiplicative' if prophet is None else 'additive'
+        csp = cl.make_spec(growth='logistic' if prophet is None else 'linear',
+                           seasonalities=[(s['period'], s['fourier_order'], mode, 10.0) for s in seas],
+                           eval_mode=int(prophet is not None))
+        fut = ds[-1] + synth.DAY_NS * np.arange(1, H + 1)
+        for n in (0, 3, 17):
+            t0 = 30 if n % 5 == 3 else 0
+            cap = float(np.float32(y[n][t0:].max() * 1.1))            # (the cap crosses the model frame as float32, :35-36)
+            o = cl.fit(csp, ds[t0:], y[n][t0:].astype(np.float64), 0.0, y[n][t0:].max() * 1.1)
+            yo, _ = cl.predict(csp, o, fut, 0.0, cap)
+            got = out['chunked'][1].query('series_id == %d' % (100 + n))['forecast_quantity'].to_numpy()
+            assert np.array_equal(got, np.maximum(np.trunc(yo), 0).astype(np.int64)), (kind, n)
+    capsys.readouterr()
+
+
 def test_permissive_input_mode_end_to_end(env, tmp_path):
     """io.input_mode: PERMISSIVE through the whole training job (round-3 advice: one malformed line used to come
     out as the key (series_id, dim_id = 0) and abort the run with 'less than 2 non-NaN rows', or merge into a real

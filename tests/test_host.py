@@ -18,9 +18,13 @@ from time_series_spark_amd.jobs import prophet_modeler as pm, prophet_scorer as 
 
 def test_library_loads_and_exports_every_declared_symbol(built):
     L = _lib.load()
+    # include/tsf.h: the drop-in surface; include/tsf_dev.h: what tests and measurements need on top of it
     hdr = open(os.path.join(helpers.ROOT, 'include', 'tsf.h')).read()
-    declared = set(re.findall(r'\b(tsf_[a-z_A-Z0-9]+)\s*\(', hdr))
+    dev = open(os.path.join(helpers.ROOT, 'include', 'tsf_dev.h')).read()
+    surface = set(re.findall(r'\b(tsf_[a-z_A-Z0-9]+)\s*\(', hdr))
+    declared = surface | set(re.findall(r'\b(tsf_[a-z_A-Z0-9]+)\s*\(', dev))
     assert declared == set(_lib.EXPORTS)
+    assert not surface & {'tsf_set_option', 'tsf_get_option', 'tsf_eval', 'tsf_design', 'tsf_profile_read'}
     for sym in declared:
         assert hasattr(L, sym), sym
     assert L.tsf_spec_size() == ctypes.sizeof(_lib.TsfSpec)
@@ -1006,3 +1010,286 @@ def test_no_stream_ordered_allocation_in_product_paths():
     q = open(os.path.join(root, 'tsf_inst_quad.hip')).read()
     # ... and there only under the debug switch
     assert 'dbg_async & 1' in q and q.count('hipMallocAsync(') == 1 and q.count('hipFreeAsync(') == 1
+
+
+# ---- round 6: the jobs as pipelines, blobs and panel flags written by the library ---------------------------------
+
+def _blob_reference(spec_dict, theta, y_scale, grid, last_ds_ns, status, n_iter):
+    """numpy statement of the blob layout (panel.py, version 2): what tsf_model_blobs must write."""
+    theta = np.atleast_2d(np.asarray(theta, dtype=np.float64))
+    N, nth = theta.shape
+    ntc = int(grid['S'].max()) if len(grid) else 0
+    rec = np.zeros(N, dtype=pk._rec_dtype(nth, ntc))
+    rec['y_scale'] = y_scale
+    for f in ('start_ns', 't_scale_ns', 'T', 'S', 'i1', 'NT'):
+        rec[f] = grid[f]
+    rec['last_ds_ns'], rec['status'], rec['n_iter'] = last_ds_ns, status, n_iter
+    rec['n_theta'], rec['n_tchange'] = nth, ntc
+    rec['theta'] = theta
+    rec['t_change'] = grid['t_change'][:, :ntc]
+    body, L, pre = rec.tobytes(), rec.dtype.itemsize, pk._prefix(spec_dict)
+    return [pre + body[i * L:(i + 1) * L] for i in range(N)]
+
+
+def test_model_blobs_written_by_the_library_match_the_numpy_layout(built, tmp_path):
+    rng = np.random.default_rng(3)
+    spec = fc.ModelSpec(growth='logistic', seasonality_mode='multiplicative', seasonalities=[helpers.WEEKLY])
+    for N, n_grids in ((1, 1), (5, 1), (5, 5), (3000, 1), (3000, 3000)):
+        grid = np.zeros(n_grids, dtype=_lib.GRID_DTYPE)
+        grid['S'] = rng.integers(1, 26, n_grids)
+        grid['T'], grid['NT'], grid['i1'] = 730, 12, 729
+        grid['start_ns'] = rng.integers(0, 2 ** 60, n_grids)
+        grid['t_scale_ns'] = rng.integers(1, 2 ** 50, n_grids)
+        grid['t_change'] = rng.random((n_grids, _lib.MAX_S + 4))
+        theta = rng.standard_normal((N, spec.theta_stride))
+        args = (spec.to_dict(), theta, rng.random(N) + 1, grid, rng.integers(0, 2 ** 60, N),
+                rng.integers(-3, 40, N).astype(np.int32), rng.integers(1, 9000, N).astype(np.int32))
+        want = _blob_reference(*args)
+        buf = pk.dump_models_buffer(*args)
+        assert buf.dtype == np.uint8 and buf.shape == (N, len(want[0]))
+        assert pk.dump_models(*args) == want and [bytes(r) for r in buf] == want
+        # the buffer is an Arrow binary column as it stands, survives parquet, and loads without a Python object per series
+        import pyarrow as pa
+        import pyarrow.parquet as pq
+        col = pk.model_column_arrow(buf)
+        assert col.to_pylist() == want
+        pq.write_table(pa.table({'model': col}), str(tmp_path / 'm.parquet'), row_group_size=max(1, N // 3))
+        back = pq.read_table(str(tmp_path / 'm.parquet')).column('model')
+        view = pk.model_column_buffer(back)
+        assert view is not None and np.array_equal(view, buf)
+        for source in (buf, want, view):
+            (sd, pos, rec), = pk.load_models(source)
+            assert sd == spec.to_dict() and np.array_equal(pos, np.arange(N))
+            assert np.array_equal(rec['theta'], theta) and np.array_equal(rec['status'], args[5])
+    # blobs of different lengths / a null: no buffer view, the list path takes over
+    import pyarrow as pa
+    assert pk.model_column_buffer(pa.array([b'ab', b'abc'])) is None
+    assert pk.model_column_buffer(pa.array([b'ab', None])) is None
+
+
+def test_packer_reports_calendar_infinity_and_integer_flags(built):
+    day = np.int64(86400) * 10 ** 9
+    sid = np.repeat(np.arange(4, dtype=np.int64), 5)
+    did = np.ones(20, dtype=np.int64)
+    ds = np.tile(np.arange(5, dtype=np.int64) * day, 4)
+    y = np.arange(20, dtype=np.float64)
+    p = pk.pack_rows(sid, did, ds, y)
+    assert p.aligned and not p.has_inf and p.integral and p.y2d.shape == (4, 5)
+    assert np.array_equal(p.ds_grid, ds[:5])
+    ds2 = ds.copy()
+    ds2[17] += 1                                       # one timestamp of the last series moved
+    p = pk.pack_rows(sid, did, ds2, y)
+    assert not p.aligned and p.y2d is None
+    y2 = y.copy()
+    y2[3] = 0.5
+    y2[11] = np.inf
+    p = pk.pack_rows(sid, did, ds, y2)
+    assert p.aligned and p.has_inf and not p.integral
+    y3 = y.copy()
+    y3[4] = 2.0 ** 31                                  # an integer that does not fit int32
+    assert not pk.pack_rows(sid, did, ds, y3).integral
+    # the flags describe the PACKED rows: shuffled input, a null row dropped from one series -> lengths differ
+    o = np.random.default_rng(0).permutation(20)
+    p = pk.pack_rows(sid[o], did[o], ds[o], y[o])
+    assert p.aligned and p.integral and np.array_equal(p.y2d, y.reshape(4, 5))
+    y4 = y.copy()
+    y4[7] = np.nan
+    p = pk.pack_rows(sid, did, ds, y4)
+    assert not p.aligned and list(p.lengths) == [5, 4, 5, 5]
+    # several Python threads in the packer at once (the jobs' pipeline stages share the library's thread pool)
+    import concurrent.futures
+    big_sid = np.repeat(np.arange(3000, dtype=np.int64), 40)
+    big_ds = np.tile(np.arange(40, dtype=np.int64) * day, 3000)
+    big_y = np.arange(120000, dtype=np.float64)
+    with concurrent.futures.ThreadPoolExecutor(max_workers=6) as ex:
+        got = list(ex.map(lambda k: pk.pack_rows(big_sid, np.full(120000, k, np.int64), big_ds, big_y + k), range(12)))
+    for k, g in enumerate(got):
+        assert g.N == 3000 and g.aligned and np.array_equal(g.y2d, (big_y + k).reshape(3000, 40))
+        assert (g.keys['dim_id'] == k).all() and np.array_equal(g.stats[2], (big_y + k).reshape(3000, 40).max(axis=1))
+
+
+def test_pipeline_keeps_order_and_hands_the_first_error_to_the_caller():
+    from time_series_spark_amd import pipeline
+    import time as _t
+    seen = []
+
+    def slow(x):
+        _t.sleep(0.002 * (x % 3))
+        return x * 10
+
+    out = pipeline.run_pipeline(iter(range(17)), [slow, lambda v: (seen.append(v), v + 1)[1]], depth=2)
+    assert out == [x * 10 + 1 for x in range(17)] and seen == [x * 10 for x in range(17)]
+    assert pipeline.run_pipeline(iter(()), [slow]) == []
+
+    def bad(x):
+        if x == 5:
+            raise KeyError('chunk 5')
+        return x
+
+    with pytest.raises(KeyError):
+        pipeline.run_pipeline(iter(range(100)), [bad, slow])
+
+    def source():
+        yield 1
+        raise OSError('cannot list')
+
+    with pytest.raises(OSError):
+        pipeline.run_pipeline(source(), [slow])
+
+
+def test_clear_directory_moves_the_old_run_aside_and_deletes_it(tmp_path):
+    from time_series_spark_amd import pipeline
+    d = tmp_path / 'models'
+    d.mkdir()
+    (d / 'part-00000.parquet').write_bytes(b'x' * 1000)
+    wait = pipeline.clear_directory(str(d))
+    assert d.is_dir() and list(d.iterdir()) == []
+    (d / 'new').write_text('1')
+    wait()
+    assert sorted(p.name for p in tmp_path.iterdir()) == ['models'] and (d / 'new').exists()
+    assert pipeline.clear_directory(str(tmp_path / 'fresh'))() is None and (tmp_path / 'fresh').is_dir()
+
+
+def _fake_gpu(monkeypatch):
+    """Stand-ins for the GPU calls whose results depend on the data, so that 'the same models' means something."""
+    def fit(spec, N, grid_n, ymean, T):
+        g = np.zeros(grid_n, dtype=_lib.GRID_DTYPE)
+        g['S'], g['T'], g['NT'] = 3, T, (T + 63) // 64
+        g['t_scale_ns'] = 1
+        th = np.zeros((N, spec.theta_stride))
+        th[:, 0] = ymean
+        return fc.FitResult(spec, th, np.asarray(ymean) + 1.0, np.zeros(N), np.full(N, 31, np.int32),
+                            (np.asarray(ymean) % 7 + 1).astype(np.int32), np.ones(N, np.int32), g)
+
+    def fake_aligned(spec, ds_ns, y, floor=None, cap=None, extra=None, ctx=None, devices=None, cost_hints=None):
+        return fit(spec, len(y), 1, np.asarray(y, dtype=np.float64).mean(axis=1), y.shape[1])
+
+    def fake_ragged(spec, offsets, ds_ns, y, floor=None, cap=None, extra=None, ctx=None, devices=None, cost_hints=None):
+        m = np.add.reduceat(np.asarray(y, dtype=np.float64), offsets[:-1]) / np.diff(offsets)
+        return fit(spec, len(offsets) - 1, len(offsets) - 1, m, int(np.diff(offsets).max()))
+
+    def fake_predict(spec, theta, y_scale, grid, fut, floor=None, cap=None, extra_future=None, want_int=False, ctx=None,
+                     devices=None):
+        H = np.shape(fut)[-1]
+        yh = theta[:, :1] + np.arange(H)[None, :] + 0.5
+        return (yh, np.maximum(np.trunc(yh), 0).astype(np.int32)) if want_int else yh
+
+    monkeypatch.setattr(fc, 'fit_aligned', fake_aligned)
+    monkeypatch.setattr(fc, 'fit_ragged', fake_ragged)
+    monkeypatch.setattr(fc, 'predict', fake_predict)
+
+
+def _write_hive_input(root, n_series, T, two_dims=()):
+    day = np.datetime64('2020-01-01T00:00:00', 's')
+    for s in range(n_series):
+        d = root / ('series_id=%d' % (s * 3 + 1))
+        d.mkdir(parents=True)
+        rows = []
+        for dim in ((1, 2) if s in two_dims else (1,)):
+            rows += ['%d,%s,%d' % (dim, str(day + np.timedelta64(i, 'D')).replace('T', ' '), 10 + (s * 7 + i * dim) % 23)
+                     for i in range(T - (s % 2))]
+        (d / 'part-00000.csv').write_text('\n'.join(rows) + '\n')
+
+
+def test_jobs_run_as_pipelines_over_chunks_with_the_same_results(built, tmp_path, monkeypatch, capsys):
+    """ProphetModeler.model over ranges of partition directories (io.chunks) and ProphetScorer.score over the row groups
+    of the model parts write what the whole-input runs write: same models (series by series), same forecast rows."""
+    _fake_gpu(monkeypatch)
+    _write_hive_input(tmp_path / 'in', 11, 120, two_dims=(2, 5))
+    base = {'model': {'floor': 0, 'cap_multiplier': 1.1, 'prophet': {'growth': 'linear', 'seasonality_mode': 'additive'}}}
+    out = {}
+    for tag, chunks in (('whole', 1), ('chunked', 4), ('auto', 'auto')):
+        cfg = dict(base, io={'input': str(tmp_path / 'in'), 'models': str(tmp_path / ('m_' + tag)), 'chunks': chunks})
+        frame = pm.ProphetModeler.model(None, cfg)
+        assert pm.ProphetModeler.model(None, cfg, return_frame=False) is None          # (second run: overwrites, uses the hints)
+        parts = sorted(f for f in os.listdir(cfg['io']['models']) if f.endswith('.parquet'))
+        assert len(parts) == (4 if tag == 'chunked' else 1)
+        assert [f for f in os.listdir(tmp_path) if '.old-' in f] == []                # nothing of the overwritten run left
+        back = pd.read_parquet(cfg['io']['models']).sort_values(['series_id', 'dim_id']).reset_index(drop=True)
+        assert list(back.columns) == pm.MODEL_OUTPUT_COLUMNS and len(back) == 13
+        assert (back.dtypes[['series_id', 'dim_id', 'floor', 'cap']].astype(str) == ['int32', 'int32', 'float32', 'float32']).all()
+        f2 = frame.sort_values(['series_id', 'dim_id']).reset_index(drop=True)
+        assert list(f2['model']) == list(back['model']) and np.array_equal(f2['cap'].astype('float32'), back['cap'])
+        side = pm.previous_run_cost(cfg['io']['models'], sidecar_only=True)
+        assert side is not None and len(side) == 13
+        blobs = pm.previous_run_cost(back)
+        assert np.array_equal(side.sort_values(['series_id', 'dim_id'])['cost'].to_numpy(), blobs['cost'].to_numpy())
+        out[tag] = back
+    assert out['whole'].equals(out['chunked']) and out['whole'].equals(out['auto'])
+    # the scorer: one pass over the row groups of every part; the CSV parts together = the single-file sink
+    monkeypatch.setattr(pm, 'MODEL_ROW_GROUP', 4)
+    monkeypatch.setattr(ps, 'SINK_PART_ROWS', 25)
+    cfg = dict(base, io={'input': str(tmp_path / 'in'), 'models': str(tmp_path / 'm_rg'), 'chunks': 2})
+    pm.ProphetModeler.model(None, cfg, return_frame=False)
+    import pyarrow.parquet as pq
+    assert [pq.ParquetFile(os.path.join(cfg['io']['models'], f)).num_row_groups
+            for f in sorted(os.listdir(cfg['io']['models'])) if f.endswith('.parquet')] == [2, 2]
+    scfg = {'io': {'models': cfg['io']['models'], 'forecasts': str(tmp_path / 'fc')},
+            'forecast': {'periods': 10, 'frequency': 'D'}}
+    assert ps.ProphetScorer.score(None, scfg) is None
+    parts = sorted(f for f in os.listdir(scfg['io']['forecasts']) if f.endswith('.csv'))
+    assert len(parts) >= 4
+    got = pd.concat([pd.read_csv(os.path.join(scfg['io']['forecasts'], f)) for f in parts], ignore_index=True)
+    sc = ps.ProphetScorer(dict(scfg, io=dict(scfg['io'], forecasts=str(tmp_path / 'fc_one'))))
+    created = got['created_timestamp'].iloc[0]
+    sc.write_converted(ps.forecast_panel(scfg)(pd.read_parquet(cfg['io']['models'])), created_timestamp=created)
+    want = pd.read_csv(os.path.join(str(tmp_path / 'fc_one'), 'part-00000.csv'))
+    key = ['series_id', 'dim_id', 'forecast_timestamp']
+    assert list(got.columns) == ps.CONVERTED_COLUMNS and len(got) == 130
+    assert got.sort_values(key).reset_index(drop=True).equals(want.sort_values(key).reset_index(drop=True))
+    # a partition directory below another one: the same series could sit in two ranges -> the tree is read whole
+    nested = tmp_path / 'in' / 'series_id=1' / 'series_id=99'
+    nested.mkdir()
+    (nested / 'x.csv').write_text('1,2020-01-01 00:00:00,5\n1,2020-01-02 00:00:00,6\n')
+    cfg = dict(base, io={'input': str(tmp_path / 'in'), 'models': str(tmp_path / 'm_nested'), 'chunks': 3})
+    frame = pm.ProphetModeler.model(None, cfg)
+    assert len(frame) == 14 and len([f for f in os.listdir(cfg['io']['models']) if f.endswith('.parquet')]) == 1
+    # a plain file among the root's children: not a Hive-only layout, read whole as well
+    (tmp_path / 'in' / 'loose.csv').write_text('8,1,2020-01-01 00:00:00,5\n8,1,2020-01-02 00:00:00,6\n')
+    frame = pm.ProphetModeler.model(None, cfg)
+    assert len(frame) == 15 and len([f for f in os.listdir(cfg['io']['models']) if f.endswith('.parquet')]) == 1
+    capsys.readouterr()
+
+
+def test_model_batch_frame_and_table_agree_with_dropped_and_retried_series(built, monkeypatch):
+    """fbprophet's rule inside fit_packed leaves pieces from several fit calls (L-BFGS, the Newton retry of its failures,
+    Newton for short series); ModelBatch turns them into the reference's frame and into an Arrow table: same rows."""
+    def result(spec, N, grid_n, status, mark):
+        g = np.zeros(grid_n, dtype=_lib.GRID_DTYPE)
+        g['S'] = 3
+        th = np.full((N, spec.theta_stride), float(mark))
+        return fc.FitResult(spec, th, np.ones(N), np.zeros(N), np.asarray(status, np.int32), np.full(N, mark, np.int32),
+                            np.ones(N, np.int32), g)
+
+    def fake_aligned(spec, ds_ns, y, floor=None, cap=None, extra=None, ctx=None, devices=None):
+        algo = spec.lbfgs.get('algorithm')
+        st = np.full(len(y), 31 if algo == _lib.ALGO_LBFGS else 60)
+        if algo == _lib.ALGO_LBFGS:
+            st[0] = -1                                       # first series: line search failed -> retried by Newton
+        return result(spec, len(y), 1, st, 1 if algo == _lib.ALGO_LBFGS else 2)
+
+    def fake_ragged(spec, offsets, ds_ns, y, floor=None, cap=None, extra=None, ctx=None, devices=None):
+        algo = spec.lbfgs.get('algorithm')
+        n = len(offsets) - 1
+        st = np.full(n, 60 if algo else 31)
+        if algo == _lib.ALGO_NEWTON and tuple(np.diff(offsets)) == (99,):
+            st[0] = _lib.ST_NEWTON_FAIL                      # the 99-row series fails under Newton: dropped
+        return result(spec, n, n, st, 3 if algo else 4)
+
+    monkeypatch.setattr(fc, 'fit_aligned', fake_aligned)
+    monkeypatch.setattr(fc, 'fit_ragged', fake_ragged)
+    day = np.datetime64('2020-01-01', 'ns') + np.arange(150).astype('timedelta64[D]')
+    rows = []
+    for sid, T in enumerate([150, 150, 150, 60, 60, 99]):
+        rows += [(sid, 1, d, 5 + (i * (sid + 1)) % 7) for i, d in enumerate(day[:T])]
+    df = pd.DataFrame(rows, columns=['series_id', 'dim_id', 'ds', 'y'])
+    cfg = {'model': {'floor': 0, 'cap_multiplier': 1.1, 'prophet': {'growth': 'linear', 'seasonality_mode': 'additive',
+                                                                     'min_aligned_group': 2}}}
+    batch = pm._model_packed(cfg, pk.pack_long_frame(df), len(df), 0.0)
+    assert isinstance(batch, pm.ModelBatch) and len(batch) == 5 and list(batch.keep) == [0, 1, 2, 3, 4]
+    frame, table = batch.to_frame(), batch.to_table()
+    assert list(frame['series_id']) == [0, 1, 2, 3, 4] and table.column('model').to_pylist() == list(frame['model'])
+    assert table.schema.names == pm.MODEL_OUTPUT_COLUMNS and str(table.schema.field('cap').type) == 'float'
+    marks = [pk.load_model(b)['theta'][0] for b in frame['model']]
+    assert marks == [3.0, 1.0, 1.0, 2.0, 2.0]               # retried by Newton (ragged call), L-BFGS, L-BFGS, Newton (short), Newton (short)
+    assert list(np.asarray(frame.attrs['tsf_cost'])) == [3, 1, 1, 2, 2]

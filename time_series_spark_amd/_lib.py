@@ -81,9 +81,9 @@ EXPORTS = ['tsf_create', 'tsf_destroy', 'tsf_last_error', 'tsf_device_count', 't
            'tsf_fit_aligned', 'tsf_fit_aligned_dev', 'tsf_fit_ragged', 'tsf_fit_ragged_dev',
            'tsf_predict', 'tsf_predict_dev', 'tsf_predict_intervals', 'tsf_predict_intervals_dev', 'tsf_eval', 'tsf_eval_quadratic', 'tsf_design', 'tsf_selftest_math',
            'tsf_set_option', 'tsf_get_option', 'tsf_set_cost_hints', 'tsf_set_profiling', 'tsf_profile_read', 'tsf_last_fit_kernel_ms', 'tsf_last_fit_route',
-           'tsf_pack_rows', 'tsf_pack_fetch', 'tsf_pack_free',
+           'tsf_pack_rows', 'tsf_pack_fetch', 'tsf_pack_flags', 'tsf_pack_free', 'tsf_model_blobs',
            'tsf_csv_read', 'tsf_csv_fetch', 'tsf_csv_columns', 'tsf_csv_malformed', 'tsf_csv_free', 'tsf_csv_write_forecasts', 'tsf_csv_write_forecasts_i32',
-           'tsf_csv_discover', 'tsf_csv_discover_load', 'tsf_csv_read_loaded', 'tsf_csv_dir_paths', 'tsf_csv_dir_series_id', 'tsf_csv_dir_error_path', 'tsf_csv_dir_free']
+           'tsf_csv_discover', 'tsf_csv_discover_load', 'tsf_csv_root_open', 'tsf_csv_root_load', 'tsf_csv_root_free', 'tsf_csv_read_loaded', 'tsf_csv_dir_paths', 'tsf_csv_dir_series_id', 'tsf_csv_dir_error_path', 'tsf_csv_dir_free']
 
 CSV_E_OPEN, CSV_E_PARSE, CSV_E_CODEC = -10, -11, -12          # TSF_CSV_E_* (include/tsf.h)
 
@@ -149,8 +149,10 @@ def load():
     L.tsf_pack_rows.argtypes = [i64, vp, vp, vp, vp, i32, ctypes.POINTER(vp), ctypes.POINTER(i64),
                                 ctypes.POINTER(i64), ctypes.POINTER(i32)]
     L.tsf_pack_fetch.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.tsf_pack_flags.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32)]
     L.tsf_pack_free.argtypes = [vp]
     L.tsf_pack_free.restype = None
+    L.tsf_model_blobs.argtypes = [i64, vp, i32, i32, vp, vp, vp, i32, vp, vp, vp, i32, vp, i32]
     L.tsf_csv_read.argtypes = [i32, vp, vp, ctypes.c_char_p, i32,
                                ctypes.POINTER(vp), ctypes.POINTER(i64), ctypes.POINTER(i32),
                                ctypes.POINTER(i64)]
@@ -160,6 +162,11 @@ def load():
     L.tsf_csv_discover_load.argtypes = L.tsf_csv_discover.argtypes
     L.tsf_csv_read_loaded.argtypes = [vp, i32, i32, ctypes.c_char_p, i32, ctypes.POINTER(vp), ctypes.POINTER(i64),
                                       ctypes.POINTER(i32), ctypes.POINTER(i64)]
+    L.tsf_csv_root_open.argtypes = [ctypes.c_char_p, ctypes.POINTER(vp), ctypes.POINTER(i32), ctypes.POINTER(i32)]
+    L.tsf_csv_root_load.argtypes = [vp, i32, i32, i32, ctypes.POINTER(vp), ctypes.POINTER(i32), ctypes.POINTER(i32),
+                                    ctypes.POINTER(i32)]
+    L.tsf_csv_root_free.argtypes = [vp]
+    L.tsf_csv_root_free.restype = None
     L.tsf_csv_dir_paths.argtypes = [vp]
     L.tsf_csv_dir_paths.restype = vp
     L.tsf_csv_dir_series_id.argtypes = [vp]

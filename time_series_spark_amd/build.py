@@ -29,6 +29,7 @@ def _hipcc():
 def _newest_header():
     hs = glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(CSRC, '*.inc'))
     hs.append(os.path.join(HERE, '..', 'include', 'tsf.h'))
+    hs.append(os.path.join(HERE, '..', 'include', 'tsf_dev.h'))
     return max(os.path.getmtime(h) for h in hs)
 
 

@@ -466,12 +466,26 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
         // Round 5: a model whose Fourier columns have a compiled expansion reads 32-byte base pairs per row from its OWN
         // tables (eval_fg HARM) -- faster than the gathered 224-byte rows of the lattice table in the one-wave kernel (ragged
         // bench panel, a grid per series: 93 -> 60 ms) and, above all, in the cooperative tail (gathered rows stream: 11 us
-        // per evaluation against 5) -- wherever a table per series is affordable (<= 32 GB of design tables per call: ~190 000 series of 730 rows).
+        // per evaluation against 5) -- wherever a table per series is affordable: <= 32 GB of design tables per call
+        // (~190 000 series of 730 rows) AND no more than two fifths of the memory this context can have (what is free
+        // now + its own cached workspace; the tables are ~4/5 of the layout): several contexts or ranks on one GPU, or
+        // a smaller part, keep the shared lattice table -- the route that needs no table per series -- instead of
+        // failing in ensure_ws (round-5 advice).
         const int el = ctx->opt[TSF_OPT_LATTICE];
         const size_t tab = sizeof(double) * (size_t)n_grids * (size_t)NTmax * hs.KP * W;
         const bool harm_model = ctx->opt[TSF_OPT_HARM] != 0 && mode != 2 &&
                                 ((hs.harm == HARM_Y10_W3 && hs.KP == 28) || (hs.harm == HARM_W3_D4 && hs.KP == 16) || (hs.harm == HARM_W3 && hs.KP == 8));
-        if (el >= 0 ? el == 0 : ((grid_of != nullptr && tab <= ((size_t)64 << 20)) || (harm_model && tab <= ((size_t)32 << 30)))) lat_U = 0;
+        size_t harm_cap = (size_t)32 << 30;
+        if (lat_U > 0 && el < 0 && harm_model && tab > ((size_t)256 << 20)) {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                const size_t mine = (free_b + ctx->ws_bytes) / 5 * 2;
+                if (mine < harm_cap) harm_cap = mine;
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+        if (el >= 0 ? el == 0 : ((grid_of != nullptr && tab <= ((size_t)64 << 20)) || (harm_model && tab <= harm_cap))) lat_U = 0;
     }
     // matrix-core residual kernel (tsf_mfma_kernels.h): aligned panel, L-BFGS, one parameter per lane
     // (KP <= 28 implies one column mode and P <= 64), at most MT_SP changepoints, and an upper bound
@@ -593,6 +607,9 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
         HIP_TRY(ctx, hipGetLastError());
     } else {
         HIP_TRY(ctx, hipMemsetAsync(Xw, 0, sizeof(double) * (size_t)n_grids * NTmax * hs.KP * W, st));
+        // (the base pairs too: rows past a chunk's end are (0, 0) -- every harmonic 0 --, never stale bits that could be
+        // NaN or Inf under an `fma(x, 0, acc)` that relies on finite x; round-5 advice)
+        if (bw_ns) HIP_TRY(ctx, hipMemsetAsync(ws + l.Bw, 0, sizeof(double) * (size_t)n_grids * NTmax * bw_ns * 2 * W, st));
     }
     HIP_TRY(ctx, hipMemsetAsync(gtab, 0, sizeof(GridTab) * (size_t)n_grids, st));
     hipLaunchKernelGGL(setup_grid_kernel, dim3((unsigned)n_grids), dim3(256), 0, st, ctx->d_spec,

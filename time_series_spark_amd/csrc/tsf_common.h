@@ -25,7 +25,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "../../include/tsf.h"
+#include "../../include/tsf_dev.h"
 #include "tsf_detmath.h"
 
 namespace tsf {

@@ -37,6 +37,7 @@
 #include <vector>
 
 #include "../../include/tsf.h"
+#include "tsf_pool.h"
 
 namespace {
 
@@ -56,6 +57,48 @@ struct SegOut {
 };
 
 // file contents: one uninitialised allocation (a std::vector would zero 170 MB first)
+// Large host blocks of the reader -- the 8 MB chunks its threads read file bytes into, the table of parsed columns --
+// are kept by the process between uses (round 6), up to TSF_HOST_CACHE_MB megabytes (default 768; 0: never): a block that
+// comes back from here is mapped and its pages are resident, where a fresh one costs a page fault and the zeroing of every
+// 2 MB page it touches and, later, their unmapping -- measured on the GPU box at a quarter of the read stage for
+// 10 000 x 730 rows (profiles/r06_host/).  The jobs' pipelines read chunk k + 2 into what chunk k was read into, and a
+// process that runs the job again (a service, a reused Python worker) starts with warm blocks.  Exact sizes only.
+struct HostCache {
+    struct Entry { void *p; size_t bytes; };
+    static std::mutex &mu() { static std::mutex m; return m; }
+    static std::vector<Entry> &list() { static std::vector<Entry> *l = new std::vector<Entry>(); return *l; }
+    static size_t &held() { static size_t h = 0; return h; }
+    static size_t limit() {
+        static const size_t lim = [] {
+            const char *e = std::getenv("TSF_HOST_CACHE_MB");
+            const long v = e ? std::atol(e) : 768;
+            return (size_t)(v < 0 ? 0 : v) << 20;
+        }();
+        return lim;
+    }
+    static void *take(size_t bytes) {
+        std::lock_guard<std::mutex> lk(mu());
+        auto &l = list();
+        for (size_t i = l.size(); i-- > 0;)
+            if (l[i].bytes == bytes) {
+                void *p = l[i].p;
+                held() -= bytes;
+                l[i] = l.back();
+                l.pop_back();
+                return p;
+            }
+        return nullptr;
+    }
+    static bool keep(void *p, size_t bytes) {
+        if (!p || bytes == 0) return false;
+        std::lock_guard<std::mutex> lk(mu());
+        if (held() + bytes > limit()) return false;
+        list().push_back(Entry{p, bytes});
+        held() += bytes;
+        return true;
+    }
+};
+
 // Bump allocator of one reader thread: the bytes of the files it reads go side by side into 8 MB chunks on
 // transparent huge pages.  (One malloc per file -- 10 000 x 146 KB, each its own mmap above glibc's threshold -- was
 // 36 000 page faults and 20 000 map / unmap calls contending for the process's mmap lock: 15 ms in a bare process,
@@ -74,9 +117,12 @@ struct Arena {
         bytes = (bytes + 63) & ~(size_t)63;
         if (bytes > CHUNK / 4) return nullptr;
         if (bytes > left) {
-            void *c = nullptr;
-            if (posix_memalign(&c, HUGE, CHUNK) != 0) return nullptr;
-            (void)::madvise(c, CHUNK, MADV_HUGEPAGE);
+            void *c = HostCache::take(CHUNK);
+            if (!c) {
+                if (posix_memalign(&c, HUGE, CHUNK) != 0) return nullptr;
+                static const bool thp = !(std::getenv("TSF_CSV_THP") && std::atoi(std::getenv("TSF_CSV_THP")) == 0);   // (dev: probe)
+                if (thp) (void)::madvise(c, CHUNK, MADV_HUGEPAGE);
+            }
             chunks.push_back(c);
             cur = (char *)c; left = CHUNK;
         }
@@ -94,6 +140,15 @@ struct Reaper {
     static bool enabled() {
         static const bool on = !(std::getenv("TSF_CSV_BG_FREE") && std::atoi(std::getenv("TSF_CSV_BG_FREE")) == 0);
         return on;
+    }
+    // arena chunks: to the process's cache while it has room, the rest back to the system
+    static void give_chunks(std::vector<void *> &&chunks) noexcept {
+        std::vector<void *> rest;
+        for (void *c : chunks)
+            if (!HostCache::keep(c, Arena::CHUNK)) rest.push_back(c);
+        chunks.clear();
+        if (enabled()) give(std::move(rest));
+        else for (void *c : rest) std::free(c);
     }
     static void give(std::vector<void *> &&blocks) noexcept {
         if (blocks.empty()) return;
@@ -424,6 +479,7 @@ struct tsf_csv {
     int64_t *sid = nullptr, *did = nullptr, *ds = nullptr;     // the table: one block, [cap] rows per column
     double *y = nullptr;
     void *block = nullptr;
+    size_t block_bytes = 0;         // > 0: a 2 MB-aligned block of that size (HostCache takes it back)
     int64_t n_rows = 0, malformed = 0;
     int n_threads = 1;
     ~tsf_csv() { std::free(block); }
@@ -450,10 +506,13 @@ void run_workers_w(int n_threads, int64_t n_items, std::atomic<int> &oom, F item
         worker(0);
         return;
     }
-    std::vector<std::thread> th;
-    int k = (int64_t)n_threads < n_items ? n_threads : (int)n_items;
-    for (int i = 0; i < k; ++i) th.emplace_back(worker, i);
-    for (auto &x : th) x.join();
+    // (the library's pool, tsf_pool.h: a phase used to start and join its own threads -- ten times per job)
+    const int k = (int64_t)n_threads < n_items ? n_threads : (int)n_items;
+    try {
+        tsfpool::Pool::get().run(k, worker);
+    } catch (...) {
+        oom.store(1);
+    }
 }
 
 template <class F>
@@ -550,9 +609,13 @@ static int read_impl(int32_t n_files, const char *const *paths, const int64_t *s
             // one block for the table, on transparent huge pages where the system grants them: 234 MB of 4 KB pages
             // are 57 000 page faults while the rows are written and 50 ms of unmapping when the table is freed
             const size_t bytes = (size_t)(cap > 0 ? cap : 1) * 32, huge = (size_t)2 << 20;
-            if (bytes >= 4 * huge && posix_memalign(&t->block, huge, (bytes + huge - 1) / huge * huge) == 0)
-                (void)::madvise(t->block, (bytes + huge - 1) / huge * huge, MADV_HUGEPAGE);
-            else
+            const size_t rounded = (bytes + huge - 1) / huge * huge;
+            if (bytes >= 4 * huge && (t->block = HostCache::take(rounded)) != nullptr)
+                t->block_bytes = rounded;
+            else if (bytes >= 4 * huge && posix_memalign(&t->block, huge, rounded) == 0) {
+                (void)::madvise(t->block, rounded, MADV_HUGEPAGE);
+                t->block_bytes = rounded;
+            } else
                 t->block = std::malloc(bytes);
         }
         if (!t->block) { delete t; return -2; }
@@ -600,15 +663,10 @@ static int read_impl(int32_t n_files, const char *const *paths, const int64_t *s
             // the file buffers go back in parallel too: 10 000 frees are 20 ms on one thread, 4 ms on the pool
             const double t_a = timing ? now() : 0.0;
             run_workers(t->n_threads, n_files, oom, [&](int64_t i) { bufs[(size_t)i].release(); });
-            if (Reaper::enabled()) {
+            {
                 std::vector<void *> all;
                 for (Arena &a : arenas) { all.insert(all.end(), a.chunks.begin(), a.chunks.end()); a.chunks.clear(); }
-                Reaper::give(std::move(all));
-            } else {
-                run_workers(t->n_threads, (int64_t)arenas.size(), oom, [&](int64_t i) {
-                    for (void *c : arenas[(size_t)i].chunks) std::free(c);
-                    arenas[(size_t)i].chunks.clear();
-                });
+                Reaper::give_chunks(std::move(all));
             }
             if (timing) std::fprintf(stderr, "[csv-timing] releasing the file buffers %.1f ms\n", now() - t_a);
         }
@@ -678,6 +736,7 @@ int tsf_csv_fetch(tsf_csv *t, int64_t *series_id, int64_t *dim_id, int64_t *ds, 
 }
 
 void tsf_csv_free(tsf_csv *t) {
+    if (t && t->block && t->block_bytes && HostCache::keep(t->block, t->block_bytes)) t->block = nullptr;
     if (t && t->block && Reaper::enabled()) {
         std::vector<void *> b{t->block};
         t->block = nullptr;
@@ -698,16 +757,16 @@ struct tsf_csv_dir {
     std::vector<Arena> arenas;      // preload: the bytes of the files, read by the thread that listed their directory
     bool preloaded = false;
     ~tsf_csv_dir() {
-        if (!Reaper::enabled()) return;
         std::vector<void *> all;
         for (Arena &a : arenas) { all.insert(all.end(), a.chunks.begin(), a.chunks.end()); a.chunks.clear(); }
-        Reaper::give(std::move(all));
+        Reaper::give_chunks(std::move(all));
     }
     std::vector<const char *> paths;
     std::vector<int64_t> sids;
     int32_t n_part = 0;
     int err = 0;
     std::string err_path;
+    int nested = 0;                 // a `series_id=` directory below another one with a different value was seen
 };
 
 namespace {
@@ -721,7 +780,7 @@ bool has_suffix(const std::string &s, const char *suf) {
 
 // one directory: files appended to `out`, sub-directories to `dirs`
 void scan_dir(const std::string &d, int64_t sid, bool has, std::vector<tsf_csv_dir::Item> &out,
-              std::vector<tsf_csv_dir::Item> &dirs, int &err, std::string &err_path, Arena *arena) {
+              std::vector<tsf_csv_dir::Item> &dirs, int &err, std::string &err_path, Arena *arena, int *nested = nullptr) {
     DIR *h = ::opendir(d.c_str());
     if (!h) { err = TSF_CSV_E_OPEN; err_path = d; return; }
     while (struct dirent *e = ::readdir(h)) {
@@ -742,6 +801,7 @@ void scan_dir(const std::string &d, int64_t sid, bool has, std::vector<tsf_csv_d
                 errno = 0;
                 const long long q = std::strtoll(nm + 10, &end, 10);
                 if (end == nm + 10 || *end != '\0' || errno != 0) { err = TSF_CSV_E_PARSE; err_path = p; continue; }
+                if (has && q != sid && nested) *nested = 1;
                 v = q; hv = true;
             }
             dirs.push_back(tsf_csv_dir::Item{std::move(p), v, hv, FileBuf(), 0});
@@ -762,9 +822,12 @@ void scan_dir(const std::string &d, int64_t sid, bool has, std::vector<tsf_csv_d
 
 }  // namespace
 
+// start (or null): the walk begins at these entries -- directories with the partition value they carry, files as they are
+// -- instead of at `root` (tsf_csv_root_load: a range of the root's children)
 static int discover_impl(const char *root, int32_t n_threads, tsf_csv_dir **out, int32_t *n_files, int32_t *n_partitioned,
-                         bool preload) {
-    if (!root || !out) return -1;
+                         bool preload, const std::vector<tsf_csv_dir::Item> *start = nullptr,
+                         const std::vector<char> *start_is_dir = nullptr) {
+    if ((!root && !start) || !out) return -1;
     *out = nullptr;
     tsf_csv_dir *d = nullptr;
     static const bool timing = std::getenv("TSF_CSV_TIMING") != nullptr;
@@ -775,28 +838,49 @@ static int discover_impl(const char *root, int32_t n_threads, tsf_csv_dir **out,
         d = new tsf_csv_dir();
         struct stat sb;
         d->preloaded = preload;
-        if (::stat(root, &sb) == 0 && S_ISREG(sb.st_mode)) {
+        if (!start && ::stat(root, &sb) == 0 && S_ISREG(sb.st_mode)) {
             tsf_csv_dir::Item it{root, 0, false, FileBuf(), 0};
             if (preload) {
                 bool corrupt = false;
                 it.ok = read_whole(root, it.buf, &corrupt, nullptr) ? 1 : (corrupt ? 2 : 0);
             }
             d->items.push_back(std::move(it));
-        } else if (::stat(root, &sb) == 0 && S_ISDIR(sb.st_mode)) {
+        } else if (start || (::stat(root, &sb) == 0 && S_ISDIR(sb.st_mode))) {
             int hw = (int)std::thread::hardware_concurrency();
             if (hw < 1) hw = 1;
             const int nt = n_threads > 0 ? n_threads : (hw < 32 ? hw : 32);
-            std::string r(root);
-            while (r.size() > 1 && r.back() == '/') r.pop_back();
             // breadth first: the directories of one level are read by the pool, each thread into its own lists
             std::vector<tsf_csv_dir::Item> level;
-            level.push_back(tsf_csv_dir::Item{r, 0, false, FileBuf(), 0});
             if (preload) d->arenas = std::vector<Arena>((size_t)nt);
+            if (start) {
+                std::vector<size_t> plain;
+                for (size_t i = 0; i < start->size(); ++i) {
+                    const tsf_csv_dir::Item &s = (*start)[i];
+                    if ((*start_is_dir)[i]) level.push_back(tsf_csv_dir::Item{s.path, s.sid, s.has, FileBuf(), 0});
+                    else plain.push_back(i);
+                }
+                for (size_t i : plain) {          // files among the root's children (few, if any)
+                    const tsf_csv_dir::Item &s = (*start)[i];
+                    tsf_csv_dir::Item it{s.path, s.sid, s.has, FileBuf(), 0};
+                    bool codec = false;
+                    for (const char *suf : {".bz2", ".snappy", ".lz4", ".zst", ".xz"})
+                        if (has_suffix(it.path, suf)) { d->err = TSF_CSV_E_CODEC; d->err_path = it.path; codec = true; }
+                    if (preload && !codec) {
+                        bool corrupt = false;
+                        it.ok = read_whole(it.path.c_str(), it.buf, &corrupt, &d->arenas[0]) ? 1 : (corrupt ? 2 : 0);
+                    }
+                    d->items.push_back(std::move(it));
+                }
+            } else {
+                std::string r(root);
+                while (r.size() > 1 && r.back() == '/') r.pop_back();
+                level.push_back(tsf_csv_dir::Item{r, 0, false, FileBuf(), 0});
+            }
             while (!level.empty()) {
                 const int64_t n = (int64_t)level.size();
                 const int k = (int)std::min<int64_t>(nt, n);
                 std::vector<std::vector<tsf_csv_dir::Item>> files((size_t)k), dirs((size_t)k);
-                std::vector<int> errs((size_t)k, 0);
+                std::vector<int> errs((size_t)k, 0), nest((size_t)k, 0);
                 std::vector<std::string> eps((size_t)k);
                 std::atomic<int64_t> next(0);
                 auto work = [&](int w) {
@@ -804,17 +888,14 @@ static int discover_impl(const char *root, int32_t n_threads, tsf_csv_dir **out,
                         const int64_t i = next.fetch_add(1);
                         if (i >= n) break;
                         scan_dir(level[(size_t)i].path, level[(size_t)i].sid, level[(size_t)i].has, files[(size_t)w], dirs[(size_t)w],
-                                 errs[(size_t)w], eps[(size_t)w], preload ? &d->arenas[(size_t)w] : nullptr);
+                                 errs[(size_t)w], eps[(size_t)w], preload ? &d->arenas[(size_t)w] : nullptr, &nest[(size_t)w]);
                     }
                 };
                 if (k <= 1) work(0);
-                else {
-                    std::vector<std::thread> th;
-                    for (int w = 0; w < k; ++w) th.emplace_back(work, w);
-                    for (auto &x : th) x.join();
-                }
+                else tsfpool::Pool::get().run(k, work);
                 level.clear();
                 for (int w = 0; w < k; ++w) {
+                    if (nest[(size_t)w]) d->nested = 1;
                     if (errs[(size_t)w] && !d->err) { d->err = errs[(size_t)w]; d->err_path = eps[(size_t)w]; }
                     for (auto &it : files[(size_t)w]) d->items.push_back(std::move(it));
                     for (auto &it : dirs[(size_t)w]) level.push_back(std::move(it));
@@ -876,6 +957,79 @@ int tsf_csv_read_loaded(tsf_csv_dir *d, int32_t first, int32_t count, const char
         return -2;
     }
 }
+
+// ---- the input directory in chunks (round 6) -----------------------------------------------------
+// tsf_csv_root_open lists the CHILDREN of the input directory once; tsf_csv_root_load walks and loads the subtrees of a
+// range of them -- so that a job can read, fit and persist partition directories [0, c), [c, 2c), ... as a pipeline
+// (jobs/prophet_modeler.ProphetModeler.model: files of chunk k + 1 are read while chunk k is on the GPU and chunk k - 1
+// goes to parquet).  *hive_only = 1 when every child is a `series_id=<int>` directory and no value occurs twice: chunks
+// of children then hold disjoint sets of series, and fitting chunk by chunk fits every series once, on all its rows --
+// the layout the reference reads (tests/fixtures/model-input/series_id=751/...).  Anything else: read the tree whole.
+struct tsf_csv_root {
+    std::vector<tsf_csv_dir::Item> kids;      // sorted: partition directories by value, then the rest by name
+    std::vector<char> is_dir;
+    int hive_only = 0;
+};
+
+int tsf_csv_root_open(const char *root, tsf_csv_root **out, int32_t *n_children, int32_t *hive_only) {
+    if (!root || !out) return -1;
+    *out = nullptr;
+    try {
+        std::unique_ptr<tsf_csv_root> r(new tsf_csv_root());
+        struct stat sb;
+        if (::stat(root, &sb) != 0) return TSF_CSV_E_OPEN;
+        if (S_ISDIR(sb.st_mode)) {
+            std::string base(root);
+            while (base.size() > 1 && base.back() == '/') base.pop_back();
+            std::vector<tsf_csv_dir::Item> files, dirs;
+            int err = 0;
+            std::string ep;
+            scan_dir(base, 0, false, files, dirs, err, ep, nullptr);
+            if (err == TSF_CSV_E_OPEN) return TSF_CSV_E_OPEN;
+            bool hive = (err == 0) && files.empty() && !dirs.empty();
+            for (const auto &d : dirs) hive = hive && d.has;
+            std::sort(dirs.begin(), dirs.end(), [](const tsf_csv_dir::Item &a, const tsf_csv_dir::Item &b) {
+                if (a.has != b.has) return a.has;
+                if (a.has && a.sid != b.sid) return a.sid < b.sid;
+                return a.path < b.path;
+            });
+            for (size_t i = 1; i < dirs.size() && hive; ++i) hive = dirs[i].sid != dirs[i - 1].sid;
+            std::sort(files.begin(), files.end(), [](const tsf_csv_dir::Item &a, const tsf_csv_dir::Item &b) { return a.path < b.path; });
+            for (auto &d : dirs) { r->kids.push_back(std::move(d)); r->is_dir.push_back(1); }
+            for (auto &f : files) { r->kids.push_back(std::move(f)); r->is_dir.push_back(0); }
+            r->hive_only = hive ? 1 : 0;
+        }
+        if (n_children) *n_children = (int32_t)r->kids.size();
+        if (hive_only) *hive_only = r->hive_only;
+        *out = r.release();
+        return 0;
+    } catch (const std::bad_alloc &) {
+        return -2;
+    } catch (...) {
+        return -3;
+    }
+}
+
+int tsf_csv_root_load(tsf_csv_root *r, int32_t first, int32_t count, int32_t n_threads, tsf_csv_dir **out,
+                      int32_t *n_files, int32_t *n_partitioned, int32_t *nested) {
+    if (!r || !out || first < 0 || count < 0 || (size_t)first + (size_t)count > r->kids.size()) return -1;
+    try {
+        std::vector<tsf_csv_dir::Item> start;
+        std::vector<char> is_dir;
+        for (int32_t i = first; i < first + count; ++i) {
+            const tsf_csv_dir::Item &k = r->kids[(size_t)i];
+            start.push_back(tsf_csv_dir::Item{k.path, k.sid, k.has, FileBuf(), 0});
+            is_dir.push_back(r->is_dir[(size_t)i]);
+        }
+        const int rc = discover_impl(nullptr, n_threads, out, n_files, n_partitioned, true, &start, &is_dir);
+        if (nested) *nested = (*out) ? (*out)->nested : 0;
+        return rc;
+    } catch (const std::bad_alloc &) {
+        return -2;
+    }
+}
+
+void tsf_csv_root_free(tsf_csv_root *r) { delete r; }
 
 const char *const *tsf_csv_dir_paths(const tsf_csv_dir *d) { return d ? d->paths.data() : nullptr; }
 const int64_t *tsf_csv_dir_series_id(const tsf_csv_dir *d) { return d ? d->sids.data() : nullptr; }
@@ -957,11 +1111,13 @@ int write_forecasts(const char *path, const char *created_timestamp, int64_t n,
     if (hw < 1) hw = 1;
     const int nt = n_threads > 0 ? n_threads : (hw < 32 ? hw : 32);
     const size_t row_max = clen + 1 + 21 + 21 + 11 + 25 + 21 + 1;
-    // Blocks of 16 384 rows are formatted by the pool into buffers of their own (uninitialised: round 3 zero-filled
+    // Blocks of rows are formatted by the pool into buffers of their own (uninitialised: round 3 zero-filled
     // 16 buffers of 8.5 MB before the first row), their lengths prefix-summed, and every block then written at its
-    // offset by the thread that holds it (pwrite): 900 000 rows in 55 blocks instead of one turn of 14 threads and
-    // a serial fwrite of 60 MB.
-    const int64_t block = 1 << 14;
+    // offset by the thread that holds it (pwrite) instead of one turn of 14 threads and a serial fwrite of 60 MB.
+    // 16 384 rows per block for a file of a million rows; round 6: the scorer writes one part per chunk of models
+    // (~370 000 rows), whose 22 blocks left a third of the pool idle -- blocks shrink to 4 096 rows so that a part has at
+    // least ~3 per thread.
+    const int64_t block = n >= ((int64_t)1 << 22) ? (1 << 14) : (1 << 12);
     const int64_t nb = (n + block - 1) / block;
     bool ok = true;
     try {

@@ -28,6 +28,7 @@
 #include <cstdlib>
 
 #include "../../include/tsf.h"
+#include "tsf_pool.h"
 
 namespace {
 
@@ -85,32 +86,9 @@ struct KeyMap {
     }
 };
 
-// f(begin, end, thread_index) over static contiguous chunks.  An exception inside a worker
-// (allocation failure) is carried back to the caller as std::bad_alloc instead of terminating
-// the process.
-template <class F>
-void parallel_for(int64_t n, int n_threads, F f) {
-    if (n_threads <= 1) {
-        f((int64_t)0, n, 0);
-        return;
-    }
-    std::vector<std::thread> th;
-    std::atomic<int> failed(0);
-    int64_t per = (n + n_threads - 1) / n_threads;
-    for (int t = 0; t < n_threads; ++t) {
-        int64_t a = std::min<int64_t>(n, per * t), b = std::min<int64_t>(n, a + per);
-        if (a >= b) break;
-        th.emplace_back([=, &failed] {
-            try {
-                f(a, b, t);
-            } catch (...) {
-                failed.store(1);
-            }
-        });
-    }
-    for (auto &x : th) x.join();
-    if (failed.load()) throw std::bad_alloc();
-}
+// f(begin, end, piece_index) over static contiguous pieces, on the library's pool (tsf_pool.h).  An exception inside a
+// piece (allocation failure) comes back to the caller as std::bad_alloc instead of terminating the process.
+using tsfpool::parallel_for;
 
 // one packed row; stable scatter + stable sort keep ties in input order, so the input row
 // number itself is not needed
@@ -130,6 +108,9 @@ struct tsf_pack {
     std::vector<Key> keys;             // [n_series], ascending
     std::vector<int64_t> offsets;      // [n_series + 1]
     std::vector<Pair> pairs;           // [n_rows] (ds, y) of each packed row (empty if identity)
+    // what tsf_pack_fetch's pass over the packed rows sees on the way (tsf_pack_flags): every series on the first
+    // series' timestamp vector; an infinite y; every y an integer that fits int32 (the reference's schema)
+    int32_t aligned = 0, has_inf = 0, integral = 0, fetched = 0;
 };
 
 extern "C" {
@@ -176,12 +157,23 @@ int tsf_pack_rows(int64_t n, const int64_t *series_id, const int64_t *dim_id, co
         if (ordered.load()) {
             p->identity = 1;
             p->n_rows = n;
-            for (int64_t i = 0; i < n; ++i) {
-                if (i == 0 || series_id[i] != series_id[i - 1] || dim_id[i] != dim_id[i - 1]) {
+            // run starts, found by the pool (round 6: this loop ran on ONE thread over both key columns -- 117 MB for
+            // 10 000 x 730 rows, 15 of the packer's 21 ms on the GPU box), appended in chunk order
+            std::vector<std::vector<int64_t>> starts((size_t)nt);
+            parallel_for(n, nt, [&](int64_t a, int64_t b, int t) {
+                std::vector<int64_t> &s = starts[(size_t)t];
+                for (int64_t i = a; i < b; ++i)
+                    if (i == 0 || series_id[i] != series_id[i - 1] || dim_id[i] != dim_id[i - 1]) s.push_back(i);
+            });
+            size_t total_runs = 0;
+            for (auto &s : starts) total_runs += s.size();
+            p->keys.reserve(total_runs);
+            p->offsets.reserve(total_runs + 1);
+            for (auto &s : starts)
+                for (int64_t i : s) {
                     p->keys.push_back(Key{series_id[i], dim_id[i]});
                     p->offsets.push_back(i);
                 }
-            }
             p->offsets.push_back(n);
             p->n_series = (int64_t)p->keys.size();
         } else {
@@ -296,13 +288,8 @@ int tsf_pack_rows(int64_t n, const int64_t *series_id, const int64_t *dim_id, co
                     }
                 }
             };
-            if (nt <= 1 || NS < 128) {
-                worker();
-            } else {
-                std::vector<std::thread> th;
-                for (int t = 0; t < nt; ++t) th.emplace_back(worker);
-                for (auto &x : th) x.join();
-            }
+            if (nt <= 1 || NS < 128) worker();
+            else tsfpool::Pool::get().run(nt, [&](int) { worker(); });
             lap("sort");
         }
     } catch (const std::bad_alloc &) {
@@ -332,8 +319,11 @@ int tsf_pack_fetch(tsf_pack *p, int64_t *key_series_id, int64_t *key_dim_id, int
         if (key_series_id) key_series_id[s] = p->keys[(size_t)s].sid;
         if (key_dim_id) key_dim_id[s] = p->keys[(size_t)s].did;
     }
-    // gather + statistics, series-parallel
+    // gather + statistics, series-parallel; the same pass notes what tsf_pack_flags reports
     std::atomic<int64_t> next(0);
+    std::atomic<int> not_aligned(0), any_inf(0), not_integral(0);
+    const int64_t len0 = NS > 0 ? p->offsets[1] - p->offsets[0] : 0;
+    const int64_t a0 = NS > 0 ? p->offsets[0] : 0;
     auto worker = [&]() {
         for (;;) {
             int64_t s0 = next.fetch_add(64);
@@ -343,11 +333,15 @@ int tsf_pack_fetch(tsf_pack *p, int64_t *key_series_id, int64_t *key_dim_id, int
                 int64_t a = p->offsets[(size_t)s], b = p->offsets[(size_t)s + 1];
                 int64_t first = 0, prev = 0, md = -1;
                 double ym = -std::numeric_limits<double>::infinity();
+                bool same = (b - a == len0), fin = true, whole = true;
                 for (int64_t r = a; r < b; ++r) {
                     int64_t d = ident ? ds[r] : pairs[r].ds;
                     double v = ident ? y[r] : pairs[r].y;
                     if (ds_out && !(ident && ds_out == ds)) ds_out[r] = d;
                     if (y_out && !(ident && y_out == y)) y_out[r] = v;
+                    if (same && d != (ident ? ds[a0 + (r - a)] : pairs[a0 + (r - a)].ds)) same = false;
+                    if (std::isinf(v)) fin = false;
+                    if (!(v >= -2147483648.0 && v <= 2147483647.0 && v == (double)(int32_t)v)) whole = false;
                     if (r == a) first = d;
                     else {
                         int64_t dt = d - prev;
@@ -356,22 +350,78 @@ int tsf_pack_fetch(tsf_pack *p, int64_t *key_series_id, int64_t *key_dim_id, int
                     prev = d;
                     if (v > ym) ym = v;
                 }
+                if (!same) not_aligned.store(1, std::memory_order_relaxed);
+                if (!fin) any_inf.store(1, std::memory_order_relaxed);
+                if (!whole) not_integral.store(1, std::memory_order_relaxed);
                 if (span) span[s] = prev - first;
                 if (min_dt) min_dt[s] = md;
                 if (y_max) y_max[s] = ym;
             }
         }
     };
-    if (p->n_threads <= 1 || NS < 128) {
-        worker();
-    } else {
-        std::vector<std::thread> th;
-        for (int t = 0; t < p->n_threads; ++t) th.emplace_back(worker);
-        for (auto &x : th) x.join();
+    try {
+        if (p->n_threads <= 1 || NS < 128) worker();
+        else tsfpool::Pool::get().run(p->n_threads, [&](int) { worker(); });
+    } catch (...) {
+        return -2;
     }
+    p->aligned = (NS > 0 && len0 > 0 && !not_aligned.load()) ? 1 : 0;
+    p->has_inf = any_inf.load();
+    p->integral = (NS > 0 && !not_integral.load()) ? 1 : 0;
+    p->fetched = 1;
+    return 0;
+}
+
+int tsf_pack_flags(const tsf_pack *p, int32_t *aligned, int32_t *has_inf, int32_t *integral) {
+    if (!p || !p->fetched) return -1;
+    if (aligned) *aligned = p->aligned;
+    if (has_inf) *has_inf = p->has_inf;
+    if (integral) *integral = p->integral;
     return 0;
 }
 
 void tsf_pack_free(tsf_pack *p) { delete p; }
+
+// ---- model blobs ------------------------------------------------------------------------------
+// The `model` column of the fit UDF's output (/root/reference/src/jobs/prophet_modeler.py:72-75: pickle.dumps(model) per
+// series).  The replacement blob (time_series_spark_amd/panel.py, version 2) is a prefix shared by the batch -- magic,
+// version, the constructor arguments as JSON -- and one fixed little-endian record per series:
+//   f64 y_scale | i64 start_ns, t_scale_ns, last_ds_ns | i32 T, S, i1, NT, status, n_iter, n_theta, n_tchange |
+//   f64 theta[n_theta] | f64 t_change[n_tchange]
+// Written here for the whole batch into ONE buffer, blob n at n * stride: the buffer is the data buffer of an Arrow
+// binary column as it stands (offsets n * stride), so the model parquet is written without a Python object per series.
+int tsf_model_blobs(int64_t N, const void *prefix, int32_t prefix_len, int32_t n_theta, const double *theta,
+                    const double *y_scale, const tsf_grid_info *grid, int32_t n_grids, const int64_t *last_ds,
+                    const int32_t *status, const int32_t *n_iter, int32_t n_tchange, void *out, int32_t n_threads) {
+    if (N < 0 || prefix_len < 0 || n_theta < 0 || n_tchange < 0 || n_tchange > TSF_MAX_S + 4 ||
+        (N > 0 && (!theta || !y_scale || !grid || !last_ds || !status || !n_iter || !out || (prefix_len > 0 && !prefix))) ||
+        !(n_grids == 1 || (int64_t)n_grids == N))
+        return -1;
+    const size_t stride = (size_t)prefix_len + 64 + 8 * ((size_t)n_theta + (size_t)n_tchange);
+    int hw = (int)std::thread::hardware_concurrency();
+    if (hw < 1) hw = 1;
+    int nt = n_threads > 0 ? n_threads : std::min(hw, 16);
+    if (N < 2048) nt = 1;
+    try {
+        parallel_for(N, nt, [&](int64_t a, int64_t b, int) {
+            for (int64_t n = a; n < b; ++n) {
+                char *q = (char *)out + (size_t)n * stride;
+                if (prefix_len) std::memcpy(q, prefix, (size_t)prefix_len);
+                q += prefix_len;
+                const tsf_grid_info &g = grid[n_grids == 1 ? 0 : n];
+                const int64_t i8[3] = {g.start_ns, g.t_scale_ns, last_ds[n]};
+                const int32_t i4[8] = {g.T, g.S, g.i1, g.NT, status[n], n_iter[n], n_theta, n_tchange};
+                std::memcpy(q, &y_scale[n], 8);
+                std::memcpy(q + 8, i8, 24);
+                std::memcpy(q + 32, i4, 32);
+                std::memcpy(q + 64, theta + (size_t)n * n_theta, 8 * (size_t)n_theta);
+                std::memcpy(q + 64 + 8 * (size_t)n_theta, g.t_change, 8 * (size_t)n_tchange);
+            }
+        });
+    } catch (...) {
+        return -2;
+    }
+    return 0;
+}
 
 }  // extern "C"

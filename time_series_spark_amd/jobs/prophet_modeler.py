@@ -82,6 +82,8 @@ def previous_run_cost(models, sidecar_only=False):
         return None
 
 
+MODEL_ROW_GROUP = 6144          # most rows per parquet row group of a model part (a part is cut into equal groups): what
+                                # the scorer's pipeline reads, forecasts and writes at a time
 COST_SIDECAR = '_tsf_cost.npz'         # leading underscore: Spark and pyarrow skip it when they read the directory
 
 
@@ -109,29 +111,32 @@ class _CostVector(object):
         return self.values if dtype is None else self.values.astype(dtype)
 
 
-def _write_cost_sidecar(path, part, model_df):
-    """The iteration counts persist_models' frame carries (model_df.attrs['tsf_cost'], set by _model_packed) next to
-    the parquet part, with that part's size and mtime: previous_run_cost then reads 10 000 counts in under a
-    millisecond instead of parsing 10 000 model blobs (17 ms), and a part that was replaced since (size / mtime differ)
-    sends it back to the blobs."""
-    cost = model_df.attrs.get('tsf_cost')
-    if cost is None or len(cost) != len(model_df.index):
+def _write_cost_sidecar(path, parts, sids, dids, cost):
+    """The iteration counts of the models persist_models wrote (ModelBatch.cost / model_df.attrs['tsf_cost']) next to
+    the parquet parts, with every part's size and mtime: previous_run_cost then reads 10 000 counts in under a
+    millisecond instead of parsing 10 000 model blobs (17 ms), and a directory whose parts were replaced since (names,
+    sizes or mtimes differ) sends it back to the blobs."""
+    if cost is None or len(cost) != len(sids):
         return
-    st = os.stat(os.path.join(path, part))
-    np.savez(os.path.join(path, COST_SIDECAR), series_id=model_df['series_id'].to_numpy().astype(np.int64),
-             dim_id=model_df['dim_id'].to_numpy().astype(np.int64), cost=np.asarray(cost, dtype=np.int64),
-             part=np.array([part]), stat=np.array([st.st_size, st.st_mtime_ns], dtype=np.int64))
+    stat = [[os.stat(os.path.join(path, f)).st_size, os.stat(os.path.join(path, f)).st_mtime_ns] for f in parts]
+    np.savez(os.path.join(path, COST_SIDECAR), series_id=np.asarray(sids).astype(np.int64),
+             dim_id=np.asarray(dids).astype(np.int64), cost=np.asarray(cost, dtype=np.int64),
+             part=np.array(list(parts)), stat=np.array(stat, dtype=np.int64).reshape(len(parts), 2))
 
 
 def _read_cost_sidecar(path, parts):
     f = os.path.join(path, COST_SIDECAR)
-    if len(parts) != 1 or not os.path.isfile(f):
+    if not parts or not os.path.isfile(f):
         return None
     try:
         z = np.load(f)
-        st = os.stat(os.path.join(path, parts[0]))
-        if str(z['part'][0]) != parts[0] or list(z['stat']) != [st.st_size, st.st_mtime_ns]:
+        if [str(x) for x in z['part']] != list(parts):
             return None
+        stat = np.asarray(z['stat']).reshape(len(parts), 2)
+        for f_, (size, mtime) in zip(parts, stat):
+            st = os.stat(os.path.join(path, f_))
+            if (st.st_size, st.st_mtime_ns) != (int(size), int(mtime)):
+                return None
         return pd.DataFrame({'series_id': z['series_id'], 'dim_id': z['dim_id'], 'cost': z['cost']})
     except Exception:
         return None
@@ -141,25 +146,28 @@ def _empty_models():
     return pd.DataFrame(columns=MODEL_OUTPUT_COLUMNS)
 
 
-def fit_packed(panel, floor, cap, kw, devices=None, cost=None):
+def fit_packed(panel, floor, cap, kw, devices=None, cost=None, lap=None):
     """Fit every series of a PackedPanel.  Series are bucketed by the seasonality set
     fbprophet's 'auto' rules give their own history (each Prophet object decides alone), one
-    kernel launch per bucket.  Returns per-series (blob | None, status).
+    kernel launch per bucket.  Returns (pieces, status, n_iter): pieces = [(members, buffer)] -- the blobs of one fit
+    call, uint8 [len(members)][stride] (panel.dump_models_buffer), row i the model of series members[i]; a series whose
+    status is negative has no model, and a later piece (fbprophet's Newton retry) supersedes an earlier one.
     cost: optional [N] expected relative cost per series (the iteration counts of the previous run's models):
     scheduling hints for the launches (tsf_set_cost_hints); results do not depend on them."""
     N = panel.N
+    lap = lap or (lambda name: None)
     hint = (lambda mem: None) if cost is None else (lambda mem: np.asarray(cost)[mem])
     span, min_dt, _ = pk.per_series_stats(panel)
     growth = kw.get('growth', 'linear')
     mode = kw.get('seasonality_mode', 'additive')
     sps = float(kw.get('seasonality_prior_scale', 10.0))
     # the auto rules depend on the series only through three booleans
-    sig = np.stack([span < 730 * fc.DAY_NS,
-                    (span < 14 * fc.DAY_NS) | ((min_dt >= 0) & (min_dt >= 7 * fc.DAY_NS)),
-                    (span < 2 * fc.DAY_NS) | ((min_dt >= 0) & (min_dt >= fc.DAY_NS))], axis=1)
+    sig = ((span < 730 * fc.DAY_NS).astype(np.int8)
+           | (((span < 14 * fc.DAY_NS) | ((min_dt >= 0) & (min_dt >= 7 * fc.DAY_NS))).astype(np.int8) << 1)
+           | (((span < 2 * fc.DAY_NS) | ((min_dt >= 0) & (min_dt >= fc.DAY_NS))).astype(np.int8) << 2))
     specs = {}
-    for row in np.unique(sig, axis=0):
-        members = np.flatnonzero((sig == row).all(axis=1))
+    for code in np.flatnonzero(np.bincount(sig, minlength=8)):
+        members = np.flatnonzero(sig == code)
         n0 = int(members[0])
         seas = fc.ModelSpec.auto_from_stats(
             int(span[n0]), int(min_dt[n0]), yearly=kw.get('yearly_seasonality', 'auto'),
@@ -176,7 +184,7 @@ def fit_packed(panel, floor, cap, kw, devices=None, cost=None):
     hol = features.normalize_holidays(kw.get('holidays'), float(kw.get('holidays_prior_scale', 10.0)))
     hol_names, hol_scales, hol_days = features.holiday_columns(hol)
     hol_extra = [{'name': n, 'prior_scale': p, 'mode': mode} for n, p in zip(hol_names, hol_scales)]
-    blobs = [None] * N
+    pieces = []
     status = np.zeros(N, dtype=np.int32)
     n_iter = np.zeros(N, dtype=np.int32)
     # make_future_dataframe starts at history_dates.max(): the last ds of the group INCLUDING rows
@@ -187,6 +195,7 @@ def fit_packed(panel, floor, cap, kw, devices=None, cost=None):
         raise ValueError("algorithm must be 'auto', 'lbfgs' or 'newton'")
     opts = _spec_opts(kw)
     min_group = int(kw.get('min_aligned_group', MIN_ALIGNED_GROUP))
+    lap('specs')
 
     def run(spec, sd, seas, members):
         """One optimiser over `members`: series that share a timestamp vector are fitted
@@ -197,6 +206,7 @@ def fit_packed(panel, floor, cap, kw, devices=None, cost=None):
         # aligned ones: a group pays for its launch from a few thousand series on.  A bucket that IS one group keeps
         # the aligned path whatever its size; otherwise small groups join the ragged call (same bits either way).
         groups, rest = pk.group_by_grid(panel, members, min_group=min_group, keep_single=True)
+        lap('group_by_grid')
         calls = []
         for gm in groups:
             T = int(panel.lengths[gm[0]])
@@ -208,6 +218,7 @@ def fit_packed(panel, floor, cap, kw, devices=None, cost=None):
                 spec, panel.ds_ns[a0:a0 + T], y2d,
                 floor=None if floor is None else np.asarray(floor)[gm],
                 cap=None if cap is None else np.asarray(cap)[gm], extra=ex, devices=devices, **_hint_kw(hint(gm)))))
+            lap('fit_aligned %d' % len(gm))
         if len(rest):
             lens = panel.lengths[rest]
             off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
@@ -226,14 +237,14 @@ def fit_packed(panel, floor, cap, kw, devices=None, cost=None):
                 spec, off, ds_r, y_r,
                 floor=None if floor is None else np.asarray(floor)[rest],
                 cap=None if cap is None else np.asarray(cap)[rest], extra=ex, devices=devices, **_hint_kw(hint(rest)))))
+            lap('fit_ragged %d' % len(rest))
         for mem, res in calls:
             st = np.asarray(res.status)
             status[mem] = st
             n_iter[mem] = np.asarray(res.n_iter)
-            bl = pk.dump_models(sd, res.theta, res.y_scale, res.grid, last_ds[mem], st, res.n_iter)
-            # optimiser failure (pystan RuntimeError) or invalid input: no model for the series
-            for i in np.flatnonzero(st >= 0):
-                blobs[mem[i]] = bl[i]
+            # (optimiser failure -- pystan RuntimeError -- or invalid input: status < 0, no model for the series)
+            pieces.append((mem, pk.dump_models_buffer(sd, res.theta, res.y_scale, res.grid, last_ds[mem], st, res.n_iter)))
+            lap('blobs')
 
     for key, (seas, members) in specs.items():
         members = np.sort(np.asarray(members))
@@ -275,7 +286,75 @@ def fit_packed(panel, floor, cap, kw, devices=None, cost=None):
                 run(newton, sd, seas, failed)
         if len(first_newton):
             run(newton, sd, seas, first_newton)
-    return blobs, status, n_iter
+    return pieces, status, n_iter
+
+
+class ModelBatch(object):
+    """The rows of the fit UDF's output (prophet_modeler.py:68-79: series_id, dim_id, floor, cap, model) for a whole
+    panel, before they become a frame: key and cap columns, and the model blobs as the buffers the library wrote them
+    into (fit_packed's pieces).  to_frame(): the reference's frame, one bytes object per series; to_table(): the same
+    rows as a pyarrow table over the same buffers -- what persist_models writes, with no Python object per series."""
+
+    def __init__(self, sids, dids, floor, cap, pieces, status, n_iter):
+        N = len(sids)
+        self.sids, self.dids, self.floor, self.cap = sids, dids, floor, cap
+        self.pieces, self.status, self.n_iter = pieces, status, n_iter
+        self.piece_of = np.full(N, -1, dtype=np.int64)       # which piece holds the model of series n (-1: none)
+        self.row_of = np.zeros(N, dtype=np.int64)
+        for p, (mem, _buf) in enumerate(pieces):
+            ok = np.flatnonzero(status[mem] >= 0)
+            # (status is the FINAL status: a series that failed under L-BFGS and succeeded in the Newton retry takes the
+            # later piece; one that failed in both has status < 0 and no model)
+            self.piece_of[mem[ok]] = p
+            self.row_of[mem[ok]] = ok
+        self.keep = np.flatnonzero(self.piece_of >= 0)
+
+    def __len__(self):
+        return len(self.keep)
+
+    @property
+    def cost(self):
+        return self.n_iter[self.keep]
+
+    def to_frame(self):
+        model = np.empty(len(self.sids), dtype=object)
+        for p, (_mem, buf) in enumerate(self.pieces):
+            sel = np.flatnonzero(self.piece_of == p)
+            if len(sel) == 0:
+                continue
+            body, L = buf.tobytes(), buf.shape[1]
+            rows = [body[r * L:(r + 1) * L] for r in self.row_of[sel].tolist()]
+            model[sel] = np.array(rows + [None], dtype=object)[:-1]      # (an object array, never a 2-D char array)
+        keep = self.keep
+        out = pd.DataFrame({'series_id': self.sids[keep], 'dim_id': self.dids[keep],
+                            'floor': np.full(len(keep), self.floor), 'cap': self.cap[keep],
+                            'model': pd.Series(model[keep], dtype=object)}, columns=MODEL_OUTPUT_COLUMNS)
+        # persist_models writes them beside the parquet (scheduling hints of the next run)
+        out.attrs['tsf_cost'] = _CostVector(self.cost)
+        return out
+
+    def to_table(self):
+        import pyarrow as pa
+        keep = self.keep
+        live = [p for p in range(len(self.pieces)) if (self.piece_of == p).any()]
+        if len(live) == 1 and len(keep) == self.pieces[live[0]][1].shape[0] and \
+                np.array_equal(self.row_of[keep], np.arange(len(keep))):
+            model = pk.model_column_arrow(self.pieces[live[0]][1])          # the usual case: the buffer as it stands
+        elif not live:
+            model = pa.array([], type=pa.binary())
+        else:
+            cols, base, start = [], {}, 0
+            for p in live:
+                cols.append(pk.model_column_arrow(self.pieces[p][1]).cast(pa.large_binary()))
+                base[p] = start
+                start += self.pieces[p][1].shape[0]
+            at = np.array([base[int(p)] for p in self.piece_of[keep]], dtype=np.int64) + self.row_of[keep]
+            model = pa.concat_arrays(cols).take(pa.array(at)).cast(pa.binary())
+        return pa.table({'series_id': pa.array(np.ascontiguousarray(self.sids[keep], dtype=np.int32)),
+                         'dim_id': pa.array(np.ascontiguousarray(self.dids[keep], dtype=np.int32)),
+                         'floor': pa.array(np.full(len(keep), self.floor, dtype=np.float32)),
+                         'cap': pa.array(np.ascontiguousarray(self.cap[keep], dtype=np.float32)),
+                         'model': model})
 
 
 def _spec_opts(kw):
@@ -288,7 +367,9 @@ def _spec_opts(kw):
     return out
 
 
-def _model_packed(config, panel, n_rows, execution_time, previous=None):
+def _model_packed(config, panel, n_rows, execution_time, previous=None, lap=None):
+    """-> ModelBatch"""
+    lap = lap or (lambda name: None)
     floor = config['model']['floor']                                   # :56-57
     ymax = pk.per_series_stats(panel)[2]
     cap = ymax * config['model']['cap_multiplier']                     # :59-60
@@ -296,6 +377,8 @@ def _model_packed(config, panel, n_rows, execution_time, previous=None):
     floors = np.full(panel.N, float(floor))
     # ValueError cases propagate exactly as fbprophet's would (SURVEY 8b error convention);
     # a group whose every y is null never reaches the packed panel but fails the same way
+    if panel.has_inf or (panel.has_inf is None and np.isinf(panel.y).any()):
+        raise ValueError('Found infinity in column y.')
     if panel.dropped_keys or (panel.lengths < 2).any():
         raise ValueError('Dataframe has less than 2 non-NaN rows.')
     if kw['growth'] == 'logistic' and (cap <= floors).any():
@@ -315,20 +398,16 @@ def _model_packed(config, panel, n_rows, execution_time, previous=None):
         k = key64(panel.keys['series_id'].to_numpy(), panel.keys['dim_id'].to_numpy())
         at = np.minimum(np.searchsorted(pkey, k), len(pkey) - 1)
         cost = np.where(pkey[at] == k, pcost[at], int(np.median(pcost))).astype(np.int32)
-    blobs, status, n_iter = fit_packed(panel, floors, cap, kw, devices=config.get('devices'), cost=cost)
+    lap('checks + hints')
+    pieces, status, n_iter = fit_packed(panel, floors, cap, kw, devices=config.get('devices'), cost=cost, lap=lap)
+    lap('fit_packed tail')
     sids = panel.keys['series_id'].to_numpy()
     dids = panel.keys['dim_id'].to_numpy()
-    ok = np.fromiter((b is not None for b in blobs), dtype=bool, count=panel.N)
-    for n in np.flatnonzero(~ok):
+    out = ModelBatch(sids, dids, floor, cap, pieces, status, n_iter)
+    for n in np.flatnonzero(out.piece_of < 0):
         # pystan RuntimeError -> the reference prints and drops the series (:81-85)
         print(f"Runtime error {_lib.STATUS_NAMES.get(int(status[n]), status[n])} for "
               f"series_id: {int(sids[n])}, dim_id: {int(dids[n])}")
-    keep = np.flatnonzero(ok)
-    out = pd.DataFrame({'series_id': sids[keep], 'dim_id': dids[keep],
-                        'floor': np.full(len(keep), floor), 'cap': cap[keep],
-                        'model': pd.Series([blobs[n] for n in keep], dtype=object)},
-                       columns=MODEL_OUTPUT_COLUMNS)
-    out.attrs['tsf_cost'] = _CostVector(n_iter[keep])   # persist_models writes them beside the parquet (scheduling hints of the next run)
     print(f"Modeled {panel.N} series ({n_rows} rows) in {time.time() - execution_time}")
     return out
 
@@ -341,24 +420,30 @@ def model_panel(config):
         execution_time = time.time()
         if len(pdf.index) == 0:
             return _empty_models()
-        return _model_packed(config, pk.pack_long_frame(pdf), len(pdf.index), execution_time)
+        return _model_packed(config, pk.pack_long_frame(pdf), len(pdf.index), execution_time).to_frame()
 
     return model_panel_fn
 
 
-def model_arrays(config, previous=None):
+def model_arrays(config, previous=None, batch=False):
     """model_panel for columns that never were a DataFrame (what read_model_input returns):
     series_id, dim_id int64; ds_ns int64 ns; y float64 with NaN for nulls.
-    previous: previous_run_cost(...) of an earlier run, or None."""
+    previous: previous_run_cost(...) of an earlier run, or None.
+    batch: return the ModelBatch (the blobs in the library's buffers: persist_models writes it to parquet without a
+    Python object per series) instead of the reference's frame."""
 
     def model_arrays_fn(sid, did, ds_ns, y):
+        from ..pipeline import Laps
         execution_time = time.time()
         if len(y) == 0:
-            return _empty_models()
-        if np.isinf(y).any():
-            raise ValueError('Found infinity in column y.')
-        panel = pk.pack_rows(sid, did, ds_ns, y, key_dtypes=(np.int32, np.int32))
-        return _model_packed(config, panel, len(y), execution_time, previous=previous)
+            return None if batch else _empty_models()
+        with Laps('model_arrays %d rows' % len(y)) as lap:
+            # (an infinite y raises in _model_packed: the packer's own pass over the rows reports it, tsf_pack_flags)
+            panel = pk.pack_rows(sid, did, ds_ns, y, key_dtypes=(np.int32, np.int32))
+            lap('pack_rows')
+            out = _model_packed(config, panel, len(y), execution_time, previous=previous, lap=lap)
+            lap('rest')
+            return out if batch else out.to_frame()
 
     return model_arrays_fn
 
@@ -547,16 +632,7 @@ def read_model_input_dir(root, n_threads=0, mode='FAILFAST', stats=None):
     # (the thread that lists a directory reads its files at once: tsf_csv_discover_load)
     rc = L.tsf_csv_discover_load(os.fsencode(root), int(n_threads), ctypes.byref(d), ctypes.byref(n), ctypes.byref(n_part))
     try:
-        if rc in (_lib.CSV_E_OPEN, _lib.CSV_E_PARSE, _lib.CSV_E_CODEC):
-            bad = os.fsdecode(L.tsf_csv_dir_error_path(d))
-            if rc == _lib.CSV_E_CODEC:
-                raise ValueError('compressed input file %s: decompress it first (Spark reads it, '
-                                 'this reader does not)' % bad)
-            if rc == _lib.CSV_E_PARSE:
-                raise ValueError('partition directory %s: series_id is not an integer' % bad)
-            raise OSError('cannot list %s' % bad)
-        if rc != 0:
-            raise _lib.TsfError('tsf_csv_discover failed (%d)' % rc)
+        _raise_discover_error(rc, d)
         if n.value == 0:
             z = np.zeros(0, np.int64)
             return z, z.copy(), z.copy(), np.zeros(0)
@@ -573,6 +649,86 @@ def read_model_input_dir(root, n_threads=0, mode='FAILFAST', stats=None):
     if len(out) == 1:
         return out[0]
     return tuple(np.concatenate([o[k] for o in out]) for k in range(4))
+
+
+class _CsvRoot:
+    """tsf_csv_root_open / _load (include/tsf.h): the input directory's children, read in ranges."""
+
+    def __init__(self, root):
+        import ctypes
+        L = _lib.load()
+        self.handle, n, hive = ctypes.c_void_p(), ctypes.c_int32(), ctypes.c_int32()
+        rc = L.tsf_csv_root_open(os.fsencode(root), ctypes.byref(self.handle), ctypes.byref(n), ctypes.byref(hive))
+        if rc == _lib.CSV_E_OPEN:
+            raise OSError('cannot list %s' % root)
+        if rc != 0:
+            raise _lib.TsfError('tsf_csv_root_open failed (%d)' % rc)
+        self.n_children, self.hive_only = n.value, bool(hive.value)
+
+    def close(self):
+        if self.handle:
+            _lib.load().tsf_csv_root_free(self.handle)
+            self.handle = None
+
+    __del__ = close
+
+    def read(self, first, count, mode='FAILFAST', stats=None, n_threads=0):
+        """The rows of children [first, first + count) as (series_id, dim_id, ds_ns, y) -- read_model_input_dir over that
+        range.  Raises _Nested when a `series_id=` directory sits below another one (the caller reads the tree whole)."""
+        import ctypes
+        L = _lib.load()
+        lay_part, lay_all = _layouts(mode)
+        d, n, n_part, nested = ctypes.c_void_p(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        rc = L.tsf_csv_root_load(self.handle, int(first), int(count), int(n_threads), ctypes.byref(d), ctypes.byref(n),
+                                 ctypes.byref(n_part), ctypes.byref(nested))
+        try:
+            _raise_discover_error(rc, d)
+            if nested.value:
+                raise _Nested()
+            if n.value == 0:
+                z = np.zeros(0, np.int64)
+                return z, z.copy(), z.copy(), np.zeros(0)
+            paths, sids = L.tsf_csv_dir_paths(d), L.tsf_csv_dir_series_id(d)
+            pp = ctypes.cast(paths, ctypes.POINTER(ctypes.c_char_p))
+            out = []
+            for layout, lo, hi in ((lay_part, 0, n_part.value), (lay_all, n_part.value, n.value)):
+                if hi > lo:
+                    out.append(_csv_read_call(hi - lo, paths + 8 * lo, sids + 8 * lo, layout, n_threads,
+                                              lambda i, lo=lo: os.fsdecode(pp[lo + i]), stats, loaded=(d, lo)))
+        finally:
+            if d:
+                L.tsf_csv_dir_free(d)
+        if len(out) == 1:
+            return out[0]
+        return tuple(np.concatenate([o[k] for o in out]) for k in range(4))
+
+
+class _Nested(Exception):
+    pass
+
+
+def _raise_discover_error(rc, d):
+    L = _lib.load()
+    if rc in (_lib.CSV_E_OPEN, _lib.CSV_E_PARSE, _lib.CSV_E_CODEC):
+        bad = os.fsdecode(L.tsf_csv_dir_error_path(d))
+        if rc == _lib.CSV_E_CODEC:
+            raise ValueError('compressed input file %s: decompress it first (Spark reads it, '
+                             'this reader does not)' % bad)
+        if rc == _lib.CSV_E_PARSE:
+            raise ValueError('partition directory %s: series_id is not an integer' % bad)
+        raise OSError('cannot list %s' % bad)
+    if rc != 0:
+        raise _lib.TsfError('tsf_csv_discover failed (%d)' % rc)
+
+
+# A run over this many partition directories or more is read, fitted and persisted in chunks, as a pipeline
+# (ProphetModeler.model); config['io']['chunks'] overrides ('auto', or a number; 1 = the whole input at once).
+# Measured on the GPU box (profiles/r06_host/): 10 000 x 730 rows take 58 ms whole and 63 ms in four chunks (every chunk
+# pays its walk, its launch -- which lasts as long as its longest fit -- and its Python), 40 000 take 357 ms whole and
+# 248 ms in chunks (the chunks' file and table blocks fit the process's block cache and are read into again and again).
+PIPELINE_MIN_CHILDREN = 16384
+PIPELINE_CHUNK_CHILDREN = 4096
+PIPELINE_MAX_CHUNKS = 32
 
 
 class ProphetModeler:
@@ -615,23 +771,73 @@ class ProphetModeler:
         return cols
 
     def persist_models(self, model_df):
-        """Parquet, mode='overwrite' (:123-125)."""
-        import shutil
-        path = self.config['io']['models']
-        if os.path.isdir(path):
-            shutil.rmtree(path)
-        os.makedirs(path, exist_ok=True)
-        out = model_df.copy()
-        out.attrs = {}                              # (pandas would try to store them in the parquet metadata as JSON)
-        for c, t in MODEL_OUTPUT_DTYPES.items():
-            out[c] = out[c].astype(t)
-        out.to_parquet(os.path.join(path, 'part-00000.parquet'), index=False)
-        _write_cost_sidecar(path, 'part-00000.parquet', model_df)
+        """Parquet, mode='overwrite' (:123-125).  model_df: the reference's model frame, or a ModelBatch (model_arrays(...,
+        batch=True)), whose blobs go to the file from the buffers the library wrote them into."""
+        wait = self._clear_models()
+        part = self._write_part(0, model_df)
+        wait()
+        if isinstance(model_df, ModelBatch):
+            keep = model_df.keep
+            _write_cost_sidecar(self.config['io']['models'], [part], model_df.sids[keep], model_df.dids[keep], model_df.cost)
+        else:
+            _write_cost_sidecar(self.config['io']['models'], [part], model_df['series_id'].to_numpy(),
+                                model_df['dim_id'].to_numpy(), model_df.attrs.get('tsf_cost'))
+
+    def _clear_models(self):
+        """-> function that waits until the previous run's files are gone (pipeline.clear_directory)"""
+        from ..pipeline import clear_directory
+        return clear_directory(self.config['io']['models'])
+
+    def _write_part(self, k, model_df):
+        """part-<k>.parquet of the model directory (Spark writes one part per task: a directory of parts is what
+        spark.read.parquet / pd.read_parquet read back, prophet_scorer.py:124-126)."""
+        import pyarrow as pa
+        import pyarrow.parquet as pq
+        part = 'part-%05d.parquet' % k
+        if isinstance(model_df, ModelBatch):
+            table = model_df.to_table()
+        else:
+            out = model_df.copy()
+            out.attrs = {}                          # (pandas would try to store them in the parquet metadata as JSON)
+            for c, t in MODEL_OUTPUT_DTYPES.items():
+                out[c] = out[c].astype(t)
+            table = pa.Table.from_pandas(out, preserve_index=False)
+        # blobs of ~1 KB that share a few hundred prefix bytes: the default page compression (snappy) is what shrinks
+        # them; dictionary encoding of the binary column only costs time (every blob is distinct)
+        n = table.num_rows
+        groups = max(1, -(-n // MODEL_ROW_GROUP))
+        pq.write_table(table, os.path.join(self.config['io']['models'], part), use_dictionary=False,
+                       row_group_size=max(1, -(-n // groups)))
+        return part
+
+    def _chunk_plan(self):
+        """(root handle, [(first, count), ...]) when the input is read in chunks, else None: a directory whose children
+        are all `series_id=<int>` partition directories (tsf_csv_root_open: ranges of them hold disjoint series), enough
+        of them, and io.chunks not 1."""
+        root = self.config['io']['input']
+        want = self.config['io'].get('chunks', 'auto')
+        if want == 1 or not os.path.isdir(root):
+            return None
+        r = _CsvRoot(root)
+        n = r.n_children
+        if not r.hive_only or n < 2:
+            r.close()
+            return None
+        if want == 'auto':
+            if n < PIPELINE_MIN_CHILDREN:
+                r.close()
+                return None
+            k = min(PIPELINE_MAX_CHUNKS, max(2, n // PIPELINE_CHUNK_CHILDREN))
+        else:
+            k = max(1, min(int(want), n))
+        cuts = [(n * i) // k for i in range(k + 1)]
+        return r, [(a, b - a) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
 
     @staticmethod
-    def model(spark_session, config):
+    def model(spark_session, config, return_frame=True):
         """Create the trained time series models (:127-143).  spark_session is accepted for
-        signature compatibility and may be None."""
+        signature compatibility and may be None.  return_frame=False: return nothing, as the reference's does (the
+        drivers; a chunked run then never builds the frame)."""
         scorer = ProphetModeler(config)
         # A re-run overwrites io.models (:123-125).  Before it does, what the previous run left there gives this run
         # its scheduling hints: the iteration count of every model, the one cheap predictor of how long each fit takes,
@@ -644,8 +850,67 @@ class ProphetModeler:
         how = (config.get('model') or {}).get('schedule_from_previous_models', 'auto')
         if how:
             previous = previous_run_cost(config['io']['models'], sidecar_only=(how == 'auto'))
+        # Round 6: a Hive-partitioned input of a few thousand partition directories or more runs as a pipeline over ranges
+        # of them (time_series_spark_amd/pipeline.py): the files of chunk k + 1 are read and parsed while chunk k is packed
+        # and fitted on the GPU and the models of chunk k - 1 go to their parquet part -- Spark's answer to the same problem
+        # is many tasks at once (:139-141).  Every series lies in one partition directory, so it is fitted once, on all of
+        # its rows, whatever the chunking; one part file per chunk, as Spark writes one per task.
+        fit = model_arrays(scorer.config, previous=previous, batch=True)
+        plan = scorer._chunk_plan()
+        if plan is not None:
+            try:
+                return scorer._model_chunked(plan, fit, return_frame)
+            except _Nested:
+                pass            # a partition directory below another one: the tree is read whole
+            finally:
+                plan[0].close()
         # the columns go from the reader to the packer as arrays; read_input_dataframe gives the
         # same rows as a frame for callers that want one
-        model_df = model_arrays(scorer.config, previous=previous)(*scorer.read_input_columns())
-        scorer.persist_models(model_df)
-        return model_df
+        batch = fit(*scorer.read_input_columns())
+        if batch is None:
+            scorer.persist_models(_empty_models())
+            return _empty_models() if return_frame else None
+        scorer.persist_models(batch)
+        return batch.to_frame() if return_frame else None
+
+    def _model_chunked(self, plan, fit, return_frame):
+        from .. import pipeline
+        root, ranges = plan
+        mode = str(self.config['io'].get('input_mode', 'FAILFAST')).upper()
+        stats = {}
+
+        def chunks():
+            for k, (first, count) in enumerate(ranges):
+                yield k, root.read(first, count, mode=mode, stats=stats)
+
+        cleared = []
+
+        def persist(item):
+            k, batch = item
+            if not cleared:                 # mode='overwrite' (:123-125): the old directory goes when the first part is ready
+                cleared.append(self._clear_models())        # (its models were this run's scheduling hints until now)
+            return k, batch, (self._write_part(k, batch) if batch is not None and len(batch) else None)
+
+        try:
+            done = pipeline.run_pipeline(chunks(), [lambda it: (it[0], fit(*it[1])), persist])
+        finally:
+            for wait in cleared:
+                wait()
+        if stats.get('malformed'):
+            self.logger.warning('%d malformed model-input records dropped (PERMISSIVE)', stats['malformed'])
+        if not cleared:
+            self._clear_models()()
+        live = [(b, part) for _k, b, part in done if part is not None]
+        if live:
+            _write_cost_sidecar(self.config['io']['models'], [part for _b, part in live],
+                                np.concatenate([b.sids[b.keep] for b, _p in live]),
+                                np.concatenate([b.dids[b.keep] for b, _p in live]),
+                                np.concatenate([b.cost for b, _p in live]))
+        if not return_frame:
+            return None
+        frames = [b.to_frame() for b, _p in live]
+        if not frames:
+            return _empty_models()
+        out = pd.concat(frames, ignore_index=True)
+        out.attrs['tsf_cost'] = _CostVector(np.concatenate([b.cost for b, _p in live]))
+        return out

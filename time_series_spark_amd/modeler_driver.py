@@ -18,7 +18,7 @@ def main(argv=None):
     with open(argv[1]) as file:
         config = yaml.safe_load(file)
     print(f"config: {config}")
-    ProphetModeler.model(None, config)
+    ProphetModeler.model(None, config, return_frame=False)
     return 0
 
 

@@ -34,7 +34,7 @@ class PackedPanel(object):
     offsets [N+1]; ds_ns [rows]; y [rows] float64; aligned: True when every series has the same
     timestamp vector (then ds_grid [T] and y2d [N][T] are set)."""
 
-    def __init__(self, keys, offsets, ds_ns, y):
+    def __init__(self, keys, offsets, ds_ns, y, aligned=None):
         self.keys = keys
         self.offsets = offsets
         self.ds_ns = ds_ns
@@ -52,13 +52,16 @@ class PackedPanel(object):
         self.dropped_keys = []
         self.ds_grid = None
         self.y2d = None
-        if self.N > 0 and lens.min() == lens.max() and lens[0] > 0:
+        # aligned: the native packer saw it on its pass over the rows (tsf_pack_flags) -- None = look here
+        if self.N > 0 and lens.min() == lens.max() and lens[0] > 0 and aligned is not False:
             T = int(lens[0])
             grid = ds_ns.reshape(self.N, T)
-            if np.all(grid == grid[0]):
+            if aligned or np.all(grid == grid[0]):
                 self.aligned = True
                 self.ds_grid = np.ascontiguousarray(grid[0])
                 self.y2d = np.ascontiguousarray(y.reshape(self.N, T))
+        self.has_inf = None          # (tsf_pack_flags: an infinite y among the packed rows; None = not looked at)
+        self.integral = None         # every y an integer that fits int32 (the reference's quantity column)
 
 
 def pack_long_frame(pdf, y_col='y', n_threads=0):
@@ -121,10 +124,14 @@ def pack_rows(sid, did, ds_ns, y, n_threads=0, key_dtypes=(np.int64, np.int64)):
                                   min_dt.ctypes.data, ymax.ctypes.data)
         if rc != 0:
             raise _lib.TsfError('tsf_pack_fetch failed (%d)' % rc)
+        f_al, f_inf, f_int = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        if L.tsf_pack_flags(h, ctypes.byref(f_al), ctypes.byref(f_inf), ctypes.byref(f_int)) != 0:
+            raise _lib.TsfError('tsf_pack_flags failed')
     finally:
         L.tsf_pack_free(h)
     keys = pd.DataFrame({'series_id': ksid.astype(key_dtypes[0]), 'dim_id': kdid.astype(key_dtypes[1])})
-    panel = PackedPanel(keys, offsets, ds_out, y_out)
+    panel = PackedPanel(keys, offsets, ds_out, y_out, aligned=bool(f_al.value))
+    panel.has_inf, panel.integral = bool(f_inf.value), bool(f_int.value)
     panel.stats = (span, min_dt, ymax)
     if R < n:
         # rows with a null y were dropped: they still count for the last history date
@@ -254,31 +261,38 @@ def _prefix(spec_dict):
     return MAGIC + struct.pack('<II', VERSION, len(hb)) + hb
 
 
-def dump_models(spec_dict, theta, y_scale, grid, last_ds_ns, status, n_iter):
-    """One blob per series of a fitted batch.  Layout (little endian): 'TSFM', u32 version,
-    u32 len(spec json), spec json (the constructor arguments, shared by the batch), then one
-    fixed record: y_scale, start_ns, t_scale_ns, last_ds_ns, T, S, i1, NT, status, n_iter,
-    n_theta, n_tchange, theta[n_theta], t_change[n_tchange].  grid: 1 entry (aligned batch) or
-    one per series."""
-    theta = np.atleast_2d(np.asarray(theta, dtype=np.float64))
+def dump_models_buffer(spec_dict, theta, y_scale, grid, last_ds_ns, status, n_iter):
+    """The blobs of a fitted batch in ONE buffer: uint8 [N][stride], row n = the blob of series n.  Layout of a blob
+    (little endian): 'TSFM', u32 version, u32 len(spec json), spec json (the constructor arguments, shared by the
+    batch), then one fixed record: y_scale, start_ns, t_scale_ns, last_ds_ns, T, S, i1, NT, status, n_iter, n_theta,
+    n_tchange, theta[n_theta], t_change[n_tchange].  grid: 1 entry (aligned batch) or one per series.  Assembled by the
+    library (tsf_model_blobs, include/tsf.h); equal strides make the buffer an Arrow binary column as it stands."""
+    theta = np.ascontiguousarray(np.atleast_2d(np.asarray(theta, dtype=np.float64)))
     N, nth = theta.shape
-    grid = np.asarray(grid)
+    grid = np.ascontiguousarray(grid, dtype=_lib.GRID_DTYPE)
     ntc = int(grid['S'].max()) if len(grid) else 0
-    rec = np.zeros(N, dtype=_rec_dtype(nth, ntc))
-    rec['y_scale'] = y_scale
-    for f in ('start_ns', 't_scale_ns', 'T', 'S', 'i1', 'NT'):
-        rec[f] = grid[f]                     # broadcasts the single entry of an aligned batch
-    rec['last_ds_ns'] = last_ds_ns
-    rec['status'] = status
-    rec['n_iter'] = n_iter
-    rec['n_theta'] = nth
-    rec['n_tchange'] = ntc
-    rec['theta'] = theta
-    rec['t_change'] = grid['t_change'][:, :ntc]
-    body = rec.tobytes()
-    L = rec.dtype.itemsize
     pre = _prefix(spec_dict)
-    return [pre + body[i * L:(i + 1) * L] for i in range(N)]
+
+    def col(a, dt):
+        return np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=dt), (N,)))
+    y_scale, last_ds_ns = col(y_scale, np.float64), col(last_ds_ns, np.int64)
+    status, n_iter = col(status, np.int32), col(n_iter, np.int32)
+    out = np.empty((N, len(pre) + _REC_FIXED + 8 * (nth + ntc)), dtype=np.uint8)
+    if N:
+        rc = _lib.load().tsf_model_blobs(N, pre, len(pre), nth, theta.ctypes.data, y_scale.ctypes.data, grid.ctypes.data,
+                                         len(grid), last_ds_ns.ctypes.data, status.ctypes.data, n_iter.ctypes.data, ntc,
+                                         out.ctypes.data, 0)
+        if rc != 0:
+            raise _lib.TsfError('tsf_model_blobs failed (%d)' % rc)
+    return out
+
+
+def dump_models(spec_dict, theta, y_scale, grid, last_ds_ns, status, n_iter):
+    """One blob (bytes) per series of a fitted batch: the rows of dump_models_buffer."""
+    buf = dump_models_buffer(spec_dict, theta, y_scale, grid, last_ds_ns, status, n_iter)
+    body = buf.tobytes()
+    L = buf.shape[1]
+    return [body[i * L:(i + 1) * L] for i in range(buf.shape[0])]
 
 
 def dump_model(spec_dict, theta, y_scale, grid_row, last_ds_ns, status, n_iter):
@@ -303,23 +317,21 @@ def load_models(blobs):
     index into `blobs`; records is a structured array (fields as in dump_models).  None
     entries are skipped."""
     # the usual column -- every series of a run fitted with one spec: all blobs the same length with the same prefix --
-    # is one reshape of the joined bytes instead of a Python loop over the blobs
+    # is one reshape of the joined bytes instead of a Python loop over the blobs; a column that arrives as ONE buffer
+    # (uint8 [n][L]: dump_models_buffer, or the data buffer of an Arrow binary column with equal strides,
+    # model_column_buffer) is not even joined
+    if isinstance(blobs, np.ndarray) and blobs.dtype == np.uint8 and blobs.ndim == 2:
+        got = _load_uniform(blobs)
+        if got is not None:
+            return got
+        blobs = [bytes(r) for r in blobs]
     n = len(blobs)
     if n > 1 and all(type(b) is bytes for b in blobs):
         L = len(blobs[0])
         if min(map(len, blobs)) == L == max(map(len, blobs)):
-            pre, body0 = _split(blobs[0])
-            pl = len(pre)
-            arr = np.frombuffer(b''.join(blobs), dtype=np.uint8).reshape(n, L)
-            if L - pl >= _REC_FIXED and (arr[:, :pl] == arr[0, :pl]).all():
-                nth, ntc = struct.unpack_from('<ii', body0, _REC_FIXED - 8)
-                dt = _rec_dtype(nth, ntc)
-                if dt.itemsize != L - pl:
-                    raise ValueError('model blob size does not match its header')
-                rec = np.ascontiguousarray(arr[:, pl:]).view(dt).reshape(n)
-                if (rec['n_theta'] != nth).any() or (rec['n_tchange'] != ntc).any():
-                    raise ValueError('inconsistent model blobs')
-                return [(json.loads(pre[12:].decode()), np.arange(n, dtype=np.int64), rec)]
+            got = _load_uniform(np.frombuffer(b''.join(blobs), dtype=np.uint8).reshape(n, L))
+            if got is not None:
+                return got
     buckets = {}
     for i, blob in enumerate(blobs):
         if blob is None:
@@ -343,6 +355,58 @@ def load_models(blobs):
         spec = json.loads(pre[12:].decode())
         out.append((spec, np.asarray(pos, dtype=np.int64), rec))
     return out
+
+
+def _load_uniform(arr):
+    """load_models for uint8 [n][L] rows that share one prefix (else None)."""
+    n, L = arr.shape
+    if n == 0:
+        return []
+    pre, body0 = _split(arr[0].tobytes())
+    pl = len(pre)
+    if L - pl < _REC_FIXED or not (arr[:, :pl] == arr[0, :pl]).all():
+        return None
+    nth, ntc = struct.unpack_from('<ii', body0, _REC_FIXED - 8)
+    dt = _rec_dtype(nth, ntc)
+    if dt.itemsize != L - pl:
+        raise ValueError('model blob size does not match its header')
+    rec = np.ascontiguousarray(arr[:, pl:]).view(dt).reshape(n)
+    if (rec['n_theta'] != nth).any() or (rec['n_tchange'] != ntc).any():
+        raise ValueError('inconsistent model blobs')
+    return [(json.loads(pre[12:].decode()), np.arange(n, dtype=np.int64), rec)]
+
+
+def model_column_arrow(buf):
+    """uint8 [n][L] (dump_models_buffer) -> pyarrow binary array over the same bytes (no copy, no Python object per
+    series): offsets n * L."""
+    import pyarrow as pa
+    n, L = buf.shape
+    buf = np.ascontiguousarray(buf)
+    if n * L < 2 ** 31:
+        off = (np.arange(n + 1, dtype=np.int64) * L).astype(np.int32)
+        return pa.Array.from_buffers(pa.binary(), n, [None, pa.py_buffer(off), pa.py_buffer(buf)])
+    off = np.arange(n + 1, dtype=np.int64) * L
+    return pa.Array.from_buffers(pa.large_binary(), n, [None, pa.py_buffer(off), pa.py_buffer(buf)])
+
+
+def model_column_buffer(col):
+    """Inverse of model_column_arrow for a model column read from parquet (pyarrow Array / ChunkedArray of binary):
+    uint8 [n][L] view of its data buffer when every blob has the same length and none is null -- what load_models takes
+    without a Python object per series --, else None (the caller falls back to col.to_pylist())."""
+    import pyarrow as pa
+    if isinstance(col, pa.ChunkedArray):
+        col = col.chunk(0) if col.num_chunks == 1 else col.combine_chunks()
+    if len(col) == 0 or col.null_count:
+        return None
+    wide = pa.types.is_large_binary(col.type)
+    if not (wide or pa.types.is_binary(col.type)):
+        return None
+    _, off_b, data_b = col.buffers()
+    off = np.frombuffer(off_b, dtype=np.int64 if wide else np.int32)[col.offset:col.offset + len(col) + 1]
+    L = int(off[1] - off[0])
+    if L <= 0 or not (np.diff(off) == L).all():
+        return None
+    return np.frombuffer(data_b, dtype=np.uint8)[int(off[0]):int(off[0]) + len(col) * L].reshape(len(col), L)
 
 
 def load_model(blob):

@@ -1,10 +1,12 @@
 """End-to-end run of the reference's two jobs through the drop-in entry points, from files to
-files: Hive-partitioned model-input CSV -> ProphetModeler.model's steps (read, pack, GPU fit, model
-parquet) -> ProphetScorer.score (read models, GPU predict, convert, forecast CSV).  Prints the
-wall time of every stage and the series/s of the whole thing (host IO included -- this is NOT
-bench.py's `value`, which times the hot path with inputs resident in HBM).
+files: Hive-partitioned model-input CSV -> ProphetModeler.model (read, pack, GPU fit, model parquet)
+-> ProphetScorer.score (read models, GPU predict, convert, forecast CSV).  Prints the wall time of the
+two jobs as their drivers run them (round 6: each a pipeline over chunks, time_series_spark_amd/pipeline.py)
+and the series/s of the whole thing (host IO included -- this is NOT bench.py's `value`, which times
+the hot path with inputs resident in HBM); with --stages also the jobs' steps called one after the
+other, each timed (the round-5 arrangement: no overlap).
 
-    python tools/e2e_bench.py [--n 10000] [--t 730] [--kind cfg2|reference] [--fake-gpu]
+    python tools/e2e_bench.py [--n 10000] [--t 730] [--kind cfg2|reference] [--fake-gpu] [--stages] [--chunks K]
 """
 import argparse
 import json
@@ -41,6 +43,9 @@ def main():
     ap.add_argument('--no-hints', action='store_true', help='do not schedule the second pass from the first pass\'s models')
     ap.add_argument('--fake-gpu', action='store_true', help='stand-ins for the GPU calls (host cost only)')
     ap.add_argument('--keep', action='store_true')
+    ap.add_argument('--stages', action='store_true', help='also time the steps of the two jobs one after the other')
+    ap.add_argument('--chunks', default=None, help="io.chunks of the modeler config ('auto' by default; 1 = no pipeline)")
+    ap.add_argument('--passes', type=int, default=3, help='timed passes of the two jobs (the best and the median are reported)')
     a = ap.parse_args()
     if a.fake_gpu:
         import host_profile as hp
@@ -55,6 +60,10 @@ def main():
     t['(write synthetic input)'] = time.time() - t0
     mcfg = {'io': {'input': os.path.join(work, 'model-input'), 'models': os.path.join(work, 'models')},
             'model': {'floor': 0, 'cap_multiplier': 1.1}}
+    if a.chunks is not None:
+        mcfg['io']['chunks'] = a.chunks if a.chunks == 'auto' else int(a.chunks)
+    if a.no_hints:
+        mcfg['model']['schedule_from_previous_models'] = False
     if linear:
         mcfg['model']['prophet'] = {'growth': 'linear', 'seasonality_mode': 'additive',
                                     'yearly_seasonality': True}
@@ -69,8 +78,24 @@ def main():
 
     devnull = open(os.devnull, 'w')
     out, sys.stdout = sys.stdout, devnull          # the jobs print one line per dropped series
+    jobs = []
     try:
-        for rep in ('warm-up ', ''):              # first pass pays library load + HIP init
+        # the two jobs as their drivers run them (modeler_driver / scorer_driver): first pass pays library load + HIP init
+        for rep in ['warm-up '] + ['pass %d ' % i for i in range(a.passes)]:
+            t0 = time.time()
+            pm.ProphetModeler.model(None, mcfg, return_frame=False)
+            t1 = time.time()
+            ps.ProphetScorer.score(None, scfg)
+            t2 = time.time()
+            t[rep + 'ProphetModeler.model'] = t1 - t0
+            t[rep + 'ProphetScorer.score'] = t2 - t1
+            if not rep.startswith('warm'):
+                jobs.append((t1 - t0, t2 - t1))
+        import pandas as pd_
+        models = pd_.read_parquet(mcfg['io']['models'])
+        n_fc = sum(sum(1 for _ in open(os.path.join(scfg['io']['forecasts'], f))) - 1
+                   for f in os.listdir(scfg['io']['forecasts']) if f.endswith('.csv'))
+        for rep in (('warm-up ', '') if a.stages else ()):
             mo = pm.ProphetModeler(mcfg)
             # what ProphetModeler.model does: the previous run's models (none in the first pass) give this run its
             # scheduling hints before they are overwritten
@@ -87,13 +112,19 @@ def main():
             stage(rep + 'write_converted (convert + native sink)', sc.write_converted, fdf)
     finally:
         sys.stdout = out
-    total = sum(v for k, v in t.items() if not k.startswith(('warm-up', '(')))
     for k, v in t.items():
         print('%-44s %8.3f s' % (k, v))
+    tot = sorted(m + s for m, s in jobs)
+    best, med = tot[0], tot[len(tot) // 2]
     res = {'n_series': a.n, 'T': a.t, 'kind': a.kind, 'fake_gpu': a.fake_gpu, 'models': int(len(models)),
-           'forecast_rows': int(len(fdf)), 'total_s': round(total, 3),
-           'series_per_s_files_to_files': round(a.n / total, 1),
+           'forecast_rows': int(n_fc), 'total_s': round(med, 4), 'total_s_best': round(best, 4),
+           'modeler_s': round(sorted(m for m, _ in jobs)[len(jobs) // 2], 4),
+           'scorer_s': round(sorted(s for _, s in jobs)[len(jobs) // 2], 4),
+           'series_per_s_files_to_files': round(a.n / med, 1), 'series_per_s_best_pass': round(a.n / best, 1),
+           'passes': a.passes, 'chunks': mcfg['io'].get('chunks', 'auto'),
            'stages_s': {k: round(v, 4) for k, v in t.items()}}
+    if a.stages:
+        res['total_s_stages_one_after_the_other'] = round(sum(v for k, v in t.items() if not k.startswith(('warm-up', '(', 'pass')) and 'Prophet' not in k), 4)
     print(json.dumps(res))
     if not a.keep:
         shutil.rmtree(work, ignore_errors=True)

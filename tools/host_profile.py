@@ -43,7 +43,7 @@ def fake_fit_ragged(spec, offsets, ds_ns, y, floor=None, cap=None, extra=None, c
 
 def fake_predict(spec, theta, y_scale, grid, fut, floor=None, cap=None, extra_future=None,
                  want_int=False, ctx=None, devices=None):
-    yh = np.full(fut.shape, 5.5)
+    yh = np.full((len(theta), np.shape(fut)[-1]), 5.5)
     return (yh, yh.astype(np.int32)) if want_int else yh
 
 

@@ -1,6 +1,6 @@
 """dev tool: per-phase cycles of the quadratic-form fit kernel (a -DTSF_QUAD_TIMING build of tsf_inst_quad3.hip /
 tsf_inst_quad4.hip, tools/build_variant.sh) for waves that run ALONE (one series per CU) and under load.
-  TSF_QUAD_REG=0 TSF_LIB_PATH=tools/variants/libtsf_amd_qtime.so python tools/quad_lone_timing.py"""
+  TSF_OPTIONS=quad_reg=0 TSF_LIB_PATH=tools/variants/libtsf_amd_qtime.so python tools/quad_lone_timing.py"""
 import os
 import sys
 
