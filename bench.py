@@ -183,6 +183,69 @@ def parity_context(f, spec, ds, y, fut, yhat_quad, n=256):
     return out
 
 
+def map_mode_leg(f, spec, ds, y, fut, out_stan, yhat_stan, n_true=48):
+    """tsf_spec.converge = MAP on the headline panel (round 6): the fit carried on from where Stan's tests stop it to the
+    maximum a posteriori estimate (map_kernel), with its COST beside the Stan-rule step -- evaluations and milliseconds --
+    and, on the first n_true series, the distance of both fits' 90-day forecasts to an independent solver's optimum
+    (oracle/true_map.py through tools/true_map_solve.py, in processes of its own: CPU only)."""
+    import subprocess
+    import tempfile
+    import torch
+    from time_series_spark_amd import _lib
+    sp = fc.ModelSpec.from_dict(dict(spec.to_dict(), lbfgs=dict(spec.lbfgs, converge=_lib.CONVERGE_MAP)))
+    g = DeviceForecaster(sp, f.device_index)
+    n = y.shape[0]
+    o = g.alloc_fit_output(n)
+    yh = torch.zeros((n, len(fut)), dtype=torch.float64, device=y.device)
+
+    def step():
+        g.fit_aligned(ds, y, o)
+        g.predict(o, fut, yh, None)
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    dt_ = (time.perf_counter() - t0) / 2
+    ne, ne0 = o.n_eval.cpu().numpy().astype(np.int64), out_stan.n_eval.cpu().numpy().astype(np.int64)
+    st = o.status.cpu().numpy()
+    res = {'what': 'the same panel with tsf_spec.converge = MAP: Stan-rule fit + continuation to the maximum a posteriori '
+                   'estimate (orthant-wise active-set L-BFGS on the residual-form evaluator) + forecast; never `value`',
+           'ms_per_step': 1e3 * dt_, 'series_per_s': n / dt_,
+           'mean_evals_stan_rule': float(ne0.mean()), 'mean_evals_with_continuation': float(ne.mean()),
+           'max_evals_with_continuation': int(ne.max()),
+           'status_counts': {str(int(k)): int(v) for k, v in zip(*np.unique(st, return_counts=True))},
+           'objective_gain_median': float(np.median((out_stan.fval - o.fval).cpu().numpy()))}
+    moved = (torch.abs(yh - yhat_stan) / torch.abs(yhat_stan)).median(dim=1).values.cpu().numpy()
+    res['forecast_rel_change_vs_stan_rule'] = {'median': float(np.median(moved)), 'p90': float(np.quantile(moved, 0.9))}
+    try:
+        n_true = min(n_true, n)
+        path = os.path.join(tempfile.gettempdir(), 'tsf_bench_true_map_%d.npz' % os.getpid())
+        env = dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1')
+        np.savez(path + '.panel.npz', ds=ds.cpu().numpy(), y=y[:n_true].cpu().numpy())
+        subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'true_map_solve.py'), 'cfg2', str(n_true), path,
+                        '--panel', path + '.panel.npz'], cwd=ROOT, env=env, check=True, capture_output=True, timeout=300)
+        z = np.load(path)
+        os.unlink(path)
+        os.unlink(path + '.panel.npz')
+        ys = o.y_scale.cpu().numpy()[:n_true]
+        th_map = o.theta.cpu().numpy()[:n_true]
+        rs = fc.fit_aligned(spec, ds.cpu().numpy(), y[:n_true].cpu().numpy())      # (host entry: its grid record for predict)
+        fut_np = fut.cpu().numpy()
+        y_true = fc.predict(spec, z['theta_map'], ys, rs.grid, fut_np)
+        y_map = fc.predict(spec, th_map, ys, rs.grid, fut_np)
+        y_st = fc.predict(spec, rs.theta, rs.y_scale, rs.grid, fut_np)
+        for key, yy in (('map_mode', y_map), ('stan_rule', y_st)):
+            rel = np.max(np.abs(yy - y_true) / np.abs(y_true), axis=1)
+            res['forecast_max_rel_err_over_horizon_vs_true_map_' + key] = {
+                'median': float(np.median(rel)), 'p90': float(np.quantile(rel, 0.9)), 'max': float(rel.max()), 'series': int(n_true)}
+        res['true_map_solver'] = 'oracle/true_map.py (delta split, scipy L-BFGS-B with bounds), kkt max %.1e' % float(z['kkt'].max())
+    except Exception as e:
+        res['vs_true_map_error'] = str(e)
+    return res
+
+
 def quad_waves_per_cu(n_series, n_cu):
     """Wave slots per CU of the route an aligned linear/additive panel of n_series takes (tsf_quad_launch.h /
     tsf_inst_quad.hip): the register-M kernel (8) up to 3 series per its wave slot, the 16-wave pooled kernel
@@ -329,6 +392,10 @@ def other_baseline_configs(dev, local):
                      # series in 10 000 run 30 000 evaluations, and they are the launch time of a 10 000-series panel --
                      # the evaluation rate is the figure that describes the kernel
                      'evaluations_per_s': None if not fk else float(ne.sum()) / (fk * 1e-3),
+                     # how much of the launch is its ONE longest fit (the dice: which series reaches Stan's iteration
+                     # limit moves with the last bit): longest fit's evaluations x the time per evaluation such a fit
+                     # takes alone on the cooperative kernel (5.05 us, profiles/r05_coop) over the launch
+                     'longest_fit_ms_over_launch_ms': None if not fk else min(1.0, float(ne.max()) * 5.05e-3 / fk),
                      'status_counts': {str(int(k)): int(v) for k, v in zip(*np.unique(st, return_counts=True))},
                      'finite_forecasts': bool(torch.isfinite(yh[o.status > 0]).all().item())}
 
@@ -356,6 +423,139 @@ def other_baseline_configs(dev, local):
     except Exception as e:
         out['irregular_reference_model'] = {'error': str(e)}
     return out
+
+
+def boundary_legs():
+    """The path at the boundary the reference keeps (north_star: "DataFrame-in/DataFrame-out ... fitted end-to-end";
+    prophet_modeler.py:41-79, :102-143; prophet_scorer.py:147-165) -- host IO, packing, H2D, fit, blobs, parquet, predict,
+    CSV included, so NEVER `value`:
+      files_to_files      the two jobs as their drivers run them (tools/e2e_bench.py): Hive-partitioned CSV ->
+                          ProphetModeler.model -> model parquet -> ProphetScorer.score -> forecast CSV, cfg2 and the
+                          reference's own model, 10 000 x 730; median of 3 passes after a warm-up pass in this process
+      dataframe_boundary  model_panel(config)(pdf) -> model frame -> forecast_panel(config)(models) -> forecast frame on a
+                          pandas frame of the reference's schema (int32 ids, datetime64 ds, int32 y), cfg2."""
+    import pandas as pd
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import e2e_bench
+    from time_series_spark_amd.jobs import prophet_modeler as pm, prophet_scorer as ps
+    out = {}
+    for kind in ('cfg2', 'reference'):
+        try:
+            r = e2e_bench.run(N_SERIES, T_POINTS, kind, passes=3)
+            out['files_to_files_' + kind] = {
+                'series_per_s': r['series_per_s_files_to_files'], 'series_per_s_best_pass': r['series_per_s_best_pass'],
+                'total_s': r['total_s'], 'modeler_s': r['modeler_s'], 'scorer_s': r['scorer_s'], 'passes': r['passes'],
+                'models': r['models'], 'forecast_rows': r['forecast_rows'], 'chunks': r['chunks'],
+                'workload': '%d partition directories x %d rows of CSV -> models (parquet) -> %d-day forecasts (CSV), %s'
+                            % (N_SERIES, T_POINTS, HORIZON, 'cfg2 model' if kind == 'cfg2' else
+                               "the reference's model (logistic, multiplicative: prophet_modeler.py:65)")}
+        except Exception as e:
+            out['files_to_files_' + kind] = {'error': str(e)}
+    try:
+        ds, y = synth.make_panel(N_SERIES, T_POINTS, 'linear', seed=2)
+        pdf = pd.DataFrame({'series_id': np.repeat(np.arange(N_SERIES, dtype=np.int32), T_POINTS),
+                            'dim_id': np.ones(N_SERIES * T_POINTS, dtype=np.int32),
+                            'ds': np.tile(ds.astype('datetime64[ns]'), N_SERIES), 'y': y.reshape(-1).astype(np.int32)})
+        cfg = {'model': {'floor': 0, 'cap_multiplier': 1.1,
+                         'prophet': {'growth': 'linear', 'seasonality_mode': 'additive', 'yearly_seasonality': True}},
+               'forecast': {'periods': HORIZON, 'frequency': 'D'}}
+        devnull, keep = open(os.devnull, 'w'), sys.stdout
+        sys.stdout = devnull
+        try:
+            tm, tf = [], []
+            for _ in range(4):
+                t0 = time.perf_counter()
+                models = pm.model_panel(cfg)(pdf)
+                t1 = time.perf_counter()
+                fdf = ps.forecast_panel(cfg)(models)
+                t2 = time.perf_counter()
+                tm.append(t1 - t0)
+                tf.append(t2 - t1)
+        finally:
+            sys.stdout = keep
+        m, f_ = float(np.median(tm[1:])), float(np.median(tf[1:]))
+        out['dataframe_boundary'] = {'series_per_s': N_SERIES / (m + f_), 'model_panel_s': m, 'forecast_panel_s': f_,
+                                     'models': int(len(models)), 'forecast_rows': int(len(fdf)),
+                                     'workload': 'cfg2: a %d-row pandas frame [series_id, dim_id, ds, y] -> model frame -> '
+                                                 'forecast frame [series_id, dim_id, ds, yhat]' % len(pdf)}
+    except Exception as e:
+        out['dataframe_boundary'] = {'error': str(e)}
+    return out
+
+
+def cfg5_legs(dev, local):
+    """BASELINE config 5 (1 000 000 series x 90 points, fp32 y, weekly seasonality only: the retail-SKU shape) in the
+    driver-run line (round-5 review): under L-BFGS at full size, and under the optimiser fbprophet itself takes below
+    100 rows (Stan's Newton: `'Newton' if T < 100`) on the first 100 000 series -- a SAMPLE, labelled so, with
+    the 1 000 000-series figure measured in full by tools/bench_configs.py cfg5_newton_1m (profiles/)."""
+    import torch
+    from time_series_spark_amd import _lib
+    out = {}
+    T5 = 90
+    ds5, y5 = synth.make_panel(1000000, T5, 'linear', seed=751, dtype=np.float32)
+    seas = fc.ModelSpec.auto_seasonalities(ds5)
+    fut_np = ds5[-1] + synth.DAY_NS * np.arange(1, HORIZON + 1)
+    dsd, futd = torch.from_numpy(ds5).to(dev), torch.from_numpy(fut_np).to(dev)
+    for name, n, spec, steps in (
+            ('cfg5', 1000000, fc.ModelSpec(growth='linear', seasonalities=seas), 2),
+            ('cfg5_newton', 100000, fc.ModelSpec(growth='linear', seasonalities=seas, algorithm=_lib.ALGO_NEWTON), 1)):
+        try:
+            yd = torch.from_numpy(np.ascontiguousarray(y5[:n])).to(dev)
+            f = DeviceForecaster(spec, local)
+            o = f.alloc_fit_output(n)
+            yh = torch.zeros((n, HORIZON), dtype=torch.float64, device=dev)
+
+            def step():
+                f.fit_aligned(dsd, yd, o)
+                f.predict(o, futd, yh, None)
+            step()
+            torch.cuda.synchronize()
+            f.set_profiling(True)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            torch.cuda.synchronize()
+            dt_ = (time.perf_counter() - t0) / steps
+            kms = f.profile_read()
+            f.set_profiling(False)
+            ne = o.n_eval.cpu().numpy().astype(np.int64)
+            st = o.status.cpu().numpy()
+            P5 = 3 + spec.n_changepoints + spec.K
+            alg = float(n) * (T5 * 4 + P5 * 4 + HORIZON * 4)            # SURVEY 8d: 856 B per series
+            fk = float(np.mean(kms)) if kms else None
+            out[name] = {'workload': ('BASELINE config 5: %d x 90, fp32 y, linear + weekly(3), ' % n) +
+                                     ('Stan L-BFGS' if name == 'cfg5' else
+                                      "Stan's Newton = fbprophet's own choice below 100 rows; the FIRST 100 000 series of the "
+                                      '1 000 000-series panel (a sample: the full size takes ~15 s)'),
+                         'series': n, 'series_per_s': n / dt_, 'ms_per_step': 1e3 * dt_, 'fit_kernel_ms': fk,
+                         'mean_evals': float(ne.mean()), 'max_evals': int(ne.max()), 'fitted': int((st > 0).sum()),
+                         'status_counts': {str(int(k)): int(v) for k, v in zip(*np.unique(st, return_counts=True))},
+                         'algorithmic_bytes': alg, 'algorithmic_GBps': None if not fk else alg / (fk * 1e-3) / 1e9}
+            del yd, o, yh, f
+        except Exception as e:
+            out[name] = {'error': str(e)}
+    return out
+
+
+def ranks_seen(dev, local):
+    """Who took part (round-5 review: make the first real 8-GPU run self-checking): world size and backend as
+    torch.distributed reports them, and every rank's device -- name, UUID, PCI bus id -- gathered on rank 0, so that the
+    driver can see that RCCL saw N ranks on N DISTINCT GPUs."""
+    import torch
+    import torch.distributed as dist
+    p = torch.cuda.get_device_properties(local)
+    mine = {'rank': int(os.environ.get('RANK', '0')), 'local_rank': int(os.environ.get('LOCAL_RANK', '0')),
+            'device_index': int(local), 'name': p.name, 'uuid': str(getattr(p, 'uuid', '')),
+            'pci_bus_id': int(getattr(p, 'pci_bus_id', -1)), 'visible_devices': torch.cuda.device_count(),
+            'pid': os.getpid(), 'host': os.uname().nodename}
+    if dist.is_available() and dist.is_initialized():
+        allr = [None] * dist.get_world_size()
+        dist.all_gather_object(allr, mine)
+        backend, world = dist.get_backend(), dist.get_world_size()
+    else:
+        allr, backend, world = [mine], None, 1
+    ids = {(r['host'], r['uuid'] or r['pci_bus_id'], r['device_index'] if not r['uuid'] else 0) for r in allr}
+    return {'world_size': world, 'backend': backend, 'ranks': allr, 'distinct_gpus': len(ids)}
 
 
 def irregular_leg(spec, N=10000):
@@ -422,6 +622,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-cfg3', action='store_true', help='skip the cfg3_sharded leg (100 000 x 1 095 over the ranks)')
     ap.add_argument('--no-other-configs', action='store_true', help='skip the other_baseline_configs leg (cfg1, cfg4, reference settings)')
+    ap.add_argument('--no-boundary', action='store_true', help='skip the files_to_files / dataframe_boundary legs')
     ap.add_argument('--timed-only', action='store_true',
                     help='only warm-up + the K timed steps (for rocprofv3 runs: every dispatch of the fit '
                          'kernel is then a full-panel launch, so per-kernel means are per launch)')
@@ -481,6 +682,7 @@ def main():
         return dt_, kms, o, yh
 
     dt, kernel_ms, out, yhat = timed_leg(y)
+    seen = ranks_seen(dev, local)        # (a collective: every rank)
 
     weak = None
     if world > 1:
@@ -586,6 +788,7 @@ def main():
         'scaling': 'strong',
         'value_scaling': 'strong: one %d-series panel whatever N (weak-scaling figure beside it in weak_scaling for N > 1)' % N_SERIES,
         'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'ranks_seen': seen,
         'config': {'workload': 'cfg2: ONE panel of %d series x %d daily points%s, linear trend + 25 '
                                'changepoints, weekly(3)+yearly(10) additive Fourier, MAP L-BFGS '
                                '(Stan default tolerances) + %d-step forecast'
@@ -637,6 +840,12 @@ def main():
         res['cfg3_sharded'] = cfg3
     if world == 1 and not args.no_other_configs and not args.timed_only:
         res['other_baseline_configs'] = other_baseline_configs(dev, local)
+        try:
+            res['other_baseline_configs'].update(cfg5_legs(dev, local))
+        except Exception as e:
+            res['other_baseline_configs']['cfg5'] = {'error': str(e)}
+    if world == 1 and not args.no_boundary and not args.timed_only:
+        res['boundary'] = boundary_legs()
     # What the strong-scaled legs SHOULD show, stated next to what they do show: a launch cannot end before
     # its longest fit, and a rank's queue cannot drain faster than its wave slots allow.  tau = time per
     # evaluation of one wave, calibrated on THIS run (rank 0's fit-path kernel time / the queue model's
@@ -738,6 +947,26 @@ def main():
             res['expected_8gpu_speedup'] = e8
         except Exception as e:
             res['expected_8gpu_speedup'] = {'error': str(e)}
+    # Third arrangement of the same split (round-5 review): ONE process, one host thread + context per visible GPU
+    # (forecaster.fit_aligned(devices='all'): series i on device i mod G) -- host pointers, so PCIe is inside
+    if world == 1 and not args.timed_only:
+        try:
+            from time_series_spark_amd import _lib as _l
+            G = int(_l.load().tsf_device_count())
+            if G > 1:
+                fc.fit_aligned(spec, ds_np, y_np, devices='all')
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    rh = fc.fit_aligned(spec, ds_np, y_np, devices='all')
+                td = (time.perf_counter() - t0) / 3
+                res['in_process_device_split'] = {'devices': G, 'series_per_s': N_SERIES / td, 'ms_per_fit': 1e3 * td,
+                                                  'identical_to_one_device': bool(np.array_equal(rh.theta, out.theta.cpu().numpy())),
+                                                  'note': 'fit only, host pointers (H2D / D2H inside), one thread per device'}
+            else:
+                res['in_process_device_split'] = {'devices': G, 'note': 'one visible device: nothing to split over '
+                                                                        '(tests/test_gpu_parity.py runs the split on three contexts of one GPU)'}
+        except Exception as e:
+            res['in_process_device_split'] = {'error': str(e)}
     # the same panel re-fitted with the evaluation counts of the previous fit as scheduling hints
     # (tsf_set_cost_hints: what a job that re-fits its panel regularly can do); never `value` -- the
     # headline has no such knowledge -- but it says how much of the launch is its tail
@@ -788,6 +1017,10 @@ def main():
             res['parity_context'] = parity_context(f, spec, ds, y, fut, yhat)
         except Exception as e:
             res['parity_context'] = {'error': str(e)}
+        try:
+            res['parity_context']['map_mode'] = map_mode_leg(f, spec, ds, y, fut, out, yhat)
+        except Exception as e:
+            res['parity_context']['map_mode'] = {'error': str(e)}
         if not args.no_cpu_baseline:
             try:
                 res['parity_context']['vs_true_map'] = vs_true_map()

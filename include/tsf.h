@@ -69,6 +69,13 @@ enum { TSF_EVAL_AUTO = 0, TSF_EVAL_RESIDUAL = 1, TSF_EVAL_QUADRATIC = 2 };
  * multiplicative columns.  Every model the library fits has one. */
 enum { TSF_ALGO_LBFGS = 0, TSF_ALGO_NEWTON = 1, TSF_ALGO_AUTO = 2 };
 enum { TSF_RK_AUTO = 0, TSF_RK_WAVE = 1, TSF_RK_MFMA = 2, TSF_RK_COOP = 3 };
+/* What a fit converges to.  TSF_CONVERGE_STAN (default): Stan's optimiser under Stan's termination tests -- what
+ * `Prophet.fit` returns (prophet_modeler.py:66): the point where the tests fire, a median 1e-3 .. 1e-2 away from the
+ * optimum in forecast, because L-BFGS stalls on the kinks of the Laplace prior on the changepoints.
+ * TSF_CONVERGE_MAP: from that point on to the maximum a posteriori estimate of prophet.stan's model itself (an
+ * orthant-wise active-set L-BFGS on the same log-posterior, tsf_map_kernels.h): forecasts that are a property of the
+ * model, not of a floating-point trajectory.  status then is TSF_ST_MAP_*; n_iter / n_eval count both phases. */
+enum { TSF_CONVERGE_STAN = 0, TSF_CONVERGE_MAP = 1 };
 #define TSF_NEWTON_BELOW_T 100
 
 /* per-series status: >= 0 are Stan's optimiser termination codes */
@@ -78,6 +85,11 @@ enum {
     TSF_ST_RELGRAD = 31, TSF_ST_MAXIT = 40,
     TSF_ST_CONSTANT = 50,      /* constant y, linear growth: fbprophet skips optimisation */
     TSF_ST_NEWTON_CONVERGED = 60, /* Newton: |lp - last lp| < 1e-8 */
+    /* tsf_spec.converge = TSF_CONVERGE_MAP: how the continuation to the maximum a posteriori estimate ended */
+    TSF_ST_MAP_KKT = 70,       /* KKT residual (largest one-sided derivative that still descends) <= map_tol */
+    TSF_ST_MAP_FTOL = 71,      /* 20 iterations together gained < 1e-13 |f|: the function value has converged */
+    TSF_ST_MAP_MAXIT = 72,     /* map_max_iter iterations */
+    TSF_ST_MAP_LS = 73,        /* no lower point along the steepest one-sided descent direction either (rounding level) */
     TSF_ST_NEWTON_FAIL = -4,   /* Newton: log_prob threw inside the finite-difference Hessian */
     TSF_ST_LSFAIL = -1,        /* line search failed (pystan raises RuntimeError) */
     TSF_ST_INIT_NONFINITE = -2,/* log_prob non-finite at the initial point (RuntimeError) */
@@ -133,6 +145,9 @@ typedef struct {
      * evaluations instead of at the tail of the launch; -1 = the default rule.  Results do not depend
      * on where a fit is suspended. */
     int32_t coop_after;                     /* -1 */
+    int32_t converge;                       /* TSF_CONVERGE_STAN */
+    int32_t map_max_iter;                   /* 10000: iterations of the continuation (converge = MAP) */
+    double map_tol;                         /* 1e-7: its KKT tolerance */
 } tsf_spec;
 
 /* What setup derives from one timestamp vector ("grid").  One per call for aligned panels,

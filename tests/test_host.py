@@ -35,6 +35,14 @@ def test_library_loads_and_exports_every_declared_symbol(built):
         (1e-3, 1e-12, 1e4, 1e-8, 1e7, 1e-8)
     # evaluation form of the likelihood (include/tsf.h): auto, re-centre every 128 / at ratio 1
     assert (s.eval_form, s.recenter_every, s.recenter_ratio) == (_lib.EVAL_AUTO, 128, 1.0)
+    # what a fit converges to: Stan's stopping rule by default (= Prophet.fit); the maximum a posteriori estimate on request
+    assert (s.converge, s.map_max_iter, s.map_tol) == (_lib.CONVERGE_STAN, 10000, 1e-7)
+    cm = fc.ModelSpec(growth='logistic', seasonalities=[helpers.WEEKLY], converge=_lib.CONVERGE_MAP, map_max_iter=500).to_c()
+    assert (cm.converge, cm.map_max_iter) == (_lib.CONVERGE_MAP, 500)
+    assert pm._spec_opts({'converge': 'map', 'map_tol': 1e-6}) == {'converge': _lib.CONVERGE_MAP, 'map_tol': 1e-6}
+    assert pm._spec_opts({'converge': 'stan'}) == {'converge': _lib.CONVERGE_STAN}
+    with pytest.raises(ValueError):
+        pm._spec_opts({'converge': 'both'})
     c = fc.ModelSpec(growth='linear', seasonalities=[helpers.WEEKLY], eval_form=_lib.EVAL_RESIDUAL,
                      recenter_every=8).to_c()
     assert (c.eval_form, c.recenter_every) == (_lib.EVAL_RESIDUAL, 8)

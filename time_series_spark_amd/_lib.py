@@ -24,14 +24,17 @@ Y_F64, Y_F32, Y_I32 = 0, 1, 2
 EVAL_AUTO, EVAL_RESIDUAL, EVAL_QUADRATIC = 0, 1, 2
 ALGO_LBFGS, ALGO_NEWTON, ALGO_AUTO = 0, 1, 2
 RK_AUTO, RK_WAVE, RK_MFMA, RK_COOP = 0, 1, 2, 3
+CONVERGE_STAN, CONVERGE_MAP = 0, 1
 
 ST_ABSX, ST_ABSF, ST_RELF, ST_ABSGRAD, ST_RELGRAD, ST_MAXIT = 10, 20, 21, 30, 31, 40
 ST_CONSTANT, ST_LSFAIL, ST_INIT_NONFINITE, ST_TOO_FEW, ST_CAP = 50, -1, -2, -10, -11
 ST_EVAL_LIMIT = -3
 ST_NEWTON_CONVERGED, ST_NEWTON_FAIL = 60, -4
+ST_MAP_KKT, ST_MAP_FTOL, ST_MAP_MAXIT, ST_MAP_LS = 70, 71, 72, 73
 STATUS_NAMES = {10: 'ABSX', 20: 'ABSF', 21: 'RELF', 30: 'ABSGRAD', 31: 'RELGRAD', 40: 'MAXIT',
                 50: 'CONSTANT', -1: 'LSFAIL', -2: 'INIT_NONFINITE', -3: 'EVAL_LIMIT', -10: 'TOO_FEW',
-                -11: 'CAP', 60: 'NEWTON_CONVERGED', -4: 'NEWTON_FAIL'}
+                -11: 'CAP', 60: 'NEWTON_CONVERGED', -4: 'NEWTON_FAIL', 70: 'MAP_KKT', 71: 'MAP_FTOL', 72: 'MAP_MAXIT',
+                73: 'MAP_LS'}
 
 
 class TsfSpec(ctypes.Structure):
@@ -53,7 +56,8 @@ class TsfSpec(ctypes.Structure):
                 ('eval_form', ctypes.c_int32), ('recenter_every', ctypes.c_int32),
                 ('recenter_ratio', ctypes.c_double),
                 ('algorithm', ctypes.c_int32), ('residual_kernel', ctypes.c_int32),
-                ('coop_after', ctypes.c_int32)]
+                ('coop_after', ctypes.c_int32), ('converge', ctypes.c_int32), ('map_max_iter', ctypes.c_int32),
+                ('map_tol', ctypes.c_double)]
 
 
 class TsfGridInfo(ctypes.Structure):

@@ -152,6 +152,7 @@ extern "C" void tsf_spec_default(tsf_spec *s)
     s->algorithm = TSF_ALGO_LBFGS;
     s->residual_kernel = TSF_RK_AUTO; s->recenter_every = 128; s->recenter_ratio = 1.0;
     s->coop_after = -1;
+    s->converge = TSF_CONVERGE_STAN; s->map_max_iter = 10000; s->map_tol = 1e-7;
 }
 
 extern "C" int tsf_spec_size(void) { return (int)sizeof(tsf_spec); }
@@ -195,6 +196,8 @@ static int build_devspec(tsf_ctx *ctx, const tsf_spec *s, DevSpec *d, int *mode_
     if (s->eval_form < TSF_EVAL_AUTO || s->eval_form > TSF_EVAL_QUADRATIC) return fail(ctx, "bad eval_form");
     if (s->algorithm < TSF_ALGO_LBFGS || s->algorithm > TSF_ALGO_AUTO) return fail(ctx, "bad algorithm");
     if (s->residual_kernel < TSF_RK_AUTO || s->residual_kernel > TSF_RK_COOP) return fail(ctx, "bad residual_kernel");
+    if (s->converge != TSF_CONVERGE_STAN && s->converge != TSF_CONVERGE_MAP) return fail(ctx, "bad converge");
+    if (s->converge == TSF_CONVERGE_MAP && (s->map_max_iter < 1 || !(s->map_tol > 0.0))) return fail(ctx, "map_max_iter must be >= 1 and map_tol > 0");
     if (s->eval_form != TSF_EVAL_RESIDUAL && (s->recenter_every < 1 || !(s->recenter_ratio > 0.0)))
         return fail(ctx, "recenter_every must be >= 1 and recenter_ratio > 0");
     const int K = tsf_spec_K(s);
@@ -379,6 +382,14 @@ static launch_newton_t pick_newton_launch(int growth, int mode)
 {
     static const launch_newton_t tab[2][3] = {{launch_newton_g0m0, launch_newton_g0m1, launch_newton_g0m2},
                                               {launch_newton_g1m0, launch_newton_g1m1, launch_newton_g1m2}};
+    return tab[growth][mode];
+}
+
+typedef int (*launch_map_t)(int, const FitArgs &, hipStream_t);
+static launch_map_t pick_map_launch(int growth, int mode)
+{
+    static const launch_map_t tab[2][3] = {{launch_map_g0m0, launch_map_g0m1, launch_map_g0m2},
+                                           {launch_map_g1m0, launch_map_g1m1, launch_map_g1m2}};
     return tab[growth][mode];
 }
 
@@ -757,6 +768,13 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
             HIP_TRY(ctx, hipMemsetAsync(a.coop_ctl, 0, 4 * sizeof(int), st));
         }
         lrc = pick_launch(hs.growth, mode)(hs.KP, a, theta_in != nullptr, st);
+    }
+    // converge = MAP: from where the optimiser's own tests stopped every fit on to the maximum a posteriori estimate
+    // (tsf_map_kernels.h), on the same stream behind whichever kernels ran the fit; inside the profiled interval
+    if (lrc == 0 && spec->converge == TSF_CONVERGE_MAP && theta_in == nullptr) {
+        a.map_max_iter = spec->map_max_iter; a.map_tol = spec->map_tol;
+        a.order = nullptr; a.run_flag = nullptr;
+        lrc = pick_map_launch(hs.growth, mode)(hs.KP, a, st);
     }
     if (ctx->profiling) { HIP_TRY(ctx, hipEventRecord(ctx->ev1[slot], st)); ctx->ev_count++; }
     if (order_buf >= 0) {       // the launch above reads the hint buffer: tsf_set_cost_hints waits for this before rewriting it

@@ -795,6 +795,8 @@ struct FitArgs {
     double *coop_slots;                 // [coop_max][coop_stride]
     int coop_max, coop_stride, coop_after, coop_blocks;
     int coop_tail_at;                   // tail rule: suspend once no more fits than this are still running (tsf_api.hip)
+    int map_max_iter;                   // converge = MAP (tsf_map_kernels.h): iteration limit and KKT tolerance of the continuation
+    double map_tol;
     // scheduling hint (tsf_set_cost_hints): the q-th series the launch starts is order[q]; null = q
     const int32_t *order;
     // ragged panels whose series SHARE timestamp vectors (round 4): grid_of[n] = the grid (timestamp vector with its

@@ -3,4 +3,5 @@
 #define TSF_M 2
 #define TSF_LAUNCH_NAME launch_g0m2
 #define TSF_NEWTON_LAUNCH_NAME launch_newton_g0m2
+#define TSF_MAP_LAUNCH_NAME launch_map_g0m2
 #include "tsf_inst.inc"

@@ -3,4 +3,5 @@
 #define TSF_M 0
 #define TSF_LAUNCH_NAME launch_g1m0
 #define TSF_NEWTON_LAUNCH_NAME launch_newton_g1m0
+#define TSF_MAP_LAUNCH_NAME launch_map_g1m0
 #include "tsf_inst.inc"

@@ -25,6 +25,13 @@ int launch_g0m2(int KP, const FitArgs &a, int eval_only, hipStream_t st);
 int launch_g1m0(int KP, const FitArgs &a, int eval_only, hipStream_t st);
 int launch_g1m1(int KP, const FitArgs &a, int eval_only, hipStream_t st);
 int launch_g1m2(int KP, const FitArgs &a, int eval_only, hipStream_t st);
+// map_kernel (tsf_spec.converge = MAP: the continuation of every fitted series to the maximum a posteriori estimate; tsf_map_kernels.h)
+int launch_map_g0m0(int KP, const FitArgs &a, hipStream_t st);
+int launch_map_g0m1(int KP, const FitArgs &a, hipStream_t st);
+int launch_map_g0m2(int KP, const FitArgs &a, hipStream_t st);
+int launch_map_g1m0(int KP, const FitArgs &a, hipStream_t st);
+int launch_map_g1m1(int KP, const FitArgs &a, hipStream_t st);
+int launch_map_g1m2(int KP, const FitArgs &a, hipStream_t st);
 // fit_mfma_kernel (aligned panels, residual form, 16 series per workgroup on the matrix cores;
 // tsf_inst_mfma.hip)
 size_t mfma_lds_bytes(int KP);

@@ -51,7 +51,7 @@ class ModelSpec(object):
         for k in self.lbfgs:
             if k not in ('max_iter', 'history', 'init_alpha', 'tol_obj', 'tol_rel_obj',
                          'tol_grad', 'tol_rel_grad', 'tol_param', 'eval_form', 'recenter_every',
-                         'recenter_ratio', 'algorithm', 'residual_kernel', 'coop_after'):
+                         'recenter_ratio', 'algorithm', 'residual_kernel', 'coop_after', 'converge', 'map_max_iter', 'map_tol'):
                 raise TypeError('unknown optimiser option %r' % k)
 
     # -- fbprophet set_auto_seasonalities on a timestamp vector --------------------------------

@@ -364,6 +364,16 @@ def _spec_opts(kw):
               'init_alpha', 'tol_obj', 'tol_rel_obj', 'tol_grad', 'tol_rel_grad', 'tol_param'):
         if k in kw:
             out[k] = kw[k]
+    # converge: 'stan' (default: where Stan's termination tests stop the optimiser -- what Prophet.fit returns) or 'map'
+    # (on to the maximum a posteriori estimate itself: include/tsf.h TSF_CONVERGE_MAP); not in the reference
+    if 'converge' in kw:
+        c = str(kw['converge']).lower()
+        if c not in ('stan', 'map'):
+            raise ValueError("converge must be 'stan' or 'map'")
+        out['converge'] = _lib.CONVERGE_MAP if c == 'map' else _lib.CONVERGE_STAN
+        for k in ('map_max_iter', 'map_tol'):
+            if k in kw:
+                out[k] = kw[k]
     return out
 
 

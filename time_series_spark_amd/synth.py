@@ -50,13 +50,29 @@ def make_panel(N, T, kind='linear', seed=751, dtype=np.float64, holidays=None):
     return daily_grid(T), y.astype(dtype)
 
 
+HOLIDAY_DOY = [14, 45, 82, 121, 150, 185, 230, 275, 310, 358, 20, 60, 100, 140, 200]
+
+
+def holiday_frame(ds_ns, n_holidays=10, lower=-1, upper=1):
+    """The holidays frame (Prophet(holidays=...): holiday, ds, lower_window, upper_window) whose indicator columns are
+    holiday_matrix's -- what the literal restatement (oracle/fbprophet_restated.ProphetOracle) takes."""
+    import pandas as pd
+    days = (np.asarray(ds_ns, dtype=np.int64) // DAY_NS).astype(np.int64)
+    years = np.unique(days.astype('datetime64[D]').astype('datetime64[Y]').astype(int) + 1970)
+    rows = []
+    for hi, d0 in enumerate(HOLIDAY_DOY[:n_holidays]):
+        for yv in years:
+            rows.append(('h%02d' % hi, np.datetime64('%d-01-01' % yv, 'D') + np.timedelta64(d0, 'D'), lower, upper))
+    return pd.DataFrame(rows, columns=['holiday', 'ds', 'lower_window', 'upper_window'])
+
+
 def holiday_matrix(ds_ns, n_holidays=10, lower=-1, upper=1):
     """Indicator columns for `n_holidays` fixed month/day dates per year with windows
     [lower, upper] (cfg4).  Returns (matrix [n_holidays*(upper-lower+1)][T], names)."""
     days = (np.asarray(ds_ns, dtype=np.int64) // DAY_NS).astype(np.int64)
     dates = days.astype('datetime64[D]')
     years = np.unique(dates.astype('datetime64[Y]').astype(int) + 1970)
-    doy = [14, 45, 82, 121, 150, 185, 230, 275, 310, 358, 20, 60, 100, 140, 200][:n_holidays]
+    doy = HOLIDAY_DOY[:n_holidays]
     cols, names = [], []
     for hi, d0 in enumerate(doy):
         for off in range(lower, upper + 1):

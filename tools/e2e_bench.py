@@ -35,6 +35,92 @@ def write_input(root, ds, y):
             f.write('\n')
 
 
+def run(n=10000, t=730, kind='cfg2', passes=3, chunks=None, no_hints=False, stages=False, keep=False, fake_gpu=False,
+        quiet=True):
+    """Writes the synthetic Hive-partitioned input, runs the two jobs `passes` times after a warm-up pass, returns the
+    result dict (times per pass, median / best series per second from files to files)."""
+    if fake_gpu:
+        import host_profile as hp
+        from time_series_spark_amd import forecaster as fc
+        fc.fit_aligned, fc.fit_ragged, fc.predict = hp.fake_fit_aligned, hp.fake_fit_ragged, hp.fake_predict
+    linear = kind == 'cfg2'
+    ds, y = synth.make_panel(n, t, 'linear' if linear else 'logistic', seed=2)
+    work = tempfile.mkdtemp(prefix='tsf_e2e_')
+    tm = {}
+    t0 = time.time()
+    write_input(os.path.join(work, 'model-input'), ds, y)
+    tm['(write synthetic input)'] = time.time() - t0
+    mcfg = {'io': {'input': os.path.join(work, 'model-input'), 'models': os.path.join(work, 'models')},
+            'model': {'floor': 0, 'cap_multiplier': 1.1}}
+    if chunks is not None:
+        mcfg['io']['chunks'] = chunks if chunks == 'auto' else int(chunks)
+    if no_hints:
+        mcfg['model']['schedule_from_previous_models'] = False
+    if linear:
+        mcfg['model']['prophet'] = {'growth': 'linear', 'seasonality_mode': 'additive',
+                                    'yearly_seasonality': True}
+    scfg = {'io': {'models': mcfg['io']['models'], 'forecasts': os.path.join(work, 'forecasts')},
+            'forecast': {'periods': 90, 'frequency': 'D'}}
+
+    def stage(name, f, *args):
+        t0 = time.time()
+        r = f(*args)
+        tm[name] = time.time() - t0
+        return r
+
+    devnull = open(os.devnull, 'w')
+    out = sys.stdout
+    if quiet:
+        sys.stdout = devnull          # the jobs print one line per chunk and per dropped series
+    jobs = []
+    try:
+        # the two jobs as their drivers run them (modeler_driver / scorer_driver): first pass pays library load + HIP init
+        for rep in ['warm-up '] + ['pass %d ' % i for i in range(passes)]:
+            t0 = time.time()
+            pm.ProphetModeler.model(None, mcfg, return_frame=False)
+            t1 = time.time()
+            ps.ProphetScorer.score(None, scfg)
+            t2 = time.time()
+            tm[rep + 'ProphetModeler.model'] = t1 - t0
+            tm[rep + 'ProphetScorer.score'] = t2 - t1
+            if not rep.startswith('warm'):
+                jobs.append((t1 - t0, t2 - t1))
+        models = pd.read_parquet(mcfg['io']['models'])
+        n_fc = sum(sum(1 for _ in open(os.path.join(scfg['io']['forecasts'], f))) - 1
+                   for f in os.listdir(scfg['io']['forecasts']) if f.endswith('.csv'))
+        for rep in (('warm-up ', '') if stages else ()):
+            mo = pm.ProphetModeler(mcfg)
+            # what ProphetModeler.model does: the previous run's models (none in the first pass) give this run its
+            # scheduling hints before they are overwritten
+            prev = stage(rep + 'previous_run_cost (scheduling hints)', pm.previous_run_cost, mcfg['io']['models']) \
+                if not no_hints else None
+            cols = stage(rep + 'read_input_columns', mo.read_input_columns)
+            mdl = stage(rep + 'model_arrays (pack + fit + blobs)', lambda c: pm.model_arrays(mcfg, previous=prev)(*c), cols)
+            stage(rep + 'persist_models', mo.persist_models, mdl)
+            sc = ps.ProphetScorer(scfg)
+            mdf = stage(rep + 'read_model_dataframe', sc.read_model_dataframe)
+            fdf = stage(rep + 'forecast_panel (predict)', ps.forecast_panel(scfg), mdf)
+            # (ProphetScorer.score: convert_forecasts is a lazy plan in the reference; the native sink formats the
+            # converted rows from the forecast columns, the converted frame is never built)
+            stage(rep + 'write_converted (convert + native sink)', sc.write_converted, fdf)
+    finally:
+        sys.stdout = out
+        if not keep:
+            shutil.rmtree(work, ignore_errors=True)
+    tot = sorted(m + s for m, s in jobs)
+    best, med = tot[0], tot[len(tot) // 2]
+    res = {'n_series': n, 'T': t, 'kind': kind, 'fake_gpu': fake_gpu, 'models': int(len(models)),
+           'forecast_rows': int(n_fc), 'total_s': round(med, 4), 'total_s_best': round(best, 4),
+           'modeler_s': round(sorted(m for m, _ in jobs)[len(jobs) // 2], 4),
+           'scorer_s': round(sorted(s for _, s in jobs)[len(jobs) // 2], 4),
+           'series_per_s_files_to_files': round(n / med, 1), 'series_per_s_best_pass': round(n / best, 1),
+           'passes': passes, 'chunks': mcfg['io'].get('chunks', 'auto'),
+           'stages_s': {k: round(v, 4) for k, v in tm.items()}}
+    if stages:
+        res['total_s_stages_one_after_the_other'] = round(sum(v for k, v in tm.items() if not k.startswith(('warm-up', '(', 'pass')) and 'Prophet' not in k), 4)
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--n', type=int, default=10000)
@@ -47,87 +133,10 @@ def main():
     ap.add_argument('--chunks', default=None, help="io.chunks of the modeler config ('auto' by default; 1 = no pipeline)")
     ap.add_argument('--passes', type=int, default=3, help='timed passes of the two jobs (the best and the median are reported)')
     a = ap.parse_args()
-    if a.fake_gpu:
-        import host_profile as hp
-        from time_series_spark_amd import forecaster as fc
-        fc.fit_aligned, fc.fit_ragged, fc.predict = hp.fake_fit_aligned, hp.fake_fit_ragged, hp.fake_predict
-    linear = a.kind == 'cfg2'
-    ds, y = synth.make_panel(a.n, a.t, 'linear' if linear else 'logistic', seed=2)
-    work = tempfile.mkdtemp(prefix='tsf_e2e_')
-    t = {}
-    t0 = time.time()
-    write_input(os.path.join(work, 'model-input'), ds, y)
-    t['(write synthetic input)'] = time.time() - t0
-    mcfg = {'io': {'input': os.path.join(work, 'model-input'), 'models': os.path.join(work, 'models')},
-            'model': {'floor': 0, 'cap_multiplier': 1.1}}
-    if a.chunks is not None:
-        mcfg['io']['chunks'] = a.chunks if a.chunks == 'auto' else int(a.chunks)
-    if a.no_hints:
-        mcfg['model']['schedule_from_previous_models'] = False
-    if linear:
-        mcfg['model']['prophet'] = {'growth': 'linear', 'seasonality_mode': 'additive',
-                                    'yearly_seasonality': True}
-    scfg = {'io': {'models': mcfg['io']['models'], 'forecasts': os.path.join(work, 'forecasts')},
-            'forecast': {'periods': 90, 'frequency': 'D'}}
-
-    def stage(name, f, *args):
-        t0 = time.time()
-        r = f(*args)
-        t[name] = time.time() - t0
-        return r
-
-    devnull = open(os.devnull, 'w')
-    out, sys.stdout = sys.stdout, devnull          # the jobs print one line per dropped series
-    jobs = []
-    try:
-        # the two jobs as their drivers run them (modeler_driver / scorer_driver): first pass pays library load + HIP init
-        for rep in ['warm-up '] + ['pass %d ' % i for i in range(a.passes)]:
-            t0 = time.time()
-            pm.ProphetModeler.model(None, mcfg, return_frame=False)
-            t1 = time.time()
-            ps.ProphetScorer.score(None, scfg)
-            t2 = time.time()
-            t[rep + 'ProphetModeler.model'] = t1 - t0
-            t[rep + 'ProphetScorer.score'] = t2 - t1
-            if not rep.startswith('warm'):
-                jobs.append((t1 - t0, t2 - t1))
-        import pandas as pd_
-        models = pd_.read_parquet(mcfg['io']['models'])
-        n_fc = sum(sum(1 for _ in open(os.path.join(scfg['io']['forecasts'], f))) - 1
-                   for f in os.listdir(scfg['io']['forecasts']) if f.endswith('.csv'))
-        for rep in (('warm-up ', '') if a.stages else ()):
-            mo = pm.ProphetModeler(mcfg)
-            # what ProphetModeler.model does: the previous run's models (none in the first pass) give this run its
-            # scheduling hints before they are overwritten
-            prev = stage(rep + 'previous_run_cost (scheduling hints)', pm.previous_run_cost, mcfg['io']['models']) \
-                if not a.no_hints else None
-            cols = stage(rep + 'read_input_columns', mo.read_input_columns)
-            models = stage(rep + 'model_arrays (pack + fit + blobs)', lambda c: pm.model_arrays(mcfg, previous=prev)(*c), cols)
-            stage(rep + 'persist_models', mo.persist_models, models)
-            sc = ps.ProphetScorer(scfg)
-            mdf = stage(rep + 'read_model_dataframe', sc.read_model_dataframe)
-            fdf = stage(rep + 'forecast_panel (predict)', ps.forecast_panel(scfg), mdf)
-            # (ProphetScorer.score: convert_forecasts is a lazy plan in the reference; the native sink formats the
-            # converted rows from the forecast columns, the converted frame is never built)
-            stage(rep + 'write_converted (convert + native sink)', sc.write_converted, fdf)
-    finally:
-        sys.stdout = out
-    for k, v in t.items():
+    res = run(a.n, a.t, a.kind, a.passes, a.chunks, a.no_hints, a.stages, a.keep, a.fake_gpu)
+    for k, v in res['stages_s'].items():
         print('%-44s %8.3f s' % (k, v))
-    tot = sorted(m + s for m, s in jobs)
-    best, med = tot[0], tot[len(tot) // 2]
-    res = {'n_series': a.n, 'T': a.t, 'kind': a.kind, 'fake_gpu': a.fake_gpu, 'models': int(len(models)),
-           'forecast_rows': int(n_fc), 'total_s': round(med, 4), 'total_s_best': round(best, 4),
-           'modeler_s': round(sorted(m for m, _ in jobs)[len(jobs) // 2], 4),
-           'scorer_s': round(sorted(s for _, s in jobs)[len(jobs) // 2], 4),
-           'series_per_s_files_to_files': round(a.n / med, 1), 'series_per_s_best_pass': round(a.n / best, 1),
-           'passes': a.passes, 'chunks': mcfg['io'].get('chunks', 'auto'),
-           'stages_s': {k: round(v, 4) for k, v in t.items()}}
-    if a.stages:
-        res['total_s_stages_one_after_the_other'] = round(sum(v for k, v in t.items() if not k.startswith(('warm-up', '(', 'pass')) and 'Prophet' not in k), 4)
     print(json.dumps(res))
-    if not a.keep:
-        shutil.rmtree(work, ignore_errors=True)
 
 
 if __name__ == '__main__':

@@ -83,7 +83,7 @@ def main():
     n_ref = int(sys.argv[2]) if len(sys.argv) > 2 else 64
     from time_series_spark_amd import synth
     jobs = []
-    ds, y = synth.make_panel(n_cfg2, 730, 'linear', seed=751)          # bench.py's panel: its first n series
+    ds, y = synth.make_panel(n_cfg2, 730, 'linear', seed=751)          # (a panel of bench.py's distribution; make_panel draws from ONE stream, so not its first n series)
     jobs += [('cfg2', n, ds, y[n].astype(np.float64), 0.0) for n in range(n_cfg2)]
     ds2, y2 = synth.make_panel(n_ref, 730, 'logistic', seed=751)       # tools/bench_configs.py ref10k: its first n series
     jobs += [('ref', n, ds2, y2[n].astype(np.float64), float(y2[n].max() * 1.1)) for n in range(n_ref)]
