@@ -38,9 +38,8 @@ enum {
     TSF_OPT_QUAD_RREG,       /* 0: residual-pass weights staged through memory */
     TSF_OPT_NEWTON_BATCH,    /* series per resident wave from which Newton runs several series per wave (0: never) */
     TSF_OPT_NEWTON_FLAGS, TSF_OPT_NEWTON_NS, TSF_OPT_NEWTON_LCAP, TSF_OPT_NEWTON_FILL,   /* dev knobs of that kernel */
-    TSF_OPT_QUAD_YIELD,      /* time slicing of the aligned quadratic-form kernel (default: off): n > 0 a fit is handed
-                                back after n evaluations while other series wait (panels of up to 24 series per wave
-                                slot); n < -1 after every |n| evaluations whether or not anyone waits (tests) */
+    TSF_OPT_QUAD_RAW_Y,      /* 0: the quadratic-form fit reads a scaled step-major copy of y (written by the set-up kernel) instead
+                                of the caller's rows */
     TSF_OPT_DEBUG_ASYNC_SCRATCH, /* dev (tools/dev/nb_debug.py): bit 0 the slot records of that kernel from hipMallocAsync /
                                 hipFreeAsync as in round 3 instead of the context's cached block; bit 1 synchronise the
                                 stream before the free; bit 2 canary pages either side of the records, checked after the

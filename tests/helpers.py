@@ -48,7 +48,7 @@ class _Routes(object):
              'TSF_GRAM_SHARE': 'gram_share', 'TSF_GRID_ORDER': 'grid_order', 'TSF_GRID_SHARE': 'grid_share',
              'TSF_RAGGED_SPLIT': 'ragged_split', 'TSF_QUAD_REG': 'quad_reg', 'TSF_QUAD_M2_LDS': 'quad_m2_lds',
              'TSF_QUAD_W4': 'quad_w4', 'TSF_QUAD_RREG': 'quad_rreg', 'TSF_NEWTON_BATCH': 'newton_batch',
-             'TSF_NEWTON_LCAP': 'newton_lcap', 'TSF_QUAD_YIELD': 'quad_yield'}
+             'TSF_NEWTON_LCAP': 'newton_lcap'}
 
     @staticmethod
     def _ctx():

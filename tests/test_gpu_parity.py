@@ -1944,38 +1944,3 @@ def test_baseline_config_1_every_series_against_the_oracle(env):
         r2 = fc.fit_aligned(spec, ds, y, floor=floor, cap=cap)
     for name in ('theta', 'fval', 'n_iter', 'n_eval', 'status'):
         assert np.array_equal(getattr(r, name), getattr(r2, name)), name
-
-
-def test_quadratic_form_time_slicing_changes_no_bit(env):
-    """Round 5: the aligned quadratic-form kernel hands a fit back after a quantum of evaluations while other series
-    wait (tsf_quad_kernels.h, QuadArgs::yield_evals): the optimiser state goes to a record in global memory, the series
-    to a queue, and whichever wave pops it -- on another CU, maybe another XCD -- resumes it at the top of its next
-    L-BFGS iteration.  The state is copied bit for bit, so nothing may change: off (also the default), quanta of 256 and 32
-    (only while someone waits), and unconditional suspension after every 8 and every 64 evaluations (a fit
-    of 1 500 evaluations then changes waves ~190 times) give identical outputs on a 7 000-series panel (the 12-wave
-    kernel; 2.3 series per wave slot) and on its first 200 series (nobody ever waits), and a sample incl. the longest
-    fit matches the oracle."""
-    fc, cl = env
-    from time_series_spark_amd import synth
-    N, T = 7000, 730
-    ds, y = synth.make_panel(N, T, 'linear', seed=512)
-    spec = fc.ModelSpec(growth='linear', seasonalities=[helpers.YEARLY, helpers.WEEKLY])
-    ctx = fc.get_context()
-    res = {}
-    for tag, q in (('off', 0), ('default', -1), ('q256', 256), ('q32', 32), ('every8', -8), ('every64', -64)):
-        with ctx.options(quad_yield=q, quad_reg=0):
-            res[tag] = fc.fit_aligned(spec, ds, y)
-            if tag in ('off', 'every8'):
-                res[tag + '_small'] = fc.fit_aligned(spec, ds, y[:200])
-    for tag in res:
-        ref = res['off_small'] if tag.endswith('_small') else res['off']
-        for name in ('theta', 'fval', 'n_iter', 'n_eval', 'status', 'y_scale'):
-            assert np.array_equal(getattr(ref, name), getattr(res[tag], name), equal_nan=True), (tag, name)
-    for name in ('theta', 'fval', 'n_iter', 'n_eval', 'status'):
-        assert np.array_equal(getattr(res['off'], name)[:200], getattr(res['off_small'], name)), name
-    r = res['every8']
-    csp = helpers.oracle_spec(spec)
-    for n in (0, 1, N - 1, int(np.argmax(r.n_eval)), int(np.argsort(r.n_eval)[-2])):
-        o = cl.fit(csp, ds, y[n])
-        assert (r.n_iter[n], r.n_eval[n], r.status[n]) == (o['n_iter'], o['n_eval'], o['status']), n
-        assert n_bit_diff(r.theta[n], o['theta']) == 0 and n_bit_diff(r.fval[n], o['f']) == 0, n

@@ -250,7 +250,7 @@ static int build_devspec(tsf_ctx *ctx, const tsf_spec *s, DevSpec *d, int *mode_
 // ---- workspace ------------------------------------------------------------------------------
 
 struct WsLayout {
-    size_t gtab, stab, tw, cw, Xw, yw, Mg, Mslot, rbuf, counter, uw, Xu, spm, spp, Bw, yrec, yq;
+    size_t gtab, stab, tw, cw, Xw, yw, Mg, Mslot, rbuf, counter, uw, Xu, spm, spp, Bw;
     size_t mXF, mXB, mXT, mtq, mcq, mcpof, myq, mhist;      // matrix-core path (tsf_mfma_kernels.h)
     size_t clist, cslots;                                   // cooperative tail (tsf_coop_kernels.h)
     size_t total;
@@ -278,7 +278,7 @@ static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 static WsLayout ws_layout(int64_t N, int64_t n_grids, int NTmax, int KP, int quad_P4 = 0,
                           int quad_slots = 0, int quad_ragged = 0, int64_t lat_U = 0,
                           const MfmaPlan *mp = nullptr, int coop_slots = 0, int coop_stride = 0, int64_t quad_pre = 0,
-                          bool sparse = false, int bw_ns = 0, bool yield = false)
+                          bool sparse = false, int bw_ns = 0, bool no_yw = false)
 {
     WsLayout l;
     size_t off = 0;
@@ -289,7 +289,7 @@ static WsLayout ws_layout(int64_t N, int64_t n_grids, int NTmax, int KP, int qua
     // lattice panels (lat_U > 0) keep one shared table Xu and a row index per series row
     // instead of a design matrix per grid
     l.Xw = off; off = align_up(off + (lat_U > 0 ? 0 : sizeof(double) * (size_t)n_grids * NTmax * KP * W));
-    l.yw = off; off = align_up(off + sizeof(double) * (size_t)N * NTmax * W);
+    l.yw = off; off = align_up(off + (no_yw ? 0 : sizeof(double) * (size_t)N * NTmax * W));
     // one Gram matrix for an aligned panel; quad_pre of them for a ragged panel whose series share timestamp vectors
     l.Mg = off; off = align_up(off + sizeof(double) * (size_t)quad_P4 * 2 * W * (size_t)(quad_pre > 0 ? quad_pre : 1));
     l.Mslot = off; off = align_up(off + (quad_ragged ? sizeof(double) * (size_t)quad_slots * quad_P4 * 2 * W : 0));
@@ -300,9 +300,6 @@ static WsLayout ws_layout(int64_t N, int64_t n_grids, int NTmax, int KP, int qua
     l.spp = off; off = align_up(off + (sparse ? sizeof(unsigned long long) * (size_t)n_grids * SP_MAXC : 0));
     // base pairs of the Fourier columns (fit_kernel<..., HARM>): two doubles per seasonality and row
     l.Bw = off; off = align_up(off + sizeof(double) * (size_t)n_grids * NTmax * bw_ns * 2 * W);
-    // time slicing of the quadratic-form kernel (QuadArgs::yield_evals): a record per series and the queue of suspended fits
-    l.yrec = off; off = align_up(off + (yield ? sizeof(double) * (size_t)N * YREC_D : 0));
-    l.yq = off; off = align_up(off + (yield ? sizeof(int) * (8 + 2 * (size_t)N) : 0));
     l.uw = off; off = align_up(off + (lat_U > 0 ? sizeof(int32_t) * (size_t)n_grids * NTmax * W : 0));
     l.Xu = off; off = align_up(off + (lat_U > 0 ? sizeof(double) * (size_t)lat_U * KP : 0));
     const bool mf = mp && mp->on;
@@ -585,20 +582,12 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     if (quad && !aligned && !quad_pre && lat_U == 0 && hs.harm == HARM_Y10_W3 && hs.KP == 28 && ctx->opt[TSF_OPT_HARM] != 0)
         gram_harm = hs.harm;
     const int bw_ns = (harm || gram_harm) ? hs.n_seas : 0;
-    // Time slicing of the aligned one-slot quadratic-form kernels (tsf_quad_kernels.h, QuadArgs::yield_evals): a wave
-    // hands a fit back after `quantum` evaluations while other series wait.  OFF unless asked for
-    // (tsf_set_option(TSF_OPT_QUAD_YIELD, n): n > 0 the quantum; n < -1 suspend after every |n| evaluations whether or
-    // not anyone waits -- tests): measured, it is worth 2-7 % of a launch and writes and re-reads a 9 KB
-    // record per hand-back -- 355 instead of 78 MB of HBM traffic on the headline panel, whose figure of merit next to
-    // its rate is exactly that traffic.  Never with scheduling hints (it would undo the caller's order), never beyond 24
-    // series per wave slot (throughput launches; the records would be gigabytes).
-    int yield_evals = 0;
-    if (quad && aligned && hs.KP != 64 && !(ctx->order_n == N && !theta_in) && N <= (int64_t)24 * 12 * ctx->n_cu) {
-        const int o = ctx->opt[TSF_OPT_QUAD_YIELD];
-        yield_evals = (o == -1) ? 0 : o;
-    }
+    // Quadratic-form L-BFGS fits read the caller's y rows themselves (FitArgs::y_raw) instead of a scaled step-major copy
+    // that setup_series_kernel would write and they would read back -- a second f64 panel on the device and half of the
+    // step's HBM bytes.  Not when the MAP continuation follows (its evaluator reads yw).
+    const bool raw_y = quad && spec->converge != TSF_CONVERGE_MAP && ctx->opt[TSF_OPT_QUAD_RAW_Y] != 0;
     const WsLayout l = ws_layout(N, n_grids, NTmax, hs.KP, qp.P4, qp.slots, (quad || newton_quad) && !aligned, lat_U, &mp,
-                                 coop_slots, coop_stride, quad_pre, sparse_try, bw_ns, yield_evals != 0);
+                                 coop_slots, coop_stride, quad_pre, sparse_try, bw_ns, raw_y);
     rc = ensure_ws(ctx, l.total, N, NTmax, !aligned);
     if (rc) return rc;
     char *ws = (char *)ctx->ws;
@@ -607,7 +596,7 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     double *tw = (double *)(ws + l.tw);
     uint16_t *cw = (uint16_t *)(ws + l.cw);
     double *Xw = (double *)(ws + l.Xw);
-    double *yw = (double *)(ws + l.yw);
+    double *yw = raw_y ? (double *)nullptr : (double *)(ws + l.yw);
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_spec, &hs, sizeof(hs), hipMemcpyHostToDevice, st));
     if (lat_U > 0) {
         double *Xu = (double *)(ws + l.Xu);
@@ -636,10 +625,14 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
                            (uint32_t *)(ws + l.spm), (unsigned long long *)(ws + l.spp), sp_bad);
         HIP_TRY(ctx, hipGetLastError());
     }
-    hipLaunchKernelGGL(setup_series_kernel, dim3((unsigned)N), dim3(64), 0, st, ctx->d_spec, N,
-                       aligned ? nullptr : offsets, T, ds, y, y_dtype, floor_, cap, NTmax, gtab,
-                       aligned, stab, yw, grid_of);
-    HIP_TRY(ctx, hipGetLastError());
+    // (raw_y: the quadratic-form fit kernel derives the scale and the initial values from the caller's rows itself --
+    // series_tab_wave, tsf_quad_kernels.h -- and no kernel of that route reads SeriesTab or yw)
+    if (!raw_y) {
+        hipLaunchKernelGGL(setup_series_kernel, dim3((unsigned)N), dim3(64), 0, st, ctx->d_spec, N,
+                           aligned ? nullptr : offsets, T, ds, y, y_dtype, floor_, cap, NTmax, gtab,
+                           aligned, stab, yw, grid_of);
+        HIP_TRY(ctx, hipGetLastError());
+    }
     FitArgs a;
     memset(&a, 0, sizeof(a));
     a.sp = ctx->d_spec; a.N = N; a.aligned = aligned; a.NTmax = NTmax;
@@ -655,6 +648,7 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     a.theta = out->theta; a.y_scale = out->y_scale; a.fval = out->fval; a.status = out->status;
     a.n_iter = out->n_iter; a.n_eval = out->n_eval; a.grid_out = out->grid;
     a.theta_in = theta_in; a.grad_out = grad_out;
+    if (raw_y) { a.y_raw = y; a.y_raw_dtype = y_dtype; a.y_offsets = aligned ? nullptr : offsets; a.y_T = T; }
     a.uw = (const int32_t *)(ws + l.uw); a.Xu = (const double *)(ws + l.Xu); a.xidx = lat_U > 0 ? 1 : 0;
     a.grid_of = grid_of;
     a.Bw = bw_ns ? (const double *)(ws + l.Bw) : nullptr; a.bw_ns = bw_ns; a.harm = harm;
@@ -719,10 +713,6 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
         qa.Mpre = quad_pre ? qa.Mg : nullptr; qa.n_pre = quad_pre;
         qa.gram_harm = gram_harm;
         HIP_TRY(ctx, hipMemsetAsync(qa.counter, 0, sizeof(int), st));
-        if (yield_evals != 0) {
-            qa.yield_evals = yield_evals; qa.yrec = (double *)(ws + l.yrec); qa.yq = (int *)(ws + l.yq);
-            HIP_TRY(ctx, hipMemsetAsync(qa.yq, 0, sizeof(int) * (8 + 2 * (size_t)N), st));
-        }
         lrc = launch_quad(hs.KP, qp, qa, (double *)(ws + l.Mg), st);
     } else if (mp.on) {
         MfmaTabs mt;

@@ -233,13 +233,6 @@ __global__ void setup_lattice_kernel(const DevSpec *__restrict__ sp, int64_t U, 
     }
 }
 
-__device__ __forceinline__ double load_y(const void *y, int dtype, int64_t i)
-{
-    if (dtype == TSF_Y_F64) return ((const double *)y)[i];
-    if (dtype == TSF_Y_F32) return (double)((const float *)y)[i];
-    return (double)((const int32_t *)y)[i];
-}
-
 // One wave per series: y scaling (initialize_scales), step-major copy of scaled y, growth
 // init (linear_growth_init / logistic_growth_init).
 __global__ __launch_bounds__(64) void setup_series_kernel(
@@ -256,7 +249,7 @@ __global__ __launch_bounds__(64) void setup_series_kernel(
     const int T = gt.info.T, NT = gt.info.NT;
     const int64_t row0 = offsets ? offsets[n] : n * (int64_t)T_aligned;
     const int64_t *ds = ds_all + (offsets ? offsets[n] : 0);
-    double *yw = yw_all + (size_t)n * NTmax * W;
+    double *yw = yw_all ? yw_all + (size_t)n * NTmax * W : nullptr;      // null: the fit reads the caller's rows itself (quadratic form)
     SeriesTab &st = stab[n];
     const double fl = (sp->growth == TSF_GROWTH_LOGISTIC && floor_in) ? floor_in[n] : 0.0;
     const double capv = cap_in ? cap_in[n] : 0.0;
@@ -298,7 +291,9 @@ __global__ __launch_bounds__(64) void setup_series_kernel(
         ymax = __builtin_fmax(ymax, __shfl_xor(ymax, off, W));
     }
     const double ys = (amax == 0.0) ? 1.0 : amax;
-    if (hold) {
+    if (!yw) {
+        // no scaled copy wanted
+    } else if (hold) {
 #pragma unroll
         for (int k = 0; k < HOLD; ++k) {
             const int i = lane + k * W;

@@ -123,6 +123,14 @@ struct GridTab {
     int32_t pad_;
 };
 
+// one value of the caller's y column (f64, f32 or the reference schema's int32: prophet_modeler.py:16)
+__device__ __forceinline__ double load_y(const void *y, int dtype, int64_t i)
+{
+    if (dtype == TSF_Y_F64) return ((const double *)y)[i];
+    if (dtype == TSF_Y_F32) return (double)((const float *)y)[i];
+    return (double)((const int32_t *)y)[i];
+}
+
 struct SeriesTab {
     double y_scale, cap, k0, m0, floor_;
     int32_t status0;                    // 0 ok, TSF_ST_TOO_FEW / TSF_ST_CAP / TSF_ST_CONSTANT

@@ -17,6 +17,12 @@ struct SeriesView {
     const unsigned short *sp_list;      // (SPARSE kernels) [SP_M + 1][64] entry words of the lanes, last row first, in LDS
     int S_out;                          // changepoints in the caller's layout (S = 1 > S_out = 0: dummy changepoint)
     const double *tw, *yw, *Xw;         // step-major tables
+    // (quadratic-form kernels, round 6) the caller's own y rows instead of a scaled step-major copy: row i of the series at
+    // y_raw[y_base + i], scaled in the register as setup_series_kernel would have -- (y - 0) / y_scale, linear growth
+    const void *y_raw;
+    int y_dtype;
+    long long y_base;
+    double y_scl;
     const double *Bw;                   // (HARM kernels) base pairs [NT][seasonality][64][2]: sin theta, cos theta of the row
     int n_xd;                           // (HARM kernels) dense explicit columns behind the Fourier columns (read from Xw)
     const int32_t *uw;                  // (lattice panels) row -> row of the shared table Xu, step-major
@@ -795,6 +801,11 @@ struct FitArgs {
     double *coop_slots;                 // [coop_max][coop_stride]
     int coop_max, coop_stride, coop_after, coop_blocks;
     int coop_tail_at;                   // tail rule: suspend once no more fits than this are still running (tsf_api.hip)
+    // quadratic-form fit (tsf_quad_kernels.h): the residual passes read the caller's y rows (series n at y_raw[y_T * n + i], or
+    // at y_offsets[n] + i) and scale them in the register; yw is then not written at all (null)
+    const void *y_raw;
+    const int64_t *y_offsets;
+    int y_raw_dtype, y_T;
     int map_max_iter;                   // converge = MAP (tsf_map_kernels.h): iteration limit and KKT tolerance of the continuation
     double map_tol;
     // scheduling hint (tsf_set_cost_hints): the q-th series the launch starts is order[q]; null = q
@@ -883,6 +894,7 @@ __device__ __forceinline__ void make_view(const FitArgs &a, int64_t n, SeriesVie
     sv.Bw = a.Bw ? a.Bw + (size_t)g * a.NTmax * a.bw_ns * 2 * W : nullptr;
     sv.n_xd = 0;
     sv.yw = a.yw + (size_t)n * a.NTmax * W;
+    sv.y_raw = nullptr;
     sv.Lj = gt.Lj;
     sv.t_change = gt.info.t_change;
     sv.cap = a.stab[n].cap;

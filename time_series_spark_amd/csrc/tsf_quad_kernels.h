@@ -58,35 +58,9 @@ struct QuadArgs {
     long long *dbg;                     // -DTSF_QUAD_TIMING builds only: [N][8] cycles per phase
     void *nb_buf;                       // slot records of newton_batch_kernel (tsf_newton_batch.h), or null
     size_t nb_bytes;
-    // Time slicing (round 5; aligned shared-M kernels): a launch lasts as long as the fits of its busiest wave slot, and
-    // nothing cheap predicts which series are long -- so a wave that has spent yield_evals evaluations on a series while
-    // others wait (unstarted series, or suspended ones) writes the fit's state to the series' record, appends the series
-    // to the queue of suspended fits and takes the next one; whoever pops it later resumes it at the top of its next
-    // L-BFGS iteration.  Round robin needs no knowledge of the costs and ends within a few per cent of the best
-    // possible order (longest first); the state is copied bit for bit, so no result depends on it.
-    // yield_evals: 0 off; > 0 quantum; < 0 (tests) suspend after every |yield_evals| evaluations whether or not anyone waits.
-    int yield_evals;
     int gram_harm;                      // ragged, a grid per series, M in registers: harm_code of the model when the build expands the
                                         // Fourier columns from the rows' base pairs (FitArgs::Bw; gram_columns_harm), else 0
-    double *yrec;                       // [N][YREC_D] suspended fits
-    int *yq;                            // [1] suspensions so far, [2] series finished, [8 ..] ring of N series ids, then N publish words
-                                        // (tickets come from `counter`: 0 .. N-1 unstarted series, N + k the k-th suspension)
 };
-
-// Loads and stores of the records and the queue: RELAXED ATOMICS at agent scope (sc1 accesses: coherent across the
-// XCDs' L2s word by word) with a plain s_waitcnt between the data and the publish word -- NOT agent-scope fences: on
-// this part a release / acquire fence writes back / invalidates the whole L2 of the XCD, and a few thousand of them per
-// launch stalled every wave of the chip (measured: 9 -> 346 ms; profiles/r05_yield).
-__device__ __forceinline__ void st_agent(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ double ld_agent(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_agent(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ int ld_agent(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
-// record of a suspended fit (doubles): 32 scalars, then the vectors x, g, x_prev, g_prev, p, ref, c and the history ring
-// S[QH], Y[QH], one row of 64 each (one-slot kernels)
-constexpr int YREC_NV = 7 + 2 * 5;
-constexpr int YREC_D = 32 + YREC_NV * W;
 
 template <int KP, int PPL>
 struct QuadLds {
@@ -519,7 +493,16 @@ __device__ __forceinline__ bool resid_eval_q(const SeriesView &sv, QuadLds<KP, P
     wave_sync();
     const double *beta = wl.th + 3 + S;
     auto gen = [&](int q, int idx, int c, double ti) -> double {
-        const double yi = sv.yw[idx];
+        // y of the row: from the scaled step-major copy, or (round 6) the caller's own row, scaled here with
+        // setup_series_kernel's operation -- (y - 0) / y_scale: linear growth has no floor -- so the same bits, and no
+        // second f64 panel on the device (HBM bytes of the step: 4.1 x the algorithmic figure -> 2.2 x)
+        double yi;
+        if (sv.y_raw) {
+            yi = 0.0;
+            if (q < sv.cnt) yi = load_y(sv.y_raw, sv.y_dtype, sv.y_base + (long long)lane * sv.NT + q) / sv.y_scl;
+        } else {
+            yi = sv.yw[idx];
+        }
         const double *xp = sv.Xw + (size_t)q * KP * W + lane;
         double xa = 0.0;
         if constexpr (HARM != 0) {
@@ -702,7 +685,10 @@ __device__ __forceinline__ void make_view_grid(const FitArgs &a, int64_t g, int6
     sv.cw = a.cw + (size_t)g * a.NTmax * W;
     sv.Xw = a.Xw + (size_t)g * a.NTmax * KP * W;
     sv.Bw = a.Bw ? a.Bw + (size_t)g * a.NTmax * a.bw_ns * 2 * W : nullptr;
-    sv.yw = a.yw + (size_t)n * a.NTmax * W;
+    sv.yw = a.yw ? a.yw + (size_t)n * a.NTmax * W : nullptr;
+    sv.y_raw = a.y_raw; sv.y_dtype = a.y_raw_dtype;
+    sv.y_base = a.y_raw ? (a.y_offsets ? (long long)a.y_offsets[n] : (long long)n * a.y_T) : 0;
+    sv.y_scl = 1.0;                      // (set by the caller from series_tab_wave's result)
     sv.Lj = gt.Lj;
     sv.t_change = gt.info.t_change;
     sv.cap = 0.0;
@@ -1026,21 +1012,56 @@ __global__ __launch_bounds__(64) void gram_grids_kernel(QuadArgs qa, double *Mpr
 // age h = (h0 + h) mod QH) instead of 4 QH PPL registers per lane -- what lets a third wave per
 // SIMD fit the register file (tsf_inst_quad.hip); same values, same operation order.
 // NTR > 0: the weights of a residual pass in NTR registers (ztr_pass), rb unused.
+// What setup_series_kernel derives from a series -- y_scale = max |y|, the constant-history flag, fbprophet's
+// linear_growth_init (k, m) from the first row and the first row that holds the last timestamp -- computed by the wave that
+// is about to fit the series, from the caller's own rows (round 6: the quadratic-form route has no set-up pass over y and
+// no scaled copy of it; the step moves 1.6 x its algorithmic bytes instead of 4.1 x).  Same operations on the same
+// operands as the kernel's (linear growth: the floor is 0 and (y - 0) / y_scale is y / y_scale; the two scaled times are
+// the grid table's own values, (ds - start) / t_scale by the same expression), so the same bits.
+__device__ __forceinline__ SeriesTab series_tab_wave(const SeriesView &sv, const GridTab &gt)
+{
+    SeriesTab st;
+    st.cap = 0.0; st.floor_ = 0.0; st.k0 = 0.0; st.m0 = 0.0; st.y_scale = 1.0; st.status0 = 0; st.pad_ = 0;
+    const int T = sv.T, NT = sv.NT;
+    if (T < 2) { st.status0 = TSF_ST_TOO_FEW; return st; }
+    const int lane = lane_id();
+    double amax = 0.0, ymin = __builtin_huge_val(), ymax = -__builtin_huge_val();
+    for (int i = lane; i < T; i += W) {
+        const double v = load_y(sv.y_raw, sv.y_dtype, sv.y_base + i);
+        amax = __builtin_fmax(amax, __builtin_fabs(v - 0.0));
+        ymin = __builtin_fmin(ymin, v);
+        ymax = __builtin_fmax(ymax, v);
+    }
+#pragma unroll
+    for (int off = 1; off < W; off <<= 1) {
+        amax = __builtin_fmax(amax, __shfl_xor(amax, off, W));
+        ymin = __builtin_fmin(ymin, __shfl_xor(ymin, off, W));
+        ymax = __builtin_fmax(ymax, __shfl_xor(ymax, off, W));
+    }
+    const double ys = (amax == 0.0) ? 1.0 : amax;
+    const int i1 = gt.info.i1;
+    const double t0 = sv.tw[0];                                           // row 0: chunk 0, step 0
+    const double t1 = sv.tw[(i1 - (i1 / NT) * NT) * W + i1 / NT];
+    const double y0 = (load_y(sv.y_raw, sv.y_dtype, sv.y_base) - 0.0) / ys;
+    const double y1 = (load_y(sv.y_raw, sv.y_dtype, sv.y_base + i1) - 0.0) / ys;
+    const double Td = t1 - t0;
+    st.k0 = (y1 - y0) / Td;
+    st.m0 = y0 - st.k0 * t0;
+    if (ymin == ymax) st.status0 = TSF_ST_CONSTANT;
+    st.y_scale = ys;
+    return st;
+}
+
 // POOL: wlp is null; a residual pass borrows a QuadLds of `pool` and the vectors that live across
 // evaluations (D, ref, c) sit in the wave's QuadWave `qw`.
 template <int KP, int PPL, int PQ, bool RAGGED, int MRS = W, bool HLDS = false, int MBATCH = 16, bool MREG = false, int NTR = 0, bool POOL = false,
-          bool YK = false,                                 // the time-slicing build of the kernel (a separate instantiation:
-                                                           // compiled into the default one its paths cost the headline 3-4 %)
           bool MPIPE = (TSF_QUAD_MPIPE != 0) && !POOL>     // (the 128-register kernel has no room for a second batch in flight)
 __device__ __forceinline__ bool fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL> *wlp, double *rb,
                                           const double *Mp, double *Mown, int64_t n, double *lanec,
                                           double *hist = nullptr, GramX *gx = nullptr,
-                                          QuadWave<PPL> *qw = nullptr, const QuadPool *pool = nullptr, bool resume = false)
+                                          QuadWave<PPL> *qw = nullptr, const QuadPool *pool = nullptr)
 {
     static_assert(!POOL || (!RAGGED && PQ > 0 && PPL == 1), "pooled trend tables: the shared-M one-slot kernel");
-    // time slicing: the kernels whose whole optimiser state is a handful of scalars, five registers per lane and LDS rows
-    // (not the pooled 16-wave kernel: it serves launches that are throughput, and at 128 registers the extra paths spill)
-    constexpr bool YIELD = YK && HLDS && !RAGGED && !MREG && PPL == 1 && PQ > 0 && !POOL;
     double *const dl_w = POOL ? qw->dl : wlp->th;
     double *const ref_w = POOL ? qw->ref : wlp->ref;
     double *const cvec_w = POOL ? qw->cvec : wlp->cvec;
@@ -1053,7 +1074,8 @@ __device__ __forceinline__ bool fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
     const int maxLSIts = 20, maxLSRestarts = 10;
     SeriesView sv;
     make_view_q<KP, PPL>(a, n, sv);
-    const SeriesTab st = a.stab[n];
+    const SeriesTab st = a.y_raw ? series_tab_wave(sv, a.gtab[grid_index(a, n)]) : a.stab[n];
+    sv.y_scl = st.y_scale;
     if (lane == 0) {
         a.y_scale[n] = st.y_scale;
         if (!a.aligned || n == 0) a.grid_out[a.aligned ? 0 : n] = a.gtab[grid_index(a, n)].info;
@@ -1241,35 +1263,6 @@ __device__ __forceinline__ bool fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
     // update and the termination tests for x_k] + the line search from x_k; each evaluation form
     // still has a single call site.
     bool first = true, do_resid = true;
-    int ev_slice0 = 0;                  // evaluations of this series when this wave took it
-    if constexpr (YIELD) {
-        if (resume) {
-            // a suspended fit: everything the loop below carries from one iteration to the next, bit for bit
-            // (the record's address goes through an empty asm at both sites: otherwise the compiler computes the row
-            // addresses of the save below -- beyond the 4 KB an instruction's offset reaches -- once per series, up here,
-            // and keeps ten address pairs alive, i.e. spilled, through the whole fit)
-            long long roff = (long long)n * YREC_D;
-            asm volatile("" : "+s"(roff));
-            const double *rec = qa.yrec + roff;
-            const double *rv = rec + 32 + lane;
-            xk[0] = ld_agent(rv + 0 * W); gk[0] = ld_agent(rv + 1 * W); xk1[0] = ld_agent(rv + 2 * W); gk1[0] = ld_agent(rv + 3 * W);
-            pk[0] = ld_agent(rv + 4 * W);
-            ref_w[lane] = ld_agent(rv + 5 * W); cvec_w[lane] = ld_agent(rv + 6 * W);
-#pragma unroll
-            for (int h = 0; h < QH; ++h) { histS[h * W + lane] = ld_agent(rv + (7 + h) * W); histY[h * W + lane] = ld_agent(rv + (7 + QH + h) * W); }
-            if (lane < QH) histR[lane] = ld_agent(rec + 16 + lane);
-            fk = UQ(ld_agent(rec + 0)); fk1 = UQ(ld_agent(rec + 1)); alpha = UQ(ld_agent(rec + 2)); dfp = UQ(ld_agent(rec + 3));
-            gp1s = UQ(ld_agent(rec + 4)); s0 = UQ(ld_agent(rec + 5)); q2 = UQ(ld_agent(rec + 6));
-            const int *ri = reinterpret_cast<const int *>(rec + 8);
-            itNum = __builtin_amdgcn_readfirstlane(ld_agent(ri + 0)); hist_len = __builtin_amdgcn_readfirstlane(ld_agent(ri + 1));
-            h0 = __builtin_amdgcn_readfirstlane(ld_agent(ri + 2)); since_rc = __builtin_amdgcn_readfirstlane(ld_agent(ri + 3));
-            do_resid = __builtin_amdgcn_readfirstlane(ld_agent(ri + 4)) != 0; pk1_scaled = __builtin_amdgcn_readfirstlane(ld_agent(ri + 5)) != 0;
-            sv.n_eval = __builtin_amdgcn_readfirstlane(ld_agent(ri + 6)); resetB = __builtin_amdgcn_readfirstlane(ld_agent(ri + 7));
-            first = false;
-            wave_sync();
-        }
-        ev_slice0 = sv.n_eval;
-    }
     for (;;) {
         QT_LAP(0);
         if (do_resid) {
@@ -1559,52 +1552,6 @@ __device__ __forceinline__ bool fit_one_quad(const QuadArgs &qa, QuadLds<KP, PPL
         }
         since_rc++;
         do_resid = q2 > (CT ? qc(ct, QC_RC_RATIO) : qa.recenter_ratio) * s0 || since_rc >= qa.recenter_every;
-        if constexpr (YIELD) {
-            const int ye = qa.yield_evals;
-            if (ye != 0 && sv.n_eval - ev_slice0 >= (ye < 0 ? -ye : ye)) {
-                bool waiting = ye < 0;
-                if (!waiting) {
-                    // anyone waiting?  an unstarted series, or a suspended one
-                    // (work items are numbered in ONE ticket space, handed out by qa.counter: 0 .. N-1 the unstarted series,
-                    // N + k the k-th suspended fit; pushed = yq[1])
-                    const int c0 = ld_agent(qa.counter), pushed = ld_agent(qa.yq + 1);
-                    waiting = __builtin_amdgcn_readfirstlane((c0 < (int)a.N || pushed > c0 - (int)a.N) ? 1 : 0) != 0;
-                }
-                if (waiting) {
-                    long long woff = (long long)n * YREC_D;
-                    asm volatile("" : "+s"(woff));
-                    double *rec = qa.yrec + woff;
-                    double *rv = rec + 32 + lane;
-                    st_agent(rv + 0 * W, xk[0]); st_agent(rv + 1 * W, gk[0]); st_agent(rv + 2 * W, xk1[0]); st_agent(rv + 3 * W, gk1[0]);
-                    st_agent(rv + 4 * W, pk[0]);
-                    st_agent(rv + 5 * W, ref_w[lane]); st_agent(rv + 6 * W, cvec_w[lane]);
-#pragma unroll
-                    for (int h = 0; h < QH; ++h) { st_agent(rv + (7 + h) * W, histS[h * W + lane]); st_agent(rv + (7 + QH + h) * W, histY[h * W + lane]); }
-                    if (lane < QH) st_agent(rec + 16 + lane, histR[lane]);
-                    if (lane == 0) {
-                        st_agent(rec + 0, fk); st_agent(rec + 1, fk1); st_agent(rec + 2, alpha); st_agent(rec + 3, dfp);
-                        st_agent(rec + 4, gp1s); st_agent(rec + 5, s0); st_agent(rec + 6, q2);
-                        int *ri = reinterpret_cast<int *>(rec + 8);
-                        st_agent(ri + 0, itNum); st_agent(ri + 1, hist_len); st_agent(ri + 2, h0); st_agent(ri + 3, since_rc);
-                        st_agent(ri + 4, do_resid ? 1 : 0); st_agent(ri + 5, pk1_scaled ? 1 : 0); st_agent(ri + 6, sv.n_eval);
-                        st_agent(ri + 7, resetB);
-                    }
-                    // publish: every lane's record stores are through (they are agent-coherent stores: another CU, maybe
-                    // another XCD, resumes the fit), then the series id in the ring slot of this push ticket, then the
-                    // slot's publish word = ticket + 1
-                    wait_vmem();
-                    if (lane == 0) {
-                        const int tk = __hip_atomic_fetch_add(qa.yq + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const int slot = (int)((unsigned)tk % (unsigned)a.N);
-                        st_agent(qa.yq + 8 + slot, (int)n);
-                        wait_vmem();
-                        st_agent(qa.yq + 8 + (int)a.N + slot, tk + 1);
-                    }
-                    return true;
-                }
-                ev_slice0 = sv.n_eval;          // nobody waits: a fresh slice
-            }
-        }
     }
     store_theta<PPL>(a, sv, n, xk, a.theta);
     if (lane == 0) { a.status[n] = ret; a.n_iter[n] = itNum; a.n_eval[n] = sv.n_eval; a.fval[n] = fk; }
@@ -1626,7 +1573,7 @@ constexpr size_t quad_hist_bytes(bool hlds) { return hlds ? sizeof(double) * (2 
 
 // NTR > 0: residual-pass weights of the first NTR steps in registers (RLDS false; steps beyond: global scratch)
 // RPOOL (NW = 16, four waves per SIMD at <= 128 registers): trend tables from a pool of pool_slots QuadLds
-template <int KP, int PPL, int NW, int MMODE, int PQ, bool RLDS, bool HLDS = false, int NTR = 0, bool RPOOL = false, bool YK = false>
+template <int KP, int PPL, int NW, int MMODE, int PQ, bool RLDS, bool HLDS = false, int NTR = 0, bool RPOOL = false>
 __global__ __launch_bounds__(NW * 64, quad_waves_per_simd(quad_three_waves(MMODE, PPL, HLDS), NW)) void fit_quad_kernel(QuadArgs qa, int pool_slots, int pool_slot_bytes)
 {
     static_assert(NTR == 0 || (!RLDS && MMODE == QM_LDS), "register-resident weights: the shared-M kernel without LDS staging");
@@ -1700,47 +1647,13 @@ __global__ __launch_bounds__(NW * 64, quad_waves_per_simd(quad_three_waves(MMODE
         // here, the compiler threaded lane 0's path from the lane-0-only epilogue stores of the
         // previous series straight into this block, and lanes 1..63 re-entered the loop (and
         // the readfirstlane below) without lane 0: an endless loop on the hardware.
-        if constexpr (!YK) {
-            int n32 = atomicAdd(qa.counter, lane == 0 ? 1 : 0);
-            n32 = __builtin_amdgcn_readfirstlane(n32);
-            if (n32 >= a.N) break;
-            const int64_t n = a.order ? (int64_t)a.order[n32] : (int64_t)n32;   // (cost hints: longest fits first)
-            fit_one_quad<KP, PPL, PQ, RAGGED_K, MRS, HLDS,
-                         ((quad_three_waves(MMODE, PPL, HLDS) || MMODE == QM_RAGGED_REG || MMODE == QM_GLOBAL_REG) ? 8 : 16),
-                         MMODE == QM_RAGGED_REG || MMODE == QM_GLOBAL_REG, NTR, RPOOL>(qa, wlp, rb, Mp, Mown, n, lanec, hist, gx, qw, &pool);
-        } else {
-        // One ticket space for all work (a plain fetch-add: a compare-and-swap loop on a queue head, with 3 072 waves
-        // arriving together, spent the launch in failed exchanges -- 9 -> 300 ms, profiles/r05_yield): tickets 0 .. N-1
-        // are the unstarted series, ticket N + k is the k-th suspended fit.  A wave whose ticket is a suspension that has
-        // not happened yet waits for it (its own publish word: no shared polling) -- or for the end: done = N.
-        int h32 = atomicAdd(qa.counter, lane == 0 ? 1 : 0);
-        h32 = __builtin_amdgcn_readfirstlane(h32);
-        int64_t n;
-        bool resume = false;
-        if (h32 < a.N) {
-            n = a.order ? (int64_t)a.order[h32] : (int64_t)h32;   // (cost hints: longest fits first)
-        } else {
-            if (qa.yield_evals == 0) break;
-            const int k = h32 - (int)a.N, slot = (int)((unsigned)k % (unsigned)a.N);
-            int got = -1;
-            if (lane == 0) {
-                for (;;) {
-                    if (ld_agent(qa.yq + 8 + (int)a.N + slot) == k + 1) { got = ld_agent(qa.yq + 8 + slot); break; }
-                    if (ld_agent(qa.yq + 2) >= (int)a.N) break;               // every series finished
-                    __builtin_amdgcn_s_sleep(64);
-                }
-            }
-            got = __builtin_amdgcn_readfirstlane(got);
-            if (got < 0) break;
-            n = got;                                    // (its record is read with agent-coherent loads: fit_one_quad)
-            resume = true;
-        }
-        const bool yielded =
+        int n32 = atomicAdd(qa.counter, lane == 0 ? 1 : 0);
+        n32 = __builtin_amdgcn_readfirstlane(n32);
+        if (n32 >= a.N) break;
+        const int64_t n = a.order ? (int64_t)a.order[n32] : (int64_t)n32;   // (cost hints: longest fits first)
         fit_one_quad<KP, PPL, PQ, RAGGED_K, MRS, HLDS,
                      ((quad_three_waves(MMODE, PPL, HLDS) || MMODE == QM_RAGGED_REG || MMODE == QM_GLOBAL_REG) ? 8 : 16),
-                     MMODE == QM_RAGGED_REG || MMODE == QM_GLOBAL_REG, NTR, RPOOL, YK>(qa, wlp, rb, Mp, Mown, n, lanec, hist, gx, qw, &pool, resume);
-        if (qa.yield_evals != 0 && !yielded && lane == 0) __hip_atomic_fetch_add(qa.yq + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+                     MMODE == QM_RAGGED_REG || MMODE == QM_GLOBAL_REG, NTR, RPOOL>(qa, wlp, rb, Mp, Mown, n, lanec, hist, gx, qw, &pool);
     }
 }
 

@@ -66,9 +66,7 @@ static int launch_quad_rl(const QuadPlan &qp, const QuadArgs &qa_in, double *Mg,
     constexpr int NW = RPOOL ? TSF_QUAD_NW4 : QuadShape<PPL, MMODE>::NW;
     constexpr bool MLDS = MMODE == QM_LDS;
     constexpr bool HL = QuadShape<PPL, MMODE>::HL;
-    // time slicing exists in the aligned one-slot kernels with the history ring in LDS (fit_one_quad YIELD)
-    QuadArgs qa = qa_in;
-    if (!(HL && MMODE == QM_LDS && PPL == 1 && PQ > 0 && !RPOOL)) qa.yield_evals = 0;
+    const QuadArgs &qa = qa_in;
     int64_t blocks = qp.n_cu;                       // persistent: LDS admits one workgroup per CU
     if (blocks > (qa.f.N + NW - 1) / NW) blocks = (qa.f.N + NW - 1) / NW;
     if (blocks < 1) blocks = 1;
@@ -103,14 +101,6 @@ static int launch_quad_rl(const QuadPlan &qp, const QuadArgs &qa_in, double *Mg,
         return (int)hipGetLastError();
     }
 #endif
-    if constexpr (HL && MMODE == QM_LDS && PPL == 1 && PQ > 0 && !RPOOL) {
-        if (qa.yield_evals != 0) {          // the time-slicing build (tsf_set_option(TSF_OPT_QUAD_YIELD, ...))
-            hipFuncSetAttribute((const void *)fit_quad_kernel<KP, PPL, NW, MMODE, PQ, RLDS, HL, NTR, RPOOL, true>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            hipLaunchKernelGGL((fit_quad_kernel<KP, PPL, NW, MMODE, PQ, RLDS, HL, NTR, RPOOL, true>), dim3((unsigned)blocks), dim3(NW * 64), lds, st, qa, pool_slots, pool_slot_bytes);
-            return (int)hipGetLastError();
-        }
-    }
     hipLaunchKernelGGL((fit_quad_kernel<KP, PPL, NW, MMODE, PQ, RLDS, HL, NTR, RPOOL>), dim3((unsigned)blocks), dim3(NW * 64), lds, st, qa, pool_slots, pool_slot_bytes);
     return (int)hipGetLastError();
 }
