@@ -122,13 +122,14 @@ def test_hip_fit_and_predict_against_the_literal_prophet(fc, case):
         assert abs(m2.y_scale - r.y_scale[0]) <= 4 * ULP * m2.y_scale
         lit = m2.predict(fdf)['yhat'].values
     assert np.max(np.abs(yhat - lit) / np.abs(lit)) <= 16 * ULP
-    # ... and on fbprophet's own sin / cos of every harmonic: design values within 1e-9, the forecast with them
+    # ... and on fbprophet's own sin / cos of every harmonic: design values within 1e-10 (measured 1.1e-11: the derived
+    # bound, tests/test_oracle.py), the forecast with them
     m3 = type(m)(growth=spec.growth, seasonality_mode=spec.seasonality_mode,
                  yearly_seasonality=m.yearly_seasonality, weekly_seasonality=True, daily_seasonality=False,
                  holidays=m.holidays)
     m3.fit(df, optimizer=lambda dat_, th0_, **kw: (r.theta[0].copy(), {'status': int(r.status[0])}))
     lit = m3.predict(fdf)['yhat'].values
-    assert np.max(np.abs(yhat - lit) / np.abs(lit)) <= 1e-9
+    assert np.max(np.abs(yhat - lit) / np.abs(lit)) <= 1e-10
 
 
 @pytest.mark.parametrize('case', ['cfg2_linear_additive', 'ref_logistic_multiplicative', 'short_90',
@@ -155,7 +156,10 @@ def test_hip_map_estimate_against_an_independent_optimiser(fc, case):
     th_b, info_b = true_map.solve(dat, th0)
     assert abs(info_a['f'] - info_b['f']) <= 1e-7 * max(1.0, abs(info_a['f'])), (case, info_a, info_b)
     gap = f_hip - min(info_a['f'], info_b['f'])
-    assert -1e-6 <= gap <= (8.0 if spec.growth == 'linear' else 50.0), (case, gap)
+    # per case, three times what the case measures (the GPU's fit is the oracle's, bit for bit: the CPU twin's table)
+    band = 3.0 * {'cfg2_linear_additive': 0.060, 'ref_logistic_multiplicative': 0.0049, 'short_90': 0.47,
+                  'logistic_additive_400': 0.025, 'cfg4_holidays': 0.21, 'short_90@newton': 0.0091}[case]
+    assert -1e-6 <= gap <= band, (case, gap)
     res_x = th_a if info_a['f'] <= info_b['f'] else th_b
 
     def fitted(th):

@@ -79,7 +79,9 @@ def test_canonical_eval_matches_literal_stan(case):
     # (1) the canonical design values against fbprophet's (numpy sin / cos of every harmonic's own argument): the
     # base pair to 2 ulp (det_sincos), the recurrence's harmonics to h x the rounding of the base argument
     X_lit = _literal(case, 0, canonical_design=False)[1]['X']
-    assert np.max(np.abs(des['X'] - X_lit)) <= 1e-9
+    # (the recurrence's error: harmonic order x the rounding of the base argument 2 pi t / period at t ~ 1.7e4 days --
+    # measured 1.1e-11 on every case; the bound asserted is the derived one, not a round number three decades above it)
+    assert np.max(np.abs(des['X'] - X_lit)) <= 1e-10
     nb = 0
     for s in spec.seasonalities:
         assert np.max(np.abs(des['X'][:, nb:nb + 2] - X_lit[:, nb:nb + 2])) <= 2 * ULP
@@ -664,7 +666,10 @@ def test_map_estimate_against_an_independent_optimiser(case):
     assert abs(info_a['f'] - info_b['f']) <= 1e-7 * max(1.0, abs(info_a['f'])), (case, info_a, info_b)   # one optimum, found twice
     f_map = min(info_a['f'], info_b['f'])
     gap = f_canon - f_map
-    band = 8.0 if spec.growth == 'linear' else 50.0
+    # per case: three times what this case measures (round-5 advice: the population maxima -- 8 for linear, 50 for
+    # logistic growth -- would hide an optimiser regression on any single case)
+    band = 3.0 * {'cfg2_linear_additive': 0.060, 'ref_logistic_multiplicative': 0.0049, 'short_90': 0.47,
+                  'logistic_additive_400': 0.025, 'cfg4_holidays': 0.21, 'short_90@newton': 0.0091}[case]
     assert -1e-6 <= gap <= band, (case, gap, f_map)
     res_x = th_a if info_a['f'] <= info_b['f'] else th_b
 
@@ -676,3 +681,54 @@ def test_map_estimate_against_an_independent_optimiser(case):
     sigma = np.exp(res_x[2])
     # measured: 0.1 % .. 2.3 % of the fitted noise level
     assert np.sqrt(np.mean((a - b) ** 2)) <= 0.05 * sigma, (case, np.sqrt(np.mean((a - b) ** 2)), sigma)
+
+
+
+def test_design_values_of_high_orders_and_sub_daily_periods():
+    """The three-term recurrence serves every Fourier order the library accepts, not only the compiled yearly / weekly /
+    daily shapes (round-5 advice): order 32 on a yearly period, and a 6-hour period of order 8 on 15-minute data -- the
+    canonical design values against numpy's sin / cos of every harmonic's own argument, at the derived bound (harmonic
+    order x the rounding of the base argument: 2 pi t / period at t ~ 1.7e4 days is ~300 for a yearly period, ~4.4e5
+    for a 6-hour one -- so the sub-daily bound is the larger one)."""
+    from oracle.fbprophet_restated import fourier_series
+    ds_d = pd.date_range('2018-01-01', periods=800, freq='D')
+    ds_q = pd.date_range('2018-01-01', periods=2000, freq='15min')
+    for ds, period, order, bound in ((ds_d, 365.25, 32, 2e-10), (ds_q, 0.25, 8, 5e-9), (ds_q, 1.0, 4, 2e-10)):
+        csp = cl.make_spec(growth='linear', seasonalities=[(period, order, 'additive', 10.0)])
+        ds_ns = ds.values.astype('datetime64[ns]').astype(np.int64)
+        des = cl.design(csp, ds_ns, np.arange(len(ds), dtype=np.float64) + 1.0)
+        X = fourier_series(ds, period, order)
+        assert des['X'].shape == X.shape == (len(ds), 2 * order)
+        err = np.max(np.abs(des['X'] - X))
+        assert err <= bound, (period, order, err)
+        assert np.max(np.abs(des['X'][:, :2] - X[:, :2])) <= 4 * ULP * max(1.0, 2 * np.pi * 17600 / period / 300)
+
+
+def test_logistic_tables_scan_and_chain_agree():
+    """The fit evaluates the logistic trend's changepoint recurrences as lane SCANS (prefix sum of delta, compositions of
+    affine maps: canonical since round 5), predict keeps fbprophet's own sequential chain (piecewise_logistic: numpy cumsum
+    and a Python loop) -- on purpose, and pinned: the same sums in another association.  Held together here where it is
+    hardest, k + cumsum(delta) CROSSING ZERO between changepoints (rates of both signs, ratios ks[j] / ks[j+1] of both
+    signs and large magnitude): the scan form's log-posterior and gradient against the literal sequential model, and the
+    chain form's trend (cn_predict on the history dates) against the literal piecewise_logistic, at the same theta."""
+    m, dat, th0, (spec, ds, y, floor, cap, extra, fut, exf) = _literal('ref_logistic_multiplicative')
+    csp = helpers.oracle_spec(spec)
+    S, K = dat['S'], dat['K']
+    rng = np.random.default_rng(5)
+    for trial in range(4):
+        th = th0 + rng.normal(0, 0.01, th0.size)
+        th[0] = 0.37 + 0.05 * trial                      # k > 0 ...
+        th[3:3 + S] = -0.11 + rng.normal(0, 0.02, S)     # ... and slope changes that take k + cumsum(delta) through zero after ~4 changepoints
+        ks = th[0] + np.concatenate([[0.0], np.cumsum(th[3:3 + S])])
+        assert ks[0] > 0 and ks[-1] < 0 and np.min(np.abs(ks)) > 1e-3          # crosses zero, never sits on it
+        f1, g1 = stan_neg_log_prob_grad(dat, th)
+        f2, g2, rc = cl.eval_at(csp, ds, y[0], th, floor[0], cap[0], extra)
+        assert rc == 0 and np.isfinite(f1) and np.isfinite(f2)
+        assert abs(f1 - f2) <= 1e-11 * abs(f1), (trial, f1, f2)
+        assert np.max(np.abs(g1 - g2) / (1 + np.abs(g1))) <= 1e-10, trial
+        o = dict(cl.fit(csp, ds, y[0], floor[0], cap[0], extra))
+        o['theta'] = th.copy()
+        _, trend = cl.predict(csp, o, ds, floor[0], cap[0], extra)
+        k, mm, ls, delta, beta = unpack_theta(th, S, K)
+        lit = stan_trend(dat, k, mm, delta) * o['info'].y_scale + floor[0]
+        assert np.max(np.abs(trend - lit) / np.abs(lit)) <= 1e-12, trial
