@@ -581,7 +581,14 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     int gram_harm = 0;
     if (quad && !aligned && !quad_pre && lat_U == 0 && hs.harm == HARM_Y10_W3 && hs.KP == 28 && ctx->opt[TSF_OPT_HARM] != 0)
         gram_harm = hs.harm;
-    const int bw_ns = (harm || gram_harm) ? hs.n_seas : 0;
+    // ... and for the MAP continuation (tsf_map_kernels.h): its evaluator reads base-pair rows wherever the model has a
+    // compiled expansion, whatever kernel ran the Stan-rule fit (the quadratic-form route builds the table for it)
+    int map_harm = 0;
+    if (spec->converge == TSF_CONVERGE_MAP && theta_in == nullptr && lat_U == 0 && mode != 2 && ctx->opt[TSF_OPT_HARM] != 0 &&
+        hs.K == harm_kf(hs.harm) &&
+        ((hs.harm == HARM_Y10_W3 && hs.KP == 28) || (hs.harm == HARM_W3_D4 && hs.KP == 16) || (hs.harm == HARM_W3 && hs.KP == 8)))
+        map_harm = hs.harm;
+    const int bw_ns = (harm || gram_harm || map_harm) ? hs.n_seas : 0;
     // Quadratic-form L-BFGS fits read the caller's y rows themselves (FitArgs::y_raw) instead of a scaled step-major copy
     // that setup_series_kernel would write and they would read back -- a second f64 panel on the device and half of the
     // step's HBM bytes.  Not when the MAP continuation follows (its evaluator reads yw).
@@ -762,7 +769,8 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     // converge = MAP: from where the optimiser's own tests stopped every fit on to the maximum a posteriori estimate
     // (tsf_map_kernels.h), on the same stream behind whichever kernels ran the fit; inside the profiled interval
     if (lrc == 0 && spec->converge == TSF_CONVERGE_MAP && theta_in == nullptr) {
-        a.map_max_iter = spec->map_max_iter; a.map_tol = spec->map_tol;
+        a.map_max_iter = spec->map_max_iter; a.map_tol = spec->map_tol; a.map_harm = map_harm;
+        if (map_harm) a.Bw = (const double *)(ws + l.Bw);
         a.order = nullptr; a.run_flag = nullptr;
         lrc = pick_map_launch(hs.growth, mode)(hs.KP, a, st);
     }

@@ -806,6 +806,7 @@ struct FitArgs {
     const void *y_raw;
     const int64_t *y_offsets;
     int y_raw_dtype, y_T;
+    int map_harm;                       // converge = MAP: harm_code of the model when map_kernel may read base-pair rows (Bw built), else 0
     int map_max_iter;                   // converge = MAP (tsf_map_kernels.h): iteration limit and KKT tolerance of the continuation
     double map_tol;
     // scheduling hint (tsf_set_cost_hints): the q-th series the launch starts is order[q]; null = q

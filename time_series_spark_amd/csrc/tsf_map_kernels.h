@@ -58,8 +58,11 @@ __host__ __device__ inline size_t map_lds_bytes()
     return ((wave_lds_bytes<KP, PPL>(1) + 15) & ~(size_t)15) + sizeof(double) * (2 * MAP_M * PPL * W + MAP_FWIN + 4);
 }
 
-template <int KP, int GROWTH, int MODE, int PPL, bool XIDX>
-__global__ __launch_bounds__(64) void map_kernel(FitArgs a)
+// HARM != 0: the evaluator that reads a row as its base pairs and expands the Fourier columns in registers (eval_fg HARM:
+// 168 registers, three waves per SIMD) -- the models whose harmonic structure has a compiled expansion, where the call
+// built the base-pair table; else the table-streaming evaluator (one wave per SIMD).
+template <int KP, int GROWTH, int MODE, int PPL, bool XIDX, int HARM = 0>
+__global__ __launch_bounds__(64, HARM != 0 ? TSF_HARM_WPS : 1) void map_kernel(FitArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     WaveLds<KP, PPL> &lds = *reinterpret_cast<WaveLds<KP, PPL> *>(smem);
@@ -73,6 +76,10 @@ __global__ __launch_bounds__(64) void map_kernel(FitArgs a)
     const int lane = lane_id();
     SeriesView sv;
     make_view<KP, PPL>(a, n, sv);
+    if constexpr (HARM != 0) {
+        const int kd = a.sp->K < KP ? a.sp->K : KP;         // dense columns of the model
+        sv.n_xd = kd - harm_kf(HARM);
+    }
     if (sv.T < 2) return;
     for (int i = threadIdx.x; i < TSF_MAX_P + W; i += W) lds.th[i] = 0.0;
     TSF_WAVE_SYNC();
@@ -90,7 +97,7 @@ __global__ __launch_bounds__(64) void map_kernel(FitArgs a)
     FT_DECL;
     // smooth part of the gradient: the evaluator's gradient without the Laplace term's sign(delta) / tau
     auto smooth = [&](const double (&xx)[PPL], double &Fo, double (&vo)[PPL]) -> bool {
-        const bool bad = eval_fg<KP, GROWTH, MODE, PPL, XIDX>(a.sp, sv, lds, xx, Fo, g FT_PASS);
+        const bool bad = eval_fg<KP, GROWTH, MODE, PPL, XIDX, WaveLds<KP, PPL>, 0, false, HARM>(a.sp, sv, lds, xx, Fo, g FT_PASS);
 #pragma unroll
         for (int s = 0; s < PPL; ++s) {
             double gv = live[s] ? g[s] : 0.0;
