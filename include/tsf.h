@@ -288,7 +288,12 @@ int tsf_set_cost_hints(tsf_ctx *ctx, const int32_t *cost, int64_t n);
  *                   to tsf_fit_aligned as [n_series][T] without another look at ds); *has_inf = 1 when a y is
  *                   infinite (fbprophet raises "Found infinity in column y."); *integral = 1 when every y is an
  *                   integer that fits int32 -- the quantity column of the reference's schema
- *                   (prophet_modeler.py:16), which may then cross to the device as TSF_Y_I32.
+ *                   (prophet_modeler.py:16), which may then cross to the device as TSF_Y_I32; *has_nat = 1 when a ds
+ *                   is INT64_MIN, pandas' NaT (fbprophet raises "Found NaN in column ds.").
+ *   tsf_pack_rows_typed  the same plan for columns in the caller's own types: keys of key_bytes = 4 (the reference's
+ *                   int32 series_id / dim_id, prophet_modeler.py:13-14) or 8, y of y_dtype TSF_Y_* (int32 = the
+ *                   reference's quantity: no NaN possible).  A table already in packed order is then used in place, in
+ *                   those types (tsf_pack_fetch writes ds_out / y_out -- always int64 / float64 -- only when asked).
  * Returns 0, -1 bad arguments, -2 out of memory, -3 other failure. */
 typedef struct tsf_pack tsf_pack;
 int tsf_pack_rows(int64_t n, const int64_t *series_id, const int64_t *dim_id, const int64_t *ds,
@@ -296,7 +301,10 @@ int tsf_pack_rows(int64_t n, const int64_t *series_id, const int64_t *dim_id, co
                   int64_t *n_series, int32_t *identity);
 int tsf_pack_fetch(tsf_pack *p, int64_t *key_series_id, int64_t *key_dim_id, int64_t *offsets,
                    int64_t *ds_out, double *y_out, int64_t *span, int64_t *min_dt, double *y_max);
-int tsf_pack_flags(const tsf_pack *p, int32_t *aligned, int32_t *has_inf, int32_t *integral);
+int tsf_pack_rows_typed(int64_t n, const void *series_id, const void *dim_id, int32_t key_bytes, const int64_t *ds,
+                        const void *y, int32_t y_dtype, int32_t n_threads, tsf_pack **out, int64_t *n_rows,
+                        int64_t *n_series, int32_t *identity);
+int tsf_pack_flags(const tsf_pack *p, int32_t *aligned, int32_t *has_inf, int32_t *integral, int32_t *has_nat);
 void tsf_pack_free(tsf_pack *p);
 
 /* ---- model blobs (host side) ------------------------------------------------------------------

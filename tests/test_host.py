@@ -1301,3 +1301,41 @@ def test_model_batch_frame_and_table_agree_with_dropped_and_retried_series(built
     marks = [pk.load_model(b)['theta'][0] for b in frame['model']]
     assert marks == [3.0, 1.0, 1.0, 2.0, 2.0]               # retried by Newton (ragged call), L-BFGS, L-BFGS, Newton (short), Newton (short)
     assert list(np.asarray(frame.attrs['tsf_cost'])) == [3, 1, 1, 2, 2]
+
+
+def test_packer_takes_the_reference_schemas_own_types_in_place(built):
+    """tsf_pack_rows_typed: int32 series_id / dim_id / y and datetime64 ds (MODEL_INPUT_SCHEMA, prophet_modeler.py:12-17)
+    go to the packer as they are; a frame already in packed order is used in place (no int64 / float64 copies of its
+    columns), any other order gives the same panel as the int64 / float64 route, and infinity / NaT raise as fbprophet does."""
+    rng = np.random.default_rng(4)
+    n_s, T = 37, 50
+    sid = np.repeat(np.arange(n_s, dtype=np.int32) * 3 + 1, T)
+    did = np.repeat((np.arange(n_s, dtype=np.int32) % 2) + 1, T)
+    ds = np.tile(np.datetime64('2020-01-01', 'ns') + np.arange(T).astype('timedelta64[D]'), n_s)
+    y = rng.integers(1, 10 ** 6, n_s * T).astype(np.int32)
+    df = pd.DataFrame({'series_id': sid, 'dim_id': did, 'ds': ds, 'y': y})
+    p = pk.pack_long_frame(df)
+    assert p.N == n_s and p.aligned and p.integral and p.y.dtype == np.int32 and p.y2d.dtype == np.int32
+    assert np.shares_memory(p.y, df['y'].to_numpy()) and np.shares_memory(p.ds_ns, df['ds'].to_numpy().view(np.int64))
+    assert str(p.keys['series_id'].dtype) == 'int32' and list(p.keys['series_id'][:3]) == [1, 4, 7]
+    rs, rd, ro, rds, ry = helpers.pack_reference(sid.astype(np.int64), did.astype(np.int64), ds.view(np.int64), y.astype(np.float64))
+    assert np.array_equal(p.offsets, ro) and np.array_equal(p.ds_ns, rds) and np.array_equal(p.y, ry)
+    assert np.array_equal(p.stats[2], y.reshape(n_s, T).max(axis=1))
+    for ydt in (np.int32, np.float32, np.float64):
+        o = rng.permutation(n_s * T)
+        q = pk.pack_long_frame(df.iloc[o].assign(y=lambda f: f['y'].astype(ydt)).reset_index(drop=True))
+        assert q.y.dtype == np.float64 and np.array_equal(q.offsets, ro) and np.array_equal(q.ds_ns, rds) and np.array_equal(q.y, ry)
+        assert q.aligned and q.integral and np.array_equal(q.keys['series_id'].to_numpy(), rs)
+    bad = df.assign(y=df['y'].astype(np.float64))
+    bad.loc[17, 'y'] = np.inf
+    with pytest.raises(ValueError, match='infinity'):
+        pk.pack_long_frame(bad)
+    bad = df.copy()
+    bad.loc[5, 'ds'] = pd.NaT
+    with pytest.raises(ValueError, match='NaN in column ds'):
+        pk.pack_long_frame(bad)
+    # float32 y with a null: dropped as fbprophet drops it, the rest unchanged
+    f32 = df.assign(y=df['y'].astype(np.float32))
+    f32.loc[3, 'y'] = np.nan
+    q = pk.pack_long_frame(f32)
+    assert q.lengths[0] == T - 1 and not q.aligned and q.y.dtype == np.float64

@@ -85,7 +85,7 @@ EXPORTS = ['tsf_create', 'tsf_destroy', 'tsf_last_error', 'tsf_device_count', 't
            'tsf_fit_aligned', 'tsf_fit_aligned_dev', 'tsf_fit_ragged', 'tsf_fit_ragged_dev',
            'tsf_predict', 'tsf_predict_dev', 'tsf_predict_intervals', 'tsf_predict_intervals_dev', 'tsf_eval', 'tsf_eval_quadratic', 'tsf_design', 'tsf_selftest_math',
            'tsf_set_option', 'tsf_get_option', 'tsf_set_cost_hints', 'tsf_set_profiling', 'tsf_profile_read', 'tsf_last_fit_kernel_ms', 'tsf_last_fit_route',
-           'tsf_pack_rows', 'tsf_pack_fetch', 'tsf_pack_flags', 'tsf_pack_free', 'tsf_model_blobs',
+           'tsf_pack_rows', 'tsf_pack_rows_typed', 'tsf_pack_fetch', 'tsf_pack_flags', 'tsf_pack_free', 'tsf_model_blobs',
            'tsf_csv_read', 'tsf_csv_fetch', 'tsf_csv_columns', 'tsf_csv_malformed', 'tsf_csv_free', 'tsf_csv_write_forecasts', 'tsf_csv_write_forecasts_i32',
            'tsf_csv_discover', 'tsf_csv_discover_load', 'tsf_csv_root_open', 'tsf_csv_root_load', 'tsf_csv_root_free', 'tsf_csv_read_loaded', 'tsf_csv_dir_paths', 'tsf_csv_dir_series_id', 'tsf_csv_dir_error_path', 'tsf_csv_dir_free']
 
@@ -153,7 +153,9 @@ def load():
     L.tsf_pack_rows.argtypes = [i64, vp, vp, vp, vp, i32, ctypes.POINTER(vp), ctypes.POINTER(i64),
                                 ctypes.POINTER(i64), ctypes.POINTER(i32)]
     L.tsf_pack_fetch.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
-    L.tsf_pack_flags.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32)]
+    L.tsf_pack_rows_typed.argtypes = [i64, vp, vp, i32, vp, vp, i32, i32, ctypes.POINTER(vp), ctypes.POINTER(i64),
+                                      ctypes.POINTER(i64), ctypes.POINTER(i32)]
+    L.tsf_pack_flags.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32)]
     L.tsf_pack_free.argtypes = [vp]
     L.tsf_pack_free.restype = None
     L.tsf_model_blobs.argtypes = [i64, vp, i32, i32, vp, vp, vp, i32, vp, vp, vp, i32, vp, i32]

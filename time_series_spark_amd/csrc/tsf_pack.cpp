@@ -104,21 +104,26 @@ struct tsf_pack {
     int32_t identity = 0;
     int n_threads = 1;
     const int64_t *ds = nullptr;       // caller's arrays; must stay alive until fetch
-    const double *y = nullptr;
+    const void *y = nullptr;           // of y_dtype (TSF_Y_*)
+    int32_t y_dtype = TSF_Y_F64;
     std::vector<Key> keys;             // [n_series], ascending
     std::vector<int64_t> offsets;      // [n_series + 1]
     std::vector<Pair> pairs;           // [n_rows] (ds, y) of each packed row (empty if identity)
     // what tsf_pack_fetch's pass over the packed rows sees on the way (tsf_pack_flags): every series on the first
     // series' timestamp vector; an infinite y; every y an integer that fits int32 (the reference's schema)
-    int32_t aligned = 0, has_inf = 0, integral = 0, fetched = 0;
+    int32_t aligned = 0, has_inf = 0, integral = 0, has_nat = 0, fetched = 0;
 };
 
-extern "C" {
+namespace {
 
-int tsf_pack_rows(int64_t n, const int64_t *series_id, const int64_t *dim_id, const int64_t *ds,
-                  const double *y, int32_t n_threads, tsf_pack **out, int64_t *n_rows,
-                  int64_t *n_series, int32_t *identity) {
-    if (!out || n < 0 || (n > 0 && (!series_id || !dim_id || !ds || !y))) return -1;
+// KT: the key columns' type (int32 as the reference's schema has them, prophet_modeler.py:12-17, or int64); YT: y's
+// (int32 -- the reference's quantity --, float or double).  A table that already is in packed order is used in place,
+// in its own types (round 6: the DataFrame boundary converted three 7.3 M-row columns to int64 / float64 before the packer
+// saw them, most of model_panel's time).
+template <class KT, class YT>
+int pack_rows_impl(int64_t n, const KT *series_id, const KT *dim_id, const int64_t *ds,
+                   const YT *y, int32_t y_dtype, int32_t n_threads, tsf_pack **out, int64_t *n_rows,
+                   int64_t *n_series, int32_t *identity) {
     *out = nullptr;
     tsf_pack *p = nullptr;
     try {
@@ -129,6 +134,7 @@ int tsf_pack_rows(int64_t n, const int64_t *series_id, const int64_t *dim_id, co
         p->n_in = n;
         p->ds = ds;
         p->y = y;
+        p->y_dtype = y_dtype;
         const int nt = p->n_threads;
         const bool timing = std::getenv("TSF_PACK_TIMING") != nullptr;
         auto t_last = std::chrono::steady_clock::now();
@@ -145,9 +151,9 @@ int tsf_pack_rows(int64_t n, const int64_t *series_id, const int64_t *dim_id, co
         parallel_for(n, nt, [&](int64_t a, int64_t b, int) {
             bool ok = true;
             for (int64_t i = a; i < b && ok; ++i) {
-                if (std::isnan(y[i])) ok = false;
+                if (std::isnan((double)y[i])) ok = false;
                 if (i == 0) continue;
-                Key k0{series_id[i - 1], dim_id[i - 1]}, k1{series_id[i], dim_id[i]};
+                Key k0{(int64_t)series_id[i - 1], (int64_t)dim_id[i - 1]}, k1{(int64_t)series_id[i], (int64_t)dim_id[i]};
                 if (k1 < k0) ok = false;
                 else if (k1 == k0 && ds[i] < ds[i - 1]) ok = false;
             }
@@ -171,7 +177,7 @@ int tsf_pack_rows(int64_t n, const int64_t *series_id, const int64_t *dim_id, co
             p->offsets.reserve(total_runs + 1);
             for (auto &s : starts)
                 for (int64_t i : s) {
-                    p->keys.push_back(Key{series_id[i], dim_id[i]});
+                    p->keys.push_back(Key{(int64_t)series_id[i], (int64_t)dim_id[i]});
                     p->offsets.push_back(i);
                 }
             p->offsets.push_back(n);
@@ -199,14 +205,14 @@ int tsf_pack_rows(int64_t n, const int64_t *series_id, const int64_t *dim_id, co
                 Key last{0, 0};
                 int64_t last_id = -1;
                 for (int64_t i = a; i < b; ++i) {
-                    Key k{series_id[i], dim_id[i]};
+                    Key k{(int64_t)series_id[i], (int64_t)dim_id[i]};
                     if (last_id < 0 || !(k == last)) {
                         last_id = c.map.get(k);
                         last = k;
                         if ((size_t)last_id >= c.count.size()) c.count.resize((size_t)last_id + 1, 0);
                     }
                     int64_t v = -1;
-                    if (!std::isnan(y[i])) {
+                    if (!std::isnan((double)y[i])) {
                         v = last_id;
                         ++c.count[(size_t)last_id];
                     }
@@ -264,7 +270,7 @@ int tsf_pack_rows(int64_t n, const int64_t *series_id, const int64_t *dim_id, co
                 Chunk &c = ch[(size_t)t];
                 for (int64_t i = a; i < b; ++i) {
                     int64_t l = small ? (int64_t)c.lid32[(size_t)(i - a)] : c.lid64[(size_t)(i - a)];
-                    if (l >= 0) p->pairs[(size_t)c.start[(size_t)l]++] = Pair{ds[i], y[i]};
+                    if (l >= 0) p->pairs[(size_t)c.start[(size_t)l]++] = Pair{ds[i], (double)y[i]};
                 }
             });
             std::vector<Chunk>().swap(ch);
@@ -306,12 +312,44 @@ int tsf_pack_rows(int64_t n, const int64_t *series_id, const int64_t *dim_id, co
     return 0;
 }
 
+}  // namespace
+
+extern "C" {
+
+int tsf_pack_rows_typed(int64_t n, const void *series_id, const void *dim_id, int32_t key_bytes, const int64_t *ds,
+                        const void *y, int32_t y_dtype, int32_t n_threads, tsf_pack **out, int64_t *n_rows,
+                        int64_t *n_series, int32_t *identity) {
+    if (!out || n < 0 || (n > 0 && (!series_id || !dim_id || !ds || !y))) return -1;
+    if ((key_bytes != 4 && key_bytes != 8) || y_dtype < TSF_Y_F64 || y_dtype > TSF_Y_I32) return -1;
+#define TSF_PACK_GO(KT, YT) return pack_rows_impl<KT, YT>(n, (const KT *)series_id, (const KT *)dim_id, ds, (const YT *)y, y_dtype, \
+                                                          n_threads, out, n_rows, n_series, identity)
+    if (key_bytes == 4) {
+        if (y_dtype == TSF_Y_F64) TSF_PACK_GO(int32_t, double);
+        if (y_dtype == TSF_Y_F32) TSF_PACK_GO(int32_t, float);
+        TSF_PACK_GO(int32_t, int32_t);
+    }
+    if (y_dtype == TSF_Y_F64) TSF_PACK_GO(int64_t, double);
+    if (y_dtype == TSF_Y_F32) TSF_PACK_GO(int64_t, float);
+    TSF_PACK_GO(int64_t, int32_t);
+#undef TSF_PACK_GO
+}
+
+int tsf_pack_rows(int64_t n, const int64_t *series_id, const int64_t *dim_id, const int64_t *ds,
+                  const double *y, int32_t n_threads, tsf_pack **out, int64_t *n_rows,
+                  int64_t *n_series, int32_t *identity) {
+    return tsf_pack_rows_typed(n, series_id, dim_id, 8, ds, y, TSF_Y_F64, n_threads, out, n_rows, n_series, identity);
+}
+
 int tsf_pack_fetch(tsf_pack *p, int64_t *key_series_id, int64_t *key_dim_id, int64_t *offsets,
                    int64_t *ds_out, double *y_out, int64_t *span, int64_t *min_dt, double *y_max) {
     if (!p) return -1;
     const int64_t NS = p->n_series;
     const int64_t *ds = p->ds;
-    const double *y = p->y;
+    const void *yv_ = p->y;
+    const int32_t ydt = p->y_dtype;
+    auto y_at = [yv_, ydt](int64_t r) -> double {
+        return ydt == TSF_Y_F64 ? ((const double *)yv_)[r] : (ydt == TSF_Y_F32 ? (double)((const float *)yv_)[r] : (double)((const int32_t *)yv_)[r]);
+    };
     const bool ident = p->identity != 0;
     const Pair *pairs = ident ? nullptr : p->pairs.data();
     if (offsets) std::memcpy(offsets, p->offsets.data(), sizeof(int64_t) * (size_t)(NS + 1));
@@ -321,7 +359,7 @@ int tsf_pack_fetch(tsf_pack *p, int64_t *key_series_id, int64_t *key_dim_id, int
     }
     // gather + statistics, series-parallel; the same pass notes what tsf_pack_flags reports
     std::atomic<int64_t> next(0);
-    std::atomic<int> not_aligned(0), any_inf(0), not_integral(0);
+    std::atomic<int> not_aligned(0), any_inf(0), not_integral(0), any_nat(0);
     const int64_t len0 = NS > 0 ? p->offsets[1] - p->offsets[0] : 0;
     const int64_t a0 = NS > 0 ? p->offsets[0] : 0;
     auto worker = [&]() {
@@ -336,11 +374,12 @@ int tsf_pack_fetch(tsf_pack *p, int64_t *key_series_id, int64_t *key_dim_id, int
                 bool same = (b - a == len0), fin = true, whole = true;
                 for (int64_t r = a; r < b; ++r) {
                     int64_t d = ident ? ds[r] : pairs[r].ds;
-                    double v = ident ? y[r] : pairs[r].y;
+                    double v = ident ? y_at(r) : pairs[r].y;
                     if (ds_out && !(ident && ds_out == ds)) ds_out[r] = d;
-                    if (y_out && !(ident && y_out == y)) y_out[r] = v;
+                    if (y_out && !(ident && (const void *)y_out == yv_)) y_out[r] = v;
                     if (same && d != (ident ? ds[a0 + (r - a)] : pairs[a0 + (r - a)].ds)) same = false;
                     if (std::isinf(v)) fin = false;
+                    if (d == std::numeric_limits<int64_t>::min()) any_nat.store(1, std::memory_order_relaxed);     // pandas NaT
                     if (!(v >= -2147483648.0 && v <= 2147483647.0 && v == (double)(int32_t)v)) whole = false;
                     if (r == a) first = d;
                     else {
@@ -367,16 +406,18 @@ int tsf_pack_fetch(tsf_pack *p, int64_t *key_series_id, int64_t *key_dim_id, int
     }
     p->aligned = (NS > 0 && len0 > 0 && !not_aligned.load()) ? 1 : 0;
     p->has_inf = any_inf.load();
+    p->has_nat = any_nat.load();
     p->integral = (NS > 0 && !not_integral.load()) ? 1 : 0;
     p->fetched = 1;
     return 0;
 }
 
-int tsf_pack_flags(const tsf_pack *p, int32_t *aligned, int32_t *has_inf, int32_t *integral) {
+int tsf_pack_flags(const tsf_pack *p, int32_t *aligned, int32_t *has_inf, int32_t *integral, int32_t *has_nat) {
     if (!p || !p->fetched) return -1;
     if (aligned) *aligned = p->aligned;
     if (has_inf) *has_inf = p->has_inf;
     if (integral) *integral = p->integral;
+    if (has_nat) *has_nat = p->has_nat;
     return 0;
 }
 

@@ -816,8 +816,9 @@ class ProphetModeler:
         # them; dictionary encoding of the binary column only costs time (every blob is distinct)
         n = table.num_rows
         groups = max(1, -(-n // MODEL_ROW_GROUP))
+        # (no min / max statistics for the blobs: nobody filters on them, and computing them compares 1 KB strings)
         pq.write_table(table, os.path.join(self.config['io']['models'], part), use_dictionary=False,
-                       row_group_size=max(1, -(-n // groups)))
+                       row_group_size=max(1, -(-n // groups)), write_statistics=['series_id', 'dim_id'])
         return part
 
     def _chunk_plan(self):
@@ -835,9 +836,9 @@ class ProphetModeler:
             return None
         if want == 'auto':
             if n < PIPELINE_MIN_CHILDREN:
-                r.close()
-                return None
-            k = min(PIPELINE_MAX_CHUNKS, max(2, n // PIPELINE_CHUNK_CHILDREN))
+                k = 1           # one "chunk": the children just listed are read as they are (no second walk of the root)
+            else:
+                k = min(PIPELINE_MAX_CHUNKS, max(2, n // PIPELINE_CHUNK_CHILDREN))
         else:
             k = max(1, min(int(want), n))
         cuts = [(n * i) // k for i in range(k + 1)]

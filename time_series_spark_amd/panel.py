@@ -62,6 +62,7 @@ class PackedPanel(object):
                 self.y2d = np.ascontiguousarray(y.reshape(self.N, T))
         self.has_inf = None          # (tsf_pack_flags: an infinite y among the packed rows; None = not looked at)
         self.integral = None         # every y an integer that fits int32 (the reference's quantity column)
+        self.has_nat = None          # a ds that is pandas' NaT
 
 
 def pack_long_frame(pdf, y_col='y', n_threads=0):
@@ -74,17 +75,32 @@ def pack_long_frame(pdf, y_col='y', n_threads=0):
     for c in need:
         if c not in pdf.columns:
             raise ValueError("Dataframe must have columns %r" % (need,))
-    yv = pd.to_numeric(pdf[y_col]).to_numpy(dtype=np.float64, na_value=np.nan)
-    if np.isinf(yv).any():
-        raise ValueError('Found infinity in column y.')
-    ds_ns = ds_to_ns(pdf['ds'])
-    if (ds_ns == np.iinfo(np.int64).min).any():
-        raise ValueError('Found NaN in column ds.')
+    # Round 6: the frame's columns go to the packer in their own types wherever it takes them -- the reference's schema is
+    # int32 series_id / dim_id / y and datetime64 ds (prophet_modeler.py:12-17), and converting three 7.3 M-row columns to
+    # int64 / float64 first was most of this function's time; infinity and NaT are reported by the packer's own pass.
+    ycol = pdf[y_col]
+    if ycol.dtype in (np.dtype(np.int32), np.dtype(np.float32), np.dtype(np.float64)):
+        yv = ycol.to_numpy()
+    else:
+        yv = pd.to_numeric(ycol).to_numpy(dtype=np.float64, na_value=np.nan)
+    dcol = pdf['ds']
+    if dcol.dtype == np.dtype('datetime64[ns]'):
+        ds_ns = dcol.to_numpy().view(np.int64)
+    else:
+        ds_ns = ds_to_ns(dcol)
     sid_col, did_col = pdf['series_id'], pdf['dim_id']
-    sid = np.ascontiguousarray(pd.to_numeric(sid_col).to_numpy(dtype=np.int64))
-    did = np.ascontiguousarray(pd.to_numeric(did_col).to_numpy(dtype=np.int64))
-    return pack_rows(sid, did, ds_ns, yv, n_threads=n_threads,
-                     key_dtypes=(_key_dtype(sid_col), _key_dtype(did_col)))
+    if sid_col.dtype == np.dtype(np.int32) and did_col.dtype == np.dtype(np.int32):
+        sid, did = sid_col.to_numpy(), did_col.to_numpy()
+    else:
+        sid = pd.to_numeric(sid_col).to_numpy(dtype=np.int64)
+        did = pd.to_numeric(did_col).to_numpy(dtype=np.int64)
+    panel = pack_rows(sid, did, ds_ns, yv, n_threads=n_threads,
+                      key_dtypes=(_key_dtype(sid_col), _key_dtype(did_col)))
+    if panel.has_inf:
+        raise ValueError('Found infinity in column y.')
+    if panel.has_nat or (panel.N == 0 and len(ds_ns) and (ds_ns == np.iinfo(np.int64).min).any()):
+        raise ValueError('Found NaN in column ds.')
+    return panel
 
 
 def _key_dtype(col):
@@ -92,20 +108,27 @@ def _key_dtype(col):
 
 
 def pack_rows(sid, did, ds_ns, y, n_threads=0, key_dtypes=(np.int64, np.int64)):
-    """Arrays form of pack_long_frame: sid, did, ds_ns int64 [n], y float64 [n] (NaN = missing)."""
+    """Arrays form of pack_long_frame: sid, did int32 or int64 [n], ds_ns int64 [n], y float64 / float32 / int32 [n] (NaN =
+    missing).  A table that already is in packed order is used in place, in those types (PackedPanel.y then has y's
+    dtype); otherwise the packed y is float64."""
     L = _lib.load()
-    sid = np.ascontiguousarray(sid, dtype=np.int64)
-    did = np.ascontiguousarray(did, dtype=np.int64)
+    if not (np.asarray(sid).dtype == np.asarray(did).dtype == np.dtype(np.int32)):
+        sid = np.ascontiguousarray(sid, dtype=np.int64)
+        did = np.ascontiguousarray(did, dtype=np.int64)
+    sid, did = np.ascontiguousarray(sid), np.ascontiguousarray(did)
     ds_ns = np.ascontiguousarray(ds_ns, dtype=np.int64)
-    y = np.ascontiguousarray(y, dtype=np.float64)
+    y = np.asarray(y)
+    if y.dtype not in (np.dtype(np.float64), np.dtype(np.float32), np.dtype(np.int32)):
+        y = y.astype(np.float64)
+    y = np.ascontiguousarray(y)
     n = len(y)
     if not (len(sid) == len(did) == len(ds_ns) == n):
         raise ValueError('pack_rows: column lengths differ')
     h = ctypes.c_void_p()
     n_rows, n_series, ident = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int32()
-    rc = L.tsf_pack_rows(n, sid.ctypes.data, did.ctypes.data, ds_ns.ctypes.data, y.ctypes.data,
-                         int(n_threads), ctypes.byref(h), ctypes.byref(n_rows),
-                         ctypes.byref(n_series), ctypes.byref(ident))
+    rc = L.tsf_pack_rows_typed(n, sid.ctypes.data, did.ctypes.data, sid.dtype.itemsize, ds_ns.ctypes.data, y.ctypes.data,
+                               _lib.y_dtype_code(y), int(n_threads), ctypes.byref(h), ctypes.byref(n_rows),
+                               ctypes.byref(n_series), ctypes.byref(ident))
     if rc != 0:
         raise _lib.TsfError('tsf_pack_rows failed (%d)' % rc)
     try:
@@ -124,18 +147,19 @@ def pack_rows(sid, did, ds_ns, y, n_threads=0, key_dtypes=(np.int64, np.int64)):
                                   min_dt.ctypes.data, ymax.ctypes.data)
         if rc != 0:
             raise _lib.TsfError('tsf_pack_fetch failed (%d)' % rc)
-        f_al, f_inf, f_int = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
-        if L.tsf_pack_flags(h, ctypes.byref(f_al), ctypes.byref(f_inf), ctypes.byref(f_int)) != 0:
+        f_al, f_inf, f_int, f_nat = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        if L.tsf_pack_flags(h, ctypes.byref(f_al), ctypes.byref(f_inf), ctypes.byref(f_int), ctypes.byref(f_nat)) != 0:
             raise _lib.TsfError('tsf_pack_flags failed')
     finally:
         L.tsf_pack_free(h)
     keys = pd.DataFrame({'series_id': ksid.astype(key_dtypes[0]), 'dim_id': kdid.astype(key_dtypes[1])})
     panel = PackedPanel(keys, offsets, ds_out, y_out, aligned=bool(f_al.value))
-    panel.has_inf, panel.integral = bool(f_inf.value), bool(f_int.value)
+    panel.has_inf, panel.integral, panel.has_nat = bool(f_inf.value), bool(f_int.value), bool(f_nat.value)
     panel.stats = (span, min_dt, ymax)
     if R < n:
         # rows with a null y were dropped: they still count for the last history date
         nan = np.isnan(y)
+        sid, did = sid.astype(np.int64), did.astype(np.int64)
         nmax = pd.DataFrame({'s': sid[nan], 'd': did[nan], 'ds': ds_ns[nan]}).groupby(['s', 'd'])['ds'].max()
         idx = pd.MultiIndex.from_arrays([ksid, kdid], names=['s', 'd'])
         m = nmax.reindex(idx).to_numpy(dtype=np.float64, na_value=np.nan)
