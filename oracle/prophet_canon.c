@@ -1246,6 +1246,47 @@ static int cn_tridiag_ql(int n, double *A, double *V, double *lam)
     return iters;
 }
 
+/* make_negative_definite_and_solve where the finite-difference Hessian already IS negative definite (round 6; a third of
+ * the iterations on BASELINE cfg5): then |H| = -H and the step V |Lambda|^-1 V^T g is the solution of (-H) step = g -- by
+ * Cholesky, -H = L L^T, instead of an eigen-decomposition (69 % of a Newton fit on the GPU).  Same step up to rounding
+ * (~1e-12 relative: Newton is not chaotic).  Canonical order, lane = row i:
+ *   column j = 0 .. P-1:  s_i = -H[i][j] - sum_{k<j} L[i][k] L[j][k]   (i >= j; one fma chain over k, H read from row j
+ *                         of the symmetric matrix);  the pivot s_j must be > 0, else H is not negative definite: return 0
+ *                         and the eigen route runs on the untouched H;  L[j][j] = sqrt(s_j), L[i][j] = s_i / L[j][j];
+ *   forward  r = g:       z_j = r_j / L[j][j], then r_i = fma(-L[i][j], z_j, r_i) for i > j;
+ *   backward r = z:       step_j = r_j / L[j][j] (j = P-1 .. 0), then r_i = fma(-L[j][i], step_j, r_i) for i < j.
+ * Only where the kernels hold one parameter per lane -- P <= 64 and one column mode (cn_newton checks): the
+ * two-parameters-per-lane kernel (wider or mixed-mode models, a handful of retried series) keeps the eigen route. */
+static int cn_chol_neg_solve(int P, const double *H, const double *g, double *step)
+{
+    double L[CN_W * CN_W], s[CN_W], r[CN_W], z[CN_W];
+    if (P > CN_W) return 0;
+    for (int j = 0; j < P; ++j) {
+        for (int i = j; i < P; ++i) {
+            double a = -H[j * P + i];
+            for (int k = 0; k < j; ++k) a = fma(-L[i * CN_W + k], L[j * CN_W + k], a);
+            s[i] = a;
+        }
+        if (!(s[j] > 0.0)) return 0;
+        const double ljj = sqrt(s[j]);
+        L[j * CN_W + j] = ljj;
+        for (int i = j + 1; i < P; ++i) L[i * CN_W + j] = s[i] / ljj;
+    }
+    for (int i = 0; i < P; ++i) { r[i] = g[i]; z[i] = 0.0; }
+    for (int j = 0; j < P; ++j) {
+        const double zj = r[j] / L[j * CN_W + j];
+        z[j] = zj;
+        for (int i = j + 1; i < P; ++i) r[i] = fma(-L[i * CN_W + j], zj, r[i]);
+    }
+    for (int i = 0; i < P; ++i) r[i] = z[i];
+    for (int j = P - 1; j >= 0; --j) {
+        const double sj = r[j] / L[j * CN_W + j];
+        step[j] = sj;
+        for (int i = 0; i < j; ++i) r[i] = fma(-L[j * CN_W + i], sj, r[i]);
+    }
+    return 1;
+}
+
 static int cn_newton(cn_series *se, const cn_spec *o, const double *theta0, double *theta_out,
                      cn_fitinfo *res)
 {
@@ -1304,19 +1345,44 @@ static int cn_newton(cn_series *se, const cn_spec *o, const double *theta0, doub
         for (int a = 0; a < P; ++a)
             for (int b = 0; b < P; ++b) H[a * P + b] = A[a * P + b] + A[b * P + a];
         /* ---- make_negative_definite_and_solve (gradient of lp = -g) ---- */
-        cn_tridiag_ql(P, H, V, lam);
-        for (int j = 0; j < P; ++j) {
-            double a = 0.0;
-            for (int i = 0; i < P; ++i) a = fma(V[i * P + j], -g[i], a);
-            proj[j] = -a / fabs(lam[j]);
-        }
         memset(step, 0, sizeof(step));
-        for (int i = 0; i < P; ++i) {
-            double a = 0.0;
-            for (int j = 0; j < P; ++j) a = fma(V[i * P + j], proj[j], a);
-            step[i] = a;
+        const int one_per_lane = P <= CN_W && (se->Ka == 0 || se->Ka == se->K);
+        if (!(one_per_lane && cn_chol_neg_solve(P, H, g, step))) {
+            cn_tridiag_ql(P, H, V, lam);
+            for (int j = 0; j < P; ++j) {
+                double a = 0.0;
+                for (int i = 0; i < P; ++i) a = fma(V[i * P + j], -g[i], a);
+                proj[j] = -a / fabs(lam[j]);
+            }
+            for (int i = 0; i < P; ++i) {
+                double a = 0.0;
+                for (int j = 0; j < P; ++j) a = fma(V[i * P + j], proj[j], a);
+                step[i] = a;
+            }
         }
-        /* ---- step halving ---- */
+        /* ---- step halving ----
+         * Round 6, quadratic form: the ~30 trials of an iteration (the recalled epsilon / 2 factor makes the step 1e6 too
+         * long) all lie on ONE line through the point the quadratic form was re-centred at a moment ago, x = th - size * step,
+         * so D = x - ref = -size * step and
+         *     SSE(size) = s0 - 2 c.D + D.(M D) = s0 + 2 size (c . step) + size^2 (step . M step):
+         * two dot products and one mat-vec per ITERATION (sw, cs below), three scalars per TRIAL, where every trial used to
+         * be a P x P mat-vec (19 % of a fit on the GPU).  The value is cn_assemble_q's on that SSE (gradient not formed:
+         * the next iteration starts with a residual-form evaluation of the accepted point).  Same function, other rounding
+         * than cn_eval_gram at the same x. */
+        double sw = 0.0, cs = 0.0;
+        if (se->gram) {
+            double Dl[CN_MAX_P], vl[CN_MAX_P];
+            for (int p = 0; p < CN_MAX_P; ++p) { Dl[p] = 0.0; vl[p] = 0.0; }
+            for (int p = 0; p < P; ++p) Dl[p] = (p == 2) ? 0.0 : step[p];
+            for (int p = 0; p < P; ++p) {
+                double a[4] = {0.0, 0.0, 0.0, 0.0};
+                const double *row = se->M + (size_t)p * P;
+                for (int q = 0; q < P; ++q) a[q & 3] = fma(row[q], Dl[q], a[q & 3]);
+                vl[p] = (a[0] + a[1]) + (a[2] + a[3]);
+            }
+            sw = dotc(Dl, vl);
+            cs = dotc(se->cvec, Dl);
+        }
         double size = 2.0, f1 = -1e100;
         int moved = 1;
         memcpy(x, th, sizeof(x));
@@ -1325,7 +1391,17 @@ static int cn_newton(cn_series *se, const cn_spec *o, const double *theta0, doub
             if (size < 1e-50) { moved = 0; break; }
             for (int i = 0; i < P; ++i) x[i] = th[i] - size * step[i];
             double fn;
-            f1 = CN_NEWTON_EVAL(x, &fn, tg) ? -1e100 : -fn;
+            if (se->gram) {
+                double zero[CN_MAX_P];
+                for (int p = 0; p < CN_MAX_P; ++p) zero[p] = 0.0;
+                se->n_eval++;
+                const double q2 = (size * size) * sw;
+                const double cd = -(size * cs);
+                const double sse = fma(-2.0, cd, se->s0) + q2;
+                f1 = cn_assemble_q(se, x, sse, zero, &fn, tg) ? -1e100 : -fn;
+            } else {
+                f1 = CN_NEWTON_EVAL(x, &fn, tg) ? -1e100 : -fn;
+            }
         }
         it++;
         if (moved) { memcpy(th, x, sizeof(th)); lp = f1; }

@@ -287,6 +287,63 @@ __global__ __launch_bounds__(64, (KP <= 16 ? TSF_NEWTON_QUAD_WPS : 1)) void newt
             bool fresh = false;
             int ret = 0;
             bool done = false;
+            // the halving trials of an iteration and what follows them (convergence test, next stage), given the step: shared
+            // by the two ways an iteration gets its step -- the eigen route (NB_HAVE_EIG, a round later) and the Cholesky
+            // shortcut (at once, in the round the Hessian was formed)
+            auto halve_and_finish = [&](const double stepv) {
+                const int P = sv.P;
+                done = false;           // (a slot may finish one series and carry another through an iteration in the same round)
+                // The ~30 halving trials of the iteration lie on ONE line through the point the quadratic form was just
+                // re-centred at: SSE = s0 + 2 size (c . step) + size^2 (step . Z^T Z step) (cn_newton, round 6) -- ONE mat-vec
+                // per iteration, straight from L2 (until round 5 every trial was a mat-vec on a compact LDS copy of Z^T Z made
+                // for the purpose: 19 % of a fit), then three scalars and cn_assemble_q's prior sums per trial.
+                wave_sync();
+                double sw, cs;
+                {
+                    const double Dl = (lane == 2 || lane >= P) ? 0.0 : stepv;
+                    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+                    const int P4l = (P + 3) & ~3;       // (rows >= P of Z^T Z are zero and meet D = 0)
+                    for (int qq = 0; qq < P4l; qq += 4) {
+                        a0 = __builtin_fma(Mp[(size_t)(qq + 0) * W + lane], readlane_f64(Dl, qq + 0), a0);
+                        a1 = __builtin_fma(Mp[(size_t)(qq + 1) * W + lane], readlane_f64(Dl, qq + 1), a1);
+                        a2 = __builtin_fma(Mp[(size_t)(qq + 2) * W + lane], readlane_f64(Dl, qq + 2), a2);
+                        a3 = __builtin_fma(Mp[(size_t)(qq + 3) * W + lane], readlane_f64(Dl, qq + 3), a3);
+                    }
+                    const double wv = (a0 + a1) + (a2 + a3);
+                    sw = bfly_sum(Dl * wv + 0.0);
+                    cs = bfly_sum(lds.cvec[lane] * Dl + 0.0);
+                }
+                // Stan's `while (f1 < f0)` step-halving loop
+                double size = 2.0, f1 = -1e100;
+                bool moved = true;
+                double x[PPL], gx[PPL], fx;
+                x[0] = th[0];
+                while (f1 < f0) {
+                    size *= 0.5;
+                    if (size < 1e-50) { moved = false; break; }
+                    x[0] = th[0] - size * stepv;
+                    sv.n_eval++;
+                    const double q2l = (size * size) * sw;
+                    const double cdl = -(size * cs);
+                    const double ssel = __builtin_fma(-2.0, cdl, s0) + q2l;
+                    const double zero[PPL] = {0.0};
+                    const bool bad = assemble_q<PPL>(sv, lk, x, ssel, zero, fx, gx);
+                    f1 = bad ? -1e100 : -fx;
+                }
+                NBT_LAP(4);
+                ++it;
+                if (moved) { th[0] = x[0]; lp = f1; }
+                else lp = f0;
+                if (mI > 0 && __builtin_fabs(lp - lastlp) < 1e-8) { ret = TSF_ST_NEWTON_CONVERGED; done = true; }
+                else if (++mI >= a.opt.max_iter) { ret = TSF_ST_MAXIT; done = true; }
+                if (done) {
+                    store_theta<PPL>(a, sv, n, th, a.theta);
+                    if (lane == 0) { a.status[n] = ret; a.n_iter[n] = it; a.n_eval[n] = sv.n_eval; a.fval[n] = -lp; }
+                    stage = NB_EMPTY;
+                } else {
+                    stage = NB_NEED_A;
+                }
+            };
             if (stage == NB_HAVE_EIG) {
                 // ---------------- finish the iteration: eigenvectors, projection, step, halving ----------------
                 n = (int64_t)rec[NB_SERIES];
@@ -341,54 +398,7 @@ __global__ __launch_bounds__(64, (KP <= 16 ? TSF_NEWTON_QUAD_WPS : 1)) void newt
                 }
                 const double stepv = (lane < P) ? sa : 0.0;
                 NBT_LAP(3);
-                // V is dead: the region takes a compact copy of Z^T Z (row stride PM) for the ~30 halving
-                // trials of this iteration, which otherwise fetch it from L2 every time
-                wave_sync();
-                {
-                    double mrow[8];
-                    for (int q0 = 0; q0 < P; q0 += 8) {
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) mrow[u] = (q0 + u < P && lane < PM) ? Mp[(size_t)(q0 + u) * W + lane] : 0.0;
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) if (q0 + u < P && lane < PM) Am[(q0 + u) * PM + lane] = mrow[u];
-                    }
-                    // rows >= P of Z^T Z are zero, and the mat-vec walks whole groups of four rows with 64
-                    // lanes each: everything from row P to the end of the region is zeroed (the matrix's
-                    // last row, the rounding pad, stale scratch of a residual pass -- uninitialised LDS
-                    // may hold a NaN, and NaN x 0 is not 0); what follows the region is ref / cvec /
-                    // lanec, finite by construction
-                    for (int idx = P * PM + lane; idx < (int)(shared_bytes / sizeof(double)); idx += W) Am[idx] = 0.0;
-                }
-                wave_sync();
-                // Stan's `while (f1 < f0)` step-halving loop
-                const int P4h = (P + 3) & ~3;       // the mat-vec walks whole groups of four rows; rows >= P meet D = 0
-                double size = 2.0, f1 = -1e100;
-                bool moved = true;
-                double x[PPL], gx[PPL], fx, q2;
-                x[0] = th[0];
-                while (f1 < f0) {
-                    size *= 0.5;
-                    if (size < 1e-50) { moved = false; break; }
-                    x[0] = th[0] - size * stepv;
-                    sv.n_eval++;
-                    const double no_mreg[1] = {0.0};
-                    const bool bad = (nb.flags & 2) ? gram_eval_q<PPL, 0>(sv, lk, Mp, qa.P4, x, lds.ref, lds.cvec, s0, fx, gx, q2, nullptr, no_mreg)
-                                                    : gram_eval_q<PPL, 0>(sv, lk, Am, P4h, x, lds.ref, lds.cvec, s0, fx, gx, q2, nullptr, no_mreg, PM);
-                    f1 = bad ? -1e100 : -fx;
-                }
-                NBT_LAP(4);
-                ++it;
-                if (moved) { th[0] = x[0]; lp = f1; }
-                else lp = f0;
-                if (mI > 0 && __builtin_fabs(lp - lastlp) < 1e-8) { ret = TSF_ST_NEWTON_CONVERGED; done = true; }
-                else if (++mI >= a.opt.max_iter) { ret = TSF_ST_MAXIT; done = true; }
-                if (done) {
-                    store_theta<PPL>(a, sv, n, th, a.theta);
-                    if (lane == 0) { a.status[n] = ret; a.n_iter[n] = it; a.n_eval[n] = sv.n_eval; a.fval[n] = -lp; }
-                    stage = NB_EMPTY;
-                } else {
-                    stage = NB_NEED_A;
-                }
+                halve_and_finish(stepv);
             }
             for (;;) {
             // ---------------- an empty slot takes the next series of the queue ----------------
@@ -434,6 +444,7 @@ __global__ __launch_bounds__(64, (KP <= 16 ? TSF_NEWTON_QUAD_WPS : 1)) void newt
                 } else if (bad) {
                     ret = TSF_ST_NEWTON_FAIL; failed = true;
                 }
+                fresh = false;          // (the Cholesky shortcut may start the next iteration of this series in the same round)
                 if (!failed) {
                     lds.ref[lane] = (lane == 2) ? 0.0 : x[0];
                     lds.cvec[lane] = (lane == 2) ? 0.0 : ztr_e[0];
@@ -502,6 +513,15 @@ __global__ __launch_bounds__(64, (KP <= 16 ? TSF_NEWTON_QUAD_WPS : 1)) void newt
                         wave_sync();
                         if (mine) { const double h = u + v; Am[r * PM + lane] = h; Am[lane * PM + r] = h; }
                         wave_sync();
+                    }
+                    {   // H negative definite (a third of the iterations): the step by Cholesky, the iteration finished here
+                        // and now -- no tridiagonalisation, no record, no round of the chain (chol_neg_solve, round 6)
+                        double st_c;
+                        if (chol_neg_solve(P, PM, Am, g[0], st_c)) {
+                            NBT_LAP(0);
+                            halve_and_finish(st_c);
+                            continue;
+                        }
                     }
                     ql_tridiag_q(P, PM, Am, Vm, lds.ql);
                     NBT_LAP(0);

@@ -240,6 +240,56 @@ __device__ __forceinline__ double ql_chain(int n, int PM, double *Vm, QlScratch 
     return (lane < n) ? dv : 0.0;
 }
 
+// make_negative_definite_and_solve where the finite-difference Hessian already IS negative definite (cn_chol_neg_solve,
+// round 6: a third of the iterations on BASELINE cfg5): -H = L L^T by Cholesky and (-H) step = g by two substitutions
+// instead of an eigen-decomposition.  Lane i = row i.  H is the full symmetric matrix in Am; L goes into its STRICTLY lower
+// triangle (the diagonal of L stays in lane j's register), -H[i][j] is read from row j (the upper triangle, never
+// written), so a failed attempt -- a pivot that is not positive: H is not negative definite -- only has to copy the upper
+// triangle back down before the eigen route runs.  gl: the lane's gradient entry.  Same operations in the same order as
+// the oracle's.
+__device__ __forceinline__ bool chol_neg_solve(int P, int PM, double *Am, double gl, double &step_out)
+{
+    const int lane = lane_id();
+    double ljj_own = 1.0;
+    bool ok = true;
+    int j = 0;
+    for (; j < P; ++j) {
+        double s = 0.0;
+        if (lane >= j && lane < P) {
+            s = -Am[j * PM + lane];
+            for (int kk = 0; kk < j; ++kk) s = __builtin_fma(-Am[lane * PM + kk], Am[j * PM + kk], s);
+        }
+        const double d = readlane_f64(s, j);
+        if (!(d > 0.0)) { ok = false; break; }
+        const double ljj = __builtin_sqrt(d);
+        if (lane == j) ljj_own = ljj;
+        if (lane > j && lane < P) Am[lane * PM + j] = s / ljj;
+        TSF_WAVE_SYNC();
+    }
+    if (!ok) {
+        // columns 0 .. j-1 of the strictly lower triangle hold L: H again, from the upper triangle
+        for (int c = 0; c < j; ++c)
+            if (lane > c && lane < P) Am[lane * PM + c] = Am[c * PM + lane];
+        TSF_WAVE_SYNC();
+        return false;
+    }
+    double r = (lane < P) ? gl : 0.0, z = 0.0;
+    for (j = 0; j < P; ++j) {
+        const double zj = readlane_f64(r, j) / readlane_f64(ljj_own, j);
+        if (lane == j) z = zj;
+        if (lane > j && lane < P) r = __builtin_fma(-Am[lane * PM + j], zj, r);
+    }
+    double r2 = z, st = 0.0;
+    for (j = P - 1; j >= 0; --j) {
+        const double sj = readlane_f64(r2, j) / readlane_f64(ljj_own, j);
+        if (lane == j) st = sj;
+        if (lane < j) r2 = __builtin_fma(-Am[j * PM + lane], sj, r2);
+    }
+    step_out = (lane < P) ? st : 0.0;
+    TSF_WAVE_SYNC();
+    return true;
+}
+
 __device__ __forceinline__ double ql_lds(int n, int PM, double *Am, double *Vm, QlScratch &sc, long long *qlt = nullptr)
 {
     ql_tridiag_q(n, PM, Am, Vm, sc, qlt);
@@ -345,7 +395,8 @@ __global__ __launch_bounds__(64) void newton_kernel(FitArgs a, int PM)
                 if (mine) { const double h = u + v; Am[r * PM + lane] = h; Am[lane * PM + r] = h; }
                 TSF_WAVE_SYNC();
             }
-            // ---- make_negative_definite_and_solve
+            // ---- make_negative_definite_and_solve: Cholesky where H is negative definite, else the eigen route
+            if (!chol_neg_solve(P, PM, Am, g[0], step[0])) {
             const double lam = ql_lds(P, PM, Am, Vm, lds.ql);
             double pa = 0.0;
             for (int i = 0; i < P; ++i) {
@@ -361,6 +412,7 @@ __global__ __launch_bounds__(64) void newton_kernel(FitArgs a, int PM)
                 sa = __builtin_fma(vij, pj, sa);
             }
             step[0] = (lane < P) ? sa : 0.0;
+            }
             x[0] = th[0];
             size = 2.0; f1 = -1e100;
             stage = S_HALVE;

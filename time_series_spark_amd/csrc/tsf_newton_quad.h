@@ -91,7 +91,8 @@ __device__ __forceinline__ void newton_one_quad(const QuadArgs &qa, NewtonQuadLd
 
     enum { S_INIT = 0, S_F0, S_HALVE };
     int stage = S_INIT, ret = TSF_ST_MAXIT, it = 0, mI = 0, d = 0, pi = 0;
-    double lp = 0.0, lastlp = 0.0, f0 = 0.0, f1 = 0.0, size = 2.0, fx = 0.0, s0 = 0.0, q2 = 0.0;
+    double lp = 0.0, lastlp = 0.0, f0 = 0.0, f1 = 0.0, size = 2.0, fx = 0.0, s0 = 0.0;
+    double sw = 0.0, cs = 0.0;      // step . (Z^T Z step) and c . step of the running iteration (the halving trials' line)
     for (;;) {
         bool bad;
         sv.n_eval++;
@@ -109,7 +110,13 @@ __device__ __forceinline__ void newton_one_quad(const QuadArgs &qa, NewtonQuadLd
             }
             QT_LAP(6);
         } else {
-            { const double no_mreg[1] = {0.0}; bad = gram_eval_q<PPL, 0>(sv, lk, Mp, qa.P4, x, lds.ref, lds.cvec, s0, fx, gx, q2, nullptr, no_mreg); }
+            // a halving trial x = th - size * step: on the line through the point the quadratic form was just re-centred at,
+            // SSE = s0 + 2 size (c . step) + size^2 (step . Z^T Z step) -- three scalars (cn_newton, round 6), not a mat-vec
+            const double q2l = (size * size) * sw;
+            const double cdl = -(size * cs);
+            const double ssel = __builtin_fma(-2.0, cdl, s0) + q2l;
+            const double zero[PPL] = {0.0};
+            bad = assemble_q<PPL>(sv, lk, x, ssel, zero, fx, gx);
             QT_LAP(5);
         }
         bool finish_iter = false, moved = false;
@@ -190,6 +197,8 @@ __device__ __forceinline__ void newton_one_quad(const QuadArgs &qa, NewtonQuadLd
             }
             // ---- make_negative_definite_and_solve
             QT_LAP(6);
+            // (Cholesky where H is negative definite -- chol_neg_solve, round 6 --, else the eigen route)
+            if (!chol_neg_solve(P, PM, Am, g[0], step[0])) {
 #ifdef TSF_QUAD_TIMING      // temporary: the eigen-solver's three parts in slots 0..2 (0 Householder, 1 Q, 2 QL)
             long long qlt[3] = {0, 0, 0};
             const double lam = ql_lds(P, PM, Am, Vm, lds.ql, qlt);
@@ -212,6 +221,22 @@ __device__ __forceinline__ void newton_one_quad(const QuadArgs &qa, NewtonQuadLd
                 sa = __builtin_fma(vij, pj, sa);
             }
             step[0] = (lane < P) ? sa : 0.0;
+            }
+            {   // the line of this iteration's halving trials: w = Z^T Z step (cn_eval_gram's four fma chains over the
+                // rows, log sigma's entry of the direction taken out), sw = step . w, cs = c . step
+                const double Dl = (lane == 2 || lane >= P) ? 0.0 : step[0];
+                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+                const int P4l = (P + 3) & ~3;       // (rows >= P of Z^T Z are zero and meet D = 0)
+                for (int qq = 0; qq < P4l; qq += 4) {
+                    a0 = __builtin_fma(Mp[(size_t)(qq + 0) * W + lane], readlane_f64(Dl, qq + 0), a0);
+                    a1 = __builtin_fma(Mp[(size_t)(qq + 1) * W + lane], readlane_f64(Dl, qq + 1), a1);
+                    a2 = __builtin_fma(Mp[(size_t)(qq + 2) * W + lane], readlane_f64(Dl, qq + 2), a2);
+                    a3 = __builtin_fma(Mp[(size_t)(qq + 3) * W + lane], readlane_f64(Dl, qq + 3), a3);
+                }
+                const double wv = (a0 + a1) + (a2 + a3);
+                sw = bfly_sum(Dl * wv + 0.0);
+                cs = bfly_sum(lds.cvec[lane] * Dl + 0.0);
+            }
             QT_LAP(4);
             x[0] = th[0];
             size = 2.0; f1 = -1e100;
