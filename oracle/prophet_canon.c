@@ -1250,8 +1250,10 @@ static int cn_tridiag_ql(int n, double *A, double *V, double *lam)
  * the iterations on BASELINE cfg5): then |H| = -H and the step V |Lambda|^-1 V^T g is the solution of (-H) step = g -- by
  * Cholesky, -H = L L^T, instead of an eigen-decomposition (69 % of a Newton fit on the GPU).  Same step up to rounding
  * (~1e-12 relative: Newton is not chaotic).  Canonical order, lane = row i:
- *   column j = 0 .. P-1:  s_i = -H[i][j] - sum_{k<j} L[i][k] L[j][k]   (i >= j; one fma chain over k, H read from row j
- *                         of the symmetric matrix);  the pivot s_j must be > 0, else H is not negative definite: return 0
+ *   column j = 0 .. P-1:  s_i = -H[i][j] - sum_{k<j} L[i][k] L[j][k]   (i >= j; FOUR fma chains over k, chain k mod 4, the
+ *                         first one starting from -H[i][j], combined (a0 + a1) + (a2 + a3) -- one chain of 33 dependent
+ *                         LDS-fed steps per column was half of the shortcut's cost on the GPU; H read from row j of the
+ *                         symmetric matrix);  the pivot s_j must be > 0, else H is not negative definite: return 0
  *                         and the eigen route runs on the untouched H;  L[j][j] = sqrt(s_j), L[i][j] = s_i / L[j][j];
  *   forward  r = g:       z_j = r_j / L[j][j], then r_i = fma(-L[i][j], z_j, r_i) for i > j;
  *   backward r = z:       step_j = r_j / L[j][j] (j = P-1 .. 0), then r_i = fma(-L[j][i], step_j, r_i) for i < j.
@@ -1263,9 +1265,9 @@ static int cn_chol_neg_solve(int P, const double *H, const double *g, double *st
     if (P > CN_W) return 0;
     for (int j = 0; j < P; ++j) {
         for (int i = j; i < P; ++i) {
-            double a = -H[j * P + i];
-            for (int k = 0; k < j; ++k) a = fma(-L[i * CN_W + k], L[j * CN_W + k], a);
-            s[i] = a;
+            double a[4] = {-H[j * P + i], 0.0, 0.0, 0.0};
+            for (int k = 0; k < j; ++k) a[k & 3] = fma(-L[i * CN_W + k], L[j * CN_W + k], a[k & 3]);
+            s[i] = (a[0] + a[1]) + (a[2] + a[3]);
         }
         if (!(s[j] > 0.0)) return 0;
         const double ljj = sqrt(s[j]);

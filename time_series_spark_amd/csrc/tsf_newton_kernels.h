@@ -256,8 +256,20 @@ __device__ __forceinline__ bool chol_neg_solve(int P, int PM, double *Am, double
     for (; j < P; ++j) {
         double s = 0.0;
         if (lane >= j && lane < P) {
-            s = -Am[j * PM + lane];
-            for (int kk = 0; kk < j; ++kk) s = __builtin_fma(-Am[lane * PM + kk], Am[j * PM + kk], s);
+            // four fma chains over k (chain k mod 4), their eight LDS reads in flight together
+            double a0 = -Am[j * PM + lane], a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            const double *li = Am + lane * PM, *lj = Am + j * PM;
+            int kk = 0;
+            for (; kk + 3 < j; kk += 4) {
+                const double l0 = li[kk], l1 = li[kk + 1], l2 = li[kk + 2], l3 = li[kk + 3];
+                const double r0 = lj[kk], r1 = lj[kk + 1], r2 = lj[kk + 2], r3 = lj[kk + 3];
+                a0 = __builtin_fma(-l0, r0, a0); a1 = __builtin_fma(-l1, r1, a1);
+                a2 = __builtin_fma(-l2, r2, a2); a3 = __builtin_fma(-l3, r3, a3);
+            }
+            if (kk < j) a0 = __builtin_fma(-li[kk], lj[kk], a0);
+            if (kk + 1 < j) a1 = __builtin_fma(-li[kk + 1], lj[kk + 1], a1);
+            if (kk + 2 < j) a2 = __builtin_fma(-li[kk + 2], lj[kk + 2], a2);
+            s = (a0 + a1) + (a2 + a3);
         }
         const double d = readlane_f64(s, j);
         if (!(d > 0.0)) { ok = false; break; }
