@@ -46,10 +46,6 @@ enum {
                                 kernel (count on stderr); bit 3 the default pool never releases memory */
     TSF_OPT_COOP_TAIL,       /* residual-form launches: the fits still running are handed to the cooperative kernel once no
                                 more of them are left than this many per hundred compute units (default 200) */
-    TSF_OPT_COOP_LIVE,       /* workgroups of the cooperative kernel resident BESIDE the one-wave kernel for the whole launch, taking
-                                over fits that have spent TSF_OPT_COOP_LIVE_AFTER evaluations (0: none; default 8 for calls of
-                                4 096 series or more whose model has a base-pair kernel) */
-    TSF_OPT_COOP_LIVE_AFTER, /* ... that many evaluations (default 2 500) */
     TSF_OPT_COUNT
 };
 int tsf_set_option(tsf_ctx *ctx, int option, int value);

@@ -54,8 +54,6 @@ struct tsf_ctx {
     hipEvent_t ev0[TSF_PROFILE_RING], ev1[TSF_PROFILE_RING];
     int ev_created;
     long ev_count;          // profiled calls since profiling was enabled
-    hipStream_t live_stream;  // the live instance of the cooperative kernel (FitArgs::live_blocks): its stream and the two events
-    hipEvent_t live_ev[2];    // that tie it to the call's stream; created by the first call that wants them
 };
 
 #define HIP_TRY(ctx, expr)                                                                   \
@@ -122,7 +120,6 @@ extern "C" void tsf_destroy(tsf_ctx *ctx)
     if (ctx->nb_ws) hipFree(ctx->nb_ws);
     if (ctx->iv_ws) hipFree(ctx->iv_ws);
     for (int b = 0; b < 2; ++b) { if (ctx->order_dev[b]) hipFree(ctx->order_dev[b]); if (ctx->order_ev[b]) hipEventDestroy(ctx->order_ev[b]); }
-    if (ctx->live_stream) { hipStreamDestroy(ctx->live_stream); hipEventDestroy(ctx->live_ev[0]); hipEventDestroy(ctx->live_ev[1]); }
     if (ctx->ev_created)
         for (int i = 0; i < TSF_PROFILE_RING; ++i) { hipEventDestroy(ctx->ev0[i]); hipEventDestroy(ctx->ev1[i]); }
     delete ctx;
@@ -269,7 +266,7 @@ constexpr size_t TSF_NB_KEEP = (size_t)1 << 30;
 static int coop_slots_for(int64_t N, int after, int n_cu)
 {
     if (after == COOP_DIRECT) return 0;
-    const int64_t cap = after >= 0 ? 8192 : 8 * (int64_t)n_cu + 1024;      // (hand-over at up to ~4 fits per CU, twice that for the waves racing past the test; 1024 for the live instance)
+    const int64_t cap = after >= 0 ? 8192 : 8 * (int64_t)n_cu;      // (hand-over at up to ~4 fits per CU, twice that for the waves racing past the test)
     return (int)(N < cap ? N : cap);
 }
 
@@ -765,22 +762,7 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
                 a.coop_tail_at = (int)((int64_t)ctx->n_cu * (pct > 400 ? 400 : pct) / 100);
                 if (a.coop_tail_at < 1) a.coop_tail_at = 1;
             }
-            HIP_TRY(ctx, hipMemsetAsync(a.coop_ctl, 0, 8 * sizeof(int), st));
-            // live workgroups beside the one-wave kernel (launchers: live_wanted): long launches of models with a base-pair kernel
-            const int lb = ctx->opt[TSF_OPT_COOP_LIVE] >= 0 ? ctx->opt[TSF_OPT_COOP_LIVE] : (N >= 4096 ? 8 : 0);
-            if (lb > 0 && coop_after < 0 && coop_after != COOP_DIRECT && a.harm != 0) {
-                if (!ctx->live_stream) {
-                    int pr_lo = 0, pr_hi = 0;
-                    HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi));
-                    HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->live_stream, hipStreamNonBlocking, pr_hi));
-                    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->live_ev[0], hipEventDisableTiming));
-                    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->live_ev[1], hipEventDisableTiming));
-                }
-                a.live_blocks = lb < ctx->n_cu / 2 ? lb : ctx->n_cu / 2;
-                a.live_after = ctx->opt[TSF_OPT_COOP_LIVE_AFTER] > 0 ? ctx->opt[TSF_OPT_COOP_LIVE_AFTER] : 2500;
-                a.live_stream = ctx->live_stream; a.live_ev0 = ctx->live_ev[0]; a.live_ev1 = ctx->live_ev[1];
-                HIP_TRY(ctx, hipMemsetAsync(a.coop_list, 0xff, sizeof(int32_t) * (size_t)coop_slots, st));      // -1: slot not published yet
-            }
+            HIP_TRY(ctx, hipMemsetAsync(a.coop_ctl, 0, 4 * sizeof(int), st));
         }
         lrc = pick_launch(hs.growth, mode)(hs.KP, a, theta_in != nullptr, st);
     }

@@ -29,7 +29,7 @@ constexpr int COOP_NTB = 16;    // steps per chunk the register-resident loops h
 template <int KP, int PPL>
 struct CoopLds {
     WaveLds<KP, PPL> w;         // the owner's tables: theta, segment tables, time-axis sums, history
-    int cmd, item, item_n;
+    int cmd, item;
     long long *dbg;             // (dev timing builds) per-series cycle counters, 16 per series
     // trend wave, NT <= COOP_NTB: where changepoint j's snapshot of the running trend sums is taken
     // (step and chunk of the first row at or after the changepoint), and the running sums of an
@@ -1337,8 +1337,6 @@ __device__ __forceinline__ void coop_report_unfitted(const FitArgs &a, const Ser
     if (lane == 0) { a.status[n] = st.status0; a.n_iter[n] = 0; a.n_eval[n] = 0; a.fval[n] = 0.0; }
 }
 
-constexpr long long COOP_LIVE_IDLE_TICKS = 300000000ll;      // 3 s of the 100 MHz clock: an idle live workgroup leaves by itself
-
 // ---- the kernel: persistent workgroups over the checkpoint list ---------------------------------
 // SPARSE: KP = SP_DENSE registers on the tables and the LDS of the 64-column model (KL), series of <= 12 steps only
 template <int KP, int GROWTH, int MODE, int PPL, int NW, bool XIDX, int HARM = 0, bool SPARSE = false>
@@ -1355,57 +1353,19 @@ __global__ __launch_bounds__(NW * 64) void fit_coop_kernel(FitArgs a)
     // direct mode: every series of the call, fitted here from its initial values; otherwise the fits
     // fit_kernel suspended
     const bool direct = a.coop_after == COOP_DIRECT;
-    const bool live = !direct && a.coop_live != 0;
-    int n_ckpt = direct ? (int)a.N : (live ? 0x7fffffff : a.coop_ctl[1]);
-    if (!direct && !live && n_ckpt > a.coop_max) n_ckpt = a.coop_max;
-    if (live && threadIdx.x == 0) atomicAdd(&a.coop_ctl[7], 1);
+    int n_ckpt = direct ? (int)a.N : a.coop_ctl[1];
+    if (!direct && n_ckpt > a.coop_max) n_ckpt = a.coop_max;
     for (;;) {
-        if (live) {
-            // the live instance: resident beside the one-wave kernel, which is still taking tickets.  Lane 0 of the owner
-            // wave watches the queue (a claim is a compare-and-swap on the head both instances share: no item is lost to a
-            // claim beyond the tickets taken), leaves when every block of the one-wave kernel has finished or suspended and
-            // the queue is empty -- or after coop_live_idle_ticks of looking at an empty queue, whatever the reason (the
-            // tail instance takes every slot nobody claimed) --, and waits for the claimed slot's release store.
-            if (threadIdx.x == 0) {
-                int it = -1, itn = -1;
-                const long long t0 = (long long)wall_clock64();
-                for (;;) {
-                    const int h = __hip_atomic_load(&a.coop_ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    int t = __hip_atomic_load(&a.coop_ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (t > a.coop_max) t = a.coop_max;
-                    if (h < t) {
-                        int expect = h;
-                        if (__hip_atomic_compare_exchange_strong(&a.coop_ctl[2], &expect, h + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { it = h; break; }
-                        continue;
-                    }
-                    if (__hip_atomic_load(&a.coop_ctl[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (int)a.N) {
-                        // (a ticket is taken before its block counts as suspended: look once more)
-                        int t2 = __hip_atomic_load(&a.coop_ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (t2 > a.coop_max) t2 = a.coop_max;
-                        if (h < t2) continue;
-                        break;
-                    }
-                    if ((long long)wall_clock64() - t0 > COOP_LIVE_IDLE_TICKS) break;
-                    __builtin_amdgcn_s_sleep(64);
-                }
-                if (it >= 0) {
-                    while ((itn = __hip_atomic_load(&a.coop_list[it], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < 0) __builtin_amdgcn_s_sleep(8);
-                } else {
-                    atomicAdd(&a.coop_ctl[7], -1);
-                }
-                cl.item = it; cl.item_n = itn;
-            }
-        } else if (wid == 0) {
-            // (queue fetch kept branch-free: see the compiler note in DESIGN.md section 5)
+        // (queue fetch kept branch-free: see the compiler note in DESIGN.md section 5)
+        if (wid == 0) {
             const int it = atomicAdd(&a.coop_ctl[2], lane_id() == 0 ? 1 : 0);
             if (lane_id() == 0) cl.item = it;
         }
         __syncthreads();
         const int item = cl.item;
-        const int item_n = cl.item_n;
         __syncthreads();
-        if (item >= n_ckpt || item < 0) break;
-        const int64_t n = direct ? (a.order ? (int64_t)a.order[item] : (int64_t)item) : (live ? (int64_t)item_n : (int64_t)a.coop_list[item]);      // (cost hints: tsf_set_cost_hints)
+        if (item >= n_ckpt) break;
+        const int64_t n = direct ? (a.order ? (int64_t)a.order[item] : (int64_t)item) : (int64_t)a.coop_list[item];      // (cost hints: tsf_set_cost_hints)
         SeriesView sv;
         make_view<KL, PPL>(a, n, sv);
         if (direct && a.stab[n].status0 != 0) {
@@ -1436,7 +1396,6 @@ __global__ __launch_bounds__(NW * 64) void fit_coop_kernel(FitArgs a)
             coop_owner<KP, GROWTH, MODE, PPL, NW, XIDX, HARM, SPARSE>(a, sv, n, direct ? nullptr : a.coop_slots + (size_t)item * a.coop_stride,
                                                                       cl, rbR, rbU, rbV,
                                                                       coop_xl_bytes(KP, a.NTmax) > 0 ? rbV + (size_t)(SPARSE ? 12 : COOP_NTB) * W : nullptr);
-            if (!direct && lane_id() == 0) atomicAdd(&a.coop_ctl[6], 1);       // (a live workgroup is free again: coop_should_suspend)
         } else if constexpr (SPARSE) {
             coop_helper_ntb<KP, GROWTH, MODE, PPL, NW, XIDX, 12, HARM, true>(a.sp, sv, cl, rbR, rbU, rbV, wid);    // (launched for NTmax <= 12 only)
         } else if (sv.NT > COOP_NTB) {

@@ -794,22 +794,13 @@ struct FitArgs {
     // cooperative tail (tsf_coop_kernels.h): where coop_ctl is set, a fit that is still running when
     // the launch has started its last block (coop_after < 0) or that has used coop_after evaluations
     // writes its optimiser state to a checkpoint slot and returns; fit_coop_kernel finishes it with a
-    // whole workgroup.  ctl[0] blocks started, ctl[1] slots taken, ctl[2] queue head (shared by the tail and the live
-    // instance), ctl[3] blocks finished or suspended, ctl[6] suspended fits the cooperative kernel has finished, ctl[7] live
-    // workgroups looking at the queue.
-    // The LIVE instance (live_blocks > 0): a few workgroups of the same kernel started BEFORE the one-wave kernel on a
-    // stream of their own (coop_live = 1 in their copy of the arguments), resident for the whole launch; a fit that has
-    // spent live_after evaluations hands itself over while one of them is free (coop_should_suspend), publishing its slot
-    // with a release store of coop_list[ticket] (-1 until then).  The tail instance behind the one-wave kernel takes
-    // whatever is left.
+    // whole workgroup.  ctl[0] blocks started, ctl[1] slots taken, ctl[2] queue head of the tail,
+    // ctl[3] blocks finished or suspended.
     int *coop_ctl;
     int32_t *coop_list;                 // [coop_max] series of each slot
     double *coop_slots;                 // [coop_max][coop_stride]
     int coop_max, coop_stride, coop_after, coop_blocks;
     int coop_tail_at;                   // tail rule: suspend once no more fits than this are still running (tsf_api.hip)
-    int coop_live, live_blocks, live_after;
-    hipStream_t live_stream;            // (host side only: the live instance's stream and the two events that tie it to the call's stream)
-    hipEvent_t live_ev0, live_ev1;
     // quadratic-form fit (tsf_quad_kernels.h): the residual passes read the caller's y rows (series n at y_raw[y_T * n + i], or
     // at y_offsets[n] + i) and scale them in the register; yw is then not written at all (null)
     const void *y_raw;
@@ -880,13 +871,6 @@ __device__ __forceinline__ bool coop_should_suspend(const FitArgs &a, int n_eval
 {
     if (a.coop_after >= 0) return n_eval >= a.coop_after;
     if ((n_eval & 3) != 0) return false;
-    if (a.live_blocks > 0 && n_eval >= a.live_after && (n_eval & 31) == 0) {
-        // a long fit while the launch is still full: over to a live workgroup if one of them is free
-        const int taken = __hip_atomic_load(&a.coop_ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int fin = __hip_atomic_load(&a.coop_ctl[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int live = __hip_atomic_load(&a.coop_ctl[7], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (taken - fin < live) return true;
-    }
     const int started = __hip_atomic_load(&a.coop_ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (started < (int)a.N) return false;
     const int done = __hip_atomic_load(&a.coop_ctl[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1301,6 +1285,7 @@ __global__ __launch_bounds__(64, HARM != 0 ? ((SPARSE || PF) ? TSF_HARM_SPARSE_W
             cv.nits = nits; cv.lsRestarts = lsRestarts; cv.zoom = zoom; cv.zit = zit;
             cv.gp_valid = gp_valid ? 1 : 0; cv.pk1_scaled = pk1_scaled ? 1 : 0; cv.n_eval = sv.n_eval; cv.pad_ = 0;
             *reinterpret_cast<CoopVars *>(slot) = cv;
+            a.coop_list[coop_ticket] = (int32_t)n;
         }
         if (lane < MAXH) slot[COOP_VARS_D + lane] = lds.rho[lane];
         coop_put_vec<PPL>(slot, 0, xk); coop_put_vec<PPL>(slot, 1, gk); coop_put_vec<PPL>(slot, 2, pk);
@@ -1312,9 +1297,6 @@ __global__ __launch_bounds__(64, HARM != 0 ? ((SPARSE || PF) ? TSF_HARM_SPARSE_W
             for (int s = 0; s < PPL; ++s) { hs_[s] = lds.SY[((2 * h) * PPL + s) * W + lane]; hy_[s] = lds.SY[((2 * h + 1) * PPL + s) * W + lane]; }
             coop_put_vec<PPL>(slot, 6 + h, hs_); coop_put_vec<PPL>(slot, 6 + MAXH + h, hy_);
         }
-        // published last, behind everything the wave wrote (a live workgroup may be waiting for exactly this slot)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        if (lane == 0) __hip_atomic_store(&a.coop_list[coop_ticket], (int32_t)n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
     store_theta<PPL>(a, sv, n, xk, a.theta);
