@@ -486,8 +486,9 @@ def boundary_legs():
 def cfg5_legs(dev, local):
     """BASELINE config 5 (1 000 000 series x 90 points, fp32 y, weekly seasonality only: the retail-SKU shape) in the
     driver-run line (round-5 review): under L-BFGS at full size, and under the optimiser fbprophet itself takes below
-    100 rows (Stan's Newton: `'Newton' if T < 100`) on the first 100 000 series -- a SAMPLE, labelled so, with
-    the 1 000 000-series figure measured in full by tools/bench_configs.py cfg5_newton_1m (profiles/)."""
+    100 rows (Stan's Newton: `'Newton' if T < 100`), at full size too since round 6 took that launch from 15 to
+    10.5 s (one timed step, no warm-up step of its own: the L-BFGS leg before it has warmed the context, and a 100 000-series
+    sample is not representative -- one series of the first 100 000 runs 605 000 evaluations and ends a short launch alone)."""
     import torch
     from time_series_spark_amd import _lib
     out = {}
@@ -498,7 +499,7 @@ def cfg5_legs(dev, local):
     dsd, futd = torch.from_numpy(ds5).to(dev), torch.from_numpy(fut_np).to(dev)
     for name, n, spec, steps in (
             ('cfg5', 1000000, fc.ModelSpec(growth='linear', seasonalities=seas), 2),
-            ('cfg5_newton', 100000, fc.ModelSpec(growth='linear', seasonalities=seas, algorithm=_lib.ALGO_NEWTON), 1)):
+            ('cfg5_newton', 1000000, fc.ModelSpec(growth='linear', seasonalities=seas, algorithm=_lib.ALGO_NEWTON), 1)):
         try:
             yd = torch.from_numpy(np.ascontiguousarray(y5[:n])).to(dev)
             f = DeviceForecaster(spec, local)
@@ -508,7 +509,8 @@ def cfg5_legs(dev, local):
             def step():
                 f.fit_aligned(dsd, yd, o)
                 f.predict(o, futd, yh, None)
-            step()
+            if name == 'cfg5':
+                step()
             torch.cuda.synchronize()
             f.set_profiling(True)
             t0 = time.perf_counter()
@@ -525,8 +527,7 @@ def cfg5_legs(dev, local):
             fk = float(np.mean(kms)) if kms else None
             out[name] = {'workload': ('BASELINE config 5: %d x 90, fp32 y, linear + weekly(3), ' % n) +
                                      ('Stan L-BFGS' if name == 'cfg5' else
-                                      "Stan's Newton = fbprophet's own choice below 100 rows; the FIRST 100 000 series of the "
-                                      '1 000 000-series panel (a sample: the full size takes ~15 s)'),
+                                      "Stan's Newton = fbprophet's own choice below 100 rows; one timed step, no warm-up step"),
                          'series': n, 'series_per_s': n / dt_, 'ms_per_step': 1e3 * dt_, 'fit_kernel_ms': fk,
                          'mean_evals': float(ne.mean()), 'max_evals': int(ne.max()), 'fitted': int((st > 0).sum()),
                          'status_counts': {str(int(k)): int(v) for k, v in zip(*np.unique(st, return_counts=True))},
