@@ -420,6 +420,7 @@ def other_baseline_configs(dev, local):
                      extra=[{'name': n} for n in names]), ds4, y4, y4.max(axis=1) * 1.1, ex4, exf4, 1)
     try:
         out['irregular_reference_model'] = irregular_leg(ref)
+        out['lattice_reference_model'] = irregular_leg(ref, lattice=True)
     except Exception as e:
         out['irregular_reference_model'] = {'error': str(e)}
     return out
@@ -559,8 +560,11 @@ def ranks_seen(dev, local):
     return {'world_size': world, 'backend': backend, 'ranks': allr, 'distinct_gpus': len(ids)}
 
 
-def irregular_leg(spec, N=10000):
-    """The reference's own call (prophet_modeler.py:65: logistic growth, multiplicative seasonality) on the reference's
+def irregular_leg(spec, N=10000, lattice=False):
+    """lattice = True (round 6): the fixture's shape taken literally -- every series at its OWN subset of the slots of one time
+    lattice (the fixture: Thu-Sun at 11:15 and 21:45; here 600..730 of 730 days, tools/bench_irregular.py's third panel): a
+    row is 22 bytes (t, y, segment word, lattice point), the base pairs are the lattice points' from one shared table.
+    lattice = False: the reference's own call (prophet_modeler.py:65: logistic growth, multiplicative seasonality) on the reference's
     own DATA SHAPE (its fixture: every (series_id, dim_id) at its own irregular timestamps): N series of 600..730 rows,
     no two sharing a timestamp vector, none on a lattice (tools/bench_irregular.py's panel).  Host-pointer ragged entry
     point; fit-path kernel time from the library's events.  Algorithmic bytes as SURVEY 8d defines them (ds + y in,
@@ -568,13 +572,18 @@ def irregular_leg(spec, N=10000):
     import ctypes
     from time_series_spark_amd import _lib
     T = 730
-    rng = np.random.default_rng(11)
+    rng = np.random.default_rng(12 if lattice else 11)
     lens = rng.integers(600, T + 1, N)
     off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     ds, y = synth.make_panel(N, T, 'logistic', seed=751)
-    dsr = np.concatenate([ds[:c] + rng.integers(-6 * 3600, 6 * 3600, c) * 1_000_000_000 for c in lens])
-    yr = np.concatenate([y[i][:c] for i, c in enumerate(lens)])
-    cap = np.array([y[i][:c].max() * 1.1 for i, c in enumerate(lens)])
+    if lattice:
+        keep = [np.sort(rng.choice(T, size=c, replace=False)) for c in lens]
+        dsr = np.concatenate([ds[k] for k in keep])
+    else:
+        keep = [np.arange(c) for c in lens]
+        dsr = np.concatenate([ds[:c] + rng.integers(-6 * 3600, 6 * 3600, c) * 1_000_000_000 for c in lens])
+    yr = np.concatenate([y[i][k] for i, k in enumerate(keep)])
+    cap = np.array([y[i][k].max() * 1.1 for i, k in enumerate(keep)])
     ctx = fc.get_context()
     L = _lib.load()
     ms = ctypes.c_float(0.0)
@@ -588,22 +597,27 @@ def irregular_leg(spec, N=10000):
     k = min(kms) * 1e-3
     P = 3 + spec.n_changepoints + spec.K
     alg = float(np.sum(lens * 16 + P * 8))
-    row_bytes = float(np.sum(np.ceil(lens / 64) * 64 * (2 * 2 * 8 + 8 + 8 + 2) * r.n_eval))
-    res = {'workload': '%d series of 600..730 rows, each at its own irregular timestamps (the shape of the reference\'s fixture), '
-                       'logistic growth + multiplicative yearly(10) + weekly(3): prophet_modeler.py:65' % N,
+    row_bytes = float(np.sum(np.ceil(lens / 64) * 64 * ((4 if lattice else 2 * 2 * 8) + 8 + 8 + 2) * r.n_eval))
+    res = {'workload': ('%d series at their own 600..730 of the 730 slots of one daily lattice (the reference\'s fixture: own subsets of '
+                        'fixed time slots), ' if lattice else
+                        '%d series of 600..730 rows, each at its own irregular timestamps on NO lattice (the fixture\'s shape with a '
+                        'jitter of seconds: the worst case), ') % N +
+                       'logistic growth + multiplicative yearly(10) + weekly(3): prophet_modeler.py:65',
            'series': N, 'rows': int(lens.sum()), 'fit_kernel_ms': kms, 'series_per_s_kernel': N / k,
            'mean_evals': float(r.n_eval.mean()), 'max_evals': int(r.n_eval.max()),
            'evaluations_per_s': float(r.n_eval.sum()) / k, 'fitted': int((r.status > 0).sum()),
            'status_counts': {str(int(a)): int(b) for a, b in zip(*np.unique(r.status, return_counts=True))},
            'algorithmic_bytes': alg, 'algorithmic_GBps': alg / k / 1e9, 'roofline_frac_of_8TBps': alg / k / 1e9 / HBM_PEAK_GBPS,
            'bytes_read_by_the_evaluations': row_bytes, 'bytes_read_by_the_evaluations_over_algorithmic': row_bytes / alg,
-           'kernel': 'fit_kernel<28, logistic, multiplicative, HARM yearly 10 + weekly 3> (base pairs per row, harmonics in '
-                     'registers) + cooperative tail'}
+           'kernel': ('fit_kernel<28, logistic, multiplicative, lattice, HARM yearly 10 + weekly 3> (rows of 22 bytes, base pairs of '
+                      'the lattice points from one shared table, harmonics in registers) + cooperative tail') if lattice else
+                     ('fit_kernel<28, logistic, multiplicative, HARM yearly 10 + weekly 3> (base pairs per row, harmonics in '
+                      'registers) + cooperative tail')}
     try:
         with open(os.path.join(ROOT, 'profiles', 'irregular_pmc_latest.json')) as fh:
             d = json.load(fh)
         if d.get('kernel_sources_sha16') == kernel_sources_digest():
-            res['traffic'] = 2.0 * d['fit_kernel_FETCH_SIZE_KiB'] * 1024.0
+            res['traffic'] = 2.0 * d['lattice_fit_kernel_FETCH_SIZE_KiB' if lattice else 'fit_kernel_FETCH_SIZE_KiB'] * 1024.0
             res['traffic_over_algorithmic'] = res['traffic'] / alg
             res['traffic_source'] = d.get('source')
         else:

@@ -597,6 +597,54 @@ def test_base_pair_kernel_with_row_prefetch_changes_no_bit(env):
         assert n_bit_diff(r.theta[n][:len(o['theta'])], o['theta']) == 0 and n_bit_diff(r.fval[n], o['f']) == 0, n
 
 
+def test_lattice_panels_read_the_base_pairs_of_their_lattice_points(env):
+    """Round 6: series observed at their OWN subsets of the slots of one time lattice (the reference's fixture: Thu-Sun at
+    11:15 and 21:45) keep rows of 22 bytes -- t, y, segment word, lattice point -- and every model with a compiled expansion
+    takes the points' base pairs from ONE table all series share (fit_kernel<..., XIDX, ..., HARM, PF>, cooperative tail
+    likewise) instead of a base-pair table per series (option lattice = 0) or gathered design rows (harm = 0).  Same
+    operations on the same values: identical bits on all three routes, whichever kernel finishes a fit, and the oracle's."""
+    fc, cl = env
+    from time_series_spark_amd import _lib, synth
+    rng = np.random.default_rng(81)
+    day = synth.DAY_NS
+    cases = [
+        # (slots of the lattice, seasonalities, growth, mode)
+        (synth.daily_grid(800), [helpers.YEARLY, helpers.WEEKLY], 'logistic', 'multiplicative'),
+        (synth.daily_grid(800), [helpers.YEARLY, helpers.WEEKLY], 'linear', 'additive'),
+        # two slots a day, as the fixture has them: weekly + daily, the model fbprophet picks for it
+        (np.sort(np.concatenate([synth.daily_grid(400) + (11 * 3600 + 900) * 10 ** 9, synth.daily_grid(400) + (21 * 3600 + 2700) * 10 ** 9])),
+         [helpers.WEEKLY, {'name': 'daily', 'period': 1, 'fourier_order': 4}], 'logistic', 'multiplicative'),
+        (synth.daily_grid(300), [helpers.WEEKLY], 'linear', 'multiplicative'),
+    ]
+    for ci, (slots, seas, growth, mode) in enumerate(cases):
+        N, Tm = 24, len(slots)
+        _, ym = synth.make_panel(N, Tm, growth, seed=40 + ci)
+        keep = [np.sort(rng.choice(Tm, size=int(rng.integers(Tm - 200, Tm - 40)), replace=False)) for _ in range(N)]
+        off = np.concatenate([[0], np.cumsum([len(k) for k in keep])]).astype(np.int64)
+        dsr = np.concatenate([slots[k] for k in keep])
+        yr = np.concatenate([ym[i][k] for i, k in enumerate(keep)])
+        cap = np.array([ym[i][k].max() * 1.1 for i, k in enumerate(keep)])
+        kw = dict(floor=np.zeros(N), cap=cap) if growth == 'logistic' else {}
+        base = dict(growth=growth, seasonality_mode=mode, seasonalities=seas, eval_form=_lib.EVAL_RESIDUAL)
+        res = {}
+        for tag, opts, extra in (('points', dict(), {}), ('tables', dict(lattice=0), {}), ('rows', dict(lattice=1, harm=0), {}),
+                                 ('points, tail after 25', dict(), dict(coop_after=25)),
+                                 ('points, workgroup kernel', dict(), dict(residual_kernel=_lib.RK_COOP))):
+            with fc.get_context().options(**opts):
+                res[tag] = fc.fit_ragged(fc.ModelSpec(**dict(base, **extra)), off, dsr, yr, **kw)
+        for tag in res:
+            for name in ('theta', 'fval', 'n_iter', 'n_eval', 'status', 'y_scale'):
+                assert np.array_equal(getattr(res['points'], name), getattr(res[tag], name), equal_nan=True), (ci, tag, name)
+        r = res['points']
+        assert (r.status > 0).sum() >= N - 2, ci
+        csp = helpers.oracle_spec(fc.ModelSpec(**base))
+        for n in (0, 11, N - 1):
+            sl = slice(off[n], off[n + 1])
+            o = cl.fit(csp, dsr[sl], yr[sl], 0.0, cap[n]) if growth == 'logistic' else cl.fit(csp, dsr[sl], yr[sl])
+            assert (r.n_iter[n], r.n_eval[n], r.status[n]) == (o['n_iter'], o['n_eval'], o['status']), (ci, n)
+            assert n_bit_diff(r.theta[n][:len(o['theta'])], o['theta']) == 0 and n_bit_diff(r.fval[n], o['f']) == 0, (ci, n)
+
+
 def _used_sparse_columns(fc):
     import ctypes
     from time_series_spark_amd import _lib

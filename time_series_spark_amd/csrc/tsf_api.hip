@@ -299,7 +299,8 @@ static WsLayout ws_layout(int64_t N, int64_t n_grids, int NTmax, int KP, int qua
     l.spm = off; off = align_up(off + (sparse ? sizeof(uint32_t) * (size_t)n_grids * SP_M * W : 0));
     l.spp = off; off = align_up(off + (sparse ? sizeof(unsigned long long) * (size_t)n_grids * SP_MAXC : 0));
     // base pairs of the Fourier columns (fit_kernel<..., HARM>): two doubles per seasonality and row
-    l.Bw = off; off = align_up(off + sizeof(double) * (size_t)n_grids * NTmax * bw_ns * 2 * W);
+    // (a panel on a timestamp lattice: per lattice POINT, one table for every series -- FitArgs::Bu)
+    l.Bw = off; off = align_up(off + sizeof(double) * (lat_U > 0 ? (size_t)lat_U * bw_ns * 2 : (size_t)n_grids * NTmax * bw_ns * 2 * W));
     l.uw = off; off = align_up(off + (lat_U > 0 ? sizeof(int32_t) * (size_t)n_grids * NTmax * W : 0));
     l.Xu = off; off = align_up(off + (lat_U > 0 ? sizeof(double) * (size_t)lat_U * KP : 0));
     const bool mf = mp && mp->on;
@@ -479,12 +480,18 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
         // now + its own cached workspace; the tables are ~4/5 of the layout): several contexts or ranks on one GPU, or
         // a smaller part, keep the shared lattice table -- the route that needs no table per series -- instead of
         // failing in ensure_ws (round-5 advice).
+        // Round 6: the base-pair kernels read a lattice panel too (rows of 22 bytes + the lattice POINTS' pairs from one
+        // shared table, FitArgs::Bu: as fast or faster than a table per series -- 10 000 / 2 000 series at their own subsets
+        // of a daily lattice: 75.9 -> 74.5 / 31.1 -> 27.0 ms -- for 0.44 of the traffic and none of the 2 GB of tables), so
+        // such a model keeps the lattice; only its MAP continuation (whose evaluator has no lattice form) still asks for
+        // tables per series.
         const int el = ctx->opt[TSF_OPT_LATTICE];
         const size_t tab = sizeof(double) * (size_t)n_grids * (size_t)NTmax * hs.KP * W;
         const bool harm_model = ctx->opt[TSF_OPT_HARM] != 0 && mode != 2 &&
                                 ((hs.harm == HARM_Y10_W3 && hs.KP == 28) || (hs.harm == HARM_W3_D4 && hs.KP == 16) || (hs.harm == HARM_W3 && hs.KP == 8));
+        const bool lat_harm = harm_model && hs.K == harm_kf(hs.harm) && spec->converge != TSF_CONVERGE_MAP;
         size_t harm_cap = (size_t)32 << 30;
-        if (lat_U > 0 && el < 0 && harm_model && tab > ((size_t)256 << 20)) {
+        if (lat_U > 0 && el < 0 && harm_model && !lat_harm && tab > ((size_t)256 << 20)) {
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
                 const size_t mine = (free_b + ctx->ws_bytes) / 5 * 2;
@@ -493,7 +500,7 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
                 (void)hipGetLastError();
             }
         }
-        if (el >= 0 ? el == 0 : ((grid_of != nullptr && tab <= ((size_t)64 << 20)) || (harm_model && tab <= harm_cap))) lat_U = 0;
+        if (el >= 0 ? el == 0 : ((grid_of != nullptr && tab <= ((size_t)64 << 20)) || (harm_model && !lat_harm && tab <= harm_cap))) lat_U = 0;
     }
     // matrix-core residual kernel (tsf_mfma_kernels.h): aligned panel, L-BFGS, one parameter per lane
     // (KP <= 28 implies one column mode and P <= 64), at most MT_SP changepoints, and an upper bound
@@ -569,11 +576,17 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     // whose harmonic structure has a compiled kernel -- yearly 10 + weekly 3 on the 28-column kernel and its
     // sparse-column form, weekly 3 + daily 4 (16 columns), weekly 3 (8 columns); never with the lattice table or the
     // matrix-core / workgroup-from-the-start routes.  tsf_set_option(TSF_OPT_HARM, 0): never.
+    // Round 6: WITH the lattice table where the model is exactly one of those (nothing behind the Fourier block): a row keeps t, y, its segment word and its lattice point (22 bytes instead of 50) and the base pairs
+    // are the point's, from one table of 32 bytes per point that every series shares (FitArgs::Bu) -- no table per series.
     int harm = 0;
     if (!quad && !newton && !mp.on && theta_in == nullptr && lat_U == 0 && ctx->opt[TSF_OPT_HARM] != 0) {
         if ((hs.harm == HARM_Y10_W3 && (hs.KP == 28 || sparse_try)) || (hs.harm == HARM_W3_D4 && hs.KP == 16) ||
             (hs.harm == HARM_W3 && hs.KP == 8))
             harm = hs.harm;
+    } else if (!quad && !newton && !mp.on && theta_in == nullptr && lat_U > 0 && ctx->opt[TSF_OPT_HARM] != 0 && mode != 2 &&
+               hs.K == harm_kf(hs.harm) &&
+               ((hs.harm == HARM_Y10_W3 && hs.KP == 28) || (hs.harm == HARM_W3_D4 && hs.KP == 16) || (hs.harm == HARM_W3 && hs.KP == 8))) {
+        harm = hs.harm;
     }
     // The same base pairs for the Gram build of a ragged quadratic-form panel whose series have a calendar each (the M-in-
     // registers kernel builds Z^T Z per series: gram_columns_harm, tsf_quad_kernels.h); shared calendars build once per
@@ -608,9 +621,11 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     if (lat_U > 0) {
         double *Xu = (double *)(ws + l.Xu);
         HIP_TRY(ctx, hipMemsetAsync(Xu, 0, sizeof(double) * (size_t)lat_U * hs.KP, st));
+        // (rows a lane's chunk does not have point at lattice point 0: the base-pair kernels gather before they mask)
+        HIP_TRY(ctx, hipMemsetAsync(ws + l.uw, 0, sizeof(int32_t) * (size_t)n_grids * NTmax * W, st));
         const int64_t work = lat_U * (hs.n_seas > 0 ? hs.n_seas : 1);
         hipLaunchKernelGGL(setup_lattice_kernel, dim3((unsigned)((work + 255) / 256 > 65535 ? 65535 : (work + 255) / 256)),
-                           dim3(256), 0, st, ctx->d_spec, lat_U, lat_base, lat_step, Xu);
+                           dim3(256), 0, st, ctx->d_spec, lat_U, lat_base, lat_step, Xu, bw_ns ? (double *)(ws + l.Bw) : (double *)nullptr);
         HIP_TRY(ctx, hipGetLastError());
     } else {
         HIP_TRY(ctx, hipMemsetAsync(Xw, 0, sizeof(double) * (size_t)n_grids * NTmax * hs.KP * W, st));
@@ -623,7 +638,7 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
                        (int)n_grids, aligned ? nullptr : offsets, T, ds, extra,
                        aligned ? (int64_t)T : total_rows, NTmax, gtab, tw, cw, Xw,
                        (int32_t *)(ws + l.uw), lat_base, lat_U > 0 ? lat_step : (int64_t)0, grid_rows,
-                       bw_ns ? (double *)(ws + l.Bw) : (double *)nullptr);
+                       (bw_ns && lat_U == 0) ? (double *)(ws + l.Bw) : (double *)nullptr);
     HIP_TRY(ctx, hipGetLastError());
     if (sparse_try) {
         int *sp_bad = (int *)(ws + l.counter) + 8;
@@ -658,7 +673,8 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     if (raw_y) { a.y_raw = y; a.y_raw_dtype = y_dtype; a.y_offsets = aligned ? nullptr : offsets; a.y_T = T; }
     a.uw = (const int32_t *)(ws + l.uw); a.Xu = (const double *)(ws + l.Xu); a.xidx = lat_U > 0 ? 1 : 0;
     a.grid_of = grid_of;
-    a.Bw = bw_ns ? (const double *)(ws + l.Bw) : nullptr; a.bw_ns = bw_ns; a.harm = harm;
+    a.Bw = (bw_ns && lat_U == 0) ? (const double *)(ws + l.Bw) : nullptr; a.bw_ns = bw_ns; a.harm = harm;
+    a.Bu = (bw_ns && lat_U > 0) ? (const double *)(ws + l.Bw) : nullptr;
     a.coop_harm = (harm != 0 && hs.K == harm_kf(harm) && mode != 2) ? 1 : 0;
     {
         // rows of the one-wave base-pair kernel from HBM?  (tables per grid: segment words, t, base pairs; y per series)
@@ -666,6 +682,7 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
                                 (size_t)N * NTmax * W * sizeof(double);
         const int oh = ctx->opt[TSF_OPT_HARM];
         a.harm_pf = (harm != 0 && (oh == 2 || (oh != 1 && !aligned && row_tabs > ((size_t)256 << 20)))) ? 1 : 0;
+        if (harm != 0 && lat_U > 0) a.harm_pf = 1;         // (the lattice form exists with the row prefetch only)
     }
     a.opt_coop_sparse = ctx->opt[TSF_OPT_SPARSE_EXTRA] != 2 ? 1 : 0;     // (2: the sparse fit kernel with the 64-column tail, for A/B runs)
     ctx->last_sp_flag = nullptr;

@@ -213,8 +213,9 @@ __global__ void setup_grid_kernel(const DevSpec *__restrict__ sp, int n_grids,
 // Design rows of a timestamp lattice base + u*step, u < U: Xu[u][KP] in internal column order,
 // same arithmetic as setup_grid_kernel (explicit columns are not functions of the timestamp:
 // lattice tables are only used when the model has none).  Xu must be zero-filled by the caller.
+// Bu (where given): the base pairs alone, [u][seasonality][2] (FitArgs::Bu).
 __global__ void setup_lattice_kernel(const DevSpec *__restrict__ sp, int64_t U, int64_t lat_base,
-                                     int64_t lat_step, double *__restrict__ Xu)
+                                     int64_t lat_step, double *__restrict__ Xu, double *__restrict__ Bu)
 {
     const int n_seas = sp->n_seas, KP = sp->KP;
     const int64_t total = U * n_seas;
@@ -225,6 +226,7 @@ __global__ void setup_lattice_kernel(const DevSpec *__restrict__ sp, int64_t U, 
         const int64_t ts = lat_base + u * lat_step;
         double s1, c1;
         dm_sincos(fourier_base_arg(ts, sp->seas_period[se]), s1, c1);
+        if (Bu) { Bu[((size_t)u * n_seas + se) * 2] = s1; Bu[((size_t)u * n_seas + se) * 2 + 1] = c1; }
         const int col0 = sp->seas_col[se];
         fourier_harmonics(s1, c1, sp->seas_order[se], [&](int h, double sv, double cv) {
             Xu[(size_t)u * KP + sp->inv_perm[col0 + 2 * (h - 1)]] = sv;

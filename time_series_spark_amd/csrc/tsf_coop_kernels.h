@@ -444,7 +444,8 @@ __device__ __forceinline__ void coop_helper_pf(const DevSpec *__restrict__ sp, c
     using SH = CoopShape<KP, NW, NTB, HARM>;
     constexpr int NRW = NW - 2, RPW = SH::RPW, XB = SH::XB, NXB = SH::NXB, CB = SH::CB, NCB = SH::NCB, NCW = SH::NCW;
     constexpr bool RES = SH::RES;
-    static_assert(HARM == 0 || (RES && MODE != 2 && !XIDX && NXB == 1), "base-pair rows: resident mode, one column mode, own tables");
+    static_assert(HARM == 0 || (RES && MODE != 2 && NXB == 1), "base-pair rows: resident mode, one column mode");
+    static_assert(!(HARM != 0 && XIDX) || !SPARSE, "base pairs of a timestamp lattice: no sparse columns");
     // base-pair rows, 28 columns: two of the wave's four columns live in LDS (behind the owner's columns in xl) instead of
     // registers -- with all four in registers the per-series constants of the rows were reloaded from scratch in every
     // evaluation (22 scratch reads per evaluation of a row wave)
@@ -536,9 +537,11 @@ __device__ __forceinline__ void coop_helper_pf(const DevSpec *__restrict__ sp, c
 #pragma unroll
         for (int i = 0; i < RPW; ++i) {
             // (a row the lane's chunk does not have: whatever Bw holds there -- its r, r g, v are replaced by zeros below)
-            const double2 *bq = reinterpret_cast<const double2 *>(sv.Bw) + (size_t)qrow[i] * HNS * W + lane;
+            // (XIDX: the pairs of the row's lattice point, FitArgs::Bu; point 0 where the chunk has no such row)
+            const double2 *bq = XIDX ? reinterpret_cast<const double2 *>(sv.Bu) + (size_t)(valid[i] ? sv.uw[idx[i]] : 0) * HNS
+                                     : reinterpret_cast<const double2 *>(sv.Bw) + (size_t)qrow[i] * HNS * W + lane;
 #pragma unroll
-            for (int se = 0; se < HNS; ++se) bpr[i][se] = bq[se * W];
+            for (int se = 0; se < HNS; ++se) bpr[i][se] = bq[se * (XIDX ? 1 : W)];
         }
     }
     // SPARSE: the dense columns between the Fourier block and the sparse ones (two of them), and where the lane's entry
@@ -1067,7 +1070,8 @@ __device__ __forceinline__ void coop_owner(const FitArgs &a, SeriesView &sv, int
                 const int qc = q < sv.NT ? q : 0;
 #pragma unroll
                 for (int c = 0; c < OWN_L; ++c)
-                    xl[(q * OWN_L + c) * W + lane] = (q < sv.NT) ? (sv.Xw + ((size_t)qc * XC + (KP - OWN_L + c)) * W)[lane] : 0.0;
+                    xl[(q * OWN_L + c) * W + lane] = XIDX ? ((q < sv.NT && qc < sv.cnt) ? sv.Xu[(size_t)sv.uw[qc * W + lane] * KP + (KP - OWN_L + c)] : 0.0)
+                                                          : ((q < sv.NT) ? (sv.Xw + ((size_t)qc * XC + (KP - OWN_L + c)) * W)[lane] : 0.0);
             }
             TSF_WAVE_SYNC();
             xol = xl;

@@ -27,6 +27,7 @@ struct SeriesView {
     int n_xd;                           // (HARM kernels) dense explicit columns behind the Fourier columns (read from Xw)
     const int32_t *uw;                  // (lattice panels) row -> row of the shared table Xu, step-major
     const double *Xu;                   // (lattice panels) [U][KP] design rows of the timestamp lattice
+    const double *Bu;                   // (lattice panels, HARM kernels) [U][seasonality][2] base pairs of the lattice points
     const uint16_t *cw;
     const int32_t *Lj;
     const double *t_change;
@@ -433,7 +434,8 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
 #endif
     constexpr bool HOLD = KP <= TSF_FIT_HOLD_MAX;
     static_assert(!SPARSE || (KP == SP_DENSE && HOLD && !XIDX && GNTR == 0 && MODE != 2), "sparse columns: the 28-column row in registers, one column mode");
-    static_assert(HARM == 0 || (HOLD && !XIDX && GNTR == 0 && MODE != 2 && harm_kf(HARM) <= KP), "harmonics in registers: the 28-column row form, one column mode");
+    static_assert(HARM == 0 || (HOLD && GNTR == 0 && MODE != 2 && harm_kf(HARM) <= KP), "harmonics in registers: the 28-column row form, one column mode");
+    static_assert(!(HARM != 0 && XIDX) || !SPARSE, "base pairs of a timestamp lattice: no sparse columns (and no dense column behind the Fourier block: sv.n_xd == 0, by the launch rule)");
     constexpr int KF = harm_kf(HARM), NS = harm_ns(HARM) > 0 ? harm_ns(HARM) : 1;
     constexpr int NXD = HARM != 0 ? KP - KF : 0;            // dense explicit columns at most
     constexpr int XCOLS = SPARSE ? 64 : KP;     // columns per row of the design table
@@ -480,19 +482,25 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
     // that latency: 107 -> 97 ms on the irregular bench panel; an aligned panel (tables in L2) is better off with three
     // waves and no prefetch (0.60 against 0.64 s on 100 000 x 730): the launcher picks (FitArgs::harm_pf).
     constexpr bool PREF = HARM != 0 && !SPARSE && PF;
-    struct RowIn { unsigned cwv; double ti, yi; double2 bp[NS]; };
-    auto row_fetch = [&](int q, RowIn &ri) {
+    // XIDX with HARM (round 6): the rows of a panel on a timestamp lattice keep t, y, the segment word and the lattice point
+    // (22 bytes); the base pairs are the lattice point's, gathered from a table every series shares (FitArgs::Bu: 32 bytes
+    // per point, cache-resident).  The point of row q - 1 is requested with row q, so the gather never waits for its index.
+    constexpr int BS = XIDX ? 1 : W;            // stride between the seasonalities of a row's base pairs
+    struct RowIn { unsigned cwv; int un; double ti, yi; double2 bp[NS]; };
+    auto row_fetch = [&](int q, int u, RowIn &ri) {
         const int idx = q * W + lane;
         ri.cwv = (unsigned)sv.cw[idx]; ri.ti = sv.tw[idx]; ri.yi = sv.yw[idx];
-        const double2 *bq = reinterpret_cast<const double2 *>(sv.Bw) + (size_t)q * NS * W + lane;
+        const double2 *bq = XIDX ? reinterpret_cast<const double2 *>(sv.Bu) + (size_t)u * NS
+                                 : reinterpret_cast<const double2 *>(sv.Bw) + (size_t)q * NS * W + lane;
 #pragma unroll
-        for (int se = 0; se < NS; ++se) ri.bp[se] = bq[se * W];
+        for (int se = 0; se < NS; ++se) ri.bp[se] = bq[se * BS];
+        ri.un = (XIDX && q > 0) ? sv.uw[idx - W] : 0;
     };
     RowIn rin;
-    if constexpr (PREF) { if (NT > 0) row_fetch(NT - 1, rin); }
+    if constexpr (PREF) { if (NT > 0) row_fetch(NT - 1, XIDX ? sv.uw[(NT - 1) * W + lane] : 0, rin); }
     for (int q = NT - 1; q >= 0; --q) {
         RowIn rcur;
-        if constexpr (PREF) { rcur = rin; if (q > 0) row_fetch(q - 1, rin); }     // (two steps ahead: measured, no better)
+        if constexpr (PREF) { rcur = rin; if (q > 0) row_fetch(q - 1, rcur.un, rin); }     // (two steps ahead: measured, no better)
         if (q < sv.cnt) {
             const int idx = q * W + lane;
             const unsigned cwv = PREF ? rcur.cwv : (unsigned)sv.cw[idx];
@@ -500,15 +508,16 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
             const double ti = PREF ? rcur.ti : sv.tw[idx];
             const double yi = PREF ? rcur.yi : sv.yw[idx];
             constexpr int XS = XIDX ? 1 : W;      // stride between the columns of a design row
-            const double *xp = XIDX ? sv.Xu + (size_t)sv.uw[idx] * KP : sv.Xw + (size_t)q * XCOLS * W + lane;
+            const double *xp = (XIDX && HARM != 0) ? nullptr : (XIDX ? sv.Xu + (size_t)sv.uw[idx] * KP : sv.Xw + (size_t)q * XCOLS * W + lane);
             double x[(HOLD && HARM == 0) ? KP : 1];
             double xa = 0.0, xm = 0.0;
             double2 bp[NS];
             double xd[NXD > 0 ? NXD : 1];
             if constexpr (HARM != 0) {
-                const double2 *bq = reinterpret_cast<const double2 *>(sv.Bw) + (size_t)q * NS * W + lane;
+                const double2 *bq = PREF ? nullptr : (XIDX ? reinterpret_cast<const double2 *>(sv.Bu) + (size_t)sv.uw[idx] * NS
+                                                           : reinterpret_cast<const double2 *>(sv.Bw) + (size_t)q * NS * W + lane);
 #pragma unroll
-                for (int se = 0; se < NS; ++se) bp[se] = PREF ? rcur.bp[se] : bq[se * W];
+                for (int se = 0; se < NS; ++se) bp[se] = PREF ? rcur.bp[se] : bq[se * BS];
                 double ch = 0.0;
                 harm_row<HARM>(bp, [&](int j, double v) { ch = __builtin_fma(v, bs[j], ch); });
                 if (NXD > 0 && sv.n_xd > 0) {
@@ -784,8 +793,9 @@ struct FitArgs {
     int coop_harm;                      // the cooperative kernel's rows from the base pairs too (harm != 0 and no dense column behind the Fourier block)
     int harm_pf;                        // HARM: the two-waves-per-SIMD kernel with the row prefetch (tables per series, read from HBM)
     int opt_coop_sparse;                // the sparse-column kernel's tail on the sparse cooperative kernel (TSF_OPT_SPARSE_EXTRA != 2 ... tests: off)
-    const int32_t *uw;                  // [grid][NTmax][64] lattice row of each series row
+    const int32_t *uw;                  // [grid][NTmax][64] lattice row of each series row (zero where a lane's chunk has no such row)
     const double *Xu;                   // [U][KP]
+    const double *Bu;                   // [U][bw_ns][2]: the lattice points' base pairs (fit_kernel<..., XIDX, ..., HARM>), or null
     int xidx;
     // launch guard: when run_flag is set the kernel runs only if (*run_flag != 0) == (run_if != 0)
     // (the one-wave kernel as the fallback of the matrix-core kernel, decided on the device)
@@ -892,6 +902,7 @@ __device__ __forceinline__ void make_view(const FitArgs &a, int64_t n, SeriesVie
     sv.Xw = a.Xw + (size_t)g * a.NTmax * KP * W;
     sv.uw = a.uw + (size_t)g * a.NTmax * W;
     sv.Xu = a.Xu;
+    sv.Bu = a.Bu;
     sv.Bw = a.Bw ? a.Bw + (size_t)g * a.NTmax * a.bw_ns * 2 * W : nullptr;
     sv.n_xd = 0;
     sv.yw = a.yw + (size_t)n * a.NTmax * W;

@@ -3,6 +3,9 @@
 gaps -- no two series share a timestamp vector, the timestamps lie on no lattice, so every series carries its own
 design table (172 KB for 26 columns) and the residual-form kernel streams it from HBM at every evaluation.
 Reference settings (logistic growth, multiplicative seasonality) and cfg2's model (quadratic form).
+Round 6, third line: the fixture's shape taken literally -- every series at its OWN subset of the slots of one time lattice
+(the fixture: Thu-Sun at 11:15 and 21:45; here 600..730 of 730 days) -- where a row is 22 bytes (t, y, segment word, lattice
+point) and the base pairs are the lattice points', from one table all series share.
     python tools/bench_irregular.py [N]"""
 import ctypes
 import json
@@ -55,3 +58,28 @@ for growth, mode in (('logistic', 'multiplicative'), ('linear', 'additive')):
                       'row_bytes_GBps': None if x_bytes is None else x_bytes / k / 1e9,
                       'algorithmic_bytes': alg, 'algorithmic_GBps': alg / k / 1e9,
                       'status_ok': int((r.status > 0).sum())}), flush=True)
+
+# the fixture's shape taken literally: own subsets of one lattice's slots (rows dropped at random from the daily grid)
+rng2 = np.random.default_rng(12)
+lens2 = rng2.integers(600, T + 1, N)
+off2 = np.concatenate([[0], np.cumsum(lens2)]).astype(np.int64)
+ds, y = synth.make_panel(N, T, 'logistic', seed=751)
+keep = [np.sort(rng2.choice(T, size=c, replace=False)) for c in lens2]
+dsr = np.concatenate([ds[k] for k in keep])
+yr = np.concatenate([y[i][k] for i, k in enumerate(keep)])
+cap = np.array([y[i][k].max() * 1.1 for i, k in enumerate(keep)])
+spec = fc.ModelSpec(growth='logistic', seasonality_mode='multiplicative', seasonalities=[YEARLY, WEEKLY])
+out = []
+for rep in range(3):
+    ctx.check(L.tsf_set_profiling(ctx.handle, 1))
+    r = fc.fit_ragged(spec, off2, dsr, yr, floor=np.zeros(N), cap=cap)
+    ctx.check(L.tsf_last_fit_kernel_ms(ctx.handle, ctypes.byref(ms)))
+    out.append(float(ms.value))
+k = min(out) * 1e-3
+alg = float(np.sum(lens2 * 16 + 54 * 8))
+x_bytes = float(np.sum(np.ceil(lens2 / 64) * 64 * (8 + 8 + 2 + 4) * r.n_eval))
+print(json.dumps({'panel': '%d series at their own 600..730 of the 730 slots of a daily lattice' % N, 'growth': 'logistic', 'mode': 'multiplicative',
+                  'fit_kernel_ms': out, 'series_per_s_kernel': N / k, 'mean_evals': float(r.n_eval.mean()), 'max_evals': int(r.n_eval.max()),
+                  'lattice_point_kernel': bool(ctx.get_option('harm') != 0 and ctx.get_option('lattice') != 0),
+                  'row_bytes_read_by_the_evaluations': x_bytes, 'row_bytes_GBps': x_bytes / k / 1e9,
+                  'algorithmic_bytes': alg, 'algorithmic_GBps': alg / k / 1e9, 'status_ok': int((r.status > 0).sum())}), flush=True)

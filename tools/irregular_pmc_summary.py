@@ -25,8 +25,13 @@ out = {'kernel_sources_sha16': bench.kernel_sources_digest(),
 for k, d in per.items():
     v = sorted(d.values())
     out['kernels'][k] = {'FETCH_SIZE_KiB_median': v[len(v) // 2], 'launches': len(v)}
-    if 'fit_kernel<' in k and 'fit_kernel_FETCH_SIZE_KiB' not in out:
+    # fit_kernel<KP, GROWTH, MODE, PPL, XIDX, GNTR, SPARSE, HARM, PF>: XIDX = true is the lattice panel's kernel (round 6)
+    targs = [t.strip() for t in k.split('<', 1)[1].rsplit('>', 1)[0].split(',')] if 'fit_kernel<' in k else []
+    if targs and targs[4] == 'false' and 'fit_kernel_FETCH_SIZE_KiB' not in out:
         out['fit_kernel_FETCH_SIZE_KiB'] = v[len(v) // 2]
         out['fit_kernel'] = k
+    if targs and targs[4] == 'true' and 'lattice_fit_kernel_FETCH_SIZE_KiB' not in out:
+        out['lattice_fit_kernel_FETCH_SIZE_KiB'] = v[len(v) // 2]
+        out['lattice_fit_kernel'] = k
 json.dump(out, open(dst, 'w'), indent=1)
 print(json.dumps({k: out[k] for k in out if k != 'kernels'}))
