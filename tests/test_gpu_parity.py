@@ -637,6 +637,15 @@ def test_lattice_panels_read_the_base_pairs_of_their_lattice_points(env):
                 assert np.array_equal(getattr(res['points'], name), getattr(res[tag], name), equal_nan=True), (ci, tag, name)
         r = res['points']
         assert (r.status > 0).sum() >= N - 2, ci
+        if ci in (0, 2):
+            # the MAP continuation reads the lattice points' pairs too (map_kernel<..., XIDX, HARM>)
+            mp = {}
+            for tag, opts in (('points', dict()), ('tables', dict(lattice=0))):
+                with fc.get_context().options(**opts):
+                    mp[tag] = fc.fit_ragged(fc.ModelSpec(**dict(base, converge=_lib.CONVERGE_MAP)), off, dsr, yr, **kw)
+            for name in ('theta', 'fval', 'n_eval', 'status'):
+                assert np.array_equal(getattr(mp['points'], name), getattr(mp['tables'], name), equal_nan=True), (ci, 'map', name)
+            assert (mp['points'].fval <= r.fval + 1e-9).all()
         csp = helpers.oracle_spec(fc.ModelSpec(**base))
         for n in (0, 11, N - 1):
             sl = slice(off[n], off[n + 1])

@@ -483,13 +483,12 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
         // Round 6: the base-pair kernels read a lattice panel too (rows of 22 bytes + the lattice POINTS' pairs from one
         // shared table, FitArgs::Bu: as fast or faster than a table per series -- 10 000 / 2 000 series at their own subsets
         // of a daily lattice: 75.9 -> 74.5 / 31.1 -> 27.0 ms -- for 0.44 of the traffic and none of the 2 GB of tables), so
-        // such a model keeps the lattice; only its MAP continuation (whose evaluator has no lattice form) still asks for
-        // tables per series.
+        // such a model keeps the lattice (its MAP continuation too).
         const int el = ctx->opt[TSF_OPT_LATTICE];
         const size_t tab = sizeof(double) * (size_t)n_grids * (size_t)NTmax * hs.KP * W;
         const bool harm_model = ctx->opt[TSF_OPT_HARM] != 0 && mode != 2 &&
                                 ((hs.harm == HARM_Y10_W3 && hs.KP == 28) || (hs.harm == HARM_W3_D4 && hs.KP == 16) || (hs.harm == HARM_W3 && hs.KP == 8));
-        const bool lat_harm = harm_model && hs.K == harm_kf(hs.harm) && spec->converge != TSF_CONVERGE_MAP;
+        const bool lat_harm = harm_model && hs.K == harm_kf(hs.harm);
         size_t harm_cap = (size_t)32 << 30;
         if (lat_U > 0 && el < 0 && harm_model && !lat_harm && tab > ((size_t)256 << 20)) {
             size_t free_b = 0, total_b = 0;
@@ -597,7 +596,7 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     // ... and for the MAP continuation (tsf_map_kernels.h): its evaluator reads base-pair rows wherever the model has a
     // compiled expansion, whatever kernel ran the Stan-rule fit (the quadratic-form route builds the table for it)
     int map_harm = 0;
-    if (spec->converge == TSF_CONVERGE_MAP && theta_in == nullptr && lat_U == 0 && mode != 2 && ctx->opt[TSF_OPT_HARM] != 0 &&
+    if (spec->converge == TSF_CONVERGE_MAP && theta_in == nullptr && mode != 2 && ctx->opt[TSF_OPT_HARM] != 0 &&
         hs.K == harm_kf(hs.harm) &&
         ((hs.harm == HARM_Y10_W3 && hs.KP == 28) || (hs.harm == HARM_W3_D4 && hs.KP == 16) || (hs.harm == HARM_W3 && hs.KP == 8)))
         map_harm = hs.harm;
@@ -787,7 +786,8 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     // (tsf_map_kernels.h), on the same stream behind whichever kernels ran the fit; inside the profiled interval
     if (lrc == 0 && spec->converge == TSF_CONVERGE_MAP && theta_in == nullptr) {
         a.map_max_iter = spec->map_max_iter; a.map_tol = spec->map_tol; a.map_harm = map_harm;
-        if (map_harm) a.Bw = (const double *)(ws + l.Bw);
+        if (map_harm && lat_U == 0) a.Bw = (const double *)(ws + l.Bw);
+        if (map_harm && lat_U > 0) a.Bu = (const double *)(ws + l.Bw);
         a.order = nullptr; a.run_flag = nullptr;
         lrc = pick_map_launch(hs.growth, mode)(hs.KP, a, st);
     }
