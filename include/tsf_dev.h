@@ -46,6 +46,8 @@ enum {
                                 kernel (count on stderr); bit 3 the default pool never releases memory */
     TSF_OPT_COOP_TAIL,       /* residual-form launches: the fits still running are handed to the cooperative kernel once no
                                 more of them are left than this many per hundred compute units (default 200) */
+    TSF_OPT_MAP_DIRECT,      /* 0: converge = MAP always as a continuation of the Stan-rule fit (map_kernel), also where the model is
+                                linear / additive on an aligned panel and the estimate can be computed directly (map_quad_kernel) */
     TSF_OPT_COUNT
 };
 int tsf_set_option(tsf_ctx *ctx, int option, int value);

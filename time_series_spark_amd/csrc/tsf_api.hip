@@ -698,6 +698,7 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     const int slot = (int)(ctx->ev_count % TSF_PROFILE_RING);
     if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev0[slot], st));
     int lrc;
+    bool map_done = false;
     if (newton_quad) {
         QuadArgs qa;
         memset(&qa, 0, sizeof(qa));
@@ -736,7 +737,15 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
         qa.Mpre = quad_pre ? qa.Mg : nullptr; qa.n_pre = quad_pre;
         qa.gram_harm = gram_harm;
         HIP_TRY(ctx, hipMemsetAsync(qa.counter, 0, sizeof(int), st));
-        lrc = launch_quad(hs.KP, qp, qa, (double *)(ws + l.Mg), st);
+        lrc = -1;
+        if (spec->converge == TSF_CONVERGE_MAP && aligned && qp.PPL == 1 && ctx->opt[TSF_OPT_MAP_DIRECT] != 0) {
+            // converge = MAP where the posterior is a quadratic form in everything but sigma: the estimate itself by
+            // alternating exact minimisations (tsf_map_quad.h) -- no L-BFGS trajectory, no continuation
+            qa.f.map_max_iter = spec->map_max_iter; qa.f.map_tol = spec->map_tol;
+            lrc = launch_map_quad(hs.KP, qp, qa, (double *)(ws + l.Mg), fit_P(hs.n_cp, hs.K) | 1, st);
+            if (lrc == 0) map_done = true;
+        }
+        if (lrc == -1) lrc = launch_quad(hs.KP, qp, qa, (double *)(ws + l.Mg), st);
     } else if (mp.on) {
         MfmaTabs mt;
         memset(&mt, 0, sizeof(mt));
@@ -784,7 +793,7 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
     }
     // converge = MAP: from where the optimiser's own tests stopped every fit on to the maximum a posteriori estimate
     // (tsf_map_kernels.h), on the same stream behind whichever kernels ran the fit; inside the profiled interval
-    if (lrc == 0 && spec->converge == TSF_CONVERGE_MAP && theta_in == nullptr) {
+    if (lrc == 0 && spec->converge == TSF_CONVERGE_MAP && theta_in == nullptr && !map_done) {
         a.map_max_iter = spec->map_max_iter; a.map_tol = spec->map_tol; a.map_harm = map_harm;
         if (map_harm && lat_U == 0) a.Bw = (const double *)(ws + l.Bw);
         if (map_harm && lat_U > 0) a.Bu = (const double *)(ws + l.Bw);

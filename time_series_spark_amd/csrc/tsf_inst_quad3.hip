@@ -5,6 +5,7 @@
 // literals of the exp / cubic-interpolation code into ~40 VGPRs for the whole kernel and then
 // spills them to scratch, reloading them in the middle of the dependent chains.
 #include "tsf_quad_launch.h"
+#include "tsf_map_quad.h"
 
 namespace tsf {
 
@@ -37,6 +38,32 @@ static int launch_eval_quad_one(const QuadPlan &qp, const QuadArgs &qa, double *
     int64_t blocks = qa.f.N < qp.slots ? qa.f.N : qp.slots;
     hipLaunchKernelGGL((eval_quad_kernel<KP, PQ, TSF_QUAD_NTR>), dim3((unsigned)blocks), dim3(64), lds, st, qa, theta_ref);
     return (int)hipGetLastError();
+}
+
+// converge = MAP on an aligned linear / additive panel: gram_build_kernel + map_quad_kernel (tsf_map_quad.h), one wave per
+// workgroup, at most qp.slots of them
+template <int KP>
+static int launch_map_quad_one(const QuadPlan &qp, const QuadArgs &qa, double *Mg, int PM, hipStream_t st)
+{
+    const size_t lds = map_quad_lds_bytes<KP>(PM);
+    if (lds > 160 * 1024) return -1;
+    hipLaunchKernelGGL((gram_build_kernel<KP, 1>), dim3((unsigned)qp.P4), dim3(64), 0, st, qa, Mg);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    hipFuncSetAttribute((const void *)map_quad_kernel<KP, TSF_QUAD_NTR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    int64_t blocks = qa.f.N < qp.slots ? qa.f.N : qp.slots;
+    hipLaunchKernelGGL((map_quad_kernel<KP, TSF_QUAD_NTR>), dim3((unsigned)blocks), dim3(64), lds, st, qa);
+    return (int)hipGetLastError();
+}
+
+int launch_map_quad(int KP, const QuadPlan &qp, const QuadArgs &qa, double *Mg, int PM, hipStream_t st)
+{
+    switch (KP) {
+    case 8: return launch_map_quad_one<8>(qp, qa, Mg, PM, st);
+    case 16: return launch_map_quad_one<16>(qp, qa, Mg, PM, st);
+    case 28: return launch_map_quad_one<28>(qp, qa, Mg, PM, st);
+    default: return -1;
+    }
 }
 
 int launch_eval_quad(int KP, const QuadPlan &qp, const QuadArgs &qa, double *Mg, const double *theta_ref, hipStream_t st)

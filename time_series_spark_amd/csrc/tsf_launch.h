@@ -14,6 +14,9 @@ int launch_quad(int KP, const QuadPlan &qp, const QuadArgs &qa, double *Mg, hipS
 int launch_quad_aligned1(int KP, const QuadPlan &qp, const QuadArgs &qa, double *Mg, hipStream_t st);
 // gram_build_kernel + eval_quad_kernel: one quadratic-form evaluation per series around theta_ref (tsf_eval_quadratic; tsf_inst_quad3.hip)
 int launch_eval_quad(int KP, const QuadPlan &qp, const QuadArgs &qa, double *Mg, const double *theta_ref, hipStream_t st);
+// gram_build_kernel + map_quad_kernel: converge = MAP of linear / additive models on aligned panels, directly (tsf_map_quad.h);
+// -1: this shape has no such kernel
+int launch_map_quad(int KP, const QuadPlan &qp, const QuadArgs &qa, double *Mg, int PM, hipStream_t st);
 int launch_quad_aligned_reg(int KP, const QuadPlan &qp, const QuadArgs &qa, double *Mg, hipStream_t st);   // -2: no such variant
 // gram_build_kernel + newton_quad_kernel (Stan's Newton, quadratic-form evaluations; tsf_inst_quad.hip)
 int launch_newton_quad(int KP, const QuadPlan &qp, const QuadArgs &qa, double *Mg, int PM, int n_cu, hipStream_t st);
