@@ -184,10 +184,13 @@ def parity_context(f, spec, ds, y, fut, yhat_quad, n=256):
 
 
 def map_mode_leg(f, spec, ds, y, fut, out_stan, yhat_stan, n_true=48):
-    """tsf_spec.converge = MAP on the headline panel (round 6): the fit carried on from where Stan's tests stop it to the
-    maximum a posteriori estimate (map_kernel), with its COST beside the Stan-rule step -- evaluations and milliseconds --
-    and, on the first n_true series, the distance of both fits' 90-day forecasts to an independent solver's optimum
-    (oracle/true_map.py through tools/true_map_solve.py, in processes of its own: CPU only)."""
+    """tsf_spec.converge = MAP on the headline panel (round 6): the maximum a posteriori estimate of the model instead of
+    the point Stan's tests stop at.  For this model (linear growth, additive seasonality, aligned panel) it is computed
+    DIRECTLY (map_quad_kernel: sigma in closed form and the L1-regularised quadratic programme by an active-set method, in
+    turn; a dozen Cholesky solves per series, no L-BFGS trajectory); `as_a_continuation` is the general route every other
+    model takes (map_kernel: the Stan-rule fit carried on by an orthant-wise L-BFGS), run here on the same panel.  With
+    their COST beside the Stan-rule step, and, on the first n_true series, the distance of the fits' 90-day forecasts to an
+    independent solver's optimum (oracle/true_map.py through tools/true_map_solve.py, in processes of its own: CPU only)."""
     import subprocess
     import tempfile
     import torch
@@ -201,22 +204,42 @@ def map_mode_leg(f, spec, ds, y, fut, out_stan, yhat_stan, n_true=48):
     def step():
         g.fit_aligned(ds, y, o)
         g.predict(o, fut, yh, None)
-    step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(2):
+    def timed(reps):
         step()
-    torch.cuda.synchronize()
-    dt_ = (time.perf_counter() - t0) / 2
-    ne, ne0 = o.n_eval.cpu().numpy().astype(np.int64), out_stan.n_eval.cpu().numpy().astype(np.int64)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+    ne0 = out_stan.n_eval.cpu().numpy().astype(np.int64)
+    cont = None
+    try:
+        g.ctx.set_option('map_direct', 0)
+        dtc = timed(1)
+        nec = o.n_eval.cpu().numpy().astype(np.int64)
+        stc = o.status.cpu().numpy()
+        cont = {'what': 'option map_direct = 0: the Stan-rule fit carried on to the estimate by map_kernel (the route of every model '
+                        'that is not linear / additive on an aligned panel)', 'ms_per_step': 1e3 * dtc, 'series_per_s': n / dtc,
+                'mean_evals': float(nec.mean()), 'max_evals': int(nec.max()),
+                'status_counts': {str(int(k)): int(v) for k, v in zip(*np.unique(stc, return_counts=True))}}
+        fval_c = o.fval.clone()
+    except Exception as e:
+        cont = {'error': str(e)}
+    g.ctx.set_option('map_direct', -1)
+    dt_ = timed(3)
+    ne = o.n_eval.cpu().numpy().astype(np.int64)
     st = o.status.cpu().numpy()
-    res = {'what': 'the same panel with tsf_spec.converge = MAP: Stan-rule fit + continuation to the maximum a posteriori '
-                   'estimate (orthant-wise active-set L-BFGS on the residual-form evaluator) + forecast; never `value`',
+    res = {'what': 'the same panel with tsf_spec.converge = MAP: the maximum a posteriori estimate computed directly '
+                   '(map_quad_kernel, tsf_map_quad.h) + forecast; never `value`',
            'ms_per_step': 1e3 * dt_, 'series_per_s': n / dt_,
-           'mean_evals_stan_rule': float(ne0.mean()), 'mean_evals_with_continuation': float(ne.mean()),
-           'max_evals_with_continuation': int(ne.max()),
+           'mean_evals_stan_rule': float(ne0.mean()), 'mean_rounds': float(o.n_iter.cpu().numpy().mean()),
+           'mean_cholesky_solves': float(ne.mean()) - 1.0, 'max_cholesky_solves': int(ne.max()) - 1,
            'status_counts': {str(int(k)): int(v) for k, v in zip(*np.unique(st, return_counts=True))},
-           'objective_gain_median': float(np.median((out_stan.fval - o.fval).cpu().numpy()))}
+           'objective_gain_median': float(np.median((out_stan.fval - o.fval).cpu().numpy())),
+           'as_a_continuation': cont}
+    if cont and 'error' not in cont:
+        cont['max_abs_objective_difference_to_direct'] = float(torch.max(torch.abs(fval_c - o.fval)).item())
     moved = (torch.abs(yh - yhat_stan) / torch.abs(yhat_stan)).median(dim=1).values.cpu().numpy()
     res['forecast_rel_change_vs_stan_rule'] = {'median': float(np.median(moved)), 'p90': float(np.quantile(moved, 0.9))}
     try:

@@ -15,7 +15,10 @@
 //     Cholesky solve (lane = row, the matrix in LDS); a step that would carry a delta through zero stops there and the
 //     delta joins the working set; when the free parameters are stationary, the held delta whose multiplier violates
 //     |g_j| <= wC the most is released into the orthant its gradient points to.
-// Alternated until the pseudo-gradient of the whole function (map_kernel's KKT residual) is below map_tol.  From
+// Alternated until the pseudo-gradient of the whole function (map_kernel's KKT residual) is below map_tol; the sequence of
+// w is a scalar fixed-point iteration, and every third round the quadratic programme is solved at its Aitken extrapolate
+// instead (short histories couple w and u through the L1 weight wC: 15 rounds on average for 90-row series without it,
+// 9 with it).  From
 // fbprophet's initial values that takes 4-6 rounds and 6-11 Cholesky solves per series, where Stan's L-BFGS spends ~450
 // evaluations to stop a median 1e-3 short of this point and map_kernel another ~340 to get there (prototype against
 // oracle/true_map.py: the parameters agree to 1e-8, the function value to its last digits).
@@ -27,7 +30,7 @@
 
 namespace tsf {
 
-constexpr int MQ_MAX_OUTER = 80, MQ_MAX_INNER = 800;
+constexpr int MQ_MAX_OUTER = 120, MQ_MAX_INNER = 800;
 
 __device__ __forceinline__ double mq_wave_max(double v)
 {
@@ -42,50 +45,92 @@ __device__ __forceinline__ double mq_wave_min(double v)
     return v;
 }
 
-// A x = rhs, A symmetric positive definite: A = L L^T and two substitutions.  Lane i = row i.  Am holds A[j][i], i >= j, at
-// Am[j * PM + i] (the upper triangle with the diagonal); L goes into the strictly lower triangle.  False: a pivot was not
-// positive.
-__device__ __forceinline__ bool mq_chol_solve(int P, int PM, double *Am, double rhs, double &sol)
+// The Cholesky factor in two phases.  Rows are ordered [k, m, seasonal coefficients | deltas]: the leading block (nN rows)
+// is free in every step of the active-set method and depends on w only, so its columns of L -- for ALL rows, the deltas'
+// too -- are computed ONCE per round (mq_factor_leading); a step then only needs the columns of the deltas that are free
+// (mq_solve_free: a held delta's column is written as zeros, its row is skipped) and the two substitutions.  A lane keeps
+// the variable it always has; `row` is that variable's row in this order, mq_owner(j) the lane that holds row j.  Am holds
+// A[j][i], i >= j, at Am[j * PM + i] (upper triangle with the diagonal, never overwritten) and L in the strictly lower
+// triangle; inv_l: the reciprocal of the lane's diagonal entry of L.
+__device__ __forceinline__ int mq_owner(int j, int nN, int S) { return j < 2 ? j : (j < nN ? 3 + S + (j - 2) : 3 + (j - nN)); }
+
+__device__ __forceinline__ double mq_column(const double *Am, int PM, int row, int j)
+{
+    // A[j][row] - sum_{k < j} L[row][k] L[j][k]: four fma chains, their eight LDS reads in flight together
+    double a0 = Am[j * PM + row], a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    const double *li = Am + row * PM, *lj = Am + j * PM;
+    int kk = 0;
+    for (; kk + 3 < j; kk += 4) {
+        const double l0 = li[kk], l1 = li[kk + 1], l2 = li[kk + 2], l3 = li[kk + 3];
+        const double r0 = lj[kk], r1 = lj[kk + 1], r2 = lj[kk + 2], r3 = lj[kk + 3];
+        a0 = __builtin_fma(-l0, r0, a0); a1 = __builtin_fma(-l1, r1, a1);
+        a2 = __builtin_fma(-l2, r2, a2); a3 = __builtin_fma(-l3, r3, a3);
+    }
+    if (kk < j) a0 = __builtin_fma(-li[kk], lj[kk], a0);
+    if (kk + 1 < j) a1 = __builtin_fma(-li[kk + 1], lj[kk + 1], a1);
+    if (kk + 2 < j) a2 = __builtin_fma(-li[kk + 2], lj[kk + 2], a2);
+    return (a0 + a1) + (a2 + a3);
+}
+
+// columns 0 .. nN-1 of L, every row (`in`: the lane holds a variable at all).  False: a pivot was not positive.
+__device__ __forceinline__ bool mq_factor_leading(int nN, int S, int PM, double *Am, bool in, int row, double &inv_l)
 {
     const int lane = lane_id();
-    double ljj_own = 1.0;
-    for (int j = 0; j < P; ++j) {
+    for (int j = 0; j < nN; ++j) {
         double s = 0.0;
-        if (lane >= j && lane < P) {
-            double a0 = Am[j * PM + lane], a1 = 0.0, a2 = 0.0, a3 = 0.0;
-            const double *li = Am + lane * PM, *lj = Am + j * PM;
-            int kk = 0;
-            for (; kk + 3 < j; kk += 4) {
-                const double l0 = li[kk], l1 = li[kk + 1], l2 = li[kk + 2], l3 = li[kk + 3];
-                const double r0 = lj[kk], r1 = lj[kk + 1], r2 = lj[kk + 2], r3 = lj[kk + 3];
-                a0 = __builtin_fma(-l0, r0, a0); a1 = __builtin_fma(-l1, r1, a1);
-                a2 = __builtin_fma(-l2, r2, a2); a3 = __builtin_fma(-l3, r3, a3);
-            }
-            if (kk < j) a0 = __builtin_fma(-li[kk], lj[kk], a0);
-            if (kk + 1 < j) a1 = __builtin_fma(-li[kk + 1], lj[kk + 1], a1);
-            if (kk + 2 < j) a2 = __builtin_fma(-li[kk + 2], lj[kk + 2], a2);
-            s = (a0 + a1) + (a2 + a3);
-        }
-        const double d = readlane_f64(s, j);
+        if (in && row >= j) s = mq_column(Am, PM, row, j);
+        const int oj = mq_owner(j, nN, S);
+        const double d = readlane_f64(s, oj);
         if (!(d > 0.0)) return false;
-        const double ljj = __builtin_sqrt(d);
-        if (lane == j) ljj_own = ljj;
-        if (lane > j && lane < P) Am[lane * PM + j] = s / ljj;
+        const double il = 1.0 / __builtin_sqrt(d);
+        if (lane == oj) inv_l = il;
+        if (in && row > j) Am[row * PM + j] = s * il;
         wave_sync();
     }
-    double r = (lane < P) ? rhs : 0.0, z = 0.0;
-    for (int j = 0; j < P; ++j) {
-        const double zj = readlane_f64(r, j) / readlane_f64(ljj_own, j);
-        if (lane == j) z = zj;
-        if (lane > j && lane < P) r = __builtin_fma(-Am[lane * PM + j], zj, r);
+    return true;
+}
+
+// the columns of the free deltas, then L z = rhs and L^T x = z over the free rows (fr: the lane's variable is free; every
+// variable of the leading block is).  False: a pivot was not positive.
+__device__ __forceinline__ bool mq_solve_free(int nN, int S, int PM, double *Am, bool in, bool fr, unsigned long long fmask, int row,
+                                              double &inv_l, double rhs, double &sol)
+{
+    const int lane = lane_id();
+    const int n = nN + S;
+    for (int j = nN; j < n; ++j) {
+        const int oj = 3 + (j - nN);
+        if (!((fmask >> oj) & 1ull)) {
+            if (in && row > j) Am[row * PM + j] = 0.0;          // a held delta: no column (and, below, no row)
+            wave_sync();
+            continue;
+        }
+        double s = 0.0;
+        if (fr && row >= j) s = mq_column(Am, PM, row, j);
+        const double d = readlane_f64(s, oj);
+        if (!(d > 0.0)) return false;
+        const double il = 1.0 / __builtin_sqrt(d);
+        if (lane == oj) inv_l = il;
+        if (fr && row > j) Am[row * PM + j] = s * il;
+        wave_sync();
+    }
+    wave_sync();
+    double r = fr ? rhs : 0.0, z = 0.0;
+    for (int j = 0; j < n; ++j) {
+        const int oj = mq_owner(j, nN, S);
+        if (!((fmask >> oj) & 1ull)) continue;
+        const double zj = readlane_f64(r, oj) * readlane_f64(inv_l, oj);
+        if (lane == oj) z = zj;
+        if (fr && row > j) r = __builtin_fma(-Am[row * PM + j], zj, r);
     }
     double r2 = z, st = 0.0;
-    for (int j = P - 1; j >= 0; --j) {
-        const double sj = readlane_f64(r2, j) / readlane_f64(ljj_own, j);
-        if (lane == j) st = sj;
-        if (lane < j) r2 = __builtin_fma(-Am[j * PM + lane], sj, r2);
+    for (int j = n - 1; j >= 0; --j) {
+        const int oj = mq_owner(j, nN, S);
+        if (!((fmask >> oj) & 1ull)) continue;
+        const double sj = readlane_f64(r2, oj) * readlane_f64(inv_l, oj);
+        if (lane == oj) st = sj;
+        if (fr && row < j) r2 = __builtin_fma(-Am[j * PM + row], sj, r2);
     }
-    sol = (lane < P) ? st : 0.0;
+    sol = fr ? st : 0.0;
     wave_sync();
     return true;
 }
@@ -135,9 +180,10 @@ __global__ __launch_bounds__(64) void map_quad_kernel(QuadArgs qa)
         // c = Z^T y and y'y: the residual pass at u = 0
         double zero[1] = {0.0}, g0[1], f0, yy, cv[1];
         resid_eval_q<KP, 1, NTR>(sv, wl, lk, rb, zero, f0, g0, yy, cv);
-        const int P = sv.P, PM = P | 1;
+        const int P = sv.P, S = sv.S, nN = P - 1 - S, PM = (P - 1) | 1;
         const bool par = lane < P && lane != 2;
-        const bool isD = lane >= 3 && lane < 3 + sv.S;
+        const bool isD = lane >= 3 && lane < 3 + S;
+        const int row = lane < 2 ? lane : (isD ? nN + (lane - 3) : 2 + (lane - 3 - S));      // the order of the factor: [k, m, beta | delta]
         const double c = par ? cv[0] : 0.0;
         const double Dl = par ? lk.lc[lane] : 0.0;
         const double C = lk.inv_tau, Tn = (double)sv.T;
@@ -150,6 +196,7 @@ __global__ __launch_bounds__(64) void map_quad_kernel(QuadArgs qa)
         double u = par ? x[0] : 0.0;               // cold start: fbprophet's initial k and m, every delta held at zero
         double w = 1.0, sse = yy, mu = 0.0;
         int n_outer = 0, n_solve = 0, status = TSF_ST_MAP_MAXIT;
+        double w1 = 0.0, w2 = 0.0;                  // w of the last and of the last but one round
         for (int outer = 0; ; ++outer) {
             mu = matvec(u);
             sse = yy + bfly_sum(u * (mu - 2.0 * c));
@@ -170,15 +217,42 @@ __global__ __launch_bounds__(64) void map_quad_kernel(QuadArgs qa)
             if (!(kkt > tol)) { status = TSF_ST_MAP_KKT; break; }
             if (outer >= max_outer) break;
             n_outer++;
+            // Aitken's extrapolate of the fixed-point sequence w_k, every third round (wq: the w the programme is solved at)
+            double wq = w;
+            if (outer >= 2 && outer % 3 == 2) {
+                // (only where the last two differences show a geometric sequence: same sign, shrinking)
+                const double d1 = w - w1, d0 = w1 - w2, d2 = d1 - d0;
+                const double rho = d1 / d0;
+                const double wa = w - d1 * d1 / d2;
+                if (rho > 0.0 && rho < 0.95 && wa > 0.0 && __builtin_fabs(wa - w) < 0.5 * w) wq = wa;
+            }
+            w2 = w1; w1 = w;
             // ---- u at fixed w: primal active-set method on 1/2 u'(M + wD)u - c'u + wC |delta|_1
-            const double Cw = w * C;
-            const double tolq = __builtin_fmax(0.05 * tol * w, 4e-14 * __builtin_fmax(1.0, cmax));
+            const double Cw = wq * C;
+            const double tolq = __builtin_fmax(0.05 * tol * wq, 4e-14 * __builtin_fmax(1.0, cmax));
             bool held = isD && u == 0.0;           // the working set: deltas held at zero
             double zs = isD ? (double)((u > 0.0) - (u < 0.0)) : 0.0;
             bool gave_up = false;
+            // A = M + wD (upper triangle, the factor's row order) and the leading columns of its factor: once per round
+            double ridge = 0.0, inv_l = 1.0;
+            bool lead = false;
+            for (int attempt = 0; attempt < 8 && !lead; ++attempt) {
+                for (int j = 0; j < P - 1; ++j) {
+                    const int q = mq_owner(j, nN, S);
+                    if (par && row >= j) {
+                        double v = Mg[(size_t)q * W + lane];
+                        if (row == j) v = v + wq * Dl + ridge;
+                        Am[j * PM + row] = v;
+                    }
+                }
+                wave_sync();
+                lead = mq_factor_leading(nN, S, PM, Am, par, row, inv_l);
+                if (!lead) ridge = ridge == 0.0 ? 1e-12 * __builtin_fmax(1.0, mq_wave_max(par ? Mg[(size_t)lane * W + lane] : 0.0)) : ridge * 100.0;
+            }
+            if (!lead) { status = TSF_ST_MAP_LS; break; }
             for (int inner = 0; inner < MQ_MAX_INNER; ++inner) {
                 if (inner > 0) mu = matvec(u);
-                const double gq = par ? (__builtin_fma(w * Dl, u, mu) - c + Cw * zs) : 0.0;
+                const double gq = par ? (__builtin_fma(wq * Dl, u, mu) - c + Cw * zs) : 0.0;
                 const bool fr = par && !held;
                 const double gF = mq_wave_max(fr ? __builtin_fabs(gq) : 0.0);
                 if (!(gF > tolq)) {
@@ -193,22 +267,9 @@ __global__ __launch_bounds__(64) void map_quad_kernel(QuadArgs qa)
                 }
                 // Newton's step on the free set: (M + wD)_FF d = -g_F
                 const unsigned long long fmask = __ballot(fr);
-                double ridge = 0.0, d = 0.0;
-                bool ok = false;
-                for (int attempt = 0; attempt < 8 && !ok; ++attempt) {
-                    for (int q = 0; q < P; ++q) {
-                        if (lane >= q && lane < P) {
-                            const bool both = fr && ((fmask >> q) & 1ull);
-                            double v = both ? Mg[(size_t)q * W + lane] : 0.0;
-                            if (q == lane) v = fr ? v + w * Dl + ridge : 1.0;
-                            Am[q * PM + lane] = v;
-                        }
-                    }
-                    wave_sync();
-                    ok = mq_chol_solve(P, PM, Am, fr ? -gq : 0.0, d);
-                    n_solve++;
-                    if (!ok) ridge = ridge == 0.0 ? 1e-12 * __builtin_fmax(1.0, mq_wave_max(fr ? Mg[(size_t)lane * W + lane] : 0.0)) : ridge * 100.0;
-                }
+                double d = 0.0;
+                const bool ok = mq_solve_free(nN, S, PM, Am, par, fr, fmask, row, inv_l, -gq, d);
+                n_solve++;
                 if (!ok) { gave_up = true; break; }
                 const double ustar = u + d;
                 // a delta may not change sign inside a step: stop at the first one that reaches zero
