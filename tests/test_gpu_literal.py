@@ -245,3 +245,36 @@ def test_map_mode_fit_reaches_the_true_map(fc, kind, n, tmp_path):
     map2 = fc.fit_aligned(mk(converge=_lib.CONVERGE_MAP), ds, y2, floor=fl, cap=capv, extra=ex)
     moved = np.max(np.abs(pred(map2.theta, map2) - y_map) / np.abs(y_map), axis=1)
     assert np.median(moved) <= (1e-5 if kind == 'cfg5' else 1e-6), (kind, float(np.median(moved)), float(moved.max()))
+
+
+@pytest.mark.gpu
+def test_direct_map_on_short_and_degenerate_histories(fc):
+    """map_quad_kernel (converge = MAP computed directly) where its matrix is singular or nearly so: histories shorter than
+    the parameter count, no changepoints, a constant series, a two-row series.  Every series ends with a finite estimate whose
+    objective is no worse than the continuation's (option map_direct = 0: the Stan-rule fit carried on by map_kernel), and
+    series that never reach an optimiser are reported as every fit kernel reports them."""
+    from time_series_spark_amd import _lib, synth
+    rng = np.random.default_rng(5)
+    wk = [dict(name='weekly', period=7, fourier_order=3)]
+    for T, n_cp, seas in ((3, 25, wk), (8, 25, wk), (20, 3, [dict(name='weekly', period=7, fourier_order=3)]),
+                          (40, 0, [dict(name='weekly', period=7, fourier_order=3)]),
+                          (60, 25, [dict(name='weekly', period=7, fourier_order=3)]),
+                          (200, 25, [dict(name='weekly', period=7, fourier_order=3), dict(name='monthly', period=30.5, fourier_order=5)])):
+        N = 12
+        ds, y = synth.make_panel(N, T, 'linear', seed=60 + T)
+        y[1] = 5.0                              # constant: fbprophet skips the optimiser
+        y[2] = y[2, 0] + np.arange(T)           # a straight line: sigma -> 0
+        y[3, ::2] = y[3, 0]                     # half the rows equal
+        kw = dict(growth='linear', seasonalities=seas, n_changepoints=n_cp)
+        direct = fc.fit_aligned(fc.ModelSpec(converge=_lib.CONVERGE_MAP, **kw), ds, y)
+        with fc.get_context().options(map_direct=0):
+            cont = fc.fit_aligned(fc.ModelSpec(converge=_lib.CONVERGE_MAP, **kw), ds, y)
+        assert direct.status[1] == _lib.ST_CONSTANT == cont.status[1], (T, direct.status[1])
+        ok = np.ones(N, bool); ok[1] = False
+        assert set(np.unique(direct.status[ok])) <= {_lib.ST_MAP_KKT, _lib.ST_MAP_MAXIT, _lib.ST_MAP_LS}, (T, np.unique(direct.status))
+        assert np.isfinite(direct.theta[ok]).all() and np.isfinite(direct.fval[ok]).all(), T
+        both = ok & (cont.status >= _lib.ST_MAP_KKT)
+        # (the straight line drives sigma to its floor on either route: compare the rest)
+        both[2] = False
+        assert (direct.fval[both] <= cont.fval[both] + 1e-6 * np.maximum(1.0, np.abs(cont.fval[both]))).all(), \
+            (T, n_cp, direct.fval[both] - cont.fval[both], direct.status, cont.status)
