@@ -47,6 +47,7 @@ done
 fi
 echo "== converge = MAP against the independent solver" | tee -a $OUT/summary.txt
 timeout 900 python tools/dev/map_probe.py cfg2:256 ref:64 cfg5:64 cfg4:16 > $OUT/map_probe.txt 2>&1; cat $OUT/map_probe.txt | tee -a $OUT/summary.txt
+timeout 600 python tools/dev/map_direct_timing.py 2>&1 | grep -v amdgpu.ids > $OUT/map_direct_timing.txt; cut -c1-700 $OUT/map_direct_timing.txt | tee -a $OUT/summary.txt
 echo "== lattice panels: a table per series / lattice points / gathered rows" | tee -a $OUT/summary.txt
 timeout 600 python tools/dev/lattice_probe.py 10000 daily 2>&1 | grep -v amdgpu.ids | cut -c1-330 | tee $OUT/lattice_probe.txt | tee -a $OUT/summary.txt
 echo "== Stan's Newton, 1 000 000 x 90" | tee -a $OUT/summary.txt
