@@ -278,3 +278,34 @@ def test_direct_map_on_short_and_degenerate_histories(fc):
         both[2] = False
         assert (direct.fval[both] <= cont.fval[both] + 1e-6 * np.maximum(1.0, np.abs(cont.fval[both]))).all(), \
             (T, n_cp, direct.fval[both] - cont.fval[both], direct.status, cont.status)
+
+
+@pytest.mark.gpu
+def test_direct_map_on_ragged_panels(fc):
+    """The direct MAP solver on ragged calls of linear / additive models: series with calendars of their own (the Gram matrix
+    built per series inside map_quad_kernel) and series that share a few calendars (one matrix per calendar, built ahead) --
+    the estimate of the same series in an aligned call, and the continuation's (option map_direct = 0)."""
+    from time_series_spark_amd import _lib, synth
+    rng = np.random.default_rng(9)
+    N, T = 40, 730
+    ds, y = synth.make_panel(N, T, 'linear', seed=77)
+    seas = fc.ModelSpec.auto_seasonalities(ds, yearly=True)
+    spec = fc.ModelSpec(growth='linear', seasonalities=seas, converge=_lib.CONVERGE_MAP)
+    whole = fc.fit_aligned(spec, ds, y)
+    assert (whole.status == _lib.ST_MAP_KKT).all()
+    for shared in (False, True):
+        cuts = [T, T - 30, T - 61] if shared else None
+        lens = np.array([cuts[i % 3] for i in range(N)]) if shared else rng.integers(600, T + 1, N)
+        lens[0] = T
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        dsr = np.concatenate([ds[:c] for c in lens])
+        yr = np.concatenate([y[i][:c] for i, c in enumerate(lens)])
+        r = fc.fit_ragged(spec, off, dsr, yr)
+        assert (r.status == _lib.ST_MAP_KKT).all(), (shared, np.unique(r.status, return_counts=True))
+        full = np.where(lens == T)[0]
+        # the full-length series: the aligned call's estimate (another matrix build, the same optimum)
+        assert np.max(np.abs(r.fval[full] - whole.fval[full])) <= 1e-8 * np.max(np.abs(whole.fval[full])), shared
+        assert np.max(np.abs(r.theta[full] - whole.theta[full])) <= 1e-6, (shared, float(np.max(np.abs(r.theta[full] - whole.theta[full]))))
+        with fc.get_context().options(map_direct=0):
+            cont = fc.fit_ragged(spec, off, dsr, yr)
+        assert np.max(np.abs(cont.fval - r.fval)) <= 1e-7 * np.max(np.abs(r.fval)), (shared, float(np.max(np.abs(cont.fval - r.fval))))

@@ -738,7 +738,7 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
         qa.gram_harm = gram_harm;
         HIP_TRY(ctx, hipMemsetAsync(qa.counter, 0, sizeof(int), st));
         lrc = -1;
-        if (spec->converge == TSF_CONVERGE_MAP && aligned && qp.PPL == 1 && ctx->opt[TSF_OPT_MAP_DIRECT] != 0) {
+        if (spec->converge == TSF_CONVERGE_MAP && qp.PPL == 1 && ctx->opt[TSF_OPT_MAP_DIRECT] != 0) {
             // converge = MAP where the posterior is a quadratic form in everything but sigma: the estimate itself by
             // alternating exact minimisations (tsf_map_quad.h) -- no L-BFGS trajectory, no continuation
             qa.f.map_max_iter = spec->map_max_iter; qa.f.map_tol = spec->map_tol;

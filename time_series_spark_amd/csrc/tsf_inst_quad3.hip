@@ -47,11 +47,27 @@ static int launch_map_quad_one(const QuadPlan &qp, const QuadArgs &qa, double *M
 {
     const size_t lds = map_quad_lds_bytes<KP>(PM);
     if (lds > 160 * 1024) return -1;
+    int64_t blocks = qa.f.N < qp.slots ? qa.f.N : qp.slots;
+    if (!qa.f.aligned) {
+        // ragged: Z^T Z per distinct calendar ahead of the kernel where calendars are shared (as tsf_inst_quad.hip does for
+        // the fit kernels: one rbuf slot per (grid, column)), else per series inside it
+        if (qa.Mpre) {
+            const int64_t per = qp.slots / qp.P4 > 0 ? qp.slots / qp.P4 : 1;
+            for (int64_t g0 = 0; g0 < qa.n_pre; g0 += per) {
+                const int64_t cnt = qa.n_pre - g0 < per ? qa.n_pre - g0 : per;
+                hipLaunchKernelGGL((gram_grids_kernel<KP, 1>), dim3((unsigned)qp.P4, (unsigned)cnt), dim3(64), 0, st, qa, const_cast<double *>(qa.Mpre), g0);
+                hipError_t e = hipGetLastError();
+                if (e != hipSuccess) return (int)e;
+            }
+        }
+        hipFuncSetAttribute((const void *)map_quad_kernel<KP, TSF_QUAD_NTR, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL((map_quad_kernel<KP, TSF_QUAD_NTR, true>), dim3((unsigned)blocks), dim3(64), lds, st, qa);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL((gram_build_kernel<KP, 1>), dim3((unsigned)qp.P4), dim3(64), 0, st, qa, Mg);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     hipFuncSetAttribute((const void *)map_quad_kernel<KP, TSF_QUAD_NTR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    int64_t blocks = qa.f.N < qp.slots ? qa.f.N : qp.slots;
     hipLaunchKernelGGL((map_quad_kernel<KP, TSF_QUAD_NTR>), dim3((unsigned)blocks), dim3(64), lds, st, qa);
     return (int)hipGetLastError();
 }

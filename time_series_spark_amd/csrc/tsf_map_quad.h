@@ -1,5 +1,5 @@
-// tsf_map_quad.h -- converge = MAP for linear growth with additive seasonality on aligned panels (round 6): the maximum a
-// posteriori estimate of prophet.stan's model DIRECTLY, without an L-BFGS trajectory before it.
+// tsf_map_quad.h -- converge = MAP for linear growth with additive seasonality (round 6; aligned and ragged panels, P <= 64):
+// the maximum a posteriori estimate of prophet.stan's model DIRECTLY, without an L-BFGS trajectory before it.
 //
 // For this model the data enter the posterior through a quadratic form.  With u = (k, m, delta, beta), Z the design of
 // the trend and the seasonal columns, M = Z^T Z (one matrix for the whole aligned panel: gram_build_kernel), c = Z^T y,
@@ -30,7 +30,7 @@
 
 namespace tsf {
 
-constexpr int MQ_MAX_OUTER = 120, MQ_MAX_INNER = 800;
+constexpr int MQ_MAX_OUTER = 120, MQ_MAX_INNER = 800, MQ_MAX_SOLVES = 3000;
 
 __device__ __forceinline__ double mq_wave_max(double v)
 {
@@ -141,7 +141,10 @@ constexpr size_t map_quad_lds_bytes(int PM)
     return quad_lanec_bytes<1>() + ((sizeof(QuadLds<KP, 1>) + 15) & ~(size_t)15) + sizeof(double) * (size_t)PM * PM;
 }
 
-template <int KP, int NTR>
+// RAGGED: every series has its own rows, hence its own M -- the Gram matrix of its calendar where calendars are shared
+// (QuadArgs::Mpre, built ahead by gram_grids_kernel), else built here column by column into the workgroup's slot of
+// global memory (QuadArgs::Mslot; lane p writes and later reads its own column entries only).
+template <int KP, int NTR, bool RAGGED = false>
 __global__ __launch_bounds__(64) void map_quad_kernel(QuadArgs qa)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -151,6 +154,7 @@ __global__ __launch_bounds__(64) void map_quad_kernel(QuadArgs qa)
     QuadLds<KP, 1> &wl = *reinterpret_cast<QuadLds<KP, 1> *>(smem + quad_lanec_bytes<1>());
     double *Am = reinterpret_cast<double *>(smem + quad_lanec_bytes<1>() + ((sizeof(QuadLds<KP, 1>) + 15) & ~(size_t)15));
     const double *Mg = qa.Mg;
+    double *const Mown = RAGGED ? qa.Mslot + (size_t)blockIdx.x * qa.P4 * W : nullptr;
     for (int i = lane; i < 2 * W; i += W) wl.th[i] = 0.0;
     wave_sync();
     double *rb = qa.rbuf + (size_t)blockIdx.x * a.NTmax * W;
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(64) void map_quad_kernel(QuadArgs qa)
         const SeriesTab st = a.stab[n];
         if (lane == 0) {
             a.y_scale[n] = st.y_scale;
-            if (n == 0) a.grid_out[0] = a.gtab[0].info;
+            if (!a.aligned || n == 0) a.grid_out[a.aligned ? 0 : n] = a.gtab[grid_index(a, n)].info;
         }
         double x[1];
         x[0] = (lane == 0) ? st.k0 : (lane == 1 ? st.m0 : 0.0);
@@ -177,6 +181,19 @@ __global__ __launch_bounds__(64) void map_quad_kernel(QuadArgs qa)
         quad_const_table(lanec + 3 * W, a.opt, qa.recenter_ratio);
         lane_consts<1>(a.sp, sv, lanec, lk);
         lk.ct = lanec + 3 * W;
+        if constexpr (RAGGED) {
+            if (qa.Mpre) {
+                Mg = qa.Mpre + (size_t)grid_index(a, n) * qa.P4 * W;
+            } else {
+                for (int q = 0; q < qa.P4; ++q) {
+                    double col[1] = {0.0};
+                    if (q != 2 && q < sv.P) gram_column<KP, 1>(sv, wl, rb, q, col);
+                    Mown[(size_t)q * W + lane] = col[0];
+                }
+                wave_sync();
+                Mg = Mown;
+            }
+        }
         // c = Z^T y and y'y: the residual pass at u = 0
         double zero[1] = {0.0}, g0[1], f0, yy, cv[1];
         resid_eval_q<KP, 1, NTR>(sv, wl, lk, rb, zero, f0, g0, yy, cv);
@@ -234,6 +251,7 @@ __global__ __launch_bounds__(64) void map_quad_kernel(QuadArgs qa)
             double zs = isD ? (double)((u > 0.0) - (u < 0.0)) : 0.0;
             bool gave_up = false;
             // A = M + wD (upper triangle, the factor's row order) and the leading columns of its factor: once per round
+            bool tabu = false;                     // released in this round and pushed straight back to zero: not released again
             double ridge = 0.0, inv_l = 1.0;
             bool lead = false;
             for (int attempt = 0; attempt < 8 && !lead; ++attempt) {
@@ -257,7 +275,7 @@ __global__ __launch_bounds__(64) void map_quad_kernel(QuadArgs qa)
                 const double gF = mq_wave_max(fr ? __builtin_fabs(gq) : 0.0);
                 if (!(gF > tolq)) {
                     // stationary on the free set: the multipliers of the held deltas
-                    const double viol = held ? __builtin_fabs(gq) - Cw : -1.0;
+                    const double viol = (held && !tabu) ? __builtin_fabs(gq) - Cw : -1.0;
                     const double vmax = mq_wave_max(viol);
                     if (!(vmax > tolq)) break;
                     const unsigned long long who = __ballot(held && viol == vmax);
@@ -282,10 +300,11 @@ __global__ __launch_bounds__(64) void map_quad_kernel(QuadArgs qa)
                     if (fr) u = __builtin_fma(amin, d, u);
                     const unsigned long long who = __ballot(wrong && aj == amin);
                     const int j = __builtin_ctzll(who);
-                    if (lane == j) { u = 0.0; held = true; zs = 0.0; }
+                    if (lane == j) { if (u == 0.0) tabu = true; u = 0.0; held = true; zs = 0.0; }
                 }
+                if (n_solve > MQ_MAX_SOLVES) { gave_up = true; break; }
             }
-            if (gave_up) { status = TSF_ST_MAP_LS; break; }
+            if (gave_up) { status = n_solve > MQ_MAX_SOLVES ? TSF_ST_MAP_MAXIT : TSF_ST_MAP_LS; break; }
         }
         // theta, the function value (cn_assemble_q's terms at this point) and the counts
         if (status != TSF_ST_MAP_KKT) {             // (left inside a round: the sums of the point it was left at)
