@@ -34,3 +34,11 @@ if os.path.exists(os.path.join(src, 'pmc_latest.json')):
     shutil.copy(os.path.join(src, 'pmc_latest.json'), os.path.join('profiles', 'pmc_latest.json'))
     shutil.copy(os.path.join(src, 'pmc_latest.json'), os.path.join(dst, 'pmc_latest.json'))
 print('saved', dst)
+# round 6 (tools/gpu_round6.sh): the other outputs of the closing run, as they are
+for name in ('configs.jsonl', 'ragged.txt', 'irregular.jsonl', 'irregular_pmc_latest.json', 'e2e_cfg2.txt', 'e2e_cfg2_40k.txt',
+             'e2e_reference.txt', 'e2e_reference_40k.txt', 'map_probe.txt', 'map_direct_timing.txt', 'lattice_probe.txt',
+             'newton_1m.txt', 'pytest_gpu.log', 'bench_time.txt', 'pmc_summary.txt'):
+    if os.path.exists(os.path.join(src, name)):
+        shutil.copy(os.path.join(src, name), os.path.join(dst, name))
+if os.path.exists(os.path.join(src, 'irregular_pmc_latest.json')):
+    shutil.copy(os.path.join(src, 'irregular_pmc_latest.json'), os.path.join('profiles', 'irregular_pmc_latest.json'))
