@@ -74,7 +74,10 @@ enum { TSF_RK_AUTO = 0, TSF_RK_WAVE = 1, TSF_RK_MFMA = 2, TSF_RK_COOP = 3 };
  * optimum in forecast, because L-BFGS stalls on the kinks of the Laplace prior on the changepoints.
  * TSF_CONVERGE_MAP: from that point on to the maximum a posteriori estimate of prophet.stan's model itself (an
  * orthant-wise active-set L-BFGS on the same log-posterior, tsf_map_kernels.h): forecasts that are a property of the
- * model, not of a floating-point trajectory.  status then is TSF_ST_MAP_*; n_iter / n_eval count both phases. */
+ * model, not of a floating-point trajectory.  status then is TSF_ST_MAP_*; n_iter / n_eval count both phases.
+ * For linear growth with additive seasonality (<= 64 parameters) the estimate is computed directly, without the Stan-rule
+ * fit before it (tsf_map_quad.h: sigma in closed form and an L1-regularised quadratic programme by an active-set method,
+ * in turn): n_iter then counts those rounds, n_eval the Cholesky solves + 1, and the call is faster than a Stan-rule fit. */
 enum { TSF_CONVERGE_STAN = 0, TSF_CONVERGE_MAP = 1 };
 #define TSF_NEWTON_BELOW_T 100
 
@@ -88,7 +91,7 @@ enum {
     /* tsf_spec.converge = TSF_CONVERGE_MAP: how the continuation to the maximum a posteriori estimate ended */
     TSF_ST_MAP_KKT = 70,       /* KKT residual (largest one-sided derivative that still descends) <= map_tol */
     TSF_ST_MAP_FTOL = 71,      /* 20 iterations together gained < 1e-13 |f|: the function value has converged */
-    TSF_ST_MAP_MAXIT = 72,     /* map_max_iter iterations */
+    TSF_ST_MAP_MAXIT = 72,     /* map_max_iter iterations (the direct solver: 120 rounds or 3 000 solves) */
     TSF_ST_MAP_LS = 73,        /* no lower point along the steepest one-sided descent direction either (rounding level) */
     TSF_ST_NEWTON_FAIL = -4,   /* Newton: log_prob threw inside the finite-difference Hessian */
     TSF_ST_LSFAIL = -1,        /* line search failed (pystan raises RuntimeError) */
