@@ -209,15 +209,17 @@ def test_map_mode_fit_reaches_the_true_map(fc, kind, n, tmp_path):
     direct = kind in ('cfg2', 'cfg5')
     if direct:
         # linear growth, additive seasonality, aligned panel: the estimate is computed DIRECTLY (map_quad_kernel: exact
-        # minimisations of sigma and of the L1-regularised quadratic programme in turn) -- a handful of rounds and
-        # Cholesky solves per series, every series at the KKT tolerance; the continuation of the Stan-rule fit
-        # (map_kernel, option map_direct = 0) must arrive at the same estimate
+        # minimisations of sigma and of the L1-regularised quadratic programme in turn, once from above and once from
+        # below in sigma) -- a few rounds and Cholesky solves per series, every series at the KKT tolerance; the
+        # continuation of the Stan-rule fit (map_kernel, option map_direct = 0) must arrive at the same estimate or, where
+        # the posterior has two minima, at one that is no better
         assert (mapf.status == _lib.ST_MAP_KKT).all(), np.unique(mapf.status, return_counts=True)
-        assert mapf.n_iter.max() <= 20 and mapf.n_eval.max() <= 120, (int(mapf.n_iter.max()), int(mapf.n_eval.max()))
+        assert mapf.n_iter.max() <= 80 and mapf.n_eval.max() <= 400, (int(mapf.n_iter.max()), int(mapf.n_eval.max()))
         with fc.get_context().options(map_direct=0):
             cont = fc.fit_aligned(mk(converge=_lib.CONVERGE_MAP), ds, yy, floor=fl, cap=capv, extra=ex)
         assert (cont.n_eval > stan.n_eval).all()                                           # it went on from the Stan-rule fit
-        assert np.max(np.abs(cont.fval - mapf.fval)) <= 1e-7 * np.max(np.abs(mapf.fval))
+        assert (mapf.fval <= cont.fval + 1e-7 * np.abs(cont.fval)).all()
+        assert np.median(np.abs(cont.fval - mapf.fval) / np.abs(mapf.fval)) <= 1e-9
     else:
         assert (mapf.n_eval > stan.n_eval).all()                                           # it went on
     out = str(tmp_path / 'true_map.npz')
