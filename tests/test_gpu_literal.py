@@ -273,7 +273,8 @@ def test_direct_map_on_short_and_degenerate_histories(fc):
             cont = fc.fit_aligned(fc.ModelSpec(converge=_lib.CONVERGE_MAP, **kw), ds, y)
         assert direct.status[1] == _lib.ST_CONSTANT == cont.status[1], (T, direct.status[1])
         ok = np.ones(N, bool); ok[1] = False
-        assert set(np.unique(direct.status[ok])) <= {_lib.ST_MAP_KKT, _lib.ST_MAP_MAXIT, _lib.ST_MAP_LS}, (T, np.unique(direct.status))
+        assert set(np.unique(direct.status[ok])) <= {_lib.ST_MAP_KKT, _lib.ST_MAP_FTOL, _lib.ST_MAP_MAXIT, _lib.ST_MAP_LS}, (T, np.unique(direct.status))
+        assert direct.n_eval[2] <= 400, (T, int(direct.n_eval[2]))      # the noiseless line ends on the function-value test, not at the round limit
         assert np.isfinite(direct.theta[ok]).all() and np.isfinite(direct.fval[ok]).all(), T
         both = ok & (cont.status >= _lib.ST_MAP_KKT)
         # (the straight line drives sigma to its floor on either route: compare the rest)
