@@ -48,8 +48,6 @@ enum {
                                 more of them are left than this many per hundred compute units (default 200) */
     TSF_OPT_MAP_DIRECT,      /* 0: converge = MAP always as a continuation of the Stan-rule fit (map_kernel), also where the model is
                                 linear / additive on an aligned panel and the estimate can be computed directly (map_quad_kernel) */
-    TSF_OPT_STAGE_TY,        /* 0: the prefetch form of the base-pair kernel reads t and y of a row from its tables at every
-                                evaluation instead of keeping them in LDS for the fit */
     TSF_OPT_COUNT
 };
 int tsf_set_option(tsf_ctx *ctx, int option, int value);

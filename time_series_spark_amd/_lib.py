@@ -94,7 +94,7 @@ CSV_E_OPEN, CSV_E_PARSE, CSV_E_CODEC = -10, -11, -12          # TSF_CSV_E_* (inc
 # TSF_OPT_* (include/tsf.h): route switches of one context
 OPTIONS = ['harm', 'lattice', 'sparse_extra', 'fit_grouped', 'gram_share', 'grid_order', 'grid_share', 'ragged_split',
            'quad_reg', 'quad_m2_lds', 'quad_w4', 'quad_rreg', 'newton_batch', 'newton_flags', 'newton_ns', 'newton_lcap',
-           'newton_fill', 'quad_raw_y', 'debug_async_scratch', 'coop_tail', 'map_direct', 'stage_ty']
+           'newton_fill', 'quad_raw_y', 'debug_async_scratch', 'coop_tail', 'map_direct']
 
 _lib = None
 

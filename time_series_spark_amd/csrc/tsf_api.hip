@@ -682,7 +682,6 @@ static int run_fit(tsf_ctx *ctx, const tsf_spec *spec, int64_t N, int aligned, i
         const int oh = ctx->opt[TSF_OPT_HARM];
         a.harm_pf = (harm != 0 && (oh == 2 || (oh != 1 && !aligned && row_tabs > ((size_t)256 << 20)))) ? 1 : 0;
         if (harm != 0 && lat_U > 0) a.harm_pf = 1;         // (the lattice form exists with the row prefetch only)
-        a.stage_ty = (a.harm_pf && NTmax <= 12 && ctx->opt[TSF_OPT_STAGE_TY] != 0) ? 1 : 0;
     }
     a.opt_coop_sparse = ctx->opt[TSF_OPT_SPARSE_EXTRA] != 2 ? 1 : 0;     // (2: the sparse fit kernel with the 64-column tail, for A/B runs)
     ctx->last_sp_flag = nullptr;

@@ -28,7 +28,6 @@ struct SeriesView {
     const int32_t *uw;                  // (lattice panels) row -> row of the shared table Xu, step-major
     const double *Xu;                   // (lattice panels) [U][KP] design rows of the timestamp lattice
     const double *Bu;                   // (lattice panels, HARM kernels) [U][seasonality][2] base pairs of the lattice points
-    int stage_off, stage_n;             // (prefetch kernels) t and y of the rows in the wave's LDS: bytes from its WaveLds to t, doubles from t to y; 0: not staged
     const uint16_t *cw;
     const int32_t *Lj;
     const double *t_change;
@@ -490,14 +489,7 @@ __device__ __forceinline__ bool eval_fg(const DevSpec *__restrict__ sp, SeriesVi
     struct RowIn { unsigned cwv; int un; double ti, yi; double2 bp[NS]; };
     auto row_fetch = [&](int q, int u, RowIn &ri) {
         const int idx = q * W + lane;
-        ri.cwv = (unsigned)sv.cw[idx];
-        if (sv.stage_off) {
-            // (t and y of the series live in the wave's LDS for the whole fit: fit_kernel<..., PF>)
-            const double *lt = reinterpret_cast<const double *>(reinterpret_cast<const unsigned char *>(&lds) + sv.stage_off);
-            ri.ti = lt[idx]; ri.yi = lt[sv.stage_n + idx];
-        } else {
-            ri.ti = sv.tw[idx]; ri.yi = sv.yw[idx];
-        }
+        ri.cwv = (unsigned)sv.cw[idx]; ri.ti = sv.tw[idx]; ri.yi = sv.yw[idx];
         const double2 *bq = XIDX ? reinterpret_cast<const double2 *>(sv.Bu) + (size_t)u * NS
                                  : reinterpret_cast<const double2 *>(sv.Bw) + (size_t)q * NS * W + lane;
 #pragma unroll
@@ -800,7 +792,6 @@ struct FitArgs {
     int bw_ns, harm;                    // seasonalities per row of Bw; the model's harmonic structure (harm_code), 0 = none compiled
     int coop_harm;                      // the cooperative kernel's rows from the base pairs too (harm != 0 and no dense column behind the Fourier block)
     int harm_pf;                        // HARM: the two-waves-per-SIMD kernel with the row prefetch (tables per series, read from HBM)
-    int stage_ty;                       // ... which then keeps the series' t and y rows in LDS for the whole fit (round 6: 16 of a row's 50 / 22 bytes)
     int opt_coop_sparse;                // the sparse-column kernel's tail on the sparse cooperative kernel (TSF_OPT_SPARSE_EXTRA != 2 ... tests: off)
     const int32_t *uw;                  // [grid][NTmax][64] lattice row of each series row (zero where a lane's chunk has no such row)
     const double *Xu;                   // [U][KP]
@@ -912,7 +903,6 @@ __device__ __forceinline__ void make_view(const FitArgs &a, int64_t n, SeriesVie
     sv.uw = a.uw + (size_t)g * a.NTmax * W;
     sv.Xu = a.Xu;
     sv.Bu = a.Bu;
-    sv.stage_off = 0; sv.stage_n = 0;
     sv.Bw = a.Bw ? a.Bw + (size_t)g * a.NTmax * a.bw_ns * 2 * W : nullptr;
     sv.n_xd = 0;
     sv.yw = a.yw + (size_t)n * a.NTmax * W;
@@ -1054,19 +1044,6 @@ __global__ __launch_bounds__(64, HARM != 0 ? ((SPARSE || PF) ? TSF_HARM_SPARSE_W
         return;
     }
 
-    if constexpr (PF) {
-        // rows from HBM (a table per series): t and y of the series -- 16 of the 50 bytes an evaluation reads per row, 16 of 22
-        // on a lattice panel -- are copied into LDS once and read from there by every evaluation (the kernel runs at two waves
-        // per SIMD: 8 x 12 KB per CU beside the optimiser's 5 KB per wave).  Same values, same operations.
-        if (a.stage_ty) {
-            double *lt = reinterpret_cast<double *>(smem + ((wave_lds_bytes<KL, PPL>(a.opt.history) + 15) & ~(size_t)15));
-            double *ly = lt + (size_t)a.NTmax * W;
-            for (int q = 0; q < sv.NT; ++q) { lt[q * W + lane] = sv.tw[q * W + lane]; ly[q * W + lane] = sv.yw[q * W + lane]; }
-            TSF_WAVE_SYNC();
-            sv.stage_off = (int)((wave_lds_bytes<KL, PPL>(a.opt.history) + 15) & ~(size_t)15);
-            sv.stage_n = a.NTmax * W;
-        }
-    }
     const int H = a.opt.history > MAXH ? MAXH : a.opt.history;
     const double eps = 2.220446049250313e-16;
     const double c1 = 1e-4, c2 = 0.9, minAlpha = 1e-12, min_range = 1e-16;
