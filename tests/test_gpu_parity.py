@@ -654,6 +654,42 @@ def test_lattice_panels_read_the_base_pairs_of_their_lattice_points(env):
             assert n_bit_diff(r.theta[n][:len(o['theta'])], o['theta']) == 0 and n_bit_diff(r.fval[n], o['f']) == 0, (ci, n)
 
 
+def test_randomised_lattice_panels_equal_a_table_per_series(env):
+    """Randomised form of the test above (tools/dev/route_stress.py ran 16 113 such panels for the round's record): random time
+    lattices (steps of 24 / 12 / 6 / 1.5 hours, 60-900 slots), every series at a random subset of the slots, five models (three
+    with a compiled expansion, two without: those take the gathered design rows), both growths and column modes, three
+    changepoint counts and three iteration limits -- the lattice routes against a table per series (option lattice = 0), every
+    output bit for bit."""
+    fc, cl = env
+    from time_series_spark_amd import _lib, synth
+    rng = np.random.default_rng(2026)
+    Y10, W3 = helpers.YEARLY, helpers.WEEKLY
+    D4 = {'name': 'daily', 'period': 1, 'fourier_order': 4}
+    M5 = {'name': 'monthly', 'period': 30.5, 'fourier_order': 5}
+    for trial in range(40):
+        step_h = float(rng.choice([24, 12, 6, 1.5]))
+        n_slots = int(rng.integers(60, 900))
+        slots = synth.START_NS + (np.arange(n_slots) * step_h * 3600e9).astype(np.int64)
+        N = int(rng.integers(1, 30))
+        growth = str(rng.choice(['linear', 'logistic']))
+        mode = str(rng.choice(['additive', 'multiplicative']))
+        seas = [[Y10, W3], [W3, D4], [W3], [W3, M5], [Y10, W3, M5]][int(rng.integers(0, 5))]
+        _, ym = synth.make_panel(N, n_slots, growth, seed=int(rng.integers(1, 1 << 30)))
+        keep = [np.sort(rng.choice(n_slots, size=int(rng.integers(max(4, n_slots // 2), n_slots + 1)), replace=False)) for _ in range(N)]
+        off = np.concatenate([[0], np.cumsum([len(k) for k in keep])]).astype(np.int64)
+        dsr = np.concatenate([slots[k] for k in keep])
+        yr = np.concatenate([ym[i][k] for i, k in enumerate(keep)])
+        kw = dict(floor=np.zeros(N), cap=np.array([ym[i][k].max() * 1.1 for i, k in enumerate(keep)])) if growth == 'logistic' else {}
+        spec = fc.ModelSpec(growth=growth, seasonality_mode=mode, seasonalities=seas, n_changepoints=int(rng.choice([0, 5, 25])),
+                            eval_form=_lib.EVAL_RESIDUAL, max_iter=int(rng.choice([30, 200, 10000])))
+        a = fc.fit_ragged(spec, off, dsr, yr, **kw)
+        with fc.get_context().options(lattice=0):
+            b = fc.fit_ragged(spec, off, dsr, yr, **kw)
+        for name in ('theta', 'fval', 'n_iter', 'n_eval', 'status', 'y_scale'):
+            assert np.array_equal(getattr(a, name), getattr(b, name), equal_nan=True), \
+                (trial, name, step_h, n_slots, N, growth, mode, [s_['name'] for s_ in seas])
+
+
 def _used_sparse_columns(fc):
     import ctypes
     from time_series_spark_amd import _lib
