@@ -409,11 +409,22 @@ __global__ __launch_bounds__(PREDICT_WAVES * 64) void predict_kernel(PredictArgs
     const double fl_clamp = a.floor_ ? a.floor_[n] : 0.0;
     const double capsc = (sp->growth == TSF_GROWTH_LOGISTIC) ? (a.cap[n] - fl) / ys : 0.0;
     // slope / offset of every trend segment: the sequential recurrence, once per series
+    // (the changepoints' deltas and times in lanes first: one load each instead of S dependent ones per wave)
+    double dl[(TSF_MAX_S + W - 1) / W], tl[(TSF_MAX_S + W - 1) / W];
     {
         double ks = th[0], mc = th[1];
         if (lane == 0) { seg_ks[wid][0] = ks; seg_mc[wid][0] = mc; }
+#pragma unroll
+        for (int s = 0; s < (TSF_MAX_S + W - 1) / W; ++s) {
+            const int c = lane + s * W;
+            dl[s] = c < S ? delta[c] : 0.0;
+            tl[s] = c < S ? gi.t_change[c] : 0.0;
+        }
         for (int c = 0; c < S; ++c) {
-            const double dj = delta[c], tcj = gi.t_change[c];
+            double dj = 0.0, tcj = 0.0;
+#pragma unroll
+            for (int s = 0; s < (TSF_MAX_S + W - 1) / W; ++s)
+                if ((c >> 6) == s) { dj = readlane_f64(dl[s], c & 63); tcj = readlane_f64(tl[s], c & 63); }
             const double ksn = ks + dj;
             if (sp->growth == TSF_GROWTH_LINEAR) {
                 mc = mc + ((-tcj) * dj);
@@ -429,12 +440,27 @@ __global__ __launch_bounds__(PREDICT_WAVES * 64) void predict_kernel(PredictArgs
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int nf = K - sp->n_extra;
+    // (the coefficients in chain order in lanes: bl[j mod 64 of slot j / 64] = beta[perm[j]])
+    double bl[(TSF_MAX_P + W - 1) / W];
+#pragma unroll
+    for (int s = 0; s < (TSF_MAX_P + W - 1) / W; ++s) {
+        const int j = lane + s * W;
+        bl[s] = j < K ? beta[sp->perm[j]] : 0.0;
+    }
     for (int h = lane; h < H; h += 64) {
         const int64_t gid = n * (int64_t)H + h;
         const int64_t dsv = a.ds_future[a.shared_future ? h : gid];
         const double t = (double)(dsv - gi.start_ns) / (double)gi.t_scale_ns;
+        // (the segment of t: the changepoint times ascend, so the first one beyond t is their count up to t -- taken from
+        // the lanes that hold them instead of a dependent load per step)
         int c = 0;
-        while (c < S && t >= gi.t_change[c]) ++c;
+        for (int j = 0; j < S; ++j) {
+            double tcj = 0.0;
+#pragma unroll
+            for (int s = 0; s < (TSF_MAX_S + W - 1) / W; ++s)
+                if ((j >> 6) == s) tcj = readlane_f64(tl[s], j & 63);
+            c += (c == j && t >= tcj) ? 1 : 0;
+        }
         const double ks = seg_ks[wid][c], mc = seg_mc[wid][c];
         // X.beta in the order of the chain: additive columns in original order, then the
         // multiplicative ones (internal column j = original column perm[j])
@@ -445,8 +471,12 @@ __global__ __launch_bounds__(PREDICT_WAVES * 64) void predict_kernel(PredictArgs
                 const double xv = (col < nf) ? a.Xf[(size_t)col * H + h]
                                              : a.extra_future[a.shared_future ? (size_t)(col - nf) * H + h
                                                                               : ((size_t)n * sp->n_extra + (col - nf)) * H + h];
-                if (j < Ka) xa = __builtin_fma(xv, beta[col], xa);
-                else xm = __builtin_fma(xv, beta[col], xm);
+                double bj = 0.0;
+#pragma unroll
+                for (int s = 0; s < (TSF_MAX_P + W - 1) / W; ++s)
+                    if ((j >> 6) == s) bj = readlane_f64(bl[s], j & 63);
+                if (j < Ka) xa = __builtin_fma(xv, bj, xa);
+                else xm = __builtin_fma(xv, bj, xm);
             }
         } else {
             for (int pass = 0; pass < 2; ++pass) {
